@@ -1,0 +1,94 @@
+"""ctypes binding of libdvq_hip.so (include/dvq_hip.h).  There is no CPU fallback: if the library
+is missing the product path fails loudly here."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdvq_hip.so")
+
+F32, BF16 = 0, 1
+
+vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("N", i64), ("H", i64), ("W", i64), ("Cin", i64), ("OH", i64), ("OW", i64), ("Cout", i64),
+                ("KH", i32), ("KW", i32), ("stride", i32), ("pad_t", i32), ("pad_l", i32), ("upsample", i32),
+                ("dtype", i32), ("impl", i32)]
+
+
+# name -> (restype, argtypes); mirrors include/dvq_hip.h one to one
+SIGNATURES = {
+    "dvq_last_error": (C.c_char_p, []),
+    "dvq_version": (i32, []),
+    "dvq_check_device": (i32, []),
+    "dvq_vq_prep_bytes": (sz, [i64, i64]),
+    "dvq_vq_prepare": (i32, [vp, i64, i64, vp, vp]),
+    "dvq_vq_argmin_workspace_bytes": (sz, [i64]),
+    "dvq_vq_argmin": (i32, [vp, i32, vp, vp, i64, i64, i64, vp, vp, i32, vp]),
+    "dvq_vq_gather_loss": (i32, [vp, i32, vp, vp, vp, i64, i64, vp, vp, vp]),
+    "dvq_vq_backward": (i32, [vp, vp, i32, vp, vp, vp, vp, i64, i64, vp, vp]),
+    "dvq_vq_embed": (i32, [vp, vp, i64, i64, i32, vp, vp]),
+    "dvq_vq_ema_stats": (i32, [vp, i32, vp, i64, i64, i64, vp, vp]),
+    "dvq_vq_ema_apply": (i32, [vp, vp, f32, f32, i64, i64, vp, vp, vp, vp, vp]),
+    "dvq_patch_entropy_gate": (i32, [vp, i64, i64, i64, i32, f32, vp, vp, vp]),
+    "dvq_gn_stats": (i32, [vp, i32, i64, i64, i64, i32, vp, vp]),
+    "dvq_gn_apply": (i32, [vp, i32, i64, i64, i64, i32, f32, vp, vp, vp, i32, vp, vp, vp]),
+    "dvq_gn_bwd_reduce": (i32, [vp, vp, i32, i64, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "dvq_gn_bwd_dx": (i32, [vp, vp, i32, i64, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp]),
+    "dvq_conv2d_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
+    "dvq_conv2d_dgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
+    "dvq_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
+    "dvq_pack_weight": (i32, [vp, i64, i64, i64, i64, i64, i64, i32, vp, vp, vp]),
+    "dvq_unpack_wgrad": (i32, [vp, i64, i64, i64, i64, i64, vp, vp]),
+    "dvq_nchw_to_nhwc_pad": (i32, [vp, i64, i64, i64, i64, i64, i32, vp, vp]),
+    "dvq_nhwc_pad_to_nchw": (i32, [vp, i32, i64, i64, i64, i64, i64, vp, vp]),
+    "dvq_gemm_nt": (i32, [vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp, i32, i32, vp]),
+    "dvq_gemm_tn": (i32, [vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64, i32, vp]),
+    "dvq_softmax_rows": (i32, [vp, i32, i64, i64, f32, vp, vp]),
+    "dvq_softmax_rows_bwd": (i32, [vp, vp, i32, i64, i64, f32, vp, vp]),
+    "dvq_transpose": (i32, [vp, i32, i64, i64, i64, vp, vp]),
+    "dvq_dual_merge": (i32, [vp, vp, vp, i32, i64, i64, i64, i64, vp, vp, vp]),
+    "dvq_dual_merge_bwd": (i32, [vp, vp, i32, i64, i64, i64, i64, vp, vp, vp]),
+    "dvq_add": (i32, [vp, vp, i32, i64, vp, vp]),
+    "dvq_add_bias_bcast": (i32, [vp, vp, i32, i64, i64, vp, vp]),
+    "dvq_sum_batch": (i32, [vp, i32, i64, i64, vp, vp]),
+    "dvq_sumpool2x2": (i32, [vp, i32, i64, i64, i64, i64, vp, vp]),
+    "dvq_cast": (i32, [vp, i32, vp, i32, i64, vp]),
+    "dvq_l1_loss": (i32, [vp, vp, i64, vp, vp, vp, vp]),
+    "dvq_adam": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
+    "dvq_fill_f32": (i32, [vp, f32, i64, vp]),
+}
+
+
+class DvqError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libdvq_hip.so and declare every signature.  Raises DvqError if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DvqError(
+            f"{LIB_PATH} not found. Build it with `python -m dynamicvectorquantization_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback for the DQ-VAE hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so is stale w.r.t. the header
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().dvq_last_error().decode("utf-8", "replace")
+        raise DvqError(f"{what or 'libdvq_hip'} failed (code {rc}): {msg}")

@@ -1,0 +1,135 @@
+// Shared device/host helpers for libdvq_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dvq_hip.h"
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libdvq_hip targets gfx950 (MI355X) only"
+#endif
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+#define DVQ_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (host)
+// ---------------------------------------------------------------------------------------------
+void dvq_set_error(const char* fmt, ...);
+
+#define DVQ_REQUIRE(cond, code, ...)      \
+    do {                                  \
+        if (!(cond)) {                    \
+            dvq_set_error(__VA_ARGS__);   \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+#define DVQ_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            dvq_set_error("%s: launch failed: %s", (name), hipGetErrorString(e__));   \
+            return DVQ_ELAUNCH;                                                       \
+        }                                                                             \
+    } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// bf16 <-> f32 (device)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// round-to-nearest-even; NaN kept quiet
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+template <typename T>
+struct ElemIO;
+template <>
+struct ElemIO<float> {
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <>
+struct ElemIO<bf16_t> {
+    static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 8 consecutive elements <-> 8 floats (16 B for bf16, 32 B for f32); pointers must be 16-B aligned
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    uint4 a = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    uint4 a;
+    a.x = pack_bf16x2(v[0], v[1]); a.y = pack_bf16x2(v[2], v[3]);
+    a.z = pack_bf16x2(v[4], v[5]); a.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave / block reductions
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float swishf(float z) { return z / (1.0f + __expf(-z)); }
+// d/dz [z * sigmoid(z)] = s * (1 + z * (1 - s))
+__device__ __forceinline__ float swish_grad(float z) {
+    float s = 1.0f / (1.0f + __expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+#define DVQ_DISPATCH_DTYPE(dtype, T, ...)          \
+    do {                                           \
+        if ((dtype) == DVQ_F32) {                  \
+            using T = float;                       \
+            __VA_ARGS__                            \
+        } else {                                   \
+            using T = bf16_t;                      \
+            __VA_ARGS__                            \
+        }                                          \
+    } while (0)

@@ -1,0 +1,282 @@
+// GroupNorm(G, eps) (+ fused swish) forward and backward on NHWC tensors (gfx950, HBM-bound).
+// Replaces Normalize + nonlinearity, modules/diffusionmodules/model.py:29-35 (torch.nn.GroupNorm(32, C, 1e-6)
+// followed by x*sigmoid(x)) and their autograd backward.
+//
+// Layout: x[n][p][c], p = pixel, c fastest.  A thread owns one 8-channel vector column (16 B in bf16)
+// and walks pixels, so every global access is a full 16/32-B vector and gamma/beta/mean/rstd sit in
+// registers.  Statistics are accumulated in fp32 per thread, combined in fp64 (LDS + one global fp64
+// atomic per (block, group)), so E[x^2]-E[x]^2 is evaluated in fp64.
+#include "dvq_common.h"
+
+namespace {
+
+constexpr int GN_ROWS_PER_BLOCK = 1024;   // pixels per block
+
+struct GnGeom {
+    int ncol;           // C / 8
+    int rows_per_pass;  // 256 / ncol
+    int cpg;            // channels per group
+};
+
+__device__ __forceinline__ GnGeom gn_geom(int64_t C, int G) {
+    GnGeom g;
+    g.ncol = (int)(C / 8);
+    g.rows_per_pass = 256 / g.ncol;
+    g.cpg = (int)(C / G);
+    return g;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int64_t HW, int64_t C, int G,
+                                                       double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* gs = reinterpret_cast<double*>(smem);   // [G][2]
+    const GnGeom ge = gn_geom(C, G);
+    const int64_t n = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * G; i += 256) gs[i] = 0.0;
+    __syncthreads();
+    const int col = threadIdx.x % ge.ncol, prow = threadIdx.x / ge.ncol;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    if (prow < ge.rows_per_pass) {
+        const int64_t p_end = min((int64_t)(blockIdx.x + 1) * GN_ROWS_PER_BLOCK, HW);
+        const T* base = x + n * HW * C + col * 8;
+        for (int64_t p = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK + prow; p < p_end; p += ge.rows_per_pass) {
+            float v[8];
+            load8(base + p * C, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += v[j];
+                q[j] = fmaf(v[j], v[j], q[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (col * 8 + j) / ge.cpg;
+            atomicAdd(&gs[2 * g], (double)s[j]);
+            atomicAdd(&gs[2 * g + 1], (double)q[j]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(&stats[n * 2 * G + i], gs[i]);
+}
+
+__device__ __forceinline__ void gn_mean_rstd(const double* stats, int64_t n, int G, int g, double cnt, float eps,
+                                             float& mean, float& rstd) {
+    const double m = stats[(n * G + g) * 2] / cnt;
+    double var = stats[(n * G + g) * 2 + 1] / cnt - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int64_t HW, int64_t C, int G, float eps,
+                                                       const double* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       T* __restrict__ y, float* __restrict__ mean_rstd) {
+    const GnGeom ge = gn_geom(C, G);
+    const int64_t n = blockIdx.y;
+    const double cnt = (double)HW * ge.cpg;
+    if (blockIdx.x == 0 && mean_rstd != nullptr && (int)threadIdx.x < G) {
+        float m, r;
+        gn_mean_rstd(stats, n, G, threadIdx.x, cnt, eps, m, r);
+        mean_rstd[(n * G + threadIdx.x) * 2] = m;
+        mean_rstd[(n * G + threadIdx.x) * 2 + 1] = r;
+    }
+    const int col = threadIdx.x % ge.ncol, prow = threadIdx.x / ge.ncol;
+    if (prow >= ge.rows_per_pass) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = col * 8 + j;
+        float m, r;
+        gn_mean_rstd(stats, n, G, c / ge.cpg, cnt, eps, m, r);
+        sc[j] = r * gamma[c];
+        sh[j] = beta[c] - m * sc[j];
+    }
+    const int64_t p_end = min((int64_t)(blockIdx.x + 1) * GN_ROWS_PER_BLOCK, HW);
+    const int64_t off = n * HW * C + col * 8;
+    for (int64_t p = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK + prow; p < p_end; p += ge.rows_per_pass) {
+        float v[8];
+        load8(x + off + p * C, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = fmaf(v[j], sc[j], sh[j]);
+            v[j] = SILU ? swishf(z) : z;
+        }
+        store8(y + off + p * C, v);
+    }
+}
+
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            int64_t HW, int64_t C, int G,
+                                                            const float* __restrict__ mean_rstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, double* __restrict__ red,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sA = reinterpret_cast<float*>(smem);   // [C] sum dz
+    float* sB = sA + C;                            // [C] sum dz*xhat
+    const GnGeom ge = gn_geom(C, G);
+    const int64_t n = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) sA[i] = 0.f;
+    __syncthreads();
+    const int col = threadIdx.x % ge.ncol, prow = threadIdx.x / ge.ncol;
+    if (prow < ge.rows_per_pass) {
+        float mu[8], rs[8], ga[8], be[8], a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = col * 8 + j, g = c / ge.cpg;
+            mu[j] = mean_rstd[(n * G + g) * 2];
+            rs[j] = mean_rstd[(n * G + g) * 2 + 1];
+            ga[j] = gamma[c];
+            be[j] = beta[c];
+            a[j] = b[j] = 0.f;
+        }
+        const int64_t p_end = min((int64_t)(blockIdx.x + 1) * GN_ROWS_PER_BLOCK, HW);
+        const int64_t off = n * HW * C + col * 8;
+        for (int64_t p = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK + prow; p < p_end; p += ge.rows_per_pass) {
+            float v[8], g8[8];
+            load8(x + off + p * C, v);
+            load8(dy + off + p * C, g8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (v[j] - mu[j]) * rs[j];
+                float dz = g8[j];
+                if (SILU) dz *= swish_grad(fmaf(xh, ga[j], be[j]));
+                a[j] += dz;
+                b[j] = fmaf(dz, xh, b[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(&sA[col * 8 + j], a[j]);
+            atomicAdd(&sB[col * 8 + j], b[j]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(&dbeta[c], sA[c]);
+        atomicAdd(&dgamma[c], sB[c]);
+    }
+    for (int g = threadIdx.x; g < G; g += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int c = g * ge.cpg; c < (g + 1) * ge.cpg; ++c) {
+            s1 += (double)gamma[c] * (double)sA[c];
+            s2 += (double)gamma[c] * (double)sB[c];
+        }
+        atomicAdd(&red[(n * G + g) * 2], s1);
+        atomicAdd(&red[(n * G + g) * 2 + 1], s2);
+    }
+}
+
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t HW,
+                                                        int64_t C, int G, const float* __restrict__ mean_rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const double* __restrict__ red, T* __restrict__ dx) {
+    const GnGeom ge = gn_geom(C, G);
+    const int64_t n = blockIdx.y;
+    const int col = threadIdx.x % ge.ncol, prow = threadIdx.x / ge.ncol;
+    if (prow >= ge.rows_per_pass) return;
+    const double cnt = (double)HW * ge.cpg;
+    float mu[8], rs[8], ga[8], be[8], m1[8], m2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = col * 8 + j, g = c / ge.cpg;
+        mu[j] = mean_rstd[(n * G + g) * 2];
+        rs[j] = mean_rstd[(n * G + g) * 2 + 1];
+        ga[j] = gamma[c];
+        be[j] = beta[c];
+        m1[j] = (float)(red[(n * G + g) * 2] / cnt);
+        m2[j] = (float)(red[(n * G + g) * 2 + 1] / cnt);
+    }
+    const int64_t p_end = min((int64_t)(blockIdx.x + 1) * GN_ROWS_PER_BLOCK, HW);
+    const int64_t off = n * HW * C + col * 8;
+    for (int64_t p = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK + prow; p < p_end; p += ge.rows_per_pass) {
+        float v[8], g8[8];
+        load8(x + off + p * C, v);
+        load8(dy + off + p * C, g8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (v[j] - mu[j]) * rs[j];
+            float dz = g8[j];
+            if (SILU) dz *= swish_grad(fmaf(xh, ga[j], be[j]));
+            v[j] = rs[j] * (dz * ga[j] - m1[j] - xh * m2[j]);
+        }
+        store8(dx + off + p * C, v);
+    }
+}
+
+int gn_check(const char* who, int64_t N, int64_t HW, int64_t C, int G) {
+    DVQ_REQUIRE(N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C % 8 == 0 && C / 8 <= 256 && N <= 65535, DVQ_ESHAPE,
+                "%s: unsupported shape N=%lld HW=%lld C=%lld G=%d", who, (long long)N, (long long)HW, (long long)C, G);
+    return DVQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvq_gn_stats(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int G, double* stats,
+                 dvq_stream_t stream) {
+    DVQ_REQUIRE(x && stats, DVQ_EINVAL, "dvq_gn_stats: null pointer");
+    if (int e = gn_check("dvq_gn_stats", N, HW, C, G)) return e;
+    dim3 grid((unsigned)cdiv64(HW, GN_ROWS_PER_BLOCK), (unsigned)N);
+    DVQ_DISPATCH_DTYPE(dtype, T, gn_stats_kernel<T><<<grid, dim3(256), 2 * G * sizeof(double), (hipStream_t)stream>>>(
+                                     (const T*)x, HW, C, G, stats););
+    DVQ_CHECK_LAUNCH("gn_stats");
+    return DVQ_OK;
+}
+
+int dvq_gn_apply(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int G, float eps, const double* stats,
+                 const float* gamma, const float* beta, int silu, void* y, float* mean_rstd, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && stats && gamma && beta && y, DVQ_EINVAL, "dvq_gn_apply: null pointer");
+    if (int e = gn_check("dvq_gn_apply", N, HW, C, G)) return e;
+    DVQ_REQUIRE(G <= 256, DVQ_ESHAPE, "dvq_gn_apply: G > 256");
+    dim3 grid((unsigned)cdiv64(HW, GN_ROWS_PER_BLOCK), (unsigned)N);
+    hipStream_t s = (hipStream_t)stream;
+    DVQ_DISPATCH_DTYPE(dtype, T, if (silu) gn_apply_kernel<T, true><<<grid, dim3(256), 0, s>>>(
+                                     (const T*)x, HW, C, G, eps, stats, gamma, beta, (T*)y, mean_rstd);
+                       else gn_apply_kernel<T, false><<<grid, dim3(256), 0, s>>>((const T*)x, HW, C, G, eps, stats, gamma,
+                                                                                 beta, (T*)y, mean_rstd););
+    DVQ_CHECK_LAUNCH("gn_apply");
+    return DVQ_OK;
+}
+
+int dvq_gn_bwd_reduce(const void* x, const void* dy, int dtype, int64_t N, int64_t HW, int64_t C, int G,
+                      const float* mean_rstd, const float* gamma, const float* beta, int silu, double* red,
+                      float* dgamma, float* dbeta, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && dy && mean_rstd && gamma && beta && red && dgamma && dbeta, DVQ_EINVAL,
+                "dvq_gn_bwd_reduce: null pointer");
+    if (int e = gn_check("dvq_gn_bwd_reduce", N, HW, C, G)) return e;
+    dim3 grid((unsigned)cdiv64(HW, GN_ROWS_PER_BLOCK), (unsigned)N);
+    hipStream_t s = (hipStream_t)stream;
+    size_t lds = 2 * C * sizeof(float);
+    DVQ_DISPATCH_DTYPE(dtype, T, if (silu) gn_bwd_reduce_kernel<T, true><<<grid, dim3(256), lds, s>>>(
+                                     (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, dgamma, dbeta);
+                       else gn_bwd_reduce_kernel<T, false><<<grid, dim3(256), lds, s>>>(
+                           (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, dgamma, dbeta););
+    DVQ_CHECK_LAUNCH("gn_bwd_reduce");
+    return DVQ_OK;
+}
+
+int dvq_gn_bwd_dx(const void* x, const void* dy, int dtype, int64_t N, int64_t HW, int64_t C, int G,
+                  const float* mean_rstd, const float* gamma, const float* beta, int silu, const double* red,
+                  void* dx, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && dy && mean_rstd && gamma && beta && red && dx, DVQ_EINVAL, "dvq_gn_bwd_dx: null pointer");
+    if (int e = gn_check("dvq_gn_bwd_dx", N, HW, C, G)) return e;
+    dim3 grid((unsigned)cdiv64(HW, GN_ROWS_PER_BLOCK), (unsigned)N);
+    hipStream_t s = (hipStream_t)stream;
+    DVQ_DISPATCH_DTYPE(dtype, T, if (silu) gn_bwd_dx_kernel<T, true><<<grid, dim3(256), 0, s>>>(
+                                     (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, (T*)dx);
+                       else gn_bwd_dx_kernel<T, false><<<grid, dim3(256), 0, s>>>(
+                           (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, (T*)dx););
+    DVQ_CHECK_LAUNCH("gn_bwd_dx");
+    return DVQ_OK;
+}
+
+}  // extern "C"

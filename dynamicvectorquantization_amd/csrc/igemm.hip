@@ -1,0 +1,692 @@
+// Implicit-GEMM convolution + batched GEMM on MFMA for gfx950 (bf16 32x32x16 and exact-fp32 32x32x2).
+//
+// Replaces the torch.nn.Conv2d call sites of the DQ-VAE (modules/diffusionmodules/model.py:38-192 --
+// ResnetBlock 3x3, Upsample nearest+3x3, Downsample pad+3x3/s2, AttnBlock 1x1 q/k/v/proj and the
+// q.k / p.v batched matmuls -- plus quant_conv/post_quant_conv, dqvae_dual_entropy.py:93-94) and
+// their autograd backward (dgrad = transposed gather, wgrad = pixel-dimension reduction).
+//
+// Two kernels share one LDS tile format and one MFMA inner loop:
+//   NT  C[m][n]  = sum_k A[m][k] * B[n][k]      A rows are gathered on the fly (im2col never exists)
+//   TN  C[i][j] += sum_m A[m][i] * B[m][j]      both operands are transposed 8x8 (4x4 fp32) in registers
+//                                               on their way to LDS; split over m with fp32 atomics
+// Tile 128x128, 256 threads = 2x2 waves, each wave 2x2 MFMA 32x32 tiles (64 accumulator VGPRs).
+// LDS rows are 128 B of K-contiguous data + 16 B pad (conflict-free ds_read_b128 for the MFMA
+// fragment pattern), 2 stages x (A+B) = 72 KiB -> 2 workgroups per CU.  Global->LDS is register
+// staged: loads for stage j+1 are issued before the MFMAs of stage j and written to LDS after them.
+#include <type_traits>
+
+#include "dvq_common.h"
+
+namespace {
+
+constexpr int TILE = 128;
+constexpr int ROWB = 144;                 // LDS bytes per tile row
+constexpr int OPB = TILE * ROWB;          // one operand tile
+constexpr int STAGEB = 2 * OPB;
+
+enum { MODE_FWD = 0, MODE_TCONV = 1, MODE_GEMM = 2 };
+
+struct NtParams {
+    const void* A;
+    const void* B;
+    void* C;
+    const void* R;       // residual (same layout as C) or null
+    const float* bias;
+    int mode;
+    int M, Ncols, Ktot;  // GEMM dims (elements)
+    int64_t lda;         // GEMM: A row stride; conv: Cs (source channels)
+    int64_t ldb, ldc;
+    int SH, SW;          // stored source grid
+    int LH, LW;          // logical bounds (FWD: H,W after upsample; TCONV: OH,OW)
+    int DH, DW;          // destination pixel grid (rows of the GEMM)
+    int KW, stride, pad_t, pad_l, up;
+    float alpha;
+    int bias_mode;       // 0 none, 1 per column, 2 per row
+    int64_t sA, sB, sC;  // batch strides
+};
+
+template <typename T>
+struct Vec {
+    static constexpr int N = 16 / sizeof(T);   // elements per 16-B chunk
+    static constexpr int BK = 128 / sizeof(T);  // K elements per stage
+};
+
+// -------------------------------------------------------------------------------------------------
+// MFMA over one LDS stage: acc[mt][nt] += A(64 rows of this wave) x B(64 rows of this wave)^T
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void mma_stage(const char* sA, const char* sB, f32x16 (&acc)[2][2], int wm, int wn,
+                                          int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+    const char* pa = sA + (wm * 64 + l31) * ROWB + half * 16;
+    const char* pb = sB + (wn * 64 + l31) * ROWB + half * 16;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const bf16x8*>(pa + t * 32 * ROWB + ks * 32);
+                b[t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * ROWB + ks * 32);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            f32x4 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const f32x4*>(pa + t * 32 * ROWB + jj * 32);
+                b[t] = *reinterpret_cast<const f32x4*>(pb + t * 32 * ROWB + jj * 32);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// NT kernel
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void igemm_nt_kernel(NtParams p) {
+    constexpr int VN = Vec<T>::N;
+    constexpr int BK = Vec<T>::BK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE;
+    const int64_t bz = blockIdx.z;
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
+    const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
+
+    const int ch = tid & 7;         // 16-B chunk within the 128-B row
+    const int r0 = tid >> 3;        // rows r0 + 32*i
+    // per-row gather state
+    int rn[4], ra[4], rb[4];
+    bool rok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        rok[i] = m < p.M;
+        const int mm = rok[i] ? m : 0;
+        if (p.mode == MODE_GEMM) {
+            rn[i] = mm;
+            ra[i] = rb[i] = 0;
+        } else {
+            const int hw = p.DH * p.DW;
+            const int n = mm / hw, rem = mm - n * hw;
+            const int y = rem / p.DW, x = rem - y * p.DW;
+            rn[i] = n;
+            if (p.mode == MODE_FWD) {
+                ra[i] = y * p.stride - p.pad_t;
+                rb[i] = x * p.stride - p.pad_l;
+            } else {
+                ra[i] = y + p.pad_t;
+                rb[i] = x + p.pad_l;
+            }
+        }
+    }
+    const int cpt = (int)(p.lda / VN);   // conv: 16-B units per tap
+    const int sshift = p.stride == 2 ? 1 : 0;
+    // B rows
+    int64_t boff[4];
+    bool bok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        bok[i] = n < p.Ncols;
+        boff[i] = (int64_t)(bok[i] ? n : 0) * p.ldb;
+    }
+
+    uint4 pa[4], pb[4];
+    auto g_load = [&](int j) {
+        const int u = j * 8 + ch;              // 16-B unit index along K
+        const int ke = u * VN;
+        const bool kok = ke < p.Ktot;
+        int kh = 0, kw = 0, c0 = ke;
+        if (p.mode != MODE_GEMM) {
+            const int tap = u / cpt;
+            c0 = (u - tap * cpt) * VN;
+            kh = tap / p.KW;
+            kw = tap - kh * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bool ok = kok && rok[i];
+            int64_t off = 0;
+            if (p.mode == MODE_GEMM) {
+                off = (int64_t)rn[i] * p.lda + ke;
+            } else if (p.mode == MODE_FWD) {
+                const int ih = ra[i] + kh, iw = rb[i] + kw;
+                ok = ok && (unsigned)ih < (unsigned)p.LH && (unsigned)iw < (unsigned)p.LW;
+                off = (((int64_t)rn[i] * p.SH + (ih >> p.up)) * p.SW + (iw >> p.up)) * p.lda + c0;
+            } else {
+                const int t = ra[i] - kh, v = rb[i] - kw;
+                const int mask = p.stride - 1;
+                ok = ok && t >= 0 && v >= 0 && ((t | v) & mask) == 0;
+                const int oh = t >> sshift, ow = v >> sshift;
+                ok = ok && oh < p.LH && ow < p.LW;
+                off = (((int64_t)rn[i] * p.SH + oh) * p.SW + ow) * p.lda + c0;
+            }
+            pa[i] = ok ? *reinterpret_cast<const uint4*>(Ag + off) : make_uint4(0, 0, 0, 0);
+            pb[i] = (kok && bok[i]) ? *reinterpret_cast<const uint4*>(Bg + boff[i] + ke) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto s_store = [&](int buf) {
+        char* sa = smem + buf * STAGEB + r0 * ROWB + ch * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(sa + i * 32 * ROWB) = pa[i];
+            *reinterpret_cast<uint4*>(sa + OPB + i * 32 * ROWB) = pb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = (p.Ktot + BK - 1) / BK;
+    g_load(0);
+    s_store(0);
+    __syncthreads();
+    for (int j = 0; j < nk; ++j) {
+        const int buf = j & 1;
+        if (j + 1 < nk) g_load(j + 1);
+        mma_stage<T>(smem + buf * STAGEB, smem + buf * STAGEB + OPB, acc, wm, wn, lane);
+        if (j + 1 < nk) s_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+    T* __restrict__ Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
+    const T* __restrict__ Rg = p.R ? reinterpret_cast<const T*>(p.R) + bz * p.sC : nullptr;
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = n0 + wn * 64 + nt * 32 + l31;
+        if (col >= p.Ncols) continue;
+        const float bcol = p.bias_mode == 1 ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < p.M) {
+                    float v = acc[mt][nt][r] * p.alpha + bcol;
+                    if (p.bias_mode == 2) v += p.bias[row];
+                    const int64_t o = (int64_t)row * p.ldc + col;
+                    if (Rg) v += ElemIO<T>::load(Rg + o);
+                    ElemIO<T>::store(Cg + o, v);
+                }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// TN kernel (wgrad / generic).  C fp32, accumulated with atomics; grid.y splits the reduction.
+// -------------------------------------------------------------------------------------------------
+struct TnParams {
+    const void* A;   // [Mred][lda]           (wgrad: dy, lda = Cout)
+    const void* B;   // GEMM: [Mred][ldb]; conv: gathered from x (Cs = ldb)
+    float* C;
+    float* colsumA;  // optional: colsumA[i] += sum_m A[m][i]  (dbias), done by tap-0 / jtile-0 blocks
+    int conv;        // 0 plain, 1 gather B rows through the FWD conv geometry
+    int Mred, I, J;
+    int64_t lda, ldb, ldc;
+    int taps, jtiles, itiles;
+    int SH, SW, LH, LW, DH, DW, KW, stride, pad_t, pad_l, up;
+    int m_per_split;
+    int64_t sA, sB, sC;
+    int batch_in_z;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
+    constexpr int VN = Vec<T>::N;      // 8 (bf16) / 4 (fp32): block edge of the register transpose
+    constexpr int BK = Vec<T>::BK;     // 64 / 32 reduction rows per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx = blockIdx.x;
+    const int it = bx % p.itiles;
+    bx /= p.itiles;
+    const int jt = bx % p.jtiles;
+    const int tap = bx / p.jtiles;
+    const int i0 = it * TILE, j0 = jt * TILE;
+    const int64_t bz = blockIdx.z;
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
+    const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
+    const int mbeg = blockIdx.y * p.m_per_split;
+    const int mend = min(p.Mred, mbeg + p.m_per_split);
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+
+    // thread -> (operand, VN x VN block).  bf16: 128 blocks per operand -> half the threads each;
+    // fp32: 256 blocks per operand -> every thread does both.
+    constexpr int NBLK_COL = TILE / VN;          // 16 / 32 blocks across the i (or j) dimension
+    constexpr bool SPLIT_OPS = sizeof(T) == 2;
+    const int u = SPLIT_OPS ? (tid & 127) : tid;
+    const int mb = u / NBLK_COL, cb = u % NBLK_COL;   // m block (rows mb*VN..), column block
+    const bool doA = !SPLIT_OPS || tid < 128;
+    const bool doB = !SPLIT_OPS || tid >= 128;
+    const bool do_bias = p.colsumA != nullptr && tap == 0 && jt == 0 && doA;
+
+    uint4 ra[VN], rb[VN];
+    float bsum[VN];
+#pragma unroll
+    for (int c = 0; c < VN; ++c) bsum[c] = 0.f;
+
+    auto g_load = [&](int ms) {   // ms: first reduction row of the stage
+        const int mrow = ms + mb * VN;
+        if (doA) {
+            const int col = i0 + cb * VN;
+#pragma unroll
+            for (int r = 0; r < VN; ++r) {
+                const int m = mrow + r;
+                const bool ok = m < mend && col < p.I;
+                ra[r] = ok ? *reinterpret_cast<const uint4*>(Ag + (int64_t)m * p.lda + col) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        if (doB) {
+            const int col = j0 + cb * VN;
+            if (!p.conv) {
+#pragma unroll
+                for (int r = 0; r < VN; ++r) {
+                    const int m = mrow + r;
+                    const bool ok = m < mend && col < p.J;
+                    rb[r] = ok ? *reinterpret_cast<const uint4*>(Bg + (int64_t)m * p.ldb + col) : make_uint4(0, 0, 0, 0);
+                }
+            } else {
+                // decompose the first row once, then walk (x, y, n) with carries
+                const int hw = p.DH * p.DW;
+                const int mm0 = mrow < p.Mred ? mrow : 0;
+                int n = mm0 / hw;
+                const int rem = mm0 - n * hw;
+                int y = rem / p.DW, x = rem - y * p.DW;
+#pragma unroll
+                for (int r = 0; r < VN; ++r) {
+                    const int m = mrow + r;
+                    bool ok = m < mend && col < p.J;
+                    const int ih = y * p.stride - p.pad_t + kh, iw = x * p.stride - p.pad_l + kw;
+                    ok = ok && (unsigned)ih < (unsigned)p.LH && (unsigned)iw < (unsigned)p.LW;
+                    const int64_t off = (((int64_t)n * p.SH + (ih >> p.up)) * p.SW + (iw >> p.up)) * p.ldb + col;
+                    rb[r] = ok ? *reinterpret_cast<const uint4*>(Bg + off) : make_uint4(0, 0, 0, 0);
+                    if (++x == p.DW) {
+                        x = 0;
+                        if (++y == p.DH) {
+                            y = 0;
+                            ++n;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    // register transpose + LDS store: column c of the block becomes LDS row (cb*VN + c), bytes mb*16..
+    auto store_op = [&](const uint4 (&rg)[VN], char* sbase) {
+        char* dst = sbase + (cb * VN) * ROWB + mb * 16;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                unsigned w[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const unsigned x0 = (&rg[2 * v].x)[c >> 1], x1 = (&rg[2 * v + 1].x)[c >> 1];
+                    w[v] = (c & 1) ? ((x0 >> 16) | (x1 & 0xffff0000u)) : ((x0 & 0xffffu) | (x1 << 16));
+                }
+                *reinterpret_cast<uint4*>(dst + c * ROWB) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<uint4*>(dst + c * ROWB) =
+                    make_uint4((&rg[0].x)[c], (&rg[1].x)[c], (&rg[2].x)[c], (&rg[3].x)[c]);
+        }
+    };
+    auto s_store = [&](int buf) {
+        if (doA) {
+            if (do_bias) {
+#pragma unroll
+                for (int r = 0; r < VN; ++r) {
+                    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const unsigned wv = (&ra[r].x)[c >> 1];
+                            bsum[c] += __uint_as_float((c & 1) ? (wv & 0xffff0000u) : (wv << 16));
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) bsum[c] += __uint_as_float((&ra[r].x)[c]);
+                    }
+                }
+            }
+            store_op(ra, smem + buf * STAGEB);
+        }
+        if (doB) store_op(rb, smem + buf * STAGEB + OPB);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = (mend - mbeg + BK - 1) / BK;
+    if (nk > 0) {
+        g_load(mbeg);
+        s_store(0);
+        __syncthreads();
+        for (int j = 0; j < nk; ++j) {
+            const int buf = j & 1;
+            if (j + 1 < nk) g_load(mbeg + (j + 1) * BK);
+            mma_stage<T>(smem + buf * STAGEB, smem + buf * STAGEB + OPB, acc, wm, wn, lane);
+            if (j + 1 < nk) s_store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ Cg = p.C + bz * p.sC;
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = j0 + wn * 64 + nt * 32 + l31;
+        if (col >= p.J) continue;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < p.I) atomicAdd(Cg + (int64_t)row * p.ldc + (int64_t)tap * p.J + col, acc[mt][nt][r]);
+            }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int c = 0; c < VN; ++c) {
+            const int col = i0 + cb * VN + c;
+            if (col < p.I) atomicAdd(p.colsumA + col, bsum[c]);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// naive kernels (any shape; used for validation, tiny shapes and as the loud fallback of impl=1)
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void naive_nt_kernel(NtParams p) {
+    const int64_t total = (int64_t)p.M * p.Ncols;
+    const int64_t bz = blockIdx.z;
+    const T* Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
+    const T* Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
+    T* Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
+    const T* Rg = p.R ? reinterpret_cast<const T*>(p.R) + bz * p.sC : nullptr;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(e / p.Ncols), col = (int)(e % p.Ncols);
+        float acc = 0.f;
+        if (p.mode == MODE_GEMM) {
+            for (int k = 0; k < p.Ktot; ++k)
+                acc = fmaf(ElemIO<T>::load(Ag + (int64_t)m * p.lda + k), ElemIO<T>::load(Bg + (int64_t)col * p.ldb + k), acc);
+        } else {
+            const int Cs = (int)p.lda;
+            const int taps = p.Ktot / Cs;
+            const int hw = p.DH * p.DW;
+            const int n = m / hw, rem = m % hw, y = rem / p.DW, x = rem % p.DW;
+            for (int tap = 0; tap < taps; ++tap) {
+                const int kh = tap / p.KW, kw = tap % p.KW;
+                int64_t off;
+                if (p.mode == MODE_FWD) {
+                    const int ih = y * p.stride - p.pad_t + kh, iw = x * p.stride - p.pad_l + kw;
+                    if ((unsigned)ih >= (unsigned)p.LH || (unsigned)iw >= (unsigned)p.LW) continue;
+                    off = (((int64_t)n * p.SH + (ih >> p.up)) * p.SW + (iw >> p.up)) * Cs;
+                } else {
+                    const int t = y + p.pad_t - kh, v = x + p.pad_l - kw;
+                    if (t < 0 || v < 0 || t % p.stride || v % p.stride) continue;
+                    const int oh = t / p.stride, ow = v / p.stride;
+                    if (oh >= p.LH || ow >= p.LW) continue;
+                    off = (((int64_t)n * p.SH + oh) * p.SW + ow) * Cs;
+                }
+                const T* a = Ag + off;
+                const T* b = Bg + (int64_t)col * p.ldb + (int64_t)tap * Cs;
+                for (int c = 0; c < Cs; ++c) acc = fmaf(ElemIO<T>::load(a + c), ElemIO<T>::load(b + c), acc);
+            }
+        }
+        float v = acc * p.alpha;
+        if (p.bias_mode == 1) v += p.bias[col];
+        if (p.bias_mode == 2) v += p.bias[m];
+        const int64_t o = (int64_t)m * p.ldc + col;
+        if (Rg) v += ElemIO<T>::load(Rg + o);
+        ElemIO<T>::store(Cg + o, v);
+    }
+}
+
+// one wave per output element C[i][tap*J + j]; lanes stride the reduction dimension
+template <typename T>
+__global__ void naive_tn_kernel(TnParams p) {
+    const int64_t bz = blockIdx.z;
+    const T* Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
+    const T* Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
+    float* Cg = p.C + bz * p.sC;
+    const int lane = threadIdx.x & 63;
+    const int64_t nout = (int64_t)p.I * p.taps * p.J;
+    const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 64;
+    const int64_t nw = (int64_t)gridDim.x * blockDim.x / 64;
+    for (int64_t e = wid; e < nout + (p.colsumA ? p.I : 0); e += nw) {
+        float acc = 0.f;
+        if (e >= nout) {   // column sums of A
+            const int i = (int)(e - nout);
+            for (int m = lane; m < p.Mred; m += 64) acc += ElemIO<T>::load(Ag + (int64_t)m * p.lda + i);
+            acc = wave_sum(acc);
+            if (lane == 0) atomicAdd(p.colsumA + i, acc);
+            continue;
+        }
+        const int i = (int)(e / ((int64_t)p.taps * p.J));
+        const int rest = (int)(e % ((int64_t)p.taps * p.J));
+        const int tap = rest / p.J, j = rest % p.J;
+        const int kh = tap / p.KW, kw = tap % p.KW;
+        const int hw = p.DH * p.DW;
+        for (int m = lane; m < p.Mred; m += 64) {
+            float bv;
+            if (!p.conv) {
+                bv = ElemIO<T>::load(Bg + (int64_t)m * p.ldb + j);
+            } else {
+                const int n = m / hw, rem = m % hw, y = rem / p.DW, x = rem % p.DW;
+                const int ih = y * p.stride - p.pad_t + kh, iw = x * p.stride - p.pad_l + kw;
+                if ((unsigned)ih >= (unsigned)p.LH || (unsigned)iw >= (unsigned)p.LW) continue;
+                bv = ElemIO<T>::load(Bg + (((int64_t)n * p.SH + (ih >> p.up)) * p.SW + (iw >> p.up)) * p.ldb + j);
+            }
+            acc = fmaf(ElemIO<T>::load(Ag + (int64_t)m * p.lda + i), bv, acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) atomicAdd(Cg + (int64_t)i * p.ldc + rest, acc);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// launch helpers
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+int launch_nt(const NtParams& p, int64_t batch, int impl, hipStream_t s) {
+    constexpr int VN = Vec<T>::N;
+    bool mfma_ok = p.Ktot % VN == 0 && p.ldb % VN == 0 && p.lda % VN == 0 && (p.stride == 1 || p.stride == 2);
+    if (p.mode == MODE_GEMM) mfma_ok = mfma_ok && (p.sA % VN == 0) && (p.sB % VN == 0);
+    DVQ_REQUIRE(!(impl == 2 && !mfma_ok), DVQ_ESHAPE,
+                "igemm_nt: MFMA path needs K, lda, ldb multiples of %d (K=%d lda=%lld ldb=%lld) and stride 1/2", VN,
+                p.Ktot, (long long)p.lda, (long long)p.ldb);
+    const bool use_mfma = impl == 2 || (impl == 0 && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
+    if (use_mfma) {
+        dim3 grid((unsigned)cdiv64(p.M, TILE), (unsigned)cdiv64(p.Ncols, TILE), (unsigned)batch);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGEB);
+        igemm_nt_kernel<T><<<grid, dim3(256), 2 * STAGEB, s>>>(p);
+        DVQ_CHECK_LAUNCH("igemm_nt");
+    } else {
+        int64_t total = (int64_t)p.M * p.Ncols;
+        unsigned blocks = (unsigned)(cdiv64(total, 256) < 16384 ? cdiv64(total, 256) : 16384);
+        naive_nt_kernel<T><<<dim3(blocks, 1, (unsigned)batch), dim3(256), 0, s>>>(p);
+        DVQ_CHECK_LAUNCH("naive_nt");
+    }
+    return DVQ_OK;
+}
+
+template <typename T>
+int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
+    constexpr int VN = Vec<T>::N;
+    constexpr int BK = Vec<T>::BK;
+    bool mfma_ok = p.lda % VN == 0 && p.ldb % VN == 0 && p.sA % VN == 0 && p.sB % VN == 0;
+    DVQ_REQUIRE(!(impl == 2 && !mfma_ok), DVQ_ESHAPE, "igemm_tn: MFMA path needs lda, ldb multiples of %d", VN);
+    const bool use_mfma = impl == 2 || (impl == 0 && mfma_ok && (int64_t)p.Mred >= 256);
+    if (use_mfma) {
+        p.itiles = (int)cdiv64(p.I, TILE);
+        p.jtiles = (int)cdiv64(p.J, TILE);
+        const int64_t tiles = (int64_t)p.itiles * p.jtiles * p.taps * batch;
+        int64_t splits = cdiv64(1024, tiles);
+        const int64_t max_splits = cdiv64(p.Mred, 4 * BK);
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        int64_t mps = cdiv64(cdiv64(p.Mred, splits), BK) * BK;
+        splits = cdiv64(p.Mred, mps);
+        p.m_per_split = (int)mps;
+        dim3 grid((unsigned)(p.itiles * p.jtiles * p.taps), (unsigned)splits, (unsigned)batch);
+        (void)hipFuncSetAttribute((const void*)igemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGEB);
+        igemm_tn_kernel<T><<<grid, dim3(256), 2 * STAGEB, s>>>(p);
+        DVQ_CHECK_LAUNCH("igemm_tn");
+    } else {
+        int64_t nout = (int64_t)p.I * p.taps * p.J + (p.colsumA ? p.I : 0);
+        unsigned blocks = (unsigned)(cdiv64(nout, 4) < 8192 ? cdiv64(nout, 4) : 8192);
+        naive_tn_kernel<T><<<dim3(blocks, 1, (unsigned)batch), dim3(256), 0, s>>>(p);
+        DVQ_CHECK_LAUNCH("naive_tn");
+    }
+    return DVQ_OK;
+}
+
+int conv_check(const dvq_conv_desc* d, const char* who) {
+    DVQ_REQUIRE(d != nullptr, DVQ_EINVAL, "%s: null descriptor", who);
+    DVQ_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0 && d->KH > 0 &&
+                    d->KW > 0 && d->stride > 0 && d->pad_t >= 0 && d->pad_l >= 0,
+                DVQ_ESHAPE, "%s: non-positive dimension", who);
+    DVQ_REQUIRE(d->N * d->OH * d->OW < (1ll << 31) && d->N * d->H * d->W < (1ll << 31), DVQ_ESHAPE,
+                "%s: more than 2^31 pixels", who);
+    DVQ_REQUIRE(!d->upsample || (d->H % 2 == 0 && d->W % 2 == 0), DVQ_ESHAPE, "%s: upsample needs even H, W", who);
+    DVQ_REQUIRE(d->dtype == DVQ_F32 || d->dtype == DVQ_BF16, DVQ_EINVAL, "%s: bad dtype", who);
+    // the implied bottom/right padding must keep every tap within one pad of the input
+    DVQ_REQUIRE((d->OH - 1) * d->stride - d->pad_t + d->KH - 1 < d->H + d->KH && (d->OW - 1) * d->stride - d->pad_l + d->KW - 1 < d->W + d->KW,
+                DVQ_ESHAPE, "%s: inconsistent output size", who);
+    return DVQ_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int dvq_conv2d_fwd(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                   void* y, dvq_stream_t stream) {
+    if (int e = conv_check(d, "dvq_conv2d_fwd")) return e;
+    DVQ_REQUIRE(x && w && y, DVQ_EINVAL, "dvq_conv2d_fwd: null pointer");
+    NtParams p{};
+    p.A = x; p.B = w; p.C = y; p.R = residual; p.bias = bias;
+    p.mode = MODE_FWD;
+    p.M = (int)(d->N * d->OH * d->OW); p.Ncols = (int)d->Cout; p.Ktot = (int)(d->KH * d->KW * d->Cin);
+    p.lda = d->Cin; p.ldb = p.Ktot; p.ldc = d->Cout;
+    p.SH = (int)(d->H >> d->upsample); p.SW = (int)(d->W >> d->upsample);
+    p.LH = (int)d->H; p.LW = (int)d->W; p.DH = (int)d->OH; p.DW = (int)d->OW;
+    p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.up = d->upsample;
+    p.alpha = 1.f; p.bias_mode = bias ? 1 : 0;
+    if (d->dtype == DVQ_F32) return launch_nt<float>(p, 1, d->impl, (hipStream_t)stream);
+    return launch_nt<bf16_t>(p, 1, d->impl, (hipStream_t)stream);
+}
+
+int dvq_sumpool2x2(const void* in, int dtype, int64_t N, int64_t h, int64_t w, int64_t C, void* out, dvq_stream_t stream);
+
+int dvq_conv2d_dgrad(const dvq_conv_desc* d, const void* dy, const void* wt, void* dx, void* ws, dvq_stream_t stream) {
+    if (int e = conv_check(d, "dvq_conv2d_dgrad")) return e;
+    DVQ_REQUIRE(dy && wt && dx && (!d->upsample || ws), DVQ_EINVAL, "dvq_conv2d_dgrad: null pointer");
+    NtParams p{};
+    p.A = dy; p.B = wt; p.C = d->upsample ? ws : dx; p.R = nullptr; p.bias = nullptr;
+    p.mode = MODE_TCONV;
+    p.M = (int)(d->N * d->H * d->W); p.Ncols = (int)d->Cin; p.Ktot = (int)(d->KH * d->KW * d->Cout);
+    p.lda = d->Cout; p.ldb = p.Ktot; p.ldc = d->Cin;
+    p.SH = (int)d->OH; p.SW = (int)d->OW; p.LH = (int)d->OH; p.LW = (int)d->OW;
+    p.DH = (int)d->H; p.DW = (int)d->W;
+    p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.up = 0;
+    p.alpha = 1.f; p.bias_mode = 0;
+    int rc = d->dtype == DVQ_F32 ? launch_nt<float>(p, 1, d->impl, (hipStream_t)stream)
+                                 : launch_nt<bf16_t>(p, 1, d->impl, (hipStream_t)stream);
+    if (rc) return rc;
+    if (d->upsample) return dvq_sumpool2x2(ws, d->dtype, d->N, d->H / 2, d->W / 2, d->Cin, dx, stream);
+    return DVQ_OK;
+}
+
+int dvq_conv2d_wgrad(const dvq_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                     dvq_stream_t stream) {
+    if (int e = conv_check(d, "dvq_conv2d_wgrad")) return e;
+    DVQ_REQUIRE(x && dy && dw, DVQ_EINVAL, "dvq_conv2d_wgrad: null pointer");
+    TnParams p{};
+    p.A = dy; p.B = x; p.C = dw; p.colsumA = dbias;
+    p.conv = 1;
+    p.Mred = (int)(d->N * d->OH * d->OW); p.I = (int)d->Cout; p.J = (int)d->Cin;
+    p.lda = d->Cout; p.ldb = d->Cin; p.ldc = (int64_t)d->KH * d->KW * d->Cin;
+    p.taps = d->KH * d->KW;
+    p.SH = (int)(d->H >> d->upsample); p.SW = (int)(d->W >> d->upsample);
+    p.LH = (int)d->H; p.LW = (int)d->W; p.DH = (int)d->OH; p.DW = (int)d->OW;
+    p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.up = d->upsample;
+    if (d->dtype == DVQ_F32) return launch_tn<float>(p, 1, d->impl, (hipStream_t)stream);
+    return launch_tn<bf16_t>(p, 1, d->impl, (hipStream_t)stream);
+}
+
+int dvq_gemm_nt(const void* A, const void* B, void* C, int dtype, int64_t M, int64_t N, int64_t K, int64_t lda,
+                int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, float alpha,
+                const float* bias, int bias_mode, int impl, dvq_stream_t stream) {
+    DVQ_REQUIRE(A && B && C, DVQ_EINVAL, "dvq_gemm_nt: null pointer");
+    DVQ_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535 && M < (1ll << 31) && N < (1ll << 31), DVQ_ESHAPE,
+                "dvq_gemm_nt: bad shape");
+    DVQ_REQUIRE(bias_mode == 0 || bias != nullptr, DVQ_EINVAL, "dvq_gemm_nt: bias_mode without bias");
+    NtParams p{};
+    p.A = A; p.B = B; p.C = C; p.R = nullptr; p.bias = bias;
+    p.mode = MODE_GEMM;
+    p.M = (int)M; p.Ncols = (int)N; p.Ktot = (int)K;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.stride = 1; p.KW = 1;
+    p.alpha = alpha; p.bias_mode = bias_mode;
+    p.sA = sA; p.sB = sB; p.sC = sC;
+    if (dtype == DVQ_F32) return launch_nt<float>(p, batch, impl, (hipStream_t)stream);
+    if (dtype == DVQ_BF16) return launch_nt<bf16_t>(p, batch, impl, (hipStream_t)stream);
+    dvq_set_error("dvq_gemm_nt: bad dtype");
+    return DVQ_EINVAL;
+}
+
+int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred, int64_t I, int64_t J, int64_t lda,
+                int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int impl,
+                dvq_stream_t stream) {
+    DVQ_REQUIRE(A && B && C, DVQ_EINVAL, "dvq_gemm_tn: null pointer");
+    DVQ_REQUIRE(Mred > 0 && I > 0 && J > 0 && batch > 0 && batch <= 65535 && Mred < (1ll << 31), DVQ_ESHAPE,
+                "dvq_gemm_tn: bad shape");
+    TnParams p{};
+    p.A = A; p.B = B; p.C = C; p.colsumA = nullptr;
+    p.conv = 0;
+    p.Mred = (int)Mred; p.I = (int)I; p.J = (int)J;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.taps = 1; p.KW = 1; p.stride = 1;
+    p.sA = sA; p.sB = sB; p.sC = sC;
+    if (dtype == DVQ_F32) return launch_tn<float>(p, batch, impl, (hipStream_t)stream);
+    if (dtype == DVQ_BF16) return launch_tn<bf16_t>(p, batch, impl, (hipStream_t)stream);
+    dvq_set_error("dvq_gemm_tn: bad dtype");
+    return DVQ_EINVAL;
+}
+
+}  // extern "C"

@@ -1,0 +1,475 @@
+// Small HBM-bound kernels of the DQ-VAE path (gfx950): softmax rows, transposes, dual-grain merge,
+// residual/bias adds, pooling, casts, weight (un)packing, image layout changes, L1 loss, Adam.
+// Each cites the reference call site it replaces in include/dvq_hip.h.
+#include <stdarg.h>
+
+#include "dvq_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void dvq_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+constexpr unsigned MAXB = 8192;
+inline unsigned nblocks(int64_t work, int per_block) {
+    int64_t b = cdiv64(work, per_block);
+    return (unsigned)(b < 1 ? 1 : (b > MAXB ? MAXB : b));
+}
+
+// ---- softmax over rows: one wave per row ---------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ s, int64_t rows, int64_t L,
+                                                           float scale, T* __restrict__ p) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const T* sr = s + r * L;
+        float mx = -__builtin_inff();
+        for (int64_t i = lane; i < L; i += 64) mx = fmaxf(mx, ElemIO<T>::load(sr + i) * scale);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int64_t i = lane; i < L; i += 64) sum += __expf(ElemIO<T>::load(sr + i) * scale - mx);
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int64_t i = lane; i < L; i += 64)
+            ElemIO<T>::store(p + r * L + i, __expf(ElemIO<T>::load(sr + i) * scale - mx) * inv);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const T* __restrict__ p, const T* __restrict__ dp,
+                                                               int64_t rows, int64_t L, float scale,
+                                                               T* __restrict__ ds) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        float dot = 0.f;
+        for (int64_t i = lane; i < L; i += 64)
+            dot = fmaf(ElemIO<T>::load(p + r * L + i), ElemIO<T>::load(dp + r * L + i), dot);
+        dot = wave_sum(dot);
+        for (int64_t i = lane; i < L; i += 64) {
+            const float pv = ElemIO<T>::load(p + r * L + i);
+            ElemIO<T>::store(ds + r * L + i, scale * pv * (ElemIO<T>::load(dp + r * L + i) - dot));
+        }
+    }
+}
+
+// ---- batched transpose through a padded LDS tile -------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, int64_t R, int64_t C,
+                                                        T* __restrict__ out) {
+    __shared__ T tile[32][33];
+    const int64_t b = blockIdx.z;
+    const T* ib = in + b * R * C;
+    T* ob = out + b * R * C;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < R && c0 + tx < C) tile[k][tx] = ib[(r0 + k) * C + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < C && r0 + tx < R) ob[(c0 + k) * R + r0 + tx] = tile[tx][k];
+}
+
+// ---- dual-grain merge -----------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dual_merge_kernel(const T* __restrict__ hf, const T* __restrict__ hc,
+                                                         const int64_t* __restrict__ grain, int64_t B, int64_t h,
+                                                         int64_t w, int64_t C, T* __restrict__ out,
+                                                         float* __restrict__ mask) {
+    const int64_t cv = C / 8;
+    const int64_t total = B * 4 * h * w * cv;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t c8 = e % cv, pix = e / cv;
+        const int64_t x = pix % (2 * w), y = (pix / (2 * w)) % (2 * h), b = pix / (4 * h * w);
+        const int64_t cell = (b * h + y / 2) * w + x / 2;
+        const bool fine = grain[cell] != 0;
+        const T* src = fine ? hf + pix * C + c8 * 8 : hc + cell * C + c8 * 8;
+        float v[8];
+        load8(src, v);
+        store8(out + pix * C + c8 * 8, v);
+        if (mask && c8 == 0) mask[pix] = fine ? 1.0f : 0.25f;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dual_merge_bwd_kernel(const T* __restrict__ g, const int64_t* __restrict__ grain,
+                                                             int64_t B, int64_t h, int64_t w, int64_t C,
+                                                             T* __restrict__ gf, T* __restrict__ gc) {
+    const int64_t cv = C / 8;
+    const int64_t total = B * h * w * cv;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t c8 = e % cv, cell = e / cv;
+        const int64_t xc = cell % w, yc = (cell / w) % h, b = cell / (h * w);
+        const bool fine = grain[cell] != 0;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int64_t pix = (b * 2 * h + 2 * yc + dy) * 2 * w + 2 * xc + dx;
+                float v[8];
+                load8(g + pix * C + c8 * 8, v);
+                if (fine) {
+                    store8(gf + pix * C + c8 * 8, v);
+                } else {
+                    store8(gf + pix * C + c8 * 8, zero);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+                }
+            }
+        store8(gc + cell * C + c8 * 8, acc);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t n8,
+                                                  T* __restrict__ y) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
+        float u[8], v[8];
+        load8(a + e * 8, u);
+        load8(b + e * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] += v[j];
+        store8(y + e * 8, u);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_bias_bcast_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                             int64_t batch, int64_t inner8, T* __restrict__ y) {
+    const int64_t total = batch * inner8;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e % inner8;
+        float u[8], v[8];
+        load8(x + e * 8, u);
+        load8(bias + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] += v[j];
+        store8(y + e * 8, u);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sum_batch_kernel(const T* __restrict__ x, int64_t batch, int64_t inner,
+                                                        float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < inner; i += (int64_t)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int64_t b = 0; b < batch; ++b) acc += ElemIO<T>::load(x + b * inner + i);
+        out[i] += acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ in, int64_t N, int64_t h, int64_t w,
+                                                         int64_t C, T* __restrict__ out) {
+    const int64_t cv = C / 8;
+    const int64_t total = N * h * w * cv;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t c8 = e % cv, cell = e / cv;
+        const int64_t xc = cell % w, yc = (cell / w) % h, n = cell / (h * w);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float v[8];
+                load8(in + (((n * 2 * h + 2 * yc + dy) * 2 * w) + 2 * xc + dx) * C + c8 * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+        store8(out + cell * C + c8 * 8, acc);
+    }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+        ElemIO<TO>::store(out + e, ElemIO<TI>::load(in + e));
+}
+
+// master OIHW fp32 -> w [Cout][KH][KW][Cin_p] and wt [Cin][KH][KW][Cout_p] (zero padded)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ m, int64_t Cout, int64_t Cin,
+                                                          int64_t KH, int64_t KW, int64_t Cin_p, int64_t Cout_p,
+                                                          T* __restrict__ w, T* __restrict__ wt) {
+    const int64_t taps = KH * KW;
+    const int64_t nw = w ? Cout * taps * Cin_p : 0, nwt = wt ? Cin * taps * Cout_p : 0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nw + nwt; e += (int64_t)gridDim.x * 256) {
+        if (e < nw) {
+            const int64_t ci = e % Cin_p, tap = (e / Cin_p) % taps, co = e / (Cin_p * taps);
+            ElemIO<T>::store(w + e, ci < Cin ? m[(co * Cin + ci) * taps + tap] : 0.f);
+        } else {
+            const int64_t f = e - nw;
+            const int64_t co = f % Cout_p, tap = (f / Cout_p) % taps, ci = f / (Cout_p * taps);
+            ElemIO<T>::store(wt + f, co < Cout ? m[(co * Cin + ci) * taps + tap] : 0.f);
+        }
+    }
+}
+
+// grad_oihw[co][ci][tap] += dw[co][tap][ci]   (dw: [Cout][taps][Cin_p] fp32)
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dw, int64_t Cout, int64_t Cin,
+                                                           int64_t taps, int64_t Cin_p, float* __restrict__ g) {
+    const int64_t n = Cout * Cin * taps;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t tap = e % taps, ci = (e / taps) % Cin, co = e / (taps * Cin);
+        g[e] += dw[(co * taps + tap) * Cin_p + ci];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ in, int64_t B, int64_t C,
+                                                               int64_t HW, int64_t Cp, T* __restrict__ out) {
+    const int64_t total = B * HW * Cp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t c = e % Cp, p = (e / Cp) % HW, b = e / (Cp * HW);
+        ElemIO<T>::store(out + e, c < C ? in[(b * C + c) * HW + p] : 0.f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_pad_to_nchw_kernel(const T* __restrict__ in, int64_t B, int64_t C,
+                                                               int64_t HW, int64_t Cp, float* __restrict__ out) {
+    const int64_t total = B * C * HW;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t p = e % HW, c = (e / HW) % C, b = e / (HW * C);
+        out[e] = ElemIO<T>::load(in + (b * HW + p) * Cp + c);
+    }
+}
+
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ x, const float* __restrict__ xr,
+                                                      int64_t n, double* loss_sum, const float* __restrict__ scale_dev,
+                                                      float* __restrict__ g) {
+    __shared__ double part[4];
+    const float sc = (g && scale_dev) ? scale_dev[0] : 0.f;
+    float acc = 0.f;
+    double dacc = 0.0;
+    int cnt = 0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float d = xr[e] - x[e];
+        acc += fabsf(d);
+        if (g) g[e] = d > 0.f ? sc : (d < 0.f ? -sc : 0.f);
+        if (++cnt == 64) {
+            dacc += (double)acc;
+            acc = 0.f;
+            cnt = 0;
+        }
+    }
+    dacc += (double)acc;
+    dacc = wave_sum(dacc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = dacc;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float step_size, float beta1, float beta2, float eps,
+                                                   float inv_sqrt_bc2) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float gv = g[e];
+        const float mm = beta1 * m[e] + (1.f - beta1) * gv;
+        const float vv = beta2 * v[e] + (1.f - beta2) * gv * gv;
+        m[e] = mm;
+        v[e] = vv;
+        p[e] -= step_size * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, float v, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) p[e] = v;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* dvq_last_error(void) { return g_err; }
+int dvq_version(void) { return 100; }
+
+int dvq_check_device(void) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        dvq_set_error("dvq_check_device: no HIP device");
+        return DVQ_EARCH;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        dvq_set_error("dvq_check_device: device is %s, libdvq_hip is built for gfx950 only", prop.gcnArchName);
+        return DVQ_EARCH;
+    }
+    return DVQ_OK;
+}
+
+int dvq_softmax_rows(const void* s, int dtype, int64_t rows, int64_t L, float scale, void* p, dvq_stream_t stream) {
+    DVQ_REQUIRE(s && p && rows > 0 && L > 0, DVQ_EINVAL, "dvq_softmax_rows: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T, softmax_rows_kernel<T><<<dim3(nblocks(rows, 4)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)s, rows, L, scale, (T*)p););
+    DVQ_CHECK_LAUNCH("softmax_rows");
+    return DVQ_OK;
+}
+
+int dvq_softmax_rows_bwd(const void* p, const void* dp, int dtype, int64_t rows, int64_t L, float scale, void* ds,
+                         dvq_stream_t stream) {
+    DVQ_REQUIRE(p && dp && ds && rows > 0 && L > 0, DVQ_EINVAL, "dvq_softmax_rows_bwd: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T,
+                       softmax_rows_bwd_kernel<T><<<dim3(nblocks(rows, 4)), dim3(256), 0, (hipStream_t)stream>>>(
+                           (const T*)p, (const T*)dp, rows, L, scale, (T*)ds););
+    DVQ_CHECK_LAUNCH("softmax_rows_bwd");
+    return DVQ_OK;
+}
+
+int dvq_transpose(const void* in, int dtype, int64_t batch, int64_t R, int64_t C, void* out, dvq_stream_t stream) {
+    DVQ_REQUIRE(in && out && batch > 0 && batch <= 65535 && R > 0 && C > 0, DVQ_EINVAL, "dvq_transpose: bad arguments");
+    dim3 grid((unsigned)cdiv64(C, 32), (unsigned)cdiv64(R, 32), (unsigned)batch);
+    DVQ_REQUIRE(grid.y <= 65535, DVQ_ESHAPE, "dvq_transpose: R too large");
+    DVQ_DISPATCH_DTYPE(dtype, T, transpose_kernel<T><<<grid, dim3(256), 0, (hipStream_t)stream>>>((const T*)in, R, C,
+                                                                                                (T*)out););
+    DVQ_CHECK_LAUNCH("transpose");
+    return DVQ_OK;
+}
+
+int dvq_dual_merge(const void* h_fine, const void* h_coarse, const int64_t* grain, int dtype, int64_t B, int64_t h,
+                   int64_t w, int64_t C, void* h_dual, float* mask, dvq_stream_t stream) {
+    DVQ_REQUIRE(h_fine && h_coarse && grain && h_dual, DVQ_EINVAL, "dvq_dual_merge: null pointer");
+    DVQ_REQUIRE(C % 8 == 0, DVQ_ESHAPE, "dvq_dual_merge: C %% 8 != 0");
+    DVQ_DISPATCH_DTYPE(dtype, T, dual_merge_kernel<T><<<dim3(nblocks(B * 4 * h * w * C / 8, 256)), dim3(256), 0,
+                                                        (hipStream_t)stream>>>((const T*)h_fine, (const T*)h_coarse, grain,
+                                                                               B, h, w, C, (T*)h_dual, mask););
+    DVQ_CHECK_LAUNCH("dual_merge");
+    return DVQ_OK;
+}
+
+int dvq_dual_merge_bwd(const void* g_dual, const int64_t* grain, int dtype, int64_t B, int64_t h, int64_t w, int64_t C,
+                       void* g_fine, void* g_coarse, dvq_stream_t stream) {
+    DVQ_REQUIRE(g_dual && grain && g_fine && g_coarse, DVQ_EINVAL, "dvq_dual_merge_bwd: null pointer");
+    DVQ_REQUIRE(C % 8 == 0, DVQ_ESHAPE, "dvq_dual_merge_bwd: C %% 8 != 0");
+    DVQ_DISPATCH_DTYPE(dtype, T, dual_merge_bwd_kernel<T><<<dim3(nblocks(B * h * w * C / 8, 256)), dim3(256), 0,
+                                                            (hipStream_t)stream>>>((const T*)g_dual, grain, B, h, w, C,
+                                                                                   (T*)g_fine, (T*)g_coarse););
+    DVQ_CHECK_LAUNCH("dual_merge_bwd");
+    return DVQ_OK;
+}
+
+int dvq_add(const void* a, const void* b, int dtype, int64_t n, void* y, dvq_stream_t stream) {
+    DVQ_REQUIRE(a && b && y && n > 0 && n % 8 == 0, DVQ_EINVAL, "dvq_add: bad arguments (n %% 8 == 0 required)");
+    DVQ_DISPATCH_DTYPE(dtype, T, add_kernel<T><<<dim3(nblocks(n / 8, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)a, (const T*)b, n / 8, (T*)y););
+    DVQ_CHECK_LAUNCH("add");
+    return DVQ_OK;
+}
+
+int dvq_add_bias_bcast(const void* x, const float* bias, int dtype, int64_t batch, int64_t inner, void* y,
+                       dvq_stream_t stream) {
+    DVQ_REQUIRE(x && bias && y && batch > 0 && inner > 0 && inner % 8 == 0, DVQ_EINVAL, "dvq_add_bias_bcast: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T, add_bias_bcast_kernel<T><<<dim3(nblocks(batch * inner / 8, 256)), dim3(256), 0,
+                                                            (hipStream_t)stream>>>((const T*)x, bias, batch, inner / 8,
+                                                                                   (T*)y););
+    DVQ_CHECK_LAUNCH("add_bias_bcast");
+    return DVQ_OK;
+}
+
+int dvq_sum_batch(const void* x, int dtype, int64_t batch, int64_t inner, float* out, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && out && batch > 0 && inner > 0, DVQ_EINVAL, "dvq_sum_batch: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T, sum_batch_kernel<T><<<dim3(nblocks(inner, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)x, batch, inner, out););
+    DVQ_CHECK_LAUNCH("sum_batch");
+    return DVQ_OK;
+}
+
+int dvq_sumpool2x2(const void* in, int dtype, int64_t N, int64_t h, int64_t w, int64_t C, void* out,
+                   dvq_stream_t stream) {
+    DVQ_REQUIRE(in && out && C % 8 == 0, DVQ_EINVAL, "dvq_sumpool2x2: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T, sumpool2x2_kernel<T><<<dim3(nblocks(N * h * w * C / 8, 256)), dim3(256), 0,
+                                                        (hipStream_t)stream>>>((const T*)in, N, h, w, C, (T*)out););
+    DVQ_CHECK_LAUNCH("sumpool2x2");
+    return DVQ_OK;
+}
+
+int dvq_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, dvq_stream_t stream) {
+    DVQ_REQUIRE(in && out && n > 0, DVQ_EINVAL, "dvq_cast: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(nblocks(n, 256)), block(256);
+    if (in_dtype == DVQ_F32 && out_dtype == DVQ_BF16) cast_kernel<float, bf16_t><<<grid, block, 0, s>>>((const float*)in, (bf16_t*)out, n);
+    else if (in_dtype == DVQ_BF16 && out_dtype == DVQ_F32) cast_kernel<bf16_t, float><<<grid, block, 0, s>>>((const bf16_t*)in, (float*)out, n);
+    else if (in_dtype == DVQ_F32 && out_dtype == DVQ_F32) cast_kernel<float, float><<<grid, block, 0, s>>>((const float*)in, (float*)out, n);
+    else if (in_dtype == DVQ_BF16 && out_dtype == DVQ_BF16) cast_kernel<bf16_t, bf16_t><<<grid, block, 0, s>>>((const bf16_t*)in, (bf16_t*)out, n);
+    else {
+        dvq_set_error("dvq_cast: bad dtypes");
+        return DVQ_EINVAL;
+    }
+    DVQ_CHECK_LAUNCH("cast");
+    return DVQ_OK;
+}
+
+int dvq_pack_weight(const float* master, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW, int64_t Cin_p,
+                    int64_t Cout_p, int dtype, void* w, void* wt, dvq_stream_t stream) {
+    DVQ_REQUIRE(master && (w || wt) && Cin_p >= Cin && Cout_p >= Cout, DVQ_EINVAL, "dvq_pack_weight: bad arguments");
+    const int64_t n = Cout * KH * KW * Cin_p + Cin * KH * KW * Cout_p;
+    DVQ_DISPATCH_DTYPE(dtype, T, pack_weight_kernel<T><<<dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     master, Cout, Cin, KH, KW, Cin_p, Cout_p, (T*)w, (T*)wt););
+    DVQ_CHECK_LAUNCH("pack_weight");
+    return DVQ_OK;
+}
+
+int dvq_unpack_wgrad(const float* dw, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW, int64_t Cin_p, float* grad,
+                     dvq_stream_t stream) {
+    DVQ_REQUIRE(dw && grad && Cin_p >= Cin, DVQ_EINVAL, "dvq_unpack_wgrad: bad arguments");
+    unpack_wgrad_kernel<<<dim3(nblocks(Cout * Cin * KH * KW, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        dw, Cout, Cin, KH * KW, Cin_p, grad);
+    DVQ_CHECK_LAUNCH("unpack_wgrad");
+    return DVQ_OK;
+}
+
+int dvq_nchw_to_nhwc_pad(const float* in, int64_t B, int64_t C, int64_t H, int64_t W, int64_t Cp, int dtype, void* out,
+                         dvq_stream_t stream) {
+    DVQ_REQUIRE(in && out && Cp >= C, DVQ_EINVAL, "dvq_nchw_to_nhwc_pad: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T, nchw_to_nhwc_pad_kernel<T><<<dim3(nblocks(B * H * W * Cp, 256)), dim3(256), 0,
+                                                              (hipStream_t)stream>>>(in, B, C, H * W, Cp, (T*)out););
+    DVQ_CHECK_LAUNCH("nchw_to_nhwc_pad");
+    return DVQ_OK;
+}
+
+int dvq_nhwc_pad_to_nchw(const void* in, int dtype, int64_t B, int64_t C, int64_t H, int64_t W, int64_t Cp, float* out,
+                         dvq_stream_t stream) {
+    DVQ_REQUIRE(in && out && Cp >= C, DVQ_EINVAL, "dvq_nhwc_pad_to_nchw: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T, nhwc_pad_to_nchw_kernel<T><<<dim3(nblocks(B * C * H * W, 256)), dim3(256), 0,
+                                                              (hipStream_t)stream>>>((const T*)in, B, C, H * W, Cp, out););
+    DVQ_CHECK_LAUNCH("nhwc_pad_to_nchw");
+    return DVQ_OK;
+}
+
+int dvq_l1_loss(const float* x, const float* xrec, int64_t n, double* loss_sum, const float* scale_dev, float* g,
+                dvq_stream_t stream) {
+    DVQ_REQUIRE(x && xrec && n > 0, DVQ_EINVAL, "dvq_l1_loss: bad arguments");
+    l1_loss_kernel<<<dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream>>>(x, xrec, n, loss_sum, scale_dev, g);
+    DVQ_CHECK_LAUNCH("l1_loss");
+    return DVQ_OK;
+}
+
+int dvq_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             int step, dvq_stream_t stream) {
+    DVQ_REQUIRE(p && g && m && v && n > 0 && step >= 1, DVQ_EINVAL, "dvq_adam: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    adam_kernel<<<dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, n, (float)(lr / bc1), beta1,
+                                                                             beta2, eps, (float)(1.0 / sqrt(bc2)));
+    DVQ_CHECK_LAUNCH("adam");
+    return DVQ_OK;
+}
+
+int dvq_fill_f32(float* p, float v, int64_t n, dvq_stream_t stream) {
+    DVQ_REQUIRE(p && n > 0, DVQ_EINVAL, "dvq_fill_f32: bad arguments");
+    fill_kernel<<<dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream>>>(p, v, n);
+    DVQ_CHECK_LAUNCH("fill");
+    return DVQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,563 @@
+// Vector-quantisation kernels for gfx950: exact L2 codebook argmin without the [N,K] matrix,
+// gather + masked commitment loss, straight-through backward, deterministic EMA statistics.
+//
+// Replaces modules/vector_quantization/quantize2_mask.py:29-132,157-191 of the reference.
+//
+// Exactness scheme (DESIGN.md "VQ argmin"):
+//   score_k = |e_k|^2 - 2 x.e_k.  The dot product runs on bf16 MFMA with x and e each split into
+//   bf16 planes (x = x1 + x2 + r, e = e1 + e2 + r', |r| <= 2^-18 |x|): x1.e1 + x1.e2 + x2.e1,
+//   fp32 accumulate.  Every row keeps best and second-best score; when their gap is not larger
+//   than a sound bound on the evaluation error the row is re-ranked in fp64 over all K codes
+//   (a few 0.1 % of rows).  The result is the mathematically exact argmin, lowest index on ties.
+#include <type_traits>
+
+#include "dvq_common.h"
+
+namespace {
+
+struct VqPrepView {
+    float* emax;     // [1]  max_k |e_k|   (stored as float bits, atomicMax on uint)
+    float* en;       // [Kp] |e_k|^2 (fp64 accumulate, rounded); +inf for padded codes
+    bf16_t* e1;      // [Kp][D]
+    bf16_t* e2;      // [Kp][D]
+    int64_t Kp;
+};
+
+__host__ __device__ inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+__host__ __device__ inline VqPrepView prep_view(void* prep, int64_t K, int64_t D) {
+    VqPrepView v;
+    v.Kp = align_up(K, 32);
+    char* p = (char*)prep;
+    v.emax = (float*)p;
+    v.en = (float*)(p + 256);
+    int64_t off = 256 + align_up(v.Kp * 4, 256);
+    v.e1 = (bf16_t*)(p + off);
+    v.e2 = (bf16_t*)(p + off + v.Kp * D * 2);
+    return v;
+}
+
+// one wave per (padded) code
+__global__ void vq_prepare_kernel(const float* __restrict__ cb, int64_t K, int64_t D, void* prep) {
+    VqPrepView pv = prep_view(prep, K, D);
+    int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    int lane = threadIdx.x & 63;
+    if (k >= pv.Kp) return;
+    double acc = 0.0;
+    for (int64_t d = lane; d < D; d += 64) {
+        float e = k < K ? cb[k * D + d] : 0.0f;
+        bf16_t h = f32_to_bf16(e);
+        float r = e - bf16_to_f32(h);
+        pv.e1[k * D + d] = h;
+        pv.e2[k * D + d] = f32_to_bf16(r);
+        acc += (double)e * (double)e;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (k < K) {
+            pv.en[k] = (float)acc;
+            float nrm = (float)sqrt(acc) * 1.0000002f;  // round up
+            atomicMax((unsigned*)pv.emax, __float_as_uint(nrm));
+        } else {
+            pv.en[k] = __builtin_inff();
+        }
+    }
+}
+
+struct VqWs {
+    int count;      // flagged rows
+    int pad[63];
+    int list[1];    // [N]
+};
+
+// ---------------------------------------------------------------------------------------------
+// main kernel: 4 waves x 32 rows per block, x fragments live in registers, codebook streams
+// through LDS in 32-code stages (double buffered, register-staged prefetch).
+// ---------------------------------------------------------------------------------------------
+template <int KSTEPS, typename XT>
+__global__ __launch_bounds__(256, 1) void vq_argmin_mfma_kernel(const XT* __restrict__ x, const void* prep_c,
+                                                                int64_t N, int64_t K, int64_t* __restrict__ idx_out,
+                                                                VqWs* ws) {
+    constexpr int D = KSTEPS * 16;
+    constexpr bool XBF16 = sizeof(XT) == 2;
+    constexpr int ROWB = D * 2 + 16;          // LDS bytes per code row (16-B pad -> conflict-free b128 reads)
+    constexpr int PIECE = 32 * ROWB;          // one bf16 plane of a 32-code stage
+    constexpr int STAGE = 2 * PIECE;
+    constexpr int CH_PER_THREAD = D / 64;     // 16-B chunks per thread per plane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xnorm = reinterpret_cast<float*>(smem + 2 * STAGE);   // [128]
+
+    VqPrepView pv = prep_view(const_cast<void*>(prep_c), K, D);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+
+    // ---- load + split x fragments -------------------------------------------------------------
+    bf16x8 xa1[KSTEPS];
+    bf16x8 xa2[XBF16 ? 1 : KSTEPS];
+    float sq = 0.f;
+    {
+        const int64_t r = row0 + l31;
+        const bool ok = r < N;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            float v[8];
+            if (ok) {
+                load8(x + r * D + ks * 16 + half * 8, v);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sq = fmaf(v[j], v[j], sq);
+                bf16_t h = f32_to_bf16(v[j]);
+                xa1[ks][j] = __builtin_bit_cast(__bf16, h);
+                if constexpr (!XBF16) {
+                    float rr = v[j] - bf16_to_f32(h);
+                    xa2[ks][j] = __builtin_bit_cast(__bf16, f32_to_bf16(rr));
+                }
+            }
+        }
+    }
+    sq += __shfl_xor(sq, 32, 64);
+    if (half == 0) xnorm[wave * 32 + l31] = sqrtf(sq) * 1.000001f;
+
+    // ---- stage loader -------------------------------------------------------------------------
+    const int nstage = (int)(pv.Kp / 32);
+    // per-thread 16-B chunks of a stage (named registers: arrays here end up in scratch)
+    uint4 p1_0, p1_1, p1_2, p1_3, p2_0, p2_1, p2_2, p2_3;
+    p1_0 = p1_1 = p1_2 = p1_3 = p2_0 = p2_1 = p2_2 = p2_3 = make_uint4(0, 0, 0, 0);
+    auto chunk_goff = [&](int i) { const int q = tid + 256 * i; return (q / (D / 8)) * D + (q % (D / 8)) * 8; };
+    auto chunk_soff = [&](int i) { const int q = tid + 256 * i; return (q / (D / 8)) * ROWB + (q % (D / 8)) * 16; };
+    const int go0 = chunk_goff(0), go1 = chunk_goff(1), go2 = chunk_goff(2), go3 = chunk_goff(3);
+    const int so0 = chunk_soff(0), so1 = chunk_soff(1), so2 = chunk_soff(2), so3 = chunk_soff(3);
+#define VQ_G1(i, c)                                                                           \
+    if constexpr (CH_PER_THREAD > i) {                                                        \
+        const int64_t g = (int64_t)(c) * 32 * D + go##i;                                      \
+        p1_##i = *reinterpret_cast<const uint4*>(pv.e1 + g);                                  \
+        p2_##i = *reinterpret_cast<const uint4*>(pv.e2 + g);                                  \
+    }
+#define VQ_G_LOAD(c) VQ_G1(0, c) VQ_G1(1, c) VQ_G1(2, c) VQ_G1(3, c)
+#define VQ_S1(i, buf)                                                                         \
+    if constexpr (CH_PER_THREAD > i) {                                                        \
+        char* base = smem + (buf) * STAGE + so##i;                                            \
+        *reinterpret_cast<uint4*>(base) = p1_##i;                                             \
+        *reinterpret_cast<uint4*>(base + PIECE) = p2_##i;                                     \
+    }
+#define VQ_S_STORE(buf) VQ_S1(0, buf) VQ_S1(1, buf) VQ_S1(2, buf) VQ_S1(3, buf)
+
+    float b1[16], b2[16];
+    int i1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        b1[r] = __builtin_inff();
+        b2[r] = __builtin_inff();
+        i1[r] = 0x7fffffff;
+    }
+
+    VQ_G_LOAD(0)
+    VQ_S_STORE(0)
+    __syncthreads();
+
+    for (int c = 0; c < nstage; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nstage) {
+            VQ_G_LOAD(c + 1)
+        }
+        const float en_k = pv.en[c * 32 + l31];
+        f32x16 acc_hi = {0}, acc_lo = {0};
+        const char* bbase = smem + buf * STAGE + l31 * ROWB + half * 16;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            bf16x8 e1f = *reinterpret_cast<const bf16x8*>(bbase + ks * 32);
+            bf16x8 e2f = *reinterpret_cast<const bf16x8*>(bbase + PIECE + ks * 32);
+            acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1[ks], e1f, acc_hi, 0, 0, 0);
+            acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1[ks], e2f, acc_lo, 0, 0, 0);
+            if constexpr (!XBF16) acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa2[ks], e1f, acc_lo, 0, 0, 0);
+        }
+        const int kidx = c * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = fmaf(-2.0f, acc_hi[r] + acc_lo[r], en_k);
+            bool lt = s < b1[r];
+            float nb2 = lt ? b1[r] : (s < b2[r] ? s : b2[r]);
+            b2[r] = nb2;
+            i1[r] = lt ? kidx : i1[r];
+            b1[r] = lt ? s : b1[r];
+        }
+        if (c + 1 < nstage) {
+            VQ_S_STORE(buf ^ 1)
+        }
+        __syncthreads();
+    }
+#undef VQ_G_LOAD
+#undef VQ_S_STORE
+#undef VQ_G1
+#undef VQ_S1
+
+    // ---- reduce over the 32 code lanes of each half ----------------------------------------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            float ob1 = __shfl_xor(b1[r], o, 64);
+            float ob2 = __shfl_xor(b2[r], o, 64);
+            int oi1 = __shfl_xor(i1[r], o, 64);
+            bool take = (ob1 < b1[r]) || (ob1 == b1[r] && oi1 < i1[r]);
+            float loser = take ? b1[r] : ob1;
+            float m2 = b2[r] < ob2 ? b2[r] : ob2;
+            b2[r] = loser < m2 ? loser : m2;
+            b1[r] = take ? ob1 : b1[r];
+            i1[r] = take ? oi1 : i1[r];
+        }
+    }
+    if (l31 == 0) {
+        const float emax = *pv.emax;
+        // error bound of one score: split residual 3*2^-18, accumulate D*2^-23 (relative to |x||e|),
+        // norm rounding + final fma 4*2^-24; two scores are compared -> factor 2, -2x.e -> factor 2.
+        const float coefA = 4.0f * (3.0f * 3.8147e-6f + (float)D * 1.1921e-7f);
+        const float coefB = 8.0f * 5.9605e-8f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int64_t row = row0 + rl;
+            if (row < N) {
+                idx_out[row] = (int64_t)i1[r];
+                const float xn = xnorm[wave * 32 + rl];
+                const float tau = coefA * xn * emax + coefB * (emax * emax + 2.0f * xn * emax + xn * xn) + 1e-37f;
+                const float gap = b2[r] - b1[r];
+                if (!(gap > tau)) {
+                    int pos = atomicAdd(&ws->count, 1);
+                    ws->list[pos] = (int)row;
+                }
+            }
+        }
+    }
+}
+
+__global__ void vq_flag_all_kernel(VqWs* ws, int64_t N) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) ws->count = (int)N;
+    if (i < N) ws->list[i] = (int)i;
+}
+
+// fp64 exact re-rank of flagged rows: one block per flagged row (grid-stride), wave per code.
+template <typename XT>
+__global__ __launch_bounds__(256) void vq_rerank_fp64_kernel(const XT* __restrict__ x, const float* __restrict__ cb,
+                                                             int64_t K, int64_t D, int64_t* __restrict__ idx_out,
+                                                             const VqWs* ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* xs = reinterpret_cast<double*>(smem);            // [D]
+    double* wbest = xs + D;                                  // [4]
+    int* widx = reinterpret_cast<int*>(wbest + 4);           // [4]
+    const int cnt = ws->count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int f = blockIdx.x; f < cnt; f += gridDim.x) {
+        const int64_t row = ws->list[f];
+        __syncthreads();
+        for (int64_t d = threadIdx.x; d < D; d += blockDim.x) xs[d] = (double)ElemIO<XT>::load(x + row * D + d);
+        __syncthreads();
+        double best = __builtin_inf();
+        int bi = 0x7fffffff;
+        for (int64_t k = wave; k < K; k += 4) {
+            double acc = 0.0;
+            for (int64_t d = lane; d < D; d += 64) {
+                double t = xs[d] - (double)cb[k * D + d];
+                acc = fma(t, t, acc);
+            }
+            acc = wave_sum(acc);
+            if (acc < best) {   // k increasing within a wave -> first minimum kept
+                best = acc;
+                bi = (int)k;
+            }
+        }
+        if (lane == 0) {
+            wbest[wave] = best;
+            widx[wave] = bi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double b = wbest[0];
+            int i = widx[0];
+            for (int w = 1; w < 4; ++w)
+                if (wbest[w] < b || (wbest[w] == b && widx[w] < i)) {
+                    b = wbest[w];
+                    i = widx[w];
+                }
+            idx_out[row] = (int64_t)i;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather + loss, backward, embed: one wave per row
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void vq_gather_loss_kernel(const T* __restrict__ x, const float* __restrict__ cb,
+                                                             const int64_t* __restrict__ idx,
+                                                             const float* __restrict__ mask, int64_t N, int64_t D,
+                                                             T* __restrict__ xq, double* loss_sum) {
+    __shared__ double part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+        const int64_t k = idx[n];
+        const float m = mask ? mask[n] : 1.0f;
+        float a = 0.f;
+        for (int64_t d = lane; d < D; d += 64) {
+            float xv = ElemIO<T>::load(x + n * D + d);
+            float e = cb[k * D + d];
+            float df = e - xv;
+            a = fmaf(df, df, a);
+            ElemIO<T>::store(xq + n * D + d, xv + df);
+        }
+        acc += (double)(wave_sum(a) * m);
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, part[0] + part[1] + part[2] + part[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vq_backward_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                          const float* __restrict__ cb,
+                                                          const int64_t* __restrict__ idx,
+                                                          const float* __restrict__ mask,
+                                                          const float* __restrict__ coef_dev, int64_t N, int64_t D,
+                                                          T* __restrict__ dx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float coef = coef_dev[0];
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+        const int64_t k = idx[n];
+        const float cm = coef * (mask ? mask[n] : 1.0f);
+        for (int64_t d = lane; d < D; d += 64) {
+            float xv = ElemIO<T>::load(x + n * D + d);
+            float gv = ElemIO<T>::load(g + n * D + d);
+            ElemIO<T>::store(dx + n * D + d, fmaf(cm, xv - cb[k * D + d], gv));
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vq_embed_kernel(const float* __restrict__ cb, const int64_t* __restrict__ idx,
+                                                       int64_t N, int64_t D, T* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+        const int64_t k = idx[n];
+        for (int64_t d = lane; d < D; d += 64) ElemIO<T>::store(out + n * D + d, cb[k * D + d]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// EMA statistics: one block per code, deterministic (rows are visited in index order, no atomics).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void vq_ema_stats_kernel(const T* __restrict__ x, const int64_t* __restrict__ idx,
+                                                           int64_t N, int64_t K, int64_t D,
+                                                           float* __restrict__ stats) {
+    const int64_t k = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};   // dims threadIdx.x + 256*j, D <= 1024
+    int count = 0;
+    for (int64_t n0 = 0; n0 < N; n0 += 64) {
+        const int64_t n = n0 + lane;
+        const bool hit = n < N && idx[n] == k;
+        unsigned long long m = __ballot(hit);
+        count += __popcll(m);
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const T* row = x + (n0 + b) * D;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t d = threadIdx.x + 256 * j;
+                if (d < D) acc[j] += ElemIO<T>::load(row + d);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t d = threadIdx.x + 256 * j;
+        if (d < D) stats[k * (D + 1) + d] = acc[j];
+    }
+    if (threadIdx.x == 0) stats[k * (D + 1) + D] = (float)count;
+}
+
+__global__ __launch_bounds__(256) void vq_ema_update_kernel(const float* __restrict__ stats,
+                                                            const float* __restrict__ restart, float decay,
+                                                            int64_t K, int64_t D, float* __restrict__ n_ema,
+                                                            float* __restrict__ s_ema) {
+    const int64_t k = blockIdx.x;
+    __shared__ float s_n;
+    __shared__ int s_dead;
+    if (threadIdx.x == 0) {
+        float nn = n_ema[k] * decay + stats[k * (D + 1) + D] * (1.0f - decay);
+        int dead = restart != nullptr && !(nn >= 1.0f);
+        s_dead = dead;
+        s_n = dead ? 1.0f : nn;
+    }
+    __syncthreads();
+    const int dead = s_dead;
+    for (int64_t d = threadIdx.x; d < D; d += blockDim.x) {
+        float v = s_ema[k * D + d] * decay + stats[k * (D + 1) + d] * (1.0f - decay);
+        if (dead) v = restart[k * D + d];
+        s_ema[k * D + d] = v;
+    }
+    if (threadIdx.x == 0) n_ema[k] = s_n;
+}
+
+__global__ __launch_bounds__(256) void vq_ema_normalize_kernel(const float* __restrict__ n_ema,
+                                                               const float* __restrict__ s_ema, float eps, int64_t K,
+                                                               int64_t D, float* __restrict__ weight) {
+    __shared__ float part[256];
+    float a = 0.f;
+    for (int64_t i = threadIdx.x; i < K; i += 256) a += n_ema[i];
+    part[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float n = part[0];
+    const int64_t k = blockIdx.x;
+    const float norm = n * (n_ema[k] + eps) / (n + (float)K * eps);
+    for (int64_t d = threadIdx.x; d < D; d += 256) weight[k * D + d] = s_ema[k * D + d] / norm;
+}
+
+}  // namespace
+
+template <typename XT>
+static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_t N, int64_t K, int64_t D,
+                          int64_t* idx, void* wsv, int impl, hipStream_t s) {
+    VqWs* ws = (VqWs*)wsv;
+    const bool mfma_ok = (D == 64 || D == 128 || D == 256) && prep != nullptr;
+    DVQ_REQUIRE(!(impl == 2 && !mfma_ok), DVQ_ESHAPE, "dvq_vq_argmin: MFMA path needs D in {64,128,256} and prep");
+    const bool use_mfma = impl == 2 || (impl == 0 && mfma_ok);
+    if (use_mfma) {
+        if (hipMemsetAsync(ws, 0, 256, s) != hipSuccess) {
+            dvq_set_error("dvq_vq_argmin: memset failed");
+            return DVQ_ELAUNCH;
+        }
+        dim3 grid((unsigned)cdiv64(N, 128)), block(256);
+        auto launch = [&](auto ksteps) {
+            constexpr int KS = decltype(ksteps)::value;
+            constexpr int Dc = KS * 16;
+            size_t lds = 2 * (2 * 32 * (Dc * 2 + 16)) + 128 * 4;
+            (void)hipFuncSetAttribute((const void*)vq_argmin_mfma_kernel<KS, XT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            vq_argmin_mfma_kernel<KS, XT><<<grid, block, lds, s>>>(x, prep, N, K, idx, ws);
+        };
+        if (D == 64) launch(std::integral_constant<int, 4>{});
+        else if (D == 128) launch(std::integral_constant<int, 8>{});
+        else launch(std::integral_constant<int, 16>{});
+        DVQ_CHECK_LAUNCH("vq_argmin_mfma");
+    } else {
+        vq_flag_all_kernel<<<dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, s>>>(ws, N);
+        DVQ_CHECK_LAUNCH("vq_flag_all");
+    }
+    size_t lds = (size_t)D * 8 + 64;
+    int64_t blocks = use_mfma ? 1024 : (N < 65535 ? N : 65535);
+    vq_rerank_fp64_kernel<XT><<<dim3((unsigned)blocks), dim3(256), lds, s>>>(x, cb, K, D, idx, ws);
+    DVQ_CHECK_LAUNCH("vq_rerank_fp64");
+    return DVQ_OK;
+}
+
+// =================================================================================================
+extern "C" {
+
+size_t dvq_vq_prep_bytes(int64_t K, int64_t D) {
+    int64_t Kp = align_up(K, 32);
+    return (size_t)(256 + align_up(Kp * 4, 256) + 2 * Kp * D * 2);
+}
+
+int dvq_vq_prepare(const float* codebook, int64_t K, int64_t D, void* prep, dvq_stream_t stream) {
+    DVQ_REQUIRE(codebook && prep && K > 0 && D > 0, DVQ_EINVAL, "dvq_vq_prepare: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(prep, 0, 256, s) != hipSuccess) {
+        dvq_set_error("dvq_vq_prepare: memset failed");
+        return DVQ_ELAUNCH;
+    }
+    int64_t Kp = align_up(K, 32);
+    vq_prepare_kernel<<<dim3((unsigned)cdiv64(Kp, 4)), dim3(256), 0, s>>>(codebook, K, D, prep);
+    DVQ_CHECK_LAUNCH("vq_prepare");
+    return DVQ_OK;
+}
+
+size_t dvq_vq_argmin_workspace_bytes(int64_t N) { return (size_t)(256 + 4 * (N + 1)); }
+
+int dvq_vq_argmin(const void* x, int x_dtype, const float* codebook, const void* prep, int64_t N, int64_t K,
+                  int64_t D, int64_t* idx, void* ws, int impl, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && codebook && idx && ws, DVQ_EINVAL, "dvq_vq_argmin: null pointer");
+    DVQ_REQUIRE(N > 0 && K > 0 && D > 0 && N < (1ll << 31) && K < (1ll << 31), DVQ_ESHAPE,
+                "dvq_vq_argmin: bad shape N=%lld K=%lld D=%lld", (long long)N, (long long)K, (long long)D);
+    DVQ_REQUIRE(D * 8 + 64 <= 64 * 1024, DVQ_ESHAPE, "dvq_vq_argmin: D too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == DVQ_F32) return vq_argmin_impl<float>((const float*)x, codebook, prep, N, K, D, idx, ws, impl, s);
+    if (x_dtype == DVQ_BF16) return vq_argmin_impl<bf16_t>((const bf16_t*)x, codebook, prep, N, K, D, idx, ws, impl, s);
+    dvq_set_error("dvq_vq_argmin: bad dtype %d", x_dtype);
+    return DVQ_EINVAL;
+}
+
+int dvq_vq_gather_loss(const void* x, int dtype, const float* codebook, const int64_t* idx, const float* mask,
+                       int64_t N, int64_t D, void* x_q, double* loss_sum, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && codebook && idx && x_q && loss_sum, DVQ_EINVAL, "dvq_vq_gather_loss: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned grid = (unsigned)(cdiv64(N, 4) < 4096 ? cdiv64(N, 4) : 4096);
+    DVQ_DISPATCH_DTYPE(dtype, T, vq_gather_loss_kernel<T><<<dim3(grid), dim3(256), 0, s>>>(
+                                     (const T*)x, codebook, idx, mask, N, D, (T*)x_q, loss_sum););
+    DVQ_CHECK_LAUNCH("vq_gather_loss");
+    return DVQ_OK;
+}
+
+int dvq_vq_backward(const void* g_xq, const void* x, int dtype, const float* codebook, const int64_t* idx,
+                    const float* mask, const float* coef_dev, int64_t N, int64_t D, void* dx, dvq_stream_t stream) {
+    DVQ_REQUIRE(g_xq && x && codebook && idx && coef_dev && dx, DVQ_EINVAL, "dvq_vq_backward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned grid = (unsigned)(cdiv64(N, 4) < 4096 ? cdiv64(N, 4) : 4096);
+    DVQ_DISPATCH_DTYPE(dtype, T, vq_backward_kernel<T><<<dim3(grid), dim3(256), 0, s>>>(
+                                     (const T*)g_xq, (const T*)x, codebook, idx, mask, coef_dev, N, D, (T*)dx););
+    DVQ_CHECK_LAUNCH("vq_backward");
+    return DVQ_OK;
+}
+
+int dvq_vq_embed(const float* codebook, const int64_t* idx, int64_t N, int64_t D, int out_dtype, void* out,
+                 dvq_stream_t stream) {
+    DVQ_REQUIRE(codebook && idx && out, DVQ_EINVAL, "dvq_vq_embed: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned grid = (unsigned)(cdiv64(N, 4) < 4096 ? cdiv64(N, 4) : 4096);
+    DVQ_DISPATCH_DTYPE(out_dtype, T,
+                       vq_embed_kernel<T><<<dim3(grid), dim3(256), 0, s>>>(codebook, idx, N, D, (T*)out););
+    DVQ_CHECK_LAUNCH("vq_embed");
+    return DVQ_OK;
+}
+
+int dvq_vq_ema_stats(const void* x, int dtype, const int64_t* idx, int64_t N, int64_t K, int64_t D, float* stats,
+                     dvq_stream_t stream) {
+    DVQ_REQUIRE(x && idx && stats, DVQ_EINVAL, "dvq_vq_ema_stats: null pointer");
+    DVQ_REQUIRE(D <= 1024, DVQ_ESHAPE, "dvq_vq_ema_stats: D > 1024 unsupported");
+    hipStream_t s = (hipStream_t)stream;
+    DVQ_DISPATCH_DTYPE(dtype, T, vq_ema_stats_kernel<T><<<dim3((unsigned)K), dim3(256), 0, s>>>(
+                                     (const T*)x, idx, N, K, D, stats););
+    DVQ_CHECK_LAUNCH("vq_ema_stats");
+    return DVQ_OK;
+}
+
+int dvq_vq_ema_apply(const float* stats, const float* restart_rows, float decay, float eps, int64_t K, int64_t D,
+                     float* cluster_size_ema, float* embed_ema, float* weight, float* scratch_sum,
+                     dvq_stream_t stream) {
+    (void)scratch_sum;
+    DVQ_REQUIRE(stats && cluster_size_ema && embed_ema && weight, DVQ_EINVAL, "dvq_vq_ema_apply: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    vq_ema_update_kernel<<<dim3((unsigned)K), dim3(256), 0, s>>>(stats, restart_rows, decay, K, D, cluster_size_ema,
+                                                                embed_ema);
+    DVQ_CHECK_LAUNCH("vq_ema_update");
+    vq_ema_normalize_kernel<<<dim3((unsigned)K), dim3(256), 0, s>>>(cluster_size_ema, embed_ema, eps, K, D, weight);
+    DVQ_CHECK_LAUNCH("vq_ema_normalize");
+    return DVQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,597 @@
+"""Host-side mirror of the DQ-VAE model family on libdvq_hip kernels.
+
+Mirrors (same class names, constructor kwargs, parameter names/shapes, call signatures):
+  * Entropy, DualGrainVQModel      /root/reference/models/stage1_dynamic/dqvae_dual_entropy.py:13-262
+  * DualGrainFixedEntropyRouter    /root/reference/modules/dynamic_modules/RouterDual.py:46-57
+  * DualGrainEncoder               /root/reference/modules/dynamic_modules/EncoderDual.py:16-156
+  * Decoder, PositionEmbedding2DLearned  /root/reference/modules/dynamic_modules/DecoderPositional.py:13-146
+  * FourierPositionEmbedding       /root/reference/modules/dynamic_modules/fourier_embedding.py:7-55
+
+Data layout: images stay NCHW fp32 at the API (the reference's batch format); inside the model every
+activation is NHWC in the runtime compute dtype, 3-channel images are zero-padded to one 16-byte
+channel vector.  The whole autoencoder runs as ONE autograd node (`_AEFn`); its backward is an explicit
+reverse walk over the per-layer tapes.
+"""
+from __future__ import annotations
+
+import json
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from . import runtime as rt
+from .config import instantiate_from_config
+from .layers import (AttnBlock, Conv2d, Downsample, HipModule, Normalize, ResnetBlock, Tape, Upsample, _child,
+                     _grad_buf, to_nchw, to_nhwc)
+
+
+# ---------------------------------------------------------------------------------------------
+class Entropy(nn.Sequential):
+    """dqvae_dual_entropy.py:13-63: per-patch soft-histogram entropy.  forward(x NCHW fp32) -> [B,h,w]."""
+
+    def __init__(self, patch_size, image_width, image_height):
+        super().__init__()
+        self.width, self.height, self.psize = image_width, image_height, patch_size
+        self.patch_num = int(self.width * self.height / self.psize ** 2)
+        self.hw = int(self.width // self.psize)
+
+    def forward(self, inputs):
+        x = inputs.contiguous().float() if inputs.dtype != torch.float32 or not inputs.is_contiguous() else inputs
+        assert x.shape[2] == self.height and x.shape[3] == self.width, (x.shape, self.height, self.width)
+        ent, _ = K.patch_entropy_gate(x, self.psize, None)
+        return ent
+
+
+class DualGrainFixedEntropyRouter(nn.Module):
+    """RouterDual.py:46-57 (incl. the reference's key arithmetic int(100 - r*100) and its spelling)."""
+
+    def __init__(self, json_path, fine_grain_ratito):
+        super().__init__()
+        with open(json_path, "r", encoding="utf-8") as f:
+            content = json.load(f)
+        self.fine_grain_threshold = content["{}".format(str(int(100 - fine_grain_ratito * 100)))]
+
+    def forward(self, h_fine=None, h_coarse=None, entropy=None):
+        """entropy [B,h,w] fp32 -> gate int64 [B,h,w,2] = [coarse, fine]"""
+        t = torch.tensor(self.fine_grain_threshold, dtype=torch.float32, device=entropy.device)
+        fine = entropy > t
+        return torch.stack([~fine, fine], dim=-1).long()
+
+
+class DualGrainFeatureRouter(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("feature-routed (Gumbel) DQ-VAE is SURVEY 8(f)/round-2 scope: "
+                                  "RouterDual.py:6-43 has no HIP path yet")
+
+
+# ---------------------------------------------------------------------------------------------
+class DualGrainEncoder(HipModule):
+    """EncoderDual.py:16-156."""
+
+    def __init__(self, *, ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, router_config=None, update_router=True,
+                 **ignore_kwargs):
+        super().__init__()
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.conv_in = Conv2d(in_channels, ch, 3, 1, 1)
+        curr_res = resolution
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        for i_level in range(self.num_resolutions):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_in, block_out = ch * in_ch_mult[i_level], ch * ch_mult[i_level]
+            for _ in range(num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(AttnBlock(block_in))
+            down = nn.Module()
+            down.block, down.attn = block, attn
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+                curr_res = curr_res // 2
+            self.down.append(down)
+        self.mid_coarse = nn.Module()
+        self.mid_coarse.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.mid_coarse.attn_1 = AttnBlock(block_in)
+        self.mid_coarse.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.norm_out_coarse = Normalize(block_in)
+        self.conv_out_coarse = Conv2d(block_in, z_channels, 3, 1, 1)
+        block_in_fine = block_in // (ch_mult[-1] // ch_mult[-2])
+        self.mid_fine = nn.Module()
+        self.mid_fine.block_1 = ResnetBlock(in_channels=block_in_fine, out_channels=block_in_fine, temb_channels=0, dropout=dropout)
+        self.mid_fine.attn_1 = AttnBlock(block_in_fine)
+        self.mid_fine.block_2 = ResnetBlock(in_channels=block_in_fine, out_channels=block_in_fine, temb_channels=0, dropout=dropout)
+        self.norm_out_fine = Normalize(block_in_fine)
+        self.conv_out_fine = Conv2d(block_in_fine, z_channels, 3, 1, 1)
+        self.router = instantiate_from_config(router_config)
+        self.update_router = update_router
+        if update_router:
+            raise NotImplementedError("update_router=True (Gumbel feature routing) has no HIP path yet (SURVEY 8f)")
+
+    # NHWC core -------------------------------------------------------------------------------------
+    def fwd(self, x_img, grain, tape):
+        """x_img: NCHW fp32 image; grain: int64 [B,h,w] (1 = fine).  Returns (h_dual NHWC, mask [B,2h,2w])."""
+        cd = rt.compute_dtype()
+        x = K.nchw_to_nhwc_pad(x_img, K.vec(cd) * -(-self.in_channels // K.vec(cd)), cd)
+        h = self.conv_in.fwd(x, _child(tape, "conv_in"))
+        h_fine = None
+        for i_level in range(self.num_resolutions):
+            lvl = self.down[i_level]
+            for i_block in range(self.num_res_blocks):
+                h = lvl.block[i_block].fwd(h, _child(tape, f"d{i_level}b{i_block}"))
+                if len(lvl.attn) > 0:
+                    h = lvl.attn[i_block].fwd(h, _child(tape, f"d{i_level}a{i_block}"))
+            if i_level == self.num_resolutions - 2:
+                h_fine = h
+            if i_level != self.num_resolutions - 1:
+                h = lvl.downsample.fwd(h, _child(tape, f"d{i_level}ds"))
+        hc = self.mid_coarse.block_1.fwd(h, _child(tape, "mc1"))
+        hc = self.mid_coarse.attn_1.fwd(hc, _child(tape, "mca"))
+        hc = self.mid_coarse.block_2.fwd(hc, _child(tape, "mc2"))
+        hc = self.norm_out_coarse.fwd(hc, _child(tape, "noc"), silu=True)
+        hc = self.conv_out_coarse.fwd(hc, _child(tape, "coc"))
+        hf = self.mid_fine.block_1.fwd(h_fine, _child(tape, "mf1"))
+        hf = self.mid_fine.attn_1.fwd(hf, _child(tape, "mfa"))
+        hf = self.mid_fine.block_2.fwd(hf, _child(tape, "mf2"))
+        hf = self.norm_out_fine.fwd(hf, _child(tape, "nof"), silu=True)
+        hf = self.conv_out_fine.fwd(hf, _child(tape, "cof"))
+        h_dual, mask = K.dual_merge(hf, hc, grain)
+        if tape is not None:
+            tape.s["grain"] = grain
+        return h_dual, mask
+
+    def bwd(self, g_dual, tape):
+        grain = tape.s["grain"]
+        gf, gc = K.dual_merge_bwd(g_dual, grain)
+        gf = self.conv_out_fine.bwd(gf, tape.child("cof"))
+        gf = self.norm_out_fine.bwd(gf, tape.child("nof"))
+        gf = self.mid_fine.block_2.bwd(gf, tape.child("mf2"))
+        gf = self.mid_fine.attn_1.bwd(gf, tape.child("mfa"))
+        gf = self.mid_fine.block_1.bwd(gf, tape.child("mf1"))
+        gc = self.conv_out_coarse.bwd(gc, tape.child("coc"))
+        gc = self.norm_out_coarse.bwd(gc, tape.child("noc"))
+        gc = self.mid_coarse.block_2.bwd(gc, tape.child("mc2"))
+        gc = self.mid_coarse.attn_1.bwd(gc, tape.child("mca"))
+        g = self.mid_coarse.block_1.bwd(gc, tape.child("mc1"))
+        for i_level in reversed(range(self.num_resolutions)):
+            lvl = self.down[i_level]
+            if i_level != self.num_resolutions - 1:
+                g = lvl.downsample.bwd(g, tape.child(f"d{i_level}ds"))
+            if i_level == self.num_resolutions - 2:
+                g = K.add(g, gf)
+            for i_block in reversed(range(self.num_res_blocks)):
+                if len(lvl.attn) > 0:
+                    g = lvl.attn[i_block].bwd(g, tape.child(f"d{i_level}a{i_block}"))
+                g = lvl.block[i_block].bwd(g, tape.child(f"d{i_level}b{i_block}"))
+        self.conv_in.bwd(g, tape.child("conv_in"), need_dx=False)
+        return None
+
+    # reference signature ---------------------------------------------------------------------------
+    def forward(self, x, x_entropy):
+        assert x.shape[2] == x.shape[3] == self.resolution, "{}, {}, {}".format(x.shape[2], x.shape[3], self.resolution)
+        gate = self.router(h_fine=None, h_coarse=None, entropy=x_entropy)
+        gate = gate.permute(0, 3, 1, 2)
+        indices = gate.argmax(dim=1)
+        h_dual, mask = _EncFn.apply(self, x, indices.contiguous(), *[p for p in self.parameters() if p.requires_grad])
+        return {"h_dual": h_dual, "indices": indices, "codebook_mask": mask, "gate": gate}
+
+
+class _EncFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, grain, *params):
+        ctx.module, ctx.tape, ctx.n = module, Tape(), len(params)
+        with torch.no_grad():
+            h_dual, mask = module.fwd(x.contiguous().float(), grain, ctx.tape)
+            out = to_nchw(K.cast(h_dual, torch.float32))
+        ctx.mark_non_differentiable(mask)
+        return out, mask.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, g, _gm):
+        with torch.no_grad():
+            ctx.module.bwd(to_nhwc(g, rt.compute_dtype()), ctx.tape)
+        return (None, None, None) + (None,) * ctx.n
+
+
+# ---------------------------------------------------------------------------------------------
+def convert_to_coord_format(b, h, w, device="cpu", integer_values=False):
+    if integer_values:
+        x_channel = torch.arange(w, dtype=torch.float, device=device).view(1, 1, 1, -1).repeat(b, 1, w, 1)
+        y_channel = torch.arange(h, dtype=torch.float, device=device).view(1, 1, -1, 1).repeat(b, 1, 1, h)
+    else:
+        x_channel = torch.linspace(-1, 1, w, device=device).view(1, 1, 1, -1).repeat(b, 1, w, 1)
+        y_channel = torch.linspace(-1, 1, h, device=device).view(1, 1, -1, 1).repeat(b, 1, 1, h)
+    return torch.cat((x_channel, y_channel), dim=1)
+
+
+class _ParamConv1x1(nn.Module):
+    """parameter holder with nn.Conv2d names (`weight` [Cout,Cin,1,1], `bias`) for tiny host-side maps"""
+
+    def __init__(self, ch_in, ch_out, bound):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(ch_out, ch_in, 1, 1).uniform_(-bound, bound))
+        b = 1 / math.sqrt(ch_in)
+        self.bias = nn.Parameter(torch.empty(ch_out).uniform_(-b, b))
+
+
+class ConLinear(nn.Module):
+    def __init__(self, ch_in, ch_out, is_first=False, bias=True):
+        super().__init__()
+        self.conv = _ParamConv1x1(ch_in, ch_out, np.sqrt(9 / ch_in) if is_first else np.sqrt(3 / ch_in))
+
+
+class LFF(nn.Module):
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.ffm = ConLinear(2, hidden_size, is_first=True)
+
+
+class FourierPositionEmbedding(nn.Module):
+    """fourier_embedding.py:45-55: x + sin(Conv1x1([x;y] coords)).  The [C,h,w] bias does not depend on
+    the batch, so it is evaluated once per step on the 2xC parameters (1024 x 2 x 256 MACs: host-side
+    torch, not a kernel) and added by dvq_add_bias_bcast; its gradient is a batch reduction
+    (dvq_sum_batch) followed by the same tiny map."""
+
+    def __init__(self, coord_size, hidden_size, integer_values=False):
+        super().__init__()
+        self.coord = convert_to_coord_format(1, coord_size, coord_size, "cpu", integer_values)
+        self.lff = LFF(hidden_size)
+
+    def bias_hwc(self, device):
+        coord = self.coord.to(device)[0]                                     # [2,h,w]
+        w = self.lff.ffm.conv.weight[:, :, 0, 0]                             # [C,2]
+        pre = torch.einsum("ck,khw->hwc", w, coord) + self.lff.ffm.conv.bias
+        return torch.sin(pre), pre, coord
+
+    def accumulate_grad(self, g_hwc, pre, coord):
+        gp = g_hwc * torch.cos(pre)                                           # [h,w,C]
+        _grad_buf(self.lff.ffm.conv.weight).add_(torch.einsum("hwc,khw->ck", gp, coord)[:, :, None, None])
+        _grad_buf(self.lff.ffm.conv.bias).add_(gp.sum(dim=(0, 1)))
+
+
+class PositionEmbedding2DLearned(nn.Module):
+    """DecoderPositional.py:13-39 (trunc-normal init, tools.py:40-57)."""
+
+    def __init__(self, n_row, feats_dim, n_col=None):
+        super().__init__()
+        n_col = n_col if n_col is not None else n_row
+        self.row_embed = nn.Embedding(n_row, feats_dim)
+        self.col_embed = nn.Embedding(n_col, feats_dim)
+        nn.init.trunc_normal_(self.row_embed.weight, mean=0.0, std=1.0, a=-2.0, b=2.0)
+        nn.init.trunc_normal_(self.col_embed.weight, mean=0.0, std=1.0, a=-2.0, b=2.0)
+
+    def bias_hwc(self, h, w):
+        return self.col_embed.weight[:w].unsqueeze(0) + self.row_embed.weight[:h].unsqueeze(1)   # [h,w,C]
+
+    def accumulate_grad(self, g_hwc):
+        h, w, _ = g_hwc.shape
+        _grad_buf(self.col_embed.weight)[:w].add_(g_hwc.sum(dim=0))
+        _grad_buf(self.row_embed.weight)[:h].add_(g_hwc.sum(dim=1))
+
+
+class Decoder(HipModule):
+    """DecoderPositional.py:41-146 (position_type 'fourier+learned', 'fourier', 'learned')."""
+
+    def __init__(self, ch, in_ch, out_ch, ch_mult, num_res_blocks, resolution, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, give_pre_end=False, latent_size=32, window_size=2, position_type="relative"):
+        super().__init__()
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks, self.resolution, self.in_ch, self.ch = num_res_blocks, resolution, in_ch, ch
+        self.temb_ch, self.give_pre_end, self.out_ch = 0, give_pre_end, out_ch
+        if give_pre_end:
+            raise NotImplementedError("give_pre_end=True is unused by the shipped configs")
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        curr_res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, in_ch, curr_res, curr_res)
+        self.conv_in = Conv2d(in_ch, block_in, 3, 1, 1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(AttnBlock(block_in))
+            up = nn.Module()
+            up.block, up.attn = block, attn
+            if i_level != 0:
+                up.upsample = Upsample(block_in, resamp_with_conv)
+                curr_res = curr_res * 2
+            self.up.insert(0, up)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = Conv2d(block_in, out_ch, 3, 1, 1)
+        self.position_type = position_type
+        if position_type == "learned":
+            self.position_bias = PositionEmbedding2DLearned(n_row=latent_size, feats_dim=in_ch)
+        elif position_type == "fourier":
+            self.position_bias = FourierPositionEmbedding(coord_size=latent_size, hidden_size=in_ch)
+        elif position_type == "fourier+learned":
+            self.position_bias_fourier = FourierPositionEmbedding(coord_size=latent_size, hidden_size=in_ch)
+            self.position_bias_learned = PositionEmbedding2DLearned(n_row=latent_size, feats_dim=in_ch)
+        else:
+            raise NotImplementedError()
+
+    def _position_bias(self, h, w, device):
+        four = learned = None
+        ctx = {}
+        if self.position_type in ("fourier", "fourier+learned"):
+            mod = self.position_bias if self.position_type == "fourier" else self.position_bias_fourier
+            four, pre, coord = mod.bias_hwc(device)
+            ctx.update(pre=pre, coord=coord)
+        if self.position_type in ("learned", "fourier+learned"):
+            mod = self.position_bias if self.position_type == "learned" else self.position_bias_learned
+            learned = mod.bias_hwc(h, w)
+        bias = four if learned is None else (learned if four is None else four + learned)
+        return bias.contiguous().float(), ctx
+
+    def fwd(self, z, tape, grain_indices=None):
+        """z NHWC [B,h,w,in_ch] -> rec NHWC [B,H,W,out_ch padded]"""
+        b, hh, ww, _ = z.shape
+        bias, pctx = self._position_bias(hh, ww, z.device)
+        h = K.add_bias_bcast(z, bias)
+        h = self.conv_in.fwd(h, _child(tape, "conv_in"))
+        h = self.mid.block_1.fwd(h, _child(tape, "m1"))
+        h = self.mid.attn_1.fwd(h, _child(tape, "ma"))
+        h = self.mid.block_2.fwd(h, _child(tape, "m2"))
+        for i_level in reversed(range(self.num_resolutions)):
+            lvl = self.up[i_level]
+            for i_block in range(self.num_res_blocks + 1):
+                h = lvl.block[i_block].fwd(h, _child(tape, f"u{i_level}b{i_block}"))
+                if len(lvl.attn) > 0:
+                    h = lvl.attn[i_block].fwd(h, _child(tape, f"u{i_level}a{i_block}"))
+            if i_level != 0:
+                h = lvl.upsample.fwd(h, _child(tape, f"u{i_level}us"))
+        h = self.norm_out.fwd(h, _child(tape, "no"), silu=True)
+        h = self.conv_out.fwd(h, _child(tape, "co"))
+        if tape is not None:
+            tape.s["pctx"] = pctx
+        return h
+
+    def bwd(self, g, tape):
+        g = self.conv_out.bwd(g, tape.child("co"))
+        g = self.norm_out.bwd(g, tape.child("no"))
+        for i_level in range(self.num_resolutions):
+            lvl = self.up[i_level]
+            if i_level != 0:
+                g = lvl.upsample.bwd(g, tape.child(f"u{i_level}us"))
+            for i_block in reversed(range(self.num_res_blocks + 1)):
+                if len(lvl.attn) > 0:
+                    g = lvl.attn[i_block].bwd(g, tape.child(f"u{i_level}a{i_block}"))
+                g = lvl.block[i_block].bwd(g, tape.child(f"u{i_level}b{i_block}"))
+        g = self.mid.block_2.bwd(g, tape.child("m2"))
+        g = self.mid.attn_1.bwd(g, tape.child("ma"))
+        g = self.mid.block_1.bwd(g, tape.child("m1"))
+        g = self.conv_in.bwd(g, tape.child("conv_in"))
+        # position-bias gradients: batch reduction on the GPU, tiny parameter maps on the host side
+        b, hh, ww, c = g.shape
+        gsum = K.sum_batch(g, torch.zeros(hh, ww, c, dtype=torch.float32, device=g.device))
+        pctx = tape.s["pctx"]
+        if self.position_type in ("fourier", "fourier+learned"):
+            mod = self.position_bias if self.position_type == "fourier" else self.position_bias_fourier
+            mod.accumulate_grad(gsum, pctx["pre"], pctx["coord"])
+        if self.position_type in ("learned", "fourier+learned"):
+            mod = self.position_bias if self.position_type == "learned" else self.position_bias_learned
+            mod.accumulate_grad(gsum)
+        return g
+
+    def _fwd_nchw(self, x, tape):
+        y = self.fwd(to_nhwc(x, rt.compute_dtype()), tape)
+        return K.nhwc_pad_to_nchw(y, self.out_ch)
+
+    def _bwd_nchw(self, dy, tape, in_dtype):
+        cd = rt.compute_dtype()
+        g = K.nchw_to_nhwc_pad(dy.contiguous().float(), K.vec(cd) * -(-self.out_ch // K.vec(cd)), cd)
+        dx = self.bwd(g, tape)
+        return to_nchw(K.cast(dx, in_dtype))
+
+    def forward(self, h, grain_indices=None):
+        return super().forward(h)
+
+
+# ---------------------------------------------------------------------------------------------
+class DualGrainVQModel(nn.Module):
+    """dqvae_dual_entropy.py:65-262.  The Lightning surface (training_step / validation_step /
+    configure_optimizers / log / attributes set by train.py) is kept; the trainer is
+    dynamicvectorquantization_amd.trainer (pytorch_lightning is not a dependency)."""
+
+    def __init__(self, encoderconfig, decoderconfig, lossconfig, vqconfig, quant_before_dim, quant_after_dim,
+                 quant_sample_temperature=0., ckpt_path=None, ignore_keys=[], image_key="image", monitor=None,
+                 warmup_epochs=0, loss_with_epoch=True, scheduler_type="linear-warmup_cosine-decay",
+                 entropy_patch_size=16, image_size=256):
+        super().__init__()
+        self.image_key = image_key
+        self.encoder = instantiate_from_config(encoderconfig)
+        self.decoder = instantiate_from_config(decoderconfig)
+        self.loss = instantiate_from_config(lossconfig)
+        self.quantize = instantiate_from_config(vqconfig)
+        self.quant_conv = Conv2d(quant_before_dim, quant_after_dim, 1)
+        self.post_quant_conv = Conv2d(quant_after_dim, quant_before_dim, 1)
+        self.quant_sample_temperature = quant_sample_temperature
+        self.entropy_patch_size, self.image_size = entropy_patch_size, image_size
+        self.entropy_calculation = Entropy(entropy_patch_size, image_size, image_size)
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
+        if monitor is not None:
+            self.monitor = monitor
+        self.warmup_epochs, self.loss_with_epoch, self.scheduler_type = warmup_epochs, loss_with_epoch, scheduler_type
+        # trainer-provided state (train.py:243-267)
+        self.learning_rate, self.min_learning_rate = 0.0, 0.0
+        self.training_steps, self.steps_per_epoch, self.max_epoch = 1, 1, 1
+        self.current_epoch, self.global_step = 0, 0
+        self._logged = {}
+
+    def init_from_ckpt(self, path, ignore_keys=list()):
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        for k in list(sd.keys()):
+            for ik in ignore_keys:
+                if k.startswith(ik):
+                    print("Deleting key {} from state_dict.".format(k))
+                    del sd[k]
+        self.load_state_dict(sd, strict=False)
+        print(f"Restored from {path}")
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        rt.bump_weights_epoch()
+        return out
+
+    # -- fused AE core (NHWC) ---------------------------------------------------------------------
+    def _threshold(self):
+        return self.encoder.router.fine_grain_threshold
+
+    def ae_fwd(self, x, tape):
+        """x NCHW fp32 -> dict(rec NCHW fp32, qloss, codes, grain, gate, entropy)"""
+        ent, gate = K.patch_entropy_gate(x, self.entropy_patch_size, self._threshold())
+        grain = gate[..., 1].contiguous()
+        h_dual, mask = self.encoder.fwd(x, grain, _child(tape, "enc"))
+        h = self.quant_conv.fwd(h_dual, _child(tape, "qc"))
+        xq, qloss, codes = self.quantize.fwd(h, mask, _child(tape, "vq"))
+        z = self.post_quant_conv.fwd(xq, _child(tape, "pqc"))
+        rec_p = self.decoder.fwd(z, _child(tape, "dec"))
+        rec = K.nhwc_pad_to_nchw(rec_p, self.decoder.out_ch)
+        return {"rec": rec, "qloss": qloss, "codes": codes, "grain": grain, "gate": gate.permute(0, 3, 1, 2),
+                "entropy": ent, "quant": xq, "mask": mask}
+
+    def ae_bwd(self, g_rec, g_qloss, tape):
+        cd = rt.compute_dtype()
+        g = K.nchw_to_nhwc_pad(g_rec, K.vec(cd) * -(-self.decoder.out_ch // K.vec(cd)), cd)
+        g = self.decoder.bwd(g, tape.child("dec"))
+        g = self.post_quant_conv.bwd(g, tape.child("pqc"))
+        g = self.quantize.bwd(g, g_qloss, tape.child("vq"))
+        g = self.quant_conv.bwd(g, tape.child("qc"))
+        self.encoder.bwd(g, tape.child("enc"))
+
+    # -- reference API ------------------------------------------------------------------------------
+    def encode(self, x):
+        with torch.no_grad():
+            x_entropy = self.entropy_calculation(x)
+        h_dict = self.encoder(x, x_entropy)
+        h = self.quant_conv(h_dict["h_dual"])
+        quant, emb_loss, info = self.quantize(x=h, temp=self.quant_sample_temperature, codebook_mask=h_dict["codebook_mask"])
+        return quant, emb_loss, info, h_dict["indices"], h_dict["gate"], x_entropy
+
+    def decode(self, quant, grain_indices=None):
+        return self.decoder(self.post_quant_conv(quant), grain_indices)
+
+    def forward(self, input):
+        """-> (dec, diff, grain_indices, gate, x_entropy); one fused autograd node."""
+        x = input.contiguous().float() if input.dtype != torch.float32 or not input.is_contiguous() else input
+        params = [p for p in self.ae_parameters() if p.requires_grad]
+        rec, qloss, grain, gate, ent = _AEFn.apply(self, x, *params)
+        return rec, qloss, grain, gate, ent
+
+    def ae_parameters(self):
+        return (list(self.encoder.parameters()) + list(self.decoder.parameters()) + list(self.quantize.parameters()) +
+                list(self.quant_conv.parameters()) + list(self.post_quant_conv.parameters()))
+
+    def get_input(self, batch, k):
+        x = batch[k]
+        if len(x.shape) == 3:
+            x = x[..., None]
+        if x.size(1) != 3:
+            x = x.permute(0, 3, 1, 2).to(memory_format=torch.contiguous_format).float()
+        return x
+
+    # logging shim (Lightning's self.log / self.log_dict)
+    def log(self, name, value, **kw):
+        self._logged[name] = value
+
+    def log_dict(self, d, **kw):
+        self._logged.update(d)
+
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        x = self.get_input(batch, self.image_key)
+        xrec, qloss, indices, gate, x_entropy = self(x)
+        ratio = indices.sum() / (indices.size(0) * indices.size(1) * indices.size(2))
+        step = self.current_epoch if self.loss_with_epoch else self.global_step
+        if optimizer_idx == 0:
+            aeloss, log_dict_ae = self.loss(qloss, x, xrec, optimizer_idx, step, last_layer=self.get_last_layer(),
+                                            split="train", gate=gate)
+            self.log("train_aeloss", aeloss)
+            self.log("train_fine_ratio", ratio)
+            self.log("train_rec_loss", log_dict_ae.pop("train_rec_loss"))
+            self.log_dict(log_dict_ae)
+            return aeloss
+        if optimizer_idx == 1:
+            discloss, log_dict_disc = self.loss(qloss, x, xrec, optimizer_idx, step, last_layer=self.get_last_layer(),
+                                                split="train")
+            self.log("train_discloss", discloss)
+            self.log_dict(log_dict_disc)
+            return discloss
+
+    def validation_step(self, batch, batch_idx):
+        x = self.get_input(batch, self.image_key)
+        with torch.no_grad():
+            xrec, qloss, indices, gate, x_entropy = self(x)
+            ratio = indices.sum() / (indices.size(0) * indices.size(1) * indices.size(2))
+            self.log("val_fine_ratio", ratio)
+            step = self.current_epoch if self.loss_with_epoch else self.global_step
+            aeloss, log_dict_ae = self.loss(qloss, x, xrec, 0, step, last_layer=self.get_last_layer(), split="val", gate=gate)
+            discloss, log_dict_disc = self.loss(qloss, x, xrec, 1, step, last_layer=self.get_last_layer(), split="val")
+        self.log("val_rec_loss", log_dict_ae.pop("val_rec_loss"))
+        self.log("val_aeloss", aeloss)
+        self.log_dict(log_dict_ae)
+        self.log_dict(log_dict_disc)
+        return self.log_dict
+
+    def configure_optimizers(self):
+        from .trainer import HipAdam, scheduler_linear_warmup, scheduler_linear_warmup_cosine_decay
+        lr = self.learning_rate
+        opt_ae = HipAdam(self.ae_parameters(), lr=lr, betas=(0.5, 0.9))
+        disc = getattr(self.loss, "discriminator", None)
+        opt_disc = HipAdam(list(disc.parameters()), lr=lr, betas=(0.5, 0.9)) if disc is not None else None
+        warmup_steps = self.steps_per_epoch * self.warmup_epochs
+        if self.scheduler_type == "linear-warmup":
+            fn = scheduler_linear_warmup(warmup_steps)
+        elif self.scheduler_type == "linear-warmup_cosine-decay":
+            multipler_min = self.min_learning_rate / self.learning_rate if self.learning_rate else 0.0
+            fn = scheduler_linear_warmup_cosine_decay(warmup_steps, self.training_steps, multipler_min)
+        else:
+            raise NotImplementedError()
+        opts = [opt_ae] + ([opt_disc] if opt_disc is not None else [])
+        scheds = [{"scheduler": torch.optim.lr_scheduler.LambdaLR(o, fn), "interval": "step", "frequency": 1} for o in opts]
+        return opts, scheds
+
+    def get_last_layer(self):
+        return self.decoder.conv_out.weight
+
+    def get_code_emb_with_depth(self, code):
+        return self.quantize.get_codebook_entry(code)
+
+
+class _AEFn(torch.autograd.Function):
+    """The whole autoencoder as one autograd node: forward fills a Tape, backward walks it."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        ctx.model, ctx.n = model, len(params)
+        ctx.tape = Tape() if any(p.requires_grad for p in params) and torch.is_grad_enabled() else None
+        with torch.no_grad():
+            out = model.ae_fwd(x, ctx.tape)
+        model._last = out
+        for k in ("grain", "gate", "entropy"):
+            ctx.mark_non_differentiable(out[k])
+        return out["rec"], out["qloss"], out["grain"], out["gate"], out["entropy"]
+
+    @staticmethod
+    def backward(ctx, g_rec, g_qloss, *_):
+        with torch.no_grad():
+            if g_rec is None:
+                g_rec = torch.zeros_like(ctx.model._last["rec"])
+            if g_qloss is None:
+                g_qloss = torch.zeros((), device=g_rec.device)
+            ctx.model.ae_bwd(g_rec.contiguous().float(), g_qloss, ctx.tape)
+        return (None, None) + (None,) * ctx.n

@@ -1,0 +1,318 @@
+"""Thin tensor-level wrappers over the C ABI (no autograd here).
+
+Every function takes/returns torch tensors living on a HIP device, passes raw device pointers and
+the current stream to libdvq_hip.so and never synchronises.  Activations are NHWC contiguous
+([N,H,W,C]); `dt(t)` maps torch dtypes to DVQ_F32 / DVQ_BF16.  torch is used for memory and streams
+only -- a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+
+
+def dt(t) -> int:
+    d = t if isinstance(t, torch.dtype) else t.dtype
+    if d not in _DT:
+        raise TypeError(f"unsupported dtype {d}; libdvq_hip computes in float32 or bfloat16")
+    return _DT[d]
+
+
+def vec(dtype) -> int:
+    """channel granularity of the MFMA path (elements per 16 bytes)"""
+    return 4 if dtype == torch.float32 else 8
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.DvqError("libdvq_hip kernels need device tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise _lib.DvqError("libdvq_hip kernels need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def lib():
+    return _lib.load()
+
+
+# ---------------------------------------------------------------------------------------------
+# VQ
+# ---------------------------------------------------------------------------------------------
+def vq_prepare(codebook: torch.Tensor) -> torch.Tensor:
+    k, d = codebook.shape
+    prep = torch.empty(lib().dvq_vq_prep_bytes(k, d), dtype=torch.uint8, device=codebook.device)
+    check(lib().dvq_vq_prepare(_p(codebook), k, d, _p(prep), _s()), "dvq_vq_prepare")
+    return prep
+
+
+def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, prep: torch.Tensor | None = None, impl: int = 0,
+              return_flagged: bool = False):
+    """x [N,D] (fp32/bf16), codebook [K,D] fp32 -> idx int64 [N] (exact argmin, lowest index on ties)."""
+    n, d = x.shape
+    k = codebook.shape[0]
+    assert codebook.dtype == torch.float32 and codebook.shape[1] == d
+    if prep is None and impl != 1 and d in (64, 128, 256):
+        prep = vq_prepare(codebook)
+    idx = torch.empty(n, dtype=torch.int64, device=x.device)
+    ws = torch.empty(lib().dvq_vq_argmin_workspace_bytes(n), dtype=torch.uint8, device=x.device)
+    check(lib().dvq_vq_argmin(_p(x), dt(x), _p(codebook), _p(prep), n, k, d, _p(idx), _p(ws), impl, _s()),
+          "dvq_vq_argmin")
+    if return_flagged:
+        return idx, ws[:4].view(torch.int32)
+    return idx
+
+
+def vq_gather_loss(x, codebook, idx, mask=None):
+    n, d = x.shape
+    xq = torch.empty_like(x)
+    loss_sum = torch.zeros(1, dtype=torch.float64, device=x.device)
+    check(lib().dvq_vq_gather_loss(_p(x), dt(x), _p(codebook), _p(idx), _p(mask), n, d, _p(xq), _p(loss_sum), _s()),
+          "dvq_vq_gather_loss")
+    return xq, loss_sum
+
+
+def vq_backward(g_xq, x, codebook, idx, mask, coef_dev):
+    n, d = x.shape
+    dx = torch.empty_like(x)
+    check(lib().dvq_vq_backward(_p(g_xq), _p(x), dt(x), _p(codebook), _p(idx), _p(mask), _p(coef_dev), n, d, _p(dx), _s()),
+          "dvq_vq_backward")
+    return dx
+
+
+def vq_embed(codebook, idx, dtype=torch.float32):
+    d = codebook.shape[1]
+    flat = idx.reshape(-1).contiguous()
+    out = torch.empty(flat.numel(), d, dtype=dtype, device=codebook.device)
+    check(lib().dvq_vq_embed(_p(codebook), _p(flat), flat.numel(), d, dt(dtype), _p(out), _s()), "dvq_vq_embed")
+    return out.reshape(*idx.shape, d)
+
+
+def vq_ema_stats(x, idx, k):
+    n, d = x.shape
+    stats = torch.empty(k, d + 1, dtype=torch.float32, device=x.device)
+    check(lib().dvq_vq_ema_stats(_p(x), dt(x), _p(idx), n, k, d, _p(stats), _s()), "dvq_vq_ema_stats")
+    return stats
+
+
+def vq_ema_apply(stats, restart_rows, decay, eps, cluster_size_ema, embed_ema, weight):
+    k, d = embed_ema.shape
+    check(lib().dvq_vq_ema_apply(_p(stats), _p(restart_rows), decay, eps, k, d, _p(cluster_size_ema), _p(embed_ema),
+                                 _p(weight), None, _s()), "dvq_vq_ema_apply")
+
+
+# ---------------------------------------------------------------------------------------------
+# entropy / gate
+# ---------------------------------------------------------------------------------------------
+def patch_entropy_gate(img: torch.Tensor, patch: int, threshold: float | None):
+    """img NCHW fp32 [B,3,H,W] -> (entropy [B,h,w] fp32, gate int64 [B,h,w,2] or None)"""
+    b, c, h, w = img.shape
+    assert c == 3 and img.dtype == torch.float32
+    ent = torch.empty(b, h // patch, w // patch, dtype=torch.float32, device=img.device)
+    gate = None
+    if threshold is not None:
+        gate = torch.empty(b, h // patch, w // patch, 2, dtype=torch.int64, device=img.device)
+    check(lib().dvq_patch_entropy_gate(_p(img), b, h, w, patch, float(threshold or 0.0), _p(ent), _p(gate), _s()),
+          "dvq_patch_entropy_gate")
+    return ent, gate
+
+
+# ---------------------------------------------------------------------------------------------
+# GroupNorm (+swish)
+# ---------------------------------------------------------------------------------------------
+def gn_forward(x, gamma, beta, groups=32, eps=1e-6, silu=True):
+    """x NHWC [N,H,W,C]; returns (y, mean_rstd [N,G,2] fp32)"""
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    stats = torch.zeros(n, groups, 2, dtype=torch.float64, device=x.device)
+    check(lib().dvq_gn_stats(_p(x), dt(x), n, hw, c, groups, _p(stats), _s()), "dvq_gn_stats")
+    y = torch.empty_like(x)
+    mr = torch.empty(n, groups, 2, dtype=torch.float32, device=x.device)
+    check(lib().dvq_gn_apply(_p(x), dt(x), n, hw, c, groups, eps, _p(stats), _p(gamma), _p(beta), int(silu), _p(y), _p(mr),
+                             _s()), "dvq_gn_apply")
+    return y, mr
+
+
+def gn_backward(x, dy, mean_rstd, gamma, beta, dgamma, dbeta, groups=32, silu=True):
+    """dgamma/dbeta (fp32 [C]) are accumulated into; returns dx"""
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    red = torch.zeros(n, groups, 2, dtype=torch.float64, device=x.device)
+    check(lib().dvq_gn_bwd_reduce(_p(x), _p(dy), dt(x), n, hw, c, groups, _p(mean_rstd), _p(gamma), _p(beta), int(silu),
+                                  _p(red), _p(dgamma), _p(dbeta), _s()), "dvq_gn_bwd_reduce")
+    dx = torch.empty_like(x)
+    check(lib().dvq_gn_bwd_dx(_p(x), _p(dy), dt(x), n, hw, c, groups, _p(mean_rstd), _p(gamma), _p(beta), int(silu),
+                              _p(red), _p(dx), _s()), "dvq_gn_bwd_dx")
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------------------------
+def conv_desc(n, h, w, cin, cout, kh, kw, stride, pad_t, pad_l, oh, ow, upsample, dtype, impl=0) -> ConvDesc:
+    return ConvDesc(n, h, w, cin, oh, ow, cout, kh, kw, stride, pad_t, pad_l, int(upsample), dt(dtype), impl)
+
+
+def pack_weight(master_oihw, cin_p, cout_p, dtype, want_w=True, want_wt=True):
+    cout, cin, kh, kw = master_oihw.shape
+    dev = master_oihw.device
+    w = torch.empty(cout, kh, kw, cin_p, dtype=dtype, device=dev) if want_w else None
+    wt = torch.empty(cin, kh, kw, cout_p, dtype=dtype, device=dev) if want_wt else None
+    check(lib().dvq_pack_weight(_p(master_oihw), cout, cin, kh, kw, cin_p, cout_p, dt(dtype), _p(w), _p(wt), _s()),
+          "dvq_pack_weight")
+    return w, wt
+
+
+def unpack_wgrad(dw, grad_oihw, cin_p):
+    cout, cin, kh, kw = grad_oihw.shape
+    check(lib().dvq_unpack_wgrad(_p(dw), cout, cin, kh, kw, cin_p, _p(grad_oihw), _s()), "dvq_unpack_wgrad")
+
+
+def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None):
+    y = torch.empty(d.N, d.OH, d.OW, d.Cout, dtype=x.dtype, device=x.device)
+    check(lib().dvq_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), _p(y), _s()), "dvq_conv2d_fwd")
+    return y
+
+
+def conv2d_dgrad(d: ConvDesc, dy, wt):
+    sh, sw = (d.H // 2, d.W // 2) if d.upsample else (d.H, d.W)
+    dx = torch.empty(d.N, sh, sw, d.Cin, dtype=dy.dtype, device=dy.device)
+    ws = torch.empty(d.N, d.H, d.W, d.Cin, dtype=dy.dtype, device=dy.device) if d.upsample else None
+    check(lib().dvq_conv2d_dgrad(C.byref(d), _p(dy), _p(wt), _p(dx), _p(ws), _s()), "dvq_conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(d: ConvDesc, x, dy, want_bias=True):
+    dw = torch.zeros(d.Cout, d.KH, d.KW, d.Cin, dtype=torch.float32, device=x.device)
+    db = torch.zeros(d.Cout, dtype=torch.float32, device=x.device) if want_bias else None
+    check(lib().dvq_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _s()), "dvq_conv2d_wgrad")
+    return dw, db
+
+
+def nchw_to_nhwc_pad(img, cp, dtype):
+    b, c, h, w = img.shape
+    out = torch.empty(b, h, w, cp, dtype=dtype, device=img.device)
+    check(lib().dvq_nchw_to_nhwc_pad(_p(img), b, c, h, w, cp, dt(dtype), _p(out), _s()), "dvq_nchw_to_nhwc_pad")
+    return out
+
+
+def nhwc_pad_to_nchw(x, c):
+    b, h, w, cp = x.shape
+    out = torch.empty(b, c, h, w, dtype=torch.float32, device=x.device)
+    check(lib().dvq_nhwc_pad_to_nchw(_p(x), dt(x), b, c, h, w, cp, _p(out), _s()), "dvq_nhwc_pad_to_nchw")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMMs / attention pieces
+# ---------------------------------------------------------------------------------------------
+def gemm_nt(a, b, m, n, k, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, alpha=1.0, bias=None, bias_mode=0, out=None,
+            impl=0):
+    """C[b][m][n] = alpha * sum_k A[b][m][k] B[b][n][k] (+bias).  a, b, out are flat device tensors."""
+    if out is None:
+        out = torch.empty(batch * m * ldc if sc == 0 else batch * sc, dtype=a.dtype, device=a.device)
+    check(lib().dvq_gemm_nt(_p(a), _p(b), _p(out), dt(a), m, n, k, lda, ldb, ldc, batch, sa, sb, sc, alpha, _p(bias),
+                            bias_mode, impl, _s()), "dvq_gemm_nt")
+    return out
+
+
+def gemm_tn(a, b, mred, i, j, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, out=None, impl=0):
+    """C[b][i][j] (fp32) += sum_m A[b][m][i] B[b][m][j]"""
+    if out is None:
+        out = torch.zeros(batch * (sc if sc else i * ldc), dtype=torch.float32, device=a.device)
+    check(lib().dvq_gemm_tn(_p(a), _p(b), _p(out), dt(a), mred, i, j, lda, ldb, ldc, batch, sa, sb, sc, impl, _s()),
+          "dvq_gemm_tn")
+    return out
+
+
+def softmax_rows(s, rows, length, scale):
+    p = torch.empty_like(s)
+    check(lib().dvq_softmax_rows(_p(s), dt(s), rows, length, scale, _p(p), _s()), "dvq_softmax_rows")
+    return p
+
+
+def softmax_rows_bwd(p, dp, rows, length, scale):
+    ds = torch.empty_like(p)
+    check(lib().dvq_softmax_rows_bwd(_p(p), _p(dp), dt(p), rows, length, scale, _p(ds), _s()), "dvq_softmax_rows_bwd")
+    return ds
+
+
+def transpose(x, batch, r, c):
+    out = torch.empty_like(x)
+    check(lib().dvq_transpose(_p(x), dt(x), batch, r, c, _p(out), _s()), "dvq_transpose")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# small ops
+# ---------------------------------------------------------------------------------------------
+def dual_merge(h_fine, h_coarse, grain):
+    b, h, w, c = h_coarse.shape
+    out = torch.empty_like(h_fine)
+    mask = torch.empty(b, 2 * h, 2 * w, dtype=torch.float32, device=h_fine.device)
+    check(lib().dvq_dual_merge(_p(h_fine), _p(h_coarse), _p(grain), dt(h_fine), b, h, w, c, _p(out), _p(mask), _s()),
+          "dvq_dual_merge")
+    return out, mask
+
+
+def dual_merge_bwd(g_dual, grain):
+    b, h2, w2, c = g_dual.shape
+    h, w = h2 // 2, w2 // 2
+    gf = torch.empty_like(g_dual)
+    gc = torch.empty(b, h, w, c, dtype=g_dual.dtype, device=g_dual.device)
+    check(lib().dvq_dual_merge_bwd(_p(g_dual), _p(grain), dt(g_dual), b, h, w, c, _p(gf), _p(gc), _s()),
+          "dvq_dual_merge_bwd")
+    return gf, gc
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    check(lib().dvq_add(_p(a), _p(b), dt(a), a.numel(), _p(y), _s()), "dvq_add")
+    return y
+
+
+def add_bias_bcast(x, bias):
+    batch = x.shape[0]
+    y = torch.empty_like(x)
+    check(lib().dvq_add_bias_bcast(_p(x), _p(bias), dt(x), batch, x.numel() // batch, _p(y), _s()), "dvq_add_bias_bcast")
+    return y
+
+
+def sum_batch(x, out):
+    batch = x.shape[0]
+    check(lib().dvq_sum_batch(_p(x), dt(x), batch, x.numel() // batch, _p(out), _s()), "dvq_sum_batch")
+    return out
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib().dvq_cast(_p(x), dt(x), _p(out), dt(dtype), x.numel(), _s()), "dvq_cast")
+    return out
+
+
+def l1_loss(x, xrec, scale_dev=None, want_grad=False):
+    loss_sum = torch.zeros(1, dtype=torch.float64, device=x.device)
+    g = torch.empty_like(xrec) if want_grad else None
+    check(lib().dvq_l1_loss(_p(x), _p(xrec), x.numel(), _p(loss_sum), _p(scale_dev), _p(g), _s()), "dvq_l1_loss")
+    return loss_sum, g
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+    check(lib().dvq_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, _s()), "dvq_adam")
+
+
+def fill(p, value):
+    check(lib().dvq_fill_f32(_p(p), float(value), p.numel(), _s()), "dvq_fill_f32")

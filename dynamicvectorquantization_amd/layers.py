@@ -1,0 +1,345 @@
+"""Host-side mirror of the reference's CNN building blocks, running on libdvq_hip kernels.
+
+Mirrors /root/reference/modules/diffusionmodules/model.py:29-192 -- same class names, constructor
+arguments, parameter names/shapes (state_dict compatible) and call signatures -- but the compute is
+hand-written HIP: every module has
+
+    fwd(x_nhwc, tape)   -> y_nhwc      (tape=None: inference, nothing saved)
+    bwd(dy_nhwc, tape)  -> dx_nhwc     (accumulates parameter gradients in place into .grad)
+
+on NHWC tensors of the runtime compute dtype, and ``forward()`` keeps the reference's NCHW call
+signature by wrapping fwd/bwd in one ``torch.autograd.Function`` (torch autograd is only the outer
+tape; there is no per-op autograd graph and no ATen math on the path).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from . import runtime as rt
+
+
+class Tape:
+    """Per-forward-call storage of what the backward needs (children keyed by name)."""
+
+    def __init__(self):
+        self.s = {}
+        self.c = {}
+
+    def child(self, name: str) -> "Tape":
+        t = self.c.get(name)
+        if t is None:
+            t = self.c[name] = Tape()
+        return t
+
+
+def _child(tape, name):
+    return None if tape is None else tape.child(name)
+
+
+def to_nhwc(x: torch.Tensor, dtype=None) -> torch.Tensor:
+    """NCHW-shaped tensor (any strides) -> contiguous NHWC view/copy of the compute dtype."""
+    y = x.permute(0, 2, 3, 1)
+    if not y.is_contiguous():
+        y = y.contiguous()          # foreign (non channels_last) input: one layout copy at the boundary
+    if dtype is not None and y.dtype != dtype:
+        y = K.cast(y, dtype)
+    return y
+
+
+def to_nchw(y: torch.Tensor) -> torch.Tensor:
+    """contiguous NHWC -> NCHW-shaped channels_last view (no copy)"""
+    return y.permute(0, 3, 1, 2)
+
+
+def _grad_buf(p: nn.Parameter) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class HipModule(nn.Module):
+    """nn.Module whose forward() is fwd/bwd wrapped in a single autograd node."""
+
+    def forward(self, x, *args, **kwargs):
+        if kwargs.pop("_raw", False):
+            return self.fwd(x, *args, **kwargs)
+        return _ModuleFn.apply(self, x, *[p for p in self.parameters() if p.requires_grad])
+
+    # NCHW <-> NHWC adapters used by the generic autograd wrapper
+    def _fwd_nchw(self, x, tape):
+        return to_nchw(self.fwd(to_nhwc(x, rt.compute_dtype()), tape))
+
+    def _bwd_nchw(self, dy, tape, in_dtype):
+        dx = self.bwd(to_nhwc(dy, rt.compute_dtype()), tape)
+        if dx is None:
+            return None
+        if dx.dtype != in_dtype:
+            dx = K.cast(dx, in_dtype)
+        return to_nchw(dx)
+
+
+class _ModuleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        ctx.module = module
+        ctx.tape = Tape() if torch.is_grad_enabled() or any(p.requires_grad for p in params) else None
+        ctx.in_dtype = x.dtype
+        ctx.n_params = len(params)
+        with torch.no_grad():
+            y = module._fwd_nchw(x, ctx.tape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        with torch.no_grad():
+            dx = ctx.module._bwd_nchw(dy, ctx.tape, ctx.in_dtype)
+        # parameter gradients were accumulated in place into .grad by the kernels
+        return (None, dx) + (None,) * ctx.n_params
+
+
+# ---------------------------------------------------------------------------------------------
+def nonlinearity(x):
+    """swish (model.py:29-31) -- only reachable fused with GroupNorm on the HIP path"""
+    raise NotImplementedError("nonlinearity() is fused into Normalize.fwd(silu=True) on the HIP path")
+
+
+class Normalize(HipModule):
+    """GroupNorm(32, C, eps=1e-6, affine) (model.py:34-35) with optional fused swish."""
+
+    def __init__(self, in_channels, num_groups=32, eps=1e-6):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = num_groups, in_channels, eps
+        self.weight = nn.Parameter(torch.ones(in_channels))
+        self.bias = nn.Parameter(torch.zeros(in_channels))
+        self.fuse_silu = False   # standalone forward(): plain GroupNorm like the reference
+
+    def fwd(self, x, tape, silu=None):
+        silu = self.fuse_silu if silu is None else silu
+        y, mr = K.gn_forward(x, self.weight, self.bias, self.num_groups, self.eps, silu)
+        if tape is not None:
+            tape.s.update(x=x, mr=mr, silu=silu)
+        return y
+
+    def bwd(self, dy, tape):
+        s = tape.s
+        return K.gn_backward(s["x"], dy, s["mr"], self.weight, self.bias, _grad_buf(self.weight), _grad_buf(self.bias),
+                             self.num_groups, s["silu"])
+
+
+class Conv2d(HipModule):
+    """torch.nn.Conv2d-compatible parameters ([Cout,Cin,KH,KW] + bias, same default init) driving the
+    implicit-GEMM kernels.  `asym_pad` reproduces Downsample's F.pad(0,1,0,1); `upsample` reads the
+    input through nearest x2 (Upsample) without materialising it."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, asym_pad=False,
+                 upsample=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.asym_pad, self.upsample = asym_pad, upsample
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+        self._packs = {}
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1 / math.sqrt(self.in_channels * self.kernel_size ** 2)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def _padded(self, dtype):
+        v = K.vec(dtype)
+        return -(-self.in_channels // v) * v, -(-self.out_channels // v) * v
+
+    def packed(self, dtype):
+        ent = self._packs.get(dtype)
+        if ent is None or ent[0] != rt.weights_epoch() or ent[1].device != self.weight.device:
+            cin_p, cout_p = self._padded(dtype)
+            w, wt = K.pack_weight(self.weight.detach(), cin_p, cout_p, dtype)
+            if cout_p != self.out_channels:
+                # output channels are padded too (Cout=3 image head): zero rows / zero bias
+                wp = torch.zeros(cout_p, *w.shape[1:], dtype=dtype, device=w.device)
+                wp[: self.out_channels] = w
+                w = wp
+            bias = None
+            if self.bias is not None:
+                bias = self.bias.detach()
+                if cout_p != self.out_channels:
+                    bias = torch.zeros(cout_p, dtype=torch.float32, device=w.device)
+                    bias[: self.out_channels] = self.bias.detach()
+            ent = (rt.weights_epoch(), w, wt, bias)
+            self._packs[dtype] = ent
+        return ent[1], ent[2], ent[3]
+
+    def _desc(self, x):
+        n, h, w, _ = x.shape
+        if self.upsample:
+            h, w = 2 * h, 2 * w
+        k, s = self.kernel_size, self.stride
+        if self.asym_pad:
+            pt = pl = 0
+            oh, ow = (h + 1 - k) // s + 1, (w + 1 - k) // s + 1
+        else:
+            pt = pl = self.padding
+            oh, ow = (h + 2 * self.padding - k) // s + 1, (w + 2 * self.padding - k) // s + 1
+        cin_p, cout_p = self._padded(x.dtype)
+        assert x.shape[-1] == cin_p, f"expected {cin_p} (padded) input channels, got {x.shape[-1]}"
+        return K.conv_desc(n, h, w, cin_p, cout_p, k, k, s, pt, pl, oh, ow, self.upsample, x.dtype, rt.impl())
+
+    def fwd(self, x, tape, residual=None):
+        w, _, bias = self.packed(x.dtype)
+        d = self._desc(x)
+        y = K.conv2d_fwd(d, x, w, bias, residual)
+        if tape is not None:
+            tape.s.update(x=x, d=d)
+        return y
+
+    def bwd(self, dy, tape, need_dx=True):
+        x, d = tape.s["x"], tape.s["d"]
+        cin_p, cout_p = self._padded(x.dtype)
+        direct_bias = self.bias is not None and cout_p == self.out_channels
+        dw = torch.zeros(d.Cout, d.KH, d.KW, d.Cin, dtype=torch.float32, device=x.device)
+        db = _grad_buf(self.bias) if direct_bias else (
+            torch.zeros(cout_p, dtype=torch.float32, device=x.device) if self.bias is not None else None)
+        K.check(K.lib().dvq_conv2d_wgrad(K.C.byref(d), K._p(x), K._p(dy), K._p(dw), K._p(db), K._s()), "dvq_conv2d_wgrad")
+        K.unpack_wgrad(dw, _grad_buf(self.weight), cin_p)
+        if self.bias is not None and not direct_bias:
+            _grad_buf(self.bias).add_(db[: self.out_channels])
+        if not need_dx:
+            return None
+        _, wt, _ = self.packed(x.dtype)
+        return K.conv2d_dgrad(d, dy, wt)
+
+
+class Upsample(HipModule):
+    """nearest x2 + 3x3 conv (model.py:38-53); the upsampled tensor is never materialised."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("Upsample(with_conv=False) is not on the shipped configs' path")
+        self.with_conv = with_conv
+        self.conv = Conv2d(in_channels, in_channels, 3, stride=1, padding=1, upsample=True)
+
+    def fwd(self, x, tape):
+        return self.conv.fwd(x, _child(tape, "conv"))
+
+    def bwd(self, dy, tape):
+        return self.conv.bwd(dy, tape.child("conv"))
+
+
+class Downsample(HipModule):
+    """pad (0,1,0,1) + 3x3 stride-2 conv (model.py:56-75); the padding is folded into the gather."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("Downsample(with_conv=False) is not on the shipped configs' path")
+        self.with_conv = with_conv
+        self.conv = Conv2d(in_channels, in_channels, 3, stride=2, padding=0, asym_pad=True)
+
+    def fwd(self, x, tape):
+        return self.conv.fwd(x, _child(tape, "conv"))
+
+    def bwd(self, dy, tape):
+        return self.conv.bwd(dy, tape.child("conv"))
+
+
+class ResnetBlock(HipModule):
+    """GN-swish-conv3x3-GN-swish-conv3x3 + (1x1) shortcut (model.py:78-137); temb is always None."""
+
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=512):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        if conv_shortcut:
+            raise NotImplementedError("conv_shortcut=True is unused by the shipped configs")
+        if temb_channels > 0:
+            raise NotImplementedError("temb_channels > 0 is unused by the DQ-VAE (temb is None)")
+        if dropout != 0.0:
+            raise NotImplementedError("dropout != 0 is unused by the shipped configs")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.use_conv_shortcut = conv_shortcut
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = Conv2d(in_channels, out_channels, 3, 1, 1)
+        self.norm2 = Normalize(out_channels)
+        self.conv2 = Conv2d(out_channels, out_channels, 3, 1, 1)
+        if in_channels != out_channels:
+            self.nin_shortcut = Conv2d(in_channels, out_channels, 1, 1, 0)
+
+    def forward(self, x, temb=None, **kw):
+        assert temb is None
+        return super().forward(x, **kw)
+
+    def fwd(self, x, tape, temb=None):
+        a1 = self.norm1.fwd(x, _child(tape, "norm1"), silu=True)
+        h1 = self.conv1.fwd(a1, _child(tape, "conv1"))
+        a2 = self.norm2.fwd(h1, _child(tape, "norm2"), silu=True)
+        sc = self.nin_shortcut.fwd(x, _child(tape, "nin")) if self.in_channels != self.out_channels else x
+        return self.conv2.fwd(a2, _child(tape, "conv2"), residual=sc)
+
+    def bwd(self, dy, tape):
+        d = self.conv2.bwd(dy, tape.child("conv2"))
+        d = self.norm2.bwd(d, tape.child("norm2"))
+        d = self.conv1.bwd(d, tape.child("conv1"))
+        d = self.norm1.bwd(d, tape.child("norm1"))
+        sc = self.nin_shortcut.bwd(dy, tape.child("nin")) if self.in_channels != self.out_channels else dy
+        return K.add(d, sc)
+
+
+class AttnBlock(HipModule):
+    """single-head spatial self-attention with 1x1-conv q/k/v/proj (model.py:140-192)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = Conv2d(in_channels, in_channels, 1)
+        self.k = Conv2d(in_channels, in_channels, 1)
+        self.v = Conv2d(in_channels, in_channels, 1)
+        self.proj_out = Conv2d(in_channels, in_channels, 1)
+
+    def fwd(self, x, tape):
+        b, h, w, c = x.shape
+        n = h * w
+        hn = self.norm.fwd(x, _child(tape, "norm"), silu=False)
+        q = self.q.fwd(hn, _child(tape, "q"))
+        k = self.k.fwd(hn, _child(tape, "k"))
+        v = self.v.fwd(hn, _child(tape, "v"))
+        impl = rt.impl()
+        s = K.gemm_nt(q, k, n, n, c, c, c, n, batch=b, sa=n * c, sb=n * c, sc=n * n, impl=impl)       # q k^T
+        p = K.softmax_rows(s, b * n, n, float(int(c) ** (-0.5)))
+        vt = K.transpose(v, b, n, c)                                                                    # [b,c,n]
+        o = K.gemm_nt(p, vt, n, c, n, n, n, c, batch=b, sa=n * n, sb=c * n, sc=n * c, impl=impl)       # p v
+        o = o.view(b, h, w, c)
+        y = self.proj_out.fwd(o, _child(tape, "proj"), residual=x)
+        if tape is not None:
+            tape.s.update(q=q, k=k, v=v, p=p, shape=(b, h, w, c))
+        return y
+
+    def bwd(self, dy, tape):
+        st = tape.s
+        b, h, w, c = st["shape"]
+        n = h * w
+        q, k, v, p = st["q"], st["k"], st["v"], st["p"]
+        impl = rt.impl()
+        do = self.proj_out.bwd(dy, tape.child("proj"))
+        dp = K.gemm_nt(do, v, n, n, c, c, c, n, batch=b, sa=n * c, sb=n * c, sc=n * n, impl=impl)      # dO v^T
+        dv32 = K.gemm_tn(p, do, n, n, c, n, c, c, batch=b, sa=n * n, sb=n * c, sc=n * c, impl=impl)    # p^T dO
+        ds = K.softmax_rows_bwd(p, dp, b * n, n, float(int(c) ** (-0.5)))
+        kt = K.transpose(k, b, n, c)
+        dq = K.gemm_nt(ds, kt, n, c, n, n, n, c, batch=b, sa=n * n, sb=c * n, sc=n * c, impl=impl)     # dS k
+        dk32 = K.gemm_tn(ds, q, n, n, c, n, c, c, batch=b, sa=n * n, sb=n * c, sc=n * c, impl=impl)    # dS^T q
+        dt_ = q.dtype
+        dq = dq.view(b, h, w, c)
+        dk = K.cast(dk32.view(b, h, w, c), dt_)
+        dv = K.cast(dv32.view(b, h, w, c), dt_)
+        dh = self.q.bwd(dq, tape.child("q"))
+        dh = K.add(dh, self.k.bwd(dk, tape.child("k")))
+        dh = K.add(dh, self.v.bwd(dv, tape.child("v")))
+        dx = self.norm.bwd(dh, tape.child("norm"))
+        return K.add(dx, dy)

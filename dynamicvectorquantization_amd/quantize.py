@@ -1,0 +1,194 @@
+"""Host-side mirror of /root/reference/modules/vector_quantization/quantize2_mask.py
+(VQEmbedding :10-132, VectorQuantize2 :135-210) on the libdvq_hip VQ kernels.
+
+Same constructor kwargs, buffers (`cluster_size_ema`, `embed_ema`), parameter (`weight` [K+1, D], row K =
+padding row, requires_grad False under EMA) and return signatures.  Differences that matter:
+  * the [N,K] distance matrix and the [K,N] one-hot matrix are never formed;
+  * the argmin is the mathematically exact one (oracle/vq.py), lowest index on ties;
+  * the two data-parallel all-reduces (:86-88) are ONE all-reduce of a fused [K, D+1] buffer, and the
+    restart broadcast (:99-100) is kept (rank 0's rows) -- see SURVEY.md section 5/8e;
+  * RNG: the restart candidate rows come from torch.randperm on the device generator unless
+    `restart_perm` is injected (tests), since the reference's CPU/CUDA streams cannot be reproduced.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import kernels as K
+from . import runtime as rt
+from .layers import Tape, to_nchw, to_nhwc
+
+
+class VQEmbedding(nn.Embedding):
+    """VQ embedding module with EMA update (quantize2_mask.py:10-132)."""
+
+    def __init__(self, n_embed, embed_dim, ema=True, decay=0.99, restart_unused_codes=True, eps=1e-5):
+        super().__init__(n_embed + 1, embed_dim, padding_idx=n_embed)
+        self.ema, self.decay, self.eps = ema, decay, eps
+        self.restart_unused_codes = restart_unused_codes
+        self.n_embed = n_embed
+        if self.ema:
+            for p in self.parameters():
+                p.requires_grad_(False)
+            self.register_buffer("cluster_size_ema", torch.zeros(n_embed))
+            self.register_buffer("embed_ema", self.weight[:-1, :].detach().clone())
+        self._prep = None          # (version, prep buffer)
+        self._cb_version = 0       # bumped by every in-place codebook rewrite (EMA); conv packs are unaffected
+        self.restart_perm = None   # optional injected permutation (tests)
+        self.last_flagged = None   # device int32 scalar: rows re-ranked in fp64 by the last search
+
+    # -- search -------------------------------------------------------------------------------------
+    def _codebook(self):
+        return self.weight.detach()[:-1]    # contiguous leading rows
+
+    def _prepared(self):
+        ent = self._prep
+        ver = (self._cb_version, rt.weights_epoch())
+        if ent is None or ent[0] != ver or ent[1].device != self.weight.device:
+            ent = (ver, K.vq_prepare(self._codebook()))
+            self._prep = ent
+        return ent[1]
+
+    @torch.no_grad()
+    def compute_distances(self, inputs):
+        raise NotImplementedError(
+            "the HIP path never materialises the [N,K] distance matrix (quantize2_mask.py:29-48); "
+            "use find_nearest_embedding / get_soft_codes on the reference for analysis code")
+
+    @torch.no_grad()
+    def find_nearest_embedding(self, inputs):
+        """inputs [..., D] -> int64 [...] exact nearest code (quantize2_mask.py:50-55)."""
+        d = inputs.shape[-1]
+        flat = inputs.reshape(-1, d)
+        if not flat.is_contiguous():
+            flat = flat.contiguous()
+        cb = self._codebook()
+        prep = self._prepared() if d in (64, 128, 256) else None
+        idx, flagged = K.vq_argmin(flat, cb, prep, impl=rt.impl(), return_flagged=True)
+        self.last_flagged = flagged
+        return idx.reshape(inputs.shape[:-1])
+
+    # -- EMA ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _update_buffers(self, vectors, idxs):
+        """quantize2_mask.py:66-105.  vectors [N,D] (compute dtype), idxs [N]."""
+        k, d = self.n_embed, self.weight.shape[-1]
+        vectors = vectors.reshape(-1, d)
+        idxs = idxs.reshape(-1)
+        stats = K.vq_ema_stats(vectors, idxs, k)                      # [K, D+1] = (sums | count)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)              # ONE fused collective
+        restart = None
+        if self.restart_unused_codes:
+            n = vectors.shape[0]
+            if n < k:
+                raise NotImplementedError("restart with fewer input rows than codes (_tile_with_noise, "
+                                          "quantize2_mask.py:57-64) is not on the benchmark path")
+            if self.restart_perm is not None:
+                perm = self.restart_perm.to(vectors.device)[:k]
+            else:
+                perm = torch.randperm(n, device=vectors.device)[:k]
+            restart = K.vq_embed(K.cast(vectors, torch.float32), perm)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.broadcast(restart, 0)
+        K.vq_ema_apply(stats, restart, self.decay, self.eps, self.cluster_size_ema, self.embed_ema, self.weight.data)
+        self._cb_version += 1
+
+    def forward(self, inputs):
+        """inputs [B, N, D] -> (embeds, idx) with the reference's ordering (quantize2_mask.py:117-128):
+        search, EMA buffer update, gather with the OLD weight, then rewrite the weight."""
+        idx = self.find_nearest_embedding(inputs)
+        embeds = self.embed(idx)
+        if self.training and self.ema:
+            self._update_buffers(inputs, idx)
+        return embeds, idx
+
+    def embed(self, idxs):
+        return K.vq_embed(self.weight.detach(), idxs.contiguous(), torch.float32)
+
+
+class VectorQuantize2(nn.Module):
+    """quantize2_mask.py:135-210."""
+
+    def __init__(self, codebook_size, codebook_dim=None, accept_image_fmap=True, commitment_beta=0.25, decay=0.99,
+                 restart_unused_codes=True, channel_last=False):
+        super().__init__()
+        self.accept_image_fmap = accept_image_fmap
+        self.beta = commitment_beta
+        self.channel_last = channel_last
+        self.restart_unused_codes = restart_unused_codes
+        self.codebook = VQEmbedding(codebook_size, codebook_dim, decay=decay, restart_unused_codes=restart_unused_codes)
+        self.codebook.weight.data.uniform_(-1.0 / codebook_size, 1.0 / codebook_size)
+        if not accept_image_fmap:
+            raise NotImplementedError("only accept_image_fmap=True is on the shipped configs' path")
+
+    # -- NHWC core used by the model -----------------------------------------------------------------
+    def fwd(self, h, mask, tape):
+        """h NHWC [B,H,W,D] (compute dtype), mask fp32 [B,H,W] or None ->
+        (x_q NHWC, loss fp32 scalar tensor, idx int64 [B,H,W])"""
+        b, hh, ww, d = h.shape
+        flat = h.view(-1, d)
+        cbk = self.codebook
+        idx = cbk.find_nearest_embedding(flat)
+        mflat = None if mask is None else mask.reshape(-1)
+        # gather with the OLD weight before the EMA rewrite (quantize2_mask.py:123-126)
+        xq, loss_sum = K.vq_gather_loss(flat, cbk._codebook(), idx, mflat)
+        if cbk.training and cbk.ema:
+            if tape is not None:
+                tape.s["cb_old"] = cbk._codebook().clone()
+            cbk._update_buffers(flat, idx)
+        n_el = flat.numel()
+        loss = (loss_sum * ((1.0 + self.beta) / n_el)).to(torch.float32).reshape(())
+        if tape is not None:
+            tape.s.update(h=flat, idx=idx, mask=mflat, n_el=n_el)
+            tape.s.setdefault("cb_old", cbk._codebook())
+        return xq.view(b, hh, ww, d), loss, idx.view(b, hh, ww)
+
+    def bwd(self, g_xq, g_loss, tape):
+        """g_xq NHWC grad of x_q, g_loss device scalar (grad of the loss) -> grad of h (NHWC)"""
+        s = tape.s
+        d = s["h"].shape[1]
+        coef = (g_loss.to(torch.float32) * (2.0 * self.beta / s["n_el"])).reshape(1).contiguous()
+        dx = K.vq_backward(g_xq.reshape(-1, d), s["h"], s["cb_old"], s["idx"], s["mask"], coef)
+        return dx.view(g_xq.shape)
+
+    # -- reference signature ---------------------------------------------------------------------------
+    def forward(self, x, codebook_mask=None, *ignorewargs, **ignorekwargs):
+        """x [B,D,H,W] -> (x_q [B,D,H,W], loss, (None, None, idx [B,H,W]))  (quantize2_mask.py:157-191)"""
+        mask = None
+        if codebook_mask is not None:
+            mask = codebook_mask.reshape(codebook_mask.shape[0], *codebook_mask.shape[-2:]).to(torch.float32).contiguous()
+        xq, loss, idx = _VQFn.apply(self, x, mask)
+        return xq, loss, (None, None, idx)
+
+    @torch.no_grad()
+    def get_soft_codes(self, x, temp=1.0, stochastic=False):
+        raise NotImplementedError("get_soft_codes materialises the [N,K] matrix; not on the HIP path")
+
+    def get_codebook_entry(self, indices, *kwargs):
+        return self.codebook.embed(indices)   # (batch, height, width, channel)
+
+
+class _VQFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, mask):
+        ctx.module, ctx.in_dtype = module, x.dtype
+        ctx.tape = Tape()
+        with torch.no_grad():
+            h = to_nhwc(x, rt.compute_dtype())
+            xq, loss, idx = module.fwd(h, mask, ctx.tape)
+            xq = to_nchw(K.cast(xq, x.dtype))
+        ctx.mark_non_differentiable(idx)
+        return xq, loss, idx
+
+    @staticmethod
+    def backward(ctx, g_xq, g_loss, _g_idx):
+        with torch.no_grad():
+            if g_loss is None:
+                g_loss = torch.zeros((), device=g_xq.device)
+            dx = ctx.module.bwd(to_nhwc(g_xq, rt.compute_dtype()), g_loss, ctx.tape)
+            dx = to_nchw(K.cast(dx, ctx.in_dtype))
+        return None, dx, None

@@ -1,0 +1,65 @@
+"""Process-wide runtime state of the HIP path: compute dtype, packed-weight epoch, kernel selection."""
+from __future__ import annotations
+
+import contextlib
+
+import torch
+
+# activations / packed weights are computed in this dtype ("fp32" = parity mode, "bf16" = perf mode)
+_compute_dtype = torch.float32
+# bumped whenever parameters change in place (optimizer step, load_state_dict): invalidates packed weights
+_weights_epoch = 0
+# 0 auto, 1 force naive kernels, 2 force MFMA kernels (tests use 1 vs 2 to cross-check on the GPU)
+_impl = 0
+
+
+def compute_dtype() -> torch.dtype:
+    return _compute_dtype
+
+
+def set_compute_dtype(dtype):
+    global _compute_dtype
+    if isinstance(dtype, str):
+        dtype = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
+                 "bfloat16": torch.bfloat16}[dtype]
+    assert dtype in (torch.float32, torch.bfloat16)
+    _compute_dtype = dtype
+
+
+@contextlib.contextmanager
+def compute_dtype_ctx(dtype):
+    old = _compute_dtype
+    set_compute_dtype(dtype)
+    try:
+        yield
+    finally:
+        set_compute_dtype(old)
+
+
+def weights_epoch() -> int:
+    return _weights_epoch
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def impl() -> int:
+    return _impl
+
+
+def set_impl(v: int):
+    global _impl
+    assert v in (0, 1, 2)
+    _impl = v
+
+
+@contextlib.contextmanager
+def impl_ctx(v: int):
+    old = _impl
+    set_impl(v)
+    try:
+        yield
+    finally:
+        set_impl(old)

@@ -1,0 +1,209 @@
+/*
+ * dvq_hip.h -- C ABI of libdvq_hip.so: the MI355X (gfx950) kernels of the DQ-VAE hot path.
+ *
+ * The reference (CrossmodalGroup/DynamicVectorQuantization) has no FFI of its own: its operator
+ * boundary is the Python `target:`/`params:` plugin API (utils/utils.py:41-51) and every kernel is an
+ * ATen call.  This header is the boundary a maintainer binds with ctypes from those Python modules
+ * (see INTEGRATION.md); each entry point cites the reference call site it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (incl. workspaces); the library allocates
+ *     nothing, keeps no mutable global state, launches only on `stream`, never synchronises;
+ *   - activations are NHWC ("pixel-major"): element (n,h,w,c) at ((n*H+h)*W+w)*C+c;
+ *   - conv weights are OHWI: element (co,kh,kw,ci) at ((co*KH+kh)*KW+kw)*Cin+ci
+ *     (= torch.channels_last storage of the reference's [Cout,Cin,KH,KW] parameter);
+ *   - `dtype` is DVQ_F32 or DVQ_BF16 and applies to activations and packed weights; statistics,
+ *     losses, optimizer state and codebooks are always fp32;
+ *   - return value 0 on success, negative DVQ_E* otherwise; dvq_last_error() gives a thread-local
+ *     message.  Nothing is thrown across the boundary.
+ */
+#ifndef DVQ_HIP_H
+#define DVQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dvq_stream_t; /* hipStream_t */
+
+enum { DVQ_F32 = 0, DVQ_BF16 = 1 };
+enum { DVQ_OK = 0, DVQ_EINVAL = -1, DVQ_ESHAPE = -2, DVQ_EARCH = -3, DVQ_ELAUNCH = -4, DVQ_EWORKSPACE = -5 };
+
+const char* dvq_last_error(void);
+int dvq_version(void);
+/* 0 if the current HIP device is gfx950, DVQ_EARCH otherwise */
+int dvq_check_device(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Vector quantisation.  Replaces VQEmbedding.compute_distances + argmin
+ * (modules/vector_quantization/quantize2_mask.py:29-55): exact argmin_k |x_n - e_k|^2, lowest k on
+ * ties, without materialising the [N,K] distance matrix.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Codebook preparation (once per codebook version): splits e into two bf16 planes, row norms, max
+ * norm.  prep must hold dvq_vq_prep_bytes(K,D) bytes. */
+size_t dvq_vq_prep_bytes(int64_t K, int64_t D);
+int dvq_vq_prepare(const float* codebook, int64_t K, int64_t D, void* prep, dvq_stream_t stream);
+
+/* idx[n] = argmin_k |x[n,:] - codebook[k,:]|^2.  x is [N,D] (row stride D) of `x_dtype`.
+ * ws: dvq_vq_argmin_workspace_bytes(N) bytes.  impl: 0 = auto, 1 = force generic VALU kernel,
+ * 2 = force MFMA kernel (DVQ_ESHAPE if unsupported). */
+size_t dvq_vq_argmin_workspace_bytes(int64_t N);
+int dvq_vq_argmin(const void* x, int x_dtype, const float* codebook, const void* prep, int64_t N, int64_t K,
+                  int64_t D, int64_t* idx, void* ws, int impl, dvq_stream_t stream);
+/* Diagnostic: after the call, the first int32 of `ws` holds the number of rows that took the fp64
+ * re-rank path. */
+
+/* x_q[n,:] = x[n,:] + (e[idx[n],:] - x[n,:])  (straight-through forward value, quantize2_mask.py:182)
+ * and loss_sum[0] += sum_n mask[n] * |e[idx[n]] - x[n]|^2   (fp64 accumulator; :172-180).
+ * mask may be NULL (all ones).  x, x_q: `dtype`; mask fp32 [N]. */
+int dvq_vq_gather_loss(const void* x, int dtype, const float* codebook, const int64_t* idx, const float* mask,
+                       int64_t N, int64_t D, void* x_q, double* loss_sum, dvq_stream_t stream);
+/* VQ backward: dx = g_xq + coef * mask[n] * (x - e[idx[n]]),
+ * coef = 2*beta*g_loss/(N*D) read from coef_dev[0] (device scalar). */
+int dvq_vq_backward(const void* g_xq, const void* x, int dtype, const float* codebook, const int64_t* idx,
+                    const float* mask, const float* coef_dev, int64_t N, int64_t D, void* dx, dvq_stream_t stream);
+/* codebook gather: out[n,:] = codebook[idx[n],:]  (VQEmbedding.embed, quantize2_mask.py:130-132) */
+int dvq_vq_embed(const float* codebook, const int64_t* idx, int64_t N, int64_t D, int out_dtype, void* out,
+                 dvq_stream_t stream);
+
+/* EMA statistics (quantize2_mask.py:66-84): stats[k*(D+1)+d] += sum of x rows assigned to k,
+ * stats[k*(D+1)+D] += count.  stats is a zeroed fp32 [K,D+1] buffer (one fused buffer so the
+ * data-parallel exchange is ONE all-reduce). */
+int dvq_vq_ema_stats(const void* x, int dtype, const int64_t* idx, int64_t N, int64_t K, int64_t D, float* stats,
+                     dvq_stream_t stream);
+/* EMA apply + dead-code restart + Laplace-smoothed normalisation (quantize2_mask.py:89-115).
+ * restart_rows: [K,D] fp32 candidate rows or NULL (restart disabled). weight: [K+1,D] (row K untouched). */
+int dvq_vq_ema_apply(const float* stats, const float* restart_rows, float decay, float eps, int64_t K, int64_t D,
+                     float* cluster_size_ema, float* embed_ema, float* weight, float* scratch_sum,
+                     dvq_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Patch entropy + fixed-entropy gate.  Replaces Entropy.forward
+ * (models/stage1_dynamic/dqvae_dual_entropy.py:25-63) and DualGrainFixedEntropyRouter.forward
+ * (modules/dynamic_modules/RouterDual.py:53-57).  img: NCHW fp32 [B,3,H,W]; entropy: [B,H/p,W/p] fp32;
+ * gate (may be NULL): int64 [B,H/p,W/p,2] = [H<=t, H>t].
+ * ---------------------------------------------------------------------------------------------- */
+int dvq_patch_entropy_gate(const float* img, int64_t B, int64_t H, int64_t W, int patch, float threshold,
+                           float* entropy, int64_t* gate, dvq_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm(32, eps) + swish.  Replaces Normalize + nonlinearity
+ * (modules/diffusionmodules/model.py:29-35).  x,y: NHWC [N,HW,C] of `dtype`.
+ * stats: fp64 [N,G,2] zeroed by the caller before dvq_gn_stats (sum, sum of squares).
+ * ---------------------------------------------------------------------------------------------- */
+int dvq_gn_stats(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int G, double* stats,
+                 dvq_stream_t stream);
+/* y = act(gn(x)); act = swish if silu != 0.  mean_rstd (fp32 [N,G,2]) is written for the backward. */
+int dvq_gn_apply(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int G, float eps, const double* stats,
+                 const float* gamma, const float* beta, int silu, void* y, float* mean_rstd, dvq_stream_t stream);
+/* backward pass 1: red fp64 [N,G,2] (zeroed) += (sum dz*gamma, sum dz*gamma*xhat); dgamma/dbeta fp32 [C] += .
+ * backward pass 2: dx.  dy: grad w.r.t. y. */
+int dvq_gn_bwd_reduce(const void* x, const void* dy, int dtype, int64_t N, int64_t HW, int64_t C, int G,
+                      const float* mean_rstd, const float* gamma, const float* beta, int silu, double* red,
+                      float* dgamma, float* dbeta, dvq_stream_t stream);
+int dvq_gn_bwd_dx(const void* x, const void* dy, int dtype, int64_t N, int64_t HW, int64_t C, int G,
+                  const float* mean_rstd, const float* gamma, const float* beta, int silu, const double* red,
+                  void* dx, dvq_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA.  Replaces torch.nn.Conv2d call sites of ResnetBlock /
+ * Upsample / Downsample / AttnBlock 1x1 / quant_conv (modules/diffusionmodules/model.py:38-192,
+ * models/stage1_dynamic/dqvae_dual_entropy.py:93-94).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dvq_conv_desc {
+    int64_t N;        /* batch */
+    int64_t H, W;     /* LOGICAL input height/width (after the optional nearest x2 upsample) */
+    int64_t Cin;
+    int64_t OH, OW;   /* output height/width */
+    int64_t Cout;
+    int32_t KH, KW;
+    int32_t stride;
+    int32_t pad_t, pad_l; /* zero padding top/left; bottom/right padding is implied by OH/OW */
+    int32_t upsample; /* 1: the stored input is [N,H/2,W/2,Cin] and is read through nearest x2 (model.py:50) */
+    int32_t dtype;    /* DVQ_F32 / DVQ_BF16: activations and packed weights */
+    int32_t impl;     /* 0 auto, 1 naive direct kernel, 2 MFMA implicit GEMM (DVQ_ESHAPE if unsupported) */
+} dvq_conv_desc;
+
+/* y[n,oh,ow,co] = bias[co] + sum x[n,oh*s-pt+kh, ow*s-pl+kw, ci] * w[co,kh,kw,ci] (+ residual).
+ * w: packed [Cout][KH][KW][Cin] of `dtype` (Cin here is the padded count); bias fp32 [Cout] or NULL;
+ * residual NHWC like y or NULL. */
+int dvq_conv2d_fwd(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                   void* y, dvq_stream_t stream);
+/* dx (stored-input shape, i.e. [N,H/2,W/2,Cin] when upsample) from dy [N,OH,OW,Cout].
+ * wt: weights in IHWO layout [Cin,KH,KW,Cout] of `dtype` (dvq_pack_weight_t).  When upsample is set,
+ * ws must hold N*H*W*Cin elements of `dtype` (gradient at the upsampled resolution). */
+int dvq_conv2d_dgrad(const dvq_conv_desc* d, const void* dy, const void* wt, void* dx, void* ws,
+                     dvq_stream_t stream);
+/* dw (fp32 OHWI, ACCUMULATED into -- zero it first) and dbias (fp32 [Cout], accumulated; may be NULL). */
+int dvq_conv2d_wgrad(const dvq_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                     dvq_stream_t stream);
+
+/* weight packing: master fp32 OIHW (the reference's nn.Conv2d parameter layout) -> `dtype`
+ * w [Cout][KH][KW][Cin_p] (forward / wgrad layout) and wt [Cin][KH][KW][Cout_p] (dgrad layout), zero padded
+ * to Cin_p / Cout_p channels (multiples of 8 for bf16, 4 for fp32); either output may be NULL. */
+int dvq_pack_weight(const float* master, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW, int64_t Cin_p,
+                    int64_t Cout_p, int dtype, void* w, void* wt, dvq_stream_t stream);
+/* grad_oihw[co][ci][kh][kw] += dw[co][kh][kw][ci]   (dw: the fp32 [Cout][KH][KW][Cin_p] output of wgrad) */
+int dvq_unpack_wgrad(const float* dw, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW, int64_t Cin_p, float* grad,
+                     dvq_stream_t stream);
+/* image layout: NCHW fp32 [B,C,H,W] <-> NHWC `dtype` [B,H,W,Cp] (channels zero-padded to Cp) */
+int dvq_nchw_to_nhwc_pad(const float* in, int64_t B, int64_t C, int64_t H, int64_t W, int64_t Cp, int dtype, void* out,
+                         dvq_stream_t stream);
+int dvq_nhwc_pad_to_nchw(const void* in, int dtype, int64_t B, int64_t C, int64_t H, int64_t W, int64_t Cp, float* out,
+                         dvq_stream_t stream);
+
+/* Generic batched GEMM on the same kernels.
+ * NT:  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k] (+ bias) ; bias_mode 0 none, 1 per-n, 2 per-m.
+ * TN:  C[b][i][j] (fp32, accumulated) += sum_m A[b][m][i] * B[b][m][j].
+ * Strides in elements. */
+int dvq_gemm_nt(const void* A, const void* B, void* C, int dtype, int64_t M, int64_t N, int64_t K, int64_t lda,
+                int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, float alpha,
+                const float* bias, int bias_mode, int impl, dvq_stream_t stream);
+int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred, int64_t I, int64_t J, int64_t lda,
+                int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int impl,
+                dvq_stream_t stream);
+
+/* row softmax (AttnBlock, model.py:182) and its backward, rows of length L, in place allowed */
+int dvq_softmax_rows(const void* s, int dtype, int64_t rows, int64_t L, float scale, void* p, dvq_stream_t stream);
+int dvq_softmax_rows_bwd(const void* p, const void* dp, int dtype, int64_t rows, int64_t L, float scale, void* ds,
+                         dvq_stream_t stream);
+/* batched 2-D transpose: out[b][c][r] = in[b][r][c] */
+int dvq_transpose(const void* in, int dtype, int64_t batch, int64_t R, int64_t C, void* out, dvq_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise / small ops of the path
+ * ---------------------------------------------------------------------------------------------- */
+/* Dual-grain merge (EncoderDual.py:134-149): h_dual = grain? h_fine : up2(h_coarse); mask = grain?1:.25.
+ * h_fine [B,2h,2w,C], h_coarse [B,h,w,C], grain int64 [B,h,w] (1 = fine). mask fp32 [B,2h,2w]. */
+int dvq_dual_merge(const void* h_fine, const void* h_coarse, const int64_t* grain, int dtype, int64_t B, int64_t h,
+                   int64_t w, int64_t C, void* h_dual, float* mask, dvq_stream_t stream);
+int dvq_dual_merge_bwd(const void* g_dual, const int64_t* grain, int dtype, int64_t B, int64_t h, int64_t w,
+                       int64_t C, void* g_fine, void* g_coarse, dvq_stream_t stream);
+/* y = a + b (same dtype), y = x + bias[hw,c] broadcast over batch (decoder position bias) */
+int dvq_add(const void* a, const void* b, int dtype, int64_t n, void* y, dvq_stream_t stream);
+int dvq_add_bias_bcast(const void* x, const float* bias, int dtype, int64_t batch, int64_t inner, void* y,
+                       dvq_stream_t stream);
+/* sum over batch: out[inner] (fp32, accumulated) += sum_b x[b][inner] */
+int dvq_sum_batch(const void* x, int dtype, int64_t batch, int64_t inner, float* out, dvq_stream_t stream);
+/* 2x2 sum pool NHWC (backward of nearest x2): out[n,h,w,c] = sum in[n,2h+a,2w+b,c] */
+int dvq_sumpool2x2(const void* in, int dtype, int64_t N, int64_t h, int64_t w, int64_t C, void* out,
+                   dvq_stream_t stream);
+/* dtype casts */
+int dvq_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, dvq_stream_t stream);
+/* L1 reconstruction loss (vqperceptual_multidisc.py:116): loss_sum(fp64) += sum |x - xrec|,
+ * g[i] = scale_dev[0] * sign(xrec - x) when g != NULL.  x,xrec fp32 NCHW. */
+int dvq_l1_loss(const float* x, const float* xrec, int64_t n, double* loss_sum, const float* scale_dev, float* g,
+                dvq_stream_t stream);
+/* fused Adam over one flat fp32 tensor (torch.optim.Adam semantics, no weight decay / amsgrad) */
+int dvq_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             int step, dvq_stream_t stream);
+int dvq_fill_f32(float* p, float v, int64_t n, dvq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVQ_HIP_H */
