@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DQ-VAE (dual-grain, entropy-routed) train-step images/sec on synthetic 256x256
+batches + VQ-argmin GB/s, on N MI355X of one node (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: entropy gate -> encoder -> quant_conv -> VQ (argmin,
+EMA codebook update) -> post_quant_conv -> decoder -> loss -> full backward -> (RCCL gradient all-reduce) ->
+Adam, in bf16 activations / fp32 master weights.  `config.objective` states which loss terms the step
+carries (round 1: L1 + codebook; LPIPS / PatchGAN are not on the HIP path yet and are NOT counted).
+Weak scaling: bs/GPU is fixed, value = global images / max-over-ranks time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+METRIC = "images/sec (256x256) DQ-VAE train step + VQ argmin GB/s, 1/2/4/8 MI355X"
+PEAK_BF16 = 2.5e15      # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12
+AE_TRAIN_FLOP_PER_IMG = 1180.8e9   # 3 x 393.6 GFLOP (conv + attention + VQ), 256x256 dual config
+THR_JSON = os.path.join(REPO, "scripts/tools/thresholds/entropy_thresholds_imagenet_train_patch-16.json")
+
+
+def full_config(bs_unused=None):
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_gpu_model import model_config
+    return model_config(ch=128, resolution=256, latent=32, zc=256, k=1024, attn_enc=[16, 32], attn_dec=[32], loss="ae")
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """oracle (a port of the reference's CPU path) timed on this host: AE fwd+bwd+Adam, 256x256."""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    from oracle import entropy as oent
+    from oracle import train_step as ots
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = instantiate_from_config(full_config())          # only for reference-identical init + key names (CPU)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("loss.")}
+    del model
+    thr = oent.threshold_from_table(THR_JSON, 0.5)
+    bs = 2
+    x = torch.from_numpy(synth.half_flat_images(bs, 256, seed=1234))
+    t0 = time.time()
+    n = 0
+    while True:
+        ots.train_steps(sd, [x], thr, steps=1)
+        n += 1
+        if time.time() - t0 > seconds_budget or n >= 3:
+            break
+    dt_ = time.time() - t0
+    return {"value": round(n * bs / dt_, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} AE train steps (fwd+bwd+Adam, L1+codebook loss) at bs={bs}, 256x256 fp32, torch-CPU oracle, {cores} threads"}
+
+
+def vq_microbench(dev, reps=20):
+    """VQ argmin at the BASELINE shape (N=65536, D=256, K=1024): algorithmic GB/s, inputs resident in HBM."""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import synth
+    out = {}
+    for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        x, cb = synth.vq_inputs(65536, 256, 1024, "normal", 0)
+        xt = torch.from_numpy(x).to(dev).to(dtype)
+        cbt = torch.from_numpy(cb).to(dev)
+        prep = K.vq_prepare(cbt)
+        for _ in range(3):
+            K.vq_argmin(xt, cbt, prep, impl=2)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            idx, flagged = K.vq_argmin(xt, cbt, prep, impl=2, return_flagged=True)
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / reps
+        nbytes = 65536 * 256 * xt.element_size() + 1024 * 256 * 4 + 65536 * 8
+        out[tag] = {"ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 2), "frac_hbm_peak": round(nbytes / (ms * 1e-3) / PEAK_HBM, 4),
+                    "TFLOPs_equiv": round(2 * 65536 * 1024 * 256 / ms / 1e9, 2), "rerank_rows": int(flagged.item()),
+                    "alg_bytes": nbytes}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bs", type=int, default=64, help="images per GPU (BASELINE config: 64)")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vq-microbench", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: an MI355X is required"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from dynamicvectorquantization_amd import _lib
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    from dynamicvectorquantization_amd.trainer import Trainer
+    _lib.check(_lib.load().dvq_check_device(), "dvq_check_device")
+    rt.set_compute_dtype(args.dtype)
+
+    torch.manual_seed(0)       # identical initial weights on every rank
+    model = instantiate_from_config(full_config()).to(dev)
+    model.learning_rate = 4.5e-6 * args.bs * world     # train.py:248-257
+    model.training_steps, model.steps_per_epoch = 100000, 1000
+    model.train()
+    trainer = Trainer(model, max_steps=args.steps)
+    # two distinct resident batches per rank (synthetic half-flat images: fine ratio exactly 0.5)
+    nb = 2
+    imgs = [torch.from_numpy(synth.half_flat_images(args.bs, 256, seed=1234 + 17 * rank + 1000 * i)).to(dev) for i in range(nb)]
+    batches = [{"image": im} for im in imgs]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.train_step(batches[i % nb], i)
+    barrier()
+    K.profile_start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.train_step(batches[i % nb], args.warmup + i)
+    barrier()
+    dt_ = time.perf_counter() - t0
+    prof = K.profile_stop()
+    if world > 1:
+        tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_ = float(tmax.item())
+    ratio = float(model._logged.get("train_fine_ratio", torch.tensor(float("nan"))))
+
+    if rank == 0:
+        ips = world * args.bs * args.steps / dt_
+        fam = {k: dict(v, ms_per_launch=v["ms"] / max(1, v["launches"]),
+                       TFLOPs=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0) for k, v in prof.items()}
+        conv = [k for k in fam if k.startswith("conv_")]
+        dom = max(conv, key=lambda k: fam[k]["ms"]) if conv else None
+        roofline = None
+        if dom:
+            v = fam[dom]
+            ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            roofline = {"kernel": {"conv_fwd": "igemm_nt_kernel<bf16> (forward)", "conv_dgrad": "igemm_nt_kernel<bf16> (dgrad)",
+                                   "conv_wgrad": "igemm_tn_kernel<bf16> (wgrad)"}.get(dom, dom),
+                        "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                        "frac": round(ach / (PEAK_BF16 / 1e12), 4), "traffic": None,
+                        "launches": v["launches"], "avg_launch_ms": round(v["ms_per_launch"], 4),
+                        "alg_flops_per_launch": v["flops"] / max(1, v["launches"])}
+        out = {
+            "metric": METRIC, "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt_ / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "DQ-VAE dual F=16/8 (configs/stage1/dqvae-entropy-dual-r05_imagenet.yml), codebook 1024x256, "
+                                   f"bs={args.bs}/GPU, 256x256 half-flat synthetic images",
+                       "objective": "AE step: entropy gate + encoder + VQ(argmin+EMA) + decoder, loss = L1 + codebook, "
+                                    "full backward + Adam; LPIPS and PatchGAN terms not yet on the HIP path (not counted)",
+                       "global_batch": world * args.bs, "parallelism": f"dp{world}", "fine_ratio": ratio},
+            "ae_mfma_frac": round(ips / world * AE_TRAIN_FLOP_PER_IMG / PEAK_BF16, 4),
+            "roofline": roofline,
+            "kernel_families": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+                                    "TFLOPs": round(v["TFLOPs"], 2)} for k, v in fam.items()},
+        }
+        if not args.no_vq_microbench:
+            out["vq_argmin"] = vq_microbench(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

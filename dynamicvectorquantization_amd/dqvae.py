@@ -552,6 +552,8 @@ class DualGrainVQModel(nn.Module):
         lr = self.learning_rate
         opt_ae = HipAdam(self.ae_parameters(), lr=lr, betas=(0.5, 0.9))
         disc = getattr(self.loss, "discriminator", None)
+        if getattr(self.loss, "disc_factor", 0) == 0:
+            disc = None     # AE-only objective: no discriminator pass, no second forward
         opt_disc = HipAdam(list(disc.parameters()), lr=lr, betas=(0.5, 0.9)) if disc is not None else None
         warmup_steps = self.steps_per_epoch * self.warmup_epochs
         if self.scheduler_type == "linear-warmup":

@@ -48,6 +48,48 @@ def lib():
 
 
 # ---------------------------------------------------------------------------------------------
+# optional per-kernel-family timing with HIP events on the launch stream (bench.py roofline)
+# ---------------------------------------------------------------------------------------------
+_prof = None
+
+
+def profile_start():
+    global _prof
+    _prof = {}
+
+
+def profile_stop():
+    """-> {family: dict(launches, ms, flops, bytes)}; synchronises."""
+    global _prof
+    p, _prof = _prof, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, recs in (p or {}).items():
+        out[name] = dict(launches=len(recs), ms=sum(s.elapsed_time(e) for s, e, _, _ in recs),
+                         flops=sum(r[2] for r in recs), bytes=sum(r[3] for r in recs))
+    return out
+
+
+def _timed(name, flops, nbytes, fn):
+    if _prof is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    _prof.setdefault(name, []).append((s, e, flops, nbytes))
+    return r
+
+
+def _conv_cost(d: ConvDesc, esize: int):
+    """algorithmic cost of one conv pass: 2*M*K*N flops; bytes = input + weights + output once each"""
+    flops = 2 * d.N * d.OH * d.OW * d.Cout * d.KH * d.KW * d.Cin
+    sh, sw = (d.H // 2, d.W // 2) if d.upsample else (d.H, d.W)
+    nbytes = esize * (d.N * sh * sw * d.Cin + d.Cout * d.KH * d.KW * d.Cin + d.N * d.OH * d.OW * d.Cout)
+    return flops, nbytes
+
+
+# ---------------------------------------------------------------------------------------------
 # VQ
 # ---------------------------------------------------------------------------------------------
 def vq_prepare(codebook: torch.Tensor) -> torch.Tensor:
@@ -67,8 +109,9 @@ def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, prep: torch.Tensor | None
         prep = vq_prepare(codebook)
     idx = torch.empty(n, dtype=torch.int64, device=x.device)
     ws = torch.empty(lib().dvq_vq_argmin_workspace_bytes(n), dtype=torch.uint8, device=x.device)
-    check(lib().dvq_vq_argmin(_p(x), dt(x), _p(codebook), _p(prep), n, k, d, _p(idx), _p(ws), impl, _s()),
-          "dvq_vq_argmin")
+    nbytes = n * d * x.element_size() + k * d * 4 + n * 8
+    _timed("vq_argmin", 2 * n * k * d, nbytes, lambda: check(
+        lib().dvq_vq_argmin(_p(x), dt(x), _p(codebook), _p(prep), n, k, d, _p(idx), _p(ws), impl, _s()), "dvq_vq_argmin"))
     if return_flagged:
         return idx, ws[:4].view(torch.int32)
     return idx
@@ -181,7 +224,9 @@ def unpack_wgrad(dw, grad_oihw, cin_p):
 
 def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None):
     y = torch.empty(d.N, d.OH, d.OW, d.Cout, dtype=x.dtype, device=x.device)
-    check(lib().dvq_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), _p(y), _s()), "dvq_conv2d_fwd")
+    fl, nb = _conv_cost(d, x.element_size())
+    _timed("conv_fwd", fl, nb, lambda: check(
+        lib().dvq_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), _p(y), _s()), "dvq_conv2d_fwd"))
     return y
 
 
@@ -189,15 +234,19 @@ def conv2d_dgrad(d: ConvDesc, dy, wt):
     sh, sw = (d.H // 2, d.W // 2) if d.upsample else (d.H, d.W)
     dx = torch.empty(d.N, sh, sw, d.Cin, dtype=dy.dtype, device=dy.device)
     ws = torch.empty(d.N, d.H, d.W, d.Cin, dtype=dy.dtype, device=dy.device) if d.upsample else None
-    check(lib().dvq_conv2d_dgrad(C.byref(d), _p(dy), _p(wt), _p(dx), _p(ws), _s()), "dvq_conv2d_dgrad")
+    fl, nb = _conv_cost(d, dy.element_size())
+    _timed("conv_dgrad", fl, nb, lambda: check(
+        lib().dvq_conv2d_dgrad(C.byref(d), _p(dy), _p(wt), _p(dx), _p(ws), _s()), "dvq_conv2d_dgrad"))
     return dx
 
 
-def conv2d_wgrad(d: ConvDesc, x, dy, want_bias=True):
+def conv2d_wgrad(d: ConvDesc, x, dy, db=None):
+    """returns dw (fp32 packed [Cout,KH,KW,Cin]); db (fp32 [Cout]) is accumulated into when given"""
     dw = torch.zeros(d.Cout, d.KH, d.KW, d.Cin, dtype=torch.float32, device=x.device)
-    db = torch.zeros(d.Cout, dtype=torch.float32, device=x.device) if want_bias else None
-    check(lib().dvq_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _s()), "dvq_conv2d_wgrad")
-    return dw, db
+    fl, nb = _conv_cost(d, x.element_size())
+    _timed("conv_wgrad", fl, nb, lambda: check(
+        lib().dvq_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _s()), "dvq_conv2d_wgrad"))
+    return dw
 
 
 def nchw_to_nhwc_pad(img, cp, dtype):

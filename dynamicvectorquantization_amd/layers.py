@@ -203,10 +203,9 @@ class Conv2d(HipModule):
         x, d = tape.s["x"], tape.s["d"]
         cin_p, cout_p = self._padded(x.dtype)
         direct_bias = self.bias is not None and cout_p == self.out_channels
-        dw = torch.zeros(d.Cout, d.KH, d.KW, d.Cin, dtype=torch.float32, device=x.device)
         db = _grad_buf(self.bias) if direct_bias else (
             torch.zeros(cout_p, dtype=torch.float32, device=x.device) if self.bias is not None else None)
-        K.check(K.lib().dvq_conv2d_wgrad(K.C.byref(d), K._p(x), K._p(dy), K._p(dw), K._p(db), K._s()), "dvq_conv2d_wgrad")
+        dw = K.conv2d_wgrad(d, x, dy, db)
         K.unpack_wgrad(dw, _grad_buf(self.weight), cin_p)
         if self.bias is not None and not direct_bias:
             _grad_buf(self.bias).add_(db[: self.out_channels])

@@ -79,8 +79,6 @@ class VQEmbedding(nn.Embedding):
         vectors = vectors.reshape(-1, d)
         idxs = idxs.reshape(-1)
         stats = K.vq_ema_stats(vectors, idxs, k)                      # [K, D+1] = (sums | count)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM)              # ONE fused collective
         restart = None
         if self.restart_unused_codes:
             n = vectors.shape[0]
@@ -92,10 +90,20 @@ class VQEmbedding(nn.Embedding):
             else:
                 perm = torch.randperm(n, device=vectors.device)[:k]
             restart = K.vq_embed(K.cast(vectors, torch.float32), perm)
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                dist.broadcast(restart, 0)
+        stats, restart = self._exchange(stats, restart)
         K.vq_ema_apply(stats, restart, self.decay, self.eps, self.cluster_size_ema, self.embed_ema, self.weight.data)
         self._cb_version += 1
+
+    @staticmethod
+    def _exchange(stats, restart):
+        """Data-parallel step of the EMA update: ONE all-reduce(SUM) of the fused [K, D+1] statistics
+        (reference: two, quantize2_mask.py:86-88) and the rank-0 broadcast of the restart rows (:99-100).
+        Device-agnostic (tested on CPU tensors over gloo)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+            if restart is not None:
+                dist.broadcast(restart, 0)
+        return stats, restart
 
     def forward(self, inputs):
         """inputs [B, N, D] -> (embeds, idx) with the reference's ordering (quantize2_mask.py:117-128):

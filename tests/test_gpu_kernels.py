@@ -1,0 +1,344 @@
+"""GPU parity tests: every HIP kernel family against the CPU oracle / reference goldens, through the
+C ABI (ctypes) exactly as the product path calls it.  Run with `pytest -m gpu` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import REPO, load_golden
+from dynamicvectorquantization_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+THR_JSON = os.path.join(REPO, "scripts/tools/thresholds/entropy_thresholds_{}_patch-16.json")
+
+
+def T(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t if dtype is None else t.to(dtype)
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).float().numpy()
+
+
+# ---------------------------------------------------------------------------------------------
+# VQ argmin: bit-exact indices
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ci", range(5))
+@pytest.mark.parametrize("impl", [0, 1])
+def test_vq_argmin_golden(dev, ci, impl):
+    from dynamicvectorquantization_amd import kernels as K
+    g = load_golden("vq_argmin")
+    n, d, k, seed = (int(v) for v in g[f"case{ci}_meta"])
+    x, cb = synth.vq_inputs(n, d, k, str(g[f"case{ci}_dist"]), seed)
+    idx, flagged = K.vq_argmin(T(x, dev), T(cb, dev), impl=impl, return_flagged=True)
+    idx = idx.cpu().numpy()
+    exact = g[f"case{ci}_exact_idx"]
+    assert np.array_equal(idx, exact), f"{(idx != exact).sum()} / {n} rows differ from the exact argmin"
+    if impl == 0 and d in (64, 128, 256):
+        frac = int(flagged.item()) / n
+        assert frac < 0.2, f"fp64 re-rank fraction {frac} unexpectedly high"
+
+
+def test_vq_argmin_ties(dev):
+    from dynamicvectorquantization_amd import kernels as K
+    g = load_golden("vq_argmin")
+    for impl in (0, 1):
+        idx = K.vq_argmin(T(g["tie_x"], dev), T(g["tie_cb"], dev), impl=impl).cpu().numpy()
+        assert np.array_equal(idx, g["tie_exact_idx"])
+    # duplicated codes on the MFMA path (D = 64)
+    rs = np.random.RandomState(5)
+    cb = rs.standard_normal((96, 64)).astype(np.float32)
+    cb[50] = cb[3]
+    cb[95] = cb[3]
+    x = rs.standard_normal((300, 64)).astype(np.float32)
+    x[:10] = cb[3] + 1e-3 * rs.standard_normal((10, 64)).astype(np.float32)
+    from oracle import vq as ovq
+    exact = ovq.argmin_exact(x, cb)
+    idx = K.vq_argmin(T(x, dev), T(cb, dev), impl=2).cpu().numpy()
+    assert np.array_equal(idx, exact)
+    assert np.all(idx[:10] == 3)
+
+
+@pytest.mark.parametrize("k", [1024, 8192])
+def test_vq_argmin_full_size_properties(dev, k):
+    """BASELINE size N=65536: MFMA path == fp64 path on a row sample; codebook rows map to themselves."""
+    from dynamicvectorquantization_amd import kernels as K
+    from oracle import vq as ovq
+    n, d = 65536, 256
+    for dist_ in ("normal", "encoder"):
+        x, cb = synth.vq_inputs(n, d, k, dist_, 0)
+        xt, cbt = T(x, dev), T(cb, dev)
+        idx, flagged = K.vq_argmin(xt, cbt, impl=2, return_flagged=True)
+        idx = idx.cpu().numpy()
+        sample = np.random.RandomState(1).choice(n, 2048, replace=False)
+        assert np.array_equal(idx[sample], ovq.argmin_exact(x[sample], cb))
+        assert int(flagged.item()) < 0.1 * n
+        # idempotence: quantising code vectors returns their own index
+        self_idx = K.vq_argmin(cbt, cbt, impl=2).cpu().numpy()
+        assert np.array_equal(self_idx, np.arange(k))
+        # bf16 activations (perf mode): still exact w.r.t. the bf16-rounded rows
+        xb = xt[:4096].to(torch.bfloat16)
+        idxb = K.vq_argmin(xb, cbt, impl=2).cpu().numpy()
+        assert np.array_equal(idxb, ovq.argmin_exact(xb.float().cpu().numpy(), cb))
+
+
+def test_vq_forward_golden(dev):
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    g = load_golden("vq_forward")
+    for tag in ("a", "b"):
+        b, d, h, k, use_mask = (int(v) for v in g[f"{tag}_meta"])
+        vq = VectorQuantize2(codebook_size=k, codebook_dim=d).to(dev).eval()
+        w = synth.det_param(f"vqfwd.{tag}.codebook", (k + 1, d)) * 4.0
+        x = synth.det_param(f"vqfwd.{tag}.x", (b, d, h, h)) * 6.0
+        with torch.no_grad():
+            vq.codebook.weight.copy_(T(w, dev))
+        xt = T(x, dev).requires_grad_(True)
+        mask = T(g[f"{tag}_mask"], dev) if use_mask else None
+        xq, loss, (_, _, idx) = vq(xt, codebook_mask=mask)
+        gout = T(synth.det_param(f"vqfwd.{tag}.gout", x.shape), dev)
+        (loss * 3.0 + (xq * gout).sum()).backward()
+        assert np.array_equal(idx.cpu().numpy(), g[f"{tag}_idx"])
+        np.testing.assert_allclose(xq.detach().cpu().numpy(), g[f"{tag}_x_q"], atol=1e-6)
+        np.testing.assert_allclose(loss.item(), g[f"{tag}_loss"], rtol=1e-5)
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), g[f"{tag}_dx"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(vq.get_codebook_entry(idx).cpu().numpy(), g[f"{tag}_entry"])
+
+
+def test_vq_ema_golden(dev):
+    from dynamicvectorquantization_amd.quantize import VQEmbedding
+    g = load_golden("vq_ema")
+    for tag, dead in (("live", False), ("dead", True)):
+        n, d, k = (int(v) for v in g[f"{tag}_meta"])
+        emb = VQEmbedding(k, d).to(dev).train()
+        w = synth.det_param(f"ema.{tag}.w", (k + 1, d)) * 3.0
+        x = synth.det_param(f"ema.{tag}.x", (n, d)) * (1.5 if dead else 3.0)
+        n0 = g[f"{tag}_n_ema0"]
+        with torch.no_grad():
+            emb.weight.copy_(T(w, dev))
+            emb.embed_ema.copy_(T(w[:-1] * n0[:, None], dev))
+            emb.cluster_size_ema.copy_(T(n0, dev))
+        emb.restart_perm = T(g[f"{tag}_perm"], dev)
+        embeds, idx = emb(T(x, dev).view(1, n, d))
+        assert np.array_equal(idx.cpu().numpy().reshape(-1), g[f"{tag}_idx"])
+        np.testing.assert_allclose(embeds.cpu().numpy().reshape(n, d), w[:-1][g[f"{tag}_idx"]])   # OLD weight
+        np.testing.assert_allclose(emb.cluster_size_ema.cpu().numpy(), g[f"{tag}_n_ema"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(emb.embed_ema.cpu().numpy(), g[f"{tag}_s_ema"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(emb.weight[:-1].detach().cpu().numpy(), g[f"{tag}_weight"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(emb.weight[-1].detach().cpu().numpy(), w[-1])                    # padding row untouched
+
+
+# ---------------------------------------------------------------------------------------------
+# entropy + gate: H to 1e-5, gates bit-exact
+# ---------------------------------------------------------------------------------------------
+def test_entropy_gate_golden(dev):
+    from dynamicvectorquantization_amd import kernels as K
+    from oracle import entropy as oent
+    g = load_golden("entropy")
+    imgs = {"small": g["small_img"], "big": synth.half_flat_images(2, 256, seed=1234)}
+    for tag, img in imgs.items():
+        for table in ("imagenet_train", "imagenet_val", "ffhq_train"):
+            for r in (0.3, 0.5, 0.7, 0.55):
+                thr = oent.threshold_from_table(THR_JSON.format(table), r)
+                ent, gate = K.patch_entropy_gate(T(img, dev), 16, thr)
+                ent = ent.cpu().numpy()
+                ref = g[f"{tag}_H"]
+                np.testing.assert_allclose(ent, ref, rtol=2e-5, atol=1e-36)
+                margin = np.abs(ref - np.float32(thr))
+                safe = margin > 1e-4 * np.maximum(1.0, np.abs(ref))
+                gg = gate.cpu().numpy().astype(np.int8)
+                assert np.array_equal(gg[safe], g[f"{tag}_gate_{table}_{r}"][safe])
+                assert safe.mean() > 0.99
+    # all-underflow patch: H = 32 * eps * ln(1/eps) needs fp32 subnormals
+    ent, _ = K.patch_entropy_gate(T(g["small_img"], dev), 16, None)
+    assert abs(float(ent[2, 0, 0]) - 2.947293e-37) < 1e-40
+
+
+# ---------------------------------------------------------------------------------------------
+# GroupNorm (+swish)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,silu", [((2, 64, 8, 8), True), ((3, 128, 20, 12), True), ((2, 32, 5, 7), False),
+                                        ((1, 512, 16, 16), True), ((2, 256, 33, 31), False)])
+def test_groupnorm(dev, dtype, shape, silu):
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Normalize
+    n, c, h, w = shape
+    rs = np.random.RandomState(c + h)
+    x = (rs.standard_normal(shape) * 2 + 0.5).astype(np.float32)
+    gam = (1 + 0.2 * rs.standard_normal(c)).astype(np.float32)
+    bet = (0.2 * rs.standard_normal(c)).astype(np.float32)
+    go = rs.standard_normal(shape).astype(np.float32)
+    if dtype == torch.bfloat16:
+        x, go = bf16_round(x), bf16_round(go)
+    xr = torch.from_numpy(x).requires_grad_(True)
+    gr, br = torch.from_numpy(gam).requires_grad_(True), torch.from_numpy(bet).requires_grad_(True)
+    yr = F.group_norm(xr, 32, gr, br, 1e-6)
+    if silu:
+        yr = yr * torch.sigmoid(yr)
+    (yr * torch.from_numpy(go)).sum().backward()
+    mod = Normalize(c).to(dev)
+    mod.fuse_silu = silu
+    with torch.no_grad():
+        mod.weight.copy_(T(gam, dev))
+        mod.bias.copy_(T(bet, dev))
+    with rt.compute_dtype_ctx(dtype):
+        xt = T(x, dev).requires_grad_(True)
+        y = mod(xt)
+        (y.float() * T(go, dev)).sum().backward()
+    tol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), yr.detach().numpy(), **tol)
+    np.testing.assert_allclose(xt.grad.float().cpu().numpy(), xr.grad.numpy(), **tol)
+    scale = max(1.0, float(np.abs(gr.grad.numpy()).max()))
+    gtol = 2e-4 if dtype == torch.float32 else 3e-2
+    np.testing.assert_allclose(mod.weight.grad.cpu().numpy() / scale, gr.grad.numpy() / scale, atol=gtol)
+    np.testing.assert_allclose(mod.bias.grad.cpu().numpy() / scale, br.grad.numpy() / scale, atol=gtol)
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution: fwd / dgrad / wgrad, naive (impl 1) and MFMA (impl 2)
+# ---------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # cin, cout, k, kind, H, W, N
+    (32, 64, 3, "same", 8, 8, 2),
+    (64, 64, 3, "same", 12, 20, 2),
+    (128, 128, 3, "same", 16, 16, 3),
+    (64, 128, 1, "same", 9, 7, 2),
+    (64, 64, 3, "down", 8, 8, 2),
+    (128, 128, 3, "down", 16, 12, 2),
+    (64, 64, 3, "up", 6, 6, 2),
+    (128, 64, 3, "up", 8, 4, 1),
+    (3, 32, 3, "same", 16, 16, 2),
+    (64, 3, 3, "same", 16, 16, 2),
+    (256, 256, 3, "same", 16, 16, 1),
+    (16, 32, 4, "s2p1", 16, 16, 2),
+]
+
+
+def _conv_ref(x, w, b, kind, k):
+    if kind == "same":
+        return F.conv2d(x, w, b, stride=1, padding=(k - 1) // 2)
+    if kind == "down":
+        return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    if kind == "up":
+        return F.conv2d(x.repeat_interleave(2, dim=-1).repeat_interleave(2, dim=-2), w, b, stride=1, padding=1)
+    if kind == "s2p1":
+        return F.conv2d(x, w, b, stride=2, padding=1)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(map(str, c)))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("impl", [1, 2])
+def test_conv(dev, case, dtype, impl):
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d
+    cin, cout, k, kind, h, w_, n = case
+    rs = np.random.RandomState(cin * 7 + cout + k)
+    x = rs.standard_normal((n, cin, h, w_)).astype(np.float32)
+    wt = (rs.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = (0.1 * rs.standard_normal(cout)).astype(np.float32)
+    if dtype == torch.bfloat16:
+        x, wt = bf16_round(x), bf16_round(wt)
+    xr = torch.from_numpy(x).requires_grad_(True)
+    wr, br = torch.from_numpy(wt).requires_grad_(True), torch.from_numpy(b).requires_grad_(True)
+    yr = _conv_ref(xr, wr, br, kind, k)
+    go = rs.standard_normal(tuple(yr.shape)).astype(np.float32)
+    if dtype == torch.bfloat16:
+        go = bf16_round(go)
+    (yr * torch.from_numpy(go)).sum().backward()
+    kw = dict(same=dict(stride=1, padding=(k - 1) // 2), down=dict(stride=2, padding=0, asym_pad=True),
+              up=dict(stride=1, padding=1, upsample=True), s2p1=dict(stride=2, padding=1))[kind]
+    mod = Conv2d(cin, cout, k, **kw).to(dev)
+    with torch.no_grad():
+        mod.weight.copy_(T(wt, dev))
+        mod.bias.copy_(T(b, dev))
+    pad_in = (cin % (4 if dtype == torch.float32 else 8)) != 0
+    with rt.compute_dtype_ctx(dtype), rt.impl_ctx(impl):
+        if pad_in or cout % (4 if dtype == torch.float32 else 8):
+            pytest.skip("channel-padded image convs are exercised through the encoder/decoder tests")
+        xt = T(x, dev).requires_grad_(True)
+        y = mod(xt)
+        (y.float() * T(go, dev)).sum().backward()
+    if dtype == torch.float32:
+        tol = dict(rtol=1e-4, atol=1e-4)
+    else:
+        tol = dict(rtol=2e-2, atol=2e-2 * float(np.abs(yr.detach().numpy()).max()))
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), yr.detach().numpy(), **tol)
+    gtol = 1e-4 if dtype == torch.float32 else 2e-2
+    for name, got, ref in (("dx", xt.grad.float().cpu().numpy(), xr.grad.numpy()),
+                           ("dw", mod.weight.grad.cpu().numpy(), wr.grad.numpy()),
+                           ("db", mod.bias.grad.cpu().numpy(), br.grad.numpy())):
+        s = max(1e-6, float(np.abs(ref).max()))
+        err = float(np.abs(got - ref).max()) / s
+        assert err < gtol * 5, f"{name}: rel-to-max error {err}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("impl", [1, 2])
+def test_gemm_nt_tn(dev, dtype, impl):
+    from dynamicvectorquantization_amd import kernels as K
+    rs = np.random.RandomState(3)
+    b, m, n, k = 3, 200, 72, 96
+    a = rs.standard_normal((b, m, k)).astype(np.float32)
+    bb = rs.standard_normal((b, n, k)).astype(np.float32)
+    bias = rs.standard_normal(n).astype(np.float32)
+    if dtype == torch.bfloat16:
+        a, bb = bf16_round(a), bf16_round(bb)
+    ref = 0.5 * np.einsum("bmk,bnk->bmn", a, bb) + bias
+    out = K.gemm_nt(T(a, dev, dtype), T(bb, dev, dtype), m, n, k, k, k, n, batch=b, sa=m * k, sb=n * k, sc=m * n, alpha=0.5,
+                    bias=T(bias, dev), bias_mode=1, impl=impl)
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    err = np.abs(out.float().cpu().numpy().reshape(b, m, n) - ref).max() / np.abs(ref).max()
+    assert err < tol, err
+    # TN: C[i][j] = sum_m A[m][i] B[m][j]
+    mred, i, j = 520, 72, 40
+    a2 = rs.standard_normal((b, mred, i)).astype(np.float32)
+    b2 = rs.standard_normal((b, mred, j)).astype(np.float32)
+    if dtype == torch.bfloat16:
+        a2, b2 = bf16_round(a2), bf16_round(b2)
+    ref2 = np.einsum("bmi,bmj->bij", a2, b2)
+    out2 = K.gemm_tn(T(a2, dev, dtype), T(b2, dev, dtype), mred, i, j, i, j, j, batch=b, sa=mred * i, sb=mred * j, sc=i * j,
+                     impl=impl)
+    err2 = np.abs(out2.cpu().numpy().reshape(b, i, j) - ref2).max() / np.abs(ref2).max()
+    assert err2 < tol, err2
+
+
+# ---------------------------------------------------------------------------------------------
+# blocks against the reference goldens (fp32, forward + input/parameter gradients)
+# ---------------------------------------------------------------------------------------------
+def _load_block(mod, name, dev):
+    with torch.no_grad():
+        for k, p in mod.named_parameters():
+            p.copy_(T(synth.det_param(name + "." + k, p.shape), dev))
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("name", ["res_32_64", "res_64_64", "attn_64", "attn_128", "down_64", "up_64"])
+def test_blocks_golden(dev, name, impl):
+    from dynamicvectorquantization_amd import layers as L
+    from dynamicvectorquantization_amd import runtime as rt
+    from test_oracle_golden import BLOCK_SHAPES
+    g = load_golden("blocks")
+    shapes, xshape, _ = BLOCK_SHAPES[name]
+    ctor = {"res_32_64": lambda: L.ResnetBlock(in_channels=32, out_channels=64, temb_channels=0, dropout=0.0),
+            "res_64_64": lambda: L.ResnetBlock(in_channels=64, out_channels=64, temb_channels=0, dropout=0.0),
+            "attn_64": lambda: L.AttnBlock(64), "attn_128": lambda: L.AttnBlock(128),
+            "down_64": lambda: L.Downsample(64, True), "up_64": lambda: L.Upsample(64, True)}[name]
+    mod = ctor().to(dev)
+    assert sorted(k for k, _ in mod.named_parameters()) == sorted(shapes)
+    _load_block(mod, name, dev)
+    x = T(synth.det_param(name + ".x", xshape) * 8.0, dev).requires_grad_(True)
+    with rt.compute_dtype_ctx(torch.float32), rt.impl_ctx(impl):
+        y = mod(x, None) if name.startswith("res") else mod(x)
+        gout = T(synth.det_param(name + ".gout", tuple(y.shape)), dev)
+        (y * gout).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[name + "_y"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[name + "_dx"], rtol=1e-3, atol=1e-3)
+    for k, p in mod.named_parameters():
+        ref = g[name + "_d." + k]
+        s = max(1e-6, float(np.abs(ref).max()))
+        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) / s < 2e-3, k

