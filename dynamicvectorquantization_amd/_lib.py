@@ -75,6 +75,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; it must be the HIP runtime of the process (streams and
+    # device pointers come from torch), so load torch BEFORE libdvq_hip.so resolves its dependency
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise DvqError(
             f"{LIB_PATH} not found. Build it with `python -m dynamicvectorquantization_amd.build` "

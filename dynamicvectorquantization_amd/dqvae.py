@@ -180,14 +180,15 @@ class DualGrainEncoder(HipModule):
         gate = self.router(h_fine=None, h_coarse=None, entropy=x_entropy)
         gate = gate.permute(0, 3, 1, 2)
         indices = gate.argmax(dim=1)
-        h_dual, mask = _EncFn.apply(self, x, indices.contiguous(), *[p for p in self.parameters() if p.requires_grad])
+        h_dual, mask = _EncFn.apply(self, torch.is_grad_enabled(), x, indices.contiguous(),
+                                    *[p for p in self.parameters() if p.requires_grad])
         return {"h_dual": h_dual, "indices": indices, "codebook_mask": mask, "gate": gate}
 
 
 class _EncFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, x, grain, *params):
-        ctx.module, ctx.tape, ctx.n = module, Tape(), len(params)
+    def forward(ctx, module, want_grad, x, grain, *params):
+        ctx.module, ctx.tape, ctx.n = module, (Tape() if want_grad else None), len(params)
         with torch.no_grad():
             h_dual, mask = module.fwd(x.contiguous().float(), grain, ctx.tape)
             out = to_nchw(K.cast(h_dual, torch.float32))
@@ -198,7 +199,7 @@ class _EncFn(torch.autograd.Function):
     def backward(ctx, g, _gm):
         with torch.no_grad():
             ctx.module.bwd(to_nhwc(g, rt.compute_dtype()), ctx.tape)
-        return (None, None, None) + (None,) * ctx.n
+        return (None, None, None, None) + (None,) * ctx.n
 
 
 # ---------------------------------------------------------------------------------------------
@@ -490,7 +491,7 @@ class DualGrainVQModel(nn.Module):
         """-> (dec, diff, grain_indices, gate, x_entropy); one fused autograd node."""
         x = input.contiguous().float() if input.dtype != torch.float32 or not input.is_contiguous() else input
         params = [p for p in self.ae_parameters() if p.requires_grad]
-        rec, qloss, grain, gate, ent = _AEFn.apply(self, x, *params)
+        rec, qloss, grain, gate, ent = _AEFn.apply(self, torch.is_grad_enabled() and len(params) > 0, x, *params)
         return rec, qloss, grain, gate, ent
 
     def ae_parameters(self):
@@ -578,9 +579,9 @@ class _AEFn(torch.autograd.Function):
     """The whole autoencoder as one autograd node: forward fills a Tape, backward walks it."""
 
     @staticmethod
-    def forward(ctx, model, x, *params):
+    def forward(ctx, model, want_grad, x, *params):
         ctx.model, ctx.n = model, len(params)
-        ctx.tape = Tape() if any(p.requires_grad for p in params) and torch.is_grad_enabled() else None
+        ctx.tape = Tape() if want_grad else None    # grad mode is off inside Function.forward
         with torch.no_grad():
             out = model.ae_fwd(x, ctx.tape)
         model._last = out
@@ -596,4 +597,4 @@ class _AEFn(torch.autograd.Function):
             if g_qloss is None:
                 g_qloss = torch.zeros((), device=g_rec.device)
             ctx.model.ae_bwd(g_rec.contiguous().float(), g_qloss, ctx.tape)
-        return (None, None) + (None,) * ctx.n
+        return (None, None, None) + (None,) * ctx.n

@@ -67,7 +67,7 @@ class HipModule(nn.Module):
     def forward(self, x, *args, **kwargs):
         if kwargs.pop("_raw", False):
             return self.fwd(x, *args, **kwargs)
-        return _ModuleFn.apply(self, x, *[p for p in self.parameters() if p.requires_grad])
+        return _ModuleFn.apply(self, torch.is_grad_enabled(), x, *[p for p in self.parameters() if p.requires_grad])
 
     # NCHW <-> NHWC adapters used by the generic autograd wrapper
     def _fwd_nchw(self, x, tape):
@@ -84,9 +84,9 @@ class HipModule(nn.Module):
 
 class _ModuleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, x, *params):
+    def forward(ctx, module, want_grad, x, *params):
         ctx.module = module
-        ctx.tape = Tape() if torch.is_grad_enabled() or any(p.requires_grad for p in params) else None
+        ctx.tape = Tape() if want_grad else None    # grad mode is off inside Function.forward: decided by caller
         ctx.in_dtype = x.dtype
         ctx.n_params = len(params)
         with torch.no_grad():
@@ -98,7 +98,7 @@ class _ModuleFn(torch.autograd.Function):
         with torch.no_grad():
             dx = ctx.module._bwd_nchw(dy, ctx.tape, ctx.in_dtype)
         # parameter gradients were accumulated in place into .grad by the kernels
-        return (None, dx) + (None,) * ctx.n_params
+        return (None, None, dx) + (None,) * ctx.n_params
 
 
 # ---------------------------------------------------------------------------------------------

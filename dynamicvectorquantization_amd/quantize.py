@@ -82,14 +82,19 @@ class VQEmbedding(nn.Embedding):
         restart = None
         if self.restart_unused_codes:
             n = vectors.shape[0]
+            src = K.cast(vectors, torch.float32)
             if n < k:
-                raise NotImplementedError("restart with fewer input rows than codes (_tile_with_noise, "
-                                          "quantize2_mask.py:57-64) is not on the benchmark path")
+                # _tile_with_noise (quantize2_mask.py:57-64): repeat rows and add U(0,1) * 0.01/sqrt(D);
+                # only reachable with tiny batches, host-side torch on a [K,D]-sized tensor
+                reps = (k + n - 1) // n
+                src = src.repeat(reps, 1)
+                src = src + torch.rand_like(src) * (0.01 / np.sqrt(d))
+                n = src.shape[0]
             if self.restart_perm is not None:
                 perm = self.restart_perm.to(vectors.device)[:k]
             else:
                 perm = torch.randperm(n, device=vectors.device)[:k]
-            restart = K.vq_embed(K.cast(vectors, torch.float32), perm)
+            restart = K.vq_embed(src.contiguous(), perm)
         stats, restart = self._exchange(stats, restart)
         K.vq_ema_apply(stats, restart, self.decay, self.eps, self.cluster_size_ema, self.embed_ema, self.weight.data)
         self._cb_version += 1

@@ -340,5 +340,6 @@ def test_blocks_golden(dev, name, impl):
     np.testing.assert_allclose(x.grad.cpu().numpy(), g[name + "_dx"], rtol=1e-3, atol=1e-3)
     for k, p in mod.named_parameters():
         ref = g[name + "_d." + k]
-        s = max(1e-6, float(np.abs(ref).max()))
+        # floor: gradients that are analytically zero (softmax is invariant to the k bias) are pure rounding noise
+        s = max(1e-5, float(np.abs(ref).max()))
         assert float(np.abs(p.grad.cpu().numpy() - ref).max()) / s < 2e-3, k

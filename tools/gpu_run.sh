@@ -17,7 +17,7 @@ if [ "${RUN_BENCH:-1}" = "1" ]; then
 fi
 if [ "${RUN_PROF:-1}" = "1" ]; then
   echo "== rocprofv3 kernel stats"
-  cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1
+  cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1
   echo "rocprof exit $?"; cd "$OLDPWD"
   ls gpurun_out/prof/* 2>/dev/null | head; f=$(ls gpurun_out/prof/*/*kernel_stats.csv gpurun_out/prof/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -25 "$f"
 fi
