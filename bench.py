@@ -115,7 +115,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bs", type=int, default=64, help="images per GPU (BASELINE config: 64)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -141,6 +141,7 @@ def main():
     from dynamicvectorquantization_amd.trainer import Trainer
     _lib.check(_lib.load().dvq_check_device(), "dvq_check_device")
     rt.set_compute_dtype(args.dtype)
+    rt.set_impl(int(os.environ.get("DVQ_IMPL", "0")))     # 0 auto; 2 LDS-DMA MFMA kernels; 3 register-staged (A/B)
 
     torch.manual_seed(0)       # identical initial weights on every rank
     model = instantiate_from_config(full_config()).to(dev)

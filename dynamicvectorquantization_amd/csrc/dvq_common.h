@@ -43,6 +43,9 @@ void dvq_set_error(const char* fmt, ...);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) costs ~0.3 ms per call: do it once per kernel symbol.
+void dvq_ensure_dynamic_lds(const void* kernel, int bytes);
+
 // ---------------------------------------------------------------------------------------------
 // bf16 <-> f32 (device)
 // ---------------------------------------------------------------------------------------------

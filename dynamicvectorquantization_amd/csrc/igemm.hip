@@ -43,7 +43,18 @@ struct NtParams {
     float alpha;
     int bias_mode;       // 0 none, 1 per column, 2 per row
     int64_t sA, sB, sC;  // batch strides
+    int gm, gn;          // tile grid (M tiles x N tiles); the launch grid is 1-D over gm*gn, XCD-remapped
 };
+
+// XCD-aware work-item order (MI355X: block b is dispatched to XCD b % 8, each XCD has a private 4-MiB L2):
+// remap the linear block id so that every XCD walks one CONTIGUOUS range of work items; neighbouring items
+// (adjacent output rows of a conv, the taps of one wgrad split) then share operand rows through the same L2
+// instead of each XCD fetching them again.  Bijective for any item count.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = id & 7, j = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
 
 template <typename T>
 struct Vec {
@@ -96,6 +107,37 @@ __device__ __forceinline__ void mma_stage(const char* sA, const char* sB, f32x16
 }
 
 // -------------------------------------------------------------------------------------------------
+// NT epilogue: alpha * acc + bias (+ residual) -> C, shared by the register-staged and the LDS-DMA kernels
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[2][2], int m0, int n0, int64_t bz, int wm,
+                                            int wn, int lane) {
+    T* __restrict__ Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
+    const T* __restrict__ Rg = p.R ? reinterpret_cast<const T*>(p.R) + bz * p.sC : nullptr;
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = n0 + wn * 64 + nt * 32 + l31;
+        if (col >= p.Ncols) continue;
+        const float bcol = p.bias_mode == 1 ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < p.M) {
+                    float v = acc[mt][nt][r] * p.alpha + bcol;
+                    if (p.bias_mode == 2) v += p.bias[row];
+                    const int64_t o = (int64_t)row * p.ldc + col;
+                    if (Rg) v += ElemIO<T>::load(Rg + o);
+                    ElemIO<T>::store(Cg + o, v);
+                }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // NT kernel
 // -------------------------------------------------------------------------------------------------
 template <typename T>
@@ -105,7 +147,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE;
+    const int wi = xcd_remap(blockIdx.x, p.gm * p.gn);
+    const int m0 = (wi / p.gn) * TILE, n0 = (wi % p.gn) * TILE;
     const int64_t bz = blockIdx.z;
     const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
     const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
@@ -212,30 +255,195 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(NtParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue ---------------------------------------------------------------------------------
-    T* __restrict__ Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
-    const T* __restrict__ Rg = p.R ? reinterpret_cast<const T*>(p.R) + bz * p.sC : nullptr;
+    nt_epilogue<T>(p, acc, m0, n0, bz, wm, wn, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
+// NT kernel, LDS-DMA staging (global_load_lds_dwordx4): no VGPR round trip, no ds_write.
+// LDS tile rows are 128 B unpadded; the 16-B chunk c of row r lives at chunk position c ^ ((r >> 1) & 7)
+// (the DMA writes lane-linear, so the permutation is applied to the per-lane SOURCE address and again on
+// the fragment read: conflict-free ds_read_b128 for the MFMA pattern).  Out-of-image taps and K / row
+// tails read a 16-byte zero page instead of being predicated.
+// -------------------------------------------------------------------------------------------------
+__device__ uint4 g_zero_page[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+
+constexpr int GROW = 128;               // unpadded LDS row bytes
+constexpr int GOPB = TILE * GROW;       // 16 KiB per operand tile
+constexpr int GSTAGEB = 2 * GOPB;
+
+// swizzle kinds for unpadded 128-B LDS rows: chunk c of row r is stored at chunk position c ^ f(r)
+//   SWZ_NT: f(r) = (r >> 1) & 7                                   (conflict-free b128 fragment reads; DMA fill)
+//   SWZ_TN: f(r) = ((r >> 3) & 3) | (((r >> 1) ^ (r >> 5)) & 1) << 2
+//           additionally conflict-free for the transposing stores of the TN loader, where 8 consecutive lanes
+//           write rows 8 apart (found by exhaustive search over XOR-linear maps)
+enum { SWZ_NT = 0, SWZ_TN = 1 };
+__device__ __forceinline__ int swz_tn(int r) { return ((r >> 3) & 3) | ((((r >> 1) ^ (r >> 5)) & 1) << 2); }
+
+template <typename T, int SWZ = SWZ_NT>
+__device__ __forceinline__ void mma_stage_swz(const char* sA, const char* sB, f32x16 (&acc)[2][2], int wm, int wn,
+                                              int lane) {
     const int l31 = lane & 31, half = lane >> 5;
+    // rows are wm*64 + t*32 + l31: only bit 5 of the row depends on t
+    int swz[2];
+    swz[0] = SWZ == SWZ_NT ? ((l31 >> 1) & 7) : swz_tn(l31);
+    swz[1] = SWZ == SWZ_NT ? swz[0] : swz_tn(l31 + 32);
+    const char* pa = sA + (wm * 64 + l31) * GROW;
+    const char* pb = sB + (wn * 64 + l31) * GROW;
+    if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = n0 + wn * 64 + nt * 32 + l31;
-        if (col >= p.Ncols) continue;
-        const float bcol = p.bias_mode == 1 ? p.bias[col] : 0.f;
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[2], b[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < p.M) {
-                    float v = acc[mt][nt][r] * p.alpha + bcol;
-                    if (p.bias_mode == 2) v += p.bias[row];
-                    const int64_t o = (int64_t)row * p.ldc + col;
-                    if (Rg) v += ElemIO<T>::load(Rg + o);
-                    ElemIO<T>::store(Cg + o, v);
-                }
+            for (int t = 0; t < 2; ++t) {
+                const int off = ((ks * 2 + half) ^ swz[t]) << 4;
+                a[t] = *reinterpret_cast<const bf16x8*>(pa + t * 32 * GROW + off);
+                b[t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * GROW + off);
             }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            f32x4 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int off = ((jj * 2 + half) ^ swz[t]) << 4;
+                a[t] = *reinterpret_cast<const f32x4*>(pa + t * 32 * GROW + off);
+                b[t] = *reinterpret_cast<const f32x4*>(pb + t * 32 * GROW + off);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
         }
     }
+}
+
+template <typename T, int MODE, bool TAPU>
+__global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
+    constexpr int VN = Vec<T>::N;
+    constexpr int BK = Vec<T>::BK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wi = xcd_remap(blockIdx.x, p.gm * p.gn);
+    const int m0 = (wi / p.gn) * TILE, n0 = (wi % p.gn) * TILE;
+    const int64_t bz = blockIdx.z;
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
+    const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
+    const T* zero = reinterpret_cast<const T*>(g_zero_page);
+
+    // DMA instruction i of this wave fills tile rows wave*32 + i*8 .. +7 (one 1-KiB piece); lane -> (row, chunk pos)
+    const int lrow = lane >> 3, cpos = lane & 7;
+    int rn[4], ra[4], rb[4], cg[4];
+    bool rok[4];
+    int64_t boff[4];
+    bool bok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int trow = wave * 32 + i * 8 + lrow;
+        cg[i] = cpos ^ ((trow >> 1) & 7);          // which 16-B chunk of the row this lane fetches
+        const int m = m0 + trow;
+        rok[i] = m < p.M;
+        const int mm = rok[i] ? m : 0;
+        if constexpr (MODE == MODE_GEMM) {
+            rn[i] = mm;
+            ra[i] = rb[i] = 0;
+        } else {
+            const int hw = p.DH * p.DW;
+            const int n = mm / hw, rem = mm - n * hw;
+            const int y = rem / p.DW, x = rem - y * p.DW;
+            rn[i] = n * p.SH * p.SW;                // source pixel base of image n
+            if constexpr (MODE == MODE_FWD) {
+                ra[i] = y * p.stride - p.pad_t;
+                rb[i] = x * p.stride - p.pad_l;
+            } else {
+                ra[i] = y + p.pad_t;
+                rb[i] = x + p.pad_l;
+            }
+        }
+        const int nn = n0 + trow;
+        bok[i] = nn < p.Ncols;
+        boff[i] = (int64_t)(bok[i] ? nn : 0) * p.ldb;
+    }
+    const int cpt = (int)(p.lda / VN);              // conv: 16-B units per tap
+    constexpr bool tap_uniform = TAPU;              // a K stage never straddles a tap ((Cs / VN) % 8 == 0)
+    const int sshift = p.stride == 2 ? 1 : 0;
+    const int smask = p.stride - 1;
+
+    auto issue = [&](int j, int buf) {
+        char* sa = smem + buf * GSTAGEB + wave * 32 * GROW;
+        int kh0 = 0, kw0 = 0, cu0 = 0;
+        if constexpr (MODE != MODE_GEMM && tap_uniform) {
+            const int tap = (j * 8) / cpt;
+            cu0 = j * 8 - tap * cpt;
+            kh0 = tap / p.KW;
+            kw0 = tap - kh0 * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = j * 8 + cg[i];
+            const int ke = u * VN;
+            const bool kok = ke < p.Ktot;
+            bool ok = kok && rok[i];
+            int64_t off = 0;
+            if constexpr (MODE == MODE_GEMM) {
+                off = (int64_t)rn[i] * p.lda + ke;
+            } else {
+                int kh = kh0, kw = kw0, c0 = (cu0 + cg[i]) * VN;
+                if constexpr (!tap_uniform) {
+                    const int tap = u / cpt;
+                    c0 = (u - tap * cpt) * VN;
+                    kh = tap / p.KW;
+                    kw = tap - kh * p.KW;
+                }
+                if constexpr (MODE == MODE_FWD) {
+                    const int ih = ra[i] + kh, iw = rb[i] + kw;
+                    ok = ok && (unsigned)ih < (unsigned)p.LH && (unsigned)iw < (unsigned)p.LW;
+                    off = (int64_t)(rn[i] + (ih >> p.up) * p.SW + (iw >> p.up)) * p.lda + c0;
+                } else {
+                    const int t = ra[i] - kh, v = rb[i] - kw;
+                    ok = ok && t >= 0 && v >= 0 && ((t | v) & smask) == 0;
+                    const int oh = t >> sshift, ow = v >> sshift;
+                    ok = ok && oh < p.LH && ow < p.LW;
+                    off = (int64_t)(rn[i] + oh * p.SW + ow) * p.lda + c0;
+                }
+            }
+            const T* srcA = ok ? Ag + off : zero;
+            const T* srcB = (kok && bok[i]) ? Bg + boff[i] + ke : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcA,
+                                             (__attribute__((address_space(3))) void*)(sa + i * 8 * GROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcB,
+                                             (__attribute__((address_space(3))) void*)(sa + GOPB + i * 8 * GROW), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = (p.Ktot + BK - 1) / BK;
+    issue(0, 0);
+    __syncthreads();                 // drains the DMA (vmcnt(0)) and publishes the stage
+    for (int j = 0; j < nk; ++j) {
+        const int buf = j & 1;
+        if (j + 1 < nk) issue(j + 1, buf ^ 1);
+        mma_stage_swz<T>(smem + buf * GSTAGEB, smem + buf * GSTAGEB + GOPB, acc, wm, wn, lane);
+        __syncthreads();
+    }
+    nt_epilogue<T>(p, acc, m0, n0, bz, wm, wn, lane);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -251,19 +459,22 @@ struct TnParams {
     int64_t lda, ldb, ldc;
     int taps, jtiles, itiles;
     int SH, SW, LH, LW, DH, DW, KW, stride, pad_t, pad_l, up;
-    int m_per_split;
+    int m_per_split, nsplit;
     int64_t sA, sB, sC;
     int batch_in_z;
 };
 
-template <typename T>
+template <typename T, bool CONV>
 __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
     constexpr int VN = Vec<T>::N;      // 8 (bf16) / 4 (fp32): block edge of the register transpose
     constexpr int BK = Vec<T>::BK;     // 64 / 32 reduction rows per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bx = blockIdx.x;
+    const int per_split = p.itiles * p.jtiles * p.taps;
+    int bx = xcd_remap(blockIdx.x, per_split * p.nsplit);
+    const int split = bx / per_split;       // all tiles/taps of one split are consecutive -> same XCD, same time
+    bx -= split * per_split;
     const int it = bx % p.itiles;
     bx /= p.itiles;
     const int jt = bx % p.jtiles;
@@ -272,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
     const int64_t bz = blockIdx.z;
     const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
     const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
-    const int mbeg = blockIdx.y * p.m_per_split;
+    const int mbeg = split * p.m_per_split;
     const int mend = min(p.Mred, mbeg + p.m_per_split);
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
 
@@ -291,41 +502,45 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
 #pragma unroll
     for (int c = 0; c < VN; ++c) bsum[c] = 0.f;
 
+    // conv gather: pixel coordinates of this thread's first row, advanced by BK rows per stage (no divisions
+    // in the loop); pixel offsets stay 32-bit, one 64-bit multiply-add per row forms the element offset
+    int gn = 0, gy = 0, gx = 0;
+    if constexpr (CONV) {
+        const int hw = p.DH * p.DW;
+        const int mm0 = min(mbeg + mb * VN, p.Mred - 1);
+        gn = mm0 / hw;
+        const int rem = mm0 - gn * hw;
+        gy = rem / p.DW;
+        gx = rem - gy * p.DW;
+    }
+    const int colA = i0 + cb * VN, colB = j0 + cb * VN;
     auto g_load = [&](int ms) {   // ms: first reduction row of the stage
         const int mrow = ms + mb * VN;
         if (doA) {
-            const int col = i0 + cb * VN;
+            const T* src = Ag + (int64_t)mrow * p.lda + colA;
 #pragma unroll
             for (int r = 0; r < VN; ++r) {
-                const int m = mrow + r;
-                const bool ok = m < mend && col < p.I;
-                ra[r] = ok ? *reinterpret_cast<const uint4*>(Ag + (int64_t)m * p.lda + col) : make_uint4(0, 0, 0, 0);
+                const bool ok = mrow + r < mend && colA < p.I;
+                ra[r] = ok ? *reinterpret_cast<const uint4*>(src + (int64_t)r * p.lda) : make_uint4(0, 0, 0, 0);
             }
         }
         if (doB) {
-            const int col = j0 + cb * VN;
-            if (!p.conv) {
+            if constexpr (!CONV) {
+                const T* src = Bg + (int64_t)mrow * p.ldb + colB;
 #pragma unroll
                 for (int r = 0; r < VN; ++r) {
-                    const int m = mrow + r;
-                    const bool ok = m < mend && col < p.J;
-                    rb[r] = ok ? *reinterpret_cast<const uint4*>(Bg + (int64_t)m * p.ldb + col) : make_uint4(0, 0, 0, 0);
+                    const bool ok = mrow + r < mend && colB < p.J;
+                    rb[r] = ok ? *reinterpret_cast<const uint4*>(src + (int64_t)r * p.ldb) : make_uint4(0, 0, 0, 0);
                 }
             } else {
-                // decompose the first row once, then walk (x, y, n) with carries
-                const int hw = p.DH * p.DW;
-                const int mm0 = mrow < p.Mred ? mrow : 0;
-                int n = mm0 / hw;
-                const int rem = mm0 - n * hw;
-                int y = rem / p.DW, x = rem - y * p.DW;
+                int n = gn, y = gy, x = gx;
 #pragma unroll
                 for (int r = 0; r < VN; ++r) {
-                    const int m = mrow + r;
-                    bool ok = m < mend && col < p.J;
+                    bool ok = mrow + r < mend && colB < p.J;
                     const int ih = y * p.stride - p.pad_t + kh, iw = x * p.stride - p.pad_l + kw;
                     ok = ok && (unsigned)ih < (unsigned)p.LH && (unsigned)iw < (unsigned)p.LW;
-                    const int64_t off = (((int64_t)n * p.SH + (ih >> p.up)) * p.SW + (iw >> p.up)) * p.ldb + col;
-                    rb[r] = ok ? *reinterpret_cast<const uint4*>(Bg + off) : make_uint4(0, 0, 0, 0);
+                    const int pix = (n * p.SH + (ih >> p.up)) * p.SW + (iw >> p.up);
+                    rb[r] = ok ? *reinterpret_cast<const uint4*>(Bg + (int64_t)pix * p.ldb + colB) : make_uint4(0, 0, 0, 0);
                     if (++x == p.DW) {
                         x = 0;
                         if (++y == p.DH) {
@@ -334,12 +549,21 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
                         }
                     }
                 }
+                // advance the walk by one stage (BK rows)
+                gx += BK;
+                while (gx >= p.DW) {
+                    gx -= p.DW;
+                    if (++gy == p.DH) {
+                        gy = 0;
+                        ++gn;
+                    }
+                }
             }
         }
     };
-    // register transpose + LDS store: column c of the block becomes LDS row (cb*VN + c), bytes mb*16..
+    // register transpose + LDS store: column c of the block becomes LDS row (cb*VN + c), 16-B chunk mb,
+    // stored at chunk position mb ^ swz_tn(row) of an unpadded 128-B row (conflict-free, see SWZ_TN)
     auto store_op = [&](const uint4 (&rg)[VN], char* sbase) {
-        char* dst = sbase + (cb * VN) * ROWB + mb * 16;
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -349,13 +573,16 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
                     const unsigned x0 = (&rg[2 * v].x)[c >> 1], x1 = (&rg[2 * v + 1].x)[c >> 1];
                     w[v] = (c & 1) ? ((x0 >> 16) | (x1 & 0xffff0000u)) : ((x0 & 0xffffu) | (x1 << 16));
                 }
-                *reinterpret_cast<uint4*>(dst + c * ROWB) = make_uint4(w[0], w[1], w[2], w[3]);
+                const int row = cb * VN + c;
+                *reinterpret_cast<uint4*>(sbase + row * GROW + ((mb ^ swz_tn(row)) << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                *reinterpret_cast<uint4*>(dst + c * ROWB) =
+            for (int c = 0; c < 4; ++c) {
+                const int row = cb * VN + c;
+                *reinterpret_cast<uint4*>(sbase + row * GROW + ((mb ^ swz_tn(row)) << 4)) =
                     make_uint4((&rg[0].x)[c], (&rg[1].x)[c], (&rg[2].x)[c], (&rg[3].x)[c]);
+            }
         }
     };
     auto s_store = [&](int buf) {
@@ -375,9 +602,9 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
                     }
                 }
             }
-            store_op(ra, smem + buf * STAGEB);
+            store_op(ra, smem + buf * GSTAGEB);
         }
-        if (doB) store_op(rb, smem + buf * STAGEB + OPB);
+        if (doB) store_op(rb, smem + buf * GSTAGEB + GOPB);
     };
 
     f32x16 acc[2][2];
@@ -396,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
         for (int j = 0; j < nk; ++j) {
             const int buf = j & 1;
             if (j + 1 < nk) g_load(mbeg + (j + 1) * BK);
-            mma_stage<T>(smem + buf * STAGEB, smem + buf * STAGEB + OPB, acc, wm, wn, lane);
+            mma_stage_swz<T, SWZ_TN>(smem + buf * GSTAGEB, smem + buf * GSTAGEB + GOPB, acc, wm, wn, lane);
             if (j + 1 < nk) s_store(buf ^ 1);
             __syncthreads();
         }
@@ -521,17 +748,33 @@ __global__ void naive_tn_kernel(TnParams p) {
 // launch helpers
 // -------------------------------------------------------------------------------------------------
 template <typename T>
-int launch_nt(const NtParams& p, int64_t batch, int impl, hipStream_t s) {
+int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
     constexpr int VN = Vec<T>::N;
+    p.gm = (int)cdiv64(p.M, TILE);
+    p.gn = (int)cdiv64(p.Ncols, TILE);
     bool mfma_ok = p.Ktot % VN == 0 && p.ldb % VN == 0 && p.lda % VN == 0 && (p.stride == 1 || p.stride == 2);
     if (p.mode == MODE_GEMM) mfma_ok = mfma_ok && (p.sA % VN == 0) && (p.sB % VN == 0);
-    DVQ_REQUIRE(!(impl == 2 && !mfma_ok), DVQ_ESHAPE,
+    DVQ_REQUIRE(!(impl >= 2 && !mfma_ok), DVQ_ESHAPE,
                 "igemm_nt: MFMA path needs K, lda, ldb multiples of %d (K=%d lda=%lld ldb=%lld) and stride 1/2", VN,
                 p.Ktot, (long long)p.lda, (long long)p.ldb);
-    const bool use_mfma = impl == 2 || (impl == 0 && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
-    if (use_mfma) {
-        dim3 grid((unsigned)cdiv64(p.M, TILE), (unsigned)cdiv64(p.Ncols, TILE), (unsigned)batch);
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGEB);
+    DVQ_REQUIRE(!(impl == 3 && !mfma_ok), DVQ_ESHAPE, "igemm_nt: register-staged MFMA path unsupported for this shape");
+    const bool use_mfma = impl == 2 || impl == 3 || (impl == 0 && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
+    if (use_mfma && impl != 3) {
+        dim3 grid((unsigned)(p.gm * p.gn), 1, (unsigned)batch);
+        const bool tapu = p.mode != MODE_GEMM && ((p.lda / VN) % 8) == 0;
+        auto go = [&](auto kern) {
+            dvq_ensure_dynamic_lds((const void*)kern, 2 * GSTAGEB);
+            kern<<<grid, dim3(256), 2 * GSTAGEB, s>>>(p);
+        };
+        if (p.mode == MODE_GEMM) go(igemm_nt_glds_kernel<T, MODE_GEMM, false>);
+        else if (p.mode == MODE_FWD && tapu) go(igemm_nt_glds_kernel<T, MODE_FWD, true>);
+        else if (p.mode == MODE_FWD) go(igemm_nt_glds_kernel<T, MODE_FWD, false>);
+        else if (tapu) go(igemm_nt_glds_kernel<T, MODE_TCONV, true>);
+        else go(igemm_nt_glds_kernel<T, MODE_TCONV, false>);
+        DVQ_CHECK_LAUNCH("igemm_nt_glds");
+    } else if (use_mfma) {
+        dim3 grid((unsigned)(p.gm * p.gn), 1, (unsigned)batch);
+        dvq_ensure_dynamic_lds((const void*)igemm_nt_kernel<T>, 2 * STAGEB);
         igemm_nt_kernel<T><<<grid, dim3(256), 2 * STAGEB, s>>>(p);
         DVQ_CHECK_LAUNCH("igemm_nt");
     } else {
@@ -548,22 +791,29 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
     constexpr int VN = Vec<T>::N;
     constexpr int BK = Vec<T>::BK;
     bool mfma_ok = p.lda % VN == 0 && p.ldb % VN == 0 && p.sA % VN == 0 && p.sB % VN == 0;
-    DVQ_REQUIRE(!(impl == 2 && !mfma_ok), DVQ_ESHAPE, "igemm_tn: MFMA path needs lda, ldb multiples of %d", VN);
-    const bool use_mfma = impl == 2 || (impl == 0 && mfma_ok && (int64_t)p.Mred >= 256);
+    DVQ_REQUIRE(!(impl >= 2 && !mfma_ok), DVQ_ESHAPE, "igemm_tn: MFMA path needs lda, ldb multiples of %d", VN);
+    const bool use_mfma = impl >= 2 || (impl == 0 && mfma_ok && (int64_t)p.Mred >= 256);
     if (use_mfma) {
         p.itiles = (int)cdiv64(p.I, TILE);
         p.jtiles = (int)cdiv64(p.J, TILE);
         const int64_t tiles = (int64_t)p.itiles * p.jtiles * p.taps * batch;
-        int64_t splits = cdiv64(1024, tiles);
+        // 512 resident workgroups (2 per CU): aim at two full rounds, never slightly more than a round
+        int64_t splits = 1024 / tiles;
         const int64_t max_splits = cdiv64(p.Mred, 4 * BK);
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
         int64_t mps = cdiv64(cdiv64(p.Mred, splits), BK) * BK;
         splits = cdiv64(p.Mred, mps);
         p.m_per_split = (int)mps;
-        dim3 grid((unsigned)(p.itiles * p.jtiles * p.taps), (unsigned)splits, (unsigned)batch);
-        (void)hipFuncSetAttribute((const void*)igemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGEB);
-        igemm_tn_kernel<T><<<grid, dim3(256), 2 * STAGEB, s>>>(p);
+        p.nsplit = (int)splits;
+        dim3 grid((unsigned)(p.itiles * p.jtiles * p.taps * splits), 1, (unsigned)batch);
+        if (p.conv) {
+            dvq_ensure_dynamic_lds((const void*)igemm_tn_kernel<T, true>, 2 * GSTAGEB);
+            igemm_tn_kernel<T, true><<<grid, dim3(256), 2 * GSTAGEB, s>>>(p);
+        } else {
+            dvq_ensure_dynamic_lds((const void*)igemm_tn_kernel<T, false>, 2 * GSTAGEB);
+            igemm_tn_kernel<T, false><<<grid, dim3(256), 2 * GSTAGEB, s>>>(p);
+        }
         DVQ_CHECK_LAUNCH("igemm_tn");
     } else {
         int64_t nout = (int64_t)p.I * p.taps * p.J + (p.colsumA ? p.I : 0);

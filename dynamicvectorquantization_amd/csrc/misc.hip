@@ -16,6 +16,18 @@ void dvq_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+#include <mutex>
+#include <vector>
+void dvq_ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : done)
+        if (e.first == kernel && e.second >= bytes) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.emplace_back(kernel, bytes);
+}
+
 namespace {
 
 constexpr unsigned MAXB = 8192;

@@ -245,17 +245,21 @@ __global__ void vq_flag_all_kernel(VqWs* ws, int64_t N) {
     if (i < N) ws->list[i] = (int)i;
 }
 
-// fp64 exact re-rank of flagged rows: one block per flagged row (grid-stride), wave per code.
+// fp64 exact re-rank of flagged rows: one 1024-thread block per flagged row (grid-stride); 8 lanes share a
+// code (each 4 consecutive dims per step -> 128-B coalesced codebook reads), 8 codes per wave at a time.
+constexpr int RR_THREADS = 1024;
 template <typename XT>
-__global__ __launch_bounds__(256) void vq_rerank_fp64_kernel(const XT* __restrict__ x, const float* __restrict__ cb,
-                                                             int64_t K, int64_t D, int64_t* __restrict__ idx_out,
-                                                             const VqWs* ws) {
+__global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __restrict__ x,
+                                                                    const float* __restrict__ cb, int64_t K, int64_t D,
+                                                                    int64_t* __restrict__ idx_out, const VqWs* ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* xs = reinterpret_cast<double*>(smem);            // [D]
-    double* wbest = xs + D;                                  // [4]
-    int* widx = reinterpret_cast<int*>(wbest + 4);           // [4]
+    double* wbest = xs + D;                                  // [16]
+    int* widx = reinterpret_cast<int*>(wbest + 16);          // [16]
     const int cnt = ws->count;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 3, sub = lane & 7;
+    constexpr int NW = RR_THREADS / 64;
     for (int f = blockIdx.x; f < cnt; f += gridDim.x) {
         const int64_t row = ws->list[f];
         __syncthreads();
@@ -263,16 +267,33 @@ __global__ __launch_bounds__(256) void vq_rerank_fp64_kernel(const XT* __restric
         __syncthreads();
         double best = __builtin_inf();
         int bi = 0x7fffffff;
-        for (int64_t k = wave; k < K; k += 4) {
+        for (int64_t k0 = (int64_t)wave * 8; k0 < K; k0 += NW * 8) {
+            const int64_t k = k0 + grp;
             double acc = 0.0;
-            for (int64_t d = lane; d < D; d += 64) {
-                double t = xs[d] - (double)cb[k * D + d];
-                acc = fma(t, t, acc);
+            if (k < K) {
+                for (int64_t d = sub; d < D; d += 8) {          // generic D; 8 lanes cover 8 consecutive dims
+                    double t = xs[d] - (double)cb[k * D + d];
+                    acc = fma(t, t, acc);
+                }
+            } else {
+                acc = __builtin_inf();
             }
-            acc = wave_sum(acc);
-            if (acc < best) {   // k increasing within a wave -> first minimum kept
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if (acc < best) {    // k increasing per lane group -> first minimum kept
                 best = acc;
                 bi = (int)k;
+            }
+        }
+        // combine the 8 groups of the wave (lexicographic on (distance, index))
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            double ob = __shfl_xor(best, o, 64);
+            int oi = __shfl_xor(bi, o, 64);
+            if (ob < best || (ob == best && oi < bi)) {
+                best = ob;
+                bi = oi;
             }
         }
         if (lane == 0) {
@@ -283,7 +304,7 @@ __global__ __launch_bounds__(256) void vq_rerank_fp64_kernel(const XT* __restric
         if (threadIdx.x == 0) {
             double b = wbest[0];
             int i = widx[0];
-            for (int w = 1; w < 4; ++w)
+            for (int w = 1; w < NW; ++w)
                 if (wbest[w] < b || (wbest[w] == b && widx[w] < i)) {
                     b = wbest[w];
                     i = widx[w];
@@ -355,36 +376,53 @@ __global__ __launch_bounds__(256) void vq_embed_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 // EMA statistics: one block per code, deterministic (rows are visited in index order, no atomics).
 // ---------------------------------------------------------------------------------------------
+constexpr int EMA_SLICE = 1024;   // rows per (code, slice) work item
+
+// One wave per (code k, slice of EMA_SLICE rows): scan the slice's indices 64 at a time (all loads issued
+// up front), accumulate the matching rows, flush with one fp32 atomic per dimension.  Work per wave is
+// bounded by the slice even when code usage is extremely skewed (untrained codebooks).
 template <typename T>
-__global__ __launch_bounds__(256) void vq_ema_stats_kernel(const T* __restrict__ x, const int64_t* __restrict__ idx,
-                                                           int64_t N, int64_t K, int64_t D,
-                                                           float* __restrict__ stats) {
+__global__ __launch_bounds__(64) void vq_ema_stats_kernel(const T* __restrict__ x, const int64_t* __restrict__ idx,
+                                                          int64_t N, int64_t K, int64_t D,
+                                                          float* __restrict__ stats) {
     const int64_t k = blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};   // dims threadIdx.x + 256*j, D <= 1024
+    const int64_t nbeg = (int64_t)blockIdx.y * EMA_SLICE, nend = min(N, nbeg + EMA_SLICE);
+    const int lane = threadIdx.x;
+    constexpr int NCH = EMA_SLICE / 64;
+    unsigned long long hit[NCH];
     int count = 0;
-    for (int64_t n0 = 0; n0 < N; n0 += 64) {
-        const int64_t n = n0 + lane;
-        const bool hit = n < N && idx[n] == k;
-        unsigned long long m = __ballot(hit);
-        count += __popcll(m);
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const int64_t n = nbeg + q * 64 + lane;
+        const bool h = n < nend && idx[n] == k;
+        hit[q] = __ballot(h);
+        count += __popcll(hit[q]);
+    }
+    if (count == 0) return;
+    constexpr int MAXJ = 16;                 // D <= 1024
+    float acc[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        unsigned long long m = hit[q];
         while (m) {
             const int b = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const T* row = x + (n0 + b) * D;
+            const T* row = x + (nbeg + q * 64 + b) * D;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t d = threadIdx.x + 256 * j;
+            for (int j = 0; j < MAXJ; ++j) {
+                const int64_t d = lane + 64 * j;
                 if (d < D) acc[j] += ElemIO<T>::load(row + d);
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t d = threadIdx.x + 256 * j;
-        if (d < D) stats[k * (D + 1) + d] = acc[j];
+    for (int j = 0; j < MAXJ; ++j) {
+        const int64_t d = lane + 64 * j;
+        if (d < D) atomicAdd(stats + k * (D + 1) + d, acc[j]);
     }
-    if (threadIdx.x == 0) stats[k * (D + 1) + D] = (float)count;
+    if (lane == 0) atomicAdd(stats + k * (D + 1) + D, (float)count);
 }
 
 __global__ __launch_bounds__(256) void vq_ema_update_kernel(const float* __restrict__ stats,
@@ -447,8 +485,7 @@ static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_
             constexpr int KS = decltype(ksteps)::value;
             constexpr int Dc = KS * 16;
             size_t lds = 2 * (2 * 32 * (Dc * 2 + 16)) + 128 * 4;
-            (void)hipFuncSetAttribute((const void*)vq_argmin_mfma_kernel<KS, XT>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            dvq_ensure_dynamic_lds((const void*)vq_argmin_mfma_kernel<KS, XT>, (int)lds);
             vq_argmin_mfma_kernel<KS, XT><<<grid, block, lds, s>>>(x, prep, N, K, idx, ws);
         };
         if (D == 64) launch(std::integral_constant<int, 4>{});
@@ -459,9 +496,9 @@ static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_
         vq_flag_all_kernel<<<dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, s>>>(ws, N);
         DVQ_CHECK_LAUNCH("vq_flag_all");
     }
-    size_t lds = (size_t)D * 8 + 64;
-    int64_t blocks = use_mfma ? 1024 : (N < 65535 ? N : 65535);
-    vq_rerank_fp64_kernel<XT><<<dim3((unsigned)blocks), dim3(256), lds, s>>>(x, cb, K, D, idx, ws);
+    size_t lds = (size_t)D * 8 + 16 * 8 + 16 * 4;
+    int64_t blocks = use_mfma ? 2048 : (N < 65535 ? N : 65535);
+    vq_rerank_fp64_kernel<XT><<<dim3((unsigned)blocks), dim3(RR_THREADS), lds, s>>>(x, cb, K, D, idx, ws);
     DVQ_CHECK_LAUNCH("vq_rerank_fp64");
     return DVQ_OK;
 }
@@ -494,7 +531,7 @@ int dvq_vq_argmin(const void* x, int x_dtype, const float* codebook, const void*
     DVQ_REQUIRE(x && codebook && idx && ws, DVQ_EINVAL, "dvq_vq_argmin: null pointer");
     DVQ_REQUIRE(N > 0 && K > 0 && D > 0 && N < (1ll << 31) && K < (1ll << 31), DVQ_ESHAPE,
                 "dvq_vq_argmin: bad shape N=%lld K=%lld D=%lld", (long long)N, (long long)K, (long long)D);
-    DVQ_REQUIRE(D * 8 + 64 <= 64 * 1024, DVQ_ESHAPE, "dvq_vq_argmin: D too large");
+    DVQ_REQUIRE(D * 8 + 192 <= 64 * 1024, DVQ_ESHAPE, "dvq_vq_argmin: D too large");
     hipStream_t s = (hipStream_t)stream;
     if (x_dtype == DVQ_F32) return vq_argmin_impl<float>((const float*)x, codebook, prep, N, K, D, idx, ws, impl, s);
     if (x_dtype == DVQ_BF16) return vq_argmin_impl<bf16_t>((const bf16_t*)x, codebook, prep, N, K, D, idx, ws, impl, s);
@@ -540,8 +577,13 @@ int dvq_vq_ema_stats(const void* x, int dtype, const int64_t* idx, int64_t N, in
     DVQ_REQUIRE(x && idx && stats, DVQ_EINVAL, "dvq_vq_ema_stats: null pointer");
     DVQ_REQUIRE(D <= 1024, DVQ_ESHAPE, "dvq_vq_ema_stats: D > 1024 unsupported");
     hipStream_t s = (hipStream_t)stream;
-    DVQ_DISPATCH_DTYPE(dtype, T, vq_ema_stats_kernel<T><<<dim3((unsigned)K), dim3(256), 0, s>>>(
-                                     (const T*)x, idx, N, K, D, stats););
+    if (hipMemsetAsync(stats, 0, (size_t)K * (D + 1) * sizeof(float), s) != hipSuccess) {
+        dvq_set_error("dvq_vq_ema_stats: memset failed");
+        return DVQ_ELAUNCH;
+    }
+    dim3 grid((unsigned)K, (unsigned)cdiv64(N, EMA_SLICE));
+    DVQ_REQUIRE(grid.y <= 65535, DVQ_ESHAPE, "dvq_vq_ema_stats: N too large");
+    DVQ_DISPATCH_DTYPE(dtype, T, vq_ema_stats_kernel<T><<<grid, dim3(64), 0, s>>>((const T*)x, idx, N, K, D, stats););
     DVQ_CHECK_LAUNCH("vq_ema_stats");
     return DVQ_OK;
 }

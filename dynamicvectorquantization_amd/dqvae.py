@@ -249,12 +249,14 @@ class FourierPositionEmbedding(nn.Module):
     def bias_hwc(self, device):
         coord = self.coord.to(device)[0]                                     # [2,h,w]
         w = self.lff.ffm.conv.weight[:, :, 0, 0]                             # [C,2]
-        pre = torch.einsum("ck,khw->hwc", w, coord) + self.lff.ffm.conv.bias
+        # 2 input channels: two broadcast multiply-adds (no GEMM library call)
+        pre = (coord[0].unsqueeze(-1) * w[:, 0] + coord[1].unsqueeze(-1) * w[:, 1]) + self.lff.ffm.conv.bias
         return torch.sin(pre), pre, coord
 
     def accumulate_grad(self, g_hwc, pre, coord):
         gp = g_hwc * torch.cos(pre)                                           # [h,w,C]
-        _grad_buf(self.lff.ffm.conv.weight).add_(torch.einsum("hwc,khw->ck", gp, coord)[:, :, None, None])
+        gw = torch.stack([(gp * coord[0].unsqueeze(-1)).sum(dim=(0, 1)), (gp * coord[1].unsqueeze(-1)).sum(dim=(0, 1))], dim=1)
+        _grad_buf(self.lff.ffm.conv.weight).add_(gw[:, :, None, None])
         _grad_buf(self.lff.ffm.conv.bias).add_(gp.sum(dim=(0, 1)))
 
 

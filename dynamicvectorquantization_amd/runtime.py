@@ -51,7 +51,7 @@ def impl() -> int:
 
 def set_impl(v: int):
     global _impl
-    assert v in (0, 1, 2)
+    assert v in (0, 1, 2, 3)
     _impl = v
 
 

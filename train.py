@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""`train.py` with the reference's command-line surface (train.py:27-50,58-270 of the reference) on the HIP
+path, without pytorch_lightning / OmegaConf:
+
+    python train.py --gpus -1 --base configs/stage1/dqvae-entropy-dual-r05_imagenet.yml --max_epochs 50 \
+        model.params.lossconfig.params.perceptual_weight=0 model.params.lossconfig.params.disc_factor=0
+
+* `-b/--base` YAMLs are merged left to right, then `key.sub=value` overrides (train.py:109-111);
+* `--gpus N|-1|a,b,c`: one process per GPU; when launched under torchrun the env ranks are used, otherwise
+  ranks are spawned here; gradients are averaged with RCCL (`trainer.GradBuckets`);
+* learning rate = ngpu * batch_size * base_learning_rate (train.py:248-257);
+* data: the BASELINE configs run on synthetic batches (`--synthetic`, default); a real
+  `data:` section is instantiated only when its target is importable.
+Unsupported Trainer flags are accepted and ignored with a warning, like unknown Lightning flags would be.
+"""
+from __future__ import annotations
+
+import argparse
+import datetime
+import os
+import sys
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+
+def get_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("-n", "--name", type=str, const=True, default="", nargs="?", help="postfix for logdir")
+    p.add_argument("-r", "--resume", type=str, const=True, default="", nargs="?", help="resume from logdir or checkpoint")
+    p.add_argument("-b", "--base", nargs="*", metavar="base_config.yaml", default=list())
+    p.add_argument("-s", "--seed", type=int, default=2021)
+    p.add_argument("-f", "--postfix", type=str, default="")
+    p.add_argument("-l", "--logger", type=str, default="none")
+    p.add_argument("-d", "--debug", action="store_true")
+    p.add_argument("-p", "--project", type=str, default="dvq")
+    p.add_argument("--save_n", type=int, default=1)
+    p.add_argument("--activate_ddp_share", action="store_true")
+    p.add_argument("--gpus", type=str, default="1")
+    p.add_argument("--max_epochs", type=int, default=1)
+    p.add_argument("--max_steps", type=int, default=-1)
+    p.add_argument("--steps_per_epoch", type=int, default=100, help="synthetic data: batches per epoch")
+    p.add_argument("--synthetic", action="store_true", default=True)
+    p.add_argument("--precision", type=str, default="bf16", help="compute dtype of the HIP path: bf16 | fp32")
+    p.add_argument("--logdir", type=str, default="logs")
+    return p
+
+
+def run(rank, world, opt, unknown):
+    import torch
+    import torch.distributed as dist
+    from dynamicvectorquantization_amd import config as cfg
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.trainer import Trainer
+
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(rank % max(1, torch.cuda.device_count()))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rt.set_compute_dtype(opt.precision)
+    torch.manual_seed(opt.seed)
+
+    dot = [u for u in unknown if "=" in u and not u.startswith("--")]
+    ignored = [u for u in unknown if u not in dot]
+    if ignored and rank == 0:
+        print(f"[train.py] ignoring unsupported Trainer flags: {ignored}")
+    config = cfg.merge(*[cfg.load_yaml(b) for b in opt.base], cfg.from_dotlist(dot))
+    model = cfg.instantiate_from_config(config.model).to(dev)
+
+    bs = config.data.params.batch_size
+    model.steps_per_epoch = opt.steps_per_epoch
+    model.training_steps = opt.steps_per_epoch * opt.max_epochs
+    model.max_epoch = opt.max_epochs
+    if "base_learning_rate" in config.model:
+        model.learning_rate = world * bs * config.model.base_learning_rate
+        if rank == 0:
+            print("Setting learning rate to {:.2e} = {} (num_gpus) * {} (batchsize) * {:.2e} (base_lr)".format(
+                model.learning_rate, world, bs, config.model.base_learning_rate))
+    elif "learning_rate" in config.model:
+        model.learning_rate = config.model.learning_rate
+    else:
+        raise NotImplementedError("Please set learning rate!")
+    model.min_learning_rate = config.model.get("min_learning_rate", 0.)
+
+    size = config.model.params.get("image_size", 256)
+    total = model.training_steps if opt.max_steps < 0 else min(opt.max_steps, model.training_steps)
+    trainer = Trainer(model, max_steps=total, log_every=10 if rank == 0 else 0)
+    pool = [torch.from_numpy(synth.half_flat_images(bs, size, seed=opt.seed + 977 * rank + i)).to(dev) for i in range(4)]
+
+    def batch_fn(step):
+        model.current_epoch = step // opt.steps_per_epoch
+        return {model.image_key: pool[step % len(pool)]}
+
+    trainer.fit(batch_fn)
+    if rank == 0:
+        now = datetime.datetime.now().strftime("%Y-%m-%dT%H-%M-%S")
+        ckptdir = os.path.join(opt.logdir, now + ("_" + opt.name if opt.name else "") + opt.postfix, "checkpoints")
+        os.makedirs(ckptdir, exist_ok=True)
+        torch.save({"state_dict": model.state_dict(), "global_step": model.global_step}, os.path.join(ckptdir, "last.ckpt"))
+        print("saved", os.path.join(ckptdir, "last.ckpt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    opt, unknown = get_parser().parse_known_args()
+    if not opt.base:
+        raise SystemExit("-b/--base <config.yaml> is required")
+    import torch
+    if "WORLD_SIZE" in os.environ:          # launched by torchrun
+        return run(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), opt, unknown)
+    ngpu = torch.cuda.device_count() if opt.gpus.strip() == "-1" else (
+        len([g for g in opt.gpus.split(",") if g.strip() != ""]) if "," in opt.gpus else int(opt.gpus))
+    if ngpu <= 1:
+        return run(0, 1, opt, unknown)
+    import torch.multiprocessing as mp
+    mp.spawn(run, args=(ngpu, opt, unknown), nprocs=ngpu, join=True)
+
+
+if __name__ == "__main__":
+    main()
