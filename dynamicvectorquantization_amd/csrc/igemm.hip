@@ -138,6 +138,76 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[2][
 }
 
 // -------------------------------------------------------------------------------------------------
+// Vectorised NT epilogue: the 128x128 tile goes through LDS (as T) so that global stores and the residual
+// read are full 16-byte accesses along the channel dimension instead of 2-byte scalar accesses.
+// Caller guarantees a preceding __syncthreads() (all MFMA reads of smem are done) and ldc % VN == 0.
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void nt_epilogue_vec(const NtParams& p, f32x16 (&acc)[2][2], char* smem, int m0, int n0,
+                                                int64_t bz, int wm, int wn, int tid) {
+    constexpr int VN = Vec<T>::N;
+    constexpr int ROW = TILE * (int)sizeof(T);          // staged row bytes (256 / 512)
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    T* st = reinterpret_cast<T*>(smem);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int lc = wn * 64 + nt * 32 + l31;
+        const int col = n0 + lc;
+        const float bcol = (p.bias_mode == 1 && col < p.Ncols) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[mt][nt][r] * p.alpha + bcol;
+                if (p.bias_mode == 2 && m0 + lr < p.M) v += p.bias[m0 + lr];
+                ElemIO<T>::store(st + lr * TILE + lc, v);
+            }
+    }
+    __syncthreads();
+    T* __restrict__ Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
+    const T* __restrict__ Rg = p.R ? reinterpret_cast<const T*>(p.R) + bz * p.sC : nullptr;
+    constexpr int CPR = TILE / VN;                       // 16-byte chunks per staged row
+#pragma unroll
+    for (int i = 0; i < (TILE * CPR) / 256; ++i) {
+        const int q = tid + 256 * i;
+        const int lr = q / CPR, ch = q % CPR;
+        const int row = m0 + lr, col = n0 + ch * VN;
+        if (row >= p.M || col >= p.Ncols) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(smem + lr * ROW + ch * 16);
+        const int64_t o = (int64_t)row * p.ldc + col;
+        if (col + VN <= p.Ncols) {
+            if (Rg) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(Rg + o);
+                if constexpr (sizeof(T) == 2) {
+                    unsigned* pv = &v.x;
+                    const unsigned* pr = &rv.x;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lo = __uint_as_float(pv[k] << 16) + __uint_as_float(pr[k] << 16);
+                        const float hi = __uint_as_float(pv[k] & 0xffff0000u) + __uint_as_float(pr[k] & 0xffff0000u);
+                        pv[k] = pack_bf16x2(lo, hi);
+                    }
+                } else {
+                    float* pv = reinterpret_cast<float*>(&v.x);
+                    const float* pr = reinterpret_cast<const float*>(&rv.x);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pv[k] += pr[k];
+                }
+            }
+            *reinterpret_cast<uint4*>(Cg + o) = v;
+        } else {      // ragged last chunk of a row (Ncols % VN != 0): element-wise
+            const T* sv = reinterpret_cast<const T*>(&v);
+            for (int k = 0; k < VN && col + k < p.Ncols; ++k) {
+                float f = ElemIO<T>::load(sv + k);
+                if (Rg) f += ElemIO<T>::load(Rg + o + k);
+                ElemIO<T>::store(Cg + o + k, f);
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // NT kernel
 // -------------------------------------------------------------------------------------------------
 template <typename T>
@@ -443,7 +513,11 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
         mma_stage_swz<T>(smem + buf * GSTAGEB, smem + buf * GSTAGEB + GOPB, acc, wm, wn, lane);
         __syncthreads();
     }
-    nt_epilogue<T>(p, acc, m0, n0, bz, wm, wn, lane);
+    if ((p.ldc % VN) == 0) {
+        nt_epilogue_vec<T>(p, acc, smem, m0, n0, bz, wm, wn, tid);     // LDS-staged, 16-byte global accesses
+    } else {
+        nt_epilogue<T>(p, acc, m0, n0, bz, wm, wn, lane);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
