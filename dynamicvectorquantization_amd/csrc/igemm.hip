@@ -727,6 +727,190 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// TN kernel, bf16, LDS-DMA staging + hardware transpose reads (ds_read_b64_tr_b16).
+// Both operand tiles stay in their natural [reduction row m][channel] layout (256-B rows filled by
+// global_load_lds), and the MFMA fragments -- which need 8 consecutive m for one channel per lane -- are
+// formed by two transpose reads each: within a 16-lane group, lanes 4r..4r+3 address row r (8 B each) of a
+// 4-row x 16-channel block and lane i receives column i (probed on hardware, tools/probes/tr_probe.hip).
+// Swizzle: 16-B chunk c of row r lives at chunk position c ^ ((r & 3) << 2), so the 4 rows x 64 B that one
+// 32-lane half reads cover all 64 banks exactly once.
+// -------------------------------------------------------------------------------------------------
+constexpr int TROW = 256;              // LDS row bytes: 128 bf16 channels
+constexpr int TOPB = 64 * TROW;        // 64 reduction rows per stage and operand
+constexpr int TSTAGEB = 2 * TOPB;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void igemm_tn_tr_kernel(TnParams p) {
+    using T = bf16_t;
+    constexpr int BK = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int per_split = p.itiles * p.jtiles * p.taps;
+    int bx = xcd_remap(blockIdx.x, per_split * p.nsplit);
+    const int split = bx / per_split;
+    bx -= split * per_split;
+    const int it = bx % p.itiles;
+    bx /= p.itiles;
+    const int jt = bx % p.jtiles;
+    const int tap = bx / p.jtiles;
+    const int i0 = it * TILE, j0 = jt * TILE;
+    const int64_t bz = blockIdx.z;
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
+    const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
+    const T* zero = reinterpret_cast<const T*>(g_zero_page);
+    const int mbeg = split * p.m_per_split;
+    const int mend = min(p.Mred, mbeg + p.m_per_split);
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+
+    // ---- loader: DMA piece i of this wave = stage rows (wave*4 + i)*4 .. +3, lane -> (row lr, chunk position) ----
+    const int lr = lane >> 4, cpos = lane & 15;
+    const int cg = cpos ^ (lr << 2);               // source chunk of this lane (stage rows of a piece are 4-aligned)
+    const int colA = i0 + cg * 8, colB = j0 + cg * 8;
+    const bool cokA = colA < p.I, cokB = colB < p.J;
+    int gn[4], gy[4], gx[4];
+    if constexpr (CONV) {
+        const int hw = p.DH * p.DW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = min(mbeg + (wave * 4 + i) * 4 + lr, p.Mred - 1);
+            gn[i] = m / hw;
+            const int rem = m - gn[i] * hw;
+            gy[i] = rem / p.DW;
+            gx[i] = rem - gy[i] * p.DW;
+        }
+    }
+    auto issue = [&](int ms, int buf) {            // ms: first reduction row of the stage
+        char* sa = smem + buf * TSTAGEB + wave * 16 * TROW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = ms + (wave * 4 + i) * 4 + lr;
+            const bool okm = m < mend;
+            const T* srcA = (okm && cokA) ? Ag + (int64_t)m * p.lda + colA : zero;
+            const T* srcB;
+            if constexpr (!CONV) {
+                srcB = (okm && cokB) ? Bg + (int64_t)m * p.ldb + colB : zero;
+            } else {
+                const int ih = gy[i] * p.stride - p.pad_t + kh, iw = gx[i] * p.stride - p.pad_l + kw;
+                const bool ok = okm && cokB && (unsigned)ih < (unsigned)p.LH && (unsigned)iw < (unsigned)p.LW;
+                const int pix = (gn[i] * p.SH + (ih >> p.up)) * p.SW + (iw >> p.up);
+                srcB = ok ? Bg + (int64_t)pix * p.ldb + colB : zero;
+                gx[i] += BK;                       // walk to the next stage (BK rows further), no divisions
+                while (gx[i] >= p.DW) {
+                    gx[i] -= p.DW;
+                    if (++gy[i] == p.DH) {
+                        gy[i] = 0;
+                        ++gn[i];
+                    }
+                }
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcA,
+                                             (__attribute__((address_space(3))) void*)(sa + i * 4 * TROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcB,
+                                             (__attribute__((address_space(3))) void*)(sa + TOPB + i * 4 * TROW), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addressing (per lane constants) ----
+    const int g = lane >> 4, li = lane & 15;
+    const int frow = 8 * (g >> 1) + (li >> 2);                 // + ks*16 + 4*t (multiples of 4: swizzle term unchanged)
+    const int fz = ((li >> 2) & 3) << 2;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int chA = wm * 8 + t * 4 + 2 * (g & 1) + ((li & 3) >> 1);
+        const int chB = wn * 8 + t * 4 + 2 * (g & 1) + ((li & 3) >> 1);
+        offA[t] = frow * TROW + ((chA ^ fz) << 4) + (li & 1) * 8;
+        offB[t] = frow * TROW + ((chB ^ fz) << 4) + (li & 1) * 8;
+    }
+    const bool do_bias = p.colsumA != nullptr && tap == 0 && jt == 0 && wn == 0;
+    float bsum[2] = {0.f, 0.f};
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto frag = [&](const char* base, int off, int ks) -> bf16x8 {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off + (ks * 16) * TROW));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off + (ks * 16 + 4) * TROW));
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = lo[j];
+            v[4 + j] = hi[j];
+        }
+        return v;
+    };
+
+    const int nk = (mend - mbeg + BK - 1) / BK;
+    if (nk > 0) {
+        issue(mbeg, 0);
+        __syncthreads();
+        for (int j = 0; j < nk; ++j) {
+            const int buf = j & 1;
+            if (j + 1 < nk) issue(mbeg + (j + 1) * BK, buf ^ 1);
+            const char* sA = smem + buf * TSTAGEB;
+            const char* sB = sA + TOPB;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[t] = frag(sA, offA[t], ks);
+                    b[t] = frag(sB, offB[t], ks);
+                }
+                if (do_bias) {
+                    // (element-wise extraction from a __bf16 vector mis-compiles to element 0 here: go through uint4)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const uint4 u = __builtin_bit_cast(uint4, a[t]);
+                        bsum[t] += (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) +
+                                   (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u)) +
+                                   (__uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u)) +
+                                   (__uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u));
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ Cg = p.C + bz * p.sC;
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = j0 + wn * 64 + nt * 32 + l31;
+        if (col >= p.J) continue;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < p.I) atomicAdd(Cg + (int64_t)row * p.ldc + (int64_t)tap * p.J + col, acc[mt][nt][r]);
+            }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);    // the two lane halves hold different m
+            const int col = i0 + wm * 64 + t * 32 + l31;
+            if (half == 0 && col < p.I) atomicAdd(p.colsumA + col, v);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // naive kernels (any shape; used for validation, tiny shapes and as the loud fallback of impl=1)
 // -------------------------------------------------------------------------------------------------
 template <typename T>
@@ -881,7 +1065,15 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
         p.m_per_split = (int)mps;
         p.nsplit = (int)splits;
         dim3 grid((unsigned)(p.itiles * p.jtiles * p.taps * splits), 1, (unsigned)batch);
-        if (p.conv) {
+        if (sizeof(T) == 2 && impl != 3) {      // LDS-DMA + transpose-read kernel
+            if (p.conv) {
+                dvq_ensure_dynamic_lds((const void*)igemm_tn_tr_kernel<true>, 2 * TSTAGEB);
+                igemm_tn_tr_kernel<true><<<grid, dim3(256), 2 * TSTAGEB, s>>>(p);
+            } else {
+                dvq_ensure_dynamic_lds((const void*)igemm_tn_tr_kernel<false>, 2 * TSTAGEB);
+                igemm_tn_tr_kernel<false><<<grid, dim3(256), 2 * TSTAGEB, s>>>(p);
+            }
+        } else if (p.conv) {
             dvq_ensure_dynamic_lds((const void*)igemm_tn_kernel<T, true>, 2 * GSTAGEB);
             igemm_tn_kernel<T, true><<<grid, dim3(256), 2 * GSTAGEB, s>>>(p);
         } else {
