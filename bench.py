@@ -159,13 +159,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    n_timed_launches = 0
     for i in range(args.warmup):
+        if i == args.warmup - 1:
+            K.profile_count_start()
         trainer.train_step(batches[i % nb], i)
+    n_timed_launches = K.profile_count_stop() if args.warmup > 0 else 1200
     barrier()
-    K.profile_start()
+    K.profile_start(max_launches=(n_timed_launches + 8) * args.steps)     # events created outside the timed region
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         trainer.train_step(batches[i % nb], args.warmup + i)
+    host_issue = time.perf_counter() - t0          # time the host needed to enqueue all steps (no sync inside)
     barrier()
     dt_ = time.perf_counter() - t0
     prof = K.profile_stop()
@@ -201,6 +207,7 @@ def main():
                                     "full backward + Adam; LPIPS and PatchGAN terms not yet on the HIP path (not counted)",
                        "global_batch": world * args.bs, "parallelism": f"dp{world}", "fine_ratio": ratio},
             "ae_mfma_frac": round(ips / world * AE_TRAIN_FLOP_PER_IMG / PEAK_BF16, 4),
+            "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 2),
             "roofline": roofline,
             "kernel_families": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                     "TFLOPs": round(v["TFLOPs"], 2)} for k, v in fam.items()},

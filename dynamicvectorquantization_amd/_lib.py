@@ -19,6 +19,11 @@ class ConvDesc(C.Structure):
                 ("dtype", i32), ("impl", i32)]
 
 
+class PackEntry(C.Structure):
+    _fields_ = [("master", vp), ("w", vp), ("wt", vp), ("Cout", i64), ("Cin", i64), ("taps", i64), ("Cin_p", i64),
+                ("Cout_p", i64), ("begin", i64), ("dtype", i64)]
+
+
 # name -> (restype, argtypes); mirrors include/dvq_hip.h one to one
 SIGNATURES = {
     "dvq_last_error": (C.c_char_p, []),
@@ -41,6 +46,8 @@ SIGNATURES = {
     "dvq_conv2d_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
     "dvq_conv2d_dgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
     "dvq_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
+    "dvq_conv2d_wgrad_oihw": (i32, [C.POINTER(ConvDesc), vp, vp, i64, i64, vp, vp, i32, vp]),
+    "dvq_pack_weights_multi": (i32, [vp, i64, i64, vp]),
     "dvq_pack_weight": (i32, [vp, i64, i64, i64, i64, i64, i64, i32, vp, vp, vp]),
     "dvq_unpack_wgrad": (i32, [vp, i64, i64, i64, i64, i64, vp, vp]),
     "dvq_nchw_to_nhwc_pad": (i32, [vp, i64, i64, i64, i64, i64, i32, vp, vp]),

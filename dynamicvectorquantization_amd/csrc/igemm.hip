@@ -523,6 +523,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
 // -------------------------------------------------------------------------------------------------
 // TN kernel (wgrad / generic).  C fp32, accumulated with atomics; grid.y splits the reduction.
 // -------------------------------------------------------------------------------------------------
+struct TnParams;
+__device__ __forceinline__ int64_t tn_c_offset(const TnParams& p, int row, int tap, int col);
 struct TnParams {
     const void* A;   // [Mred][lda]           (wgrad: dy, lda = Cout)
     const void* B;   // GEMM: [Mred][ldb]; conv: gathered from x (Cs = ldb)
@@ -534,9 +536,15 @@ struct TnParams {
     int taps, jtiles, itiles;
     int SH, SW, LH, LW, DH, DW, KW, stride, pad_t, pad_l, up;
     int m_per_split, nsplit;
+    int c_oihw;      // 1: C is laid out [I][Jc][taps] (element (i, tap, j) at (i*Jc + j)*taps + tap); 0: [I][taps][Jc] with row stride ldc
+    int Jc;          // columns per tap of C (<= J; smaller when the operand channels are padded)
     int64_t sA, sB, sC;
     int batch_in_z;
 };
+
+__device__ __forceinline__ int64_t tn_c_offset(const TnParams& p, int row, int tap, int col) {
+    return p.c_oihw ? ((int64_t)row * p.Jc + col) * p.taps + tap : (int64_t)row * p.ldc + (int64_t)tap * p.Jc + col;
+}
 
 template <typename T, bool CONV>
 __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
@@ -708,13 +716,13 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = j0 + wn * 64 + nt * 32 + l31;
-        if (col >= p.J) continue;
+        if (col >= p.Jc) continue;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < p.I) atomicAdd(Cg + (int64_t)row * p.ldc + (int64_t)tap * p.J + col, acc[mt][nt][r]);
+                if (row < p.I) atomicAdd(Cg + tn_c_offset(p, row, tap, col), acc[mt][nt][r]);
             }
     }
     if (do_bias) {
@@ -891,13 +899,13 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_tr_kernel(TnParams p) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = j0 + wn * 64 + nt * 32 + l31;
-        if (col >= p.J) continue;
+        if (col >= p.Jc) continue;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < p.I) atomicAdd(Cg + (int64_t)row * p.ldc + (int64_t)tap * p.J + col, acc[mt][nt][r]);
+                if (row < p.I) atomicAdd(Cg + tn_c_offset(p, row, tap, col), acc[mt][nt][r]);
             }
     }
     if (do_bias) {
@@ -998,7 +1006,7 @@ __global__ void naive_tn_kernel(TnParams p) {
             acc = fmaf(ElemIO<T>::load(Ag + (int64_t)m * p.lda + i), bv, acc);
         }
         acc = wave_sum(acc);
-        if (lane == 0) atomicAdd(Cg + (int64_t)i * p.ldc + rest, acc);
+        if (lane == 0 && j < p.Jc) atomicAdd(Cg + tn_c_offset(p, i, tap, j), acc);
     }
 }
 
@@ -1161,6 +1169,27 @@ int dvq_conv2d_wgrad(const dvq_conv_desc* d, const void* x, const void* dy, floa
     p.SH = (int)(d->H >> d->upsample); p.SW = (int)(d->W >> d->upsample);
     p.LH = (int)d->H; p.LW = (int)d->W; p.DH = (int)d->OH; p.DW = (int)d->OW;
     p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.up = d->upsample;
+    p.Jc = p.J;
+    if (d->dtype == DVQ_F32) return launch_tn<float>(p, 1, d->impl, (hipStream_t)stream);
+    return launch_tn<bf16_t>(p, 1, d->impl, (hipStream_t)stream);
+}
+
+int dvq_conv2d_wgrad_oihw(const dvq_conv_desc* d, const void* x, const void* dy, int64_t cin_real, int64_t cout_real,
+                          float* grad_oihw, float* dbias, int ohwi, dvq_stream_t stream) {
+    if (int e = conv_check(d, "dvq_conv2d_wgrad_oihw")) return e;
+    DVQ_REQUIRE(x && dy && grad_oihw && cin_real > 0 && cin_real <= d->Cin && cout_real > 0 && cout_real <= d->Cout,
+                DVQ_EINVAL, "dvq_conv2d_wgrad_oihw: bad arguments");
+    TnParams p{};
+    p.A = dy; p.B = x; p.C = grad_oihw; p.colsumA = dbias;
+    p.conv = 1;
+    p.Mred = (int)(d->N * d->OH * d->OW); p.I = (int)cout_real; p.J = (int)d->Cin;   // rows/cols beyond the real counts are padding
+    p.lda = d->Cout; p.ldb = d->Cin; p.ldc = (int64_t)d->KH * d->KW * d->Cin;
+    p.taps = d->KH * d->KW;
+    p.SH = (int)(d->H >> d->upsample); p.SW = (int)(d->W >> d->upsample);
+    p.LH = (int)d->H; p.LW = (int)d->W; p.DH = (int)d->OH; p.DW = (int)d->OW;
+    p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.up = d->upsample;
+    p.c_oihw = ohwi ? 0 : 1; p.Jc = (int)cin_real;
+    if (ohwi) p.ldc = (int64_t)d->KH * d->KW * cin_real;
     if (d->dtype == DVQ_F32) return launch_tn<float>(p, 1, d->impl, (hipStream_t)stream);
     return launch_tn<bf16_t>(p, 1, d->impl, (hipStream_t)stream);
 }
@@ -1198,6 +1227,7 @@ int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred,
     p.Mred = (int)Mred; p.I = (int)I; p.J = (int)J;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.taps = 1; p.KW = 1; p.stride = 1;
+    p.Jc = p.J;
     p.sA = sA; p.sB = sB; p.sC = sC;
     if (dtype == DVQ_F32) return launch_tn<float>(p, batch, impl, (hipStream_t)stream);
     if (dtype == DVQ_BF16) return launch_tn<bf16_t>(p, batch, impl, (hipStream_t)stream);

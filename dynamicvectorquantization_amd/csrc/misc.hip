@@ -30,6 +30,8 @@ void dvq_ensure_dynamic_lds(const void* kernel, int bytes) {
 
 namespace {
 
+__device__ __forceinline__ float master_at(const float* m, int64_t co, int64_t ci, int64_t tap, int64_t Cin, int64_t taps, bool ohwi);
+
 constexpr unsigned MAXB = 8192;
 inline unsigned nblocks(int64_t work, int per_block) {
     int64_t b = cdiv64(work, per_block);
@@ -211,18 +213,62 @@ __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, TO
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ m, int64_t Cout, int64_t Cin,
                                                           int64_t KH, int64_t KW, int64_t Cin_p, int64_t Cout_p,
-                                                          T* __restrict__ w, T* __restrict__ wt) {
+                                                          T* __restrict__ w, T* __restrict__ wt, bool ohwi) {
     const int64_t taps = KH * KW;
     const int64_t nw = w ? Cout * taps * Cin_p : 0, nwt = wt ? Cin * taps * Cout_p : 0;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nw + nwt; e += (int64_t)gridDim.x * 256) {
         if (e < nw) {
             const int64_t ci = e % Cin_p, tap = (e / Cin_p) % taps, co = e / (Cin_p * taps);
-            ElemIO<T>::store(w + e, ci < Cin ? m[(co * Cin + ci) * taps + tap] : 0.f);
+            ElemIO<T>::store(w + e, ci < Cin ? master_at(m, co, ci, tap, Cin, taps, ohwi) : 0.f);
         } else {
             const int64_t f = e - nw;
             const int64_t co = f % Cout_p, tap = (f / Cout_p) % taps, ci = f / (Cout_p * taps);
-            ElemIO<T>::store(wt + f, co < Cout ? m[(co * Cin + ci) * taps + tap] : 0.f);
+            ElemIO<T>::store(wt + f, co < Cout ? master_at(m, co, ci, tap, Cin, taps, ohwi) : 0.f);
         }
+    }
+}
+
+// One launch packs every conv weight of the model (replaces ~340 launches per optimizer step).
+struct PackEntry {       // mirrored by ctypes in _lib.py (7 x int64 + 3 pointers + dtype)
+    const float* master;
+    void* w;
+    void* wt;
+    int64_t Cout, Cin, taps, Cin_p, Cout_p;
+    int64_t begin;       // first flat work index of this entry (prefix sum of nw + nwt)
+    int64_t dtype;       // bit 0: DVQ_F32/DVQ_BF16; bit 8: master is stored [Cout][taps][Cin] (OHWI) instead of OIHW
+};
+
+__device__ __forceinline__ float master_at(const float* m, int64_t co, int64_t ci, int64_t tap, int64_t Cin, int64_t taps, bool ohwi) {
+    return ohwi ? m[(co * taps + tap) * Cin + ci] : m[(co * Cin + ci) * taps + tap];
+}
+
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackEntry* __restrict__ tab, int n, int64_t total) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int lo = 0, hi = n - 1;            // last entry with begin <= e
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[mid].begin <= e) lo = mid; else hi = mid - 1;
+        }
+        const PackEntry t = tab[lo];
+        const int64_t f0 = e - t.begin;
+        const int64_t nw = t.w ? t.Cout * t.taps * t.Cin_p : 0;
+        float v;
+        void* dst;
+        int64_t di;
+        if (f0 < nw) {
+            const int64_t ci = f0 % t.Cin_p, tap = (f0 / t.Cin_p) % t.taps, co = f0 / (t.Cin_p * t.taps);
+            v = ci < t.Cin ? master_at(t.master, co, ci, tap, t.Cin, t.taps, (t.dtype >> 8) & 1) : 0.f;
+            dst = t.w;
+            di = f0;
+        } else {
+            const int64_t f = f0 - nw;
+            const int64_t co = f % t.Cout_p, tap = (f / t.Cout_p) % t.taps, ci = f / (t.Cout_p * t.taps);
+            v = co < t.Cout ? master_at(t.master, co, ci, tap, t.Cin, t.taps, (t.dtype >> 8) & 1) : 0.f;
+            dst = t.wt;
+            di = f;
+        }
+        if ((t.dtype & 0xff) == DVQ_F32) reinterpret_cast<float*>(dst)[di] = v;
+        else reinterpret_cast<bf16_t*>(dst)[di] = f32_to_bf16(v);
     }
 }
 
@@ -426,9 +472,19 @@ int dvq_pack_weight(const float* master, int64_t Cout, int64_t Cin, int64_t KH, 
                     int64_t Cout_p, int dtype, void* w, void* wt, dvq_stream_t stream) {
     DVQ_REQUIRE(master && (w || wt) && Cin_p >= Cin && Cout_p >= Cout, DVQ_EINVAL, "dvq_pack_weight: bad arguments");
     const int64_t n = Cout * KH * KW * Cin_p + Cin * KH * KW * Cout_p;
+    const bool ohwi = (dtype >> 8) & 1;      // bit 8: master stored [Cout][KH][KW][Cin]
+    dtype &= 0xff;
     DVQ_DISPATCH_DTYPE(dtype, T, pack_weight_kernel<T><<<dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(
-                                     master, Cout, Cin, KH, KW, Cin_p, Cout_p, (T*)w, (T*)wt););
+                                     master, Cout, Cin, KH, KW, Cin_p, Cout_p, (T*)w, (T*)wt, ohwi););
     DVQ_CHECK_LAUNCH("pack_weight");
+    return DVQ_OK;
+}
+
+int dvq_pack_weights_multi(const void* table_dev, int64_t n_entries, int64_t total_work, dvq_stream_t stream) {
+    DVQ_REQUIRE(table_dev && n_entries > 0 && n_entries < (1 << 30) && total_work > 0, DVQ_EINVAL, "dvq_pack_weights_multi: bad arguments");
+    pack_weights_multi_kernel<<<dim3(nblocks(total_work, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        (const PackEntry*)table_dev, (int)n_entries, total_work);
+    DVQ_CHECK_LAUNCH("pack_weights_multi");
     return DVQ_OK;
 }
 

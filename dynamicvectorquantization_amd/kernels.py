@@ -39,6 +39,26 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _praw(t):
+    """device pointer of a tensor whose physical layout the caller vouches for (e.g. channel-last weight views)"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.DvqError("libdvq_hip kernels need device tensors (no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def is_ohwi(t) -> bool:
+    """True if a [Cout,Cin,KH,KW]-shaped tensor is physically stored [Cout][KH][KW][Cin] (FlatParams storage);
+    False if it is torch-contiguous.  1x1 kernels are both: reported as contiguous."""
+    if t.is_contiguous():
+        return False
+    co, ci, kh, kw = t.shape
+    if t.stride() == (kh * kw * ci, 1, kw * ci, ci):
+        return True
+    raise _lib.DvqError(f"unsupported weight strides {t.stride()} for shape {tuple(t.shape)}")
+
+
 def _s():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -50,18 +70,35 @@ def lib():
 # ---------------------------------------------------------------------------------------------
 # optional per-kernel-family timing with HIP events on the launch stream (bench.py roofline)
 # ---------------------------------------------------------------------------------------------
-_prof = None
+_prof = None          # {family: [(start_event, end_event, flops, bytes), ...]} while profiling
+_pool = []            # pre-created timing events (hipEventCreate is slow on some hosts: never create in the timed region)
+_count = None         # launch counter (sizing pass)
 
 
-def profile_start():
-    global _prof
+def profile_count_start():
+    """count timed launches without recording anything (used to size the event pool)"""
+    global _count
+    _count = 0
+
+
+def profile_count_stop() -> int:
+    global _count
+    n, _count = _count or 0, None
+    return n
+
+
+def profile_start(max_launches=0):
+    """start recording; `max_launches` timing-event pairs are created up front"""
+    global _prof, _pool
+    _pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * max_launches)]
     _prof = {}
 
 
 def profile_stop():
     """-> {family: dict(launches, ms, flops, bytes)}; synchronises."""
-    global _prof
+    global _prof, _pool
     p, _prof = _prof, None
+    _pool = []
     torch.cuda.synchronize()
     out = {}
     for name, recs in (p or {}).items():
@@ -71,9 +108,12 @@ def profile_stop():
 
 
 def _timed(name, flops, nbytes, fn):
-    if _prof is None:
+    global _count
+    if _count is not None:
+        _count += 1
+    if _prof is None or len(_pool) < 2:
         return fn()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s, e = _pool.pop(), _pool.pop()
     s.record()
     r = fn()
     e.record()
@@ -178,7 +218,7 @@ def gn_forward(x, gamma, beta, groups=32, eps=1e-6, silu=True):
     """x NHWC [N,H,W,C]; returns (y, mean_rstd [N,G,2] fp32)"""
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
-    stats = torch.zeros(n, groups, 2, dtype=torch.float64, device=x.device)
+    stats = zeros_small((n, groups, 2), torch.float64, x.device)
     check(lib().dvq_gn_stats(_p(x), dt(x), n, hw, c, groups, _p(stats), _s()), "dvq_gn_stats")
     y = torch.empty_like(x)
     mr = torch.empty(n, groups, 2, dtype=torch.float32, device=x.device)
@@ -191,7 +231,7 @@ def gn_backward(x, dy, mean_rstd, gamma, beta, dgamma, dbeta, groups=32, silu=Tr
     """dgamma/dbeta (fp32 [C]) are accumulated into; returns dx"""
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
-    red = torch.zeros(n, groups, 2, dtype=torch.float64, device=x.device)
+    red = zeros_small((n, groups, 2), torch.float64, x.device)
     check(lib().dvq_gn_bwd_reduce(_p(x), _p(dy), dt(x), n, hw, c, groups, _p(mean_rstd), _p(gamma), _p(beta), int(silu),
                                   _p(red), _p(dgamma), _p(dbeta), _s()), "dvq_gn_bwd_reduce")
     dx = torch.empty_like(x)
@@ -215,6 +255,13 @@ def pack_weight(master_oihw, cin_p, cout_p, dtype, want_w=True, want_wt=True):
     check(lib().dvq_pack_weight(_p(master_oihw), cout, cin, kh, kw, cin_p, cout_p, dt(dtype), _p(w), _p(wt), _s()),
           "dvq_pack_weight")
     return w, wt
+
+
+def pack_weight_into(master, cin_p, cout_p, dtype, w, wt):
+    cout, cin, kh, kw = master.shape
+    flag = dt(dtype) | (256 if is_ohwi(master) else 0)
+    check(lib().dvq_pack_weight(_praw(master), cout, cin, kh, kw, cin_p, cout_p, flag, _p(w), _p(wt), _s()),
+          "dvq_pack_weight")
 
 
 def unpack_wgrad(dw, grad_oihw, cin_p):
@@ -247,6 +294,47 @@ def conv2d_wgrad(d: ConvDesc, x, dy, db=None):
     _timed("conv_wgrad", fl, nb, lambda: check(
         lib().dvq_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _s()), "dvq_conv2d_wgrad"))
     return dw
+
+
+def conv2d_wgrad_oihw(d: ConvDesc, x, dy, cin_real, cout_real, grad_oihw, db=None):
+    """accumulate the weight gradient straight into the [Cout,Cin,KH,KW] fp32 grad (and db into [Cout])"""
+    fl, nb = _conv_cost(d, x.element_size())
+    _timed("conv_wgrad", fl, nb, lambda: check(
+        lib().dvq_conv2d_wgrad_oihw(C.byref(d), _p(x), _p(dy), cin_real, cout_real, _praw(grad_oihw), _p(db),
+                                    int(is_ohwi(grad_oihw)), _s()), "dvq_conv2d_wgrad_oihw"))
+
+
+def pack_weights_multi(table_dev, n_entries, total_work):
+    check(lib().dvq_pack_weights_multi(_p(table_dev), n_entries, total_work, _s()), "dvq_pack_weights_multi")
+
+
+# ---------------------------------------------------------------------------------------------
+# zero arena: one memset per step instead of one torch.zeros per small statistics buffer
+# ---------------------------------------------------------------------------------------------
+_arena = {"buf": None, "off": 0}
+
+
+def arena_reset(device=None, nbytes=8 << 20):
+    a = _arena
+    if a["buf"] is None or (device is not None and a["buf"].device != torch.device(device)):
+        a["buf"] = torch.zeros(nbytes, dtype=torch.uint8, device=device or "cuda")
+    else:
+        a["buf"].zero_()
+    a["off"] = 0
+
+
+def zeros_small(shape, dtype, device):
+    """zero-initialised small buffer: a slice of the per-step arena when one is active, else torch.zeros"""
+    a = _arena
+    n = 1
+    for s_ in shape:
+        n *= int(s_)
+    nb = (n * torch.empty((), dtype=dtype).element_size() + 255) // 256 * 256
+    if a["buf"] is None or a["buf"].device != torch.device(device) or a["off"] + nb > a["buf"].numel():
+        return torch.zeros(shape, dtype=dtype, device=device)
+    out = a["buf"][a["off"]:a["off"] + nb].view(dtype)[:n].view(shape)
+    a["off"] += nb
+    return out
 
 
 def nchw_to_nhwc_pad(img, cp, dtype):

@@ -156,25 +156,33 @@ class Conv2d(HipModule):
         v = K.vec(dtype)
         return -(-self.in_channels // v) * v, -(-self.out_channels // v) * v
 
+    def _alloc_pack(self, dtype):
+        """persistent packed buffers (stable device pointers: the multi-tensor pack table refers to them)"""
+        cin_p, cout_p = self._padded(dtype)
+        k, dev = self.kernel_size, self.weight.device
+        w = torch.zeros(cout_p, k, k, cin_p, dtype=dtype, device=dev)          # rows >= Cout stay zero
+        wt = torch.zeros(self.in_channels, k, k, cout_p, dtype=dtype, device=dev)
+        bias = None
+        if self.bias is not None and cout_p != self.out_channels:
+            bias = torch.zeros(cout_p, dtype=torch.float32, device=dev)
+        ent = {"epoch": -1, "w": w, "wt": wt, "bias": bias, "cin_p": cin_p, "cout_p": cout_p, "master": self.weight.data_ptr()}
+        self._packs[dtype] = ent
+        PACKS.register(self, dtype)
+        return ent
+
     def packed(self, dtype):
         ent = self._packs.get(dtype)
-        if ent is None or ent[0] != rt.weights_epoch() or ent[1].device != self.weight.device:
-            cin_p, cout_p = self._padded(dtype)
-            w, wt = K.pack_weight(self.weight.detach(), cin_p, cout_p, dtype)
-            if cout_p != self.out_channels:
-                # output channels are padded too (Cout=3 image head): zero rows / zero bias
-                wp = torch.zeros(cout_p, *w.shape[1:], dtype=dtype, device=w.device)
-                wp[: self.out_channels] = w
-                w = wp
-            bias = None
-            if self.bias is not None:
-                bias = self.bias.detach()
-                if cout_p != self.out_channels:
-                    bias = torch.zeros(cout_p, dtype=torch.float32, device=w.device)
-                    bias[: self.out_channels] = self.bias.detach()
-            ent = (rt.weights_epoch(), w, wt, bias)
-            self._packs[dtype] = ent
-        return ent[1], ent[2], ent[3]
+        if ent is None or ent["w"].device != self.weight.device or ent["master"] != self.weight.data_ptr():
+            ent = self._alloc_pack(dtype)
+        if ent["epoch"] != rt.weights_epoch():
+            PACKS.repack(dtype, self.weight.device)      # ONE launch refreshes every registered conv of this dtype/device
+            if ent["epoch"] != rt.weights_epoch():       # not covered by the table yet (first use)
+                K.pack_weight_into(self.weight.detach(), ent["cin_p"], ent["cout_p"], dtype, ent["w"], ent["wt"])
+                ent["epoch"] = rt.weights_epoch()
+            if ent["bias"] is not None:
+                ent["bias"][: self.out_channels] = self.bias.detach()
+        bias = ent["bias"] if ent["bias"] is not None else (self.bias.detach() if self.bias is not None else None)
+        return ent["w"], ent["wt"], bias
 
     def _desc(self, x):
         n, h, w, _ = x.shape
@@ -201,18 +209,58 @@ class Conv2d(HipModule):
 
     def bwd(self, dy, tape, need_dx=True):
         x, d = tape.s["x"], tape.s["d"]
-        cin_p, cout_p = self._padded(x.dtype)
-        direct_bias = self.bias is not None and cout_p == self.out_channels
-        db = _grad_buf(self.bias) if direct_bias else (
-            torch.zeros(cout_p, dtype=torch.float32, device=x.device) if self.bias is not None else None)
-        dw = K.conv2d_wgrad(d, x, dy, db)
-        K.unpack_wgrad(dw, _grad_buf(self.weight), cin_p)
-        if self.bias is not None and not direct_bias:
-            _grad_buf(self.bias).add_(db[: self.out_channels])
+        db = _grad_buf(self.bias) if self.bias is not None else None
+        # weight / bias gradients are accumulated by the kernel straight into the reference-layout .grad buffers
+        K.conv2d_wgrad_oihw(d, x, dy, self.in_channels, self.out_channels, _grad_buf(self.weight), db)
         if not need_dx:
             return None
         _, wt, _ = self.packed(x.dtype)
         return K.conv2d_dgrad(d, dy, wt)
+
+
+class _PackRegistry:
+    """All Conv2d packed-weight buffers of the process; `repack` refreshes every one of them with ONE kernel
+    launch (dvq_pack_weights_multi) after an optimizer step instead of one launch per layer."""
+
+    def __init__(self):
+        self.items = {}       # (dtype, device) -> list of (weakref(module))
+        self.tables = {}      # (dtype, device) -> dict(sig, table tensor, n, total)
+
+    def register(self, mod, dtype):
+        import weakref
+        key = (dtype, mod.weight.device)
+        self.items.setdefault(key, []).append(weakref.ref(mod))
+        self.tables.pop(key, None)
+
+    def repack(self, dtype, device):
+        import ctypes
+        from ._lib import PackEntry
+        key = (dtype, device)
+        mods = [m for m in (r() for r in self.items.get(key, [])) if m is not None and dtype in m._packs]
+        live = [m for m in mods if m._packs[dtype]["master"] == m.weight.data_ptr() and m._packs[dtype]["w"].device == device]
+        if len(live) < 2:
+            return
+        sig = tuple((m.weight.data_ptr(), m._packs[dtype]["w"].data_ptr(), m.weight.stride()) for m in live)
+        tab = self.tables.get(key)
+        if tab is None or tab["sig"] != sig:
+            arr = (PackEntry * len(live))()
+            begin = 0
+            for i, m in enumerate(live):
+                e = m._packs[dtype]
+                k2 = m.kernel_size * m.kernel_size
+                arr[i] = PackEntry(m.weight.data_ptr(), e["w"].data_ptr(), e["wt"].data_ptr(), m.out_channels, m.in_channels,
+                                   k2, e["cin_p"], e["cout_p"], begin, K.dt(dtype) | (256 if K.is_ohwi(m.weight) else 0))
+                begin += m.out_channels * k2 * e["cin_p"] + m.in_channels * k2 * e["cout_p"]
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+            tab = {"sig": sig, "table": raw, "n": len(live), "total": begin}
+            self.tables[key] = tab
+        K.pack_weights_multi(tab["table"], tab["n"], tab["total"])
+        ep = rt.weights_epoch()
+        for m in live:
+            m._packs[dtype]["epoch"] = ep
+
+
+PACKS = _PackRegistry()
 
 
 class Upsample(HipModule):

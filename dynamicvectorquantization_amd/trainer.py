@@ -42,15 +42,81 @@ def scheduler_linear_warmup_cosine_decay(warmup_steps, max_steps, multipler_min)
     return partial(_fn_linear_warmup_cosine_decay, warmup_steps, max_steps, multipler_min)
 
 
-# ---- optimizer ---------------------------------------------------------------------------------------
+# ---- flat parameter / gradient storage -------------------------------------------------------------------
+class FlatParams:
+    """One flat fp32 buffer for the parameters and one for their gradients; every Parameter's .data / .grad is
+    a view into them.  The HIP kernels accumulate gradients in place into the flat buffer, which is also the
+    RCCL all-reduce buffer and the operand of ONE fused Adam launch (instead of one per tensor)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                new = self._view(self.flat_p, off, p)
+                new.copy_(p.data)
+                p.data = new
+                p.grad = self._view(self.flat_g, off, p)
+                off += n
+        rt.bump_weights_epoch()      # parameter storage moved: packed copies must be rebuilt
+
+    @staticmethod
+    def _view(flat, off, p):
+        """view of the flat buffer with p's logical shape; 4-D conv weights are stored channel-last
+        ([Cout][KH][KW][Cin]): the wgrad kernel then accumulates with contiguous atomics and the bf16 forward
+        pack is a plain cast"""
+        n = p.numel()
+        if p.dim() == 4 and p.shape[2] * p.shape[3] > 1:
+            co, ci, kh, kw = p.shape
+            return flat[off:off + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return flat[off:off + n].view(p.shape)
+
+    def attach_grads(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                p.grad = self._view(self.flat_g, off, p)
+            off += n
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        self.attach_grads()
+
+
+# ---- optimizer ------------------------------------------------------------------------------------------
 class HipAdam(torch.optim.Optimizer):
-    """torch.optim.Adam semantics (no weight decay / amsgrad), one fused HIP kernel per parameter tensor."""
+    """torch.optim.Adam semantics (no weight decay / amsgrad).  With `flatten()` (done by the Trainer) the
+    whole parameter set is updated by ONE fused dvq_adam launch; otherwise one launch per tensor."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.flat = None
+        self._fstate = None
+
+    def flatten(self) -> FlatParams:
+        assert len(self.param_groups) == 1, "flatten() supports a single parameter group"
+        if self.flat is None:
+            self.flat = FlatParams(self.param_groups[0]["params"])
+            self._fstate = {"step": 0, "m": torch.zeros_like(self.flat.flat_p), "v": torch.zeros_like(self.flat.flat_p)}
+        return self.flat
 
     @torch.no_grad()
     def step(self, closure=None):
+        if self.flat is not None:
+            g = self.param_groups[0]
+            st = self._fstate
+            st["step"] += 1
+            K.adam_step(self.flat.flat_p, self.flat.flat_g, st["m"], st["v"], g["lr"], g["betas"][0], g["betas"][1],
+                        g["eps"], st["step"])
+            rt.bump_weights_epoch()
+            return
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -68,44 +134,28 @@ class HipAdam(torch.optim.Optimizer):
 
 # ---- data-parallel gradient exchange --------------------------------------------------------------------
 class GradBuckets:
-    """Flat fp32 buckets over a parameter list; .grad of every parameter is a view into its bucket, so the
-    kernels accumulate straight into communication buffers and no copy is needed before the all-reduce."""
+    """All-reduce view of a FlatParams gradient buffer: fixed-size chunks, last layers first (their gradients are
+    final first), launched asynchronously on RCCL's stream."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params_or_flat, bucket_bytes=64 << 20, process_group=None):
+        self.fp = params_or_flat if isinstance(params_or_flat, FlatParams) else FlatParams(params_or_flat)
         self.pg = process_group
-        self.buckets = []
-        cur, cur_n = [], 0
-        for p in self.params:
-            if cur and (cur_n + p.numel()) * 4 > bucket_bytes:
-                self.buckets.append(cur)
-                cur, cur_n = [], 0
-            cur.append(p)
-            cur_n += p.numel()
-        if cur:
-            self.buckets.append(cur)
-        self.flat = []
-        for b in self.buckets:
-            n = sum(p.numel() for p in b)
-            flat = torch.zeros(n, dtype=torch.float32, device=b[0].device)
-            off = 0
-            for p in b:
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
-            self.flat.append(flat)
+        n = self.fp.flat_g.numel()
+        step = max(1, bucket_bytes // 4)
+        self.flat = [self.fp.flat_g[i:min(n, i + step)] for i in range(0, n, step)]
+        self.params = self.fp.params
 
     def zero(self):
-        for f in self.flat:
-            f.zero_()
+        self.fp.zero_grad()
 
     def reduce(self, async_op=True):
         """average gradients over ranks (no-op for world size 1); returns work handles"""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.pg) == 1:
             return []
         ws = dist.get_world_size(self.pg)
+        self.fp.flat_g.div_(ws)
         works = []
-        for f in reversed(self.flat):   # backward fills the last layers' buckets first
-            f.div_(ws)
+        for f in reversed(self.flat):
             works.append(dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op))
         return [w for w in works if w is not None]
 
@@ -127,11 +177,12 @@ class Trainer:
     def __init__(self, model, max_steps, log_every=0):
         self.model, self.max_steps, self.log_every = model, max_steps, log_every
         self.opts, self.scheds = model.configure_optimizers()
-        self.buckets = [GradBuckets(sum((g["params"] for g in o.param_groups), [])) for o in self.opts]
+        self.buckets = [GradBuckets(o.flatten()) for o in self.opts]
 
     def train_step(self, batch, batch_idx):
         m = self.model
         losses = []
+        K.arena_reset(self.buckets[0].fp.flat_g.device)
         for oi, opt in enumerate(self.opts):
             self.buckets[oi].zero()
             loss = m.training_step(batch, batch_idx, oi)

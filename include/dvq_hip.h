@@ -70,8 +70,8 @@ int dvq_vq_backward(const void* g_xq, const void* x, int dtype, const float* cod
 int dvq_vq_embed(const float* codebook, const int64_t* idx, int64_t N, int64_t D, int out_dtype, void* out,
                  dvq_stream_t stream);
 
-/* EMA statistics (quantize2_mask.py:66-84): stats[k*(D+1)+d] += sum of x rows assigned to k,
- * stats[k*(D+1)+D] += count.  stats is a zeroed fp32 [K,D+1] buffer (one fused buffer so the
+/* EMA statistics (quantize2_mask.py:66-84): stats[k*(D+1)+d] = sum of x rows assigned to k,
+ * stats[k*(D+1)+D] = count.  stats is an fp32 [K,D+1] buffer (zeroed by the call; ONE fused buffer so the
  * data-parallel exchange is ONE all-reduce). */
 int dvq_vq_ema_stats(const void* x, int dtype, const int64_t* idx, int64_t N, int64_t K, int64_t D, float* stats,
                      dvq_stream_t stream);
@@ -141,6 +141,20 @@ int dvq_conv2d_dgrad(const dvq_conv_desc* d, const void* dy, const void* wt, voi
 /* dw (fp32 OHWI, ACCUMULATED into -- zero it first) and dbias (fp32 [Cout], accumulated; may be NULL). */
 int dvq_conv2d_wgrad(const dvq_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                      dvq_stream_t stream);
+
+/* Same as dvq_conv2d_wgrad but accumulates straight into the reference-layout gradient
+ * [cout_real][cin_real][KH][KW] (no packed intermediate, no unpack pass); d->Cin / d->Cout are the padded channel
+ * counts of x / dy.  dbias: fp32 [cout_real], accumulated, may be NULL. */
+int dvq_conv2d_wgrad_oihw(const dvq_conv_desc* d, const void* x, const void* dy, int64_t cin_real, int64_t cout_real,
+                          float* grad_oihw, float* dbias, int ohwi, dvq_stream_t stream);
+/* ohwi = 0: grad is [cout][cin][KH][KW] (torch-contiguous parameter); ohwi = 1: grad is stored [cout][KH][KW][cin]
+ * (the trainer's flat storage keeps conv weights and their gradients channel-last: contiguous atomics, no unpack).
+ * dvq_pack_weight(_s_multi) accept the same storage with bit 8 of `dtype` set. */
+
+/* Pack every conv weight of a model in ONE launch.  table_dev: device array of n_entries records
+ * { const float* master; void* w; void* wt; int64 Cout, Cin, taps, Cin_p, Cout_p, begin, dtype } where `begin` is
+ * the exclusive prefix sum of (Cout*taps*Cin_p [if w] + Cin*taps*Cout_p [if wt]) and total_work the full sum. */
+int dvq_pack_weights_multi(const void* table_dev, int64_t n_entries, int64_t total_work, dvq_stream_t stream);
 
 /* weight packing: master fp32 OIHW (the reference's nn.Conv2d parameter layout) -> `dtype`
  * w [Cout][KH][KW][Cin_p] (forward / wgrad layout) and wt [Cin][KH][KW][Cout_p] (dgrad layout), zero padded

@@ -133,10 +133,12 @@ def _dp_worker(rank, world, port, q):
     from dynamicvectorquantization_amd.trainer import GradBuckets
     torch.manual_seed(0)
     params = [torch.nn.Parameter(torch.randn(s)) for s in ((7, 3), (5,), (1000, 33), (2, 2, 2, 2))]
+    w0 = [p.detach().clone() for p in params]
     gb = GradBuckets(params, bucket_bytes=40000)
     assert len(gb.flat) >= 2
     for i, p in enumerate(params):
-        assert p.grad.data_ptr() >= gb.flat[0].data_ptr() or True
+        assert torch.equal(p.detach(), w0[i])         # flattening keeps the values, .data/.grad become views
+        assert p.grad.data_ptr() >= gb.fp.flat_g.data_ptr()
         p.grad.add_(float(rank + 1) * (i + 1))        # kernels accumulate in place into bucket views
     for w in gb.reduce():
         w.wait()
