@@ -1,0 +1,205 @@
+// 3x3 stride-1 pad-1 convolution with an LDS-resident input halo (bf16, gfx950).
+//
+// The generic implicit-GEMM kernel (igemm.hip) streams every operand tile from L2 once per tap: 64 flop per
+// byte of global->LDS traffic, and PMC shows its waves parked on that stream (profiles/r01_v2_conv_probe_pmc.csv).
+// Here a workgroup owns an 8x32 pixel tile x 128 output channels; per 64-channel input chunk the
+// (8+2)x(32+2) pixel halo is DMA'd to LDS ONCE and reused by all 9 taps (a tap is just a row offset of the
+// A-fragment read), only the 128x64 weight slice of each tap is streamed: ~200 flop per byte fetched.
+// Used for the forward pass and -- with the [Cin][3][3][Cout] weight pack read at tap 8-t -- for dgrad.
+//
+// LDS: halo 344 rows x 128 B + 2 weight stages x 16 KiB = 75 KiB -> 2 workgroups per CU.  Rows are unpadded,
+// 16-B chunk c of row r sits at chunk position c ^ ((r >> 1) & 7) (conflict-free b128 fragment reads for any
+// row offset), applied on the DMA source address.  Epilogue: tile staged through LDS, 16-byte stores.
+#include "dvq_common.h"
+
+namespace {
+
+__device__ uint4 h_zero_page[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+
+constexpr int TH = 8, TW = 32;                 // pixel tile
+constexpr int HW_ = TW + 2;                    // halo width
+constexpr int HROWS = (TH + 2) * HW_;          // 340 halo pixels
+constexpr int HPIECES = (HROWS + 7) / 8;       // 43 DMA pieces of 8 rows
+constexpr int ROWB = 128;                      // one 64-channel bf16 chunk
+constexpr int HALOB = HPIECES * 8 * ROWB;      // 44032
+constexpr int BSTAGE = 128 * ROWB;             // 16 KiB: 128 output channels x 64 input channels
+constexpr int LDSB = HALOB + 2 * BSTAGE;       // 76800
+
+struct HaloParams {
+    const bf16_t* X;     // [N,H,W,Cin]
+    const bf16_t* Wt;    // [Cout][9][Cin]
+    bf16_t* Y;           // [N,H,W,Cout]
+    const bf16_t* R;     // residual like Y or null
+    const float* bias;   // [Cout] or null
+    int N, H, W, Cin, Cout;
+    int tiles_x, tiles_y, gn;
+    int flip;            // 1: weight tap index is 8 - tap (dgrad through the [Cin][3][3][Cout] pack)
+};
+
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = id & 7, j = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    char* bst = smem + HALOB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(h_zero_page);
+
+    int wi = xcd_remap(blockIdx.x, p.N * p.tiles_y * p.tiles_x * p.gn);
+    const int nt_blk = wi % p.gn;
+    wi /= p.gn;
+    const int tx = wi % p.tiles_x;
+    wi /= p.tiles_x;
+    const int ty = wi % p.tiles_y;
+    const int n = wi / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = nt_blk * 128;
+    const int64_t img = (int64_t)n * p.H * p.W;
+
+    // DMA lane roles: lane -> (row within an 8-row piece, 16-B chunk position)
+    const int lrow = lane >> 3, cpos = lane & 7;
+
+    const bf16_t* Xn = p.X + img * p.Cin;
+
+    // halo pieces of this wave: wave, wave+4, ...; source pixel / chunk recomputed per channel chunk (cheap, and
+    // keeping 11 offsets live next to 128 accumulator registers would spill)
+    auto issue_halo = [&](int c0) {
+#pragma unroll 1
+        for (int pc = wave; pc < HPIECES; pc += 4) {
+            const int hp = pc * 8 + lrow;
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const bool ok = hp < HROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const int cg = cpos ^ ((hp >> 1) & 7);
+            const bf16_t* src = ok ? Xn + ((int64_t)gy * p.W + gx) * p.Cin + cg * 8 + c0 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(halo + pc * 8 * ROWB), 16, 0, 0);
+        }
+    };
+    auto issue_b = [&](int tap, int c0, int buf) {
+        const int tb = p.flip ? 8 - tap : tap;
+        char* dst = bst + buf * BSTAGE + wave * 32 * ROWB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + lrow;
+            const int cg = cpos ^ ((row >> 1) & 7);
+            const bf16_t* src = (n0 + row < p.Cout) ? p.Wt + ((int64_t)(n0 + row) * 9 + tb) * p.Cin + cg * 8 + c0 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + i * 8 * ROWB), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int swzB = (l31 >> 1) & 7;
+    const int nchunks = p.Cin >> 6;
+    for (int c = 0; c < nchunks; ++c) {
+        const int c0 = c * 64;
+        issue_halo(c0);                 // safe: the barrier that ended the previous chunk's last tap is behind us
+        issue_b(0, c0, 0);
+        __syncthreads();                // vmcnt(0) + barrier: halo and first weight stage have landed
+        for (int tap = 0; tap < 9; ++tap) {
+            const int buf = tap & 1;
+            if (tap + 1 < 9) issue_b(tap + 1, c0, buf ^ 1);
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const char* pa[2];
+            int sa[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int hp = (2 * wave + mt + kh) * HW_ + l31 + kw;
+                pa[mt] = halo + hp * ROWB;
+                sa[mt] = (hp >> 1) & 7;
+            }
+            const char* pb = bst + buf * BSTAGE + l31 * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 a[2], b[4];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    a[mt] = *reinterpret_cast<const bf16x8*>(pa[mt] + (((ks * 2 + half) ^ sa[mt]) << 4));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    b[nt] = *reinterpret_cast<const bf16x8*>(pb + nt * 32 * ROWB + (((ks * 2 + half) ^ swzB) << 4));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: stage the 256 px x 128 co tile as bf16 rows of 256 B, then 16-byte global stores -----------
+    bf16_t* st = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int lc = nt * 32 + l31;
+        const float bcol = (p.bias != nullptr && n0 + lc < p.Cout) ? p.bias[n0 + lc] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lp = (2 * wave + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                st[lp * 128 + lc] = f32_to_bf16(acc[mt][nt][r] + bcol);
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int q = tid + 256 * i;
+        const int lp = q >> 4, ch = q & 15;
+        const int col = n0 + ch * 8;
+        if (col >= p.Cout) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(smem + lp * 256 + ch * 16);
+        const int64_t o = ((img + (int64_t)(y0 + (lp >> 5)) * p.W + x0 + (lp & 31)) * p.Cout) + col;
+        if (p.R) {
+            const uint4 rv = *reinterpret_cast<const uint4*>(p.R + o);
+            unsigned* pv = &v.x;
+            const unsigned* pr = &rv.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = __uint_as_float(pv[k] << 16) + __uint_as_float(pr[k] << 16);
+                const float hi = __uint_as_float(pv[k] & 0xffff0000u) + __uint_as_float(pr[k] & 0xffff0000u);
+                pv[k] = pack_bf16x2(lo, hi);
+            }
+        }
+        *reinterpret_cast<uint4*>(p.Y + o) = v;
+    }
+}
+
+}  // namespace
+
+// Returns 1 if the halo kernel handled the call, 0 if the shape is not eligible (caller falls back to igemm),
+// negative on error.  x: [N,H,W,Cin] bf16; w: rows of [9][Cin]; y: [N,H,W,Cout].
+int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N,
+                         int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, hipStream_t stream) {
+    if (H % TH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
+    if (N * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31) || Cout * 9 * Cin >= (1ll << 31)) return 0;
+    HaloParams p{};
+    p.X = (const bf16_t*)x; p.Wt = (const bf16_t*)w; p.Y = (bf16_t*)y; p.R = (const bf16_t*)residual; p.bias = bias;
+    p.N = (int)N; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout;
+    p.tiles_x = (int)(W / TW); p.tiles_y = (int)(H / TH); p.gn = (int)cdiv64(Cout, 128);
+    p.flip = flip;
+    const int64_t blocks = N * p.tiles_y * p.tiles_x * p.gn;
+    if (blocks >= (1ll << 31)) return 0;
+    dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel, LDSB);
+    conv3x3_halo_kernel<<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        dvq_set_error("conv3x3_halo: launch failed: %s", hipGetErrorString(e));
+        return DVQ_ELAUNCH;
+    }
+    return 1;
+}

@@ -1058,6 +1058,7 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
     constexpr int BK = Vec<T>::BK;
     bool mfma_ok = p.lda % VN == 0 && p.ldb % VN == 0 && p.sA % VN == 0 && p.sB % VN == 0;
     DVQ_REQUIRE(!(impl >= 2 && !mfma_ok), DVQ_ESHAPE, "igemm_tn: MFMA path needs lda, ldb multiples of %d", VN);
+    if (impl == 4) impl = 0;
     const bool use_mfma = impl >= 2 || (impl == 0 && mfma_ok && (int64_t)p.Mred >= 256);
     if (use_mfma) {
         p.itiles = (int)cdiv64(p.I, TILE);
@@ -1115,6 +1116,15 @@ int conv_check(const dvq_conv_desc* d, const char* who) {
 
 }  // namespace
 
+// conv_halo.hip: LDS-resident-halo kernel for 3x3 / stride 1 / pad 1 bf16 convolutions (1 = handled, 0 = not eligible)
+int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N,
+                         int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, hipStream_t stream);
+
+static bool halo_eligible(const dvq_conv_desc* d) {
+    return d->dtype == DVQ_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+           !d->upsample && d->OH == d->H && d->OW == d->W && (d->impl == 0 || d->impl == 4);
+}
+
 // =================================================================================================
 extern "C" {
 
@@ -1122,6 +1132,11 @@ int dvq_conv2d_fwd(const dvq_conv_desc* d, const void* x, const void* w, const f
                    void* y, dvq_stream_t stream) {
     if (int e = conv_check(d, "dvq_conv2d_fwd")) return e;
     DVQ_REQUIRE(x && w && y, DVQ_EINVAL, "dvq_conv2d_fwd: null pointer");
+    if (halo_eligible(d)) {
+        const int rc = dvq_conv3x3_halo_try(x, w, bias, residual, y, d->N, d->H, d->W, d->Cin, d->Cout, 0, (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : DVQ_OK;
+    }
+    DVQ_REQUIRE(d->impl != 4, DVQ_ESHAPE, "dvq_conv2d_fwd: shape not eligible for the halo kernel");
     NtParams p{};
     p.A = x; p.B = w; p.C = y; p.R = residual; p.bias = bias;
     p.mode = MODE_FWD;
@@ -1140,6 +1155,11 @@ int dvq_sumpool2x2(const void* in, int dtype, int64_t N, int64_t h, int64_t w, i
 int dvq_conv2d_dgrad(const dvq_conv_desc* d, const void* dy, const void* wt, void* dx, void* ws, dvq_stream_t stream) {
     if (int e = conv_check(d, "dvq_conv2d_dgrad")) return e;
     DVQ_REQUIRE(dy && wt && dx && (!d->upsample || ws), DVQ_EINVAL, "dvq_conv2d_dgrad: null pointer");
+    if (halo_eligible(d)) {      // dgrad of a 3x3/s1/p1 conv = the same conv over dy with the taps reversed
+        const int rc = dvq_conv3x3_halo_try(dy, wt, nullptr, nullptr, dx, d->N, d->H, d->W, d->Cout, d->Cin, 1, (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : DVQ_OK;
+    }
+    DVQ_REQUIRE(d->impl != 4, DVQ_ESHAPE, "dvq_conv2d_dgrad: shape not eligible for the halo kernel");
     NtParams p{};
     p.A = dy; p.B = wt; p.C = d->upsample ? ws : dx; p.R = nullptr; p.bias = nullptr;
     p.mode = MODE_TCONV;

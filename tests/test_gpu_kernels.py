@@ -277,6 +277,46 @@ def test_conv(dev, case, dtype, impl):
         assert err < gtol * 5, f"{name}: rel-to-max error {err}"
 
 
+HALO_CASES = [(64, 64, 8, 32, 2), (128, 128, 16, 32, 2), (64, 192, 8, 64, 1), (256, 128, 24, 32, 1), (128, 64, 8, 32, 1)]
+
+
+@pytest.mark.parametrize("case", HALO_CASES, ids=lambda c: "-".join(map(str, c)))
+@pytest.mark.parametrize("residual", [False, True])
+def test_conv3x3_halo_kernel(dev, case, residual):
+    """LDS-resident-halo kernel (impl 4) for 3x3/s1/p1 bf16: forward (+bias, +residual) and dgrad vs fp32 reference"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d, Tape
+    cin, cout, h, w_, n = case
+    rs = np.random.RandomState(cin + cout + h)
+    x = bf16_round(rs.standard_normal((n, cin, h, w_)).astype(np.float32))
+    wt = bf16_round((rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
+    b = (0.1 * rs.standard_normal(cout)).astype(np.float32)
+    res = bf16_round(rs.standard_normal((n, cout, h, w_)).astype(np.float32))
+    go = bf16_round(rs.standard_normal((n, cout, h, w_)).astype(np.float32))
+    xr = torch.from_numpy(x).requires_grad_(True)
+    yr = F.conv2d(xr, torch.from_numpy(wt), torch.from_numpy(b), padding=1)
+    if residual:
+        yr = yr + torch.from_numpy(res)
+    (yr * torch.from_numpy(go)).sum().backward()
+    mod = Conv2d(cin, cout, 3, 1, 1).to(dev)
+    with torch.no_grad():
+        mod.weight.copy_(T(wt, dev))
+        mod.bias.copy_(T(b, dev))
+    with rt.compute_dtype_ctx(torch.bfloat16), rt.impl_ctx(4):
+        xh = T(x, dev, torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+        rh = T(res, dev, torch.bfloat16).permute(0, 2, 3, 1).contiguous() if residual else None
+        tape = Tape()
+        y = mod.fwd(xh, tape, residual=rh)
+        dx = mod.bwd(T(go, dev, torch.bfloat16).permute(0, 2, 3, 1).contiguous(), tape)
+    yref = yr.detach().numpy()
+    err = np.abs(y.float().permute(0, 3, 1, 2).cpu().numpy() - yref).max() / np.abs(yref).max()
+    assert err < 2e-2, f"forward rel-to-max error {err}"
+    dref = xr.grad.numpy()
+    derr = np.abs(dx.float().permute(0, 3, 1, 2).cpu().numpy() - dref).max() / np.abs(dref).max()
+    assert derr < 2e-2, f"dgrad rel-to-max error {derr}"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("impl", [1, 2])
 def test_gemm_nt_tn(dev, dtype, impl):
