@@ -203,3 +203,201 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     }
     return 1;
 }
+
+// =================================================================================================
+// wgrad of the same convolution with an LDS-resident halo: dW[co][tap][ci] += sum_px dy[px][co] * x[px+tap][ci].
+// A workgroup (8 waves) owns 128 output channels x 64 input channels x all 9 taps and walks a range of
+// 4x32-pixel tiles; per tile the dy tile (128 px x 128 co) and the x halo (6x34 px x 64 ci) are DMA'd once and
+// serve all 9 taps (a tap is a row offset into the halo).  Both operands stay in their natural [pixel][channel]
+// layout; the MFMA fragments (8 consecutive pixels of one channel per lane) are formed by ds_read_b64_tr_b16.
+// Swizzles: dy rows (256 B): chunk ^ ((row & 3) << 2); halo rows (128 B): chunk ^ (((row >> 1) & 1) << 2).
+// =================================================================================================
+namespace {
+
+constexpr int WTH = 4;                              // pixel tile rows (x 32 columns)
+constexpr int WPX = WTH * TW;                       // 128 pixels
+constexpr int WDYB = WPX * 256;                     // 32 KiB: 128 px x 128 co
+constexpr int WHROWS = (WTH + 2) * HW_;             // 204 halo pixels
+constexpr int WHPIECES = (WHROWS + 7) / 8;          // 26
+constexpr int WHALOB = WHPIECES * 8 * ROWB;         // 26624
+constexpr int WSTAGE = WDYB + WHALOB;               // 59392
+constexpr int WNPIECES = 32 + WHPIECES;             // 58 DMA pieces per stage
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+
+struct WgParams {
+    const bf16_t* X;     // [N,H,W,Cin]
+    const bf16_t* DY;    // [N,H,W,Cout]
+    float* DW;           // fp32 gradient, layout per c_oihw
+    float* DB;           // fp32 [cout_real] or null
+    int N, H, W, Cin, Cout, cin_real, cout_real;
+    int tiles_x, tiles_y, ntiles, gi, gj, nsplit, tiles_per_split;
+    int c_oihw;          // 1: [co][ci][9], 0: [co][9][ci]
+};
+
+__global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = wave & 3, nt = wave >> 2;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(h_zero_page);
+
+    int wi = xcd_remap(blockIdx.x, p.gi * p.gj * p.nsplit);
+    const int split = wi / (p.gi * p.gj);           // the (co-tile, ci-chunk) blocks of one pixel range run together
+    wi -= split * p.gi * p.gj;
+    const int n0 = (wi % p.gi) * 128, j0 = (wi / p.gi) * 64;
+    const int tbeg = split * p.tiles_per_split, tend = min(p.ntiles, tbeg + p.tiles_per_split);
+
+    auto issue = [&](int t, int buf) {
+        const int txy = p.tiles_x * p.tiles_y;
+        const int n = t / txy, rem = t - n * txy;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int y0 = ty * WTH, x0 = tx * TW;
+        const int64_t img = (int64_t)n * p.H * p.W;
+        char* base = smem + buf * WSTAGE;
+#pragma unroll 1
+        for (int pc = wave; pc < WNPIECES; pc += 8) {
+            const bf16_t* src;
+            char* dst;
+            if (pc < 32) {                               // dy: 4 pixel rows of 256 B
+                const int pr = pc * 4 + (lane >> 4);
+                const int cg = (lane & 15) ^ ((pr & 3) << 2);
+                const int col = n0 + cg * 8;
+                src = col < p.Cout ? p.DY + (img + (int64_t)(y0 + (pr >> 5)) * p.W + x0 + (pr & 31)) * p.Cout + col : zero;
+                dst = base + pc * 4 * 256;
+            } else {                                     // x halo: 8 pixel rows of 128 B
+                const int hc = pc - 32;
+                const int hp = hc * 8 + (lane >> 3);
+                const int hy = hp / HW_, hx = hp - hy * HW_;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                const int cg = (lane & 7) ^ (((hp >> 1) & 1) << 2);
+                const bool ok = hp < WHROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                src = ok ? p.X + (img + (int64_t)gy * p.W + gx) * p.Cin + j0 + cg * 8 : zero;
+                dst = base + WDYB + hc * 8 * ROWB;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    // fragment lane constants (transpose reads: lanes 4r..4r+3 of a 16-lane group address row r, 8 B each)
+    const int g = lane >> 4, li = lane & 15;
+    const int frow = 8 * (g >> 1) + (li >> 2);                     // + 4*t + step offsets
+    const int chA = mt * 4 + 2 * (g & 1) + ((li & 3) >> 1);        // 16-B chunk of the dy row (co)
+    const int chB = nt * 4 + 2 * (g & 1) + ((li & 3) >> 1);        // 16-B chunk of the halo row (ci)
+    const int sub = (li & 1) * 8;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bool do_bias = p.DB != nullptr && j0 == 0 && nt == 0;
+    float bsum = 0.f;
+
+    if (tbeg < tend) {
+        issue(tbeg, 0);
+        __syncthreads();
+        for (int t = tbeg; t < tend; ++t) {
+            const int buf = (t - tbeg) & 1;
+            if (t + 1 < tend) issue(t + 1, buf ^ 1);
+            const char* sdy = smem + buf * WSTAGE;
+            const char* shl = sdy + WDYB;
+#pragma unroll 2
+            for (int st = 0; st < 8; ++st) {               // 16 pixels per step: image row rr, half hs
+                const int rr = st >> 1, hs = st & 1;
+                bf16x8 a;
+                {
+                    const int r0 = rr * 32 + hs * 16 + frow;            // dy tile row of the first transpose read
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4_t*)(sdy + r0 * 256 + ((chA ^ ((r0 & 3) << 2)) << 4) + sub));
+                    const int r1 = r0 + 4;
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4_t*)(sdy + r1 * 256 + ((chA ^ ((r1 & 3) << 2)) << 4) + sub));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a[j] = lo[j];
+                        a[4 + j] = hi[j];
+                    }
+                }
+                if (do_bias) {
+                    const uint4 u = __builtin_bit_cast(uint4, a);
+                    bsum += (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) +
+                            (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u)) +
+                            (__uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u)) +
+                            (__uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u));
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap - kh * 3;
+                    const int h0 = (rr + kh) * HW_ + hs * 16 + kw + frow;
+                    const int h1 = h0 + 4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4_t*)(shl + h0 * ROWB + ((chB ^ (((h0 >> 1) & 1) << 2)) << 4) + sub));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4_t*)(shl + h1 * ROWB + ((chB ^ (((h1 >> 1) & 1) << 2)) << 4) + sub));
+                    bf16x8 b;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        b[j] = lo[j];
+                        b[4 + j] = hi[j];
+                    }
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- flush: rows = co (n0 + mt*32 + ...), cols = ci (j0 + nt*32 + lane&31) ------------------------------
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ci = j0 + nt * 32 + l31;
+    if (ci < p.cin_real) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = n0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < p.cout_real) {
+                    const int64_t o = p.c_oihw ? ((int64_t)co * p.cin_real + ci) * 9 + tap
+                                               : ((int64_t)co * 9 + tap) * p.cin_real + ci;
+                    atomicAdd(p.DW + o, acc[tap][r]);
+                }
+            }
+    }
+    if (do_bias) {
+        const float v = bsum + __shfl_xor(bsum, 32, 64);       // the two lane halves hold different pixels
+        const int co = n0 + mt * 32 + l31;
+        if (half == 0 && co < p.cout_real) atomicAdd(p.DB + co, v);
+    }
+}
+
+}  // namespace
+
+// 1 = handled, 0 = not eligible, negative = error
+int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* db, int64_t N, int64_t H, int64_t W,
+                               int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw,
+                               hipStream_t stream) {
+    if (H % WTH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
+    if (N * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31)) return 0;
+    WgParams p{};
+    p.X = (const bf16_t*)x; p.DY = (const bf16_t*)dy; p.DW = dw; p.DB = db;
+    p.N = (int)N; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout;
+    p.cin_real = (int)cin_real; p.cout_real = (int)cout_real;
+    p.tiles_x = (int)(W / TW); p.tiles_y = (int)(H / WTH);
+    p.ntiles = (int)(N * p.tiles_y * p.tiles_x);
+    p.gi = (int)cdiv64(Cout, 128); p.gj = (int)(Cin / 64);
+    int64_t nsplit = 256 / ((int64_t)p.gi * p.gj);         // ~one resident workgroup (8 waves) per CU
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > p.ntiles) nsplit = p.ntiles;
+    p.tiles_per_split = (int)cdiv64(p.ntiles, nsplit);
+    p.nsplit = (int)cdiv64(p.ntiles, p.tiles_per_split);
+    p.c_oihw = c_oihw;
+    dvq_ensure_dynamic_lds((const void*)conv3x3_halo_wgrad_kernel, 2 * WSTAGE);
+    conv3x3_halo_wgrad_kernel<<<dim3((unsigned)(p.gi * p.gj * p.nsplit)), dim3(512), 2 * WSTAGE, stream>>>(p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        dvq_set_error("conv3x3_halo_wgrad: launch failed: %s", hipGetErrorString(e));
+        return DVQ_ELAUNCH;
+    }
+    return 1;
+}

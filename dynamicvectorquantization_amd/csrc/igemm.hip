@@ -1058,7 +1058,6 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
     constexpr int BK = Vec<T>::BK;
     bool mfma_ok = p.lda % VN == 0 && p.ldb % VN == 0 && p.sA % VN == 0 && p.sB % VN == 0;
     DVQ_REQUIRE(!(impl >= 2 && !mfma_ok), DVQ_ESHAPE, "igemm_tn: MFMA path needs lda, ldb multiples of %d", VN);
-    if (impl == 4) impl = 0;
     const bool use_mfma = impl >= 2 || (impl == 0 && mfma_ok && (int64_t)p.Mred >= 256);
     if (use_mfma) {
         p.itiles = (int)cdiv64(p.I, TILE);
@@ -1120,6 +1119,10 @@ int conv_check(const dvq_conv_desc* d, const char* who) {
 int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N,
                          int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, hipStream_t stream);
 
+int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* db, int64_t N, int64_t H, int64_t W,
+                               int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw,
+                               hipStream_t stream);
+
 static bool halo_eligible(const dvq_conv_desc* d) {
     return d->dtype == DVQ_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            !d->upsample && d->OH == d->H && d->OW == d->W && (d->impl == 0 || d->impl == 4);
@@ -1180,6 +1183,12 @@ int dvq_conv2d_wgrad(const dvq_conv_desc* d, const void* x, const void* dy, floa
                      dvq_stream_t stream) {
     if (int e = conv_check(d, "dvq_conv2d_wgrad")) return e;
     DVQ_REQUIRE(x && dy && dw, DVQ_EINVAL, "dvq_conv2d_wgrad: null pointer");
+    if (halo_eligible(d)) {
+        const int rc = dvq_conv3x3_halo_wgrad_try(x, dy, dw, dbias, d->N, d->H, d->W, d->Cin, d->Cout, d->Cin, d->Cout, 0,
+                                                  (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : DVQ_OK;
+    }
+    DVQ_REQUIRE(d->impl != 4, DVQ_ESHAPE, "dvq_conv2d_wgrad: shape not eligible for the halo kernel");
     TnParams p{};
     p.A = dy; p.B = x; p.C = dw; p.colsumA = dbias;
     p.conv = 1;
@@ -1199,6 +1208,12 @@ int dvq_conv2d_wgrad_oihw(const dvq_conv_desc* d, const void* x, const void* dy,
     if (int e = conv_check(d, "dvq_conv2d_wgrad_oihw")) return e;
     DVQ_REQUIRE(x && dy && grad_oihw && cin_real > 0 && cin_real <= d->Cin && cout_real > 0 && cout_real <= d->Cout,
                 DVQ_EINVAL, "dvq_conv2d_wgrad_oihw: bad arguments");
+    if (halo_eligible(d)) {
+        const int rc = dvq_conv3x3_halo_wgrad_try(x, dy, grad_oihw, dbias, d->N, d->H, d->W, d->Cin, d->Cout, cin_real,
+                                                  cout_real, ohwi ? 0 : 1, (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : DVQ_OK;
+    }
+    DVQ_REQUIRE(d->impl != 4, DVQ_ESHAPE, "dvq_conv2d_wgrad_oihw: shape not eligible for the halo kernel");
     TnParams p{};
     p.A = dy; p.B = x; p.C = grad_oihw; p.colsumA = dbias;
     p.conv = 1;

@@ -295,7 +295,8 @@ def test_conv3x3_halo_kernel(dev, case, residual):
     res = bf16_round(rs.standard_normal((n, cout, h, w_)).astype(np.float32))
     go = bf16_round(rs.standard_normal((n, cout, h, w_)).astype(np.float32))
     xr = torch.from_numpy(x).requires_grad_(True)
-    yr = F.conv2d(xr, torch.from_numpy(wt), torch.from_numpy(b), padding=1)
+    wr, br = torch.from_numpy(wt).requires_grad_(True), torch.from_numpy(b).requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=1)
     if residual:
         yr = yr + torch.from_numpy(res)
     (yr * torch.from_numpy(go)).sum().backward()
@@ -315,6 +316,9 @@ def test_conv3x3_halo_kernel(dev, case, residual):
     dref = xr.grad.numpy()
     derr = np.abs(dx.float().permute(0, 3, 1, 2).cpu().numpy() - dref).max() / np.abs(dref).max()
     assert derr < 2e-2, f"dgrad rel-to-max error {derr}"
+    for name, got, ref in (("dw", mod.weight.grad.cpu().numpy(), wr.grad.numpy()), ("db", mod.bias.grad.cpu().numpy(), br.grad.numpy())):
+        e = np.abs(got - ref).max() / np.abs(ref).max()
+        assert e < 2e-2, f"{name} rel-to-max error {e}"
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
