@@ -166,10 +166,12 @@ def main():
         trainer.train_step(batches[i % nb], i)
     n_timed_launches = K.profile_count_stop() if args.warmup > 0 else 1200
     barrier()
-    K.profile_start(max_launches=(n_timed_launches + 8) * args.steps)     # events created outside the timed region
+    K.profile_prepare(n_timed_launches + 16)          # HIP events for ONE step, created outside the timed region
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if i == args.steps - 1:
+            K.profile_start()                         # per-kernel HIP-event timing on the last timed step only
         trainer.train_step(batches[i % nb], args.warmup + i)
     host_issue = time.perf_counter() - t0          # time the host needed to enqueue all steps (no sync inside)
     barrier()
@@ -185,18 +187,18 @@ def main():
         ips = world * args.bs * args.steps / dt_
         fam = {k: dict(v, ms_per_launch=v["ms"] / max(1, v["launches"]),
                        TFLOPs=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0) for k, v in prof.items()}
-        conv = [k for k in fam if k.startswith("conv_")]
-        dom = max(conv, key=lambda k: fam[k]["ms"]) if conv else None
+        conv = [k for k in fam if k != "vq_argmin"]
+        dom = max(conv, key=lambda k: fam[k]["ms"]) if conv else None      # the kernel the step spends most time in
         roofline = None
         if dom:
             v = fam[dom]
             ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
-            roofline = {"kernel": {"conv_fwd": "igemm_nt_kernel<bf16> (forward)", "conv_dgrad": "igemm_nt_kernel<bf16> (dgrad)",
-                                   "conv_wgrad": "igemm_tn_kernel<bf16> (wgrad)"}.get(dom, dom),
+            roofline = {"kernel": dom + "<bf16>" if "igemm" in dom else dom,
                         "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                         "frac": round(ach / (PEAK_BF16 / 1e12), 4), "traffic": None,
                         "launches": v["launches"], "avg_launch_ms": round(v["ms_per_launch"], 4),
-                        "alg_flops_per_launch": v["flops"] / max(1, v["launches"])}
+                        "alg_flops_per_launch": v["flops"] / max(1, v["launches"]),
+                        "timed": "HIP events around every launch of this kernel during the last timed step"}
         out = {
             "metric": METRIC, "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt_ / args.steps * 1e3, 3), "higher_is_better": True,
@@ -209,7 +211,7 @@ def main():
             "ae_mfma_frac": round(ips / world * AE_TRAIN_FLOP_PER_IMG / PEAK_BF16, 4),
             "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 2),
             "roofline": roofline,
-            "kernel_families": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+            "kernel_families": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"], 3),
                                     "TFLOPs": round(v["TFLOPs"], 2)} for k, v in fam.items()},
         }
         if not args.no_vq_microbench:

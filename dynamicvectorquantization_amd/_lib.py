@@ -42,7 +42,7 @@ SIGNATURES = {
     "dvq_gn_stats": (i32, [vp, i32, i64, i64, i64, i32, vp, vp]),
     "dvq_gn_apply": (i32, [vp, i32, i64, i64, i64, i32, f32, vp, vp, vp, i32, vp, vp, vp]),
     "dvq_gn_bwd_reduce": (i32, [vp, vp, i32, i64, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
-    "dvq_gn_bwd_dx": (i32, [vp, vp, i32, i64, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp]),
+    "dvq_gn_bwd_dx": (i32, [vp, vp, i32, i64, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     "dvq_conv2d_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
     "dvq_conv2d_dgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
     "dvq_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),

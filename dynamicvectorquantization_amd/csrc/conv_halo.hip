@@ -34,6 +34,7 @@ struct HaloParams {
     int N, H, W, Cin, Cout;
     int tiles_x, tiles_y, gn;
     int flip;            // 1: weight tap index is 8 - tap (dgrad through the [Cin][3][3][Cout] pack)
+    int up;              // 1: X is stored [N,H/2,W/2,Cin] and read through nearest x2 (Upsample, model.py:50)
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
@@ -60,11 +61,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
     const int n = wi / p.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW, n0 = nt_blk * 128;
     const int64_t img = (int64_t)n * p.H * p.W;
+    const int SWd = p.W >> p.up;                       // stored input width
+    const int64_t simg = (int64_t)n * (p.H >> p.up) * SWd;
 
     // DMA lane roles: lane -> (row within an 8-row piece, 16-B chunk position)
     const int lrow = lane >> 3, cpos = lane & 7;
 
-    const bf16_t* Xn = p.X + img * p.Cin;
+    const bf16_t* Xn = p.X + simg * p.Cin;
 
     // halo pieces of this wave: wave, wave+4, ...; source pixel / chunk recomputed per channel chunk (cheap, and
     // keeping 11 offsets live next to 128 accumulator registers would spill)
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             const bool ok = hp < HROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             const int cg = cpos ^ ((hp >> 1) & 7);
-            const bf16_t* src = ok ? Xn + ((int64_t)gy * p.W + gx) * p.Cin + cg * 8 + c0 : zero;
+            const bf16_t* src = ok ? Xn + ((int64_t)(gy >> p.up) * SWd + (gx >> p.up)) * p.Cin + cg * 8 + c0 : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(halo + pc * 8 * ROWB), 16, 0, 0);
         }
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
 // Returns 1 if the halo kernel handled the call, 0 if the shape is not eligible (caller falls back to igemm),
 // negative on error.  x: [N,H,W,Cin] bf16; w: rows of [9][Cin]; y: [N,H,W,Cout].
 int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N,
-                         int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, hipStream_t stream) {
+                         int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, int up, hipStream_t stream) {
     if (H % TH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
     if (N * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31) || Cout * 9 * Cin >= (1ll << 31)) return 0;
     HaloParams p{};
@@ -192,6 +195,7 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     p.N = (int)N; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout;
     p.tiles_x = (int)(W / TW); p.tiles_y = (int)(H / TH); p.gn = (int)cdiv64(Cout, 128);
     p.flip = flip;
+    p.up = up;
     const int64_t blocks = N * p.tiles_y * p.tiles_x * p.gn;
     if (blocks >= (1ll << 31)) return 0;
     dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel, LDSB);
@@ -232,6 +236,7 @@ struct WgParams {
     int N, H, W, Cin, Cout, cin_real, cout_real;
     int tiles_x, tiles_y, ntiles, gi, gj, nsplit, tiles_per_split;
     int c_oihw;          // 1: [co][ci][9], 0: [co][9][ci]
+    int up;              // 1: X is stored [N,H/2,W/2,Cin] (nearest x2 folded into the halo gather)
 };
 
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) {
@@ -271,7 +276,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
                 const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
                 const int cg = (lane & 7) ^ (((hp >> 1) & 1) << 2);
                 const bool ok = hp < WHROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-                src = ok ? p.X + (img + (int64_t)gy * p.W + gx) * p.Cin + j0 + cg * 8 : zero;
+                const int SWd = p.W >> p.up;
+                src = ok ? p.X + ((int64_t)n * (p.H >> p.up) * SWd + (int64_t)(gy >> p.up) * SWd + (gx >> p.up)) * p.Cin + j0 + cg * 8 : zero;
                 dst = base + WDYB + hc * 8 * ROWB;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
 
 // 1 = handled, 0 = not eligible, negative = error
 int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* db, int64_t N, int64_t H, int64_t W,
-                               int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw,
+                               int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw, int up,
                                hipStream_t stream) {
     if (H % WTH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
     if (N * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31)) return 0;
@@ -392,6 +398,7 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
     p.tiles_per_split = (int)cdiv64(p.ntiles, nsplit);
     p.nsplit = (int)cdiv64(p.ntiles, p.tiles_per_split);
     p.c_oihw = c_oihw;
+    p.up = up;
     dvq_ensure_dynamic_lds((const void*)conv3x3_halo_wgrad_kernel, 2 * WSTAGE);
     conv3x3_halo_wgrad_kernel<<<dim3((unsigned)(p.gi * p.gj * p.nsplit)), dim3(512), 2 * WSTAGE, stream>>>(p);
     hipError_t e = hipGetLastError();

@@ -10,7 +10,8 @@
 
 namespace {
 
-constexpr int GN_ROWS_PER_BLOCK = 1024;   // pixels per block
+// pixels per block: 1024 for large maps; small maps (HW <= 4096) use 64 so that N * HW / rows still fills the chip
+__host__ __device__ inline int gn_rows_per_block(int64_t HW) { return HW > 4096 ? 1024 : 64; }
 
 struct GnGeom {
     int ncol;           // C / 8
@@ -40,9 +41,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
     if (prow < ge.rows_per_pass) {
-        const int64_t p_end = min((int64_t)(blockIdx.x + 1) * GN_ROWS_PER_BLOCK, HW);
+        const int64_t p_end = min((int64_t)(blockIdx.x + 1) * gn_rows_per_block(HW), HW);
         const T* base = x + n * HW * C + col * 8;
-        for (int64_t p = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK + prow; p < p_end; p += ge.rows_per_pass) {
+        for (int64_t p = (int64_t)blockIdx.x * gn_rows_per_block(HW) + prow; p < p_end; p += ge.rows_per_pass) {
             float v[8];
             load8(base + p * C, v);
 #pragma unroll
@@ -96,9 +97,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         sc[j] = r * gamma[c];
         sh[j] = beta[c] - m * sc[j];
     }
-    const int64_t p_end = min((int64_t)(blockIdx.x + 1) * GN_ROWS_PER_BLOCK, HW);
+    const int64_t p_end = min((int64_t)(blockIdx.x + 1) * gn_rows_per_block(HW), HW);
     const int64_t off = n * HW * C + col * 8;
-    for (int64_t p = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK + prow; p < p_end; p += ge.rows_per_pass) {
+    for (int64_t p = (int64_t)blockIdx.x * gn_rows_per_block(HW) + prow; p < p_end; p += ge.rows_per_pass) {
         float v[8];
         load8(x + off + p * C, v);
 #pragma unroll
@@ -136,9 +137,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
             be[j] = beta[c];
             a[j] = b[j] = 0.f;
         }
-        const int64_t p_end = min((int64_t)(blockIdx.x + 1) * GN_ROWS_PER_BLOCK, HW);
+        const int64_t p_end = min((int64_t)(blockIdx.x + 1) * gn_rows_per_block(HW), HW);
         const int64_t off = n * HW * C + col * 8;
-        for (int64_t p = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK + prow; p < p_end; p += ge.rows_per_pass) {
+        for (int64_t p = (int64_t)blockIdx.x * gn_rows_per_block(HW) + prow; p < p_end; p += ge.rows_per_pass) {
             float v[8], g8[8];
             load8(x + off + p * C, v);
             load8(dy + off + p * C, g8);
@@ -177,7 +178,8 @@ template <typename T, bool SILU>
 __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t HW,
                                                         int64_t C, int G, const float* __restrict__ mean_rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const double* __restrict__ red, T* __restrict__ dx) {
+                                                        const double* __restrict__ red, const T* __restrict__ addend,
+                                                        T* __restrict__ dx) {
     const GnGeom ge = gn_geom(C, G);
     const int64_t n = blockIdx.y;
     const int col = threadIdx.x % ge.ncol, prow = threadIdx.x / ge.ncol;
@@ -194,9 +196,9 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x,
         m1[j] = (float)(red[(n * G + g) * 2] / cnt);
         m2[j] = (float)(red[(n * G + g) * 2 + 1] / cnt);
     }
-    const int64_t p_end = min((int64_t)(blockIdx.x + 1) * GN_ROWS_PER_BLOCK, HW);
+    const int64_t p_end = min((int64_t)(blockIdx.x + 1) * gn_rows_per_block(HW), HW);
     const int64_t off = n * HW * C + col * 8;
-    for (int64_t p = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK + prow; p < p_end; p += ge.rows_per_pass) {
+    for (int64_t p = (int64_t)blockIdx.x * gn_rows_per_block(HW) + prow; p < p_end; p += ge.rows_per_pass) {
         float v[8], g8[8];
         load8(x + off + p * C, v);
         load8(dy + off + p * C, g8);
@@ -206,6 +208,12 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x,
             float dz = g8[j];
             if (SILU) dz *= swish_grad(fmaf(xh, ga[j], be[j]));
             v[j] = rs[j] * (dz * ga[j] - m1[j] - xh * m2[j]);
+        }
+        if (addend != nullptr) {       // gradient of a residual branch that joins here (ResnetBlock skip path)
+            float ad[8];
+            load8(addend + off + p * C, ad);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += ad[j];
         }
         store8(dx + off + p * C, v);
     }
@@ -225,7 +233,7 @@ int dvq_gn_stats(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int
                  dvq_stream_t stream) {
     DVQ_REQUIRE(x && stats, DVQ_EINVAL, "dvq_gn_stats: null pointer");
     if (int e = gn_check("dvq_gn_stats", N, HW, C, G)) return e;
-    dim3 grid((unsigned)cdiv64(HW, GN_ROWS_PER_BLOCK), (unsigned)N);
+    dim3 grid((unsigned)cdiv64(HW, gn_rows_per_block(HW)), (unsigned)N);
     DVQ_DISPATCH_DTYPE(dtype, T, gn_stats_kernel<T><<<grid, dim3(256), 2 * G * sizeof(double), (hipStream_t)stream>>>(
                                      (const T*)x, HW, C, G, stats););
     DVQ_CHECK_LAUNCH("gn_stats");
@@ -237,7 +245,7 @@ int dvq_gn_apply(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int
     DVQ_REQUIRE(x && stats && gamma && beta && y, DVQ_EINVAL, "dvq_gn_apply: null pointer");
     if (int e = gn_check("dvq_gn_apply", N, HW, C, G)) return e;
     DVQ_REQUIRE(G <= 256, DVQ_ESHAPE, "dvq_gn_apply: G > 256");
-    dim3 grid((unsigned)cdiv64(HW, GN_ROWS_PER_BLOCK), (unsigned)N);
+    dim3 grid((unsigned)cdiv64(HW, gn_rows_per_block(HW)), (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
     DVQ_DISPATCH_DTYPE(dtype, T, if (silu) gn_apply_kernel<T, true><<<grid, dim3(256), 0, s>>>(
                                      (const T*)x, HW, C, G, eps, stats, gamma, beta, (T*)y, mean_rstd);
@@ -253,7 +261,7 @@ int dvq_gn_bwd_reduce(const void* x, const void* dy, int dtype, int64_t N, int64
     DVQ_REQUIRE(x && dy && mean_rstd && gamma && beta && red && dgamma && dbeta, DVQ_EINVAL,
                 "dvq_gn_bwd_reduce: null pointer");
     if (int e = gn_check("dvq_gn_bwd_reduce", N, HW, C, G)) return e;
-    dim3 grid((unsigned)cdiv64(HW, GN_ROWS_PER_BLOCK), (unsigned)N);
+    dim3 grid((unsigned)cdiv64(HW, gn_rows_per_block(HW)), (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
     size_t lds = 2 * C * sizeof(float);
     DVQ_DISPATCH_DTYPE(dtype, T, if (silu) gn_bwd_reduce_kernel<T, true><<<grid, dim3(256), lds, s>>>(
@@ -266,15 +274,15 @@ int dvq_gn_bwd_reduce(const void* x, const void* dy, int dtype, int64_t N, int64
 
 int dvq_gn_bwd_dx(const void* x, const void* dy, int dtype, int64_t N, int64_t HW, int64_t C, int G,
                   const float* mean_rstd, const float* gamma, const float* beta, int silu, const double* red,
-                  void* dx, dvq_stream_t stream) {
+                  const void* addend, void* dx, dvq_stream_t stream) {
     DVQ_REQUIRE(x && dy && mean_rstd && gamma && beta && red && dx, DVQ_EINVAL, "dvq_gn_bwd_dx: null pointer");
     if (int e = gn_check("dvq_gn_bwd_dx", N, HW, C, G)) return e;
-    dim3 grid((unsigned)cdiv64(HW, GN_ROWS_PER_BLOCK), (unsigned)N);
+    dim3 grid((unsigned)cdiv64(HW, gn_rows_per_block(HW)), (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
     DVQ_DISPATCH_DTYPE(dtype, T, if (silu) gn_bwd_dx_kernel<T, true><<<grid, dim3(256), 0, s>>>(
-                                     (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, (T*)dx);
+                                     (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, (const T*)addend, (T*)dx);
                        else gn_bwd_dx_kernel<T, false><<<grid, dim3(256), 0, s>>>(
-                           (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, (T*)dx););
+                           (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, (const T*)addend, (T*)dx););
     DVQ_CHECK_LAUNCH("gn_bwd_dx");
     return DVQ_OK;
 }

@@ -1117,15 +1117,15 @@ int conv_check(const dvq_conv_desc* d, const char* who) {
 
 // conv_halo.hip: LDS-resident-halo kernel for 3x3 / stride 1 / pad 1 bf16 convolutions (1 = handled, 0 = not eligible)
 int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N,
-                         int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, hipStream_t stream);
+                         int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, int up, hipStream_t stream);
 
 int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* db, int64_t N, int64_t H, int64_t W,
-                               int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw,
+                               int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw, int up,
                                hipStream_t stream);
 
 static bool halo_eligible(const dvq_conv_desc* d) {
     return d->dtype == DVQ_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
-           !d->upsample && d->OH == d->H && d->OW == d->W && (d->impl == 0 || d->impl == 4);
+           d->OH == d->H && d->OW == d->W && (d->impl == 0 || d->impl == 4);
 }
 
 // =================================================================================================
@@ -1136,7 +1136,7 @@ int dvq_conv2d_fwd(const dvq_conv_desc* d, const void* x, const void* w, const f
     if (int e = conv_check(d, "dvq_conv2d_fwd")) return e;
     DVQ_REQUIRE(x && w && y, DVQ_EINVAL, "dvq_conv2d_fwd: null pointer");
     if (halo_eligible(d)) {
-        const int rc = dvq_conv3x3_halo_try(x, w, bias, residual, y, d->N, d->H, d->W, d->Cin, d->Cout, 0, (hipStream_t)stream);
+        const int rc = dvq_conv3x3_halo_try(x, w, bias, residual, y, d->N, d->H, d->W, d->Cin, d->Cout, 0, d->upsample, (hipStream_t)stream);
         if (rc != 0) return rc < 0 ? rc : DVQ_OK;
     }
     DVQ_REQUIRE(d->impl != 4, DVQ_ESHAPE, "dvq_conv2d_fwd: shape not eligible for the halo kernel");
@@ -1159,8 +1159,11 @@ int dvq_conv2d_dgrad(const dvq_conv_desc* d, const void* dy, const void* wt, voi
     if (int e = conv_check(d, "dvq_conv2d_dgrad")) return e;
     DVQ_REQUIRE(dy && wt && dx && (!d->upsample || ws), DVQ_EINVAL, "dvq_conv2d_dgrad: null pointer");
     if (halo_eligible(d)) {      // dgrad of a 3x3/s1/p1 conv = the same conv over dy with the taps reversed
-        const int rc = dvq_conv3x3_halo_try(dy, wt, nullptr, nullptr, dx, d->N, d->H, d->W, d->Cout, d->Cin, 1, (hipStream_t)stream);
-        if (rc != 0) return rc < 0 ? rc : DVQ_OK;
+        // with a folded nearest-x2 upsample the gradient is formed at the upsampled resolution (ws), then 2x2-summed
+        const int rc = dvq_conv3x3_halo_try(dy, wt, nullptr, nullptr, d->upsample ? ws : dx, d->N, d->H, d->W, d->Cout, d->Cin, 1,
+                                            0, (hipStream_t)stream);
+        if (rc < 0) return rc;
+        if (rc == 1) return d->upsample ? dvq_sumpool2x2(ws, d->dtype, d->N, d->H / 2, d->W / 2, d->Cin, dx, stream) : DVQ_OK;
     }
     DVQ_REQUIRE(d->impl != 4, DVQ_ESHAPE, "dvq_conv2d_dgrad: shape not eligible for the halo kernel");
     NtParams p{};
@@ -1185,7 +1188,7 @@ int dvq_conv2d_wgrad(const dvq_conv_desc* d, const void* x, const void* dy, floa
     DVQ_REQUIRE(x && dy && dw, DVQ_EINVAL, "dvq_conv2d_wgrad: null pointer");
     if (halo_eligible(d)) {
         const int rc = dvq_conv3x3_halo_wgrad_try(x, dy, dw, dbias, d->N, d->H, d->W, d->Cin, d->Cout, d->Cin, d->Cout, 0,
-                                                  (hipStream_t)stream);
+                                                  d->upsample, (hipStream_t)stream);
         if (rc != 0) return rc < 0 ? rc : DVQ_OK;
     }
     DVQ_REQUIRE(d->impl != 4, DVQ_ESHAPE, "dvq_conv2d_wgrad: shape not eligible for the halo kernel");
@@ -1210,7 +1213,7 @@ int dvq_conv2d_wgrad_oihw(const dvq_conv_desc* d, const void* x, const void* dy,
                 DVQ_EINVAL, "dvq_conv2d_wgrad_oihw: bad arguments");
     if (halo_eligible(d)) {
         const int rc = dvq_conv3x3_halo_wgrad_try(x, dy, grad_oihw, dbias, d->N, d->H, d->W, d->Cin, d->Cout, cin_real,
-                                                  cout_real, ohwi ? 0 : 1, (hipStream_t)stream);
+                                                  cout_real, ohwi ? 0 : 1, d->upsample, (hipStream_t)stream);
         if (rc != 0) return rc < 0 ? rc : DVQ_OK;
     }
     DVQ_REQUIRE(d->impl != 4, DVQ_ESHAPE, "dvq_conv2d_wgrad_oihw: shape not eligible for the halo kernel");

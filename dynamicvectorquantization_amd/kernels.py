@@ -87,10 +87,17 @@ def profile_count_stop() -> int:
     return n
 
 
-def profile_start(max_launches=0):
-    """start recording; `max_launches` timing-event pairs are created up front"""
-    global _prof, _pool
+def profile_prepare(max_launches):
+    """create `max_launches` timing-event pairs (slow on some hosts: do it outside any timed region)"""
+    global _pool
     _pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * max_launches)]
+
+
+def profile_start(max_launches=0):
+    """start recording with the prepared event pool (or create one now)"""
+    global _prof
+    if max_launches:
+        profile_prepare(max_launches)
     _prof = {}
 
 
@@ -119,6 +126,12 @@ def _timed(name, flops, nbytes, fn):
     e.record()
     _prof.setdefault(name, []).append((s, e, flops, nbytes))
     return r
+
+
+def _halo_eligible(d: ConvDesc) -> bool:
+    """mirrors halo_eligible()/dvq_conv3x3_halo_try in csrc: which kernel a conv call lands on (for timing labels)"""
+    return (d.dtype == _lib.BF16 and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad_t == 1 and d.pad_l == 1 and
+            d.OH == d.H and d.OW == d.W and d.impl in (0, 4) and d.W % 32 == 0 and d.Cin % 64 == 0 and d.Cout % 8 == 0)
 
 
 def _conv_cost(d: ConvDesc, esize: int):
@@ -227,7 +240,7 @@ def gn_forward(x, gamma, beta, groups=32, eps=1e-6, silu=True):
     return y, mr
 
 
-def gn_backward(x, dy, mean_rstd, gamma, beta, dgamma, dbeta, groups=32, silu=True):
+def gn_backward(x, dy, mean_rstd, gamma, beta, dgamma, dbeta, groups=32, silu=True, addend=None):
     """dgamma/dbeta (fp32 [C]) are accumulated into; returns dx"""
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
@@ -236,7 +249,7 @@ def gn_backward(x, dy, mean_rstd, gamma, beta, dgamma, dbeta, groups=32, silu=Tr
                                   _p(red), _p(dgamma), _p(dbeta), _s()), "dvq_gn_bwd_reduce")
     dx = torch.empty_like(x)
     check(lib().dvq_gn_bwd_dx(_p(x), _p(dy), dt(x), n, hw, c, groups, _p(mean_rstd), _p(gamma), _p(beta), int(silu),
-                              _p(red), _p(dx), _s()), "dvq_gn_bwd_dx")
+                              _p(red), _p(addend), _p(dx), _s()), "dvq_gn_bwd_dx")
     return dx
 
 
@@ -272,7 +285,7 @@ def unpack_wgrad(dw, grad_oihw, cin_p):
 def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None):
     y = torch.empty(d.N, d.OH, d.OW, d.Cout, dtype=x.dtype, device=x.device)
     fl, nb = _conv_cost(d, x.element_size())
-    _timed("conv_fwd", fl, nb, lambda: check(
+    _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 else "igemm_nt_glds_kernel", fl, nb, lambda: check(
         lib().dvq_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), _p(y), _s()), "dvq_conv2d_fwd"))
     return y
 
@@ -282,7 +295,8 @@ def conv2d_dgrad(d: ConvDesc, dy, wt):
     dx = torch.empty(d.N, sh, sw, d.Cin, dtype=dy.dtype, device=dy.device)
     ws = torch.empty(d.N, d.H, d.W, d.Cin, dtype=dy.dtype, device=dy.device) if d.upsample else None
     fl, nb = _conv_cost(d, dy.element_size())
-    _timed("conv_dgrad", fl, nb, lambda: check(
+    _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 and d.Cout % 64 == 0 else "igemm_nt_glds_kernel", fl, nb,
+           lambda: check(
         lib().dvq_conv2d_dgrad(C.byref(d), _p(dy), _p(wt), _p(dx), _p(ws), _s()), "dvq_conv2d_dgrad"))
     return dx
 
@@ -299,7 +313,7 @@ def conv2d_wgrad(d: ConvDesc, x, dy, db=None):
 def conv2d_wgrad_oihw(d: ConvDesc, x, dy, cin_real, cout_real, grad_oihw, db=None):
     """accumulate the weight gradient straight into the [Cout,Cin,KH,KW] fp32 grad (and db into [Cout])"""
     fl, nb = _conv_cost(d, x.element_size())
-    _timed("conv_wgrad", fl, nb, lambda: check(
+    _timed("conv3x3_halo_wgrad_kernel" if _halo_eligible(d) and d.H % 4 == 0 else "igemm_tn_tr_kernel", fl, nb, lambda: check(
         lib().dvq_conv2d_wgrad_oihw(C.byref(d), _p(x), _p(dy), cin_real, cout_real, _praw(grad_oihw), _p(db),
                                     int(is_ohwi(grad_oihw)), _s()), "dvq_conv2d_wgrad_oihw"))
 

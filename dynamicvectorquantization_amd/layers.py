@@ -124,10 +124,10 @@ class Normalize(HipModule):
             tape.s.update(x=x, mr=mr, silu=silu)
         return y
 
-    def bwd(self, dy, tape):
+    def bwd(self, dy, tape, addend=None):
         s = tape.s
         return K.gn_backward(s["x"], dy, s["mr"], self.weight, self.bias, _grad_buf(self.weight), _grad_buf(self.bias),
-                             self.num_groups, s["silu"])
+                             self.num_groups, s["silu"], addend)
 
 
 class Conv2d(HipModule):
@@ -175,7 +175,8 @@ class Conv2d(HipModule):
         if ent is None or ent["w"].device != self.weight.device or ent["master"] != self.weight.data_ptr():
             ent = self._alloc_pack(dtype)
         if ent["epoch"] != rt.weights_epoch():
-            PACKS.repack(dtype, self.weight.device)      # ONE launch refreshes every registered conv of this dtype/device
+            if ent["epoch"] >= 0:
+                PACKS.repack(dtype, self.weight.device)  # ONE launch refreshes every registered conv of this dtype/device
             if ent["epoch"] != rt.weights_epoch():       # not covered by the table yet (first use)
                 K.pack_weight_into(self.weight.detach(), ent["cin_p"], ent["cout_p"], dtype, ent["w"], ent["wt"])
                 ent["epoch"] = rt.weights_epoch()
@@ -333,9 +334,8 @@ class ResnetBlock(HipModule):
         d = self.conv2.bwd(dy, tape.child("conv2"))
         d = self.norm2.bwd(d, tape.child("norm2"))
         d = self.conv1.bwd(d, tape.child("conv1"))
-        d = self.norm1.bwd(d, tape.child("norm1"))
         sc = self.nin_shortcut.bwd(dy, tape.child("nin")) if self.in_channels != self.out_channels else dy
-        return K.add(d, sc)
+        return self.norm1.bwd(d, tape.child("norm1"), addend=sc)      # skip-path gradient added in the same pass
 
 
 class AttnBlock(HipModule):
@@ -388,5 +388,4 @@ class AttnBlock(HipModule):
         dh = self.q.bwd(dq, tape.child("q"))
         dh = K.add(dh, self.k.bwd(dk, tape.child("k")))
         dh = K.add(dh, self.v.bwd(dv, tape.child("v")))
-        dx = self.norm.bwd(dh, tape.child("norm"))
-        return K.add(dx, dy)
+        return self.norm.bwd(dh, tape.child("norm"), addend=dy)

@@ -105,9 +105,10 @@ int dvq_gn_apply(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int
 int dvq_gn_bwd_reduce(const void* x, const void* dy, int dtype, int64_t N, int64_t HW, int64_t C, int G,
                       const float* mean_rstd, const float* gamma, const float* beta, int silu, double* red,
                       float* dgamma, float* dbeta, dvq_stream_t stream);
+/* addend (may be NULL): a tensor like dx that is added to the result (gradient of a joining residual branch) */
 int dvq_gn_bwd_dx(const void* x, const void* dy, int dtype, int64_t N, int64_t HW, int64_t C, int G,
                   const float* mean_rstd, const float* gamma, const float* beta, int silu, const double* red,
-                  void* dx, dvq_stream_t stream);
+                  const void* addend, void* dx, dvq_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on MFMA.  Replaces torch.nn.Conv2d call sites of ResnetBlock /
