@@ -44,6 +44,10 @@ SIGNATURES = {
     "dvq_gn_bwd_reduce": (i32, [vp, vp, i32, i64, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     "dvq_gn_bwd_dx": (i32, [vp, vp, i32, i64, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     "dvq_conv2d_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
+    "dvq_conv3x3_fused_ok": (i32, [C.POINTER(ConvDesc)]),
+    "dvq_conv2d_fwd_ex": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "dvq_conv2d_wgrad_oihw_ex": (i32, [C.POINTER(ConvDesc), vp, vp, i64, i64, vp, vp, i32, vp, vp]),
+    "dvq_gn_scale_shift": (i32, [vp, vp, vp, i64, i64, i64, i32, f32, vp, vp, vp]),
     "dvq_conv2d_dgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
     "dvq_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
     "dvq_conv2d_wgrad_oihw": (i32, [C.POINTER(ConvDesc), vp, vp, i64, i64, vp, vp, i32, vp]),

@@ -23,7 +23,8 @@ constexpr int HPIECES = (HROWS + 7) / 8;       // 43 DMA pieces of 8 rows
 constexpr int ROWB = 128;                      // one 64-channel bf16 chunk
 constexpr int HALOB = HPIECES * 8 * ROWB;      // 44032
 constexpr int BSTAGE = 128 * ROWB;             // 16 KiB: 128 output channels x 64 input channels
-constexpr int LDSB = HALOB + 2 * BSTAGE;       // 76800
+constexpr int SSB = 64 * 2 * 4;                // fused-GN scale/shift of the current 64-channel chunk
+constexpr int LDSB = HALOB + 2 * BSTAGE + SSB; // 77312
 
 struct HaloParams {
     const bf16_t* X;     // [N,H,W,Cin]
@@ -35,6 +36,10 @@ struct HaloParams {
     int tiles_x, tiles_y, gn;
     int flip;            // 1: weight tap index is 8 - tap (dgrad through the [Cin][3][3][Cout] pack)
     int up;              // 1: X is stored [N,H/2,W/2,Cin] and read through nearest x2 (Upsample, model.py:50)
+    const float* gn_ss;  // optional fused GroupNorm+swish on the INPUT: per (n, ci) {scale, shift} fp32 [N][Cin][2];
+                         //   the halo tile is transformed in LDS once per chunk (zero padding stays zero)
+    double* out_stats;   // optional GroupNorm statistics of the OUTPUT: fp64 [N][G][2] += (sum, sum of squares)
+    int out_groups;      //   of the values as stored (after bias / residual / bf16 rounding)
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
@@ -47,6 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     char* bst = smem + HALOB;
+    float* ssl = reinterpret_cast<float*>(smem + HALOB + 2 * BSTAGE);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -111,7 +117,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
         const int c0 = c * 64;
         issue_halo(c0);                 // safe: the barrier that ended the previous chunk's last tap is behind us
         issue_b(0, c0, 0);
+        if (p.gn_ss != nullptr && tid < 128) ssl[tid] = p.gn_ss[((int64_t)n * p.Cin + c0) * 2 + tid];
         __syncthreads();                // vmcnt(0) + barrier: halo and first weight stage have landed
+        if (p.gn_ss != nullptr) {
+            // fused GroupNorm + swish: y = z * sigmoid(z), z = x * scale[c] + shift[c], applied in place to the halo tile
+            for (int q = tid; q < HROWS * 8; q += 256) {
+                const int hp = q >> 3, cp = q & 7;
+                const int hy = hp / HW_, hx = hp - hy * HW_;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                if ((unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) continue;   // padding stays zero
+                const int cg = cp ^ ((hp >> 1) & 7);                  // channel chunk stored at this position
+                uint4* ptr = reinterpret_cast<uint4*>(halo + hp * ROWB + cp * 16);
+                uint4 v = *ptr;
+                unsigned* pv = &v.x;
+                const float* sc = ssl + cg * 16;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = swishf(fmaf(__uint_as_float(pv[k] << 16), sc[4 * k + 0], sc[4 * k + 1]));
+                    const float hi = swishf(fmaf(__uint_as_float(pv[k] & 0xffff0000u), sc[4 * k + 2], sc[4 * k + 3]));
+                    pv[k] = pack_bf16x2(lo, hi);
+                }
+                *ptr = v;
+            }
+            __syncthreads();
+        }
         for (int tap = 0; tap < 9; ++tap) {
             const int buf = tap & 1;
             if (tap + 1 < 9) issue_b(tap + 1, c0, buf ^ 1);
@@ -159,6 +188,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
             }
     }
     __syncthreads();
+    float gs[8], gq[8];                 // output statistics of this thread's 8 channels (chunk tid & 15 in every iteration)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gs[k] = gq[k] = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int q = tid + 256 * i;
@@ -179,6 +211,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
             }
         }
         *reinterpret_cast<uint4*>(p.Y + o) = v;
+        if (p.out_stats != nullptr) {
+            const unsigned* pv = &v.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = __uint_as_float(pv[k] << 16), hi = __uint_as_float(pv[k] & 0xffff0000u);
+                gs[2 * k] += lo;
+                gq[2 * k] = fmaf(lo, lo, gq[2 * k]);
+                gs[2 * k + 1] += hi;
+                gq[2 * k + 1] = fmaf(hi, hi, gq[2 * k + 1]);
+            }
+        }
+    }
+    if (p.out_stats != nullptr) {
+        // combine within the workgroup in LDS (fp32 per channel), then one fp64 atomic pair per group
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);            // [128][2]
+        for (int i = tid; i < 256; i += 256) red[i] = 0.f;
+        __syncthreads();
+        const int ch = tid & 15;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            atomicAdd(&red[(ch * 8 + k) * 2], gs[k]);
+            atomicAdd(&red[(ch * 8 + k) * 2 + 1], gq[k]);
+        }
+        __syncthreads();
+        const int cpg = p.Cout / p.out_groups;                  // channels per group
+        const int ng = 128 / cpg;                               // groups covered by this workgroup's 128 channels
+        if (tid < ng && n0 + tid * cpg < p.Cout) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                s1 += (double)red[c * 2];
+                s2 += (double)red[c * 2 + 1];
+            }
+            const int g = (n0 + tid * cpg) / cpg;
+            atomicAdd(&p.out_stats[((int64_t)n * p.out_groups + g) * 2], s1);
+            atomicAdd(&p.out_stats[((int64_t)n * p.out_groups + g) * 2 + 1], s2);
+        }
     }
 }
 
@@ -187,8 +256,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
 // Returns 1 if the halo kernel handled the call, 0 if the shape is not eligible (caller falls back to igemm),
 // negative on error.  x: [N,H,W,Cin] bf16; w: rows of [9][Cin]; y: [N,H,W,Cout].
 int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N,
-                         int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, int up, hipStream_t stream) {
+                         int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, int up, const float* gn_ss,
+                         double* out_stats, int out_groups, hipStream_t stream) {
     if (H % TH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
+    if (out_stats != nullptr && (out_groups <= 0 || Cout % out_groups != 0 || 128 % (Cout / out_groups) != 0)) return 0;
     if (N * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31) || Cout * 9 * Cin >= (1ll << 31)) return 0;
     HaloParams p{};
     p.X = (const bf16_t*)x; p.Wt = (const bf16_t*)w; p.Y = (bf16_t*)y; p.R = (const bf16_t*)residual; p.bias = bias;
@@ -196,6 +267,7 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     p.tiles_x = (int)(W / TW); p.tiles_y = (int)(H / TH); p.gn = (int)cdiv64(Cout, 128);
     p.flip = flip;
     p.up = up;
+    p.gn_ss = gn_ss; p.out_stats = out_stats; p.out_groups = out_groups;
     const int64_t blocks = N * p.tiles_y * p.tiles_x * p.gn;
     if (blocks >= (1ll << 31)) return 0;
     dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel, LDSB);
@@ -237,6 +309,7 @@ struct WgParams {
     int tiles_x, tiles_y, ntiles, gi, gj, nsplit, tiles_per_split;
     int c_oihw;          // 1: [co][ci][9], 0: [co][9][ci]
     int up;              // 1: X is stored [N,H/2,W/2,Cin] (nearest x2 folded into the halo gather)
+    const float* gn_ss;  // optional fused GroupNorm+swish on x: {scale, shift} fp32 [N][Cin][2] (recomputed, never stored)
 };
 
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) {
@@ -305,9 +378,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
         __syncthreads();
         for (int t = tbeg; t < tend; ++t) {
             const int buf = (t - tbeg) & 1;
-            if (t + 1 < tend) issue(t + 1, buf ^ 1);
+            if (p.gn_ss == nullptr && t + 1 < tend) issue(t + 1, buf ^ 1);
             const char* sdy = smem + buf * WSTAGE;
             const char* shl = sdy + WDYB;
+            if (p.gn_ss != nullptr) {
+                // fused GroupNorm + swish on the freshly landed x halo (in place; padding rows stay zero)
+                const int txy = p.tiles_x * p.tiles_y;
+                const int n = t / txy, rem = t - n * txy;
+                const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+                const float* ss = p.gn_ss + ((int64_t)n * p.Cin + j0) * 2;
+                for (int q = tid; q < WHROWS * 8; q += 512) {
+                    const int hp = q >> 3, cp = q & 7;
+                    const int hy = hp / HW_, hx = hp - hy * HW_;
+                    const int gy = ty * WTH - 1 + hy, gx = tx * TW - 1 + hx;
+                    if ((unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) continue;
+                    const int cg = cp ^ (((hp >> 1) & 1) << 2);
+                    uint4* ptr = reinterpret_cast<uint4*>(const_cast<char*>(shl) + hp * ROWB + cp * 16);
+                    uint4 v = *ptr;
+                    unsigned* pv = &v.x;
+                    const float4* sc4 = reinterpret_cast<const float4*>(ss + cg * 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 c4 = sc4[k];
+                        const float lo = swishf(fmaf(__uint_as_float(pv[k] << 16), c4.x, c4.y));
+                        const float hi = swishf(fmaf(__uint_as_float(pv[k] & 0xffff0000u), c4.z, c4.w));
+                        pv[k] = pack_bf16x2(lo, hi);
+                    }
+                    *ptr = v;
+                }
+                __syncthreads();
+                if (t + 1 < tend) issue(t + 1, buf ^ 1);     // prefetch after the barrier: it would otherwise drain the DMA
+            }
 #pragma unroll 2
             for (int st = 0; st < 8; ++st) {               // 16 pixels per step: image row rr, half hs
                 const int rr = st >> 1, hs = st & 1;
@@ -382,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
 // 1 = handled, 0 = not eligible, negative = error
 int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* db, int64_t N, int64_t H, int64_t W,
                                int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw, int up,
-                               hipStream_t stream) {
+                               const float* gn_ss, hipStream_t stream) {
     if (H % WTH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
     if (N * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31)) return 0;
     WgParams p{};
@@ -399,6 +500,7 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
     p.nsplit = (int)cdiv64(p.ntiles, p.tiles_per_split);
     p.c_oihw = c_oihw;
     p.up = up;
+    p.gn_ss = gn_ss;
     dvq_ensure_dynamic_lds((const void*)conv3x3_halo_wgrad_kernel, 2 * WSTAGE);
     conv3x3_halo_wgrad_kernel<<<dim3((unsigned)(p.gi * p.gj * p.nsplit)), dim3(512), 2 * WSTAGE, stream>>>(p);
     hipError_t e = hipGetLastError();

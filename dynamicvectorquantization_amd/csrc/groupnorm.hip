@@ -219,6 +219,29 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x,
     }
 }
 
+// per-(n, c) affine of GroupNorm: y = x * scale + shift, scale = rstd * gamma, shift = beta - mean * scale
+__global__ __launch_bounds__(256) void gn_scale_shift_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int64_t N, int64_t C, int G,
+                                                             double cnt, float eps, float* __restrict__ ss,
+                                                             float* __restrict__ mean_rstd) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < N * C) {
+        const int64_t n = e / C;
+        const int c = (int)(e - n * C);
+        float m, r;
+        gn_mean_rstd(stats, n, G, c / (int)(C / G), cnt, eps, m, r);
+        const float sc = r * gamma[c];
+        ss[e * 2] = sc;
+        ss[e * 2 + 1] = beta[c] - m * sc;
+    }
+    if (mean_rstd != nullptr && e < N * G) {
+        float m, r;
+        gn_mean_rstd(stats, e / G, G, (int)(e % G), cnt, eps, m, r);
+        mean_rstd[e * 2] = m;
+        mean_rstd[e * 2 + 1] = r;
+    }
+}
+
 int gn_check(const char* who, int64_t N, int64_t HW, int64_t C, int G) {
     DVQ_REQUIRE(N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C % 8 == 0 && C / 8 <= 256 && N <= 65535, DVQ_ESHAPE,
                 "%s: unsupported shape N=%lld HW=%lld C=%lld G=%d", who, (long long)N, (long long)HW, (long long)C, G);
@@ -237,6 +260,17 @@ int dvq_gn_stats(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int
     DVQ_DISPATCH_DTYPE(dtype, T, gn_stats_kernel<T><<<grid, dim3(256), 2 * G * sizeof(double), (hipStream_t)stream>>>(
                                      (const T*)x, HW, C, G, stats););
     DVQ_CHECK_LAUNCH("gn_stats");
+    return DVQ_OK;
+}
+
+int dvq_gn_scale_shift(const double* stats, const float* gamma, const float* beta, int64_t N, int64_t HW, int64_t C, int G,
+                       float eps, float* scale_shift, float* mean_rstd, dvq_stream_t stream) {
+    DVQ_REQUIRE(stats && gamma && beta && scale_shift, DVQ_EINVAL, "dvq_gn_scale_shift: null pointer");
+    if (int e = gn_check("dvq_gn_scale_shift", N, HW, C, G)) return e;
+    const int64_t n = N * C > N * G ? N * C : N * G;
+    gn_scale_shift_kernel<<<dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        stats, gamma, beta, N, C, G, (double)HW * (double)(C / G), eps, scale_shift, mean_rstd);
+    DVQ_CHECK_LAUNCH("gn_scale_shift");
     return DVQ_OK;
 }
 

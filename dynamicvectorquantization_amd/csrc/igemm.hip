@@ -1117,11 +1117,12 @@ int conv_check(const dvq_conv_desc* d, const char* who) {
 
 // conv_halo.hip: LDS-resident-halo kernel for 3x3 / stride 1 / pad 1 bf16 convolutions (1 = handled, 0 = not eligible)
 int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N,
-                         int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, int up, hipStream_t stream);
+                         int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, int up, const float* gn_ss,
+                         double* out_stats, int out_groups, hipStream_t stream);
 
 int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* db, int64_t N, int64_t H, int64_t W,
                                int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw, int up,
-                               hipStream_t stream);
+                               const float* gn_ss, hipStream_t stream);
 
 static bool halo_eligible(const dvq_conv_desc* d) {
     return d->dtype == DVQ_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
@@ -1131,14 +1132,33 @@ static bool halo_eligible(const dvq_conv_desc* d) {
 // =================================================================================================
 extern "C" {
 
+int dvq_conv2d_fwd_ex(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                      void* y, const float* gn_scale_shift, double* out_stats, int out_groups, dvq_stream_t stream);
+int dvq_conv2d_wgrad_oihw_ex(const dvq_conv_desc* d, const void* x, const void* dy, int64_t cin_real, int64_t cout_real,
+                             float* grad_oihw, float* dbias, int ohwi, const float* gn_scale_shift, dvq_stream_t stream);
+
 int dvq_conv2d_fwd(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
                    void* y, dvq_stream_t stream) {
+    return dvq_conv2d_fwd_ex(d, x, w, bias, residual, y, nullptr, nullptr, 0, stream);
+}
+
+int dvq_conv3x3_fused_ok(const dvq_conv_desc* d) {
+    // shapes on which the halo kernels (and therefore the fused GroupNorm prologue / statistics epilogue) run
+    return d != nullptr && halo_eligible(d) && d->H % 8 == 0 && d->W % 32 == 0 && d->Cin % 64 == 0 && d->Cout % 8 == 0 &&
+           d->N * d->H * d->W * (d->Cin > d->Cout ? d->Cin : d->Cout) < (1ll << 31);
+}
+
+int dvq_conv2d_fwd_ex(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                      void* y, const float* gn_scale_shift, double* out_stats, int out_groups, dvq_stream_t stream) {
     if (int e = conv_check(d, "dvq_conv2d_fwd")) return e;
     DVQ_REQUIRE(x && w && y, DVQ_EINVAL, "dvq_conv2d_fwd: null pointer");
     if (halo_eligible(d)) {
-        const int rc = dvq_conv3x3_halo_try(x, w, bias, residual, y, d->N, d->H, d->W, d->Cin, d->Cout, 0, d->upsample, (hipStream_t)stream);
+        const int rc = dvq_conv3x3_halo_try(x, w, bias, residual, y, d->N, d->H, d->W, d->Cin, d->Cout, 0, d->upsample,
+                                            gn_scale_shift, out_stats, out_groups, (hipStream_t)stream);
         if (rc != 0) return rc < 0 ? rc : DVQ_OK;
     }
+    DVQ_REQUIRE(gn_scale_shift == nullptr && out_stats == nullptr, DVQ_ESHAPE,
+                "dvq_conv2d_fwd_ex: fused GroupNorm needs a shape accepted by dvq_conv3x3_fused_ok");
     DVQ_REQUIRE(d->impl != 4, DVQ_ESHAPE, "dvq_conv2d_fwd: shape not eligible for the halo kernel");
     NtParams p{};
     p.A = x; p.B = w; p.C = y; p.R = residual; p.bias = bias;
@@ -1161,7 +1181,7 @@ int dvq_conv2d_dgrad(const dvq_conv_desc* d, const void* dy, const void* wt, voi
     if (halo_eligible(d)) {      // dgrad of a 3x3/s1/p1 conv = the same conv over dy with the taps reversed
         // with a folded nearest-x2 upsample the gradient is formed at the upsampled resolution (ws), then 2x2-summed
         const int rc = dvq_conv3x3_halo_try(dy, wt, nullptr, nullptr, d->upsample ? ws : dx, d->N, d->H, d->W, d->Cout, d->Cin, 1,
-                                            0, (hipStream_t)stream);
+                                            0, nullptr, nullptr, 0, (hipStream_t)stream);
         if (rc < 0) return rc;
         if (rc == 1) return d->upsample ? dvq_sumpool2x2(ws, d->dtype, d->N, d->H / 2, d->W / 2, d->Cin, dx, stream) : DVQ_OK;
     }
@@ -1188,7 +1208,7 @@ int dvq_conv2d_wgrad(const dvq_conv_desc* d, const void* x, const void* dy, floa
     DVQ_REQUIRE(x && dy && dw, DVQ_EINVAL, "dvq_conv2d_wgrad: null pointer");
     if (halo_eligible(d)) {
         const int rc = dvq_conv3x3_halo_wgrad_try(x, dy, dw, dbias, d->N, d->H, d->W, d->Cin, d->Cout, d->Cin, d->Cout, 0,
-                                                  d->upsample, (hipStream_t)stream);
+                                                  d->upsample, nullptr, (hipStream_t)stream);
         if (rc != 0) return rc < 0 ? rc : DVQ_OK;
     }
     DVQ_REQUIRE(d->impl != 4, DVQ_ESHAPE, "dvq_conv2d_wgrad: shape not eligible for the halo kernel");
@@ -1208,14 +1228,20 @@ int dvq_conv2d_wgrad(const dvq_conv_desc* d, const void* x, const void* dy, floa
 
 int dvq_conv2d_wgrad_oihw(const dvq_conv_desc* d, const void* x, const void* dy, int64_t cin_real, int64_t cout_real,
                           float* grad_oihw, float* dbias, int ohwi, dvq_stream_t stream) {
+    return dvq_conv2d_wgrad_oihw_ex(d, x, dy, cin_real, cout_real, grad_oihw, dbias, ohwi, nullptr, stream);
+}
+
+int dvq_conv2d_wgrad_oihw_ex(const dvq_conv_desc* d, const void* x, const void* dy, int64_t cin_real, int64_t cout_real,
+                             float* grad_oihw, float* dbias, int ohwi, const float* gn_scale_shift, dvq_stream_t stream) {
     if (int e = conv_check(d, "dvq_conv2d_wgrad_oihw")) return e;
     DVQ_REQUIRE(x && dy && grad_oihw && cin_real > 0 && cin_real <= d->Cin && cout_real > 0 && cout_real <= d->Cout,
                 DVQ_EINVAL, "dvq_conv2d_wgrad_oihw: bad arguments");
     if (halo_eligible(d)) {
         const int rc = dvq_conv3x3_halo_wgrad_try(x, dy, grad_oihw, dbias, d->N, d->H, d->W, d->Cin, d->Cout, cin_real,
-                                                  cout_real, ohwi ? 0 : 1, d->upsample, (hipStream_t)stream);
+                                                  cout_real, ohwi ? 0 : 1, d->upsample, gn_scale_shift, (hipStream_t)stream);
         if (rc != 0) return rc < 0 ? rc : DVQ_OK;
     }
+    DVQ_REQUIRE(gn_scale_shift == nullptr, DVQ_ESHAPE, "dvq_conv2d_wgrad_oihw_ex: fused GroupNorm needs a shape accepted by dvq_conv3x3_fused_ok");
     DVQ_REQUIRE(d->impl != 4, DVQ_ESHAPE, "dvq_conv2d_wgrad_oihw: shape not eligible for the halo kernel");
     TnParams p{};
     p.A = dy; p.B = x; p.C = grad_oihw; p.colsumA = dbias;

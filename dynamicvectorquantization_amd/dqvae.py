@@ -25,7 +25,7 @@ from . import kernels as K
 from . import runtime as rt
 from .config import instantiate_from_config
 from .layers import (AttnBlock, Conv2d, Downsample, HipModule, Normalize, ResnetBlock, Tape, Upsample, _child,
-                     _grad_buf, to_nchw, to_nhwc)
+                     _grad_buf, norm_swish_conv, to_nchw, to_nhwc)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -136,13 +136,11 @@ class DualGrainEncoder(HipModule):
         hc = self.mid_coarse.block_1.fwd(h, _child(tape, "mc1"))
         hc = self.mid_coarse.attn_1.fwd(hc, _child(tape, "mca"))
         hc = self.mid_coarse.block_2.fwd(hc, _child(tape, "mc2"))
-        hc = self.norm_out_coarse.fwd(hc, _child(tape, "noc"), silu=True)
-        hc = self.conv_out_coarse.fwd(hc, _child(tape, "coc"))
+        hc = norm_swish_conv(self.norm_out_coarse, self.conv_out_coarse, hc, tape, "noc", "coc")
         hf = self.mid_fine.block_1.fwd(h_fine, _child(tape, "mf1"))
         hf = self.mid_fine.attn_1.fwd(hf, _child(tape, "mfa"))
         hf = self.mid_fine.block_2.fwd(hf, _child(tape, "mf2"))
-        hf = self.norm_out_fine.fwd(hf, _child(tape, "nof"), silu=True)
-        hf = self.conv_out_fine.fwd(hf, _child(tape, "cof"))
+        hf = norm_swish_conv(self.norm_out_fine, self.conv_out_fine, hf, tape, "nof", "cof")
         h_dual, mask = K.dual_merge(hf, hc, grain)
         if tape is not None:
             tape.s["grain"] = grain
@@ -357,8 +355,7 @@ class Decoder(HipModule):
                     h = lvl.attn[i_block].fwd(h, _child(tape, f"u{i_level}a{i_block}"))
             if i_level != 0:
                 h = lvl.upsample.fwd(h, _child(tape, f"u{i_level}us"))
-        h = self.norm_out.fwd(h, _child(tape, "no"), silu=True)
-        h = self.conv_out.fwd(h, _child(tape, "co"))
+        h = norm_swish_conv(self.norm_out, self.conv_out, h, tape, "no", "co")
         if tape is not None:
             tape.s["pctx"] = pctx
         return h

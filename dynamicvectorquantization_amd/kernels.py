@@ -91,6 +91,9 @@ def profile_prepare(max_launches):
     """create `max_launches` timing-event pairs (slow on some hosts: do it outside any timed region)"""
     global _pool
     _pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * max_launches)]
+    for ev in _pool:          # torch creates the HIP event lazily at the first record(): force that now
+        ev.record()
+    torch.cuda.synchronize()
 
 
 def profile_start(max_launches=0):
@@ -227,17 +230,39 @@ def patch_entropy_gate(img: torch.Tensor, patch: int, threshold: float | None):
 # ---------------------------------------------------------------------------------------------
 # GroupNorm (+swish)
 # ---------------------------------------------------------------------------------------------
-def gn_forward(x, gamma, beta, groups=32, eps=1e-6, silu=True):
-    """x NHWC [N,H,W,C]; returns (y, mean_rstd [N,G,2] fp32)"""
+def gn_stats(x, groups=32):
+    """x NHWC -> fp64 [N,G,2] (sum, sum of squares)"""
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
     stats = zeros_small((n, groups, 2), torch.float64, x.device)
     check(lib().dvq_gn_stats(_p(x), dt(x), n, hw, c, groups, _p(stats), _s()), "dvq_gn_stats")
+    return stats
+
+
+def gn_forward(x, gamma, beta, groups=32, eps=1e-6, silu=True, stats=None):
+    """x NHWC [N,H,W,C]; returns (y, mean_rstd [N,G,2] fp32).  `stats` may come from a producer's fused epilogue."""
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    if stats is None:
+        stats = gn_stats(x, groups)
     y = torch.empty_like(x)
     mr = torch.empty(n, groups, 2, dtype=torch.float32, device=x.device)
     check(lib().dvq_gn_apply(_p(x), dt(x), n, hw, c, groups, eps, _p(stats), _p(gamma), _p(beta), int(silu), _p(y), _p(mr),
                              _s()), "dvq_gn_apply")
     return y, mr
+
+
+def gn_scale_shift(x, gamma, beta, groups=32, eps=1e-6, stats=None):
+    """per-(n,c) {scale, shift} fp32 [N,C,2] for the fused conv prologue + mean_rstd [N,G,2] for the backward"""
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    if stats is None:
+        stats = gn_stats(x, groups)
+    ss = torch.empty(n, c, 2, dtype=torch.float32, device=x.device)
+    mr = torch.empty(n, groups, 2, dtype=torch.float32, device=x.device)
+    check(lib().dvq_gn_scale_shift(_p(stats), _p(gamma), _p(beta), n, hw, c, groups, eps, _p(ss), _p(mr), _s()),
+          "dvq_gn_scale_shift")
+    return ss, mr
 
 
 def gn_backward(x, dy, mean_rstd, gamma, beta, dgamma, dbeta, groups=32, silu=True, addend=None):
@@ -282,9 +307,18 @@ def unpack_wgrad(dw, grad_oihw, cin_p):
     check(lib().dvq_unpack_wgrad(_p(dw), cout, cin, kh, kw, cin_p, _p(grad_oihw), _s()), "dvq_unpack_wgrad")
 
 
-def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None):
+def conv_fused_ok(d: ConvDesc) -> bool:
+    return bool(lib().dvq_conv3x3_fused_ok(C.byref(d)))
+
+
+def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None, gn_ss=None, out_stats=None, out_groups=0):
     y = torch.empty(d.N, d.OH, d.OW, d.Cout, dtype=x.dtype, device=x.device)
     fl, nb = _conv_cost(d, x.element_size())
+    if gn_ss is not None or out_stats is not None:
+        _timed("conv3x3_halo_kernel", fl, nb, lambda: check(
+            lib().dvq_conv2d_fwd_ex(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), _p(y), _p(gn_ss), _p(out_stats),
+                                    out_groups, _s()), "dvq_conv2d_fwd_ex"))
+        return y
     _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 else "igemm_nt_glds_kernel", fl, nb, lambda: check(
         lib().dvq_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), _p(y), _s()), "dvq_conv2d_fwd"))
     return y
@@ -310,9 +344,15 @@ def conv2d_wgrad(d: ConvDesc, x, dy, db=None):
     return dw
 
 
-def conv2d_wgrad_oihw(d: ConvDesc, x, dy, cin_real, cout_real, grad_oihw, db=None):
-    """accumulate the weight gradient straight into the [Cout,Cin,KH,KW] fp32 grad (and db into [Cout])"""
+def conv2d_wgrad_oihw(d: ConvDesc, x, dy, cin_real, cout_real, grad_oihw, db=None, gn_ss=None):
+    """accumulate the weight gradient straight into the [Cout,Cin,KH,KW] fp32 grad (and db into [Cout]);
+    gn_ss: the fused GroupNorm+swish of the forward is re-applied to x inside the kernel"""
     fl, nb = _conv_cost(d, x.element_size())
+    if gn_ss is not None:
+        _timed("conv3x3_halo_wgrad_kernel", fl, nb, lambda: check(
+            lib().dvq_conv2d_wgrad_oihw_ex(C.byref(d), _p(x), _p(dy), cin_real, cout_real, _praw(grad_oihw), _p(db),
+                                           int(is_ohwi(grad_oihw)), _p(gn_ss), _s()), "dvq_conv2d_wgrad_oihw_ex"))
+        return
     _timed("conv3x3_halo_wgrad_kernel" if _halo_eligible(d) and d.H % 4 == 0 else "igemm_tn_tr_kernel", fl, nb, lambda: check(
         lib().dvq_conv2d_wgrad_oihw(C.byref(d), _p(x), _p(dy), cin_real, cout_real, _praw(grad_oihw), _p(db),
                                     int(is_ohwi(grad_oihw)), _s()), "dvq_conv2d_wgrad_oihw"))

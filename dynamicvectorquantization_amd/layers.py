@@ -119,10 +119,18 @@ class Normalize(HipModule):
 
     def fwd(self, x, tape, silu=None):
         silu = self.fuse_silu if silu is None else silu
-        y, mr = K.gn_forward(x, self.weight, self.bias, self.num_groups, self.eps, silu)
+        y, mr = K.gn_forward(x, self.weight, self.bias, self.num_groups, self.eps, silu, stats=getattr(x, "_gn_stats", None))
         if tape is not None:
             tape.s.update(x=x, mr=mr, silu=silu)
         return y
+
+    def prep(self, x, tape):
+        """fused path: no normalised tensor is written -- returns the per-(n,c) {scale, shift} table that the consuming
+        conv kernel applies (with swish) to its LDS-resident input tile; saves what the GroupNorm backward needs"""
+        ss, mr = K.gn_scale_shift(x, self.weight, self.bias, self.num_groups, self.eps, stats=getattr(x, "_gn_stats", None))
+        if tape is not None:
+            tape.s.update(x=x, mr=mr, silu=True)
+        return ss
 
     def bwd(self, dy, tape, addend=None):
         s = tape.s
@@ -200,19 +208,30 @@ class Conv2d(HipModule):
         assert x.shape[-1] == cin_p, f"expected {cin_p} (padded) input channels, got {x.shape[-1]}"
         return K.conv_desc(n, h, w, cin_p, cout_p, k, k, s, pt, pl, oh, ow, self.upsample, x.dtype, rt.impl())
 
-    def fwd(self, x, tape, residual=None):
+    def fused_ok(self, x) -> bool:
+        """True if this call runs on the halo kernels, which can apply GroupNorm+swish to their input tile and emit
+        the GroupNorm statistics of their output"""
+        return x.dtype == torch.bfloat16 and self.kernel_size == 3 and K.conv_fused_ok(self._desc(x))
+
+    def fwd(self, x, tape, residual=None, gn_ss=None, want_stats=False):
         w, _, bias = self.packed(x.dtype)
         d = self._desc(x)
-        y = K.conv2d_fwd(d, x, w, bias, residual)
+        stats = None
+        if want_stats and self.out_channels % 32 == 0 and 128 % (self.out_channels // 32) == 0 and self.fused_ok(x):
+            stats = K.zeros_small((d.N, 32, 2), torch.float64, x.device)
+        y = K.conv2d_fwd(d, x, w, bias, residual, gn_ss=gn_ss, out_stats=stats, out_groups=32 if stats is not None else 0)
+        if stats is not None:
+            y._gn_stats = stats            # consumed by the next Normalize (saves its statistics pass)
         if tape is not None:
-            tape.s.update(x=x, d=d)
+            tape.s.update(x=x, d=d, gn_ss=gn_ss)
         return y
 
     def bwd(self, dy, tape, need_dx=True):
         x, d = tape.s["x"], tape.s["d"]
         db = _grad_buf(self.bias) if self.bias is not None else None
         # weight / bias gradients are accumulated by the kernel straight into the reference-layout .grad buffers
-        K.conv2d_wgrad_oihw(d, x, dy, self.in_channels, self.out_channels, _grad_buf(self.weight), db)
+        K.conv2d_wgrad_oihw(d, x, dy, self.in_channels, self.out_channels, _grad_buf(self.weight), db,
+                            gn_ss=tape.s.get("gn_ss"))
         if not need_dx:
             return None
         _, wt, _ = self.packed(x.dtype)
@@ -275,7 +294,7 @@ class Upsample(HipModule):
         self.conv = Conv2d(in_channels, in_channels, 3, stride=1, padding=1, upsample=True)
 
     def fwd(self, x, tape):
-        return self.conv.fwd(x, _child(tape, "conv"))
+        return self.conv.fwd(x, _child(tape, "conv"), want_stats=True)
 
     def bwd(self, dy, tape):
         return self.conv.bwd(dy, tape.child("conv"))
@@ -296,6 +315,17 @@ class Downsample(HipModule):
 
     def bwd(self, dy, tape):
         return self.conv.bwd(dy, tape.child("conv"))
+
+
+def norm_swish_conv(norm, conv, x, tape, nname, cname, residual=None):
+    """GroupNorm -> swish -> conv3x3 (model.py:119-129).  On shapes the halo kernel takes, the normalised activation
+    is never materialised: the conv applies scale/shift + swish to its LDS input tile and also emits the GroupNorm
+    statistics of its output for whoever normalises it next."""
+    if rt.fuse_gn_prologue() and conv.fused_ok(x):
+        ss = norm.prep(x, _child(tape, nname))
+        return conv.fwd(x, _child(tape, cname), residual=residual, gn_ss=ss, want_stats=True)
+    a = norm.fwd(x, _child(tape, nname), silu=True)
+    return conv.fwd(a, _child(tape, cname), residual=residual, want_stats=True)
 
 
 class ResnetBlock(HipModule):
@@ -324,11 +354,9 @@ class ResnetBlock(HipModule):
         return super().forward(x, **kw)
 
     def fwd(self, x, tape, temb=None):
-        a1 = self.norm1.fwd(x, _child(tape, "norm1"), silu=True)
-        h1 = self.conv1.fwd(a1, _child(tape, "conv1"))
-        a2 = self.norm2.fwd(h1, _child(tape, "norm2"), silu=True)
+        h1 = norm_swish_conv(self.norm1, self.conv1, x, tape, "norm1", "conv1")
         sc = self.nin_shortcut.fwd(x, _child(tape, "nin")) if self.in_channels != self.out_channels else x
-        return self.conv2.fwd(a2, _child(tape, "conv2"), residual=sc)
+        return norm_swish_conv(self.norm2, self.conv2, h1, tape, "norm2", "conv2", residual=sc)
 
     def bwd(self, dy, tape):
         d = self.conv2.bwd(dy, tape.child("conv2"))

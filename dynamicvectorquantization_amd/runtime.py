@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import contextlib
+import os
 
 import torch
 
@@ -44,6 +45,22 @@ def weights_epoch() -> int:
 def bump_weights_epoch():
     global _weights_epoch
     _weights_epoch += 1
+
+
+# GroupNorm+swish applied inside the consuming conv kernel (no materialised activation: saves HBM traffic and
+# ~1/3 of the saved-activation memory) -- measured SLOWER than the separate HBM-bound pass at B=64 (the in-LDS
+# transform steals VALU issue slots from MFMA-feeding waves), so it is off by default; the statistics epilogue of
+# the producing conv is always on.  DVQ_FUSE_GN=1 enables it (e.g. when memory-bound on activations).
+_fuse_gn = os.environ.get("DVQ_FUSE_GN", "0") == "1"
+
+
+def fuse_gn_prologue() -> bool:
+    return _fuse_gn
+
+
+def set_fuse_gn_prologue(v: bool):
+    global _fuse_gn
+    _fuse_gn = bool(v)
 
 
 def impl() -> int:

@@ -134,6 +134,20 @@ typedef struct dvq_conv_desc {
  * residual NHWC like y or NULL. */
 int dvq_conv2d_fwd(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
                    void* y, dvq_stream_t stream);
+/* Fused variants on shapes accepted by dvq_conv3x3_fused_ok (bf16, 3x3, stride 1, pad 1, H % 8 == 0, W % 32 == 0,
+ * Cin % 64 == 0): gn_scale_shift (fp32 [N][Cin][2], from dvq_gn_scale_shift) applies GroupNorm + swish to the INPUT
+ * inside the kernel (ResnetBlock's norm -> swish -> conv, model.py:119-129, without materialising the activation);
+ * out_stats (fp64 [N][out_groups][2], accumulated) receives sum / sum of squares of the OUTPUT per group, i.e. the
+ * statistics pass of the next GroupNorm.  Either may be NULL. */
+int dvq_conv3x3_fused_ok(const dvq_conv_desc* d);
+int dvq_conv2d_fwd_ex(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                      void* y, const float* gn_scale_shift, double* out_stats, int out_groups, dvq_stream_t stream);
+int dvq_conv2d_wgrad_oihw_ex(const dvq_conv_desc* d, const void* x, const void* dy, int64_t cin_real, int64_t cout_real,
+                             float* grad_oihw, float* dbias, int ohwi, const float* gn_scale_shift, dvq_stream_t stream);
+/* scale_shift[n][c] = {rstd*gamma, beta - mean*rstd*gamma} from the fp64 statistics; mean_rstd (fp32 [N][G][2]) optional */
+int dvq_gn_scale_shift(const double* stats, const float* gamma, const float* beta, int64_t N, int64_t HW, int64_t C, int G,
+                       float eps, float* scale_shift, float* mean_rstd, dvq_stream_t stream);
+
 /* dx (stored-input shape, i.e. [N,H/2,W/2,Cin] when upsample) from dy [N,OH,OW,Cout].
  * wt: weights in IHWO layout [Cin,KH,KW,Cout] of `dtype` (dvq_pack_weight_t).  When upsample is set,
  * ws must hold N*H*W*Cin elements of `dtype` (gradient at the upsampled resolution). */

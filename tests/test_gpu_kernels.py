@@ -387,3 +387,43 @@ def test_blocks_golden(dev, name, impl):
         # floor: gradients that are analytically zero (softmax is invariant to the k bias) are pure rounding noise
         s = max(1e-5, float(np.abs(ref).max()))
         assert float(np.abs(p.grad.cpu().numpy() - ref).max()) / s < 2e-3, k
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 128), (64, 128), (256, 256)])
+def test_resnet_block_fused_groupnorm_bf16(dev, cin, cout):
+    """bf16 ResnetBlock on a halo-eligible shape: the fused path (GroupNorm+swish applied to the conv's LDS input tile,
+    GroupNorm statistics emitted by the producing conv's epilogue) against the unfused kernels and the fp32 oracle"""
+    from dynamicvectorquantization_amd import layers as L
+    from dynamicvectorquantization_amd import runtime as rt
+    from oracle import dqvae as odq
+    rs = np.random.RandomState(cin + cout)
+    n, h, w_ = 2, 16, 32
+    x = bf16_round((rs.standard_normal((n, cin, h, w_)) * 1.5 + 0.2).astype(np.float32))
+    go = bf16_round(rs.standard_normal((n, cout, h, w_)).astype(np.float32))
+    mod = L.ResnetBlock(in_channels=cin, out_channels=cout, temb_channels=0, dropout=0.0).to(dev)
+    with torch.no_grad():
+        for k, p_ in mod.named_parameters():
+            p_.copy_(T(synth.det_param("fused." + k, p_.shape), dev))
+    res = {}
+    for tag, impl in (("fused", 0), ("unfused", 2)):
+        for p_ in mod.parameters():
+            p_.grad = None
+        rt.set_fuse_gn_prologue(tag == "fused")
+        with rt.compute_dtype_ctx(torch.bfloat16), rt.impl_ctx(impl):
+            xt = T(x, dev).requires_grad_(True)
+            y = mod(xt, None)
+            (y.float() * T(go, dev)).sum().backward()
+        res[tag] = dict(y=y.detach().float().cpu().numpy(), dx=xt.grad.float().cpu().numpy(),
+                        **{k: p_.grad.cpu().numpy().copy() for k, p_ in mod.named_parameters()})
+    rt.set_fuse_gn_prologue(False)
+    sd = {"b." + k: torch.from_numpy(synth.det_param("fused." + k, p_.shape)).requires_grad_(True) for k, p_ in mod.named_parameters()}
+    xr = torch.from_numpy(x).requires_grad_(True)
+    yr = odq.resnet_block(sd, "b", xr)
+    (yr * torch.from_numpy(go)).sum().backward()
+    ref = dict(y=yr.detach().numpy(), dx=xr.grad.numpy(), **{k[2:]: v.grad.numpy() for k, v in sd.items()})
+    for key in ref:
+        s_ = max(1e-6, float(np.abs(ref[key]).max()))
+        e_f = float(np.abs(res["fused"][key] - ref[key]).max()) / s_
+        e_u = float(np.abs(res["unfused"][key] - ref[key]).max()) / s_
+        assert e_f < 4e-2, f"fused {key}: rel-to-max error {e_f} (unfused {e_u})"
+        assert e_u < 4e-2, f"unfused {key}: rel-to-max error {e_u}"
