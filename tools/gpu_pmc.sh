@@ -4,7 +4,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp; R="$PWD"
 python tools/conv_probe.py 2>&1 | tail -1
 cd /tmp
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_fetch" -o p -- python "$R/tools/conv_probe.py" > "$R/gpurun_out/pmc_fetch.log" 2>&1; echo "pmc fetch exit $?"
-timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_hit" -o p -- python "$R/tools/conv_probe.py" > "$R/gpurun_out/pmc_hit.log" 2>&1; echo "pmc hit exit $?"
-timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_sq" -o p -- python "$R/tools/conv_probe.py" > "$R/gpurun_out/pmc_sq.log" 2>&1; echo "pmc sq exit $?"
-cd "$R"; find gpurun_out/pmc_* -name "*.csv" | head
+for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_$tag" -o p -- python "$R/tools/conv_probe.py" > "$R/gpurun_out/pmc_$tag.log" 2>&1; echo "pmc $tag exit $?"
+done
