@@ -49,6 +49,13 @@ SIGNATURES = {
     "dvq_conv2d_wgrad_oihw_ex": (i32, [C.POINTER(ConvDesc), vp, vp, i64, i64, vp, vp, i32, vp, vp]),
     "dvq_gn_scale_shift": (i32, [vp, vp, vp, i64, i64, i64, i32, f32, vp, vp, vp]),
     "dvq_conv2d_dgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
+    "dvq_conv2d_fwd_act": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp]),
+    "dvq_conv2d_dgrad_mask": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
+    "dvq_affine_channels": (i32, [vp, i32, i64, i64, vp, vp, vp, vp]),
+    "dvq_axpy_dev": (i32, [vp, vp, vp, i32, i64, vp, vp]),
+    "dvq_maxpool2x2": (i32, [vp, i32, i64, i64, i64, i64, vp, vp]),
+    "dvq_maxpool2x2_relu_bwd": (i32, [vp, vp, vp, i32, i64, i64, i64, i64, vp, vp]),
+    "dvq_lpips_head": (i32, [vp, vp, vp, i32, i64, i64, i64, vp, f32, vp, vp]),
     "dvq_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
     "dvq_conv2d_wgrad_oihw": (i32, [C.POINTER(ConvDesc), vp, vp, i64, i64, vp, vp, i32, vp]),
     "dvq_pack_weights_multi": (i32, [vp, i64, i64, vp]),

@@ -40,6 +40,9 @@ struct HaloParams {
                          //   the halo tile is transformed in LDS once per chunk (zero padding stays zero)
     double* out_stats;   // optional GroupNorm statistics of the OUTPUT: fp64 [N][G][2] += (sum, sum of squares)
     int out_groups;      //   of the values as stored (after bias / residual / bf16 rounding)
+    float act_slope;     // output activation v > 0 ? v : act_slope * v (1: none, 0: ReLU, 0.2: LeakyReLU), applied last
+    int res_mask;        // 1: R is not added but gates the result: v *= (R > 0 ? 1 : mask_slope)  (backward of ReLU / LeakyReLU)
+    float mask_slope;
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
 
     // ---- epilogue: stage the 256 px x 128 co tile as bf16 rows of 256 B, then 16-byte global stores -----------
     bf16_t* st = reinterpret_cast<bf16_t*>(smem);
+    const bool early_act = p.R == nullptr || p.res_mask;     // no residual add between the accumulator and the activation
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int lc = nt * 32 + l31;
@@ -184,7 +188,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lp = (2 * wave + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                st[lp * 128 + lc] = f32_to_bf16(acc[mt][nt][r] + bcol);
+                float v = acc[mt][nt][r] + bcol;
+                if (early_act) v = v > 0.f ? v : v * p.act_slope;
+                st[lp * 128 + lc] = f32_to_bf16(v);
             }
     }
     __syncthreads();
@@ -205,8 +211,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
             const unsigned* pr = &rv.x;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float lo = __uint_as_float(pv[k] << 16) + __uint_as_float(pr[k] << 16);
-                const float hi = __uint_as_float(pv[k] & 0xffff0000u) + __uint_as_float(pr[k] & 0xffff0000u);
+                float lo = __uint_as_float(pv[k] << 16), hi = __uint_as_float(pv[k] & 0xffff0000u);
+                const float rlo = __uint_as_float(pr[k] << 16), rhi = __uint_as_float(pr[k] & 0xffff0000u);
+                if (p.res_mask) {
+                    lo *= rlo > 0.f ? 1.f : p.mask_slope;
+                    hi *= rhi > 0.f ? 1.f : p.mask_slope;
+                } else {
+                    lo += rlo;
+                    hi += rhi;
+                    lo = lo > 0.f ? lo : lo * p.act_slope;
+                    hi = hi > 0.f ? hi : hi * p.act_slope;
+                }
                 pv[k] = pack_bf16x2(lo, hi);
             }
         }
@@ -257,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
 // negative on error.  x: [N,H,W,Cin] bf16; w: rows of [9][Cin]; y: [N,H,W,Cout].
 int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N,
                          int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, int up, const float* gn_ss,
-                         double* out_stats, int out_groups, hipStream_t stream) {
+                         double* out_stats, int out_groups, float act_slope, int res_mask, float mask_slope,
+                         hipStream_t stream) {
     if (H % TH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
     if (out_stats != nullptr && (out_groups <= 0 || Cout % out_groups != 0 || 128 % (Cout / out_groups) != 0)) return 0;
     if (N * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31) || Cout * 9 * Cin >= (1ll << 31)) return 0;
@@ -268,6 +284,7 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     p.flip = flip;
     p.up = up;
     p.gn_ss = gn_ss; p.out_stats = out_stats; p.out_groups = out_groups;
+    p.act_slope = act_slope; p.res_mask = res_mask; p.mask_slope = mask_slope;
     const int64_t blocks = N * p.tiles_y * p.tiles_x * p.gn;
     if (blocks >= (1ll << 31)) return 0;
     dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel, LDSB);

@@ -13,6 +13,21 @@ namespace {
 // pixels per block: 1024 for large maps; small maps (HW <= 4096) use 64 so that N * HW / rows still fills the chip
 __host__ __device__ inline int gn_rows_per_block(int64_t HW) { return HW > 4096 ? 1024 : 64; }
 
+// activation fused behind the normalisation: 0 none, 1 swish (x*sigmoid(x)), 2 LeakyReLU(0.2) (PatchGAN, BatchNorm mode)
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_LRELU = 2 };
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float z) {
+    if (ACT == ACT_SILU) return swishf(z);
+    if (ACT == ACT_LRELU) return z > 0.f ? z : 0.2f * z;
+    return z;
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad(float z) {
+    if (ACT == ACT_SILU) return swish_grad(z);
+    if (ACT == ACT_LRELU) return z > 0.f ? 1.f : 0.2f;
+    return 1.f;
+}
+
 struct GnGeom {
     int ncol;           // C / 8
     int rows_per_pass;  // 256 / ncol
@@ -72,7 +87,7 @@ __device__ __forceinline__ void gn_mean_rstd(const double* stats, int64_t n, int
     rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-template <typename T, bool SILU>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int64_t HW, int64_t C, int G, float eps,
                                                        const double* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -80,11 +95,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const GnGeom ge = gn_geom(C, G);
     const int64_t n = blockIdx.y;
     const double cnt = (double)HW * ge.cpg;
-    if (blockIdx.x == 0 && mean_rstd != nullptr && (int)threadIdx.x < G) {
-        float m, r;
-        gn_mean_rstd(stats, n, G, threadIdx.x, cnt, eps, m, r);
-        mean_rstd[(n * G + threadIdx.x) * 2] = m;
-        mean_rstd[(n * G + threadIdx.x) * 2 + 1] = r;
+    if (blockIdx.x == 0 && mean_rstd != nullptr) {
+        for (int g = threadIdx.x; g < G; g += 256) {
+            float m, r;
+            gn_mean_rstd(stats, n, G, g, cnt, eps, m, r);
+            mean_rstd[(n * G + g) * 2] = m;
+            mean_rstd[(n * G + g) * 2 + 1] = r;
+        }
     }
     const int col = threadIdx.x % ge.ncol, prow = threadIdx.x / ge.ncol;
     if (prow >= ge.rows_per_pass) return;
@@ -105,13 +122,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float z = fmaf(v[j], sc[j], sh[j]);
-            v[j] = SILU ? swishf(z) : z;
+            v[j] = act_fwd<ACT>(z);
         }
         store8(y + off + p * C, v);
     }
 }
 
-template <typename T, bool SILU>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                             int64_t HW, int64_t C, int G,
                                                             const float* __restrict__ mean_rstd,
@@ -147,7 +164,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
             for (int j = 0; j < 8; ++j) {
                 const float xh = (v[j] - mu[j]) * rs[j];
                 float dz = g8[j];
-                if (SILU) dz *= swish_grad(fmaf(xh, ga[j], be[j]));
+                if (ACT != ACT_NONE) dz *= act_grad<ACT>(fmaf(xh, ga[j], be[j]));
                 a[j] += dz;
                 b[j] = fmaf(dz, xh, b[j]);
             }
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-template <typename T, bool SILU>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t HW,
                                                         int64_t C, int G, const float* __restrict__ mean_rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x,
         for (int j = 0; j < 8; ++j) {
             const float xh = (v[j] - mu[j]) * rs[j];
             float dz = g8[j];
-            if (SILU) dz *= swish_grad(fmaf(xh, ga[j], be[j]));
+            if (ACT != ACT_NONE) dz *= act_grad<ACT>(fmaf(xh, ga[j], be[j]));
             v[j] = rs[j] * (dz * ga[j] - m1[j] - xh * m2[j]);
         }
         if (addend != nullptr) {       // gradient of a residual branch that joins here (ResnetBlock skip path)
@@ -278,13 +295,13 @@ int dvq_gn_apply(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int
                  const float* gamma, const float* beta, int silu, void* y, float* mean_rstd, dvq_stream_t stream) {
     DVQ_REQUIRE(x && stats && gamma && beta && y, DVQ_EINVAL, "dvq_gn_apply: null pointer");
     if (int e = gn_check("dvq_gn_apply", N, HW, C, G)) return e;
-    DVQ_REQUIRE(G <= 256, DVQ_ESHAPE, "dvq_gn_apply: G > 256");
     dim3 grid((unsigned)cdiv64(HW, gn_rows_per_block(HW)), (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
-    DVQ_DISPATCH_DTYPE(dtype, T, if (silu) gn_apply_kernel<T, true><<<grid, dim3(256), 0, s>>>(
-                                     (const T*)x, HW, C, G, eps, stats, gamma, beta, (T*)y, mean_rstd);
-                       else gn_apply_kernel<T, false><<<grid, dim3(256), 0, s>>>((const T*)x, HW, C, G, eps, stats, gamma,
-                                                                                 beta, (T*)y, mean_rstd););
+#define GN_ACT_SWITCH(KERN, LDS, ...)                                                              \
+    if (silu == ACT_SILU) KERN<T, ACT_SILU><<<grid, dim3(256), LDS, s>>>(__VA_ARGS__);              \
+    else if (silu == ACT_LRELU) KERN<T, ACT_LRELU><<<grid, dim3(256), LDS, s>>>(__VA_ARGS__);       \
+    else KERN<T, ACT_NONE><<<grid, dim3(256), LDS, s>>>(__VA_ARGS__);
+    DVQ_DISPATCH_DTYPE(dtype, T, GN_ACT_SWITCH(gn_apply_kernel, 0, (const T*)x, HW, C, G, eps, stats, gamma, beta, (T*)y, mean_rstd));
     DVQ_CHECK_LAUNCH("gn_apply");
     return DVQ_OK;
 }
@@ -298,10 +315,7 @@ int dvq_gn_bwd_reduce(const void* x, const void* dy, int dtype, int64_t N, int64
     dim3 grid((unsigned)cdiv64(HW, gn_rows_per_block(HW)), (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
     size_t lds = 2 * C * sizeof(float);
-    DVQ_DISPATCH_DTYPE(dtype, T, if (silu) gn_bwd_reduce_kernel<T, true><<<grid, dim3(256), lds, s>>>(
-                                     (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, dgamma, dbeta);
-                       else gn_bwd_reduce_kernel<T, false><<<grid, dim3(256), lds, s>>>(
-                           (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, dgamma, dbeta););
+    DVQ_DISPATCH_DTYPE(dtype, T, GN_ACT_SWITCH(gn_bwd_reduce_kernel, lds, (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, dgamma, dbeta));
     DVQ_CHECK_LAUNCH("gn_bwd_reduce");
     return DVQ_OK;
 }
@@ -313,10 +327,7 @@ int dvq_gn_bwd_dx(const void* x, const void* dy, int dtype, int64_t N, int64_t H
     if (int e = gn_check("dvq_gn_bwd_dx", N, HW, C, G)) return e;
     dim3 grid((unsigned)cdiv64(HW, gn_rows_per_block(HW)), (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
-    DVQ_DISPATCH_DTYPE(dtype, T, if (silu) gn_bwd_dx_kernel<T, true><<<grid, dim3(256), 0, s>>>(
-                                     (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, (const T*)addend, (T*)dx);
-                       else gn_bwd_dx_kernel<T, false><<<grid, dim3(256), 0, s>>>(
-                           (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, (const T*)addend, (T*)dx););
+    DVQ_DISPATCH_DTYPE(dtype, T, GN_ACT_SWITCH(gn_bwd_dx_kernel, 0, (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, (const T*)addend, (T*)dx));
     DVQ_CHECK_LAUNCH("gn_bwd_dx");
     return DVQ_OK;
 }

@@ -44,6 +44,9 @@ struct NtParams {
     int bias_mode;       // 0 none, 1 per column, 2 per row
     int64_t sA, sB, sC;  // batch strides
     int gm, gn;          // tile grid (M tiles x N tiles); the launch grid is 1-D over gm*gn, XCD-remapped
+    float act_slope;     // output activation v > 0 ? v : act_slope * v (1: none, 0: ReLU, 0.2: LeakyReLU), applied last
+    int res_mask;        // 1: R gates instead of adds: v *= (R > 0 ? 1 : mask_slope) (ReLU / LeakyReLU backward)
+    float mask_slope;
 };
 
 // XCD-aware work-item order (MI355X: block b is dispatched to XCD b % 8, each XCD has a private 4-MiB L2):
@@ -129,7 +132,12 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[2][
                     float v = acc[mt][nt][r] * p.alpha + bcol;
                     if (p.bias_mode == 2) v += p.bias[row];
                     const int64_t o = (int64_t)row * p.ldc + col;
-                    if (Rg) v += ElemIO<T>::load(Rg + o);
+                    if (Rg) {
+                        const float rr = ElemIO<T>::load(Rg + o);
+                        if (p.res_mask) v *= rr > 0.f ? 1.f : p.mask_slope;
+                        else v += rr;
+                    }
+                    v = v > 0.f ? v : v * p.act_slope;
                     ElemIO<T>::store(Cg + o, v);
                 }
             }
@@ -142,6 +150,13 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[2][
 // read are full 16-byte accesses along the channel dimension instead of 2-byte scalar accesses.
 // Caller guarantees a preceding __syncthreads() (all MFMA reads of smem are done) and ldc % VN == 0.
 // -------------------------------------------------------------------------------------------------
+// residual handling of the vectorised epilogue: add (then activation) or gate
+__device__ __forceinline__ float nt_res(const NtParams& p, float v, float r) {
+    if (p.res_mask) return v * (r > 0.f ? 1.f : p.mask_slope);
+    v += r;
+    return v > 0.f ? v : v * p.act_slope;
+}
+
 template <typename T>
 __device__ __forceinline__ void nt_epilogue_vec(const NtParams& p, f32x16 (&acc)[2][2], char* smem, int m0, int n0,
                                                 int64_t bz, int wm, int wn, int tid) {
@@ -149,6 +164,7 @@ __device__ __forceinline__ void nt_epilogue_vec(const NtParams& p, f32x16 (&acc)
     constexpr int ROW = TILE * (int)sizeof(T);          // staged row bytes (256 / 512)
     const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     T* st = reinterpret_cast<T*>(smem);
+    const bool early_act = p.R == nullptr || p.res_mask;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int lc = wn * 64 + nt * 32 + l31;
@@ -161,6 +177,7 @@ __device__ __forceinline__ void nt_epilogue_vec(const NtParams& p, f32x16 (&acc)
                 const int lr = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v = acc[mt][nt][r] * p.alpha + bcol;
                 if (p.bias_mode == 2 && m0 + lr < p.M) v += p.bias[m0 + lr];
+                if (early_act) v = v > 0.f ? v : v * p.act_slope;
                 ElemIO<T>::store(st + lr * TILE + lc, v);
             }
     }
@@ -184,15 +201,15 @@ __device__ __forceinline__ void nt_epilogue_vec(const NtParams& p, f32x16 (&acc)
                     const unsigned* pr = &rv.x;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float lo = __uint_as_float(pv[k] << 16) + __uint_as_float(pr[k] << 16);
-                        const float hi = __uint_as_float(pv[k] & 0xffff0000u) + __uint_as_float(pr[k] & 0xffff0000u);
+                        const float lo = nt_res(p, __uint_as_float(pv[k] << 16), __uint_as_float(pr[k] << 16));
+                        const float hi = nt_res(p, __uint_as_float(pv[k] & 0xffff0000u), __uint_as_float(pr[k] & 0xffff0000u));
                         pv[k] = pack_bf16x2(lo, hi);
                     }
                 } else {
                     float* pv = reinterpret_cast<float*>(&v.x);
                     const float* pr = reinterpret_cast<const float*>(&rv.x);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) pv[k] += pr[k];
+                    for (int k = 0; k < 4; ++k) pv[k] = nt_res(p, pv[k], pr[k]);
                 }
             }
             *reinterpret_cast<uint4*>(Cg + o) = v;
@@ -200,7 +217,7 @@ __device__ __forceinline__ void nt_epilogue_vec(const NtParams& p, f32x16 (&acc)
             const T* sv = reinterpret_cast<const T*>(&v);
             for (int k = 0; k < VN && col + k < p.Ncols; ++k) {
                 float f = ElemIO<T>::load(sv + k);
-                if (Rg) f += ElemIO<T>::load(Rg + o + k);
+                if (Rg) f = nt_res(p, f, ElemIO<T>::load(Rg + o + k));
                 ElemIO<T>::store(Cg + o + k, f);
             }
         }
@@ -963,7 +980,12 @@ __global__ void naive_nt_kernel(NtParams p) {
         if (p.bias_mode == 1) v += p.bias[col];
         if (p.bias_mode == 2) v += p.bias[m];
         const int64_t o = (int64_t)m * p.ldc + col;
-        if (Rg) v += ElemIO<T>::load(Rg + o);
+        if (Rg) {
+            const float rr = ElemIO<T>::load(Rg + o);
+            if (p.res_mask) v *= rr > 0.f ? 1.f : p.mask_slope;
+            else v += rr;
+        }
+        v = v > 0.f ? v : v * p.act_slope;
         ElemIO<T>::store(Cg + o, v);
     }
 }
@@ -1118,11 +1140,14 @@ int conv_check(const dvq_conv_desc* d, const char* who) {
 // conv_halo.hip: LDS-resident-halo kernel for 3x3 / stride 1 / pad 1 bf16 convolutions (1 = handled, 0 = not eligible)
 int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N,
                          int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, int up, const float* gn_ss,
-                         double* out_stats, int out_groups, hipStream_t stream);
+                         double* out_stats, int out_groups, float act_slope, int res_mask, float mask_slope,
+                         hipStream_t stream);
 
 int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* db, int64_t N, int64_t H, int64_t W,
                                int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw, int up,
                                const float* gn_ss, hipStream_t stream);
+
+static float act_slope_of(int act) { return act == DVQ_ACT_RELU ? 0.f : act == DVQ_ACT_LRELU ? 0.2f : 1.f; }
 
 static bool halo_eligible(const dvq_conv_desc* d) {
     return d->dtype == DVQ_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
@@ -1142,19 +1167,36 @@ int dvq_conv2d_fwd(const dvq_conv_desc* d, const void* x, const void* w, const f
     return dvq_conv2d_fwd_ex(d, x, w, bias, residual, y, nullptr, nullptr, 0, stream);
 }
 
+static int conv2d_fwd_impl(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                           void* y, const float* gn_scale_shift, double* out_stats, int out_groups, int act,
+                           dvq_stream_t stream);
+
+int dvq_conv2d_fwd_ex(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                      void* y, const float* gn_scale_shift, double* out_stats, int out_groups, dvq_stream_t stream) {
+    return conv2d_fwd_impl(d, x, w, bias, residual, y, gn_scale_shift, out_stats, out_groups, DVQ_ACT_NONE, stream);
+}
+
+int dvq_conv2d_fwd_act(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act,
+                       dvq_stream_t stream) {
+    DVQ_REQUIRE(act == DVQ_ACT_NONE || act == DVQ_ACT_RELU || act == DVQ_ACT_LRELU, DVQ_EINVAL, "dvq_conv2d_fwd_act: bad act");
+    return conv2d_fwd_impl(d, x, w, bias, nullptr, y, nullptr, nullptr, 0, act, stream);
+}
+
 int dvq_conv3x3_fused_ok(const dvq_conv_desc* d) {
     // shapes on which the halo kernels (and therefore the fused GroupNorm prologue / statistics epilogue) run
     return d != nullptr && halo_eligible(d) && d->H % 8 == 0 && d->W % 32 == 0 && d->Cin % 64 == 0 && d->Cout % 8 == 0 &&
            d->N * d->H * d->W * (d->Cin > d->Cout ? d->Cin : d->Cout) < (1ll << 31);
 }
 
-int dvq_conv2d_fwd_ex(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
-                      void* y, const float* gn_scale_shift, double* out_stats, int out_groups, dvq_stream_t stream) {
+static int conv2d_fwd_impl(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                           void* y, const float* gn_scale_shift, double* out_stats, int out_groups, int act,
+                           dvq_stream_t stream) {
     if (int e = conv_check(d, "dvq_conv2d_fwd")) return e;
     DVQ_REQUIRE(x && w && y, DVQ_EINVAL, "dvq_conv2d_fwd: null pointer");
     if (halo_eligible(d)) {
         const int rc = dvq_conv3x3_halo_try(x, w, bias, residual, y, d->N, d->H, d->W, d->Cin, d->Cout, 0, d->upsample,
-                                            gn_scale_shift, out_stats, out_groups, (hipStream_t)stream);
+                                            gn_scale_shift, out_stats, out_groups, act_slope_of(act), 0, 0.f,
+                                            (hipStream_t)stream);
         if (rc != 0) return rc < 0 ? rc : DVQ_OK;
     }
     DVQ_REQUIRE(gn_scale_shift == nullptr && out_stats == nullptr, DVQ_ESHAPE,
@@ -1169,6 +1211,7 @@ int dvq_conv2d_fwd_ex(const dvq_conv_desc* d, const void* x, const void* w, cons
     p.LH = (int)d->H; p.LW = (int)d->W; p.DH = (int)d->OH; p.DW = (int)d->OW;
     p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.up = d->upsample;
     p.alpha = 1.f; p.bias_mode = bias ? 1 : 0;
+    p.act_slope = act_slope_of(act);
     if (d->dtype == DVQ_F32) return launch_nt<float>(p, 1, d->impl, (hipStream_t)stream);
     return launch_nt<bf16_t>(p, 1, d->impl, (hipStream_t)stream);
 }
@@ -1176,12 +1219,20 @@ int dvq_conv2d_fwd_ex(const dvq_conv_desc* d, const void* x, const void* w, cons
 int dvq_sumpool2x2(const void* in, int dtype, int64_t N, int64_t h, int64_t w, int64_t C, void* out, dvq_stream_t stream);
 
 int dvq_conv2d_dgrad(const dvq_conv_desc* d, const void* dy, const void* wt, void* dx, void* ws, dvq_stream_t stream) {
+    return dvq_conv2d_dgrad_mask(d, dy, wt, dx, ws, nullptr, DVQ_ACT_NONE, stream);
+}
+
+int dvq_conv2d_dgrad_mask(const dvq_conv_desc* d, const void* dy, const void* wt, void* dx, void* ws, const void* mask,
+                          int mask_act, dvq_stream_t stream) {
     if (int e = conv_check(d, "dvq_conv2d_dgrad")) return e;
+    DVQ_REQUIRE(mask == nullptr || ((mask_act == DVQ_ACT_RELU || mask_act == DVQ_ACT_LRELU) && !d->upsample), DVQ_EINVAL,
+                "dvq_conv2d_dgrad_mask: mask needs act in {relu, lrelu} and no folded upsample");
     DVQ_REQUIRE(dy && wt && dx && (!d->upsample || ws), DVQ_EINVAL, "dvq_conv2d_dgrad: null pointer");
     if (halo_eligible(d)) {      // dgrad of a 3x3/s1/p1 conv = the same conv over dy with the taps reversed
         // with a folded nearest-x2 upsample the gradient is formed at the upsampled resolution (ws), then 2x2-summed
-        const int rc = dvq_conv3x3_halo_try(dy, wt, nullptr, nullptr, d->upsample ? ws : dx, d->N, d->H, d->W, d->Cout, d->Cin, 1,
-                                            0, nullptr, nullptr, 0, (hipStream_t)stream);
+        const int rc = dvq_conv3x3_halo_try(dy, wt, nullptr, mask, d->upsample ? ws : dx, d->N, d->H, d->W, d->Cout, d->Cin, 1,
+                                            0, nullptr, nullptr, 0, 1.f, mask != nullptr, act_slope_of(mask_act),
+                                            (hipStream_t)stream);
         if (rc < 0) return rc;
         if (rc == 1) return d->upsample ? dvq_sumpool2x2(ws, d->dtype, d->N, d->H / 2, d->W / 2, d->Cin, dx, stream) : DVQ_OK;
     }
@@ -1195,6 +1246,7 @@ int dvq_conv2d_dgrad(const dvq_conv_desc* d, const void* dy, const void* wt, voi
     p.DH = (int)d->H; p.DW = (int)d->W;
     p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.up = 0;
     p.alpha = 1.f; p.bias_mode = 0;
+    p.act_slope = 1.f; p.R = mask; p.res_mask = mask != nullptr; p.mask_slope = act_slope_of(mask_act);
     int rc = d->dtype == DVQ_F32 ? launch_nt<float>(p, 1, d->impl, (hipStream_t)stream)
                                  : launch_nt<bf16_t>(p, 1, d->impl, (hipStream_t)stream);
     if (rc) return rc;
@@ -1272,6 +1324,7 @@ int dvq_gemm_nt(const void* A, const void* B, void* C, int dtype, int64_t M, int
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.stride = 1; p.KW = 1;
     p.alpha = alpha; p.bias_mode = bias_mode;
+    p.act_slope = 1.f;
     p.sA = sA; p.sB = sB; p.sC = sC;
     if (dtype == DVQ_F32) return launch_nt<float>(p, batch, impl, (hipStream_t)stream);
     if (dtype == DVQ_BF16) return launch_nt<bf16_t>(p, batch, impl, (hipStream_t)stream);

@@ -462,8 +462,24 @@ class DualGrainVQModel(nn.Module):
         z = self.post_quant_conv.fwd(xq, _child(tape, "pqc"))
         rec_p = self.decoder.fwd(z, _child(tape, "dec"))
         rec = K.nhwc_pad_to_nchw(rec_p, self.decoder.out_ch)
+        if tape is not None:
+            self._publish_last_layer_wgrad(tape.child("dec").child("co"))
         return {"rec": rec, "qloss": qloss, "codes": codes, "grain": grain, "gate": gate.permute(0, 3, 1, 2),
                 "entropy": ent, "quant": xq, "mask": mask}
+
+    def _publish_last_layer_wgrad(self, t_co):
+        """calculate_adaptive_weight (vqperceptual_multidisc.py:97-107) differentiates two scalars w.r.t. the decoder's
+        last conv weight.  Both are functions of the reconstruction only, so each gradient is ONE wgrad of conv_out
+        with the corresponding d/d(rec) -- this closure is what the loss module calls (no autograd graph exists)."""
+        conv = self.decoder.conv_out
+
+        def wgrad(g_rec_p):
+            buf = torch.zeros(conv.weight.shape, dtype=torch.float32, device=g_rec_p.device)
+            K.conv2d_wgrad_oihw(t_co.s["d"], t_co.s["x"], g_rec_p, conv.in_channels, conv.out_channels, buf, None,
+                                gn_ss=t_co.s.get("gn_ss"))
+            return buf
+
+        conv.weight._dvq_wgrad = wgrad
 
     def ae_bwd(self, g_rec, g_qloss, tape):
         cd = rt.compute_dtype()

@@ -311,9 +311,17 @@ def conv_fused_ok(d: ConvDesc) -> bool:
     return bool(lib().dvq_conv3x3_fused_ok(C.byref(d)))
 
 
-def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None, gn_ss=None, out_stats=None, out_groups=0):
+ACT_NONE, ACT_SWISH, ACT_LRELU, ACT_RELU = 0, 1, 2, 3      # include/dvq_hip.h DVQ_ACT_*
+
+
+def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None, gn_ss=None, out_stats=None, out_groups=0, act=ACT_NONE):
     y = torch.empty(d.N, d.OH, d.OW, d.Cout, dtype=x.dtype, device=x.device)
     fl, nb = _conv_cost(d, x.element_size())
+    if act != ACT_NONE:
+        assert residual is None and gn_ss is None and out_stats is None
+        _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 else "igemm_nt_glds_kernel", fl, nb, lambda: check(
+            lib().dvq_conv2d_fwd_act(C.byref(d), _p(x), _p(w), _p(bias), _p(y), act, _s()), "dvq_conv2d_fwd_act"))
+        return y
     if gn_ss is not None or out_stats is not None:
         _timed("conv3x3_halo_kernel", fl, nb, lambda: check(
             lib().dvq_conv2d_fwd_ex(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), _p(y), _p(gn_ss), _p(out_stats),
@@ -324,14 +332,16 @@ def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None, gn_ss=None, out_stats=Non
     return y
 
 
-def conv2d_dgrad(d: ConvDesc, dy, wt):
+def conv2d_dgrad(d: ConvDesc, dy, wt, mask=None, mask_act=ACT_NONE):
+    """mask: output of the activation that produced this conv's input; the gradient is gated through it"""
     sh, sw = (d.H // 2, d.W // 2) if d.upsample else (d.H, d.W)
     dx = torch.empty(d.N, sh, sw, d.Cin, dtype=dy.dtype, device=dy.device)
     ws = torch.empty(d.N, d.H, d.W, d.Cin, dtype=dy.dtype, device=dy.device) if d.upsample else None
     fl, nb = _conv_cost(d, dy.element_size())
     _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 and d.Cout % 64 == 0 else "igemm_nt_glds_kernel", fl, nb,
            lambda: check(
-        lib().dvq_conv2d_dgrad(C.byref(d), _p(dy), _p(wt), _p(dx), _p(ws), _s()), "dvq_conv2d_dgrad"))
+        lib().dvq_conv2d_dgrad_mask(C.byref(d), _p(dy), _p(wt), _p(dx), _p(ws), _p(mask), mask_act, _s()),
+        "dvq_conv2d_dgrad_mask"))
     return dx
 
 
@@ -507,3 +517,45 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
 
 def fill(p, value):
     check(lib().dvq_fill_f32(_p(p), float(value), p.numel(), _s()), "dvq_fill_f32")
+
+
+# ---------------------------------------------------------------------------------------------
+# loss networks (LPIPS / PatchGAN)
+# ---------------------------------------------------------------------------------------------
+def affine_channels(x, a, b=None):
+    """y[..., c] = x[..., c] * a[c] + b[c]"""
+    y = torch.empty_like(x)
+    check(lib().dvq_affine_channels(_p(x), dt(x), x.numel(), x.shape[-1], _p(a), _p(b), _p(y), _s()), "dvq_affine_channels")
+    return y
+
+
+def axpy_dev(a, b, scale_dev):
+    """a + scale_dev[0] * b (scale_dev: fp32 device scalar)"""
+    y = torch.empty_like(a)
+    check(lib().dvq_axpy_dev(_p(a), _p(b), _p(scale_dev), dt(a), a.numel(), _p(y), _s()), "dvq_axpy_dev")
+    return y
+
+
+def maxpool2x2(x):
+    n, h2, w2, c = x.shape
+    y = torch.empty(n, h2 // 2, w2 // 2, c, dtype=x.dtype, device=x.device)
+    check(lib().dvq_maxpool2x2(_p(x), dt(x), n, h2 // 2, w2 // 2, c, _p(y), _s()), "dvq_maxpool2x2")
+    return y
+
+
+def maxpool2x2_relu_bwd(a, dpool=None, dtap=None):
+    n, h2, w2, c = a.shape
+    dz = torch.empty_like(a)
+    check(lib().dvq_maxpool2x2_relu_bwd(_p(a), _p(dpool), _p(dtap), dt(a), n, h2 // 2, w2 // 2, c, _p(dz), _s()),
+          "dvq_maxpool2x2_relu_bwd")
+    return dz
+
+
+def lpips_head(f0, f1, lin, val, gscale=0.0, want_grad=False):
+    """val[n] (fp32, accumulated) += LPIPS term of one tap; returns d val / d f1 * gscale (or None)"""
+    n, c = f0.shape[0], f0.shape[-1]
+    hw = f0.numel() // (n * c)
+    df1 = torch.empty_like(f1) if want_grad else None
+    check(lib().dvq_lpips_head(_p(f0), _p(f1), _p(lin), dt(f0), n, hw, c, _p(val), float(gscale), _p(df1), _s()),
+          "dvq_lpips_head")
+    return df1

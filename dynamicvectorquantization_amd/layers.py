@@ -138,6 +138,57 @@ class Normalize(HipModule):
                              self.num_groups, s["silu"], addend)
 
 
+class BatchNorm2d(HipModule):
+    """torch.nn.BatchNorm2d(C) (eps 1e-5, momentum 0.1, affine, running statistics) with the LeakyReLU(0.2) that
+    follows it in the PatchGAN fused in (modules/discriminator/model.py:44-60).  Training mode normalises with the
+    batch statistics: that is GroupNorm with one group per channel over the whole batch, so it runs on the dvq_gn_*
+    kernels with the tensor viewed as [1, N*H*W, C].  Eval mode uses the running statistics (per-channel affine)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.act = K.ACT_NONE
+
+    def fwd(self, x, tape, act=None, update_running=True):
+        act = self.act if act is None else act
+        n, h, w, c = x.shape
+        flat = x.view(1, n * h * w, c)
+        if self.training:
+            stats = K.gn_stats(flat, c)
+            y, mr = K.gn_forward(flat, self.weight, self.bias, c, self.eps, act, stats=stats)
+            if update_running:
+                cnt = float(n * h * w)
+                mean = stats[0, :, 0] / cnt
+                var = (stats[0, :, 1] / cnt - mean * mean).clamp_(min=0) * (cnt / max(cnt - 1.0, 1.0))
+                self.running_mean.mul_(1 - self.momentum).add_(mean.float(), alpha=self.momentum)
+                self.running_var.mul_(1 - self.momentum).add_(var.float(), alpha=self.momentum)
+                self.num_batches_tracked += 1
+        else:
+            # eval: the running statistics are turned into the {sum, sum of squares} of a unit count, so the same
+            # kernel applies (x - mean) / sqrt(var + eps)
+            stats = torch.stack([self.running_mean.double(), (self.running_var + self.running_mean ** 2).double()], dim=1)
+            stats = (stats * float(n * h * w)).view(1, c, 2).contiguous()
+            y, mr = K.gn_forward(flat, self.weight, self.bias, c, self.eps, act, stats=stats)
+        if tape is not None:
+            tape.s.update(x=flat, mr=mr, act=act, shape=x.shape)
+        return y.view(n, h, w, c)
+
+    def bwd(self, dy, tape, need_dw=True):
+        s = tape.s
+        c = self.num_features
+        if need_dw:
+            dg, db = _grad_buf(self.weight), _grad_buf(self.bias)
+        else:
+            dg, db = torch.zeros_like(self.weight), torch.zeros_like(self.bias)
+        dx = K.gn_backward(s["x"], dy.view(s["x"].shape), s["mr"], self.weight, self.bias, dg, db, c, s["act"])
+        return dx.view(s["shape"])
+
+
 class Conv2d(HipModule):
     """torch.nn.Conv2d-compatible parameters ([Cout,Cin,KH,KW] + bias, same default init) driving the
     implicit-GEMM kernels.  `asym_pad` reproduces Downsample's F.pad(0,1,0,1); `upsample` reads the
@@ -213,9 +264,14 @@ class Conv2d(HipModule):
         the GroupNorm statistics of their output"""
         return x.dtype == torch.bfloat16 and self.kernel_size == 3 and K.conv_fused_ok(self._desc(x))
 
-    def fwd(self, x, tape, residual=None, gn_ss=None, want_stats=False):
+    def fwd(self, x, tape, residual=None, gn_ss=None, want_stats=False, act=K.ACT_NONE):
         w, _, bias = self.packed(x.dtype)
         d = self._desc(x)
+        if act != K.ACT_NONE:           # ReLU / LeakyReLU fused into the conv epilogue (VGG16, PatchGAN)
+            y = K.conv2d_fwd(d, x, w, bias, act=act)
+            if tape is not None:
+                tape.s.update(x=x, d=d, gn_ss=None)
+            return y
         stats = None
         if want_stats and self.out_channels % 32 == 0 and 128 % (self.out_channels // 32) == 0 and self.fused_ok(x):
             stats = K.zeros_small((d.N, 32, 2), torch.float64, x.device)
@@ -226,16 +282,19 @@ class Conv2d(HipModule):
             tape.s.update(x=x, d=d, gn_ss=gn_ss)
         return y
 
-    def bwd(self, dy, tape, need_dx=True):
+    def bwd(self, dy, tape, need_dx=True, need_dw=True, mask=None, mask_act=K.ACT_NONE):
+        """mask / mask_act: output and kind of the activation that produced this conv's input (its gate is applied to dx);
+        need_dw=False: frozen parameters (LPIPS' VGG16, the discriminator during the generator update)"""
         x, d = tape.s["x"], tape.s["d"]
-        db = _grad_buf(self.bias) if self.bias is not None else None
-        # weight / bias gradients are accumulated by the kernel straight into the reference-layout .grad buffers
-        K.conv2d_wgrad_oihw(d, x, dy, self.in_channels, self.out_channels, _grad_buf(self.weight), db,
-                            gn_ss=tape.s.get("gn_ss"))
+        if need_dw:
+            db = _grad_buf(self.bias) if self.bias is not None else None
+            # weight / bias gradients are accumulated by the kernel straight into the reference-layout .grad buffers
+            K.conv2d_wgrad_oihw(d, x, dy, self.in_channels, self.out_channels, _grad_buf(self.weight), db,
+                                gn_ss=tape.s.get("gn_ss"))
         if not need_dx:
             return None
         _, wt, _ = self.packed(x.dtype)
-        return K.conv2d_dgrad(d, dy, wt)
+        return K.conv2d_dgrad(d, dy, wt, mask=mask, mask_act=mask_act)
 
 
 class _PackRegistry:

@@ -38,6 +38,17 @@ def det_param(name: str, shape, seed: int = 0) -> np.ndarray:
     return (0.1 * rs.uniform(-1, 1, size=shape)).astype(np.float32)
 
 
+def det_lpips_param(name: str, shape, seed: int = 0) -> np.ndarray:
+    """Deterministic LPIPS parameters (ImageNet VGG16 weights cannot be fetched offline): conv weights are scaled by
+    sqrt(6) so the 13-layer ReLU stack keeps its activation variance, NetLinLayer weights are non-negative."""
+    v = det_param(name, shape, seed)
+    if ".model." in name:
+        return np.abs(v)
+    if len(tuple(shape)) == 4:
+        return (v * np.float32(np.sqrt(6.0))).astype(np.float32)
+    return v
+
+
 def det_state_dict(shapes: dict, seed: int = 0) -> dict:
     """shapes: {name: shape}. Returns {name: np.float32 array}."""
     return {k: det_param(k, v, seed) for k, v in shapes.items()}

@@ -97,7 +97,7 @@ int dvq_patch_entropy_gate(const float* img, int64_t B, int64_t H, int64_t W, in
  * ---------------------------------------------------------------------------------------------- */
 int dvq_gn_stats(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int G, double* stats,
                  dvq_stream_t stream);
-/* y = act(gn(x)); act = swish if silu != 0.  mean_rstd (fp32 [N,G,2]) is written for the backward. */
+/* y = act(gn(x)); `silu` is an activation code: 0 none, 1 swish, 2 LeakyReLU(0.2) (see DVQ_ACT_*).  mean_rstd (fp32 [N,G,2]) is written for the backward. */
 int dvq_gn_apply(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int G, float eps, const double* stats,
                  const float* gamma, const float* beta, int silu, void* y, float* mean_rstd, dvq_stream_t stream);
 /* backward pass 1: red fp64 [N,G,2] (zeroed) += (sum dz*gamma, sum dz*gamma*xhat); dgamma/dbeta fp32 [C] += .
@@ -153,6 +153,17 @@ int dvq_gn_scale_shift(const double* stats, const float* gamma, const float* bet
  * ws must hold N*H*W*Cin elements of `dtype` (gradient at the upsampled resolution). */
 int dvq_conv2d_dgrad(const dvq_conv_desc* d, const void* dy, const void* wt, void* dx, void* ws,
                      dvq_stream_t stream);
+/* Activations fused into conv epilogues / behind a normalisation (dvq_gn_* take the same codes in `silu`):
+ * 0 none, 1 swish (GroupNorm only), 2 LeakyReLU(0.2) (PatchGAN, modules/discriminator/model.py:35-62),
+ * 3 ReLU (VGG16 of LPIPS, modules/losses/lpips.py:75-93; conv epilogues only). */
+enum { DVQ_ACT_NONE = 0, DVQ_ACT_SWISH = 1, DVQ_ACT_LRELU = 2, DVQ_ACT_RELU = 3 };
+/* y = act(conv(x, w) + bias): replaces nn.Conv2d followed by nn.ReLU / nn.LeakyReLU(0.2) */
+int dvq_conv2d_fwd_act(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act,
+                       dvq_stream_t stream);
+/* dgrad through the conv AND the activation that produced the conv's input: mask = that activation's OUTPUT
+ * (same shape as dx); dx = dgrad * (mask > 0 ? 1 : slope(mask_act)).  mask == NULL: plain dvq_conv2d_dgrad. */
+int dvq_conv2d_dgrad_mask(const dvq_conv_desc* d, const void* dy, const void* wt, void* dx, void* ws, const void* mask,
+                          int mask_act, dvq_stream_t stream);
 /* dw (fp32 OHWI, ACCUMULATED into -- zero it first) and dbias (fp32 [Cout], accumulated; may be NULL). */
 int dvq_conv2d_wgrad(const dvq_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                      dvq_stream_t stream);
@@ -195,6 +206,25 @@ int dvq_gemm_nt(const void* A, const void* B, void* C, int dtype, int64_t M, int
 int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred, int64_t I, int64_t J, int64_t lda,
                 int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int impl,
                 dvq_stream_t stream);
+
+/* ---- loss networks (LPIPS + PatchGAN), modules/losses/lpips.py, modules/discriminator/model.py -------------------
+ * BatchNorm2d (training mode) = dvq_gn_* with N=1, HW=N*H*W, G=C (one group per channel over the whole batch). */
+/* ScalingLayer (lpips.py:53-61) and its backward: y[..,c] = x[..,c]*a[c] + b[c]  (b may be NULL); n = total elements */
+int dvq_affine_channels(const void* x, int dtype, int64_t n, int64_t C, const float* a, const float* b, void* y,
+                        dvq_stream_t stream);
+/* y = a + scale_dev[0] * b  (generator-loss weighting with the device-resident adaptive weight,
+ * vqperceptual_multidisc.py:97-107,139); n % 8 == 0 */
+int dvq_axpy_dev(const void* a, const void* b, const float* scale_dev, int dtype, int64_t n, void* y, dvq_stream_t stream);
+/* nn.MaxPool2d(2,2) of VGG16 on NHWC: x [N,2h,2w,C] -> y [N,h,w,C] */
+int dvq_maxpool2x2(const void* x, int dtype, int64_t N, int64_t h, int64_t w, int64_t C, void* y, dvq_stream_t stream);
+/* backward of ReLU -> {feature tap, max-pool}: dz = (route(dpool) + dtap) * (a > 0); a = ReLU output [N,2h,2w,C],
+ * dpool [N,h,w,C] or NULL, dtap like a or NULL; ties go to the first maximum in scan order (torch semantics) */
+int dvq_maxpool2x2_relu_bwd(const void* a, const void* dpool, const void* dtap, int dtype, int64_t N, int64_t h, int64_t w,
+                            int64_t C, void* dz, dvq_stream_t stream);
+/* LPIPS head of one tap (lpips.py:41-50,113-121): val[n] += mean_p sum_c lin[c]*(f0/(|f0|+1e-10) - f1/(|f1|+1e-10))^2;
+ * df1 (NULL to skip) = gscale * d val[n] / d f1, gated by f1 > 0.  C in {64,128,256,512}. */
+int dvq_lpips_head(const void* f0, const void* f1, const float* lin, int dtype, int64_t N, int64_t HW, int64_t C, float* val,
+                   float gscale, void* df1, dvq_stream_t stream);
 
 /* row softmax (AttnBlock, model.py:182) and its backward, rows of length L, in place allowed */
 int dvq_softmax_rows(const void* s, int dtype, int64_t rows, int64_t L, float scale, void* p, dvq_stream_t stream);

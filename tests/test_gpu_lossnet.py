@@ -1,0 +1,211 @@
+"""GPU parity of the training-loss networks (PatchGAN, LPIPS, VQLPIPSWithDiscriminator both optimizer branches) against
+goldens captured from the reference (tests/golden/losses.npz, lossnet.npz) and against the oracle.  `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from dynamicvectorquantization_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(got, ref, l2=False):
+    """max-norm error relative to the largest reference entry; l2=True: relative Frobenius error (bf16 runs: a
+    LeakyReLU / ReLU / max-pool decision that flips on a rounding-level pre-activation changes isolated gradient
+    entries by O(1) of their size, which the max norm would report although the tensor as a whole agrees)"""
+    ref = np.asarray(ref, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64).reshape(ref.shape)
+    if l2:
+        return float(np.linalg.norm(got - ref)) / max(1e-30, float(np.linalg.norm(ref)))
+    return float(np.abs(got - ref).max()) / max(1e-12, float(np.abs(ref).max()))
+
+
+def _load_det(module, prefix, fn=synth.det_param):
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            p.copy_(torch.from_numpy(fn(prefix + n, tuple(p.shape))).to(p.device))
+    from dynamicvectorquantization_amd import runtime as rt
+    rt.bump_weights_epoch()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 6e-2)])
+def test_patchgan_golden(dev, dtype, tol):
+    """forward logits, input gradient, parameter gradients and BatchNorm running statistics vs the reference module"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.losses import NLayerDiscriminator
+    g = load_golden("losses")
+    with rt.compute_dtype_ctx(dtype):
+        disc = NLayerDiscriminator(input_nc=3, ndf=16, n_layers=3).to(dev).train()
+        _load_det(disc, "disc.")
+        x = torch.from_numpy(synth.det_param("disc.x", (2, 3, 64, 64)) * 40).to(dev).requires_grad_(True)
+        y = disc(x)
+        assert tuple(y.shape) == g["disc_y"].shape
+        gout = torch.from_numpy(synth.det_param("disc.gout", tuple(y.shape))).to(dev)
+        (y * gout).sum().backward()
+        l2 = dtype == torch.bfloat16
+        assert _rel(y.detach().cpu().numpy(), g["disc_y"]) < tol
+        assert _rel(x.grad.cpu().numpy(), g["disc_dx"], l2) < tol * 2
+        for n, p in disc.named_parameters():
+            assert _rel(p.grad.cpu().numpy(), g["disc_d." + n], l2) < tol * 2, n
+        for n, b in disc.named_buffers():
+            ref = g["disc_buf." + n]
+            if ref.ndim == 0:
+                assert int(b) == int(ref)
+            else:
+                np.testing.assert_allclose(b.cpu().numpy(), ref, rtol=max(tol, 1e-4), atol=tol * 1e-2)
+
+
+# bf16 note: with the deterministic random VGG16 the normalised features of two images differ by only ~1e-2..1e-1 of
+# their norm, so rounding the features to bf16 (2^-9 relative) perturbs the DIFFERENCE the metric is built on by tens
+# of percent: bf16 rows are sanity bounds, the fp32 rows are the parity check.
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-3, 2e-2), (torch.bfloat16, 0.6, 0.8)])
+def test_lpips_golden(dev, dtype, tol, gtol):
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.losses import LPIPS, _padc
+    g = load_golden("lossnet")
+    with rt.compute_dtype_ctx(dtype):
+        lp = LPIPS().to(dev)
+        own = {k: tuple(v.shape) for k, v in lp.state_dict().items()}
+        ref = {str(k): tuple(int(x) for x in str(s).split(",")) for k, s in zip(g["lpips_shapes_keys"], g["lpips_shapes"])}
+        assert own == ref                                       # state_dict layout of the reference's LPIPS
+        _load_det(lp, "lpips.", synth.det_lpips_param)
+        cp = _padc(3, dtype)
+        x_p = K.nchw_to_nhwc_pad(torch.from_numpy(g["lpips_x"]).to(dev), cp, dtype)
+        r_p = K.nchw_to_nhwc_pad(torch.from_numpy(g["lpips_xrec"]).to(dev), cp, dtype)
+        val, d_r = lp.fwd(x_p, r_p, gscale=1.0)
+        assert _rel(val.cpu().numpy(), g["lpips_val"].reshape(-1)) < tol
+        d = K.nhwc_pad_to_nchw(d_r, 3).cpu().numpy()
+        assert _rel(d, g["lpips_dxrec"], True) < gtol
+        v2 = lp(torch.from_numpy(g["lpips_x"]).to(dev), torch.from_numpy(g["lpips_xrec"]).to(dev))
+        assert tuple(v2.shape) == (2, 1, 1, 1) and _rel(v2.cpu().numpy(), g["lpips_val"]) < tol
+
+
+def test_maxpool_and_head_kernels_vs_torch(dev):
+    """kernel-level checks against a plain fp32 torch restatement (tie routing, ReLU gate, tap gradient)"""
+    from dynamicvectorquantization_amd import kernels as K
+    torch.manual_seed(3)
+    for dtype in (torch.float32, torch.bfloat16):
+        a = torch.relu(torch.randn(2, 8, 12, 64, device=dev)).to(dtype)
+        a[0, :2, :2, :8] = 0.5                 # a window of exact ties: the first position must receive the gradient
+        y = K.maxpool2x2(a)
+        ref = torch.nn.functional.max_pool2d(a.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+        assert torch.equal(y.float(), ref)
+        dpool = torch.randn_like(y.float()).to(dtype)
+        dtap = torch.randn_like(a.float()).to(dtype)
+        dz = K.maxpool2x2_relu_bwd(a, dpool, dtap)
+        af = a.float().permute(0, 3, 1, 2).requires_grad_(True)
+        torch.nn.functional.max_pool2d(af, 2, 2).backward(dpool.float().permute(0, 3, 1, 2))
+        want = (af.grad.permute(0, 2, 3, 1) + dtap.float()) * (a.float() > 0)
+        tol = 0 if dtype == torch.float32 else 2e-2
+        assert float((dz.float() - want).abs().max()) <= tol * float(want.abs().max()) + 1e-12
+        assert float(dz.float()[0, 0, 0, :8].abs().sum()) > 0 and float((dz.float()[0, 0, 1, :8] - dtap.float()[0, 0, 1, :8]).abs().max()) <= 1e-2
+
+
+def _toy_last_layer(dev, dtype, g):
+    """feat -> conv3x3(8 -> 3) = reconstruction, with the weight-gradient closure the loss module expects"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d, Tape, to_nhwc
+    conv = Conv2d(8, 3, 3, 1, 1).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(synth.det_param("lossnet.last.weight", (3, 8, 3, 3)) * 2.0))
+        conv.bias.copy_(torch.from_numpy(synth.det_param("lossnet.last.bias", (3,))))
+    rt.bump_weights_epoch()
+    feat = torch.from_numpy(synth.det_param("lossnet.feat", (2, 8, 64, 64)) * 4.0).to(dev)
+    tape = Tape()
+    rec_p = conv.fwd(to_nhwc(feat, dtype), tape)
+    xrec = K.nhwc_pad_to_nchw(rec_p, 3).requires_grad_(True)
+
+    def wgrad(g_p):
+        buf = torch.zeros(3, 8, 3, 3, device=dev)
+        K.conv2d_wgrad_oihw(tape.s["d"], tape.s["x"], g_p, 8, 3, buf, None)
+        return buf
+
+    conv.weight._dvq_wgrad = wgrad
+    return conv, tape, xrec
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 3e-3, 1e-2), (torch.bfloat16, 3e-2, 0.35)])
+def test_vqlpips_with_discriminator_golden(dev, dtype, tol, gtol):
+    """both optimizer branches of the reference loss on a toy last layer: loss values, adaptive weight (free and
+    clamped), gradients w.r.t. the features / last layer, discriminator gradients and BatchNorm buffers"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    g = load_golden("lossnet")
+    x = torch.from_numpy(synth.half_flat_images(2, 64, 16, seed=5)).to(dev)
+    qloss = torch.tensor(0.123, device=dev)
+    with rt.compute_dtype_ctx(dtype):
+        for tag, wmax in (("free", None), ("capped", 0.005)):
+            loss_mod = instantiate_from_config({"target": "modules.losses.vqperceptual_multidisc.VQLPIPSWithDiscriminator", "params": dict(
+                disc_start=0, disc_init=True, disc_conditional=False, disc_loss="hinge", disc_factor=1.0, disc_weight=1.0,
+                disc_weight_max=wmax, codebook_weight=1.0, pixelloss_weight=1.0, perceptual_weight=1.0,
+                disc_config={"target": "modules.discriminator.model.NLayerDiscriminator",
+                             "params": dict(input_nc=3, ndf=16, n_layers=3, use_actnorm=False)})}).to(dev).train()
+            _load_det(loss_mod.discriminator, "disc.")
+            _load_det(loss_mod.perceptual_loss, "lpips.", synth.det_lpips_param)
+            conv, tape, xrec = _toy_last_layer(dev, dtype, g)
+            if dtype == torch.float32:
+                assert _rel(xrec.detach().cpu().numpy(), g["gen_xrec"]) < 1e-3
+            loss, log = loss_mod(qloss, x, xrec, 0, 0, last_layer=conv.weight, split="train")
+            loss.backward()
+            for k in ("nll_loss", "p_loss", "g_loss"):
+                np.testing.assert_allclose(float(log["train_" + k]), float(g[f"gen_{tag}_{k}"]), rtol=tol, atol=tol * 1e-2)
+            np.testing.assert_allclose(float(log["train_d_weight"]), float(g[f"gen_{tag}_d_weight"]), rtol=4 * tol)
+            np.testing.assert_allclose(float(loss.detach()), float(g[f"gen_{tag}_loss"]), rtol=tol)
+            conv.weight.grad = None
+            conv.bias.grad = None
+            dfeat = conv.bwd(K.nchw_to_nhwc_pad(xrec.grad, K.vec(dtype) * -(-3 // K.vec(dtype)), dtype), tape)
+            # gradients: relative Frobenius error (isolated ReLU / max-pool decisions flip on rounding-level pre-activations)
+            assert _rel(dfeat.float().permute(0, 3, 1, 2).cpu().numpy(), g[f"gen_{tag}_dfeat"], True) < gtol
+            assert _rel(conv.weight.grad.cpu().numpy(), g[f"gen_{tag}_dw"], True) < gtol
+            assert _rel(conv.bias.grad.cpu().numpy(), g[f"gen_{tag}_db"], True) < gtol
+            # the generator branch must not touch discriminator / VGG gradients
+            assert all(p.grad is None or float(p.grad.abs().sum()) == 0 for p in loss_mod.discriminator.parameters())
+            if tag != "free":
+                continue
+            d_loss, dlog = loss_mod(qloss, x, xrec.detach(), 1, 0, last_layer=conv.weight, split="train")
+            d_loss.backward()
+            np.testing.assert_allclose(float(d_loss), float(g["disc_loss"]), rtol=tol)
+            np.testing.assert_allclose(float(dlog["train_logits_real"]), float(g["disc_logits_real"]), rtol=4 * tol, atol=tol * 0.1)
+            np.testing.assert_allclose(float(dlog["train_logits_fake"]), float(g["disc_logits_fake"]), rtol=4 * tol, atol=tol * 0.1)
+            for n, p in loss_mod.discriminator.named_parameters():
+                ref = g["disc_d." + n]
+                if float(np.abs(ref).max()) == 0:
+                    assert float(p.grad.abs().max()) < 1e-6
+                else:
+                    assert _rel(p.grad.cpu().numpy(), ref, True) < gtol, n
+            for n, b in loss_mod.discriminator.named_buffers():
+                ref = g["disc_buf." + n]
+                if ref.ndim == 0:
+                    assert int(b) == int(ref)
+                else:
+                    np.testing.assert_allclose(b.cpu().numpy(), ref, rtol=max(tol, 1e-4), atol=tol * 1e-2)
+
+
+def test_full_objective_train_step(dev):
+    """the reference's complete two-optimizer step (L1 + LPIPS + adaptive GAN + codebook; then the discriminator) on the
+    small DQ-VAE in bf16: finite losses, both parameter sets move, and the reuse-forward mode gives the same generator loss"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.trainer import Trainer
+    from test_gpu_model import build
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        model, _ = build("small", dev, "spread", loss="full")
+        model.learning_rate, model.training_steps, model.steps_per_epoch = 1e-4, 100, 10
+        model.train()
+        x = torch.from_numpy(synth.half_flat_images(4, 64, seed=99)).to(dev)
+        tr = Trainer(model, max_steps=2)
+        assert len(tr.opts) == 2
+        w0 = model.decoder.conv_out.weight.detach().clone()
+        d0 = model.loss.discriminator.main[0].weight.detach().clone()
+        v0 = model.loss.perceptual_loss.net.slice1[0].weight.detach().clone()
+        l0 = tr.train_step({"image": x}, 0)
+        l1 = tr.train_step({"image": x}, 1)
+        assert len(l0) == 2 and all(torch.isfinite(l).all() for l in l0 + l1)
+        assert not torch.equal(w0, model.decoder.conv_out.weight.detach())
+        assert not torch.equal(d0, model.loss.discriminator.main[0].weight.detach())
+        assert torch.equal(v0, model.loss.perceptual_loss.net.slice1[0].weight.detach())      # VGG16 is frozen
+        assert 0.0 <= float(model._logged["train_d_weight"]) <= 0.75
+        assert int(model.loss.discriminator.main[3].num_batches_tracked) == 6                  # 3 D passes per step

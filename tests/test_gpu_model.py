@@ -21,6 +21,12 @@ def model_config(ch, resolution, latent, zc, k, attn_enc, attn_dec, loss="dummy"
                                        "params": dict(input_nc=3, ndf=64, n_layers=3, use_actnorm=False)},
             disc_init=True, codebook_weight=1.0, pixelloss_weight=1.0, disc_factor=0.0, disc_weight=1.0,
             perceptual_weight=0.0, disc_conditional=False, disc_loss="hinge", disc_weight_max=0.75)}
+    if loss == "full":      # the shipped objective: L1 + LPIPS + adaptive hinge GAN + codebook (configs/stage1/*.yml)
+        lossconfig = {"target": "modules.losses.vqperceptual_multidisc.VQLPIPSWithDiscriminator", "params": dict(
+            disc_start=0, disc_config={"target": "modules.discriminator.model.NLayerDiscriminator",
+                                       "params": dict(input_nc=3, ndf=16, n_layers=3, use_actnorm=False)},
+            disc_init=True, codebook_weight=1.0, pixelloss_weight=1.0, disc_factor=1.0, disc_weight=1.0,
+            perceptual_weight=1.0, disc_conditional=False, disc_loss="hinge", disc_weight_max=0.75)}
     return {"target": "models.stage1_dynamic.dqvae_dual_entropy.DualGrainVQModel", "params": dict(
         encoderconfig={"target": "modules.dynamic_modules.EncoderDual.DualGrainEncoder", "params": dict(
             ch=ch, ch_mult=[1, 1, 2, 2, 4], num_res_blocks=2, attn_resolutions=attn_enc, dropout=0.0,

@@ -46,6 +46,22 @@ def install_stubs():
 
     tvt.Compose = _Compose
     tvt.ToPILImage = lambda *a, **k: None
+
+    class _VGG16:
+        """torchvision.models.vgg16 topology (configuration "D"), random init: only `.features` is used by
+        modules/losses/lpips.py:75-93; every parameter is overwritten deterministically afterwards"""
+
+        def __init__(self, pretrained=False, **kw):
+            layers, cin = [], 3
+            for v in (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"):
+                if v == "M":
+                    layers.append(nn.MaxPool2d(2, 2))
+                else:
+                    layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+                    cin = v
+            self.features = nn.Sequential(*layers)
+
+    tvm.vgg16 = _VGG16
     tv.transforms = tvt
     tv.models = tvm
     sys.modules["torchvision"] = tv
@@ -422,9 +438,99 @@ def gen_losses():
     np.savez_compressed(os.path.join(GOLD, "losses.npz"), **out)
 
 
+def gen_lossnet():
+    """LPIPS + the complete VQLPIPSWithDiscriminator forward/backward (both optimizer branches) on a toy last layer."""
+    from modules.losses.lpips import LPIPS
+    from modules.losses.vqperceptual_multidisc import VQLPIPSWithDiscriminator
+    from oracle import losses as olo
+    out = {}
+    x = synth.half_flat_images(2, 64, 16, seed=5)
+    feat = synth.det_param("lossnet.feat", (2, 8, 64, 64)) * 4.0
+    w_last = synth.det_param("lossnet.last.weight", (3, 8, 3, 3)) * 2.0
+    b_last = synth.det_param("lossnet.last.bias", (3,))
+
+    def make(disc_weight_max):
+        m = VQLPIPSWithDiscriminator(disc_start=0, disc_init=True, disc_conditional=False, disc_loss="hinge", disc_factor=1.0,
+                                     disc_weight=1.0, disc_weight_max=disc_weight_max, codebook_weight=1.0, pixelloss_weight=1.0,
+                                     perceptual_weight=1.0,
+                                     disc_config={"target": "modules.discriminator.model.NLayerDiscriminator",
+                                                  "params": dict(input_nc=3, ndf=16, n_layers=3, use_actnorm=False)})
+        m.train()
+        m.perceptual_loss.eval()       # NetLinLayer dropout off (see oracle/losses.py header)
+        load_det(m.discriminator, prefix="disc.")
+        with torch.no_grad():
+            for n_, p in m.perceptual_loss.named_parameters():
+                p.copy_(torch.from_numpy(synth.det_lpips_param("lpips." + n_, p.shape)))
+        return m
+
+    m = make(None)
+    sd_l = {k: v.detach().clone() for k, v in m.perceptual_loss.state_dict().items()}
+    sd_d = {k: v.detach().clone() for k, v in m.discriminator.state_dict().items()}
+    # LPIPS alone
+    xr0 = np.clip(x + 0.3 * synth.det_param("lossnet.noise", x.shape) * 3, -1, 1).astype(np.float32)
+    xr_t = t(xr0).requires_grad_(True)
+    pv = m.perceptual_loss(t(x), xr_t)
+    pv.sum().backward()
+    out["lpips_x"], out["lpips_xrec"] = x, xr0
+    out["lpips_val"], out["lpips_dxrec"] = pv.detach().numpy(), xr_t.grad.numpy()
+    xr_o = t(xr0).requires_grad_(True)
+    po = olo.lpips(sd_l, t(x), xr_o)
+    po.sum().backward()
+    check("lpips value", po.detach().numpy(), out["lpips_val"], rtol=1e-5, atol=1e-7)
+    check("lpips grad", xr_o.grad.numpy(), out["lpips_dxrec"], rtol=1e-4, atol=1e-7)
+    out["lpips_shapes_keys"] = np.array(list(sd_l.keys()))
+    out["lpips_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd_l.values()])
+
+    for tag, wmax in (("free", None), ("capped", 0.005)):
+        m = make(wmax)
+        ft = t(feat).requires_grad_(True)
+        wl = t(w_last).requires_grad_(True)
+        bl = t(b_last).requires_grad_(True)
+        xrec = torch.nn.functional.conv2d(ft, wl, bl, padding=1)
+        qloss = torch.tensor(0.123)
+        loss, log = m(qloss, t(x), xrec, 0, 0, last_layer=wl, split="train")
+        loss.backward()
+        out[f"gen_{tag}_loss"] = np.float32(loss.item())
+        for k in ("nll_loss", "p_loss", "g_loss", "d_weight", "rec_loss"):
+            out[f"gen_{tag}_{k}"] = np.float32(float(log["train_" + k]))
+        out[f"gen_{tag}_dfeat"], out[f"gen_{tag}_dw"], out[f"gen_{tag}_db"] = ft.grad.numpy(), wl.grad.numpy(), bl.grad.numpy()
+        # oracle pin
+        fo, wo, bo = t(feat).requires_grad_(True), t(w_last).requires_grad_(True), t(b_last).requires_grad_(True)
+        xo = torch.nn.functional.conv2d(fo, wo, bo, padding=1)
+        r = olo.generator_loss(sd_d, sd_l, t(x), xo, qloss, wo, disc_weight_max=wmax)
+        r["loss"].backward()
+        check(f"gen[{tag}] loss", r["loss"].item(), out[f"gen_{tag}_loss"], rtol=1e-5)
+        check(f"gen[{tag}] d_weight", r["d_weight"].item(), out[f"gen_{tag}_d_weight"], rtol=1e-4)
+        check(f"gen[{tag}] dfeat", fo.grad.numpy(), out[f"gen_{tag}_dfeat"], rtol=1e-3, atol=1e-8)
+        if tag == "free":
+            out["gen_xrec"] = xrec.detach().numpy()
+            # discriminator branch on the same module (its BatchNorm running statistics have seen one batch already)
+            m.discriminator.zero_grad()
+            d_loss, dlog = m(qloss, t(x), xrec.detach(), 1, 0, last_layer=wl, split="train")
+            d_loss.backward()
+            out["disc_loss"] = np.float32(d_loss.item())
+            out["disc_logits_real"] = np.float32(float(dlog["train_logits_real"]))
+            out["disc_logits_fake"] = np.float32(float(dlog["train_logits_fake"]))
+            for n_, p in m.discriminator.named_parameters():
+                out["disc_d." + n_] = p.grad.numpy()
+            for n_, b in m.discriminator.named_buffers():
+                out["disc_buf." + n_] = b.numpy()
+            sd_p = {k: v.detach().clone().requires_grad_(v.dtype == torch.float32 and "running" not in k) for k, v in sd_d.items()}
+            run = {}
+            olo.patchgan(sd_p, xrec.detach(), running=run)          # the generator branch's call (statistics only)
+            sd_q = dict(sd_p)
+            sd_q.update(run)
+            dl, _, _ = olo.discriminator_loss(sd_q, t(x), xrec, running=run)
+            dl.backward()
+            check("disc loss", dl.item(), out["disc_loss"], rtol=1e-5)
+            check("disc grad main.8", sd_p["main.8.weight"].grad.numpy(), out["disc_d.main.8.weight"], rtol=1e-3, atol=1e-8)
+            check("disc running_var", run["main.9.running_var"].numpy(), out["disc_buf.main.9.running_var"], rtol=1e-5, atol=1e-7)
+    np.savez_compressed(os.path.join(GOLD, "lossnet.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses")
+    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -432,7 +538,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for name in args.only.split(","):
         print(f"[gen] {name}")
-        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses}[name]()
+        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet}[name]()
     print("done ->", GOLD)
 
 
