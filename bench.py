@@ -7,8 +7,10 @@ batches + VQ-argmin GB/s, on N MI355X of one node (BASELINE.json metric).
 
 One "step" = one pass of the hot path over one batch: entropy gate -> encoder -> quant_conv -> VQ (argmin,
 EMA codebook update) -> post_quant_conv -> decoder -> loss -> full backward -> (RCCL gradient all-reduce) ->
-Adam, in bf16 activations / fp32 master weights.  `config.objective` states which loss terms the step
-carries (round 1: L1 + codebook; LPIPS / PatchGAN are not on the HIP path yet and are NOT counted).
+Adam, in bf16 activations / fp32 master weights.  The default objective is the shipped config's complete
+two-optimizer step (L1 + LPIPS + adaptive hinge GAN + codebook on the autoencoder, then a second autoencoder
+forward and the PatchGAN hinge step -- exactly the work Lightning schedules for the reference); `--objective ae`
+times the autoencoder-only step (L1 + codebook) and says so in `config.objective`.
 Weak scaling: bs/GPU is fixed, value = global images / max-over-ranks time.
 """
 from __future__ import annotations
@@ -30,56 +32,76 @@ METRIC = "images/sec (256x256) DQ-VAE train step + VQ argmin GB/s, 1/2/4/8 MI355
 PEAK_BF16 = 2.5e15      # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
 AE_TRAIN_FLOP_PER_IMG = 1180.8e9   # 3 x 393.6 GFLOP (conv + attention + VQ), 256x256 dual config
+# complete objective: + second AE forward (393.6) + LPIPS (VGG16 40.1 GFLOP/img: 2 forwards + 1 dgrad) + PatchGAN ndf=64
+# (6.29 GFLOP/img forward: generator branch fwd+dgrad, discriminator branch 2 x (fwd+dgrad+wgrad))
+STEP_FLOP_PER_IMG = {"ae": AE_TRAIN_FLOP_PER_IMG, "full": AE_TRAIN_FLOP_PER_IMG + 393.6e9 + 3 * 40.1e9 + 8 * 6.29e9}
 THR_JSON = os.path.join(REPO, "scripts/tools/thresholds/entropy_thresholds_imagenet_train_patch-16.json")
 
 
-def full_config(bs_unused=None):
+def full_config(objective="full"):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from test_gpu_model import model_config
-    return model_config(ch=128, resolution=256, latent=32, zc=256, k=1024, attn_enc=[16, 32], attn_dec=[32], loss="ae")
+    return model_config(ch=128, resolution=256, latent=32, zc=256, k=1024, attn_enc=[16, 32], attn_dec=[32],
+                        loss="full" if objective == "full" else "ae", ndf=64)
 
 
-def _cpu_baseline_worker(threads, bs):
-    """child process: time AE train steps of the oracle on `threads` host threads; prints one JSON line"""
+def _cpu_baseline_worker(threads, bs, objective="full"):
+    """child process: time train steps of the oracle on `threads` host threads; prints one JSON line"""
     torch.set_num_threads(threads)
     from dynamicvectorquantization_amd import synth
     from dynamicvectorquantization_amd.config import instantiate_from_config
     from oracle import entropy as oent
     from oracle import train_step as ots
     torch.manual_seed(0)
-    model = instantiate_from_config(full_config())          # reference-identical init + key names (CPU tensors)
-    sd = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("loss.")}
-    del model
+    model = instantiate_from_config(full_config(objective))          # reference-identical init + key names (CPU tensors)
+    full = model.state_dict()
+    sd = {k: v.detach().clone() for k, v in full.items() if not k.startswith("loss.")}
+    sd_d = {k[len("loss.discriminator."):]: v.detach().clone() for k, v in full.items() if k.startswith("loss.discriminator.")}
+    sd_l = {k[len("loss.perceptual_loss."):]: v.detach().clone() for k, v in full.items() if k.startswith("loss.perceptual_loss.")}
+    del model, full
     thr = oent.threshold_from_table(THR_JSON, 0.5)
     x = torch.from_numpy(synth.half_flat_images(bs, 256, seed=1234))
     t0 = time.time()
     n = 0
     while True:
-        ots.train_steps(sd, [x], thr, steps=1)
+        if objective == "full":
+            ots.full_objective_steps(sd, sd_d, sd_l, [x], thr, steps=1)
+        else:
+            ots.train_steps(sd, [x], thr, steps=1)
         n += 1
         if time.time() - t0 > 12.0 or n >= 4:
             break
     print(json.dumps({"n": n, "sec": time.time() - t0}), flush=True)
 
 
-def cpu_baseline(timeout_s=90):
+def cpu_baseline(objective="full", timeout_s=150):
     """oracle (a port of the reference's CPU path) timed on this host's cores: AE fwd+bwd+Adam at 256x256.
     Bounded: a child process with a hard timeout, at most 16 threads (the torch-CPU conv path stops
     scaling / collapses under oversubscription well before the box's full core count)."""
     import subprocess
     threads = max(1, min(16, os.cpu_count() or 1))
     bs = 1
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), str(bs)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), str(bs), objective]
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
         rec = json.loads(r.stdout.strip().splitlines()[-1])
         return {"value": round(rec["n"] * bs / rec["sec"], 4), "unit": "images/sec", "cores": threads, "kind": "port",
-                "sample": f"{rec['n']} AE train step(s) (fwd+bwd+Adam, L1+codebook loss) at bs={bs}, 256x256 fp32, "
+                "sample": f"{rec['n']} train step(s) of the {'complete two-optimizer' if objective == 'full' else 'autoencoder-only'} "
+                          f"objective at bs={bs}, 256x256 fp32, "
                           f"torch-CPU oracle, {threads} threads of {os.cpu_count()} host cores, {rec['sec']:.1f} s"}
     except Exception as e:      # timeout or failure: report, never stall the GPU measurement
         return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port",
                 "sample": f"cpu baseline did not finish within {timeout_s}s ({type(e).__name__})"}
+
+
+OBJECTIVES = {
+    "full": "complete reference step, both optimizers: (0) entropy gate + encoder + VQ(argmin+EMA) + decoder, loss = L1 + LPIPS(VGG16, "
+            "random weights) + adaptive-weight hinge GAN (PatchGAN ndf=64) + codebook, full backward + Adam; (1) second autoencoder "
+            "forward, PatchGAN hinge loss on (x, xrec), backward + Adam",
+    "ae": "autoencoder-only step: entropy gate + encoder + VQ(argmin+EMA) + decoder, loss = L1 + codebook, full backward + Adam "
+          "(LPIPS and PatchGAN terms switched off: perceptual_weight = disc_factor = 0)",
+}
 
 
 def vq_microbench(dev, reps=20):
@@ -111,13 +133,18 @@ def vq_microbench(dev, reps=20):
 
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
-        return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
+        return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "full")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bs", type=int, default=64, help="images per GPU (BASELINE config: 64)")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--objective", default="full", choices=["full", "ae"],
+                    help="full: the shipped two-optimizer objective (L1+LPIPS+GAN+codebook, then the discriminator); ae: L1+codebook")
+    ap.add_argument("--reuse-forward", action="store_true",
+                    help="discriminator step reuses the generator step's reconstruction instead of a second autoencoder forward "
+                         "(NOT the reference's schedule; reported in config.objective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vq-microbench", action="store_true")
     args = ap.parse_args()
@@ -144,7 +171,8 @@ def main():
     rt.set_impl(int(os.environ.get("DVQ_IMPL", "0")))     # 0 auto; 2 LDS-DMA MFMA kernels; 3 register-staged (A/B)
 
     torch.manual_seed(0)       # identical initial weights on every rank
-    model = instantiate_from_config(full_config()).to(dev)
+    model = instantiate_from_config(full_config(args.objective)).to(dev)
+    model.reuse_generator_forward = bool(args.reuse_forward)
     model.learning_rate = 4.5e-6 * args.bs * world     # train.py:248-257
     model.training_steps, model.steps_per_epoch = 100000, 1000
     model.train()
@@ -205,10 +233,11 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "DQ-VAE dual F=16/8 (configs/stage1/dqvae-entropy-dual-r05_imagenet.yml), codebook 1024x256, "
                                    f"bs={args.bs}/GPU, 256x256 half-flat synthetic images",
-                       "objective": "AE step: entropy gate + encoder + VQ(argmin+EMA) + decoder, loss = L1 + codebook, "
-                                    "full backward + Adam; LPIPS and PatchGAN terms not yet on the HIP path (not counted)",
+                       "objective": OBJECTIVES[args.objective] + (" [discriminator step reuses the generator step's reconstruction]"
+                                                                         if args.reuse_forward else ""),
                        "global_batch": world * args.bs, "parallelism": f"dp{world}", "fine_ratio": ratio},
-            "ae_mfma_frac": round(ips / world * AE_TRAIN_FLOP_PER_IMG / PEAK_BF16, 4),
+            "step_mfma_frac": round(ips / world * STEP_FLOP_PER_IMG[args.objective] / PEAK_BF16, 4),
+            "step_flop_per_img": STEP_FLOP_PER_IMG[args.objective],
             "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 2),
             "roofline": roofline,
             "kernel_families": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"], 3),
@@ -217,7 +246,7 @@ def main():
         if not args.no_vq_microbench:
             out["vq_argmin"] = vq_microbench(dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.objective)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

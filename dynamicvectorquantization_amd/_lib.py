@@ -51,6 +51,7 @@ SIGNATURES = {
     "dvq_conv2d_dgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
     "dvq_conv2d_fwd_act": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp]),
     "dvq_conv2d_dgrad_mask": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
+    "dvq_set_workspace": (i32, [vp, i64]),
     "dvq_affine_channels": (i32, [vp, i32, i64, i64, vp, vp, vp, vp]),
     "dvq_axpy_dev": (i32, [vp, vp, vp, i32, i64, vp, vp]),
     "dvq_maxpool2x2": (i32, [vp, i32, i64, i64, i64, i64, vp, vp]),

@@ -327,7 +327,39 @@ struct WgParams {
     int c_oihw;          // 1: [co][ci][9], 0: [co][9][ci]
     int up;              // 1: X is stored [N,H/2,W/2,Cin] (nearest x2 folded into the halo gather)
     const float* gn_ss;  // optional fused GroupNorm+swish on x: {scale, shift} fp32 [N][Cin][2] (recomputed, never stored)
+    float* ws;           // split-K partials: [nsplit][gi*gj][9][128][64] fp32 (+ bias partials behind), or null -> atomics
+    float* ws_bias;      // [nsplit][gi*gj][128]
 };
+
+// Cross-XCD fp32 atomics resolve at the memory side and cost far more than plain stores: with a workspace every
+// workgroup stores its 9 x 128 x 64 partial tile with ordinary coalesced writes and this kernel folds the splits into
+// the gradient (one writer per element: plain read-modify-write, deterministic summation order).
+__global__ __launch_bounds__(256) void conv3x3_halo_wgrad_reduce_kernel(WgParams p) {
+    const int ntile = p.gi * p.gj;
+    const int64_t per_tile = 9ll * 128 * 64;
+    const int64_t total = (int64_t)ntile * per_tile;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int wi = (int)(e / per_tile);
+        const int r = (int)(e - (int64_t)wi * per_tile);
+        const int tap = r / 8192, q = r - tap * 8192;
+        const int co = (wi % p.gi) * 128 + (q >> 6), ci = (wi / p.gi) * 64 + (q & 63);
+        if (co >= p.cout_real || ci >= p.cin_real) continue;
+        float sum = 0.f;
+        for (int sidx = 0; sidx < p.nsplit; ++sidx) sum += p.ws[((int64_t)sidx * ntile + wi) * per_tile + r];
+        const int64_t o = p.c_oihw ? ((int64_t)co * p.cin_real + ci) * 9 + tap : ((int64_t)co * 9 + tap) * p.cin_real + ci;
+        p.DW[o] += sum;
+    }
+    if (p.DB != nullptr) {
+        // bias partials exist once per co-tile: only the ci-chunk 0 blocks (wi / gi == 0) wrote them
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < p.gi * 128; e += gridDim.x * 256) {
+            const int wi = e >> 7, co = e;
+            if (co >= p.cout_real) continue;
+            float sum = 0.f;
+            for (int sidx = 0; sidx < p.nsplit; ++sidx) sum += p.ws_bias[((int64_t)sidx * ntile + wi) * 128 + (e & 127)];
+            p.DB[co] += sum;
+        }
+    }
+}
 
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -475,6 +507,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
     // ---- flush: rows = co (n0 + mt*32 + ...), cols = ci (j0 + nt*32 + lane&31) ------------------------------
     const int l31 = lane & 31, half = lane >> 5;
     const int ci = j0 + nt * 32 + l31;
+    if (p.ws != nullptr) {
+        float* tile = p.ws + ((int64_t)split * (p.gi * p.gj) + wi) * (9ll * 128 * 64);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                tile[tap * 8192 + col * 64 + nt * 32 + l31] = acc[tap][r];
+            }
+        if (do_bias) {
+            const float v = bsum + __shfl_xor(bsum, 32, 64);
+            if (half == 0) p.ws_bias[((int64_t)split * (p.gi * p.gj) + wi) * 128 + mt * 32 + l31] = v;
+        }
+        return;
+    }
     if (ci < p.cin_real) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
@@ -518,8 +565,20 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
     p.c_oihw = c_oihw;
     p.up = up;
     p.gn_ss = gn_ss;
+    const int64_t nblk = (int64_t)p.gi * p.gj * p.nsplit;
+    int64_t ws_bytes = 0;
+    char* wsp = (char*)dvq_workspace(&ws_bytes);
+    const int64_t need = nblk * (9ll * 128 * 64 + 128) * 4;
+    if (wsp != nullptr && ws_bytes >= need && p.nsplit > 1) {
+        p.ws = (float*)wsp;
+        p.ws_bias = (float*)(wsp + nblk * 9ll * 128 * 64 * 4);
+    }
     dvq_ensure_dynamic_lds((const void*)conv3x3_halo_wgrad_kernel, 2 * WSTAGE);
-    conv3x3_halo_wgrad_kernel<<<dim3((unsigned)(p.gi * p.gj * p.nsplit)), dim3(512), 2 * WSTAGE, stream>>>(p);
+    conv3x3_halo_wgrad_kernel<<<dim3((unsigned)nblk), dim3(512), 2 * WSTAGE, stream>>>(p);
+    if (p.ws != nullptr) {
+        const int64_t work = (int64_t)p.gi * p.gj * 9 * 128 * 64;
+        conv3x3_halo_wgrad_reduce_kernel<<<dim3((unsigned)cdiv64(work, 256)), dim3(256), 0, stream>>>(p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         dvq_set_error("conv3x3_halo_wgrad: launch failed: %s", hipGetErrorString(e));

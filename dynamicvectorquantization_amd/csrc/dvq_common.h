@@ -45,6 +45,8 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) costs ~0.3 ms per call: do it once per kernel symbol.
 void dvq_ensure_dynamic_lds(const void* kernel, int bytes);
+// caller-registered scratch buffer (dvq_set_workspace); null if none
+void* dvq_workspace(int64_t* bytes);
 
 // ---------------------------------------------------------------------------------------------
 // bf16 <-> f32 (device)

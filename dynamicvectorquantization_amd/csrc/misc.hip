@@ -348,10 +348,25 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, float 
 }  // namespace
 
 // =================================================================================================
+static void* g_ws_ptr = nullptr;
+static int64_t g_ws_bytes = 0;
+
+void* dvq_workspace(int64_t* bytes) {
+    if (bytes) *bytes = g_ws_bytes;
+    return g_ws_ptr;
+}
+
 extern "C" {
 
 const char* dvq_last_error(void) { return g_err; }
-int dvq_version(void) { return 100; }
+int dvq_version(void) { return 101; }
+
+int dvq_set_workspace(void* ptr, int64_t bytes) {
+    DVQ_REQUIRE((ptr == nullptr) == (bytes == 0) && bytes >= 0, DVQ_EINVAL, "dvq_set_workspace: bad arguments");
+    g_ws_ptr = ptr;
+    g_ws_bytes = bytes;
+    return DVQ_OK;
+}
 
 int dvq_check_device(void) {
     int dev = 0;

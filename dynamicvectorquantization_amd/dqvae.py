@@ -528,9 +528,20 @@ class DualGrainVQModel(nn.Module):
     def log_dict(self, d, **kw):
         self._logged.update(d)
 
+    reuse_generator_forward = False   # True: the discriminator step reuses the generator step's reconstruction
+                                      # (one autoencoder forward + one EMA update per batch; NOT the reference's schedule)
+
     def training_step(self, batch, batch_idx, optimizer_idx):
         x = self.get_input(batch, self.image_key)
-        xrec, qloss, indices, gate, x_entropy = self(x)
+        if optimizer_idx == 1 and self.reuse_generator_forward and getattr(self, "_gen_out", None) is not None:
+            xrec, qloss, indices, gate, x_entropy = self._gen_out
+        elif optimizer_idx == 1:
+            with torch.no_grad():     # the discriminator loss detaches the reconstruction: same values, no tape kept
+                xrec, qloss, indices, gate, x_entropy = self(x)
+        else:
+            xrec, qloss, indices, gate, x_entropy = self(x)
+            if self.reuse_generator_forward:
+                self._gen_out = (xrec.detach(), qloss.detach(), indices, gate, x_entropy)
         ratio = indices.sum() / (indices.size(0) * indices.size(1) * indices.size(2))
         step = self.current_epoch if self.loss_with_epoch else self.global_step
         if optimizer_idx == 0:

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -354,10 +356,24 @@ def conv2d_wgrad(d: ConvDesc, x, dy, db=None):
     return dw
 
 
+_workspace = {}
+WORKSPACE_BYTES = 80 << 20       # 256 workgroups x (9 x 128 x 64 + 128) fp32 partials of the split-K weight-gradient kernels
+
+
+def ensure_workspace(device):
+    """register the process-wide scratch buffer of libdvq_hip (kept alive here)"""
+    device = torch.device(device)
+    if _workspace.get("dev") != device and os.environ.get("DVQ_NO_WORKSPACE", "0") != "1":
+        buf = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        check(lib().dvq_set_workspace(buf.data_ptr(), buf.numel()), "dvq_set_workspace")
+        _workspace.update(dev=device, buf=buf)
+
+
 def conv2d_wgrad_oihw(d: ConvDesc, x, dy, cin_real, cout_real, grad_oihw, db=None, gn_ss=None):
     """accumulate the weight gradient straight into the [Cout,Cin,KH,KW] fp32 grad (and db into [Cout]);
     gn_ss: the fused GroupNorm+swish of the forward is re-applied to x inside the kernel"""
     fl, nb = _conv_cost(d, x.element_size())
+    ensure_workspace(x.device)
     if gn_ss is not None:
         _timed("conv3x3_halo_wgrad_kernel", fl, nb, lambda: check(
             lib().dvq_conv2d_wgrad_oihw_ex(C.byref(d), _p(x), _p(dy), cin_real, cout_real, _praw(grad_oihw), _p(db),

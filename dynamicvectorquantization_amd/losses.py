@@ -389,6 +389,13 @@ class VQLPIPSWithDiscriminator(nn.Module):
             out["p"] = torch.zeros((), device=dev)
             nll = rec_mean
         out["nll"] = nll
+        if disc_factor == 0:
+            # the GAN term is multiplied by zero: skip the discriminator passes the reference would still run
+            # (train_g_loss / train_d_weight are then logged as 0)
+            out["g"] = torch.zeros((), device=dev)
+            out["d_weight"] = torch.zeros((), device=dev)
+            out["g_rec"] = K.nhwc_pad_to_nchw(g_nll, 3) if want_grad else None
+            return out
         disc = self.discriminator
         tape = Tape() if want_grad else None
         logits_fake = disc.fwd(r_p, tape)
@@ -493,10 +500,9 @@ class _DiscLossFn(torch.autograd.Function):
         if ctx.state is not None and g is not None:
             disc, t_real, t_fake, grads = ctx.state
             with torch.no_grad():
-                # upstream scale is 1 in the trainer; a different scale multiplies the (tiny) logit gradients
-                scale = None if (g.numel() == 1 and float(g) == 1.0) else g
+                # the upstream scale (1 in the trainer) multiplies the tiny logit gradients on the device: no host sync
                 for tape, dl in ((t_real, grads[0]), (t_fake, grads[1])):
-                    disc.bwd(dl if scale is None else (dl.float() * scale).to(dl.dtype), tape, need_dw=True, need_dx=False)
+                    disc.bwd((dl.float() * g).to(dl.dtype), tape, need_dw=True, need_dx=False)
         return (None,) * (5 + ctx.n)
 
 

@@ -207,6 +207,11 @@ int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred,
                 int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int impl,
                 dvq_stream_t stream);
 
+/* Register a caller-owned device scratch buffer (one per process, used stream-ordered on the caller's stream).  With
+ * >= 76 MiB registered the split-K weight-gradient kernels store per-workgroup partial tiles with plain writes and fold
+ * them in a second kernel instead of issuing cross-XCD fp32 atomics.  ptr = NULL, bytes = 0 unregisters. */
+int dvq_set_workspace(void* ptr, int64_t bytes);
+
 /* ---- loss networks (LPIPS + PatchGAN), modules/losses/lpips.py, modules/discriminator/model.py -------------------
  * BatchNorm2d (training mode) = dvq_gn_* with N=1, HW=N*H*W, G=C (one group per channel over the whole batch). */
 /* ScalingLayer (lpips.py:53-61) and its backward: y[..,c] = x[..,c]*a[c] + b[c]  (b may be NULL); n = total elements */

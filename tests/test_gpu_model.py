@@ -13,7 +13,7 @@ from test_oracle_golden import DQVAE_CFG, dqvae_state_dict
 pytestmark = pytest.mark.gpu
 
 
-def model_config(ch, resolution, latent, zc, k, attn_enc, attn_dec, loss="dummy"):
+def model_config(ch, resolution, latent, zc, k, attn_enc, attn_dec, loss="dummy", ndf=16):
     lossconfig = {"target": "modules.losses.vqperceptual.DummyLoss"}
     if loss == "ae":
         lossconfig = {"target": "modules.losses.vqperceptual_multidisc.VQLPIPSWithDiscriminator", "params": dict(
@@ -24,7 +24,7 @@ def model_config(ch, resolution, latent, zc, k, attn_enc, attn_dec, loss="dummy"
     if loss == "full":      # the shipped objective: L1 + LPIPS + adaptive hinge GAN + codebook (configs/stage1/*.yml)
         lossconfig = {"target": "modules.losses.vqperceptual_multidisc.VQLPIPSWithDiscriminator", "params": dict(
             disc_start=0, disc_config={"target": "modules.discriminator.model.NLayerDiscriminator",
-                                       "params": dict(input_nc=3, ndf=16, n_layers=3, use_actnorm=False)},
+                                       "params": dict(input_nc=3, ndf=ndf, n_layers=3, use_actnorm=False)},
             disc_init=True, codebook_weight=1.0, pixelloss_weight=1.0, disc_factor=1.0, disc_weight=1.0,
             perceptual_weight=1.0, disc_conditional=False, disc_loss="hinge", disc_weight_max=0.75)}
     return {"target": "models.stage1_dynamic.dqvae_dual_entropy.DualGrainVQModel", "params": dict(
