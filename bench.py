@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--reuse-forward", action="store_true",
                     help="discriminator step reuses the generator step's reconstruction instead of a second autoencoder forward "
                          "(NOT the reference's schedule; reported in config.objective)")
+    ap.add_argument("--no-ae-only", action="store_true", help="skip the secondary autoencoder-only measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vq-microbench", action="store_true")
     args = ap.parse_args()
@@ -170,47 +171,68 @@ def main():
     rt.set_compute_dtype(args.dtype)
     rt.set_impl(int(os.environ.get("DVQ_IMPL", "0")))     # 0 auto; 2 LDS-DMA MFMA kernels; 3 register-staged (A/B)
 
-    torch.manual_seed(0)       # identical initial weights on every rank
-    model = instantiate_from_config(full_config(args.objective)).to(dev)
-    model.reuse_generator_forward = bool(args.reuse_forward)
-    model.learning_rate = 4.5e-6 * args.bs * world     # train.py:248-257
-    model.training_steps, model.steps_per_epoch = 100000, 1000
-    model.train()
-    trainer = Trainer(model, max_steps=args.steps)
-    # two distinct resident batches per rank (synthetic half-flat images: fine ratio exactly 0.5)
-    nb = 2
-    imgs = [torch.from_numpy(synth.half_flat_images(args.bs, 256, seed=1234 + 17 * rank + 1000 * i)).to(dev) for i in range(nb)]
-    batches = [{"image": im} for im in imgs]
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    n_timed_launches = 0
-    for i in range(args.warmup):
-        if i == args.warmup - 1:
-            K.profile_count_start()
-        trainer.train_step(batches[i % nb], i)
-    n_timed_launches = K.profile_count_stop() if args.warmup > 0 else 1200
-    barrier()
-    K.profile_prepare(n_timed_launches + 16)          # HIP events for ONE step, created outside the timed region
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i == args.steps - 1:
-            K.profile_start()                         # per-kernel HIP-event timing on the last timed step only
-        trainer.train_step(batches[i % nb], args.warmup + i)
-    host_issue = time.perf_counter() - t0          # time the host needed to enqueue all steps (no sync inside)
-    barrier()
-    dt_ = time.perf_counter() - t0
-    prof = K.profile_stop()
-    if world > 1:
-        tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt_ = float(tmax.item())
+    def run(objective, steps, warmup, profile):
+        """build the model + trainer for `objective`, W untimed + K timed steps; -> (seconds [max over ranks], host issue
+        seconds, per-kernel profile of the last timed step, model)"""
+        torch.manual_seed(0)       # identical initial weights on every rank
+        model = instantiate_from_config(full_config(objective)).to(dev)
+        model.reuse_generator_forward = bool(args.reuse_forward)
+        model.learning_rate = 4.5e-6 * args.bs * world     # train.py:248-257
+        model.training_steps, model.steps_per_epoch = 100000, 1000
+        model.train()
+        trainer = Trainer(model, max_steps=steps)
+        SETUP = 2      # untimed initialisation steps before the W warmup steps: kernel code-object loading, allocator growth,
+                       # packed-weight tables (the first steps of a process are host-bound on these one-off costs)
+        # two distinct resident batches per rank (synthetic half-flat images: fine ratio exactly 0.5)
+        nb = 2
+        imgs = [torch.from_numpy(synth.half_flat_images(args.bs, 256, seed=1234 + 17 * rank + 1000 * i)).to(dev) for i in range(nb)]
+        batches = [{"image": im} for im in imgs]
+        n_launches = 0
+        for i in range(SETUP):
+            trainer.train_step(batches[i % nb], i)
+        for i in range(warmup):
+            if profile and i == warmup - 1:
+                K.profile_count_start()
+            trainer.train_step(batches[i % nb], i)
+        if profile:
+            n_launches = K.profile_count_stop() if warmup > 0 else 2400
+            barrier()
+            K.profile_prepare(n_launches + 16)          # HIP events for ONE step, created outside the timed region
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if profile and i == steps - 1:
+                K.profile_start()                         # per-kernel HIP-event timing on the last timed step only
+            trainer.train_step(batches[i % nb], warmup + i)
+        host = time.perf_counter() - t0          # time the host needed to enqueue all steps (no sync inside)
+        barrier()
+        dt = time.perf_counter() - t0
+        prof = K.profile_stop() if profile else {}
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, host, prof, model
+
+    dt_, host_issue, prof, model = run(args.objective, args.steps, args.warmup, True)
     ratio = float(model._logged.get("train_fine_ratio", torch.tensor(float("nan"))))
 
+    ae_only = None
+    if args.objective == "full" and not args.no_ae_only:
+        # SURVEY 8d asks for both accountings: the autoencoder-only step (L1 + codebook) beside the complete objective
+        del model
+        torch.cuda.empty_cache()
+        k2 = max(2, min(4, args.steps))
+        dt2, _, _, m2 = run("ae", k2, 2, False)
+        ips2 = world * args.bs * k2 / dt2
+        ae_only = {"value": round(ips2, 2), "unit": "images/sec", "steps": k2, "warmup": 2, "ms_per_step": round(dt2 / k2 * 1e3, 3),
+                   "objective": OBJECTIVES["ae"], "step_mfma_frac": round(ips2 / world * STEP_FLOP_PER_IMG["ae"] / PEAK_BF16, 4)}
+        del m2
     if rank == 0:
         ips = world * args.bs * args.steps / dt_
         fam = {k: dict(v, ms_per_launch=v["ms"] / max(1, v["launches"]),
@@ -243,6 +265,7 @@ def main():
             "kernel_families": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"], 3),
                                     "TFLOPs": round(v["TFLOPs"], 2)} for k, v in fam.items()},
         }
+        out["ae_only"] = ae_only
         if not args.no_vq_microbench:
             out["vq_argmin"] = vq_microbench(dev)
         if world == 1 and not args.no_cpu_baseline:

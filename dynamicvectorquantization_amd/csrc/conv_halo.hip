@@ -51,7 +51,13 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
+// NW = waves per workgroup: 4 -> each wave owns 2 image rows (2 x 4 accumulator tiles of 32x32, 2 waves per SIMD);
+//                           2 -> each wave owns 4 image rows (4 x 4 tiles = 256 accumulator registers, 1 wave per SIMD,
+//                                one third less LDS fragment traffic per MFMA: 8 fragment reads feed 16 MFMAs).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(HaloParams p) {
+    constexpr int MT = 8 / NW;          // image rows (32-pixel m-tiles) per wave
+    constexpr int NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     char* bst = smem + HALOB;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
     // keeping 11 offsets live next to 128 accumulator registers would spill)
     auto issue_halo = [&](int c0) {
 #pragma unroll 1
-        for (int pc = wave; pc < HPIECES; pc += 4) {
+        for (int pc = wave; pc < HPIECES; pc += NW) {
             const int hp = pc * 8 + lrow;
             const int hy = hp / HW_, hx = hp - hy * HW_;
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
@@ -95,10 +101,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
     };
     auto issue_b = [&](int tap, int c0, int buf) {
         const int tb = p.flip ? 8 - tap : tap;
-        char* dst = bst + buf * BSTAGE + wave * 32 * ROWB;
+        constexpr int RPW = 128 / NW;       // weight rows per wave
+        char* dst = bst + buf * BSTAGE + wave * RPW * ROWB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave * 32 + i * 8 + lrow;
+        for (int i = 0; i < RPW / 8; ++i) {
+            const int row = wave * RPW + i * 8 + lrow;
             const int cg = cpos ^ ((row >> 1) & 7);
             const bf16_t* src = (n0 + row < p.Cout) ? p.Wt + ((int64_t)(n0 + row) * 9 + tb) * p.Cin + cg * 8 + c0 : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -106,9 +113,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
         }
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[MT][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
         __syncthreads();                // vmcnt(0) + barrier: halo and first weight stage have landed
         if (p.gn_ss != nullptr) {
             // fused GroupNorm + swish: y = z * sigmoid(z), z = x * scale[c] + shift[c], applied in place to the halo tile
-            for (int q = tid; q < HROWS * 8; q += 256) {
+            for (int q = tid; q < HROWS * 8; q += NTH) {
                 const int hp = q >> 3, cp = q & 7;
                 const int hy = hp / HW_, hx = hp - hy * HW_;
                 const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
@@ -148,26 +155,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
             const int buf = tap & 1;
             if (tap + 1 < 9) issue_b(tap + 1, c0, buf ^ 1);
             const int kh = tap / 3, kw = tap - kh * 3;
-            const char* pa[2];
-            int sa[2];
+            const char* pa[MT];
+            int sa[MT];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int hp = (2 * wave + mt + kh) * HW_ + l31 + kw;
+            for (int mt = 0; mt < MT; ++mt) {
+                const int hp = (MT * wave + mt + kh) * HW_ + l31 + kw;
                 pa[mt] = halo + hp * ROWB;
                 sa[mt] = (hp >> 1) & 7;
             }
             const char* pb = bst + buf * BSTAGE + l31 * ROWB;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 a[2], b[4];
+                bf16x8 a[MT], b[4];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
                     a[mt] = *reinterpret_cast<const bf16x8*>(pa[mt] + (((ks * 2 + half) ^ sa[mt]) << 4));
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
                     b[nt] = *reinterpret_cast<const bf16x8*>(pb + nt * 32 * ROWB + (((ks * 2 + half) ^ swzB) << 4));
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
@@ -184,10 +191,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
         const int lc = nt * 32 + l31;
         const float bcol = (p.bias != nullptr && n0 + lc < p.Cout) ? p.bias[n0 + lc] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int lp = (2 * wave + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int lp = (MT * wave + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v = acc[mt][nt][r] + bcol;
                 if (early_act) v = v > 0.f ? v : v * p.act_slope;
                 st[lp * 128 + lc] = f32_to_bf16(v);
@@ -198,8 +205,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) gs[k] = gq[k] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int q = tid + 256 * i;
+    for (int i = 0; i < 4096 / NTH; ++i) {
+        const int q = tid + NTH * i;
         const int lp = q >> 4, ch = q & 15;
         const int col = n0 + ch * 8;
         if (col >= p.Cout) continue;
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
         // combine within the workgroup in LDS (fp32 per channel), then one fp64 atomic pair per group
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);            // [128][2]
-        for (int i = tid; i < 256; i += 256) red[i] = 0.f;
+        for (int i = tid; i < 256; i += NTH) red[i] = 0.f;
         __syncthreads();
         const int ch = tid & 15;
 #pragma unroll
@@ -287,8 +294,17 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     p.act_slope = act_slope; p.res_mask = res_mask; p.mask_slope = mask_slope;
     const int64_t blocks = N * p.tiles_y * p.tiles_x * p.gn;
     if (blocks >= (1ll << 31)) return 0;
-    dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel, LDSB);
-    conv3x3_halo_kernel<<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+    static const int nw_env = [] {
+        const char* e = getenv("DVQ_HALO_WAVES");
+        return e != nullptr ? atoi(e) : 0;
+    }();
+    if (nw_env != 2) {      // default: 4 waves (2 x 4 tiles each); the 2-wave / 4 x 4-tile variant measured 2x slower (1 wave per SIMD)
+        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4>, LDSB);
+        conv3x3_halo_kernel<4><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+    } else {
+        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<2>, LDSB);
+        conv3x3_halo_kernel<2><<<dim3((unsigned)blocks), dim3(128), LDSB, stream>>>(p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         dvq_set_error("conv3x3_halo: launch failed: %s", hipGetErrorString(e));

@@ -291,7 +291,7 @@ def pack_weight(master_oihw, cin_p, cout_p, dtype, want_w=True, want_wt=True):
     cout, cin, kh, kw = master_oihw.shape
     dev = master_oihw.device
     w = torch.empty(cout, kh, kw, cin_p, dtype=dtype, device=dev) if want_w else None
-    wt = torch.empty(cin, kh, kw, cout_p, dtype=dtype, device=dev) if want_wt else None
+    wt = torch.zeros(cin_p, kh, kw, cout_p, dtype=dtype, device=dev) if want_wt else None   # rows >= Cin stay zero
     check(lib().dvq_pack_weight(_p(master_oihw), cout, cin, kh, kw, cin_p, cout_p, dt(dtype), _p(w), _p(wt), _s()),
           "dvq_pack_weight")
     return w, wt

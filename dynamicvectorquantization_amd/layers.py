@@ -220,7 +220,7 @@ class Conv2d(HipModule):
         cin_p, cout_p = self._padded(dtype)
         k, dev = self.kernel_size, self.weight.device
         w = torch.zeros(cout_p, k, k, cin_p, dtype=dtype, device=dev)          # rows >= Cout stay zero
-        wt = torch.zeros(self.in_channels, k, k, cout_p, dtype=dtype, device=dev)
+        wt = torch.zeros(cin_p, k, k, cout_p, dtype=dtype, device=dev)                # rows >= Cin stay zero (dgrad reads cin_p rows)
         bias = None
         if self.bias is not None and cout_p != self.out_channels:
             bias = torch.zeros(cout_p, dtype=torch.float32, device=dev)
@@ -233,14 +233,19 @@ class Conv2d(HipModule):
         ent = self._packs.get(dtype)
         if ent is None or ent["w"].device != self.weight.device or ent["master"] != self.weight.data_ptr():
             ent = self._alloc_pack(dtype)
-        if ent["epoch"] != rt.weights_epoch():
-            if ent["epoch"] >= 0:
-                PACKS.repack(dtype, self.weight.device)  # ONE launch refreshes every registered conv of this dtype/device
-            if ent["epoch"] != rt.weights_epoch():       # not covered by the table yet (first use)
+        ep = rt.param_epoch(self.weight)
+        if ent["epoch"] != ep:
+            if ent["epoch"] != -1:
+                # ONE launch refreshes every registered conv of this dtype / device / optimizer group
+                PACKS.repack(dtype, self.weight.device, getattr(self.weight, "_dvq_group", 0))
+            if ent["epoch"] != ep:                       # not covered by the table yet (first use)
                 K.pack_weight_into(self.weight.detach(), ent["cin_p"], ent["cout_p"], dtype, ent["w"], ent["wt"])
-                ent["epoch"] = rt.weights_epoch()
-            if ent["bias"] is not None:
-                ent["bias"][: self.out_channels] = self.bias.detach()
+                ent["epoch"] = ep
+        if ent["bias"] is not None and ent.get("bias_epoch") != ep:
+            # zero-padded bias copy (Cout not a multiple of the vector width): tracked on its own -- the multi-tensor
+            # re-pack triggered by ANOTHER conv refreshes this module's weights but not this small copy
+            ent["bias"][: self.out_channels] = self.bias.detach()
+            ent["bias_epoch"] = ep
         bias = ent["bias"] if ent["bias"] is not None else (self.bias.detach() if self.bias is not None else None)
         return ent["w"], ent["wt"], bias
 
@@ -309,13 +314,16 @@ class _PackRegistry:
         import weakref
         key = (dtype, mod.weight.device)
         self.items.setdefault(key, []).append(weakref.ref(mod))
-        self.tables.pop(key, None)
+        for k in [k for k in self.tables if k[:2] == key]:
+            self.tables.pop(k, None)
 
-    def repack(self, dtype, device):
+    def repack(self, dtype, device, group=0):
         import ctypes
         from ._lib import PackEntry
         key = (dtype, device)
-        mods = [m for m in (r() for r in self.items.get(key, [])) if m is not None and dtype in m._packs]
+        mods = [m for m in (r() for r in self.items.get(key, [])) if m is not None and dtype in m._packs and
+                getattr(m.weight, "_dvq_group", 0) == group]
+        key = (dtype, device, group)
         live = [m for m in mods if m._packs[dtype]["master"] == m.weight.data_ptr() and m._packs[dtype]["w"].device == device]
         if len(live) < 2:
             return
@@ -334,9 +342,8 @@ class _PackRegistry:
             tab = {"sig": sig, "table": raw, "n": len(live), "total": begin}
             self.tables[key] = tab
         K.pack_weights_multi(tab["table"], tab["n"], tab["total"])
-        ep = rt.weights_epoch()
         for m in live:
-            m._packs[dtype]["epoch"] = ep
+            m._packs[dtype]["epoch"] = rt.param_epoch(m.weight)
 
 
 PACKS = _PackRegistry()

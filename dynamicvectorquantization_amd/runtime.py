@@ -43,8 +43,24 @@ def weights_epoch() -> int:
 
 
 def bump_weights_epoch():
+    """every parameter of the process may have changed (load_state_dict, manual edits, storage moves)"""
     global _weights_epoch
     _weights_epoch += 1
+
+
+# Parameters owned by one optimizer form a group (Parameter._dvq_group, set by HipAdam.flatten): its step only
+# invalidates the packed copies of that group, so the frozen VGG16 of LPIPS and the other optimizer's convs are not
+# re-packed after every step.
+_group_epoch = {}
+
+
+def bump_group_epoch(group: int):
+    _group_epoch[group] = _group_epoch.get(group, 0) + 1
+
+
+def param_epoch(param):
+    g = getattr(param, "_dvq_group", 0)
+    return (_weights_epoch, _group_epoch.get(g, 0))
 
 
 # GroupNorm+swish applied inside the consuming conv kernel (no materialised activation: saves HBM traffic and

@@ -104,6 +104,8 @@ class HipAdam(torch.optim.Optimizer):
         assert len(self.param_groups) == 1, "flatten() supports a single parameter group"
         if self.flat is None:
             self.flat = FlatParams(self.param_groups[0]["params"])
+            for p in self.flat.params:
+                p._dvq_group = id(self)
             self._fstate = {"step": 0, "m": torch.zeros_like(self.flat.flat_p), "v": torch.zeros_like(self.flat.flat_p)}
         return self.flat
 
@@ -115,7 +117,7 @@ class HipAdam(torch.optim.Optimizer):
             st["step"] += 1
             K.adam_step(self.flat.flat_p, self.flat.flat_g, st["m"], st["v"], g["lr"], g["betas"][0], g["betas"][1],
                         g["eps"], st["step"])
-            rt.bump_weights_epoch()
+            rt.bump_group_epoch(id(self))      # only this optimizer's packed weights are stale
             return
         for group in self.param_groups:
             b1, b2 = group["betas"]

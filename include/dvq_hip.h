@@ -149,7 +149,8 @@ int dvq_gn_scale_shift(const double* stats, const float* gamma, const float* bet
                        float eps, float* scale_shift, float* mean_rstd, dvq_stream_t stream);
 
 /* dx (stored-input shape, i.e. [N,H/2,W/2,Cin] when upsample) from dy [N,OH,OW,Cout].
- * wt: weights in IHWO layout [Cin,KH,KW,Cout] of `dtype` (dvq_pack_weight_t).  When upsample is set,
+ * wt: weights in IHWO layout [d->Cin,KH,KW,Cout] of `dtype` (dvq_pack_weight writes the first Cin_real rows; when the
+ * descriptor's Cin is channel-padded the caller provides zero rows up to d->Cin).  When upsample is set,
  * ws must hold N*H*W*Cin elements of `dtype` (gradient at the upsampled resolution). */
 int dvq_conv2d_dgrad(const dvq_conv_desc* d, const void* dy, const void* wt, void* dx, void* ws,
                      dvq_stream_t stream);

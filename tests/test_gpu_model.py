@@ -120,3 +120,34 @@ def test_train_step_bf16_smoke(dev):
         assert all(torch.isfinite(l).all() for l in l0 + l1)
         assert not torch.equal(w0, model.decoder.conv_out.weight.detach())
         assert not torch.equal(n0, model.quantize.codebook.cluster_size_ema)
+
+
+def test_packed_weights_follow_the_optimizer(dev):
+    """after optimizer steps every conv's packed copies (weights AND the zero-padded bias of convs whose Cout is not a
+    multiple of 8) equal the fp32 masters -- including modules whose re-pack was triggered by another module"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d
+    from dynamicvectorquantization_amd.trainer import Trainer
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        model, _ = build("small", dev, "spread", loss="full")
+        model.learning_rate, model.training_steps, model.steps_per_epoch = 1e-3, 100, 10
+        model.train()
+        x = torch.from_numpy(synth.half_flat_images(2, 64, seed=7)).to(dev)
+        tr = Trainer(model, max_steps=2)
+        b0 = model.decoder.conv_out.bias.detach().clone()
+        tr.train_step({"image": x}, 0)
+        tr.train_step({"image": x}, 1)
+        with torch.no_grad():
+            model(x)                                     # forward after the last step: packs are refreshed lazily
+        assert not torch.equal(b0, model.decoder.conv_out.bias.detach())
+        checked = 0
+        for name, m in model.named_modules():
+            if not isinstance(m, Conv2d) or torch.bfloat16 not in m._packs or name.startswith("loss.discriminator"):
+                continue
+            ent = m._packs[torch.bfloat16]
+            w = m.weight.detach().permute(0, 2, 3, 1).to(torch.bfloat16)
+            assert torch.equal(ent["w"][: m.out_channels, :, :, : m.in_channels], w), name
+            if ent["bias"] is not None:
+                assert torch.equal(ent["bias"][: m.out_channels], m.bias.detach()), name
+                checked += 1
+        assert checked >= 1
