@@ -52,6 +52,12 @@ SIGNATURES = {
     "dvq_conv2d_fwd_act": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp]),
     "dvq_conv2d_dgrad_mask": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
     "dvq_set_workspace": (i32, [vp, i64]),
+    "dvq_avgpool_slice": (i32, [vp, i32, i64, i64, i64, i64, i32, vp, i64, i64, vp]),
+    "dvq_avgpool_slice_bwd": (i32, [vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp]),
+    "dvq_silu": (i32, [vp, i32, i64, vp, vp]),
+    "dvq_silu_bwd": (i32, [vp, vp, i32, i64, vp, vp]),
+    "dvq_grain_merge": (i32, [vp, i32, vp, vp, i32, i64, i64, i64, i64, vp, vp, vp]),
+    "dvq_grain_merge_bwd": (i32, [vp, vp, i32, vp, vp, i32, i64, i64, i64, i64, vp, vp, vp]),
     "dvq_affine_channels": (i32, [vp, i32, i64, i64, vp, vp, vp, vp]),
     "dvq_axpy_dev": (i32, [vp, vp, vp, i32, i64, vp, vp]),
     "dvq_maxpool2x2": (i32, [vp, i32, i64, i64, i64, i64, vp, vp]),

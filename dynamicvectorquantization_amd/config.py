@@ -22,6 +22,10 @@ _P = "dynamicvectorquantization_amd."
 TARGET_ALIASES = {
     "models.stage1_dynamic.dqvae_dual_entropy.DualGrainVQModel": (_P + "dqvae", "DualGrainVQModel"),
     "models.stage1_dynamic.dqvae_dual_entropy.Entropy": (_P + "dqvae", "Entropy"),
+    "models.stage1_dynamic.dqvae_dual_feat.DualGrainVQModel": (_P + "dqvae", "DualGrainFeatVQModel"),
+    "models.stage1_dynamic.dqvae_triple_feat.TripleGrainVQModel": (_P + "dqvae", "TripleGrainVQModel"),
+    "modules.dynamic_modules.EncoderTriple.TripleGrainEncoder": (_P + "dqvae", "TripleGrainEncoder"),
+    "modules.dynamic_modules.RouterTriple.TripleGrainFeatureRouter": (_P + "dqvae", "TripleGrainFeatureRouter"),
     "modules.dynamic_modules.EncoderDual.DualGrainEncoder": (_P + "dqvae", "DualGrainEncoder"),
     "modules.dynamic_modules.RouterDual.DualGrainFixedEntropyRouter": (_P + "dqvae", "DualGrainFixedEntropyRouter"),
     "modules.dynamic_modules.RouterDual.DualGrainFeatureRouter": (_P + "dqvae", "DualGrainFeatureRouter"),

@@ -26,6 +26,7 @@ from . import runtime as rt
 from .config import instantiate_from_config
 from .layers import (AttnBlock, Conv2d, Downsample, HipModule, Normalize, ResnetBlock, Tape, Upsample, _child,
                      _grad_buf, norm_swish_conv, to_nchw, to_nhwc)
+from .routing import DualGrainFeatureRouter, Routing, TripleGrainFeatureRouter, _FeatureRouter  # noqa: F401
 
 
 # ---------------------------------------------------------------------------------------------
@@ -61,20 +62,17 @@ class DualGrainFixedEntropyRouter(nn.Module):
         return torch.stack([~fine, fine], dim=-1).long()
 
 
-class DualGrainFeatureRouter(nn.Module):
-    def __init__(self, *a, **k):
-        super().__init__()
-        raise NotImplementedError("feature-routed (Gumbel) DQ-VAE is SURVEY 8(f)/round-2 scope: "
-                                  "RouterDual.py:6-43 has no HIP path yet")
-
-
 # ---------------------------------------------------------------------------------------------
-class DualGrainEncoder(HipModule):
-    """EncoderDual.py:16-156."""
+class _GrainEncoder(HipModule):
+    """Shared CNN trunk + S output heads + routing of DualGrainEncoder (EncoderDual.py:16-156) and TripleGrainEncoder
+    (EncoderTriple.py:14-183).  HEADS lists the head names coarsest -> finest; parameter names follow the reference
+    (`mid_coarse.block_1...`, `norm_out_fine`, `conv_out_median`, ...)."""
 
-    def __init__(self, *, ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
-                 resamp_with_conv=True, in_channels, resolution, z_channels, router_config=None, update_router=True,
-                 **ignore_kwargs):
+    HEADS = ("coarse", "fine")
+    OUT_KEY = "h_dual"
+
+    def __init__(self, *, ch, ch_mult, num_res_blocks, attn_resolutions, dropout, resamp_with_conv, in_channels,
+                 resolution, z_channels, router_config, update_router):
         super().__init__()
         self.ch, self.temb_ch = ch, 0
         self.num_resolutions = len(ch_mult)
@@ -98,73 +96,94 @@ class DualGrainEncoder(HipModule):
                 down.downsample = Downsample(block_in, resamp_with_conv)
                 curr_res = curr_res // 2
             self.down.append(down)
-        self.mid_coarse = nn.Module()
-        self.mid_coarse.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
-        self.mid_coarse.attn_1 = AttnBlock(block_in)
-        self.mid_coarse.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
-        self.norm_out_coarse = Normalize(block_in)
-        self.conv_out_coarse = Conv2d(block_in, z_channels, 3, 1, 1)
-        block_in_fine = block_in // (ch_mult[-1] // ch_mult[-2])
-        self.mid_fine = nn.Module()
-        self.mid_fine.block_1 = ResnetBlock(in_channels=block_in_fine, out_channels=block_in_fine, temb_channels=0, dropout=dropout)
-        self.mid_fine.attn_1 = AttnBlock(block_in_fine)
-        self.mid_fine.block_2 = ResnetBlock(in_channels=block_in_fine, out_channels=block_in_fine, temb_channels=0, dropout=dropout)
-        self.norm_out_fine = Normalize(block_in_fine)
-        self.conv_out_fine = Conv2d(block_in_fine, z_channels, 3, 1, 1)
+        # heads, coarsest first; the head k levels above the bottom has block_in / (ch_mult[-k] // ch_mult[-k-1]) channels
+        width = block_in
+        for k, name in enumerate(self.HEADS):
+            if k > 0:
+                width = width // (ch_mult[-k] // ch_mult[-k - 1])
+            mid = nn.Module()
+            mid.block_1 = ResnetBlock(in_channels=width, out_channels=width, temb_channels=0, dropout=dropout)
+            mid.attn_1 = AttnBlock(width)
+            mid.block_2 = ResnetBlock(in_channels=width, out_channels=width, temb_channels=0, dropout=dropout)
+            setattr(self, f"mid_{name}", mid)
+            setattr(self, f"norm_out_{name}", Normalize(width))
+            setattr(self, f"conv_out_{name}", Conv2d(width, z_channels, 3, 1, 1))
         self.router = instantiate_from_config(router_config)
         self.update_router = update_router
-        if update_router:
-            raise NotImplementedError("update_router=True (Gumbel feature routing) has no HIP path yet (SURVEY 8f)")
+        self.feature_routed = isinstance(self.router, _FeatureRouter)
+        self.gumbel_exponential = None     # test hook: Exp(1) noise [B,hc,wc,S] replacing the device RNG draw
 
     # NHWC core -------------------------------------------------------------------------------------
     def fwd(self, x_img, grain, tape):
-        """x_img: NCHW fp32 image; grain: int64 [B,h,w] (1 = fine).  Returns (h_dual NHWC, mask [B,2h,2w])."""
+        """x_img: NCHW fp32 image; grain: int64 [B,hc,wc] level map for the fixed-entropy router (None when feature
+        routed).  Returns (merged NHWC, codebook mask [B,hf,wf], Routing or None)."""
         cd = rt.compute_dtype()
+        s = len(self.HEADS)
         x = K.nchw_to_nhwc_pad(x_img, K.vec(cd) * -(-self.in_channels // K.vec(cd)), cd)
         h = self.conv_in.fwd(x, _child(tape, "conv_in"))
-        h_fine = None
+        taps = {}
         for i_level in range(self.num_resolutions):
             lvl = self.down[i_level]
             for i_block in range(self.num_res_blocks):
                 h = lvl.block[i_block].fwd(h, _child(tape, f"d{i_level}b{i_block}"))
                 if len(lvl.attn) > 0:
                     h = lvl.attn[i_block].fwd(h, _child(tape, f"d{i_level}a{i_block}"))
-            if i_level == self.num_resolutions - 2:
-                h_fine = h
+            k = self.num_resolutions - 1 - i_level           # head k taps the trunk k levels above the bottom
+            if 0 < k < s:
+                taps[k] = h
             if i_level != self.num_resolutions - 1:
                 h = lvl.downsample.fwd(h, _child(tape, f"d{i_level}ds"))
-        hc = self.mid_coarse.block_1.fwd(h, _child(tape, "mc1"))
-        hc = self.mid_coarse.attn_1.fwd(hc, _child(tape, "mca"))
-        hc = self.mid_coarse.block_2.fwd(hc, _child(tape, "mc2"))
-        hc = norm_swish_conv(self.norm_out_coarse, self.conv_out_coarse, hc, tape, "noc", "coc")
-        hf = self.mid_fine.block_1.fwd(h_fine, _child(tape, "mf1"))
-        hf = self.mid_fine.attn_1.fwd(hf, _child(tape, "mfa"))
-        hf = self.mid_fine.block_2.fwd(hf, _child(tape, "mf2"))
-        hf = norm_swish_conv(self.norm_out_fine, self.conv_out_fine, hf, tape, "nof", "cof")
-        h_dual, mask = K.dual_merge(hf, hc, grain)
-        if tape is not None:
-            tape.s["grain"] = grain
-        return h_dual, mask
+        taps[0] = h
+        heads = []
+        for k, name in enumerate(self.HEADS):
+            mid = getattr(self, f"mid_{name}")
+            t = mid.block_1.fwd(taps[k], _child(tape, f"m{k}1"))
+            t = mid.attn_1.fwd(t, _child(tape, f"m{k}a"))
+            t = mid.block_2.fwd(t, _child(tape, f"m{k}2"))
+            heads.append(norm_swish_conv(getattr(self, f"norm_out_{name}"), getattr(self, f"conv_out_{name}"), t, tape,
+                                         f"no{k}", f"co{k}"))
+        routing = None
+        if self.feature_routed:
+            logits = self.router.fwd(heads, _child(tape, "router"))
+            routing = Routing(logits, stochastic=self.training and self.update_router, want_grad=tape is not None,
+                              exponential=self.gumbel_exponential)
+            merged, mask = K.grain_merge(heads, routing.indices, routing.scale)
+            if tape is not None:
+                tape.s.update(routing=routing, heads=heads)
+        else:
+            assert s == 2, "fixed-entropy routing is dual grain"
+            merged, mask = K.dual_merge(heads[1], heads[0], grain)
+            if tape is not None:
+                tape.s["grain"] = grain
+        return merged, mask, routing
 
-    def bwd(self, g_dual, tape):
-        grain = tape.s["grain"]
-        gf, gc = K.dual_merge_bwd(g_dual, grain)
-        gf = self.conv_out_fine.bwd(gf, tape.child("cof"))
-        gf = self.norm_out_fine.bwd(gf, tape.child("nof"))
-        gf = self.mid_fine.block_2.bwd(gf, tape.child("mf2"))
-        gf = self.mid_fine.attn_1.bwd(gf, tape.child("mfa"))
-        gf = self.mid_fine.block_1.bwd(gf, tape.child("mf1"))
-        gc = self.conv_out_coarse.bwd(gc, tape.child("coc"))
-        gc = self.norm_out_coarse.bwd(gc, tape.child("noc"))
-        gc = self.mid_coarse.block_2.bwd(gc, tape.child("mc2"))
-        gc = self.mid_coarse.attn_1.bwd(gc, tape.child("mca"))
-        g = self.mid_coarse.block_1.bwd(gc, tape.child("mc1"))
+    def bwd(self, g_merged, tape, g_gate=None):
+        s = len(self.HEADS)
+        if self.feature_routed:
+            routing, heads = tape.s["routing"], tape.s["heads"]
+            gh, dscale = K.grain_merge_bwd(g_merged, heads, routing.indices, routing.scale, want_dscale=routing.scale is not None)
+            dlogits = routing.backward(g_gate, dscale)
+            gr = self.router.bwd(dlogits, tape.child("router"))
+            gh = [K.add(a, b) for a, b in zip(gh, gr)]
+        else:
+            gf, gc = K.dual_merge_bwd(g_merged, tape.s["grain"])
+            gh = [gc, gf]
+        gt = {}
+        for k, name in enumerate(self.HEADS):
+            mid = getattr(self, f"mid_{name}")
+            g = getattr(self, f"conv_out_{name}").bwd(gh[k], tape.child(f"co{k}"))
+            g = getattr(self, f"norm_out_{name}").bwd(g, tape.child(f"no{k}"))
+            g = mid.block_2.bwd(g, tape.child(f"m{k}2"))
+            g = mid.attn_1.bwd(g, tape.child(f"m{k}a"))
+            gt[k] = mid.block_1.bwd(g, tape.child(f"m{k}1"))
+        g = gt[0]
         for i_level in reversed(range(self.num_resolutions)):
             lvl = self.down[i_level]
             if i_level != self.num_resolutions - 1:
                 g = lvl.downsample.bwd(g, tape.child(f"d{i_level}ds"))
-            if i_level == self.num_resolutions - 2:
-                g = K.add(g, gf)
+            k = self.num_resolutions - 1 - i_level
+            if 0 < k < s:
+                g = K.add(g, gt[k])
             for i_block in reversed(range(self.num_res_blocks)):
                 if len(lvl.attn) > 0:
                     g = lvl.attn[i_block].bwd(g, tape.child(f"d{i_level}a{i_block}"))
@@ -173,14 +192,42 @@ class DualGrainEncoder(HipModule):
         return None
 
     # reference signature ---------------------------------------------------------------------------
-    def forward(self, x, x_entropy):
+    def forward(self, x, x_entropy=None):
         assert x.shape[2] == x.shape[3] == self.resolution, "{}, {}, {}".format(x.shape[2], x.shape[3], self.resolution)
-        gate = self.router(h_fine=None, h_coarse=None, entropy=x_entropy)
-        gate = gate.permute(0, 3, 1, 2)
-        indices = gate.argmax(dim=1)
-        h_dual, mask = _EncFn.apply(self, torch.is_grad_enabled(), x, indices.contiguous(),
-                                    *[p for p in self.parameters() if p.requires_grad])
-        return {"h_dual": h_dual, "indices": indices, "codebook_mask": mask, "gate": gate}
+        params = [p for p in self.parameters() if p.requires_grad]
+        if self.feature_routed:
+            h, mask, gate, indices = _EncFn.apply(self, torch.is_grad_enabled(), x, None, *params)
+        else:
+            gate = self.router(h_fine=None, h_coarse=None, entropy=x_entropy).permute(0, 3, 1, 2)
+            indices = gate.argmax(dim=1)
+            h, mask, _, _ = _EncFn.apply(self, torch.is_grad_enabled(), x, indices.contiguous(), *params)
+        return {self.OUT_KEY: h, "indices": indices, "codebook_mask": mask, "gate": gate}
+
+
+class DualGrainEncoder(_GrainEncoder):
+    """EncoderDual.py:16-156 (fixed-entropy router, or feature router with Gumbel straight-through when
+    update_router=True and training)."""
+    HEADS = ("coarse", "fine")
+    OUT_KEY = "h_dual"
+
+    def __init__(self, *, ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, router_config=None, update_router=True,
+                 **ignore_kwargs):
+        super().__init__(ch=ch, ch_mult=ch_mult, num_res_blocks=num_res_blocks, attn_resolutions=attn_resolutions,
+                         dropout=dropout, resamp_with_conv=resamp_with_conv, in_channels=in_channels, resolution=resolution,
+                         z_channels=z_channels, router_config=router_config, update_router=update_router)
+
+
+class TripleGrainEncoder(_GrainEncoder):
+    """EncoderTriple.py:14-183 (always Gumbel-routed in training)."""
+    HEADS = ("coarse", "median", "fine")
+    OUT_KEY = "h_triple"
+
+    def __init__(self, *, ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, router_config=None, **ignore_kwargs):
+        super().__init__(ch=ch, ch_mult=ch_mult, num_res_blocks=num_res_blocks, attn_resolutions=attn_resolutions,
+                         dropout=dropout, resamp_with_conv=resamp_with_conv, in_channels=in_channels, resolution=resolution,
+                         z_channels=z_channels, router_config=router_config, update_router=True)
 
 
 class _EncFn(torch.autograd.Function):
@@ -188,15 +235,20 @@ class _EncFn(torch.autograd.Function):
     def forward(ctx, module, want_grad, x, grain, *params):
         ctx.module, ctx.tape, ctx.n = module, (Tape() if want_grad else None), len(params)
         with torch.no_grad():
-            h_dual, mask = module.fwd(x.contiguous().float(), grain, ctx.tape)
-            out = to_nchw(K.cast(h_dual, torch.float32))
-        ctx.mark_non_differentiable(mask)
-        return out, mask.unsqueeze(1)
+            merged, mask, routing = module.fwd(x.contiguous().float(), grain, ctx.tape)
+            out = to_nchw(K.cast(merged, torch.float32))
+        mask = mask.unsqueeze(1)
+        if routing is None:
+            ctx.mark_non_differentiable(mask)
+            return out, mask, None, None
+        gate, idx = routing.gate.detach(), routing.indices
+        ctx.mark_non_differentiable(mask, idx)
+        return out, mask, gate, idx
 
     @staticmethod
-    def backward(ctx, g, _gm):
+    def backward(ctx, g, _gm, g_gate=None, _gi=None):
         with torch.no_grad():
-            ctx.module.bwd(to_nhwc(g, rt.compute_dtype()), ctx.tape)
+            ctx.module.bwd(to_nhwc(g, rt.compute_dtype()), ctx.tape, g_gate)
         return (None, None, None, None) + (None,) * ctx.n
 
 
@@ -407,6 +459,9 @@ class DualGrainVQModel(nn.Module):
     configure_optimizers / log / attributes set by train.py) is kept; the trainer is
     dynamicvectorquantization_amd.trainer (pytorch_lightning is not a dependency)."""
 
+    USES_ENTROPY = True          # dqvae_dual_entropy: per-patch entropy feeds the fixed router; the *_feat models have none
+    N_GRAINS = 2
+
     def __init__(self, encoderconfig, decoderconfig, lossconfig, vqconfig, quant_before_dim, quant_after_dim,
                  quant_sample_temperature=0., ckpt_path=None, ignore_keys=[], image_key="image", monitor=None,
                  warmup_epochs=0, loss_with_epoch=True, scheduler_type="linear-warmup_cosine-decay",
@@ -421,7 +476,9 @@ class DualGrainVQModel(nn.Module):
         self.post_quant_conv = Conv2d(quant_after_dim, quant_before_dim, 1)
         self.quant_sample_temperature = quant_sample_temperature
         self.entropy_patch_size, self.image_size = entropy_patch_size, image_size
-        self.entropy_calculation = Entropy(entropy_patch_size, image_size, image_size)
+        self.feature_routed = bool(getattr(self.encoder, "feature_routed", False))
+        if self.USES_ENTROPY:
+            self.entropy_calculation = Entropy(entropy_patch_size, image_size, image_size)
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
         if monitor is not None:
@@ -454,9 +511,15 @@ class DualGrainVQModel(nn.Module):
 
     def ae_fwd(self, x, tape):
         """x NCHW fp32 -> dict(rec NCHW fp32, qloss, codes, grain, gate, entropy)"""
-        ent, gate = K.patch_entropy_gate(x, self.entropy_patch_size, self._threshold())
-        grain = gate[..., 1].contiguous()
-        h_dual, mask = self.encoder.fwd(x, grain, _child(tape, "enc"))
+        if self.feature_routed:
+            ent = None
+            h_dual, mask, routing = self.encoder.fwd(x, None, _child(tape, "enc"))
+            grain, gate_out = routing.indices, routing.gate.detach()          # gate: fp32 [B,S,hc,wc], differentiable
+        else:
+            ent, gate = K.patch_entropy_gate(x, self.entropy_patch_size, self._threshold())
+            grain = gate[..., 1].contiguous()
+            gate_out = gate.permute(0, 3, 1, 2)
+            h_dual, mask, _ = self.encoder.fwd(x, grain, _child(tape, "enc"))
         h = self.quant_conv.fwd(h_dual, _child(tape, "qc"))
         xq, qloss, codes = self.quantize.fwd(h, mask, _child(tape, "vq"))
         z = self.post_quant_conv.fwd(xq, _child(tape, "pqc"))
@@ -464,7 +527,7 @@ class DualGrainVQModel(nn.Module):
         rec = K.nhwc_pad_to_nchw(rec_p, self.decoder.out_ch)
         if tape is not None:
             self._publish_last_layer_wgrad(tape.child("dec").child("co"))
-        return {"rec": rec, "qloss": qloss, "codes": codes, "grain": grain, "gate": gate.permute(0, 3, 1, 2),
+        return {"rec": rec, "qloss": qloss, "codes": codes, "grain": grain, "gate": gate_out,
                 "entropy": ent, "quant": xq, "mask": mask}
 
     def _publish_last_layer_wgrad(self, t_co):
@@ -481,33 +544,41 @@ class DualGrainVQModel(nn.Module):
 
         conv.weight._dvq_wgrad = wgrad
 
-    def ae_bwd(self, g_rec, g_qloss, tape):
+    def ae_bwd(self, g_rec, g_qloss, tape, g_gate=None):
         cd = rt.compute_dtype()
         g = K.nchw_to_nhwc_pad(g_rec, K.vec(cd) * -(-self.decoder.out_ch // K.vec(cd)), cd)
         g = self.decoder.bwd(g, tape.child("dec"))
         g = self.post_quant_conv.bwd(g, tape.child("pqc"))
         g = self.quantize.bwd(g, g_qloss, tape.child("vq"))
         g = self.quant_conv.bwd(g, tape.child("qc"))
-        self.encoder.bwd(g, tape.child("enc"))
+        self.encoder.bwd(g, tape.child("enc"), g_gate)
 
     # -- reference API ------------------------------------------------------------------------------
     def encode(self, x):
-        with torch.no_grad():
-            x_entropy = self.entropy_calculation(x)
+        x_entropy = None
+        if self.USES_ENTROPY:
+            with torch.no_grad():
+                x_entropy = self.entropy_calculation(x)
         h_dict = self.encoder(x, x_entropy)
-        h = self.quant_conv(h_dict["h_dual"])
+        h = self.quant_conv(h_dict[self.encoder.OUT_KEY])
         quant, emb_loss, info = self.quantize(x=h, temp=self.quant_sample_temperature, codebook_mask=h_dict["codebook_mask"])
-        return quant, emb_loss, info, h_dict["indices"], h_dict["gate"], x_entropy
+        if self.USES_ENTROPY:
+            return quant, emb_loss, info, h_dict["indices"], h_dict["gate"], x_entropy
+        return quant, emb_loss, info, h_dict["indices"], h_dict["gate"]
 
     def decode(self, quant, grain_indices=None):
         return self.decoder(self.post_quant_conv(quant), grain_indices)
 
-    def forward(self, input):
-        """-> (dec, diff, grain_indices, gate, x_entropy); one fused autograd node."""
+    def _forward5(self, input):
         x = input.contiguous().float() if input.dtype != torch.float32 or not input.is_contiguous() else input
         params = [p for p in self.ae_parameters() if p.requires_grad]
-        rec, qloss, grain, gate, ent = _AEFn.apply(self, torch.is_grad_enabled() and len(params) > 0, x, *params)
-        return rec, qloss, grain, gate, ent
+        return _AEFn.apply(self, torch.is_grad_enabled() and len(params) > 0, x, *params)
+
+    def forward(self, input):
+        """-> (dec, diff, grain_indices, gate, x_entropy) [entropy-routed] / (dec, diff, grain_indices, gate) [feature-routed];
+        one fused autograd node."""
+        out = self._forward5(input)
+        return out if self.USES_ENTROPY else out[:4]
 
     def ae_parameters(self):
         return (list(self.encoder.parameters()) + list(self.decoder.parameters()) + list(self.quantize.parameters()) +
@@ -537,18 +608,17 @@ class DualGrainVQModel(nn.Module):
             xrec, qloss, indices, gate, x_entropy = self._gen_out
         elif optimizer_idx == 1:
             with torch.no_grad():     # the discriminator loss detaches the reconstruction: same values, no tape kept
-                xrec, qloss, indices, gate, x_entropy = self(x)
+                xrec, qloss, indices, gate, x_entropy = self._forward5(x)
         else:
-            xrec, qloss, indices, gate, x_entropy = self(x)
+            xrec, qloss, indices, gate, x_entropy = self._forward5(x)
             if self.reuse_generator_forward:
                 self._gen_out = (xrec.detach(), qloss.detach(), indices, gate, x_entropy)
-        ratio = indices.sum() / (indices.size(0) * indices.size(1) * indices.size(2))
         step = self.current_epoch if self.loss_with_epoch else self.global_step
         if optimizer_idx == 0:
             aeloss, log_dict_ae = self.loss(qloss, x, xrec, optimizer_idx, step, last_layer=self.get_last_layer(),
                                             split="train", gate=gate)
             self.log("train_aeloss", aeloss)
-            self.log("train_fine_ratio", ratio)
+            self._log_ratios("train", indices)
             self.log("train_rec_loss", log_dict_ae.pop("train_rec_loss"))
             self.log_dict(log_dict_ae)
             return aeloss
@@ -559,12 +629,19 @@ class DualGrainVQModel(nn.Module):
             self.log_dict(log_dict_disc)
             return discloss
 
+    def _log_ratios(self, split, indices):
+        n = indices.size(0) * indices.size(1) * indices.size(2)
+        if self.N_GRAINS == 2:
+            self.log(f"{split}_fine_ratio", indices.sum() / n)
+        else:       # dqvae_triple_feat.py:113-115 (the reference's spelling)
+            self.log(f"{split}_fine_radio", (indices == 2).sum() / n)
+            self.log(f"{split}_median_radio", (indices == 1).sum() / n)
+
     def validation_step(self, batch, batch_idx):
         x = self.get_input(batch, self.image_key)
         with torch.no_grad():
-            xrec, qloss, indices, gate, x_entropy = self(x)
-            ratio = indices.sum() / (indices.size(0) * indices.size(1) * indices.size(2))
-            self.log("val_fine_ratio", ratio)
+            xrec, qloss, indices, gate, x_entropy = self._forward5(x)
+            self._log_ratios("val", indices)
             step = self.current_epoch if self.loss_with_epoch else self.global_step
             aeloss, log_dict_ae = self.loss(qloss, x, xrec, 0, step, last_layer=self.get_last_layer(), split="val", gate=gate)
             discloss, log_dict_disc = self.loss(qloss, x, xrec, 1, step, last_layer=self.get_last_layer(), split="val")
@@ -601,6 +678,19 @@ class DualGrainVQModel(nn.Module):
         return self.quantize.get_codebook_entry(code)
 
 
+class DualGrainFeatVQModel(DualGrainVQModel):
+    """models/stage1_dynamic/dqvae_dual_feat.py: the same autoencoder without the entropy branch (feature router);
+    forward -> (dec, diff, grain_indices, gate)"""
+    USES_ENTROPY = False
+
+
+class TripleGrainVQModel(DualGrainVQModel):
+    """models/stage1_dynamic/dqvae_triple_feat.py:22-199: three grains (F = 32/16/8), TripleGrainFeatureRouter,
+    forward -> (dec, diff, grain_indices, gate)"""
+    USES_ENTROPY = False
+    N_GRAINS = 3
+
+
 class _AEFn(torch.autograd.Function):
     """The whole autoencoder as one autograd node: forward fills a Tape, backward walks it."""
 
@@ -611,16 +701,18 @@ class _AEFn(torch.autograd.Function):
         with torch.no_grad():
             out = model.ae_fwd(x, ctx.tape)
         model._last = out
-        for k in ("grain", "gate", "entropy"):
+        nd = ["grain"] + (["gate", "entropy"] if not model.feature_routed else [])
+        for k in nd:
             ctx.mark_non_differentiable(out[k])
+        ctx.set_materialize_grads(False)
         return out["rec"], out["qloss"], out["grain"], out["gate"], out["entropy"]
 
     @staticmethod
-    def backward(ctx, g_rec, g_qloss, *_):
+    def backward(ctx, g_rec, g_qloss, _g_grain=None, g_gate=None, _g_ent=None):
         with torch.no_grad():
             if g_rec is None:
                 g_rec = torch.zeros_like(ctx.model._last["rec"])
             if g_qloss is None:
                 g_qloss = torch.zeros((), device=g_rec.device)
-            ctx.model.ae_bwd(g_rec.contiguous().float(), g_qloss, ctx.tape)
+            ctx.model.ae_bwd(g_rec.contiguous().float(), g_qloss, ctx.tape, g_gate if ctx.model.feature_routed else None)
         return (None, None, None) + (None,) * ctx.n

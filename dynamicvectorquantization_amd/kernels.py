@@ -575,3 +575,60 @@ def lpips_head(f0, f1, lin, val, gscale=0.0, want_grad=False):
     check(lib().dvq_lpips_head(_p(f0), _p(f1), _p(lin), dt(f0), n, hw, c, _p(val), float(gscale), _p(df1), _s()),
           "dvq_lpips_head")
     return df1
+
+
+# ---------------------------------------------------------------------------------------------
+# feature-routed (Gumbel) dual / triple grain pieces
+# ---------------------------------------------------------------------------------------------
+def avgpool_slice(x, k, out, coff):
+    """mean over k x k windows of x [N,h*k,w*k,C] -> channel slice [coff, coff+C) of out [N,h,w,ldy]"""
+    n, hk, wk, c = x.shape
+    check(lib().dvq_avgpool_slice(_p(x), dt(x), n, hk // k, wk // k, c, k, _p(out), out.shape[-1], coff, _s()), "dvq_avgpool_slice")
+
+
+def avgpool_slice_bwd(dy, coff, c, k):
+    n, h, w, ldy = dy.shape
+    dx = torch.empty(n, h * k, w * k, c, dtype=dy.dtype, device=dy.device)
+    check(lib().dvq_avgpool_slice_bwd(_p(dy), dt(dy), ldy, coff, n, h, w, c, k, _p(dx), _s()), "dvq_avgpool_slice_bwd")
+    return dx
+
+
+def silu(x):
+    y = torch.empty_like(x)
+    check(lib().dvq_silu(_p(x), dt(x), x.numel(), _p(y), _s()), "dvq_silu")
+    return y
+
+
+def silu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    check(lib().dvq_silu_bwd(_p(x), _p(dy), dt(x), x.numel(), _p(dx), _s()), "dvq_silu_bwd")
+    return dx
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    for t in tensors:
+        _p(t)                 # device / contiguity checks
+    return arr
+
+
+def grain_merge(heads, idx, scale=None):
+    """heads: [coarsest, ..., finest] NHWC; idx int64 [N,hc,wc]; scale fp32 [N,hc,wc] or None -> (merged, codebook mask)"""
+    n, hc, wc, c = heads[0].shape
+    f = 1 << (len(heads) - 1)
+    out = torch.empty(n, hc * f, wc * f, c, dtype=heads[0].dtype, device=heads[0].device)
+    mask = torch.empty(n, hc * f, wc * f, dtype=torch.float32, device=out.device)
+    arr = _ptr_array(heads)
+    check(lib().dvq_grain_merge(arr, len(heads), _p(idx), _p(scale), dt(out), n, hc, wc, c, _p(out), _p(mask), _s()),
+          "dvq_grain_merge")
+    return out, mask
+
+
+def grain_merge_bwd(g_out, heads, idx, scale=None, want_dscale=False):
+    """-> ([d head_l], d scale or None)"""
+    n, hc, wc, c = heads[0].shape
+    dheads = [torch.empty_like(h) for h in heads]
+    dscale = torch.empty(n, hc, wc, dtype=torch.float32, device=g_out.device) if want_dscale else None
+    check(lib().dvq_grain_merge_bwd(_p(g_out), _ptr_array(heads), len(heads), _p(idx), _p(scale), dt(g_out), n, hc, wc, c,
+                                    _ptr_array(dheads), _p(dscale), _s()), "dvq_grain_merge_bwd")
+    return dheads, dscale

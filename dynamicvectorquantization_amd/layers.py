@@ -138,6 +138,64 @@ class Normalize(HipModule):
                              self.num_groups, s["silu"], addend)
 
 
+class Linear(nn.Module):
+    """torch.nn.Linear-compatible parameters (weight [out,in], bias [out], same default init) on the GEMM kernels; rows of
+    the activation matrix are NHWC pixels.  Output columns are zero-padded to a multiple of 8 (`out_p`)."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.out_p = -(-out_features // 8) * 8
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(in_features)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def _w(self, dtype):
+        w = K.cast(self.weight.detach().contiguous(), dtype)
+        b = self.bias.detach() if self.bias is not None else None
+        if self.out_p != self.out_features:
+            wp = torch.zeros(self.out_p, self.in_features, dtype=dtype, device=w.device)
+            wp[: self.out_features].copy_(w)
+            w = wp
+            if b is not None:
+                bp = torch.zeros(self.out_p, dtype=torch.float32, device=w.device)
+                bp[: self.out_features].copy_(b)
+                b = bp
+        return w, b
+
+    def fwd(self, x2d, tape):
+        """x2d [M, in] (compute dtype) -> [M, out_p]"""
+        m = x2d.shape[0]
+        w, b = self._w(x2d.dtype)
+        y = K.gemm_nt(x2d, w, m, self.out_p, self.in_features, self.in_features, self.in_features, self.out_p,
+                      bias=b, bias_mode=1 if b is not None else 0)
+        if tape is not None:
+            tape.s.update(x=x2d, w=w)
+        return y.view(m, self.out_p)
+
+    def bwd(self, dy, tape, need_dx=True):
+        x2d, w = tape.s["x"], tape.s["w"]
+        m = x2d.shape[0]
+        # dW[o][i] += sum_m dy[m][o] x[m][i]  straight into the fp32 gradient; db = column sums of dy
+        K.gemm_tn(dy, x2d, m, self.out_features, self.in_features, self.out_p, self.in_features, self.in_features,
+                  out=_grad_buf(self.weight))
+        if self.bias is not None:
+            if self.out_p == self.out_features:
+                K.sum_batch(dy, _grad_buf(self.bias))            # accumulates
+            else:
+                db = torch.zeros(self.out_p, dtype=torch.float32, device=dy.device)
+                K.sum_batch(dy, db)
+                _grad_buf(self.bias).add_(db[: self.out_features])
+        if not need_dx:
+            return None
+        wt = K.transpose(w, 1, self.out_p, self.in_features)                 # [in, out_p]
+        dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self.out_p, self.in_features)
+        return dx.view(m, self.in_features)
+
+
 class BatchNorm2d(HipModule):
     """torch.nn.BatchNorm2d(C) (eps 1e-5, momentum 0.1, affine, running statistics) with the LeakyReLU(0.2) that
     follows it in the PatchGAN fused in (modules/discriminator/model.py:44-60).  Training mode normalises with the

@@ -232,6 +232,27 @@ int dvq_maxpool2x2_relu_bwd(const void* a, const void* dpool, const void* dtap, 
 int dvq_lpips_head(const void* f0, const void* f1, const float* lin, int dtype, int64_t N, int64_t HW, int64_t C, float* val,
                    float gscale, void* df1, dvq_stream_t stream);
 
+/* ---- feature-routed (Gumbel) dual / triple grain pieces: RouterDual.py:6-43, RouterTriple.py:6-56,
+ * EncoderDual.py:130-156, EncoderTriple.py:143-183 ------------------------------------------------------------------ */
+/* nn.AvgPool2d(k) (k in 1,2,4) of x [N,h*k,w*k,C] written into the channel slice [coff, coff+C) of rows of ldy channels
+ * (= torch.cat(..., dim=1).permute(0,2,3,1) of the router input without materialising the pieces); and its backward */
+int dvq_avgpool_slice(const void* x, int dtype, int64_t N, int64_t h, int64_t w, int64_t C, int k, void* y, int64_t ldy,
+                      int64_t coff, dvq_stream_t stream);
+int dvq_avgpool_slice_bwd(const void* dy, int dtype, int64_t ldy, int64_t coff, int64_t N, int64_t h, int64_t w, int64_t C,
+                          int k, void* dx, dvq_stream_t stream);
+/* nn.SiLU of the router MLP and its backward (x = pre-activation); n % 8 == 0 */
+int dvq_silu(const void* x, int dtype, int64_t n, void* y, dvq_stream_t stream);
+int dvq_silu_bwd(const void* x, const void* dy, int dtype, int64_t n, void* dx, dvq_stream_t stream);
+/* S-grain merge (S = 2, 3).  heads[l]: [N, hc<<l, wc<<l, C] (l = 0 coarsest); idx int64 [N,hc,wc] = selected level of each
+ * coarsest cell; out [N, hc<<(S-1), wc<<(S-1), C] = nearest-upsampled selected head (* scale[cell] if scale != NULL, the
+ * straight-through gate_grad); mask (optional) fp32 [N,hf,wf] = 4^-(S-1-level) (codebook mask).
+ * Backward: dheads[l] = scale * (sum of g over each pixel's footprint where selected, else 0); dscale[cell] (optional) =
+ * sum g * selected head value. */
+int dvq_grain_merge(const void* const* heads, int S, const int64_t* idx, const float* scale, int dtype, int64_t N, int64_t hc,
+                    int64_t wc, int64_t C, void* out, float* mask, dvq_stream_t stream);
+int dvq_grain_merge_bwd(const void* g_out, const void* const* heads, int S, const int64_t* idx, const float* scale, int dtype,
+                        int64_t N, int64_t hc, int64_t wc, int64_t C, void* const* dheads, float* dscale, dvq_stream_t stream);
+
 /* row softmax (AttnBlock, model.py:182) and its backward, rows of length L, in place allowed */
 int dvq_softmax_rows(const void* s, int dtype, int64_t rows, int64_t L, float scale, void* p, dvq_stream_t stream);
 int dvq_softmax_rows_bwd(const void* p, const void* dp, int dtype, int64_t rows, int64_t L, float scale, void* ds,

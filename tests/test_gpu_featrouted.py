@@ -1,0 +1,164 @@
+"""GPU parity of the feature-routed (Gumbel) dual / triple grain DQ-VAE against goldens captured from the reference
+(tests/golden/featrouted_*.npz; the Exp(1) noise of gumbel_softmax is injected on both sides).  `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from dynamicvectorquantization_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def feat_model_config(kind, ch=32, resolution=64, zc=64, k=512, loss=None):
+    common = dict(
+        decoderconfig={"target": "modules.dynamic_modules.DecoderPositional.Decoder", "params": dict(
+            ch=ch, in_ch=zc, out_ch=3, ch_mult=[1, 1, 2, 2], num_res_blocks=2, resolution=resolution,
+            attn_resolutions=[8], latent_size=8, window_size=2, position_type="fourier+learned")},
+        lossconfig=loss or {"target": "modules.losses.vqperceptual.DummyLoss"},
+        vqconfig={"target": "modules.vector_quantization.quantize2_mask.VectorQuantize2", "params": dict(
+            codebook_size=k, codebook_dim=zc, channel_last=False, accept_image_fmap=True,
+            commitment_beta=0.25, decay=0.99, restart_unused_codes=True)},
+        quant_before_dim=zc, quant_after_dim=zc, quant_sample_temperature=0.0, image_key="image")
+    if kind == "triple":
+        enc = {"target": "modules.dynamic_modules.EncoderTriple.TripleGrainEncoder", "params": dict(
+            ch=ch, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2, attn_resolutions=[2, 4, 8], dropout=0.0, resamp_with_conv=True,
+            in_channels=3, resolution=resolution, z_channels=zc,
+            router_config={"target": "modules.dynamic_modules.RouterTriple.TripleGrainFeatureRouter", "params": dict(
+                num_channels=zc, normalization_type="group-32", gate_type="2layer-fc-SiLu")})}
+        return {"target": "models.stage1_dynamic.dqvae_triple_feat.TripleGrainVQModel", "params": dict(encoderconfig=enc, **common)}
+    enc = {"target": "modules.dynamic_modules.EncoderDual.DualGrainEncoder", "params": dict(
+        ch=ch, ch_mult=[1, 1, 2, 2, 4], num_res_blocks=2, attn_resolutions=[4, 8], dropout=0.0, resamp_with_conv=True,
+        in_channels=3, resolution=resolution, z_channels=zc, update_router=True,
+        router_config={"target": "modules.dynamic_modules.RouterDual.DualGrainFeatureRouter", "params": dict(
+            num_channels=zc, normalization_type="group-32", gate_type="1layer-fc")})}
+    return {"target": "models.stage1_dynamic.dqvae_dual_feat.DualGrainVQModel", "params": dict(encoderconfig=enc, **common)}
+
+
+def build_feat(kind, dev, g):
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    model = instantiate_from_config(feat_model_config(kind)).to(dev)
+    own = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    ref = {str(k): tuple(int(x) for x in str(s).split(",")) if str(s) else () for k, s in zip(g["state_keys"], g["state_shapes"])}
+    assert own == ref, set(own) ^ set(ref)                     # state_dict layout of the reference model
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(synth.det_param(n, tuple(p.shape))).to(dev))
+        cbw = synth.det_param("quantize.codebook.weight.spread", (513, 64)) * np.sqrt(64) * 1.2
+        model.quantize.codebook.weight.copy_(torch.from_numpy(cbw).to(dev))
+        last = model.encoder.router.gate if kind == "dualfeat" else model.encoder.router.gate[2]
+        last.weight.mul_(float(g["last_gate_scale"]))
+    rt.bump_weights_epoch()
+    return model
+
+
+@pytest.mark.parametrize("kind", ["triple", "dualfeat"])
+def test_feature_routed_model_golden(dev, kind):
+    from dynamicvectorquantization_amd import losses as L
+    from dynamicvectorquantization_amd import runtime as rt
+    g = load_golden(f"featrouted_{kind}")
+    x = torch.from_numpy(synth.half_flat_images(2, 64, seed=4321)).to(dev)
+    with rt.compute_dtype_ctx(torch.float32):
+        model = build_feat(kind, dev, g)
+        budget = (L.BudgetConstraint_NormedSeperateRatioMSE_TripleGrain(target_fine_ratio=0.3, target_median_ratio=0.3, gamma=1.0,
+                                                                         min_grain_size=8, median_grain_size=16, max_grain_size=32)
+                  if kind == "triple" else
+                  L.BudgetConstraint_RatioMSE_DualGrain(target_ratio=0.5, gamma=1.0, min_grain_size=8, max_grain_size=16))
+        # --- training-mode routing: Gumbel straight-through with the fixture's noise
+        model.train()
+        model.quantize.eval()
+        model.encoder.gumbel_exponential = torch.from_numpy(g["exponential"]).to(dev)
+        dec, qloss, grain, gate = model(x)
+        assert np.array_equal(grain.cpu().numpy().astype(np.int8), g["train_indices"])
+        np.testing.assert_allclose(gate.detach().cpu().numpy(), g["train_gate"], rtol=1e-3, atol=2e-6)
+        np.testing.assert_allclose(dec.detach().cpu().numpy(), g["train_rec"], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(qloss.item(), g["train_qloss"], rtol=1e-3)
+        bl = budget(gate=gate)
+        np.testing.assert_allclose(bl.item(), g["train_budget"], rtol=1e-4)
+        gout = torch.from_numpy(synth.det_param(f"featrouted.{kind}.gout", tuple(dec.shape))).to(dev)
+        ((dec * gout).sum() / dec.numel() * 100.0 + qloss + bl).backward()
+        params = dict(model.named_parameters())
+        for key in [k for k in g.files if k.startswith("grad.")]:
+            ref = g[key]
+            got = params[key[5:]].grad.cpu().numpy()
+            s = max(1e-9, float(np.abs(ref).max()))
+            err = float(np.abs(got.reshape(ref.shape) - ref).max()) / s
+            assert err < 6e-3, f"{key}: rel-to-max grad error {err}"
+        # --- eval-mode routing: raw logits, no scaling
+        model.eval()
+        with torch.no_grad():
+            dec, qloss, grain, gate = model(x)
+        assert np.array_equal(grain.cpu().numpy().astype(np.int8), g["eval_indices"])
+        np.testing.assert_allclose(gate.cpu().numpy(), g["eval_gate"], rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(dec.cpu().numpy(), g["eval_rec"], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(qloss.item(), g["eval_qloss"], rtol=1e-3)
+
+
+def test_grain_merge_kernels_vs_torch(dev):
+    """merge / merge-backward / pooled router row against a plain torch restatement (S = 3, bf16 and fp32)"""
+    from dynamicvectorquantization_amd import kernels as K
+    torch.manual_seed(5)
+    for dtype in (torch.float32, torch.bfloat16):
+        b, hc, c = 2, 3, 64
+        heads = [torch.randn(b, hc << l, hc << l, c, device=dev).to(dtype) for l in range(3)]
+        idx = torch.randint(0, 3, (b, hc, hc), device=dev)
+        scale = (torch.rand(b, hc, hc, device=dev) + 0.5).float()
+        out, mask = K.grain_merge(heads, idx, scale)
+        up = lambda t, r: t.repeat_interleave(r, dim=1).repeat_interleave(r, dim=2)
+        idr = up(idx, 4).unsqueeze(-1)
+        want = heads[2].float()
+        want = torch.where(idr == 0, up(heads[0].float(), 4), want)
+        want = torch.where(idr == 1, up(heads[1].float(), 2), want) * up(scale, 4).unsqueeze(-1)
+        tol = 1e-6 if dtype == torch.float32 else 1e-2
+        assert float((out.float() - want).abs().max()) <= tol * float(want.abs().max())
+        wm = torch.where(idr[..., 0] == 0, torch.tensor(1 / 16, device=dev), torch.where(idr[..., 0] == 1, torch.tensor(0.25, device=dev), torch.tensor(1.0, device=dev)))
+        assert torch.equal(mask, wm)
+        g = torch.randn_like(want).to(dtype)
+        hs = [h.float().requires_grad_(True) for h in heads]
+        sc = scale.clone().requires_grad_(True)
+        w2 = hs[2]
+        w2 = torch.where(idr == 0, up(hs[0], 4), w2)
+        w2 = torch.where(idr == 1, up(hs[1], 2), w2) * up(sc, 4).unsqueeze(-1)
+        w2.backward(g.float())
+        dh, ds = K.grain_merge_bwd(g, heads, idx, scale, want_dscale=True)
+        for a, h in zip(dh, hs):
+            assert float((a.float() - h.grad).abs().max()) <= (1e-5 if dtype == torch.float32 else 3e-2) * max(1.0, float(h.grad.abs().max()))
+        assert float((ds - sc.grad).abs().max()) <= (1e-4 if dtype == torch.float32 else 5e-2) * float(sc.grad.abs().max())
+        feat = torch.zeros(b, hc, hc, 3 * c, device=dev, dtype=dtype)
+        for l in range(3):
+            K.avgpool_slice(heads[l], 1 << l, feat, l * c)
+        ref = torch.cat([torch.nn.functional.avg_pool2d(heads[l].float().permute(0, 3, 1, 2), 1 << l) if l else heads[0].float().permute(0, 3, 1, 2)
+                         for l in range(3)], dim=1).permute(0, 2, 3, 1)
+        assert float((feat.float() - ref).abs().max()) <= (1e-6 if dtype == torch.float32 else 1e-2)
+        dx = K.avgpool_slice_bwd(feat, 2 * c, c, 4)
+        assert float((dx.float() - up(feat[..., 2 * c:].float(), 4) / 16).abs().max()) <= 1e-2
+
+
+def test_triple_full_objective_train_step_bf16(dev):
+    """two complete steps (L1 + LPIPS + GAN + codebook + budget; discriminator) of the triple-grain model in bf16 with the
+    device RNG driving Gumbel: finite losses, router parameters move"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    from dynamicvectorquantization_amd.trainer import Trainer
+    loss = {"target": "modules.losses.vqperceptual_multidisc.VQLPIPSWithDiscriminator", "params": dict(
+        disc_start=0, disc_config={"target": "modules.discriminator.model.NLayerDiscriminator",
+                                   "params": dict(input_nc=3, ndf=16, n_layers=3, use_actnorm=False)},
+        disc_init=True, codebook_weight=1.0, pixelloss_weight=1.0, disc_factor=1.0, disc_weight=1.0, perceptual_weight=1.0,
+        disc_conditional=False, disc_loss="hinge", disc_weight_max=0.75,
+        budget_loss_config={"target": "modules.dynamic_modules.budget.BudgetConstraint_NormedSeperateRatioMSE_TripleGrain",
+                            "params": dict(target_fine_ratio=0.3, target_median_ratio=0.3, gamma=1.0, min_grain_size=8,
+                                           median_grain_size=16, max_grain_size=32)})}
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        torch.manual_seed(0)
+        model = instantiate_from_config(feat_model_config("triple", loss=loss)).to(dev)
+        model.learning_rate, model.training_steps, model.steps_per_epoch = 1e-3, 100, 10
+        model.train()
+        x = torch.from_numpy(synth.half_flat_images(4, 64, seed=99)).to(dev)
+        tr = Trainer(model, max_steps=2)
+        w0 = model.encoder.router.gate[0].weight.detach().clone()
+        l0 = tr.train_step({"image": x}, 0)
+        l1 = tr.train_step({"image": x}, 1)
+        assert len(l0) == 2 and all(torch.isfinite(l).all() for l in l0 + l1)
+        assert not torch.equal(w0, model.encoder.router.gate[0].weight.detach())
+        assert "train_budget_loss" in model._logged and "train_fine_radio" in model._logged

@@ -58,8 +58,15 @@ def test_plugin_boundary_and_config():
     assert merged.model.params.image_size == 64 and merged.model.params.encoderconfig.params.ch == 128
     assert merged.model.params.vqconfig.params.codebook_size == 1024 and merged.data.params.batch_size == 2
     assert merged.model.target == "models.stage1_dynamic.dqvae_dual_entropy.DualGrainVQModel"
-    with pytest.raises(NotImplementedError):
-        cfg.instantiate_from_config({"target": "modules.dynamic_modules.RouterDual.DualGrainFeatureRouter", "params": {}})
+    r = cfg.instantiate_from_config({"target": "modules.dynamic_modules.RouterDual.DualGrainFeatureRouter",
+                                     "params": dict(num_channels=64, normalization_type="group-32", gate_type="2layer-fc-SiLu")})
+    assert r.gate[0].weight.shape == (128, 128) and r.gate[2].weight.shape == (2, 128) and r.feature_norm_fine.weight.shape == (64,)
+    with pytest.raises(NotImplementedError):      # same exception type as RouterDual.py:20
+        cfg.instantiate_from_config({"target": "modules.dynamic_modules.RouterDual.DualGrainFeatureRouter",
+                                     "params": dict(num_channels=64, gate_type="3layer")})
+    t3 = cfg.instantiate_from_config({"target": "modules.dynamic_modules.RouterTriple.TripleGrainFeatureRouter",
+                                      "params": dict(num_channels=32, normalization_type="none", gate_type="1layer-fc")})
+    assert t3.gate.weight.shape == (3, 96)
 
 
 @pytest.mark.parametrize("tag", ["small", "c1"])
@@ -165,3 +172,20 @@ def test_data_parallel_pieces_gloo_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+@pytest.mark.parametrize("kind", ["triple", "dualfeat"])
+def test_feature_routed_state_dict_layout_matches_reference(kind):
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_gpu_featrouted import feat_model_config
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    g = load_golden(f"featrouted_{kind}")
+    model = instantiate_from_config(feat_model_config(kind))
+    own = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    ref = {str(k): tuple(int(x) for x in str(s).split(",")) if str(s) else () for k, s in zip(g["state_keys"], g["state_shapes"])}
+    assert own == ref, (set(own) ^ set(ref))
+    # the shipped YAMLs of the feature-routed models resolve through the plugin boundary
+    from dynamicvectorquantization_amd import config as cfg
+    name = "dqvae-triple-r-03-03_imagenet.yml" if kind == "triple" else "dqvae-dual-r-05_imagenet.yml"
+    c = cfg.load_yaml(os.path.join(REPO, "configs/stage1", name))
+    assert c.model.params.lossconfig.params.budget_loss_config.target.startswith("modules.dynamic_modules.budget.")

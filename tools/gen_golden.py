@@ -528,9 +528,120 @@ def gen_lossnet():
     np.savez_compressed(os.path.join(GOLD, "lossnet.npz"), **out)
 
 
+def build_feat_model(kind, ch=32, resolution=64, zc=64, k=512):
+    """feature-routed models at a shrunken geometry: triple (F = 32/16/8 -> heads 2x2 / 4x4 / 8x8 at 64x64 input) and
+    dual_feat (heads 4x4 / 8x8)"""
+    common = dict(
+        decoderconfig=dict(target="modules.dynamic_modules.DecoderPositional.Decoder", params=dict(
+            ch=ch, in_ch=zc, out_ch=3, ch_mult=[1, 1, 2, 2], num_res_blocks=2, resolution=resolution,
+            attn_resolutions=[8], latent_size=8, window_size=2, position_type="fourier+learned")),
+        lossconfig=dict(target="modules.losses.vqperceptual.DummyLoss"),
+        vqconfig=dict(target="modules.vector_quantization.quantize2_mask.VectorQuantize2", params=dict(
+            codebook_size=k, codebook_dim=zc, channel_last=False, accept_image_fmap=True,
+            commitment_beta=0.25, decay=0.99, restart_unused_codes=True)),
+        quant_before_dim=zc, quant_after_dim=zc, quant_sample_temperature=0.0, image_key="image")
+    if kind == "triple":
+        from models.stage1_dynamic.dqvae_triple_feat import TripleGrainVQModel
+        enc = dict(target="modules.dynamic_modules.EncoderTriple.TripleGrainEncoder", params=dict(
+            ch=ch, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2, attn_resolutions=[2, 4, 8], dropout=0.0, resamp_with_conv=True,
+            in_channels=3, resolution=resolution, z_channels=zc,
+            router_config=dict(target="modules.dynamic_modules.RouterTriple.TripleGrainFeatureRouter", params=dict(
+                num_channels=zc, normalization_type="group-32", gate_type="2layer-fc-SiLu"))))
+        return TripleGrainVQModel(encoderconfig=enc, **common)
+    from models.stage1_dynamic.dqvae_dual_feat import DualGrainVQModel
+    enc = dict(target="modules.dynamic_modules.EncoderDual.DualGrainEncoder", params=dict(
+        ch=ch, ch_mult=[1, 1, 2, 2, 4], num_res_blocks=2, attn_resolutions=[4, 8], dropout=0.0, resamp_with_conv=True,
+        in_channels=3, resolution=resolution, z_channels=zc, update_router=True,
+        router_config=dict(target="modules.dynamic_modules.RouterDual.DualGrainFeatureRouter", params=dict(
+            num_channels=zc, normalization_type="group-32", gate_type="1layer-fc"))))
+    return DualGrainVQModel(encoderconfig=enc, **common)
+
+
+def gen_featrouted():
+    """Gumbel feature-routed dual / triple models, train-mode routing with INJECTED Exp(1) noise (Tensor.exponential_ is
+    patched while the reference's F.gumbel_softmax runs), budget loss on the gate, eval-mode routing too."""
+    from modules.dynamic_modules.budget import (BudgetConstraint_NormedSeperateRatioMSE_TripleGrain,
+                                                 BudgetConstraint_RatioMSE_DualGrain)
+    from oracle import routing as oro
+    for kind, s_, hc in (("triple", 3, 2), ("dualfeat", 2, 4)):
+        out = {}
+        model = build_feat_model("triple" if kind == "triple" else "dual")
+        load_det(model)
+        k, zc = 512, 64
+        cbw = synth.det_param("quantize.codebook.weight.spread", (k + 1, zc)) * np.sqrt(zc) * 1.2
+        with torch.no_grad():
+            model.quantize.codebook.weight.copy_(t(cbw))
+            # a livelier router: scale the last gate layer so the three grains all occur
+            last = model.encoder.router.gate if kind == "dualfeat" else model.encoder.router.gate[2]
+            last.weight.mul_(6.0)
+        x = synth.half_flat_images(2, 64, seed=4321)
+        xt = t(x)
+        expo = np.random.RandomState(11).exponential(size=(2, hc, hc, s_)).astype(np.float32)
+        budget = (BudgetConstraint_NormedSeperateRatioMSE_TripleGrain(target_fine_ratio=0.3, target_median_ratio=0.3, gamma=1.0,
+                                                                       min_grain_size=8, median_grain_size=16, max_grain_size=32)
+                  if kind == "triple" else
+                  BudgetConstraint_RatioMSE_DualGrain(target_ratio=0.5, gamma=1.0, min_grain_size=8, max_grain_size=16))
+        model.train()
+        model.quantize.eval()                     # no EMA / restart in this fixture (device RNG)
+        orig = torch.Tensor.exponential_
+        torch.Tensor.exponential_ = lambda self, *a, **kw: self.copy_(t(expo).reshape(self.shape))
+        try:
+            dec, qloss, grain, gate = model(xt)
+        finally:
+            torch.Tensor.exponential_ = orig
+        gout = synth.det_param(f"featrouted.{kind}.gout", dec.shape)
+        bl = budget(gate=gate)
+        ((dec * t(gout)).sum() / dec.numel() * 100.0 + qloss + bl).backward()
+        sd = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
+        sdg = {kk: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and v.dim() > 0 and not kk.startswith("quantize.") else v)
+               for kk, v in sd.items()}
+        o = oro.model_forward(sdg, xt, s_, t(expo))
+        check(f"{kind}.train.indices", grain.numpy(), o["indices"].numpy())
+        check(f"{kind}.train.gate", gate.detach().numpy(), o["gate"].detach().numpy(), rtol=1e-5, atol=1e-6)
+        check(f"{kind}.train.rec", dec.detach().numpy(), o["rec"].detach().numpy(), rtol=1e-3, atol=1e-4)
+        check(f"{kind}.train.qloss", qloss.item(), o["qloss"].item(), rtol=1e-4)
+        ((o["rec"] * t(gout)).sum() / dec.numel() * 100.0 + o["qloss"] + budget(gate=o["gate"])).backward()
+        rn = "encoder.router.gate.weight" if kind == "dualfeat" else "encoder.router.gate.0.weight"
+        check(f"{kind}.train.grad router", sdg[rn].grad.numpy(), dict(model.named_parameters())[rn].grad.numpy(), rtol=2e-3, atol=1e-7)
+        print(f"  {kind}: grain histogram {np.bincount(grain.numpy().reshape(-1), minlength=s_)}  budget {bl.item():.4f}")
+        out["exponential"] = expo
+        out["train_indices"] = grain.numpy().astype(np.int8)
+        out["train_gate"] = gate.detach().numpy()
+        out["train_rec"] = dec.detach().numpy()
+        out["train_qloss"] = np.float32(qloss.item())
+        out["train_budget"] = np.float32(bl.item())
+        names = ["encoder.conv_in.weight", "encoder.down.0.block.0.conv1.weight", "encoder.conv_out_fine.bias",
+                 "encoder.conv_out_coarse.weight", "encoder.mid_coarse.attn_1.proj_out.weight", "encoder.norm_out_fine.weight",
+                 "encoder.router.feature_norm_fine.weight", "encoder.router.feature_norm_coarse.bias", rn,
+                 "encoder.router.gate.bias" if kind == "dualfeat" else "encoder.router.gate.2.weight",
+                 "quant_conv.weight", "decoder.conv_in.weight", "decoder.conv_out.weight"]
+        if kind == "triple":
+            names += ["encoder.conv_out_median.weight", "encoder.mid_median.block_1.conv1.weight", "encoder.router.gate.0.bias",
+                      "encoder.router.feature_norm_median.weight"]
+        params = dict(model.named_parameters())
+        for nme in names:
+            out["grad." + nme] = params[nme].grad.numpy().astype(np.float32)
+        # eval-mode routing (no Gumbel, raw logits as the gate)
+        model.eval()
+        with torch.no_grad():
+            dec, qloss, grain, gate = model(xt)
+            o = oro.model_forward(sd, xt, s_, None)
+        check(f"{kind}.eval.indices", grain.numpy(), o["indices"].numpy())
+        check(f"{kind}.eval.rec", dec.numpy(), o["rec"].numpy(), rtol=1e-3, atol=1e-4)
+        out["eval_indices"] = grain.numpy().astype(np.int8)
+        out["eval_gate"] = gate.numpy()
+        out["eval_rec"] = dec.numpy()
+        out["eval_qloss"] = np.float32(qloss.item())
+        shapes = {kk: np.array(v.shape, dtype=np.int64) for kk, v in model.state_dict().items()}
+        out["state_keys"] = np.array(sorted(shapes.keys()))
+        out["state_shapes"] = np.array([",".join(map(str, shapes[kk])) for kk in sorted(shapes.keys())])
+        out["last_gate_scale"] = np.float32(6.0)
+        np.savez_compressed(os.path.join(GOLD, f"featrouted_{kind}.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet")
+    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -538,7 +649,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for name in args.only.split(","):
         print(f"[gen] {name}")
-        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet}[name]()
+        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted}[name]()
     print("done ->", GOLD)
 
 
