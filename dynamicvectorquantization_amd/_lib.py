@@ -52,6 +52,8 @@ SIGNATURES = {
     "dvq_conv2d_fwd_act": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp]),
     "dvq_conv2d_dgrad_mask": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
     "dvq_set_workspace": (i32, [vp, i64]),
+    "dvq_permute_dual": (i32, [vp, vp, i64, i32, i32, i32, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]),
+    "dvq_permute_dual_back": (i32, [vp, vp, vp, vp, i64, i64, i64, i32, i32, i64, i64, vp, vp]),
     "dvq_avgpool_slice": (i32, [vp, i32, i64, i64, i64, i64, i32, vp, i64, i64, vp]),
     "dvq_avgpool_slice_bwd": (i32, [vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp]),
     "dvq_silu": (i32, [vp, i32, i64, vp, vp]),

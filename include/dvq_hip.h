@@ -253,6 +253,22 @@ int dvq_grain_merge(const void* const* heads, int S, const int64_t* idx, const f
 int dvq_grain_merge_bwd(const void* g_out, const void* const* heads, int S, const int64_t* idx, const float* scale, int dtype,
                         int64_t N, int64_t hc, int64_t wc, int64_t C, void* const* dheads, float* dscale, dvq_stream_t stream);
 
+/* ---- stage-2 input permutation (integer, bit-exact): DualGrainSeperatePermuter, modules/dynamic_modules/permuter.py:50-135 -----
+ * forward: indices int64 [B, hw1*hw2, hw1*hw2] (codes), grain int64 [B,hw1,hw1] (0 coarse / 1 fine) -> EOS-terminated,
+ * PAD-filled rows of the MAXIMUM length: coarse_content / coarse_position [B, hw1^2 + 1], fine_content / fine_position
+ * [B, (hw1*hw2)^2 + 1]; counts int32 [B][2] = number of coarse cells / fine codes of each image (the caller narrows the
+ * rows to max(count)+1 like pad_sequence does).  order 0 = "region-first", 1 = "row-first" (hw2 must be 2). */
+int dvq_permute_dual(const int64_t* indices, const int64_t* grain, int64_t B, int hw1, int hw2, int order, int64_t content_pad,
+                     int64_t content_eos, int64_t cpos_pad, int64_t cpos_eos, int64_t fpos_pad, int64_t fpos_eos,
+                     int64_t* coarse_content, int64_t* coarse_position, int64_t* fine_content, int64_t* fine_position,
+                     int* counts, dvq_stream_t stream);
+/* forward_back: sequences [B,Lc] / [B,Lf] -> code map int64 [B, hw1*hw2, hw1*hw2].  Coarse codes are broadcast to their
+ * cells only when the coarse EOS is present, entries at and after the first EOS are ignored, a position written twice
+ * keeps the last write (the reference's sequential semantics). */
+int dvq_permute_dual_back(const int64_t* coarse_content, const int64_t* fine_content, const int64_t* coarse_position,
+                          const int64_t* fine_position, int64_t B, int64_t Lc, int64_t Lf, int hw1, int hw2, int64_t cpos_eos,
+                          int64_t fpos_eos, int64_t* out, dvq_stream_t stream);
+
 /* row softmax (AttnBlock, model.py:182) and its backward, rows of length L, in place allowed */
 int dvq_softmax_rows(const void* s, int dtype, int64_t rows, int64_t L, float scale, void* p, dvq_stream_t stream);
 int dvq_softmax_rows_bwd(const void* p, const void* dp, int dtype, int64_t rows, int64_t L, float scale, void* ds,

@@ -639,9 +639,48 @@ def gen_featrouted():
         np.savez_compressed(os.path.join(GOLD, f"featrouted_{kind}.npz"), **out)
 
 
+def gen_permuter():
+    """DualGrainSeperatePermuter forward / forward_back of the reference on seeded inputs (both fine orders, ragged batches,
+    all-coarse / all-fine images, malformed sequences for forward_back)."""
+    from modules.dynamic_modules.permuter import DualGrainSeperatePermuter
+    from oracle import permuter as ope
+    out = {}
+    rs = np.random.RandomState(2021)
+    for order in ("region-first", "row-first"):
+        tag = order.split("-")[0]
+        for name, hw1 in (("small", 4), ("full", 16)):
+            fhw = hw1 * 2
+            b = 5
+            idx = rs.randint(0, 1024, size=(b, fhw, fhw)).astype(np.int64)
+            grain = (rs.uniform(size=(b, hw1, hw1)) < np.array([0.5, 0.1, 0.9, 0.0, 1.0])[:, None, None]).astype(np.int64)
+            perm = DualGrainSeperatePermuter(coarse_hw=hw1, fine_hw=fhw, fine_position_order=order)
+            ref = perm(t(idx), t(grain))
+            ora = ope.forward(idx, grain, hw1, 2, order)
+            for k in ("coarse_content", "fine_content", "coarse_position", "fine_position", "coarse_segment", "fine_segment"):
+                check(f"permuter.{tag}.{name}.{k}", ref[k].numpy(), ora[k])
+                out[f"{tag}_{name}_{k}"] = ref[k].numpy()
+            out[f"{tag}_{name}_indices"], out[f"{tag}_{name}_grain"] = idx, grain
+            back = perm.forward_back(ref["coarse_content"], ref["fine_content"], ref["coarse_position"], ref["fine_position"])
+            check(f"permuter.{tag}.{name}.back", back.numpy(), ope.forward_back(ora["coarse_content"], ora["fine_content"],
+                                                                                 ora["coarse_position"], ora["fine_position"], hw1, 2))
+            out[f"{tag}_{name}_back"] = back.numpy()
+    # malformed / sampled-like sequences: duplicates, missing coarse EOS, early fine EOS
+    perm = DualGrainSeperatePermuter(coarse_hw=4, fine_hw=8)
+    cc = rs.randint(0, 1024, size=(4, 9)).astype(np.int64)
+    cp = rs.randint(0, 16, size=(4, 9)).astype(np.int64)
+    fc = rs.randint(0, 1024, size=(4, 21)).astype(np.int64)
+    fp = rs.randint(0, 64, size=(4, 21)).astype(np.int64)
+    cp[0, 8] = 257; cp[1, 3] = 257; cp[3, 0] = 257            # image 2: no coarse EOS at all
+    fp[0, 20] = 1025; fp[1, 5] = 1025; fp[2, 0] = 1025        # image 3: no fine EOS
+    back = perm.forward_back(t(cc), t(fc), t(cp), t(fp))
+    check("permuter.malformed.back", back.numpy(), ope.forward_back(cc, fc, cp, fp, 4, 2))
+    out.update(mal_cc=cc, mal_cp=cp, mal_fc=fc, mal_fp=fp, mal_back=back.numpy())
+    np.savez_compressed(os.path.join(GOLD, "permuter.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted")
+    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -649,7 +688,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for name in args.only.split(","):
         print(f"[gen] {name}")
-        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted}[name]()
+        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter}[name]()
     print("done ->", GOLD)
 
 
