@@ -86,6 +86,16 @@ SIGNATURES = {
     "dvq_cast": (i32, [vp, i32, vp, i32, i64, vp]),
     "dvq_l1_loss": (i32, [vp, vp, i64, vp, vp, vp, vp]),
     "dvq_adam": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
+    "dvq_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
+    "dvq_layernorm_fwd": (i32, [vp, i32, i64, i64, f32, vp, vp, vp, vp, vp]),
+    "dvq_layernorm_bwd": (i32, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, vp]),
+    "dvq_gelu": (i32, [vp, i32, i64, vp, vp]),
+    "dvq_gelu_bwd": (i32, [vp, vp, i32, i64, vp, vp]),
+    "dvq_softmax_causal": (i32, [vp, i32, i64, i64, i64, i64, f32, vp, vp]),
+    "dvq_embed_gather": (i32, [vp, i64, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp]),
+    "dvq_embed_scatter_add": (i32, [vp, i64, vp, i32, i64, i64, i64, i64, i64, i64, vp, vp]),
+    "dvq_cross_entropy": (i32, [vp, i32, i64, i64, i64, vp, i64, vp, vp, vp, vp, vp]),
+    "dvq_dropout": (i32, [vp, i32, i64, f32, C.c_uint64, vp, vp]),
     "dvq_fill_f32": (i32, [vp, f32, i64, vp]),
 }
 

@@ -48,6 +48,7 @@ TARGET_ALIASES = {
         (_P + "losses", "BudgetConstraint_NormedSeperateRatioMSE_TripleGrain"),
     "models.stage1.utils.Scheduler_LinearWarmup": (_P + "trainer", "scheduler_linear_warmup"),
     "models.stage1.utils.Scheduler_LinearWarmup_CosineDecay": (_P + "trainer", "scheduler_linear_warmup_cosine_decay"),
+    "modules.dynamic_modules.stackgpt.StackGPT": (_P + "stackgpt", "StackGPT"),
     "modules.dynamic_modules.permuter.DualGrainSeperatePermuter": (_P + "stage2", "DualGrainSeperatePermuter"),
     "modules.dynamic_modules.label_provider.PositionAwareSOSProvider": (_P + "stage2", "PositionAwareSOSProvider"),
     "modules.dynamic_modules.label_provider.ClassForContentOnlyPositionAwareSOSProvider":

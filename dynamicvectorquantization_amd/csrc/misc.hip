@@ -330,14 +330,14 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float step_size, float beta1, float beta2, float eps,
-                                                   float inv_sqrt_bc2) {
+                                                   float inv_sqrt_bc2, float decay_mul) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         const float gv = g[e];
         const float mm = beta1 * m[e] + (1.f - beta1) * gv;
         const float vv = beta2 * v[e] + (1.f - beta2) * gv * gv;
         m[e] = mm;
         v[e] = vv;
-        p[e] -= step_size * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+        p[e] = p[e] * decay_mul - step_size * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);     // decay_mul = 1 - lr * weight_decay (AdamW)
     }
 }
 
@@ -543,8 +543,19 @@ int dvq_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
     DVQ_REQUIRE(p && g && m && v && n > 0 && step >= 1, DVQ_EINVAL, "dvq_adam: bad arguments");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     adam_kernel<<<dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, n, (float)(lr / bc1), beta1,
-                                                                             beta2, eps, (float)(1.0 / sqrt(bc2)));
+                                                                             beta2, eps, (float)(1.0 / sqrt(bc2)), 1.f);
     DVQ_CHECK_LAUNCH("adam");
+    return DVQ_OK;
+}
+
+int dvq_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int step, dvq_stream_t stream) {
+    DVQ_REQUIRE(p && g && m && v && n > 0 && step >= 1 && weight_decay >= 0.f, DVQ_EINVAL, "dvq_adamw: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    adam_kernel<<<dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, n, (float)(lr / bc1), beta1,
+                                                                             beta2, eps, (float)(1.0 / sqrt(bc2)),
+                                                                             1.f - lr * weight_decay);
+    DVQ_CHECK_LAUNCH("adamw");
     return DVQ_OK;
 }
 

@@ -1,0 +1,375 @@
+// StackGPT building blocks that are not GEMMs (gfx950; all HBM-bound row / element work):
+//   LayerNorm forward / backward            nn.LayerNorm(n_embd)            stackgpt.py:75-76,152-153
+//   GELU (erf) forward / backward           nn.GELU()                       stackgpt.py:80
+//   causal softmax over attention scores    masked_fill(-inf) + softmax     stackgpt.py:59-63
+//   embedding gather(+add) / scatter-add    nn.Embedding(padding_idx)       stackgpt.py:136-146,177-199
+//   cross entropy with ignore_index         F.cross_entropy                 stackgpt.py:213-224
+//   dropout (counter-based hash RNG)        nn.Dropout                      stackgpt.py:31-32,82,146
+// The GEMMs (q/k/v/proj/MLP/heads, QK^T, PV and their backward) run on igemm.hip's kernels.
+#include "dvq_common.h"
+
+namespace {
+
+inline unsigned nblk(int64_t work, int per_block, int64_t cap = 1 << 20) {
+    int64_t b = cdiv64(work, per_block);
+    return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ---- LayerNorm: one wave per row, lanes stride over 8-channel vectors -------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int64_t rows, int C8, float eps,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     T* __restrict__ y, float* __restrict__ mean_rstd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t C = (int64_t)C8 * 8;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        float s = 0.f, q = 0.f;
+        for (int c8 = lane; c8 < C8; c8 += 64) {
+            float v[8];
+            load8(x + r * C + c8 * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s += v[j];
+                q = fmaf(v[j], v[j], q);
+            }
+        }
+        s = wave_sum(s);
+        q = wave_sum(q);
+        const float mean = s / (float)C;
+        float var = q / (float)C - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        const float rstd = rsqrtf(var + eps);
+        if (lane == 0 && mean_rstd != nullptr) {
+            mean_rstd[2 * r] = mean;
+            mean_rstd[2 * r + 1] = rstd;
+        }
+        for (int c8 = lane; c8 < C8; c8 += 64) {
+            float v[8];
+            load8(x + r * C + c8 * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf((v[j] - mean) * rstd, gamma[c8 * 8 + j], beta[c8 * 8 + j]);
+            store8(y + r * C + c8 * 8, v);
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += sum dy * xhat, dbeta += sum dy.
+// Each wave walks a contiguous block of rows and keeps its dgamma / dbeta partials in registers (C <= 4096).
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t rows, int C8,
+                                                     const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                     T* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int rows_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int64_t C = (int64_t)C8 * 8;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t r0 = wave * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
+    constexpr int MAXV = 8;                      // up to 8 vectors per lane: C <= 4096
+    float ag[MAXV][8], ab[MAXV][8];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ag[i][j] = ab[i][j] = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float mean = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c8 = lane + 64 * i;
+            if (c8 < C8) {
+                float v[8], g[8];
+                load8(x + r * C + c8 * 8, v);
+                load8(dy + r * C + c8 * 8, g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (v[j] - mean) * rstd;
+                    const float gg = g[j] * gamma[c8 * 8 + j];
+                    s1 += gg;
+                    s2 = fmaf(gg, xh, s2);
+                    ag[i][j] = fmaf(g[j], xh, ag[i][j]);
+                    ab[i][j] += g[j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c8 = lane + 64 * i;
+            if (c8 < C8) {
+                float v[8], g[8];
+                load8(x + r * C + c8 * 8, v);
+                load8(dy + r * C + c8 * 8, g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (v[j] - mean) * rstd;
+                    g[j] = rstd * (g[j] * gamma[c8 * 8 + j] - s1 - xh * s2);
+                }
+                store8(dx + r * C + c8 * 8, g);
+            }
+        }
+    }
+    if (r0 < r1) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c8 = lane + 64 * i;
+            if (c8 < C8)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    atomicAdd(&dgamma[c8 * 8 + j], ag[i][j]);
+                    atomicAdd(&dbeta[c8 * 8 + j], ab[i][j]);
+                }
+        }
+    }
+}
+
+// ---- GELU (exact, erf) -------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_g(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t n8, T* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
+        float v[8], g[8];
+        load8(x + e * 8, v);
+        if (BWD) {
+            load8(dy + e * 8, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = g[j] * gelu_g(v[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        }
+        store8(out + e * 8, v);
+    }
+}
+
+// ---- causal softmax: rows of length L; row index within its [T x L] matrix = row % T; columns > (row % T) + off are masked
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_causal_kernel(const T* __restrict__ s, int64_t rows, int64_t L, int64_t Tq, int off,
+                                                             float scale, T* __restrict__ p) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const int64_t valid = min(L, (r % Tq) + off + 1);
+        const T* row = s + r * L;
+        T* prow = p + r * L;
+        float m = -INFINITY;
+        for (int64_t c = lane; c < valid; c += 64) m = fmaxf(m, ElemIO<T>::load(row + c) * scale);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int64_t c = lane; c < valid; c += 64) sum += __expf(ElemIO<T>::load(row + c) * scale - m);
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int64_t c = lane; c < L; c += 64)
+            ElemIO<T>::store(prow + c, c < valid ? __expf(ElemIO<T>::load(row + c) * scale - m) * inv : 0.f);
+    }
+}
+
+// ---- embeddings --------------------------------------------------------------------------------------------------
+// out[b][t0 + j][:] (+)= table[idx[b][j]][:]   for j < len;  out rows have C channels, out is [B][T][C]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table,
+                                                           int64_t B, int64_t len, int64_t Ttot, int64_t t0, int C8, int accumulate,
+                                                           int64_t idx_bstride, T* __restrict__ out) {
+    const int64_t total = B * len * C8;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c8 = (int)(e % C8);
+        const int64_t j = (e / C8) % len, b = e / ((int64_t)C8 * len);
+        const int64_t id = idx[b * idx_bstride + j];
+        const float* src = table + id * ((int64_t)C8 * 8) + c8 * 8;
+        T* dst = out + ((b * Ttot + t0 + j) * C8 + c8) * 8;
+        float v[8];
+        if (accumulate) {
+            load8(dst, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += src[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = src[k];
+        }
+        store8(dst, v);
+    }
+}
+
+// dtable[idx[b][j]][:] += dout[b][t0 + j][:]   (rows equal to padding_idx receive nothing)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ idx, const T* __restrict__ dout, int64_t B,
+                                                            int64_t len, int64_t Ttot, int64_t t0, int C8, int64_t padding_idx,
+                                                            int64_t idx_bstride, float* __restrict__ dtable) {
+    const int64_t total = B * len * C8;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c8 = (int)(e % C8);
+        const int64_t j = (e / C8) % len, b = e / ((int64_t)C8 * len);
+        const int64_t id = idx[b * idx_bstride + j];
+        if (id == padding_idx) continue;
+        float v[8];
+        load8(dout + ((b * Ttot + t0 + j) * C8 + c8) * 8, v);
+        float* dst = dtable + id * ((int64_t)C8 * 8) + c8 * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(dst + k, v[k]);
+    }
+}
+
+// ---- cross entropy over V columns of rows with stride ldl; one wave per row --------------------------------------
+// loss_sum += sum over non-ignored rows of (logsumexp - logit[target]); cnt += number of them;
+// dlogits (optional) = (softmax - onehot) * gscale[0]  (0 for ignored rows and for the padding columns >= V)
+template <typename T>
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const T* __restrict__ logits, int64_t rows, int V, int ldl,
+                                                            const int64_t* __restrict__ target, int64_t ignore_index,
+                                                            float* __restrict__ loss_sum, float* __restrict__ cnt,
+                                                            const float* __restrict__ gscale, T* __restrict__ dlogits) {
+    const int lane = threadIdx.x & 63;
+    float lsum = 0.f, lcnt = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const int64_t tg = target[r];
+        const T* row = logits + r * ldl;
+        const bool ign = tg == ignore_index;
+        if (ign && dlogits == nullptr) continue;
+        float m = -INFINITY;
+        for (int c = lane; c < V; c += 64) m = fmaxf(m, ElemIO<T>::load(row + c));
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < V; c += 64) s += __expf(ElemIO<T>::load(row + c) - m);
+        s = wave_sum(s);
+        if (!ign && lane == 0) {
+            lsum += (m + __logf(s)) - ElemIO<T>::load(row + tg);
+            lcnt += 1.f;
+        }
+        if (dlogits != nullptr) {
+            const float g = ign ? 0.f : gscale[0];
+            const float inv = 1.f / s;
+            for (int c = lane; c < ldl; c += 64) {
+                float d = 0.f;
+                if (c < V && !ign) d = (__expf(ElemIO<T>::load(row + c) - m) * inv - (c == tg ? 1.f : 0.f)) * g;
+                ElemIO<T>::store(dlogits + r * ldl + c, d);
+            }
+        }
+    }
+    if (lane == 0 && lcnt > 0.f) {
+        atomicAdd(loss_sum, lsum);
+        atomicAdd(cnt, lcnt);
+    }
+}
+
+// ---- dropout: keep = hash(seed, element index) >= p; y = x * keep / (1 - p).  The same call with the same (seed, offset)
+// applies the same mask to a gradient. ------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned hash32(unsigned long long k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return (unsigned)k;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, int64_t n8, float p, unsigned long long seed,
+                                                      T* __restrict__ y) {
+    const float scale = 1.f / (1.f - p);
+    const unsigned thr = (unsigned)(p * 4294967296.0);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
+        float v[8];
+        load8(x + e * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned h = hash32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)(e * 8 + j));
+            v[j] = h >= thr ? v[j] * scale : 0.f;
+        }
+        store8(y + e * 8, v);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvq_layernorm_fwd(const void* x, int dtype, int64_t rows, int64_t C, float eps, const float* gamma, const float* beta, void* y,
+                      float* mean_rstd, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && gamma && beta && y && rows > 0 && C > 0 && C % 8 == 0, DVQ_EINVAL, "dvq_layernorm_fwd: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T, ln_fwd_kernel<T><<<dim3(nblk(rows, 4, 1 << 16)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)x, rows, (int)(C / 8), eps, gamma, beta, (T*)y, mean_rstd););
+    DVQ_CHECK_LAUNCH("layernorm_fwd");
+    return DVQ_OK;
+}
+
+int dvq_layernorm_bwd(const void* x, const void* dy, int dtype, int64_t rows, int64_t C, const float* mean_rstd, const float* gamma,
+                      void* dx, float* dgamma, float* dbeta, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && dy && mean_rstd && gamma && dx && dgamma && dbeta && rows > 0 && C > 0 && C % 8 == 0 && C <= 4096, DVQ_EINVAL,
+                "dvq_layernorm_bwd: bad arguments (C %% 8 == 0, C <= 4096)");
+    int rpw = (int)cdiv64(rows, 4 * 1024);            // <= 1024 workgroups x 4 waves
+    if (rpw < 1) rpw = 1;
+    const int64_t waves = cdiv64(rows, rpw);
+    DVQ_DISPATCH_DTYPE(dtype, T, ln_bwd_kernel<T><<<dim3((unsigned)cdiv64(waves, 4)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)x, (const T*)dy, rows, (int)(C / 8), mean_rstd, gamma, (T*)dx, dgamma, dbeta, rpw););
+    DVQ_CHECK_LAUNCH("layernorm_bwd");
+    return DVQ_OK;
+}
+
+int dvq_gelu(const void* x, int dtype, int64_t n, void* y, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && y && n > 0 && n % 8 == 0, DVQ_EINVAL, "dvq_gelu: bad arguments (n %% 8 == 0)");
+    DVQ_DISPATCH_DTYPE(dtype, T, gelu_kernel<T, false><<<dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)x, nullptr, n / 8, (T*)y););
+    DVQ_CHECK_LAUNCH("gelu");
+    return DVQ_OK;
+}
+
+int dvq_gelu_bwd(const void* x, const void* dy, int dtype, int64_t n, void* dx, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && dy && dx && n > 0 && n % 8 == 0, DVQ_EINVAL, "dvq_gelu_bwd: bad arguments (n %% 8 == 0)");
+    DVQ_DISPATCH_DTYPE(dtype, T, gelu_kernel<T, true><<<dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)x, (const T*)dy, n / 8, (T*)dx););
+    DVQ_CHECK_LAUNCH("gelu_bwd");
+    return DVQ_OK;
+}
+
+int dvq_softmax_causal(const void* s, int dtype, int64_t rows, int64_t L, int64_t Tq, int64_t offset, float scale, void* p,
+                       dvq_stream_t stream) {
+    DVQ_REQUIRE(s && p && rows > 0 && L > 0 && Tq > 0 && offset >= 0, DVQ_EINVAL, "dvq_softmax_causal: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T, softmax_causal_kernel<T><<<dim3(nblk(rows, 4, 1 << 16)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)s, rows, L, Tq, (int)offset, scale, (T*)p););
+    DVQ_CHECK_LAUNCH("softmax_causal");
+    return DVQ_OK;
+}
+
+int dvq_embed_gather(const int64_t* idx, int64_t idx_bstride, const float* table, int dtype, int64_t B, int64_t len, int64_t Ttot,
+                     int64_t t0, int64_t C, int accumulate, void* out, dvq_stream_t stream) {
+    DVQ_REQUIRE(idx && table && out && B > 0 && len > 0 && t0 >= 0 && t0 + len <= Ttot && C > 0 && C % 8 == 0, DVQ_EINVAL,
+                "dvq_embed_gather: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T, embed_gather_kernel<T><<<dim3(nblk(B * len * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     idx, table, B, len, Ttot, t0, (int)(C / 8), accumulate, idx_bstride, (T*)out););
+    DVQ_CHECK_LAUNCH("embed_gather");
+    return DVQ_OK;
+}
+
+int dvq_embed_scatter_add(const int64_t* idx, int64_t idx_bstride, const void* dout, int dtype, int64_t B, int64_t len, int64_t Ttot,
+                          int64_t t0, int64_t C, int64_t padding_idx, float* dtable, dvq_stream_t stream) {
+    DVQ_REQUIRE(idx && dout && dtable && B > 0 && len > 0 && t0 >= 0 && t0 + len <= Ttot && C > 0 && C % 8 == 0, DVQ_EINVAL,
+                "dvq_embed_scatter_add: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T, embed_scatter_kernel<T><<<dim3(nblk(B * len * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     idx, (const T*)dout, B, len, Ttot, t0, (int)(C / 8), padding_idx, idx_bstride, dtable););
+    DVQ_CHECK_LAUNCH("embed_scatter_add");
+    return DVQ_OK;
+}
+
+int dvq_cross_entropy(const void* logits, int dtype, int64_t rows, int64_t V, int64_t ldl, const int64_t* target, int64_t ignore_index,
+                      float* loss_sum, float* count, const float* gscale_dev, void* dlogits, dvq_stream_t stream) {
+    DVQ_REQUIRE(logits && target && loss_sum && count && rows > 0 && V > 0 && ldl >= V && (dlogits == nullptr || gscale_dev != nullptr),
+                DVQ_EINVAL, "dvq_cross_entropy: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T, cross_entropy_kernel<T><<<dim3(nblk(rows, 4, 1 << 14)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)logits, rows, (int)V, (int)ldl, target, ignore_index, loss_sum, count, gscale_dev,
+                                     (T*)dlogits););
+    DVQ_CHECK_LAUNCH("cross_entropy");
+    return DVQ_OK;
+}
+
+int dvq_dropout(const void* x, int dtype, int64_t n, float p, uint64_t seed, void* y, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && y && n > 0 && n % 8 == 0 && p >= 0.f && p < 1.f, DVQ_EINVAL, "dvq_dropout: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, T, dropout_kernel<T><<<dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)x, n / 8, p, (unsigned long long)seed, (T*)y););
+    DVQ_CHECK_LAUNCH("dropout");
+    return DVQ_OK;
+}
+
+}  // extern "C"

@@ -632,3 +632,75 @@ def grain_merge_bwd(g_out, heads, idx, scale=None, want_dscale=False):
     check(lib().dvq_grain_merge_bwd(_p(g_out), _ptr_array(heads), len(heads), _p(idx), _p(scale), dt(g_out), n, hc, wc, c,
                                     _ptr_array(dheads), _p(dscale), _s()), "dvq_grain_merge_bwd")
     return dheads, dscale
+
+
+# ---------------------------------------------------------------------------------------------
+# StackGPT building blocks
+# ---------------------------------------------------------------------------------------------
+def layernorm_fwd(x2d, gamma, beta, eps=1e-5, want_stats=True):
+    rows, c = x2d.shape
+    y = torch.empty_like(x2d)
+    mr = torch.empty(rows, 2, dtype=torch.float32, device=x2d.device) if want_stats else None
+    check(lib().dvq_layernorm_fwd(_p(x2d), dt(x2d), rows, c, eps, _p(gamma), _p(beta), _p(y), _p(mr), _s()), "dvq_layernorm_fwd")
+    return y, mr
+
+
+def layernorm_bwd(x2d, dy, mr, gamma, dgamma, dbeta):
+    rows, c = x2d.shape
+    dx = torch.empty_like(x2d)
+    check(lib().dvq_layernorm_bwd(_p(x2d), _p(dy), dt(x2d), rows, c, _p(mr), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _s()),
+          "dvq_layernorm_bwd")
+    return dx
+
+
+def gelu(x):
+    y = torch.empty_like(x)
+    check(lib().dvq_gelu(_p(x), dt(x), x.numel(), _p(y), _s()), "dvq_gelu")
+    return y
+
+
+def gelu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    check(lib().dvq_gelu_bwd(_p(x), _p(dy), dt(x), x.numel(), _p(dx), _s()), "dvq_gelu_bwd")
+    return dx
+
+
+def softmax_causal_(s, rows, length, tq, offset, scale):
+    """in place: s <- softmax(scale * s) with the causal mask (row r sees columns <= r % tq + offset)"""
+    check(lib().dvq_softmax_causal(_p(s), dt(s), rows, length, tq, offset, scale, _p(s), _s()), "dvq_softmax_causal")
+    return s
+
+
+def embed_gather(idx, table, out, t0, accumulate, bstride=None):
+    """out[b, t0:t0+len] (+)= table[idx[b]] ; idx int64 [B,len] (or [len] with bstride=0)"""
+    b, ttot, c = out.shape
+    ln = idx.shape[-1]
+    bs = ln if bstride is None else bstride
+    check(lib().dvq_embed_gather(_p(idx), bs, _p(table), dt(out), b, ln, ttot, t0, c, int(accumulate), _p(out), _s()),
+          "dvq_embed_gather")
+
+
+def embed_scatter_add(idx, dout, dtable, t0, padding_idx=-1, bstride=None):
+    b, ttot, c = dout.shape
+    ln = idx.shape[-1]
+    bs = ln if bstride is None else bstride
+    check(lib().dvq_embed_scatter_add(_p(idx), bs, _p(dout), dt(dout), b, ln, ttot, t0, c, padding_idx, _p(dtable), _s()),
+          "dvq_embed_scatter_add")
+
+
+def cross_entropy(logits2d, v, target, ignore_index, loss_sum, count, gscale=None, want_grad=False):
+    rows, ldl = logits2d.shape
+    dl = torch.empty_like(logits2d) if want_grad else None
+    check(lib().dvq_cross_entropy(_p(logits2d), dt(logits2d), rows, v, ldl, _p(target), ignore_index, _p(loss_sum), _p(count),
+                                  _p(gscale), _p(dl), _s()), "dvq_cross_entropy")
+    return dl
+
+
+def dropout(x, p, seed):
+    y = torch.empty_like(x)
+    check(lib().dvq_dropout(_p(x), dt(x), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(y), _s()), "dvq_dropout")
+    return y
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    check(lib().dvq_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, _s()), "dvq_adamw")

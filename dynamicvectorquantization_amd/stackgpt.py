@@ -1,0 +1,358 @@
+"""StackGPT (stacked position / content transformers of the DQ-Transformer) on libdvq_hip kernels.
+
+Mirrors /root/reference/modules/dynamic_modules/stackgpt.py:7-339: same constructor arguments, parameter / buffer names
+(`content_emb.weight`, `pos_emb`, `position_transformer.3.attn.key.weight`, `content_head.1.weight`, ...) and
+forward() contract (training: dict of the four losses; otherwise the two logit tensors).
+
+Execution: activations are [B*T, C] row matrices in the runtime compute dtype; T is padded to a multiple of 8 inside (the
+padded tail sits behind the causal mask and its targets are the ignore index, so results are unaffected) so every GEMM is
+MFMA-aligned.  Per block: LayerNorm kernels, q/k/v/proj/MLP on the GEMM kernels, attention as per-head strided batched
+GEMMs (QK^T -> causal softmax kernel -> PV), GELU / dropout kernels.  The whole model is ONE autograd node whose backward
+walks the tapes (gradients accumulate in place into .grad / the flat optimizer buffers).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from . import runtime as rt
+from .layers import Linear, Tape, _child, _grad_buf
+
+
+class StackGPTConfig:
+    embd_pdrop = 0.1
+    resid_pdrop = 0.1
+    attn_pdrop = 0.1
+
+    def __init__(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+
+_seed_counter = [0]
+
+
+def _next_seed():
+    _seed_counter[0] += 1
+    return (torch.initial_seed() * 1000003 + _seed_counter[0]) & 0x7FFFFFFFFFFFFFFF
+
+
+def _drop(x, p, training, tape, key):
+    if not training or p <= 0.0:
+        return x
+    seed = _next_seed()
+    if tape is not None:
+        tape.s[key] = (p, seed)
+    return K.dropout(x, p, seed)
+
+
+def _drop_bwd(g, tape, key):
+    ps = tape.s.get(key)
+    return g if ps is None else K.dropout(g, ps[0], ps[1])
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, n, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(n))
+        self.bias = nn.Parameter(torch.zeros(n))
+
+    def fwd(self, x2d, tape):
+        y, mr = K.layernorm_fwd(x2d, self.weight, self.bias, self.eps, want_stats=tape is not None)
+        if tape is not None:
+            tape.s.update(x=x2d, mr=mr)
+        return y
+
+    def bwd(self, dy, tape):
+        return K.layernorm_bwd(tape.s["x"], dy, tape.s["mr"], self.weight, _grad_buf(self.weight), _grad_buf(self.bias))
+
+
+class CausalSelfAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        assert config.n_embd % config.n_head == 0
+        self.key = Linear(config.n_embd, config.n_embd)
+        self.query = Linear(config.n_embd, config.n_embd)
+        self.value = Linear(config.n_embd, config.n_embd)
+        self.attn_drop = nn.Dropout(config.attn_pdrop)
+        self.resid_drop = nn.Dropout(config.resid_pdrop)
+        self.proj = Linear(config.n_embd, config.n_embd)
+        mask = torch.tril(torch.ones(config.block_size, config.block_size))
+        if hasattr(config, "n_unmasked"):
+            mask[:config.n_unmasked, :config.n_unmasked] = 1
+        self.register_buffer("mask", mask.view(1, 1, config.block_size, config.block_size))     # state_dict parity only
+        self.n_head = config.n_head
+
+    def fwd(self, x2d, b, t, tape):
+        c = x2d.shape[1]
+        nh, hs = self.n_head, c // self.n_head
+        k = self.key.fwd(x2d, _child(tape, "k"))
+        q = self.query.fwd(x2d, _child(tape, "q"))
+        v = self.value.fwd(x2d, _child(tape, "v"))
+        s = torch.empty(b * nh * t * t, dtype=x2d.dtype, device=x2d.device)
+        qf, kf = q.reshape(-1), k.reshape(-1)
+        for h in range(nh):
+            K.gemm_nt(qf[h * hs:], kf[h * hs:], t, t, hs, c, c, t, batch=b, sa=t * c, sb=t * c, sc=nh * t * t, out=s[h * t * t:])
+        p = K.softmax_causal_(s, b * nh * t, t, t, 0, 1.0 / math.sqrt(hs))
+        pd = _drop(p, self.attn_drop.p, self.training, tape, "adrop")
+        vt = K.transpose(v, b, t, c).reshape(-1)                                  # [B, C, T]
+        y = torch.empty(b * t, c, dtype=x2d.dtype, device=x2d.device)
+        yf = y.reshape(-1)
+        for h in range(nh):
+            K.gemm_nt(pd[h * t * t:], vt[h * hs * t:], t, hs, t, t, t, c, batch=b, sa=nh * t * t, sb=c * t, sc=t * c, out=yf[h * hs:])
+        out = self.proj.fwd(y, _child(tape, "proj"))
+        out = _drop(out, self.resid_drop.p, self.training, tape, "rdrop")
+        if tape is not None:
+            tape.s.update(q=q, k=k, v=v, p=p, pd=pd, b=b, t=t)
+        return out
+
+    def bwd(self, dout, tape):
+        s_ = tape.s
+        q, k, v, p, pd, b, t = s_["q"], s_["k"], s_["v"], s_["p"], s_["pd"], s_["b"], s_["t"]
+        c = q.shape[1]
+        nh, hs = self.n_head, c // self.n_head
+        dout = _drop_bwd(dout, tape, "rdrop")
+        dy = self.proj.bwd(dout, tape.child("proj"))
+        dyf, vf, qf = dy.reshape(-1), v.reshape(-1), q.reshape(-1)
+        dp = torch.empty_like(p)
+        dv32 = torch.zeros(b * t * c, dtype=torch.float32, device=dy.device)
+        for h in range(nh):
+            K.gemm_nt(dyf[h * hs:], vf[h * hs:], t, t, hs, c, c, t, batch=b, sa=t * c, sb=t * c, sc=nh * t * t, out=dp[h * t * t:])
+            K.gemm_tn(pd[h * t * t:], dyf[h * hs:], t, t, hs, t, c, c, batch=b, sa=nh * t * t, sb=t * c, sc=t * c, out=dv32[h * hs:])
+        dp = _drop_bwd(dp, tape, "adrop")
+        ds = K.softmax_rows_bwd(p, dp, b * nh * t, t, 1.0 / math.sqrt(hs))
+        kt = K.transpose(k, b, t, c).reshape(-1)
+        dq = torch.empty(b * t, c, dtype=dy.dtype, device=dy.device)
+        dqf = dq.reshape(-1)
+        dk32 = torch.zeros(b * t * c, dtype=torch.float32, device=dy.device)
+        for h in range(nh):
+            K.gemm_nt(ds[h * t * t:], kt[h * hs * t:], t, hs, t, t, t, c, batch=b, sa=nh * t * t, sb=c * t, sc=t * c, out=dqf[h * hs:])
+            K.gemm_tn(ds[h * t * t:], qf[h * hs:], t, t, hs, t, c, c, batch=b, sa=nh * t * t, sb=t * c, sc=t * c, out=dk32[h * hs:])
+        dx = self.query.bwd(dq, tape.child("q"))
+        dx = K.add(dx, self.key.bwd(K.cast(dk32.view(b * t, c), dy.dtype), tape.child("k")))
+        dx = K.add(dx, self.value.bwd(K.cast(dv32.view(b * t, c), dy.dtype), tape.child("v")))
+        return dx
+
+
+class Block(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.ln1 = LayerNorm(config.n_embd)
+        self.ln2 = LayerNorm(config.n_embd)
+        self.attn = CausalSelfAttention(config)
+        self.mlp = nn.Sequential(Linear(config.n_embd, 4 * config.n_embd), nn.GELU(), Linear(4 * config.n_embd, config.n_embd),
+                                 nn.Dropout(config.resid_pdrop))
+
+    def fwd(self, x, b, t, tape):
+        a = self.attn.fwd(self.ln1.fwd(x, _child(tape, "ln1")), b, t, _child(tape, "attn"))
+        x1 = K.add(x, a)
+        hid = self.mlp[0].fwd(self.ln2.fwd(x1, _child(tape, "ln2")), _child(tape, "fc1"))
+        m = self.mlp[2].fwd(K.gelu(hid), _child(tape, "fc2"))
+        m = _drop(m, self.mlp[3].p, self.training, tape, "mdrop")
+        if tape is not None:
+            tape.s["hid"] = hid
+        return K.add(x1, m)
+
+    def bwd(self, d, tape):
+        dm = _drop_bwd(d, tape, "mdrop")
+        dact = self.mlp[2].bwd(dm, tape.child("fc2"))
+        dh2 = self.mlp[0].bwd(K.gelu_bwd(tape.s["hid"], dact), tape.child("fc1"))
+        dx1 = K.add(d, self.ln2.bwd(dh2, tape.child("ln2")))
+        dh1 = self.attn.bwd(dx1, tape.child("attn"))
+        return K.add(dx1, self.ln1.bwd(dh1, tape.child("ln1")))
+
+
+class _Embedding(nn.Embedding):
+    """nn.Embedding parameters (incl. padding_idx bookkeeping for state_dict / init parity); lookups run on dvq_embed_*"""
+
+
+class StackGPT(nn.Module):
+    def __init__(self, vocab_size, coarse_position_size, fine_position_size, segment_size=-1, block_size=None, position_layer=12,
+                 content_layer=12, n_head=8, n_embd=256, embd_pdrop=0., resid_pdrop=0., attn_pdrop=0., content_pad_code=1025,
+                 coarse_position_pad_code=257, fine_position_pad_code=1025, activate_pad_ignore=True):
+        super().__init__()
+        config = StackGPTConfig(vocab_size=vocab_size, coarse_position_size=coarse_position_size, fine_position_size=fine_position_size,
+                                block_size=block_size, embd_pdrop=embd_pdrop, resid_pdrop=resid_pdrop, attn_pdrop=attn_pdrop,
+                                position_layer=position_layer, content_layer=content_layer, n_head=n_head, n_embd=n_embd, n_unmasked=0)
+        self.activate_segment = segment_size > 0
+        self.activate_pad_ignore = activate_pad_ignore
+        self.coarse_position_pad_code, self.fine_position_pad_code = coarse_position_pad_code, fine_position_pad_code
+        self.content_pad_code = content_pad_code
+        self.block_size = config.block_size
+        self.config = config
+        self.content_coarse_pos_emb = _Embedding(coarse_position_size, n_embd, padding_idx=coarse_position_pad_code)
+        self.content_fine_pos_emb = _Embedding(fine_position_size, n_embd, padding_idx=fine_position_pad_code)
+        self.content_emb = _Embedding(vocab_size, n_embd, padding_idx=content_pad_code)
+        self.pos_emb = nn.Parameter(torch.zeros(1, config.block_size, n_embd))
+        if self.activate_segment:
+            self.seg_emb = _Embedding(segment_size, n_embd)
+        self.drop = nn.Dropout(embd_pdrop)
+        self.position_transformer = nn.Sequential(*[Block(config) for _ in range(position_layer)])
+        self.content_transformer = nn.Sequential(*[Block(config) for _ in range(content_layer)])
+        self.position_head = nn.Sequential(LayerNorm(n_embd), Linear(n_embd, fine_position_size, bias=False))
+        self.content_head = nn.Sequential(LayerNorm(n_embd), Linear(n_embd, vocab_size, bias=False))
+        self.apply(self._init_weights)
+
+    def get_block_size(self):
+        return self.block_size
+
+    def _init_weights(self, module):
+        if isinstance(module, (Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=0.02)
+            if isinstance(module, Linear) and module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+
+    # ---- shared pieces -------------------------------------------------------------------------------------------
+    def _pad_t(self, t):
+        return -(-t // 8) * 8
+
+    def _embed(self, pieces, b, t_pad, tape, key):
+        """pieces: list of (table parameter, idx [B,len] or [len], t0, padding_idx, shared_over_batch); -> [B,t_pad,C] sum"""
+        cd = rt.compute_dtype()
+        c = self.config.n_embd
+        out = torch.zeros(b, t_pad, c, dtype=cd, device=self.pos_emb.device)
+        for table, idx, t0, pad, shared in pieces:
+            K.embed_gather(idx, table.detach().reshape(-1, c), out, t0, True, bstride=0 if shared else None)
+        if tape is not None:
+            tape.s[key] = pieces
+        return out
+
+    def _embed_bwd(self, g3d, tape, key):
+        c = self.config.n_embd
+        for table, idx, t0, pad, shared in tape.s[key]:
+            K.embed_scatter_add(idx, g3d, _grad_buf(table).view(-1, c), t0, padding_idx=-1 if pad is None else pad,
+                                bstride=0 if shared else None)
+
+    def _run(self, blocks, x2d, b, t, tape, name):
+        for i, blk in enumerate(blocks):
+            x2d = blk.fwd(x2d, b, t, _child(tape, f"{name}{i}"))
+        return x2d
+
+    def _run_bwd(self, blocks, g, tape, name):
+        for i in reversed(range(len(blocks))):
+            g = blocks[i].bwd(g, tape.child(f"{name}{i}"))
+        return g
+
+    def _head(self, head, x2d, tape, name):
+        return head[1].fwd(head[0].fwd(x2d, _child(tape, name + "ln")), _child(tape, name + "fc"))
+
+    def _head_bwd(self, head, dlogits, tape, name):
+        return head[0].bwd(head[1].bwd(dlogits, tape.child(name + "fc")), tape.child(name + "ln"))
+
+    # ---- training / teacher-forced forward (stackgpt.py:175-232) ----------------------------------------------------
+    def fwd(self, coarse_content, fine_content, coarse_position, fine_position, coarse_seg, fine_seg, tape):
+        """-> (position_logits2d [B*Tp, Vp_pad], content_logits2d [B*Tp, Vc_pad], B, T, T_pad)"""
+        b, lc = coarse_position.shape
+        lf = fine_position.shape[1]
+        t = lc + lf - 1
+        tp = self._pad_t(t)
+        dev = coarse_content.device
+        content = torch.cat([coarse_content, fine_content], dim=1)[:, :-1].contiguous()
+        ar = torch.arange(tp, device=dev)
+        pieces = [(self.content_emb.weight, content, 0, self.content_pad_code, False),
+                  (self.content_coarse_pos_emb.weight, coarse_position.contiguous(), 0, self.coarse_position_pad_code, False),
+                  (self.pos_emb, ar, 0, None, True)]
+        if lf > 1:
+            pieces.append((self.content_fine_pos_emb.weight, fine_position[:, :-1].contiguous(), lc, self.fine_position_pad_code, False))
+        if self.activate_segment:
+            seg = torch.cat([coarse_seg, fine_seg], dim=1)[:, :-1].contiguous()
+            pieces.append((self.seg_emb.weight, seg, 0, None, False))
+        x = self._embed(pieces, b, tp, tape, "emb_in").view(b * tp, -1)
+        x = _drop(x, self.drop.p, self.training, tape, "edrop")
+        pos_hidden = self._run(self.position_transformer, x, b, tp, tape, "p")
+        upd = [(self.content_fine_pos_emb.weight, fine_position.contiguous(), lc - 1, self.fine_position_pad_code, False)]
+        if lc > 1:
+            upd.append((self.content_coarse_pos_emb.weight, coarse_position[:, 1:].contiguous(), 0, self.coarse_position_pad_code, False))
+        cin = K.add(pos_hidden, self._embed(upd, b, tp, tape, "emb_upd").view(b * tp, -1))
+        con_hidden = self._run(self.content_transformer, cin, b, tp, tape, "c")
+        content_logits = self._head(self.content_head, con_hidden, tape, "ch")
+        position_logits = self._head(self.position_head, pos_hidden, tape, "ph")
+        return position_logits, content_logits, b, t, tp
+
+    def bwd(self, d_position_logits, d_content_logits, tape, b, tp):
+        g_con = self._head_bwd(self.content_head, d_content_logits, tape, "ch")
+        g_cin = self._run_bwd(self.content_transformer, g_con, tape, "c")
+        self._embed_bwd(g_cin.view(b, tp, -1), tape, "emb_upd")
+        g_pos = K.add(g_cin, self._head_bwd(self.position_head, d_position_logits, tape, "ph"))
+        g_x = self._run_bwd(self.position_transformer, g_pos, tape, "p")
+        g_x = _drop_bwd(g_x, tape, "edrop")
+        self._embed_bwd(g_x.view(b, tp, -1), tape, "emb_in")
+
+    def forward(self, coarse_content, fine_content, coarse_position, fine_position, coarse_seg, fine_seg, content_target=None,
+                coarse_position_target=None, fine_position_target=None, **ignorekwargs):
+        params = [p for p in self.parameters() if p.requires_grad]
+        with_loss = content_target is not None and coarse_position_target is not None and fine_position_target is not None
+        if not with_loss:
+            with torch.no_grad():
+                pl, cl, b, t, tp = self.fwd(coarse_content, fine_content, coarse_position, fine_position, coarse_seg, fine_seg, None)
+            vp, vc = self.config.fine_position_size, self.config.vocab_size
+            return {"position_logits": pl.view(b, tp, -1)[:, :t, :vp].float(), "content_logits": cl.view(b, tp, -1)[:, :t, :vc].float()}
+        pos, con, cpl, fpl = _StackGPTLossFn.apply(self, torch.is_grad_enabled() and len(params) > 0,
+                                                   (coarse_content, fine_content, coarse_position, fine_position, coarse_seg, fine_seg,
+                                                    content_target, coarse_position_target, fine_position_target), *params)
+        return {"position_loss": pos, "content_loss": con, "coarse_position_loss": cpl, "fine_position_loss": fpl}
+
+    def _targets(self, b, t, tp, lc, content_target, coarse_position_target, fine_position_target, dev):
+        """full-length [B*Tp] target rows per loss; rows a loss does not cover carry that loss's ignore index"""
+        ign_c = self.content_pad_code if self.activate_pad_ignore else -100
+        tc = torch.full((b, tp), ign_c, dtype=torch.long, device=dev)
+        tc[:, :t] = content_target
+        tcp = torch.full((b, tp), self.coarse_position_pad_code, dtype=torch.long, device=dev)
+        tfp = torch.full((b, tp), self.fine_position_pad_code, dtype=torch.long, device=dev)
+        if self.activate_pad_ignore:
+            tcp[:, :lc - 1] = coarse_position_target
+            tfp[:, lc - 1:t] = fine_position_target
+        else:
+            tcp[:, :lc] = coarse_position_target
+            tfp[:, lc:t] = fine_position_target
+        return (tc.view(-1), ign_c), (tcp.view(-1), self.coarse_position_pad_code), (tfp.view(-1), self.fine_position_pad_code)
+
+
+class _StackGPTLossFn(torch.autograd.Function):
+    """teacher-forced forward + the three cross entropies as one autograd node"""
+
+    @staticmethod
+    def forward(ctx, mod, want_grad, inputs, *params):
+        (cc, fc, cp, fp, cs, fs, ct, cpt, fpt) = inputs
+        ctx.mod, ctx.n = mod, len(params)
+        tape = Tape() if want_grad else None
+        with torch.no_grad():
+            pl, cl, b, t, tp = mod.fwd(cc, fc, cp, fp, cs, fs, tape)
+            dev = pl.device
+            tg = mod._targets(b, t, tp, cp.shape[1], ct, cpt, fpt, dev)
+            vp, vc = mod.config.fine_position_size, mod.config.vocab_size
+            acc = torch.zeros(3, 2, dtype=torch.float32, device=dev)         # (loss_sum, count) per loss
+            K.cross_entropy(cl, vc, tg[0][0], tg[0][1], acc[0, 0:1], acc[0, 1:2])
+            K.cross_entropy(pl, vp, tg[1][0], tg[1][1], acc[1, 0:1], acc[1, 1:2])
+            K.cross_entropy(pl, vp, tg[2][0], tg[2][1], acc[2, 0:1], acc[2, 1:2])
+            losses = acc[:, 0] / acc[:, 1]
+            content_loss, coarse_loss, fine_loss = losses[0], losses[1], losses[2]
+            position_loss = (coarse_loss + fine_loss) / 2
+        ctx.state = (tape, pl, cl, tg, acc, b, tp, vp, vc) if want_grad else None
+        return position_loss, content_loss.clone(), coarse_loss.clone(), fine_loss.clone()
+
+    @staticmethod
+    def backward(ctx, g_pos, g_con, g_coarse, g_fine):
+        if ctx.state is None:
+            return (None,) * (3 + ctx.n)
+        tape, pl, cl, tg, acc, b, tp, vp, vc = ctx.state
+        mod = ctx.mod
+        with torch.no_grad():
+            z = torch.zeros((), device=pl.device)
+            g_pos = z if g_pos is None else g_pos
+            gc = ((z if g_con is None else g_con) / acc[0, 1]).float().reshape(1)
+            gcp = ((g_pos * 0.5 + (z if g_coarse is None else g_coarse)) / acc[1, 1]).float().reshape(1)
+            gfp = ((g_pos * 0.5 + (z if g_fine is None else g_fine)) / acc[2, 1]).float().reshape(1)
+            scratch = torch.zeros(2, dtype=torch.float32, device=pl.device)
+            d_cl = K.cross_entropy(cl, vc, tg[0][0], tg[0][1], scratch[0:1], scratch[1:2], gc.contiguous(), True)
+            d_pl = K.cross_entropy(pl, vp, tg[1][0], tg[1][1], scratch[0:1], scratch[1:2], gcp.contiguous(), True)
+            d_pl = K.add(d_pl, K.cross_entropy(pl, vp, tg[2][0], tg[2][1], scratch[0:1], scratch[1:2], gfp.contiguous(), True))
+            mod.bwd(d_pl, d_cl, tape, b, tp)
+        return (None,) * (3 + ctx.n)

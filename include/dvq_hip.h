@@ -303,6 +303,39 @@ int dvq_l1_loss(const float* x, const float* xrec, int64_t n, double* loss_sum, 
 /* fused Adam over one flat fp32 tensor (torch.optim.Adam semantics, no weight decay / amsgrad) */
 int dvq_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
              int step, dvq_stream_t stream);
+/* torch.optim.AdamW (decoupled weight decay: p *= 1 - lr*wd before the Adam update), models/stage2_dynamic/
+ * dqtransformer_uncond_entropy.py:92-128 */
+int dvq_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int step, dvq_stream_t stream);
+
+/* ---- StackGPT building blocks (modules/dynamic_modules/stackgpt.py) ------------------------------------------------- */
+/* nn.LayerNorm(C) over rows [rows, C]; mean_rstd fp32 [rows][2] (optional) is what the backward needs */
+int dvq_layernorm_fwd(const void* x, int dtype, int64_t rows, int64_t C, float eps, const float* gamma, const float* beta, void* y,
+                      float* mean_rstd, dvq_stream_t stream);
+/* dx written; dgamma / dbeta (fp32 [C]) accumulated into */
+int dvq_layernorm_bwd(const void* x, const void* dy, int dtype, int64_t rows, int64_t C, const float* mean_rstd, const float* gamma,
+                      void* dx, float* dgamma, float* dbeta, dvq_stream_t stream);
+/* nn.GELU() (exact erf form) and its backward (x = pre-activation) */
+int dvq_gelu(const void* x, int dtype, int64_t n, void* y, dvq_stream_t stream);
+int dvq_gelu_bwd(const void* x, const void* dy, int dtype, int64_t n, void* dx, dvq_stream_t stream);
+/* softmax(scale * s) over rows of length L with the causal mask of CausalSelfAttention (stackgpt.py:59-63): row r of a
+ * [Tq x L] score matrix (r = row %% Tq) sees columns <= r + offset; masked probabilities are written as 0.
+ * Backward: dvq_softmax_rows_bwd on the result. */
+int dvq_softmax_causal(const void* s, int dtype, int64_t rows, int64_t L, int64_t Tq, int64_t offset, float scale, void* p,
+                       dvq_stream_t stream);
+/* nn.Embedding forward: out[b][t0+j][:] (+)= table[idx[b*idx_bstride + j]][:], j < len; out is [B][Ttot][C] of `dtype`,
+ * table fp32 [V][C].  Backward: dtable[idx] += dout rows, skipping idx == padding_idx (fp32 atomics). */
+int dvq_embed_gather(const int64_t* idx, int64_t idx_bstride, const float* table, int dtype, int64_t B, int64_t len, int64_t Ttot,
+                     int64_t t0, int64_t C, int accumulate, void* out, dvq_stream_t stream);
+int dvq_embed_scatter_add(const int64_t* idx, int64_t idx_bstride, const void* dout, int dtype, int64_t B, int64_t len, int64_t Ttot,
+                          int64_t t0, int64_t C, int64_t padding_idx, float* dtable, dvq_stream_t stream);
+/* F.cross_entropy(logits[:, :V], target, ignore_index) pieces: loss_sum / count (fp32 device scalars, accumulated) and,
+ * when dlogits != NULL, dlogits = (softmax - onehot) * gscale_dev[0] (0 on ignored rows and on columns >= V; row stride ldl) */
+int dvq_cross_entropy(const void* logits, int dtype, int64_t rows, int64_t V, int64_t ldl, const int64_t* target, int64_t ignore_index,
+                      float* loss_sum, float* count, const float* gscale_dev, void* dlogits, dvq_stream_t stream);
+/* nn.Dropout(p) with a counter-based hash RNG: y = x * keep / (1-p); the same (seed) reproduces the mask for the backward */
+int dvq_dropout(const void* x, int dtype, int64_t n, float p, uint64_t seed, void* y, dvq_stream_t stream);
+
 int dvq_fill_f32(float* p, float v, int64_t n, dvq_stream_t stream);
 
 #ifdef __cplusplus

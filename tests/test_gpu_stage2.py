@@ -76,3 +76,68 @@ def test_sos_providers(dev):
     lab = torch.tensor([3, 999], device=dev)
     o = c.encode(lab)
     assert o[0].tolist() == [[1029], [2025]] and o[1].tolist() == [[1029], [2025]] and o[4] is None
+
+
+STACKGPT_CFG = dict(vocab_size=1027, coarse_position_size=259, fine_position_size=1027, segment_size=2, block_size=64,
+                    position_layer=2, content_layer=3, n_head=4, n_embd=64, embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0,
+                    content_pad_code=1024, coarse_position_pad_code=256, fine_position_pad_code=1024, activate_pad_ignore=True)
+
+
+def stackgpt_inputs(seed=3, b=3):
+    """the fixture's ragged teacher-forcing batch (same generator as tools/gen_golden.py)"""
+    rs = np.random.RandomState(seed)
+    n_c, n_f = [6, 9, 3], [16, 8, 20]
+    lc, lf = max(n_c) + 2, max(n_f) + 2
+    cc = np.full((b, lc), 1024, dtype=np.int64); cp = np.full((b, lc), 256, dtype=np.int64)
+    fc = np.full((b, lf), 1024, dtype=np.int64); fp = np.full((b, lf), 1024, dtype=np.int64)
+    for i in range(b):
+        cc[i, 0], cp[i, 0], fc[i, 0], fp[i, 0] = 1026, 258, 1026, 1026
+        cc[i, 1:1 + n_c[i]] = rs.randint(0, 1024, n_c[i]); cc[i, 1 + n_c[i]] = 1025
+        cp[i, 1:1 + n_c[i]] = np.sort(rs.choice(256, n_c[i], replace=False)); cp[i, 1 + n_c[i]] = 257
+        fc[i, 1:1 + n_f[i]] = rs.randint(0, 1024, n_f[i]); fc[i, 1 + n_f[i]] = 1025
+        fp[i, 1:1 + n_f[i]] = np.sort(rs.choice(1024, n_f[i], replace=False)); fp[i, 1 + n_f[i]] = 1025
+    cs, fs = np.zeros_like(cc), np.ones_like(fc)
+    return dict(coarse_content=cc, fine_content=fc, coarse_position=cp, fine_position=fp, coarse_seg=cs, fine_seg=fs,
+                content_target=np.concatenate([cc, fc], 1)[:, 1:], coarse_position_target=cp[:, 1:], fine_position_target=fp)
+
+
+def build_stackgpt(dev):
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    model = instantiate_from_config({"target": "modules.dynamic_modules.stackgpt.StackGPT", "params": STACKGPT_CFG}).to(dev)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            v = synth.det_param("stackgpt." + n, tuple(p.shape))
+            p.copy_(torch.from_numpy(v * (0.3 if n == "pos_emb" else 1.0)).to(dev))
+    return model
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 5e-3), (torch.bfloat16, 2e-2, 8e-2)])
+def test_stackgpt_golden(dev, dtype, tol, gtol):
+    """teacher-forced losses, parameter gradients (incl. embeddings with padding rows) and logits vs the reference StackGPT"""
+    from dynamicvectorquantization_amd import runtime as rt
+    g = load_golden("stackgpt")
+    with rt.compute_dtype_ctx(dtype):
+        model = build_stackgpt(dev).train()
+        own = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        ref = {str(k): tuple(int(x) for x in str(s).split(",")) if str(s) else () for k, s in zip(g["state_keys"], g["state_shapes"])}
+        assert own == ref, set(own) ^ set(ref)
+        inp = {k: torch.from_numpy(v).to(dev) for k, v in stackgpt_inputs().items()}
+        out = model(**inp)
+        for k in ("position_loss", "content_loss", "coarse_position_loss", "fine_position_loss"):
+            np.testing.assert_allclose(float(out[k].detach()), float(g[k]), rtol=tol)
+        (1.0 * out["content_loss"] + 0.7 * out["position_loss"]).backward()
+        params = dict(model.named_parameters())
+        for key in [k for k in g.files if k.startswith("grad.")]:
+            ref_g = g[key].astype(np.float64)
+            got = params[key[5:]].grad.cpu().numpy().astype(np.float64).reshape(ref_g.shape)
+            err = float(np.linalg.norm(got - ref_g)) / max(1e-30, float(np.linalg.norm(ref_g)))
+            assert err < gtol, f"{key}: relative Frobenius error {err}"
+            if key == "grad.content_emb.weight":       # the padding row never receives gradient (nn.Embedding(padding_idx))
+                assert float(np.abs(got[1024]).max()) == 0.0
+        model.eval()
+        lo = model(**{k: v for k, v in inp.items() if not k.endswith("target")})
+        for k in ("position_logits", "content_logits"):
+            assert tuple(lo[k].shape) == g[k].shape
+            ref_l = g[k]
+            assert float(np.abs(lo[k].cpu().numpy() - ref_l).max()) < (2e-3 if dtype == torch.float32 else 6e-2) * float(np.abs(ref_l).max())

@@ -678,9 +678,68 @@ def gen_permuter():
     np.savez_compressed(os.path.join(GOLD, "permuter.npz"), **out)
 
 
+STACKGPT_CFG = dict(vocab_size=1027, coarse_position_size=259, fine_position_size=1027, segment_size=2, block_size=64,
+                    position_layer=2, content_layer=3, n_head=4, n_embd=64, embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0,
+                    content_pad_code=1024, coarse_position_pad_code=256, fine_position_pad_code=1024, activate_pad_ignore=True)
+
+
+def stackgpt_inputs(seed=3, b=3):
+    """ragged teacher-forcing batch shaped like Dualformer.forward builds it (SOS + codes + EOS + PAD)"""
+    rs = np.random.RandomState(seed)
+    n_c, n_f = [6, 9, 3], [16, 8, 20]
+    lc, lf = max(n_c) + 2, max(n_f) + 2
+    cc = np.full((b, lc), 1024, dtype=np.int64); cp = np.full((b, lc), 256, dtype=np.int64)
+    fc = np.full((b, lf), 1024, dtype=np.int64); fp = np.full((b, lf), 1024, dtype=np.int64)
+    for i in range(b):
+        cc[i, 0], cp[i, 0], fc[i, 0], fp[i, 0] = 1026, 258, 1026, 1026
+        cc[i, 1:1 + n_c[i]] = rs.randint(0, 1024, n_c[i]); cc[i, 1 + n_c[i]] = 1025
+        cp[i, 1:1 + n_c[i]] = np.sort(rs.choice(256, n_c[i], replace=False)); cp[i, 1 + n_c[i]] = 257
+        fc[i, 1:1 + n_f[i]] = rs.randint(0, 1024, n_f[i]); fc[i, 1 + n_f[i]] = 1025
+        fp[i, 1:1 + n_f[i]] = np.sort(rs.choice(1024, n_f[i], replace=False)); fp[i, 1 + n_f[i]] = 1025
+    cs, fs = np.zeros_like(cc), np.ones_like(fc)
+    return dict(coarse_content=cc, fine_content=fc, coarse_position=cp, fine_position=fp, coarse_seg=cs, fine_seg=fs,
+                content_target=np.concatenate([cc, fc], 1)[:, 1:], coarse_position_target=cp[:, 1:], fine_position_target=fp)
+
+
+def gen_stackgpt():
+    from modules.dynamic_modules.stackgpt import StackGPT
+    from oracle import stackgpt as osg
+    model = StackGPT(**STACKGPT_CFG).train()
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            v = synth.det_param("stackgpt." + n_, p.shape)
+            p.copy_(t(v * (0.3 if n_ == "pos_emb" else 1.0)))
+    inp = {k: t(v) for k, v in stackgpt_inputs().items()}
+    out = model(**inp)
+    (1.0 * out["content_loss"] + 0.7 * out["position_loss"]).backward()
+    res = {k: np.float32(v.item()) for k, v in out.items()}
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    o = osg.forward(sd, 4, **inp)
+    for k in res:
+        check("stackgpt." + k, o[k].item(), res[k], rtol=1e-5)
+    names = ["content_emb.weight", "content_coarse_pos_emb.weight", "content_fine_pos_emb.weight", "pos_emb", "seg_emb.weight",
+             "position_transformer.0.ln1.weight", "position_transformer.0.attn.key.weight", "position_transformer.1.attn.query.bias",
+             "position_transformer.1.attn.proj.weight", "position_transformer.0.mlp.0.weight", "content_transformer.2.mlp.2.weight",
+             "content_transformer.0.attn.value.weight", "content_transformer.1.ln2.bias", "position_head.0.weight",
+             "position_head.1.weight", "content_head.1.weight"]
+    params = dict(model.named_parameters())
+    for n_ in names:
+        res["grad." + n_] = params[n_].grad.numpy().astype(np.float32)
+    model.eval()
+    with torch.no_grad():
+        lo = model(**{k: v for k, v in inp.items() if not k.endswith("target")})
+    res["position_logits"], res["content_logits"] = lo["position_logits"].numpy(), lo["content_logits"].numpy()
+    check("stackgpt.logits", osg.forward(sd, 4, **{k: v for k, v in inp.items() if not k.endswith("target")})["content_logits"].numpy(),
+          res["content_logits"], rtol=1e-4, atol=1e-5)
+    shapes = {kk: v.shape for kk, v in model.state_dict().items()}
+    res["state_keys"] = np.array(sorted(shapes.keys()))
+    res["state_shapes"] = np.array([",".join(map(str, shapes[kk])) for kk in sorted(shapes.keys())])
+    np.savez_compressed(os.path.join(GOLD, "stackgpt.npz"), **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter")
+    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter,stackgpt")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -688,7 +747,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for name in args.only.split(","):
         print(f"[gen] {name}")
-        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter}[name]()
+        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter, "stackgpt": gen_stackgpt}[name]()
     print("done ->", GOLD)
 
 
