@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from . import kernels as K
 from ._lib import check
+from .config import instantiate_from_config
 from .kernels import lib
 
 
@@ -132,3 +133,164 @@ class ClassAwareSOSProvider(AbstractEncoder):
             const = PositionAwareSOSProvider._const
             return out + (const(b, self.coarse_seg_sos, dev), const(b, self.fine_seg_sos, dev))
         return out + (None, None)
+
+
+def disabled_train(self, mode=True):
+    """models/stage2/utils.py:20-23: the frozen first stage never leaves eval mode"""
+    return self
+
+
+class Dualformer(nn.Module):
+    """models/stage2_dynamic/dqtransformer_uncond_entropy.py:15-234: the stage-2 LightningModule surface without Lightning.
+    A frozen DQ-VAE (HIP path) encodes images to codes + grain map, the permuter kernel turns them into the coarse / fine
+    streams, StackGPT (HIP path) is trained with teacher forcing; AdamW(betas .9/.95) with the reference's decay /
+    no-decay parameter split."""
+
+    def __init__(self, transformer_config, first_stage_config, uncond_stage_config=None, permuter_config=None,
+                 content_loss_weight=1.0, position_loss_weight=1.0, activate_sos_for_fine_sequence=True, weight_decay=0.01,
+                 warmup_epochs=0, monitor=None, ckpt_path=None, ignore_keys=[]):
+        super().__init__()
+        self.first_stage_key, self.cond_stage_key = "image", "image"
+        self.content_loss_weight, self.position_loss_weight = content_loss_weight, position_loss_weight
+        self.init_first_stage_from_ckpt(first_stage_config)
+        self.permuter = instantiate_from_config(config=permuter_config)
+        self.transformer = instantiate_from_config(config=transformer_config)
+        self.cond_stage_model = instantiate_from_config(config=uncond_stage_config)
+        self.weight_decay, self.warmup_epochs = weight_decay, warmup_epochs
+        if monitor is not None:
+            self.monitor = monitor
+        self.activate_sos_for_fine_sequence = activate_sos_for_fine_sequence
+        self.activate_segment = transformer_config["params"]["segment_size"] > 0
+        pp, up = permuter_config["params"], uncond_stage_config["params"]
+        self.content_pad_code, self.content_eos_code = pp["content_pad_code"], pp["content_eos_code"]
+        self.content_sos_code = up["coarse_sos"]
+        self.coarse_position_eos_code, self.coarse_position_pad_code = pp["coarse_position_eos_code"], pp["coarse_position_pad_code"]
+        self.fine_position_sos_code = up["fine_pos_sos"]
+        self.fine_position_eos_code, self.fine_position_pad_code = pp["fine_position_eos_code"], pp["fine_position_pad_code"]
+        self.hw1, self.fine_hw = pp["coarse_hw"], pp["fine_hw"]
+        self.hw2 = self.fine_hw // self.hw1
+        self.fine_position_order = pp["fine_position_order"]
+        self.max_coarse_postion_idx = int(self.hw1 ** 2) - 1
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
+        # trainer-provided state (train.py:243-267)
+        self.learning_rate, self.min_learning_rate = 0.0, 0.0
+        self.training_steps, self.steps_per_epoch, self.max_epoch = 1, 1, 1
+        self.current_epoch, self.global_step = 0, 0
+        self._logged = {}
+
+    def init_from_ckpt(self, path, ignore_keys=list()):
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        for k in list(sd.keys()):
+            for ik in ignore_keys:
+                if k.startswith(ik):
+                    del sd[k]
+        self.load_state_dict(sd, strict=False)
+        print(f"Restored from {path}")
+
+    def init_first_stage_from_ckpt(self, config):
+        model = instantiate_from_config(config).eval()
+        for p in model.parameters():
+            p.requires_grad = False
+        model.train = disabled_train.__get__(model)
+        self.first_stage_model = model
+
+    def log(self, name, value, **kw):
+        self._logged[name] = value
+
+    def configure_optimizers(self):
+        """AdamW groups of dqtransformer_uncond_entropy.py:92-143: Linear weights decay; biases, LayerNorm / Embedding weights
+        and pos_emb do not"""
+        from .layers import Linear
+        from .stackgpt import LayerNorm
+        from .trainer import HipAdam, scheduler_linear_warmup_cosine_decay
+        decay, no_decay = set(), set()
+        for mn, m in self.transformer.named_modules():
+            for pn, _ in m.named_parameters(recurse=False):
+                fpn = f"{mn}.{pn}" if mn else pn
+                if pn.endswith("bias"):
+                    no_decay.add(fpn)
+                elif pn.endswith("weight") and isinstance(m, Linear):
+                    decay.add(fpn)
+                elif pn.endswith("weight") and isinstance(m, (LayerNorm, nn.Embedding)):
+                    no_decay.add(fpn)
+        no_decay.add("pos_emb")
+        param_dict = {pn: p for pn, p in self.transformer.named_parameters()}
+        assert len(decay & no_decay) == 0 and len(param_dict.keys() - (decay | no_decay)) == 0
+        groups = [{"params": [param_dict[pn] for pn in sorted(decay)], "weight_decay": self.weight_decay},
+                  {"params": [param_dict[pn] for pn in sorted(no_decay)], "weight_decay": 0.0}]
+        opt = HipAdam(groups, lr=self.learning_rate, betas=(0.9, 0.95))
+        warmup_steps = self.steps_per_epoch * self.warmup_epochs
+        mmin = self.min_learning_rate / self.learning_rate if self.learning_rate else 0.0
+        fn = scheduler_linear_warmup_cosine_decay(warmup_steps, self.training_steps, mmin)
+        return [opt], [{"scheduler": torch.optim.lr_scheduler.LambdaLR(opt, fn), "interval": "step", "frequency": 1}]
+
+    def get_input(self, batch, k):
+        x = batch[k]
+        if len(x.shape) == 3:
+            x = x[..., None]
+        if x.size(1) != 3 and len(x.shape) == 4:
+            x = x.permute(0, 3, 1, 2).to(memory_format=torch.contiguous_format).float()
+        return x
+
+    def get_xc(self, batch, N=None):
+        x, c = self.get_input(batch, self.first_stage_key), self.get_input(batch, self.cond_stage_key)
+        if N is not None:
+            x, c = x[:N], c[:N]
+        return x, c
+
+    @torch.no_grad()
+    def encode_to_c(self, c):
+        return self.cond_stage_model.encode(c)
+
+    @torch.no_grad()
+    def encode_to_z(self, x):
+        enc = self.first_stage_model.encode(x)
+        quant, info, grain_indices = enc[0], enc[2], enc[3]
+        return quant, self.permuter(indices=info[2], grain_indices=grain_indices)
+
+    @torch.no_grad()
+    def decode_to_img(self, coarse_content, fine_content, coarse_position, fine_position):
+        idx = self.permuter.forward_back(coarse_content, fine_content, coarse_position, fine_position)
+        quant = self.first_stage_model.get_code_emb_with_depth(idx)
+        return self.first_stage_model.decode(quant.permute(0, 3, 1, 2))
+
+    def teacher_forcing_inputs(self, z_out, c):
+        """SOS-prefixed streams and their shifted targets (dqtransformer_uncond_entropy.py:183-207)"""
+        c_coarse, c_fine, c_pos_coarse, c_pos_fine, c_seg_coarse, c_seg_fine = c
+        cc = torch.cat([c_coarse, z_out["coarse_content"]], dim=1)
+        cp = torch.cat([c_pos_coarse, z_out["coarse_position"]], dim=1)
+        cs = torch.cat([c_seg_coarse, z_out["coarse_segment"]], dim=1) if c_seg_coarse is not None else z_out["coarse_segment"]
+        if self.activate_sos_for_fine_sequence:
+            fc = torch.cat([c_fine, z_out["fine_content"]], dim=1)
+            fp = torch.cat([c_pos_fine, z_out["fine_position"]], dim=1)
+            fs = torch.cat([c_seg_fine, z_out["fine_segment"]], dim=1) if c_seg_fine is not None else z_out["fine_segment"]
+        else:
+            fc, fp, fs = z_out["fine_content"], z_out["fine_position"], z_out["fine_segment"]
+        return dict(coarse_content=cc, fine_content=fc, coarse_position=cp, fine_position=fp, coarse_seg=cs, fine_seg=fs,
+                    content_target=torch.cat([cc, fc], dim=1)[:, 1:], coarse_position_target=cp[:, 1:], fine_position_target=fp)
+
+    def forward(self, x, c):
+        _, z_out = self.encode_to_z(x)
+        return self.transformer(**self.teacher_forcing_inputs(z_out, self.encode_to_c(c)))
+
+    def shared_step(self, batch, batch_idx):
+        x, c = self.get_xc(batch)
+        return self(x, c)
+
+    def _step(self, batch, batch_idx, split):
+        out = self.shared_step(batch, batch_idx)
+        total = self.content_loss_weight * out["content_loss"] + self.position_loss_weight * out["position_loss"]
+        self.log(f"{split}_content_loss", out["content_loss"].detach())
+        self.log(f"{split}_position_loss", out["position_loss"].detach())
+        self.log(f"{split}_coarse_position_loss", out["coarse_position_loss"].detach())
+        self.log(f"{split}_fine_position_loss", out["fine_position_loss"].detach())
+        self.log(f"{split}_loss", total.detach())
+        return total
+
+    def training_step(self, batch, batch_idx):
+        return self._step(batch, batch_idx, "train")
+
+    def validation_step(self, batch, batch_idx):
+        with torch.no_grad():
+            return self._step(batch, batch_idx, "val")

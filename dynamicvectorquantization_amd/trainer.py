@@ -92,18 +92,25 @@ class FlatParams:
 
 # ---- optimizer ------------------------------------------------------------------------------------------
 class HipAdam(torch.optim.Optimizer):
-    """torch.optim.Adam semantics (no weight decay / amsgrad).  With `flatten()` (done by the Trainer) the
-    whole parameter set is updated by ONE fused dvq_adam launch; otherwise one launch per tensor."""
+    """torch.optim.Adam / AdamW semantics (no amsgrad; `weight_decay` is decoupled like AdamW, 0 = plain Adam).  With
+    `flatten()` (done by the Trainer) all parameter groups live in ONE flat buffer pair, each group a contiguous segment
+    updated by one fused kernel launch with the group's lr / weight decay; otherwise one launch per tensor."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.flat = None
         self._fstate = None
 
     def flatten(self) -> FlatParams:
-        assert len(self.param_groups) == 1, "flatten() supports a single parameter group"
         if self.flat is None:
-            self.flat = FlatParams(self.param_groups[0]["params"])
+            allp = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+            self.flat = FlatParams(allp)
+            self._segments = []
+            off = 0
+            for g in self.param_groups:
+                n = sum(p.numel() for p in g["params"] if p.requires_grad)
+                self._segments.append((off, n))
+                off += n
             for p in self.flat.params:
                 p._dvq_group = id(self)
             self._fstate = {"step": 0, "m": torch.zeros_like(self.flat.flat_p), "v": torch.zeros_like(self.flat.flat_p)}
@@ -112,11 +119,14 @@ class HipAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         if self.flat is not None:
-            g = self.param_groups[0]
             st = self._fstate
             st["step"] += 1
-            K.adam_step(self.flat.flat_p, self.flat.flat_g, st["m"], st["v"], g["lr"], g["betas"][0], g["betas"][1],
-                        g["eps"], st["step"])
+            for g, (off, n) in zip(self.param_groups, self._segments):
+                if n == 0:
+                    continue
+                sl = slice(off, off + n)
+                K.adamw_step(self.flat.flat_p[sl], self.flat.flat_g[sl], st["m"][sl], st["v"][sl], g["lr"], g["betas"][0],
+                             g["betas"][1], g["eps"], g.get("weight_decay", 0.0), st["step"])
             rt.bump_group_epoch(id(self))      # only this optimizer's packed weights are stale
             return
         for group in self.param_groups:
@@ -130,7 +140,8 @@ class HipAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
-                K.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"], st["step"])
+                K.adamw_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
+                             group.get("weight_decay", 0.0), st["step"])
         rt.bump_weights_epoch()
 
 
@@ -180,6 +191,9 @@ class Trainer:
         self.model, self.max_steps, self.log_every = model, max_steps, log_every
         self.opts, self.scheds = model.configure_optimizers()
         self.buckets = [GradBuckets(o.flatten()) for o in self.opts]
+        import inspect
+        # Lightning passes optimizer_idx only to modules that declare it (two-optimizer stage 1); stage 2 has one optimizer
+        self._takes_opt_idx = "optimizer_idx" in inspect.signature(model.training_step).parameters
 
     def train_step(self, batch, batch_idx):
         m = self.model
@@ -187,7 +201,7 @@ class Trainer:
         K.arena_reset(self.buckets[0].fp.flat_g.device)
         for oi, opt in enumerate(self.opts):
             self.buckets[oi].zero()
-            loss = m.training_step(batch, batch_idx, oi)
+            loss = m.training_step(batch, batch_idx, oi) if self._takes_opt_idx else m.training_step(batch, batch_idx)
             if loss.requires_grad:
                 loss.backward()
             works = self.buckets[oi].reduce()
