@@ -299,6 +299,87 @@ class StackGPT(nn.Module):
                                                     content_target, coarse_position_target, fine_position_target), *params)
         return {"position_loss": pos, "content_loss": con, "coarse_position_loss": cpl, "fine_position_loss": fpl}
 
+    # ---- prefix passes used by the sampler (stackgpt.py:234-339): forward only, no cache (the reference recomputes the
+    # whole prefix at every step; so does this first version -- see DESIGN.md "next") ----------------------------------
+    def _prefix_hidden(self, content, pos_pieces, seg, drop):
+        """content [B,T]; pos_pieces: list of (table, idx [B,len], t0, pad); seg [B,T] or None -> position_hidden [B*Tp, C]"""
+        b, t = content.shape
+        tp = self._pad_t(t)
+        ar = torch.arange(tp, device=content.device)
+        pieces = [(self.content_emb.weight, content.contiguous(), 0, self.content_pad_code, False), (self.pos_emb, ar, 0, None, True)]
+        pieces += [(tb, ix.contiguous(), t0, pad, False) for tb, ix, t0, pad in pos_pieces if ix.shape[1] > 0]
+        if self.activate_segment and seg is not None:
+            pieces.append((self.seg_emb.weight, seg.contiguous(), 0, None, False))
+        x = self._embed(pieces, b, tp, None, "").view(b * tp, -1)
+        if drop:
+            x = _drop(x, self.drop.p, self.training, None, "")
+        return self._run(self.position_transformer, x, b, tp, None, "p"), b, t, tp
+
+    def _content_from_hidden(self, hidden2d, upd_pieces, b, t, tp):
+        upd = self._embed([(tb, ix.contiguous(), t0, pad, False) for tb, ix, t0, pad in upd_pieces if ix.shape[1] > 0], b, tp, None, "")
+        ch = self._run(self.content_transformer, K.add(hidden2d, upd.view(b * tp, -1)), b, tp, None, "c")
+        logits = self._head(self.content_head, ch, None, "ch").view(b, tp, -1)[:, :t, : self.config.vocab_size].float()
+        return ch.view(b, tp, -1)[:, :t], logits
+
+    def _as2d(self, hidden, b, t, tp):
+        """a hidden state handed back by the caller ([B,T,C]) -> padded [B*Tp, C]"""
+        if tp == t:
+            return hidden.reshape(b * t, -1).contiguous()
+        out = torch.zeros(b, tp, hidden.shape[-1], dtype=hidden.dtype, device=hidden.device)
+        out[:, :t] = hidden
+        return out.view(b * tp, -1)
+
+    @torch.no_grad()
+    def sample_coarse_position(self, coarse_content, coarse_position, coarse_seg):
+        cpe, pad = self.content_coarse_pos_emb.weight, self.coarse_position_pad_code
+        h, b, t, tp = self._prefix_hidden(coarse_content, [(cpe, coarse_position, 0, pad)], coarse_seg, drop=False)
+        logits = self._head(self.position_head, h, None, "ph").view(b, tp, -1)[:, :t, : self.config.fine_position_size].float()
+        return h.view(b, tp, -1)[:, :t], logits
+
+    @torch.no_grad()
+    def sample_coarse_content(self, coarse_content=None, coarse_position=None, coarse_seg=None, position_hidden=None):
+        cpe, pad = self.content_coarse_pos_emb.weight, self.coarse_position_pad_code
+        if position_hidden is None:
+            seg = coarse_seg[:, :-1] if coarse_seg is not None else None
+            h, b, t, tp = self._prefix_hidden(coarse_content, [(cpe, coarse_position[:, :-1], 0, pad)], seg, drop=False)
+        else:
+            b, t = position_hidden.shape[0], position_hidden.shape[1]
+            tp = self._pad_t(t)
+            h = self._as2d(position_hidden, b, t, tp)
+        return self._content_from_hidden(h, [(cpe, coarse_position[:, 1:], 0, pad)], b, t, tp)
+
+    @torch.no_grad()
+    def sample_fine_position(self, coarse_content, fine_content, coarse_position, fine_position, coarse_seg, fine_seg):
+        lc = coarse_position.shape[1]
+        content = torch.cat([coarse_content, fine_content], dim=1)
+        seg = None
+        if self.activate_segment:
+            seg = torch.cat([coarse_seg, fine_seg], dim=1) if fine_seg is not None else coarse_seg
+        h, b, t, tp = self._prefix_hidden(content, [(self.content_coarse_pos_emb.weight, coarse_position, 0, self.coarse_position_pad_code),
+                                                    (self.content_fine_pos_emb.weight, fine_position, lc, self.fine_position_pad_code)],
+                                          seg, drop=True)
+        logits = self._head(self.position_head, h, None, "ph").view(b, tp, -1)[:, :t, : self.config.fine_position_size].float()
+        return h.view(b, tp, -1)[:, :t], logits
+
+    @torch.no_grad()
+    def sample_fine_content(self, coarse_content, fine_content, coarse_position, fine_position, coarse_seg, fine_seg,
+                            position_hidden=None):
+        lc = coarse_position.shape[1]
+        cpe, fpe = self.content_coarse_pos_emb.weight, self.content_fine_pos_emb.weight
+        if position_hidden is None:
+            content = torch.cat([coarse_content, fine_content], dim=1)
+            seg = None
+            if self.activate_segment:
+                seg = torch.cat([coarse_seg, fine_seg], dim=1) if fine_seg is not None else coarse_seg
+            h, b, t, tp = self._prefix_hidden(content, [(cpe, coarse_position, 0, self.coarse_position_pad_code),
+                                                        (fpe, fine_position[:, :-1], lc, self.fine_position_pad_code)], seg, drop=True)
+        else:
+            b, t = position_hidden.shape[0], position_hidden.shape[1]
+            tp = self._pad_t(t)
+            h = self._as2d(position_hidden, b, t, tp)
+        return self._content_from_hidden(h, [(cpe, coarse_position, 0, self.coarse_position_pad_code),
+                                             (fpe, fine_position[:, 1:], lc, self.fine_position_pad_code)], b, t, tp)
+
     def _targets(self, b, t, tp, lc, content_target, coarse_position_target, fine_position_target, dev):
         """full-length [B*Tp] target rows per loss; rows a loss does not cover carry that loss's ignore index"""
         ign_c = self.content_pad_code if self.activate_pad_ignore else -100

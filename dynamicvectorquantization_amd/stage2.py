@@ -135,12 +135,16 @@ class ClassAwareSOSProvider(AbstractEncoder):
         return out + (None, None)
 
 
+class _SamplerMixinBase:
+    """filled in below (_SamplerMixin): the sampler's methods are attached to Dualformer after both are defined"""
+
+
 def disabled_train(self, mode=True):
     """models/stage2/utils.py:20-23: the frozen first stage never leaves eval mode"""
     return self
 
 
-class Dualformer(nn.Module):
+class Dualformer(_SamplerMixinBase, nn.Module):
     """models/stage2_dynamic/dqtransformer_uncond_entropy.py:15-234: the stage-2 LightningModule surface without Lightning.
     A frozen DQ-VAE (HIP path) encodes images to codes + grain map, the permuter kernel turns them into the coarse / fine
     streams, StackGPT (HIP path) is trained with teacher forcing; AdamW(betas .9/.95) with the reference's decay /
@@ -294,3 +298,157 @@ class Dualformer(nn.Module):
     def validation_step(self, batch, batch_idx):
         with torch.no_grad():
             return self._step(batch, batch_idx, "val")
+
+
+# ---- sampling (dqtransformer_uncond_entropy.py:302-561, models/stage2/utils.py:22-40) ---------------------------------------
+def top_k_logits(logits, k):
+    v, _ = torch.topk(logits, k)
+    out = logits.clone()
+    out[out < v[..., [-1]]] = -float("Inf")
+    return out
+
+
+def top_p_logits(probs, p):
+    sorted_probs, sorted_indices = torch.sort(probs, dim=-1, descending=True)
+    remove = torch.cumsum(sorted_probs, dim=-1) >= p
+    remove[..., 1:] = remove[..., :-1].clone()
+    remove[..., 0] = 0
+    probs = probs.masked_fill(remove.scatter(-1, sorted_indices, remove), 0.0)
+    return probs / torch.sum(probs, dim=-1, keepdim=True)
+
+
+def _mask_rows(logits, finished, forbid, keep_code, pad_code):
+    """unfinished rows: -inf where `forbid`, except `keep_code` which keeps its logit; finished rows: only `pad_code` survives"""
+    neg = torch.full_like(logits, -float("Inf"))
+    out = torch.where(forbid, neg, logits)
+    if keep_code is not None:
+        out[:, keep_code] = logits[:, keep_code]
+    only_pad = neg.clone()
+    only_pad[:, pad_code] = logits[:, pad_code]
+    return torch.where(finished.bool().view(-1, 1), only_pad, out)
+
+
+class _SamplerMixin:
+    """the constrained ancestral sampler of Dualformer, batched over rows (no per-sample Python loops)"""
+
+    def avoid_repeat_or_enforce_pad_for_coarse_position(self, logits, sampled_position, flag):
+        forbid = torch.zeros_like(logits, dtype=torch.bool)
+        forbid.scatter_(1, sampled_position, True)                      # <sos> and the coarse positions already drawn
+        forbid[:, self.coarse_position_pad_code] = True
+        forbid[:, self.max_coarse_postion_idx:] = True                 # the reference forbids index hw1^2 - 1 as well
+        return _mask_rows(logits, flag, forbid, self.coarse_position_eos_code, self.coarse_position_pad_code)
+
+    def avoid_repeat_or_enforce_pad_for_fine_position(self, logits, sampled_position, flag):
+        forbid = torch.zeros_like(logits, dtype=torch.bool)
+        forbid.scatter_(1, sampled_position, True)
+        forbid[:, self.fine_position_pad_code] = True
+        out = _mask_rows(logits, flag, forbid, self.fine_position_eos_code, self.fine_position_pad_code)
+        live = ~flag.bool().view(-1)
+        out[live, self.fine_position_sos_code] = -float("Inf")         # applied after <eos> was restored (reference order)
+        return out
+
+    def avoid_special_or_enforce_pad_for_content(self, logits, flag):
+        forbid = torch.zeros_like(logits, dtype=torch.bool)
+        for code in (self.content_pad_code, self.content_eos_code, self.content_sos_code):
+            forbid[:, code] = True
+        return _mask_rows(logits, flag, forbid, None, self.content_pad_code)
+
+    def _coarse_cells_drawn(self, coarse_position):
+        """[B, hw1, hw1] int64: 1 where a coarse position was sampled before the row's <eos> (column 0 is <sos>)"""
+        pos = coarse_position[:, 1:]
+        alive = torch.cumsum((pos == self.coarse_position_eos_code).long(), dim=1) == 0
+        n = self.hw1 * self.hw1
+        drawn = torch.zeros(pos.shape[0], n + 1, dtype=torch.long, device=pos.device)
+        drawn.scatter_(1, torch.where(alive, pos.clamp(0, n - 1), torch.full_like(pos, n)), 1)
+        return drawn[:, :n].reshape(-1, self.hw1, self.hw1)
+
+    def _fine_positions_of(self, cell_flags):
+        """fine-position stream (<eos>-terminated, padded) of the cells flagged 1, in the permuter's fine order"""
+        dummy = torch.zeros(cell_flags.shape[0], self.fine_hw, self.fine_hw, dtype=torch.long, device=cell_flags.device)
+        fp = self.permuter(indices=dummy, grain_indices=cell_flags)["fine_position"]
+        if self.activate_sos_for_fine_sequence:
+            sos = torch.full((fp.shape[0], 1), self.fine_position_sos_code, dtype=torch.long, device=fp.device)
+            fp = torch.cat([sos, fp], dim=1)
+        return fp
+
+    def transfer_sampled_coarse_position_to_sampled_fine_position(self, coarse_position):
+        return self._fine_positions_of(self._coarse_cells_drawn(coarse_position))
+
+    def transfer_sampled_coarse_position_to_remain_fine_position(self, coarse_position):
+        return self._fine_positions_of(1 - self._coarse_cells_drawn(coarse_position))
+
+    @staticmethod
+    def _draw(logits, temperature, sample, k, p, constrain):
+        logits = constrain(logits[:, -1, :] / temperature)
+        if k is not None:
+            logits = top_k_logits(logits, k)
+        probs = torch.softmax(logits, dim=-1)
+        if p is not None:
+            probs = top_p_logits(probs, p)
+        return torch.multinomial(probs, num_samples=1) if sample else torch.topk(probs, k=1, dim=-1)[1]
+
+    @torch.no_grad()
+    def sample_from_scratch(self, c_coarse, c_fine, c_pos_coarse, c_pos_fine, c_seg_coarse, c_seg_fine, temperature=1.0, sample=True,
+                            top_k=None, top_p=None, top_k_pos=None, top_p_pos=None, process=True, fix_fine_position=False):
+        tr = self.transformer
+        x_c, x_pc, x_sc = c_coarse, c_pos_coarse, c_seg_coarse
+        if self.activate_sos_for_fine_sequence:
+            x_f, x_pf, x_sf = c_fine, c_pos_fine, c_seg_fine
+        else:
+            x_f, x_pf, x_sf = c_fine[:, :0], c_pos_fine[:, :0], c_seg_fine[:, :0]
+        b, dev = x_c.size(0), x_c.device
+        zeros1 = torch.zeros(b, 1, dtype=torch.long, device=dev)
+        # ---- coarse stream: position, then content, until every row has drawn <eos>
+        done = torch.zeros(b, 1, device=dev)
+        while not torch.all(done.bool()):
+            hidden, pl = tr.sample_coarse_position(coarse_content=x_c, coarse_position=x_pc, coarse_seg=x_sc)
+            ix_pos = self._draw(pl, temperature, sample, top_k_pos, top_p_pos,
+                                lambda lg: self.avoid_repeat_or_enforce_pad_for_coarse_position(lg, x_pc, done))
+            x_pc = torch.cat((x_pc, ix_pos), dim=1)
+            done = done + (ix_pos == self.coarse_position_eos_code)
+            _, cl = tr.sample_coarse_content(coarse_content=None, coarse_position=x_pc, coarse_seg=None, position_hidden=hidden)
+            ix = self._draw(cl, temperature, sample, top_k, top_p, lambda lg: self.avoid_special_or_enforce_pad_for_content(lg, done))
+            if self.activate_segment:
+                x_sc = torch.cat([x_sc, zeros1], dim=1)
+            x_c = torch.cat((x_c, ix), dim=1)
+        # ---- fine stream
+        done = torch.zeros(b, 1, device=dev)
+        if not fix_fine_position:
+            taken = self.transfer_sampled_coarse_position_to_sampled_fine_position(x_pc)
+            while not torch.all(done.bool()):
+                hidden, pl = tr.sample_fine_position(coarse_content=x_c, fine_content=x_f, coarse_position=x_pc, fine_position=x_pf,
+                                                     coarse_seg=x_sc, fine_seg=x_sf)
+                ix_pos = self._draw(pl, temperature, sample, top_k_pos, top_p_pos,
+                                    lambda lg: self.avoid_repeat_or_enforce_pad_for_fine_position(lg, taken, done))
+                x_pf = torch.cat((x_pf, ix_pos), dim=1)
+                taken = torch.cat([taken, ix_pos], dim=1)
+                done = done + (ix_pos == self.fine_position_eos_code)
+                _, cl = tr.sample_fine_content(coarse_content=x_c, fine_content=x_f, coarse_position=x_pc, fine_position=x_pf,
+                                               coarse_seg=x_sc, fine_seg=x_sf, position_hidden=hidden)
+                ix = self._draw(cl, temperature, sample, top_k, top_p, lambda lg: self.avoid_special_or_enforce_pad_for_content(lg, done))
+                x_f = torch.cat((x_f, ix), dim=1)
+                if self.activate_segment:
+                    x_sf = torch.cat([x_sf, zeros1 + 1], dim=1)
+        else:
+            remain = self.transfer_sampled_coarse_position_to_remain_fine_position(x_pc)
+            for j in range(remain.size(1)):
+                if self.activate_sos_for_fine_sequence and j == 0:
+                    continue
+                ix_pos = remain[:, j].unsqueeze(-1)
+                x_pf = torch.cat((x_pf, ix_pos), dim=1)
+                done = done + (ix_pos == self.fine_position_eos_code)
+                _, cl = tr.sample_fine_content(coarse_content=x_c, fine_content=x_f, coarse_position=x_pc, fine_position=x_pf,
+                                               coarse_seg=x_sc, fine_seg=x_sf, position_hidden=None)
+                ix = self._draw(cl, temperature, sample, top_k, top_p, lambda lg: self.avoid_special_or_enforce_pad_for_content(lg, done))
+                x_f = torch.cat((x_f, ix), dim=1)
+                if self.activate_segment:
+                    x_sf = torch.cat([x_sf, zeros1 + 1], dim=1)
+        x_c, x_pc = x_c[:, c_coarse.shape[1]:], x_pc[:, c_pos_coarse.shape[1]:]
+        if self.activate_sos_for_fine_sequence:
+            x_f, x_pf = x_f[:, c_fine.shape[1]:], x_pf[:, c_fine.shape[1]:]
+        return x_c, x_f, x_pc, x_pf
+
+
+for _name, _fn in list(vars(_SamplerMixin).items()):
+    if not _name.startswith("__"):
+        setattr(_SamplerMixinBase, _name, _fn)

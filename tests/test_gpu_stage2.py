@@ -205,3 +205,59 @@ def test_dualformer_train_steps_and_round_trip(dev):
         # vs the autoencoder's own forward: its straight-through x + (x_q - x) is rounded to bf16 once more than a direct
         # codebook lookup (1-ulp differences that the untrained decoder's GroupNorms amplify): loose bound only
         assert float((rec1 - rec2).abs().max()) <= 0.1 * float(rec1.abs().max())
+
+
+SAMPLER_GPT_CFG = dict(vocab_size=515, coarse_position_size=19, fine_position_size=67, segment_size=2, block_size=96,
+                       position_layer=2, content_layer=2, n_head=4, n_embd=64, embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0,
+                       content_pad_code=512, coarse_position_pad_code=16, fine_position_pad_code=64, activate_pad_ignore=True)
+
+
+def _sampler_model(dev, order):
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    cfg = dualformer_config()
+    cfg["params"]["transformer_config"]["params"] = dict(SAMPLER_GPT_CFG)
+    cfg["params"]["permuter_config"]["params"]["fine_position_order"] = order
+    model = instantiate_from_config(cfg).to(dev).eval()
+    with torch.no_grad():
+        for n, p in model.transformer.named_parameters():
+            v = synth.det_param("sampler." + n, tuple(p.shape))
+            p.copy_(torch.from_numpy(v * (0.3 if n == "pos_emb" else 4.0 if n.endswith("head.1.weight") else 1.0)).to(dev))
+    return model
+
+
+@pytest.mark.parametrize("order", ["region-first", "row-first"])
+def test_sampler_greedy_golden(dev, order):
+    """Dualformer.sample_from_scratch (greedy + top-k, so no RNG) reproduces the reference's sequences token for token in both
+    fine-position modes, and the decoded code maps"""
+    from dynamicvectorquantization_amd import runtime as rt
+    g = load_golden("sampler")
+    tag = order.split("-")[0]
+    with rt.compute_dtype_ctx(torch.float32):
+        model = _sampler_model(dev, order)
+        c = model.encode_to_c(torch.zeros(3, 3, 64, 64, device=dev))
+        for fix in (False, True):
+            res = model.sample_from_scratch(*c, temperature=1.0, sample=False, top_k=50, top_p=None, top_k_pos=None, top_p_pos=None,
+                                            process=False, fix_fine_position=fix)
+            for name, r in zip(("coarse_content", "fine_content", "coarse_position", "fine_position"), res):
+                assert np.array_equal(r.cpu().numpy(), g[f"{tag}_{int(fix)}_{name}"]), (fix, name)
+            codes = model.permuter.forward_back(*res)
+            assert np.array_equal(codes.cpu().numpy(), g[f"{tag}_{int(fix)}_codes"])
+        img = model.decode_to_img(*res)
+        assert tuple(img.shape) == (3, 3, 64, 64) and bool(torch.isfinite(img).all())
+
+
+def test_sampler_constraints_and_filters_golden(dev):
+    from dynamicvectorquantization_amd import stage2
+    g = load_golden("sampler")
+    model = _sampler_model(dev, "region-first")
+    lg = torch.from_numpy(g["h_logits"]).to(dev)
+    flag = torch.from_numpy(g["h_flag"]).to(dev)
+    sp = torch.from_numpy(g["h_sampled"]).to(dev)
+    assert np.array_equal(model.avoid_repeat_or_enforce_pad_for_coarse_position(lg, sp, flag).cpu().numpy(), g["h_coarse"])
+    spf = torch.tensor([[66, 3, 7], [66, 0, 65], [66, 5, 5], [66, 14, 2]], device=dev)
+    assert np.array_equal(model.avoid_repeat_or_enforce_pad_for_fine_position(lg, spf, flag).cpu().numpy(), g["h_fine"])
+    lgc = torch.from_numpy(g["h_logits_c"]).to(dev)
+    assert np.array_equal(model.avoid_special_or_enforce_pad_for_content(lgc, flag).cpu().numpy(), g["h_content"])
+    assert np.array_equal(stage2.top_k_logits(lgc, 20).cpu().numpy(), g["h_topk"])
+    np.testing.assert_allclose(stage2.top_p_logits(torch.softmax(lgc, -1), 0.6).cpu().numpy(), g["h_topp"], rtol=1e-5, atol=1e-8)

@@ -737,9 +737,69 @@ def gen_stackgpt():
     np.savez_compressed(os.path.join(GOLD, "stackgpt.npz"), **res)
 
 
+SAMPLER_GPT_CFG = dict(vocab_size=515, coarse_position_size=19, fine_position_size=67, segment_size=2, block_size=96,
+                       position_layer=2, content_layer=2, n_head=4, n_embd=64, embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0,
+                       content_pad_code=512, coarse_position_pad_code=16, fine_position_pad_code=64, activate_pad_ignore=True)
+
+
+def gen_sampler():
+    """Dualformer.sample_from_scratch of the reference (greedy, so no device RNG) on a 4x4 / 8x8 grid with a deterministic
+    StackGPT: the reference methods run unbound on a bare nn.Module carrying the attributes they read."""
+    from models.stage2_dynamic.dqtransformer_uncond_entropy import Dualformer
+    from modules.dynamic_modules.permuter import DualGrainSeperatePermuter
+    from modules.dynamic_modules.stackgpt import StackGPT
+    out = {}
+    for order in ("region-first", "row-first"):
+        gpt = StackGPT(**SAMPLER_GPT_CFG).eval()
+        with torch.no_grad():
+            for n_, p in gpt.named_parameters():
+                v = synth.det_param("sampler." + n_, p.shape)
+                p.copy_(t(v * (0.3 if n_ == "pos_emb" else 4.0 if n_.endswith("head.1.weight") else 1.0)))
+        obj = object.__new__(Dualformer)
+        nn.Module.__init__(obj)
+        obj.transformer = gpt
+        obj.permuter = DualGrainSeperatePermuter(coarse_hw=4, fine_hw=8, content_pad_code=512, content_eos_code=513,
+                                                 coarse_position_pad_code=16, coarse_position_eos_code=17, fine_position_pad_code=64,
+                                                 fine_position_eos_code=65, fine_position_order=order)
+        obj.activate_sos_for_fine_sequence, obj.activate_segment = True, True
+        obj.content_pad_code, obj.content_eos_code, obj.content_sos_code = 512, 513, 514
+        obj.coarse_position_eos_code, obj.coarse_position_pad_code = 17, 16
+        obj.fine_position_sos_code, obj.fine_position_eos_code, obj.fine_position_pad_code = 66, 65, 64
+        obj.hw1, obj.hw2, obj.fine_hw, obj.fine_position_order = 4, 2, 8, order
+        obj.max_coarse_postion_idx = 15
+        obj.fine_position_eos_tensor = obj.permuter.fine_position_eos_tensor.clone()
+        obj.position_sequence_fine = obj.permuter.position_sequence_fine.clone()
+        b = 3
+        ones = torch.ones(b, 1, dtype=torch.long)
+        c = (514 * ones, 514 * ones, 18 * ones, 66 * ones, 0 * ones, 1 * ones)
+        tag = order.split("-")[0]
+        for fix in (False, True):
+            res = obj.sample_from_scratch(*c, temperature=1.0, sample=False, top_k=50, top_p=None, top_k_pos=None, top_p_pos=None,
+                                          process=False, fix_fine_position=fix)
+            for nme, r in zip(("coarse_content", "fine_content", "coarse_position", "fine_position"), res):
+                out[f"{tag}_{int(fix)}_{nme}"] = r.numpy()
+            print(f"  sampler {order} fix={fix}: coarse len {res[0].shape[1]}, fine len {res[1].shape[1]}")
+            img_idx = obj.permuter.forward_back(*[res[i] for i in (0, 1, 2, 3)])
+            out[f"{tag}_{int(fix)}_codes"] = img_idx.numpy()
+    # constraint helpers on random logits
+    lg = t(synth.det_param("sampler.logits", (4, 67)) * 5)
+    sp = torch.tensor([[18, 3, 7], [18, 0, 17], [18, 5, 5], [18, 14, 2]])
+    flag = torch.tensor([[0.], [1.], [0.], [2.]])
+    out["h_logits"], out["h_sampled"], out["h_flag"] = lg.numpy(), sp.numpy(), flag.numpy()
+    out["h_coarse"] = obj.avoid_repeat_or_enforce_pad_for_coarse_position(lg, sp, flag).numpy()
+    out["h_fine"] = obj.avoid_repeat_or_enforce_pad_for_fine_position(lg, torch.tensor([[66, 3, 7], [66, 0, 65], [66, 5, 5], [66, 14, 2]]), flag).numpy()
+    lgc = t(synth.det_param("sampler.logits_c", (4, 515)) * 5)
+    out["h_logits_c"] = lgc.numpy()
+    out["h_content"] = obj.avoid_special_or_enforce_pad_for_content(lgc, flag).numpy()
+    from models.stage2.utils import top_k_logits, top_p_logits
+    out["h_topk"] = top_k_logits(lgc, 20).numpy()
+    out["h_topp"] = top_p_logits(torch.softmax(lgc, -1), 0.6).numpy()
+    np.savez_compressed(os.path.join(GOLD, "sampler.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter,stackgpt")
+    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter,stackgpt,sampler")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -747,7 +807,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for name in args.only.split(","):
         print(f"[gen] {name}")
-        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter, "stackgpt": gen_stackgpt}[name]()
+        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter, "stackgpt": gen_stackgpt, "sampler": gen_sampler}[name]()
     print("done ->", GOLD)
 
 
