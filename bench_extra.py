@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Secondary workloads of BASELINE.json (configs 4 and 5) on ONE MI355X -- the headline metric stays in bench.py.
+
+    python bench_extra.py --workload triple   [--bs 32] [--steps K] [--warmup W]      # dqvae-triple-r-03-03 complete step
+    python bench_extra.py --workload stage2   [--bs 32]                               # DQ-Transformer p6c18 train step
+    python bench_extra.py --workload sampling [--bs 8]                                # AR sampling tokens/s (no KV cache)
+
+Each prints one JSON line {"workload", "metric", "value", "unit", "ms_per_step", ...}.  Synthetic 256x256 half-flat images,
+random-init weights of the shipped YAML architectures, bf16 compute / fp32 master weights, inputs resident in HBM.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", required=True, choices=["triple", "stage2", "sampling"])
+    ap.add_argument("--bs", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--codebook", type=int, default=None, help="override the codebook size (BASELINE config 4 quotes 8192)")
+    args = ap.parse_args()
+    assert torch.cuda.is_available(), "an MI355X is required"
+    dev = torch.device("cuda", 0)
+    from dynamicvectorquantization_amd import _lib, config as cfg, runtime as rt, synth
+    from dynamicvectorquantization_amd.trainer import Trainer
+    _lib.check(_lib.load().dvq_check_device(), "dvq_check_device")
+    rt.set_compute_dtype("bf16")
+    os.chdir(REPO)
+    torch.manual_seed(0)
+
+    def timed_steps(trainer, batches, steps, warmup):
+        for i in range(warmup):
+            trainer.train_step(batches[i % len(batches)], i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            trainer.train_step(batches[i % len(batches)], warmup + i)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    if args.workload == "triple":
+        bs = args.bs or 32
+        c = cfg.load_yaml(os.path.join(REPO, "configs/stage1/dqvae-triple-r-03-03_imagenet.yml"))
+        if args.codebook:
+            c.model.params.vqconfig.params.codebook_size = args.codebook
+        model = cfg.instantiate_from_config(c.model).to(dev)
+        model.learning_rate, model.training_steps, model.steps_per_epoch = 4.5e-6 * bs, 100000, 1000
+        model.train()
+        tr = Trainer(model, max_steps=args.steps)
+        batches = [{"image": torch.from_numpy(synth.half_flat_images(bs, 256, seed=77 + i)).to(dev)} for i in range(2)]
+        dt = timed_steps(tr, batches, args.steps, args.warmup)
+        ind = model._last["grain"]
+        out = {"workload": "triple", "metric": "images/sec (256x256) DQ-VAE triple-grain train step, complete two-optimizer objective",
+               "value": round(bs * args.steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / args.steps * 1e3, 2),
+               "config": {"yaml": "configs/stage1/dqvae-triple-r-03-03_imagenet.yml", "bs": bs,
+                          "codebook": int(c.model.params.vqconfig.params.codebook_size),
+                          "grain_histogram": torch.bincount(ind.reshape(-1), minlength=3).tolist()},
+               "steps": args.steps, "warmup": args.warmup, "dtype": "bf16", "data": "synthetic"}
+    else:
+        c = cfg.load_yaml(os.path.join(REPO, "configs/stage2/uncond_imagenet_p6c18.yml"))
+        model = cfg.instantiate_from_config(c.model).to(dev)
+        model.learning_rate, model.min_learning_rate, model.training_steps, model.steps_per_epoch = 5e-4, 0.0, 100000, 1000
+        if args.workload == "stage2":
+            bs = args.bs or 32
+            model.train()
+            tr = Trainer(model, max_steps=args.steps)
+            batches = [{"image": torch.from_numpy(synth.half_flat_images(bs, 256, seed=177 + i)).to(dev)} for i in range(2)]
+            dt = timed_steps(tr, batches, args.steps, args.warmup)
+            with torch.no_grad():
+                _, z = model.encode_to_z(batches[0]["image"])
+            t_len = z["coarse_content"].shape[1] + z["fine_content"].shape[1] + 1
+            n_par = sum(p.numel() for p in model.transformer.parameters())
+            flops = 6.0 * n_par * bs * t_len + 12.0 * 24 * bs * t_len * t_len * 1024      # weights + attention (full square)
+            out = {"workload": "stage2", "metric": "images/sec DQ-Transformer (StackGPT p6c18) train step over frozen DQ-VAE codes",
+                   "value": round(bs * args.steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / args.steps * 1e3, 2),
+                   "tokens_per_sec": round(bs * t_len * args.steps / dt, 1),
+                   "config": {"yaml": "configs/stage2/uncond_imagenet_p6c18.yml", "bs": bs, "seq_len": int(t_len),
+                              "transformer_params": n_par, "dropout": 0.1},
+                   "mfma_frac_est": round(flops * args.steps / dt / 2.5e15, 4),
+                   "steps": args.steps, "warmup": args.warmup, "dtype": "bf16", "data": "synthetic"}
+        else:
+            bs = args.bs or 8
+            model.eval()
+            x = torch.from_numpy(synth.half_flat_images(bs, 256, seed=277)).to(dev)
+            with torch.no_grad():
+                _, z = model.encode_to_z(x)
+                tf = model.teacher_forcing_inputs(z, model.encode_to_c(x))
+                cc, fc, cp, fp, cs, fs = (tf[k] for k in ("coarse_content", "fine_content", "coarse_position", "fine_position",
+                                                         "coarse_seg", "fine_seg"))
+                tr_ = model.transformer
+                res = {}
+                # one sampling step of the fine stream at (a) half and (b) the full prefix: position pass + content pass,
+                # recomputed over the whole prefix exactly like the reference's sampler (no KV cache)
+                for tag, lf in (("half_prefix", fc.shape[1] // 2), ("full_prefix", fc.shape[1] - 1)):
+                    def step():
+                        h, pl = tr_.sample_fine_position(cc, fc[:, :lf], cp, fp[:, :lf], cs, fs[:, :lf])
+                        tr_.sample_fine_content(cc, fc[:, :lf], cp, fp[:, :lf + 1], cs, fs[:, :lf], position_hidden=h)
+                    for _ in range(2):
+                        step()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    n = 5
+                    for _ in range(n):
+                        step()
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / n
+                    res[tag] = {"prefix_len": int(cc.shape[1] + lf), "ms_per_token_step": round(dt * 1e3, 2),
+                                "tokens_per_sec": round(bs / dt, 1)}
+            out = {"workload": "sampling", "metric": "AR sampling tokens/sec (one position + one content token per step, whole "
+                                                     "prefix recomputed: the reference's sampler has no KV cache)",
+                   "value": res["full_prefix"]["tokens_per_sec"], "unit": "token-steps/sec", "detail": res,
+                   "config": {"yaml": "configs/stage2/uncond_imagenet_p6c18.yml", "bs": bs}, "dtype": "bf16", "data": "synthetic"}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

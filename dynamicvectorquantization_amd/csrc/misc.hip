@@ -171,13 +171,17 @@ __global__ __launch_bounds__(256) void add_bias_bcast_kernel(const T* __restrict
     }
 }
 
+// out[i] += sum_b x[b][i]: columns across threads (coalesced rows), the batch split over blockIdx.y; partial sums are
+// combined with fp32 atomics (one per column and batch chunk)
 template <typename T>
 __global__ __launch_bounds__(256) void sum_batch_kernel(const T* __restrict__ x, int64_t batch, int64_t inner,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int64_t rows_per_chunk) {
+    const int64_t b0 = (int64_t)blockIdx.y * rows_per_chunk, b1 = min(batch, b0 + rows_per_chunk);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < inner; i += (int64_t)gridDim.x * 256) {
         float acc = 0.f;
-        for (int64_t b = 0; b < batch; ++b) acc += ElemIO<T>::load(x + b * inner + i);
-        out[i] += acc;
+        for (int64_t b = b0; b < b1; ++b) acc += ElemIO<T>::load(x + b * inner + i);
+        if (gridDim.y == 1) out[i] += acc;
+        else atomicAdd(&out[i], acc);
     }
 }
 
@@ -452,8 +456,15 @@ int dvq_add_bias_bcast(const void* x, const float* bias, int dtype, int64_t batc
 
 int dvq_sum_batch(const void* x, int dtype, int64_t batch, int64_t inner, float* out, dvq_stream_t stream) {
     DVQ_REQUIRE(x && out && batch > 0 && inner > 0, DVQ_EINVAL, "dvq_sum_batch: bad arguments");
-    DVQ_DISPATCH_DTYPE(dtype, T, sum_batch_kernel<T><<<dim3(nblocks(inner, 256)), dim3(256), 0, (hipStream_t)stream>>>(
-                                     (const T*)x, batch, inner, out););
+    // enough workgroups to fill the chip: split the batch when there are few columns
+    const int64_t col_blocks = cdiv64(inner, 256);
+    int64_t chunks = col_blocks >= 1024 ? 1 : cdiv64(1024, col_blocks);
+    if (chunks > cdiv64(batch, 16)) chunks = cdiv64(batch, 16);
+    if (chunks < 1) chunks = 1;
+    const int64_t rpc = cdiv64(batch, chunks);
+    chunks = cdiv64(batch, rpc);
+    DVQ_DISPATCH_DTYPE(dtype, T, sum_batch_kernel<T><<<dim3((unsigned)(col_blocks < 65535 ? col_blocks : 65535), (unsigned)chunks), dim3(256), 0,
+                                                      (hipStream_t)stream>>>((const T*)x, batch, inner, out, rpc););
     DVQ_CHECK_LAUNCH("sum_batch");
     return DVQ_OK;
 }

@@ -299,7 +299,7 @@ int dvq_layernorm_bwd(const void* x, const void* dy, int dtype, int64_t rows, in
                       void* dx, float* dgamma, float* dbeta, dvq_stream_t stream) {
     DVQ_REQUIRE(x && dy && mean_rstd && gamma && dx && dgamma && dbeta && rows > 0 && C > 0 && C % 8 == 0 && C <= 4096, DVQ_EINVAL,
                 "dvq_layernorm_bwd: bad arguments (C %% 8 == 0, C <= 4096)");
-    int rpw = (int)cdiv64(rows, 4 * 1024);            // <= 1024 workgroups x 4 waves
+    int rpw = (int)cdiv64(rows, 1024);                // ~1024 waves (one per SIMD): few, long runs keep the dgamma/dbeta atomics rare
     if (rpw < 1) rpw = 1;
     const int64_t waves = cdiv64(rows, rpw);
     DVQ_DISPATCH_DTYPE(dtype, T, ln_bwd_kernel<T><<<dim3((unsigned)cdiv64(waves, 4)), dim3(256), 0, (hipStream_t)stream>>>(
