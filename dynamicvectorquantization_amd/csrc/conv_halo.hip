@@ -164,20 +164,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
                 sa[mt] = (hp >> 1) & 7;
             }
             const char* pb = bst + buf * BSTAGE + l31 * ROWB;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 a[MT], b[4];
+            // software-pipelined k-steps: the fragments of step ks+1 are requested before the MFMAs of step ks are issued
+            // (the compiler otherwise parks their ds_reads behind the MFMA group and waits on them right away)
+            bf16x8 a[2][MT], b[2][4];
+            auto load_frags = [&](int ks, int slot) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    a[mt] = *reinterpret_cast<const bf16x8*>(pa[mt] + (((ks * 2 + half) ^ sa[mt]) << 4));
+                    a[slot][mt] = *reinterpret_cast<const bf16x8*>(pa[mt] + (((ks * 2 + half) ^ sa[mt]) << 4));
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    b[nt] = *reinterpret_cast<const bf16x8*>(pb + nt * 32 * ROWB + (((ks * 2 + half) ^ swzB) << 4));
+                    b[slot][nt] = *reinterpret_cast<const bf16x8*>(pb + nt * 32 * ROWB + (((ks * 2 + half) ^ swzB) << 4));
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) load_frags(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][mt], b[ks & 1][nt], acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
         }
