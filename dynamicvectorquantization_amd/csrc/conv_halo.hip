@@ -54,9 +54,13 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // NW = waves per workgroup: 4 -> each wave owns 2 image rows (2 x 4 accumulator tiles of 32x32, 2 waves per SIMD);
 //                           2 -> each wave owns 4 image rows (4 x 4 tiles = 256 accumulator registers, 1 wave per SIMD,
 //                                one third less LDS fragment traffic per MFMA: 8 fragment reads feed 16 MFMAs).
-template <int NW>
+// NT = 32-channel output tiles per wave (4 -> 128 output channels per workgroup; 2 / 1 for Cout <= 64 / 32 so that thin
+// layers -- VGG16's 64-channel block, the 3-channel image head -- do not pay for a mostly empty 128-wide tile).
+template <int NW, int NT>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(HaloParams p) {
     constexpr int MT = 8 / NW;          // image rows (32-pixel m-tiles) per wave
+    constexpr int CO_T = 32 * NT;       // output channels per workgroup
+    constexpr int CPRW = CO_T / 8;      // 16-byte chunks per staged output row
     constexpr int NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
     wi /= p.tiles_x;
     const int ty = wi % p.tiles_y;
     const int n = wi / p.tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW, n0 = nt_blk * 128;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = nt_blk * CO_T;
     const int64_t img = (int64_t)n * p.H * p.W;
     const int SWd = p.W >> p.up;                       // stored input width
     const int64_t simg = (int64_t)n * (p.H >> p.up) * SWd;
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
     };
     auto issue_b = [&](int tap, int c0, int buf) {
         const int tb = p.flip ? 8 - tap : tap;
-        constexpr int RPW = 128 / NW;       // weight rows per wave
+        constexpr int RPW = CO_T / NW;      // weight rows per wave (>= 8: one DMA piece)
         char* dst = bst + buf * BSTAGE + wave * RPW * ROWB;
 #pragma unroll
         for (int i = 0; i < RPW / 8; ++i) {
@@ -113,11 +117,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
         }
     };
 
-    f32x16 acc[MT][4];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -166,13 +170,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
             const char* pb = bst + buf * BSTAGE + l31 * ROWB;
             // software-pipelined k-steps: the fragments of step ks+1 are requested before the MFMAs of step ks are issued
             // (the compiler otherwise parks their ds_reads behind the MFMA group and waits on them right away)
-            bf16x8 a[2][MT], b[2][4];
+            bf16x8 a[2][MT], b[2][NT];
             auto load_frags = [&](int ks, int slot) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     a[slot][mt] = *reinterpret_cast<const bf16x8*>(pa[mt] + (((ks * 2 + half) ^ sa[mt]) << 4));
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
                     b[slot][nt] = *reinterpret_cast<const bf16x8*>(pb + nt * 32 * ROWB + (((ks * 2 + half) ^ swzB) << 4));
             };
             load_frags(0, 0);
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
+                    for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][mt], b[ks & 1][nt], acc[mt][nt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
     bf16_t* st = reinterpret_cast<bf16_t*>(smem);
     const bool early_act = p.R == nullptr || p.res_mask;     // no residual add between the accumulator and the activation
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         const int lc = nt * 32 + l31;
         const float bcol = (p.bias != nullptr && n0 + lc < p.Cout) ? p.bias[n0 + lc] : 0.f;
 #pragma unroll
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
                 const int lp = (MT * wave + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v = acc[mt][nt][r] + bcol;
                 if (early_act) v = v > 0.f ? v : v * p.act_slope;
-                st[lp * 128 + lc] = f32_to_bf16(v);
+                st[lp * CO_T + lc] = f32_to_bf16(v);
             }
     }
     __syncthreads();
@@ -213,12 +217,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
 #pragma unroll
     for (int k = 0; k < 8; ++k) gs[k] = gq[k] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4096 / NTH; ++i) {
+    for (int i = 0; i < 256 * CPRW / NTH; ++i) {
         const int q = tid + NTH * i;
-        const int lp = q >> 4, ch = q & 15;
+        const int lp = q / CPRW, ch = q % CPRW;
         const int col = n0 + ch * 8;
         if (col >= p.Cout) continue;
-        uint4 v = *reinterpret_cast<const uint4*>(smem + lp * 256 + ch * 16);
+        uint4 v = *reinterpret_cast<const uint4*>(smem + lp * (CO_T * 2) + ch * 16);
         const int64_t o = ((img + (int64_t)(y0 + (lp >> 5)) * p.W + x0 + (lp & 31)) * p.Cout) + col;
         if (p.R) {
             const uint4 rv = *reinterpret_cast<const uint4*>(p.R + o);
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
         float* red = reinterpret_cast<float*>(smem);            // [128][2]
         for (int i = tid; i < 256; i += NTH) red[i] = 0.f;
         __syncthreads();
-        const int ch = tid & 15;
+        const int ch = tid % CPRW;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             atomicAdd(&red[(ch * 8 + k) * 2], gs[k]);
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
         }
         __syncthreads();
         const int cpg = p.Cout / p.out_groups;                  // channels per group
-        const int ng = 128 / cpg;                               // groups covered by this workgroup's 128 channels
+        const int ng = CO_T / cpg;                              // groups covered by this workgroup's output channels
         if (tid < ng && n0 + tid * cpg < p.Cout) {
             double s1 = 0.0, s2 = 0.0;
             for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
@@ -290,12 +294,13 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
                          double* out_stats, int out_groups, float act_slope, int res_mask, float mask_slope,
                          hipStream_t stream) {
     if (H % TH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
-    if (out_stats != nullptr && (out_groups <= 0 || Cout % out_groups != 0 || 128 % (Cout / out_groups) != 0)) return 0;
+    const int cot = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;          // output-channel tile of the kernel instance
+    if (out_stats != nullptr && (out_groups <= 0 || Cout % out_groups != 0 || cot % (Cout / out_groups) != 0)) return 0;
     if (N * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31) || Cout * 9 * Cin >= (1ll << 31)) return 0;
     HaloParams p{};
     p.X = (const bf16_t*)x; p.Wt = (const bf16_t*)w; p.Y = (bf16_t*)y; p.R = (const bf16_t*)residual; p.bias = bias;
     p.N = (int)N; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout;
-    p.tiles_x = (int)(W / TW); p.tiles_y = (int)(H / TH); p.gn = (int)cdiv64(Cout, 128);
+    p.tiles_x = (int)(W / TW); p.tiles_y = (int)(H / TH); p.gn = (int)cdiv64(Cout, cot);
     p.flip = flip;
     p.up = up;
     p.gn_ss = gn_ss; p.out_stats = out_stats; p.out_groups = out_groups;
@@ -306,12 +311,18 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
         const char* e = getenv("DVQ_HALO_WAVES");
         return e != nullptr ? atoi(e) : 0;
     }();
-    if (nw_env != 2) {      // default: 4 waves (2 x 4 tiles each); the 2-wave / 4 x 4-tile variant measured 2x slower (1 wave per SIMD)
-        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4>, LDSB);
-        conv3x3_halo_kernel<4><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+    if (nw_env == 2 && cot == 128) {   // experiment: 2 waves x (4 x 4 tiles); measured 2x slower (1 wave per SIMD)
+        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<2, 4>, LDSB);
+        conv3x3_halo_kernel<2, 4><<<dim3((unsigned)blocks), dim3(128), LDSB, stream>>>(p);
+    } else if (cot == 128) {
+        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 4>, LDSB);
+        conv3x3_halo_kernel<4, 4><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+    } else if (cot == 64) {
+        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 2>, LDSB);
+        conv3x3_halo_kernel<4, 2><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
     } else {
-        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<2>, LDSB);
-        conv3x3_halo_kernel<2><<<dim3((unsigned)blocks), dim3(128), LDSB, stream>>>(p);
+        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 1>, LDSB);
+        conv3x3_halo_kernel<4, 1><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -277,7 +277,8 @@ def test_conv(dev, case, dtype, impl):
         assert err < gtol * 5, f"{name}: rel-to-max error {err}"
 
 
-HALO_CASES = [(64, 64, 8, 32, 2), (128, 128, 16, 32, 2), (64, 192, 8, 64, 1), (256, 128, 24, 32, 1), (128, 64, 8, 32, 1)]
+HALO_CASES = [(64, 64, 8, 32, 2), (128, 128, 16, 32, 2), (64, 192, 8, 64, 1), (256, 128, 24, 32, 1), (128, 64, 8, 32, 1),
+              (128, 8, 16, 32, 1), (64, 24, 8, 32, 2), (64, 40, 8, 64, 1)]      # thin outputs: 32- / 64-wide channel tiles
 
 
 @pytest.mark.parametrize("case", HALO_CASES, ids=lambda c: "-".join(map(str, c)))
@@ -309,7 +310,11 @@ def test_conv3x3_halo_kernel(dev, case, residual):
         rh = T(res, dev, torch.bfloat16).permute(0, 2, 3, 1).contiguous() if residual else None
         tape = Tape()
         y = mod.fwd(xh, tape, residual=rh)
-        dx = mod.bwd(T(go, dev, torch.bfloat16).permute(0, 2, 3, 1).contiguous(), tape)
+        # the dgrad of a conv whose Cout is not a multiple of 64 is not a halo-kernel shape (its "input" channels): auto
+        if cout % 64 != 0:
+            tape.s["d"].impl = 0
+        with rt.impl_ctx(4 if cout % 64 == 0 else 0):
+            dx = mod.bwd(T(go, dev, torch.bfloat16).permute(0, 2, 3, 1).contiguous(), tape)
     yref = yr.detach().numpy()
     err = np.abs(y.float().permute(0, 3, 1, 2).cpu().numpy() - yref).max() / np.abs(yref).max()
     assert err < 2e-2, f"forward rel-to-max error {err}"
