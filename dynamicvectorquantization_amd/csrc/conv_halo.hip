@@ -621,3 +621,127 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
     }
     return 1;
 }
+
+// =================================================================================================
+// Thin-input 3x3 / stride 1 / pad 1 convolution: 8 (zero-padded) input channels -> Cout output channels (bf16).
+// Used for the image heads (encoder conv_in 3 -> 128, VGG16 conv1_1 3 -> 64) and for the dgrad of the 128 -> 3 output
+// conv (8 gradient channels -> 128).  K = 9 taps x 8 channels = 72: one MFMA k-step covers TWO taps (lanes 0-31 tap 2k,
+// lanes 32-63 tap 2k+1; the tenth half-step is zero), so a 32-pixel x 128-channel tile costs 20 MFMAs and the kernel is
+// bound by writing its output.  No LDS for the operands: a lane's A fragment is the 16 bytes of one input pixel (read
+// straight from global / L2, neighbouring taps hit the same lines), the weights (Cout x 72) live in registers for the
+// whole kernel.  The output tile is staged through a wave-private LDS slab for 16-byte stores.
+// =================================================================================================
+namespace {
+
+struct ThinParams {
+    const bf16_t* X;      // [N,H,W,8]
+    const bf16_t* Wt;     // [Cout][9][8]
+    bf16_t* Y;            // [N,H,W,Cout]
+    const float* bias;    // [Cout] or null
+    int N, H, W, Cout;
+    int flip;             // 1: tap index 8 - t (dgrad through the [Cin][3][3][Cout_p = 8] pack)
+    float act_slope;
+    int64_t ntiles;       // N * H * (W / 32) row segments of 32 pixels
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv3x3_thin_k_kernel(ThinParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CO_T = 32 * NT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.y * CO_T;
+    // weights of this workgroup's output channels: fragment (nt, ks) = w[n0 + nt*32 + l31][tap = 2ks + half][0:8]
+    bf16x8 b[NT][5];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            const int tap = 2 * ks + half, co = n0 + nt * 32 + l31;
+            uint4 v = {0, 0, 0, 0};
+            if (tap < 9 && co < p.Cout) v = *reinterpret_cast<const uint4*>(p.Wt + ((int64_t)co * 9 + (p.flip ? 8 - tap : tap)) * 8);
+            b[nt][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    float bcol[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bcol[nt] = (p.bias != nullptr && n0 + nt * 32 + l31 < p.Cout) ? p.bias[n0 + nt * 32 + l31] : 0.f;
+    bf16_t* st = reinterpret_cast<bf16_t*>(smem) + wave * 32 * CO_T;        // wave-private staging: 32 px x CO_T
+    const int segs = p.W / 32;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < p.ntiles; t += (int64_t)gridDim.x * 4) {
+        const int sx = (int)(t % segs);
+        const int64_t ny = t / segs;
+        const int y = (int)(ny % p.H);
+        const int64_t n = ny / p.H;
+        const int x = sx * 32 + l31;
+        bf16x8 a[5];
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            const int tap = 2 * ks + half;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int iy = y + kh - 1, ix = x + kw - 1;
+            uint4 v = {0, 0, 0, 0};
+            if (tap < 9 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *reinterpret_cast<const uint4*>(p.X + ((n * p.H + iy) * (int64_t)p.W + ix) * 8);
+            a[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[nt][ks], acc[nt], 0, 0, 0);
+        }
+        // stage (wave-private, no workgroup barrier) -> 16-byte stores
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lp = (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[nt][r] + bcol[nt];
+                v = v > 0.f ? v : v * p.act_slope;
+                st[lp * CO_T + nt * 32 + l31] = f32_to_bf16(v);
+            }
+        __builtin_amdgcn_wave_barrier();               // wave-private slab: DS ops of one wave execute in order; keep the
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // compiler from reordering and drain lgkmcnt
+        constexpr int CPRW = CO_T / 8;
+        const int64_t obase = ((n * p.H + y) * (int64_t)p.W + sx * 32) * p.Cout + n0;
+#pragma unroll
+        for (int i = 0; i < 32 * CPRW / 64; ++i) {
+            const int q = lane + 64 * i;
+            const int lp = q / CPRW, ch = q % CPRW;
+            if (n0 + ch * 8 < p.Cout)
+                *reinterpret_cast<uint4*>(p.Y + obase + (int64_t)lp * p.Cout + ch * 8) =
+                    *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(st) + lp * (CO_T * 2) + ch * 16);
+        }
+        __builtin_amdgcn_wave_barrier();               // reads done before the next iteration overwrites the slab
+    }
+}
+
+}  // namespace
+
+// 1 = handled, 0 = not eligible.  x: [N,H,W,8] bf16, w: [Cout][9][8] bf16 (flip: read at tap 8 - t), y: [N,H,W,Cout]
+int dvq_conv3x3_thin_k_try(const void* x, const void* w, const float* bias, void* y, int64_t N, int64_t H, int64_t W, int64_t Cout,
+                           int flip, float act_slope, hipStream_t stream) {
+    if (W % 32 != 0 || Cout % 8 != 0 || N * H * W * Cout >= (1ll << 40)) return 0;
+    ThinParams p{};
+    p.X = (const bf16_t*)x; p.Wt = (const bf16_t*)w; p.Y = (bf16_t*)y; p.bias = bias;
+    p.N = (int)N; p.H = (int)H; p.W = (int)W; p.Cout = (int)Cout; p.flip = flip; p.act_slope = act_slope;
+    p.ntiles = N * H * (W / 32);
+    const int cot = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
+    const unsigned gy = (unsigned)cdiv64(Cout, cot);
+    int64_t gx = cdiv64(p.ntiles, 4 * 8);             // ~8 row segments per wave
+    if (gx > 4096) gx = 4096;
+    if (gx < 1) gx = 1;
+    const int lds = 4 * 32 * cot * 2;
+    if (cot == 128) conv3x3_thin_k_kernel<4><<<dim3((unsigned)gx, gy), dim3(256), lds, stream>>>(p);
+    else if (cot == 64) conv3x3_thin_k_kernel<2><<<dim3((unsigned)gx, gy), dim3(256), lds, stream>>>(p);
+    else conv3x3_thin_k_kernel<1><<<dim3((unsigned)gx, gy), dim3(256), lds, stream>>>(p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        dvq_set_error("conv3x3_thin_k: launch failed: %s", hipGetErrorString(e));
+        return DVQ_ELAUNCH;
+    }
+    return 1;
+}

@@ -1147,6 +1147,9 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
                                int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw, int up,
                                const float* gn_ss, hipStream_t stream);
 
+int dvq_conv3x3_thin_k_try(const void* x, const void* w, const float* bias, void* y, int64_t N, int64_t H, int64_t W, int64_t Cout,
+                           int flip, float act_slope, hipStream_t stream);
+
 static float act_slope_of(int act) { return act == DVQ_ACT_RELU ? 0.f : act == DVQ_ACT_LRELU ? 0.2f : 1.f; }
 
 static bool halo_eligible(const dvq_conv_desc* d) {
@@ -1193,6 +1196,11 @@ static int conv2d_fwd_impl(const dvq_conv_desc* d, const void* x, const void* w,
                            dvq_stream_t stream) {
     if (int e = conv_check(d, "dvq_conv2d_fwd")) return e;
     DVQ_REQUIRE(x && w && y, DVQ_EINVAL, "dvq_conv2d_fwd: null pointer");
+    if (halo_eligible(d) && d->impl == 0 && d->Cin == 8 && !d->upsample && residual == nullptr && gn_scale_shift == nullptr &&
+        out_stats == nullptr) {          // image heads: 8 (padded) input channels
+        const int rc = dvq_conv3x3_thin_k_try(x, w, bias, y, d->N, d->H, d->W, d->Cout, 0, act_slope_of(act), (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : DVQ_OK;
+    }
     if (halo_eligible(d)) {
         const int rc = dvq_conv3x3_halo_try(x, w, bias, residual, y, d->N, d->H, d->W, d->Cin, d->Cout, 0, d->upsample,
                                             gn_scale_shift, out_stats, out_groups, act_slope_of(act), 0, 0.f,
@@ -1228,6 +1236,11 @@ int dvq_conv2d_dgrad_mask(const dvq_conv_desc* d, const void* dy, const void* wt
     DVQ_REQUIRE(mask == nullptr || ((mask_act == DVQ_ACT_RELU || mask_act == DVQ_ACT_LRELU) && !d->upsample), DVQ_EINVAL,
                 "dvq_conv2d_dgrad_mask: mask needs act in {relu, lrelu} and no folded upsample");
     DVQ_REQUIRE(dy && wt && dx && (!d->upsample || ws), DVQ_EINVAL, "dvq_conv2d_dgrad: null pointer");
+    if (halo_eligible(d) && d->impl == 0 && d->Cout == 8 && !d->upsample && mask == nullptr) {
+        // dgrad of the 3-channel output conv: 8 gradient channels in, Cin out, taps reversed
+        const int rc = dvq_conv3x3_thin_k_try(dy, wt, nullptr, dx, d->N, d->H, d->W, d->Cin, 1, 1.f, (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : DVQ_OK;
+    }
     if (halo_eligible(d)) {      // dgrad of a 3x3/s1/p1 conv = the same conv over dy with the taps reversed
         // with a folded nearest-x2 upsample the gradient is formed at the upsampled resolution (ws), then 2x2-summed
         const int rc = dvq_conv3x3_halo_try(dy, wt, nullptr, mask, d->upsample ? ws : dx, d->N, d->H, d->W, d->Cout, d->Cin, 1,

@@ -326,6 +326,45 @@ def test_conv3x3_halo_kernel(dev, case, residual):
         assert e < 2e-2, f"{name} rel-to-max error {e}"
 
 
+@pytest.mark.parametrize("cout", [128, 64, 40])
+def test_conv3x3_thin_input_kernel(dev, cout):
+    """image heads on the thin-K kernel (bf16): 3 -> cout forward (+bias, ReLU) and the dgrad of a cout -> 3 conv"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d, Tape
+    rs = np.random.RandomState(cout)
+    n, h, w_ = 2, 12, 64
+    x = bf16_round(rs.standard_normal((n, 3, h, w_)).astype(np.float32))
+    wt = bf16_round((rs.standard_normal((cout, 3, 3, 3)) / np.sqrt(27)).astype(np.float32))
+    b = (0.1 * rs.standard_normal(cout)).astype(np.float32)
+    yr = F.relu(F.conv2d(torch.from_numpy(x), torch.from_numpy(wt), torch.from_numpy(b), padding=1)).numpy()
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        mod = Conv2d(3, cout, 3, 1, 1).to(dev)
+        with torch.no_grad():
+            mod.weight.copy_(T(wt, dev))
+            mod.bias.copy_(T(b, dev))
+        xp = K.nchw_to_nhwc_pad(T(x, dev), 8, torch.bfloat16)
+        y = mod.fwd(xp, None, act=K.ACT_RELU)
+        err = np.abs(y.float().permute(0, 3, 1, 2).cpu().numpy()[:, :cout] - yr).max() / np.abs(yr).max()
+        assert err < 1e-2, f"forward rel-to-max error {err}"
+        # dgrad of cout -> 3: gradient [n,h,w,8 (3 real)] -> [n,h,w,cout]
+        mod2 = Conv2d(cout, 3, 3, 1, 1).to(dev)
+        w2 = bf16_round((rs.standard_normal((3, cout, 3, 3)) / np.sqrt(cout * 9)).astype(np.float32))
+        with torch.no_grad():
+            mod2.weight.copy_(T(w2, dev))
+        xin = bf16_round(rs.standard_normal((n, cout, h, w_)).astype(np.float32))
+        go = bf16_round(rs.standard_normal((n, 3, h, w_)).astype(np.float32))
+        xr = torch.from_numpy(xin).requires_grad_(True)
+        (F.conv2d(xr, torch.from_numpy(w2), None, padding=1) * torch.from_numpy(go)).sum().backward()
+        tape = Tape()
+        xh = T(xin, dev, torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+        mod2.fwd(xh, tape)
+        dx = mod2.bwd(K.nchw_to_nhwc_pad(T(go, dev), 8, torch.bfloat16), tape, need_dw=False)
+        dref = xr.grad.numpy()
+        derr = np.abs(dx.float().permute(0, 3, 1, 2).cpu().numpy() - dref).max() / np.abs(dref).max()
+        assert derr < 1e-2, f"dgrad rel-to-max error {derr}"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("impl", [1, 2])
 def test_gemm_nt_tn(dev, dtype, impl):
