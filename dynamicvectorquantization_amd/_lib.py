@@ -95,6 +95,7 @@ SIGNATURES = {
     "dvq_embed_gather": (i32, [vp, i64, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp]),
     "dvq_embed_scatter_add": (i32, [vp, i64, vp, i32, i64, i64, i64, i64, i64, i64, vp, vp]),
     "dvq_cross_entropy": (i32, [vp, i32, i64, i64, i64, vp, i64, vp, vp, vp, vp, vp]),
+    "dvq_attn_decode": (i32, [vp, vp, vp, i32, i64, i64, i64, i64, i64, f32, vp, vp]),
     "dvq_dropout": (i32, [vp, i32, i64, f32, C.c_uint64, vp, vp]),
     "dvq_fill_f32": (i32, [vp, f32, i64, vp]),
 }

@@ -373,3 +373,67 @@ int dvq_dropout(const void* x, int dtype, int64_t n, float p, uint64_t seed, voi
 }
 
 }  // extern "C"
+
+// ---- single-query attention over a K/V cache (sampling with a cache: one new row per step) ----------------------------
+// q [B][C], kcache / vcache [B][Tmax][C], T = number of valid cache rows (the new row included); out [B][C].
+// One workgroup per (batch, head): scores by wave-wide dot products, softmax in LDS, then the value mix column-parallel.
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
+                                                          int nh, int hs, int Tlen, int64_t Tmax, float scale, T* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = reinterpret_cast<float*>(smem);          // [Tlen] scores -> probabilities
+    float* qs = sc + Tlen;                               // [hs]
+    __shared__ float red[8];
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t C = (int64_t)nh * hs;
+    for (int d = tid; d < hs; d += 256) qs[d] = ElemIO<T>::load(q + b * C + h * hs + d);
+    __syncthreads();
+    const T* kb = kc + (int64_t)b * Tmax * C + h * hs;
+    for (int t = wave; t < Tlen; t += 4) {
+        float acc = 0.f;
+        for (int d = lane; d < hs; d += 64) acc = fmaf(qs[d], ElemIO<T>::load(kb + (int64_t)t * C + d), acc);
+        acc = wave_sum(acc);
+        if (lane == 0) sc[t] = acc * scale;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int t = tid; t < Tlen; t += 256) m = fmaxf(m, sc[t]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int t = tid; t < Tlen; t += 256) {
+        const float e = __expf(sc[t] - m);
+        sc[t] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[4 + wave] = s;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    const T* vb = vc + (int64_t)b * Tmax * C + h * hs;
+    for (int d = tid; d < hs; d += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < Tlen; ++t) acc = fmaf(sc[t], ElemIO<T>::load(vb + (int64_t)t * C + d), acc);
+        ElemIO<T>::store(out + b * C + h * hs + d, acc * inv);
+    }
+}
+
+}  // namespace
+
+extern "C" int dvq_attn_decode(const void* q, const void* kcache, const void* vcache, int dtype, int64_t B, int64_t n_head, int64_t head_size,
+                               int64_t T, int64_t Tmax, float scale, void* out, dvq_stream_t stream) {
+    DVQ_REQUIRE(q && kcache && vcache && out && B > 0 && n_head > 0 && head_size > 0 && T > 0 && T <= Tmax && T <= 16000 &&
+                    B * n_head < (1ll << 31),
+                DVQ_EINVAL, "dvq_attn_decode: bad arguments");
+    const int lds = (int)((T + head_size) * sizeof(float));
+    DVQ_DISPATCH_DTYPE(dtype, TT, attn_decode_kernel<TT><<<dim3((unsigned)(B * n_head)), dim3(256), lds, (hipStream_t)stream>>>(
+                                      (const TT*)q, (const TT*)kcache, (const TT*)vcache, (int)n_head, (int)head_size, (int)T, Tmax, scale,
+                                      (TT*)out););
+    DVQ_CHECK_LAUNCH("attn_decode");
+    return DVQ_OK;
+}

@@ -704,3 +704,12 @@ def dropout(x, p, seed):
 
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     check(lib().dvq_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, _s()), "dvq_adamw")
+
+
+def attn_decode(q, kcache, vcache, n_head, t, scale):
+    """q [B,C], caches [B,Tmax,C]; attention of the newest row over the first t cache rows -> [B,C]"""
+    b, c = q.shape
+    out = torch.empty_like(q)
+    check(lib().dvq_attn_decode(_p(q), _p(kcache), _p(vcache), dt(q), b, n_head, c // n_head, t, kcache.shape[1], scale, _p(out), _s()),
+          "dvq_attn_decode")
+    return out

@@ -154,6 +154,16 @@ class Linear(nn.Module):
             nn.init.uniform_(self.bias, -bound, bound)
 
     def _w(self, dtype):
+        """compute-dtype copy of the weight (+ zero-padded rows / bias), cached until the parameters change"""
+        ep = (rt.param_epoch(self.weight), self.weight.data_ptr(), self.weight._version)
+        hit = getattr(self, "_wcache", None)
+        if hit is not None and hit[0] == (ep, dtype):
+            return hit[1], hit[2]
+        w, b = self._w_uncached(dtype)
+        self._wcache = ((ep, dtype), w, b)
+        return w, b
+
+    def _w_uncached(self, dtype):
         w = K.cast(self.weight.detach().contiguous(), dtype)
         b = self.bias.detach() if self.bias is not None else None
         if self.out_p != self.out_features:

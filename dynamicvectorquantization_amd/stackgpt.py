@@ -166,6 +166,100 @@ class Block(nn.Module):
         return K.add(dx1, self.ln1.bwd(dh1, tape.child("ln1")))
 
 
+def _attn_append(attn, x2d, b, n, cache, t0):
+    """CausalSelfAttention over a K/V cache: append n rows per sequence (rows t0 .. t0+n-1) and attend causally over rows
+    [0, t0+n).  cache = (k [B,Tmax,C], v [B,Tmax,C]).  n == 1 uses the single-query kernel, otherwise per-head GEMMs."""
+    c = x2d.shape[1]
+    nh, hs = attn.n_head, c // attn.n_head
+    k = attn.key.fwd(x2d, None)
+    q = attn.query.fwd(x2d, None)
+    v = attn.value.fwd(x2d, None)
+    kc, vc = cache
+    kc[:, t0:t0 + n].copy_(k.view(b, n, c))
+    vc[:, t0:t0 + n].copy_(v.view(b, n, c))
+    t = t0 + n
+    scale = 1.0 / math.sqrt(hs)
+    if n == 1:
+        y = K.attn_decode(q, kc, vc, nh, t, scale)
+    else:
+        tmax = kc.shape[1]
+        s = torch.empty(b * nh * n * t, dtype=x2d.dtype, device=x2d.device)
+        qf, kf = q.reshape(-1), kc.reshape(-1)
+        for h in range(nh):
+            K.gemm_nt(qf[h * hs:], kf[h * hs:], n, t, hs, c, c, t, batch=b, sa=n * c, sb=tmax * c, sc=nh * n * t, out=s[h * n * t:])
+        K.softmax_causal_(s, b * nh * n, t, n, t0, scale)
+        # P [n, t] x V [t, hs]: V^T per head from the cache rows [0, t)
+        vt = K.transpose(vc[:, :t].contiguous(), b, t, c).reshape(-1)             # [B, C, t]
+        y = torch.empty(b * n, c, dtype=x2d.dtype, device=x2d.device)
+        yf = y.reshape(-1)
+        tp8 = t % 8 == 0
+        for h in range(nh):
+            K.gemm_nt(s[h * n * t:], vt[h * hs * t:], n, hs, t, t, t, c, batch=b, sa=nh * n * t, sb=c * t, sc=n * c, out=yf[h * hs:],
+                      impl=0 if tp8 else 1)
+    return attn.proj.fwd(y, None)
+
+
+def _block_append(blk, x2d, b, n, cache, t0):
+    a = _attn_append(blk.attn, blk.ln1.fwd(x2d, None), b, n, cache, t0)
+    x1 = K.add(x2d, a)
+    m = blk.mlp[2].fwd(K.gelu(blk.mlp[0].fwd(blk.ln2.fwd(x1, None), None)), None)
+    return K.add(x1, m)
+
+
+class DecodeState:
+    """K/V caches of both transformers + the position-transformer hidden rows of one sampling run (eval mode, no dropout).
+    The position transformer's row r is (content_r, position_r [, segment_r]); the content transformer's row r is that
+    hidden row plus the embedding of an `update` position token (stackgpt.py:189-196, 252-339)."""
+
+    def __init__(self, gpt, batch, max_rows):
+        cd = rt.compute_dtype()
+        dev, c = gpt.pos_emb.device, gpt.config.n_embd
+        self.gpt, self.b, self.max_rows = gpt, batch, max_rows
+        mk = lambda: (torch.zeros(batch, max_rows, c, dtype=cd, device=dev), torch.zeros(batch, max_rows, c, dtype=cd, device=dev))
+        self.pos_cache = [mk() for _ in gpt.position_transformer]
+        self.con_cache = [mk() for _ in gpt.content_transformer]
+        self.hidden = torch.zeros(batch, max_rows, c, dtype=cd, device=dev)
+        self.rows_pos = 0
+        self.rows_con = 0
+
+    def reset_content(self):
+        self.rows_con = 0
+
+    @torch.no_grad()
+    def position_rows(self, content_tok, pos_tok, pos_table, pos_pad, seg_tok=None):
+        """append n rows (tokens [B,n]) to the position transformer; -> position logits of the last appended row [B,V]"""
+        g, b = self.gpt, self.b
+        n, t0 = content_tok.shape[1], self.rows_pos
+        assert t0 + n <= self.max_rows, "DecodeState: increase max_rows"
+        ar = torch.arange(t0, t0 + n, device=content_tok.device)
+        pieces = [(g.content_emb.weight, content_tok.contiguous(), 0, None, False), (g.pos_emb, ar, 0, None, True),
+                  (pos_table, pos_tok.contiguous(), 0, None, False)]
+        if g.activate_segment and seg_tok is not None:
+            pieces.append((g.seg_emb.weight, seg_tok.contiguous(), 0, None, False))
+        x = g._embed(pieces, b, n, None, "").view(b * n, -1)
+        for blk, cache in zip(g.position_transformer, self.pos_cache):
+            x = _block_append(blk, x, b, n, cache, t0)
+        self.hidden[:, t0:t0 + n].copy_(x.view(b, n, -1))
+        self.rows_pos = t0 + n
+        last = x.view(b, n, -1)[:, -1].contiguous()
+        return g._head(g.position_head, last, None, "ph")[:, : g.config.fine_position_size].float()
+
+    @torch.no_grad()
+    def content_rows(self, upd_tok, upd_table):
+        """append the next n = upd_tok.shape[1] rows to the content transformer: hidden rows + embedding of the update position
+        tokens; -> content logits of the last appended row [B,V]"""
+        g, b = self.gpt, self.b
+        n, t0 = upd_tok.shape[1], self.rows_con
+        assert t0 + n <= self.rows_pos, "content rows cannot run ahead of the position transformer"
+        upd = g._embed([(upd_table, upd_tok.contiguous(), 0, None, False)], b, n, None, "")
+        x = K.add(self.hidden[:, t0:t0 + n].contiguous().view(b * n, -1), upd.view(b * n, -1))
+        for blk, cache in zip(g.content_transformer, self.con_cache):
+            x = _block_append(blk, x, b, n, cache, t0)
+        self.rows_con = t0 + n
+        last = x.view(b, n, -1)[:, -1].contiguous()
+        return g._head(g.content_head, last, None, "ch")[:, : g.config.vocab_size].float()
+
+
 class _Embedding(nn.Embedding):
     """nn.Embedding parameters (incl. padding_idx bookkeeping for state_dict / init parity); lookups run on dvq_embed_*"""
 

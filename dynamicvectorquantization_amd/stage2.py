@@ -388,8 +388,99 @@ class _SamplerMixin:
         return torch.multinomial(probs, num_samples=1) if sample else torch.topk(probs, k=1, dim=-1)[1]
 
     @torch.no_grad()
+    def _sample_cached(self, c_coarse, c_fine, c_pos_coarse, c_pos_fine, c_seg_coarse, c_seg_fine, temperature, sample, top_k, top_p,
+                       top_k_pos, top_p_pos, fix_fine_position):
+        """the same sampler with K/V caches: every step feeds ONE new row to each transformer instead of recomputing the whole
+        prefix (the reference's O(T^2) schedule).  The content transformer's coarse rows are re-filled once when the fine
+        stream starts, because the reference pairs them with different update positions in the two phases
+        (stackgpt.py:263 vs :331: shifted coarse positions while sampling coarse, unshifted ones afterwards)."""
+        from .stackgpt import DecodeState
+        tr = self.transformer
+        cpe, fpe = tr.content_coarse_pos_emb.weight, tr.content_fine_pos_emb.weight
+        seg = self.activate_segment
+        x_c, x_pc, x_sc = c_coarse, c_pos_coarse, c_seg_coarse
+        if self.activate_sos_for_fine_sequence:
+            x_f, x_pf, x_sf = c_fine, c_pos_fine, c_seg_fine
+        else:
+            x_f, x_pf, x_sf = c_fine[:, :0], c_pos_fine[:, :0], (c_seg_fine[:, :0] if c_seg_fine is not None else None)
+        b, dev = x_c.size(0), x_c.device
+        st = DecodeState(tr, b, self.hw1 * self.hw1 + self.fine_hw * self.fine_hw + 8)
+        zeros1 = torch.zeros(b, 1, dtype=torch.long, device=dev)
+        # ---- coarse stream
+        done = torch.zeros(b, 1, device=dev)
+        while not torch.all(done.bool()):
+            pl = st.position_rows(x_c[:, -1:], x_pc[:, -1:], cpe, None, x_sc[:, -1:] if seg else None)
+            ix_pos = self._draw(pl.unsqueeze(1), temperature, sample, top_k_pos, top_p_pos,
+                                lambda lg: self.avoid_repeat_or_enforce_pad_for_coarse_position(lg, x_pc, done))
+            x_pc = torch.cat((x_pc, ix_pos), dim=1)
+            done = done + (ix_pos == self.coarse_position_eos_code)
+            cl = st.content_rows(ix_pos, cpe)
+            ix = self._draw(cl.unsqueeze(1), temperature, sample, top_k, top_p, lambda lg: self.avoid_special_or_enforce_pad_for_content(lg, done))
+            if seg:
+                x_sc = torch.cat([x_sc, zeros1], dim=1)
+            x_c = torch.cat((x_c, ix), dim=1)
+        # ---- fine stream
+        n_coarse = x_c.shape[1]
+        st.reset_content()
+        done = torch.zeros(b, 1, device=dev)
+        fed_fine = 0
+        if fix_fine_position:
+            plan = self.transfer_sampled_coarse_position_to_remain_fine_position(x_pc)
+            taken = None
+        else:
+            plan = None
+            taken = self.transfer_sampled_coarse_position_to_sampled_fine_position(x_pc)
+        j = 1 if self.activate_sos_for_fine_sequence else 0
+        while True:
+            if fix_fine_position:
+                if j >= plan.size(1):
+                    break
+            elif torch.all(done.bool()):
+                break
+            # position rows that have not been fed yet: the last coarse row, then the fine rows
+            pl = None
+            if st.rows_pos == n_coarse - 1:
+                pl = st.position_rows(x_c[:, -1:], x_pc[:, -1:], cpe, None, x_sc[:, -1:] if seg else None)
+            while fed_fine < x_f.shape[1]:
+                pl = st.position_rows(x_f[:, fed_fine:fed_fine + 1], x_pf[:, fed_fine:fed_fine + 1], fpe, None,
+                                      x_sf[:, fed_fine:fed_fine + 1] if seg else None)
+                fed_fine += 1
+            if fix_fine_position:
+                ix_pos = plan[:, j].unsqueeze(-1)
+                j += 1
+            else:
+                ix_pos = self._draw(pl.unsqueeze(1), temperature, sample, top_k_pos, top_p_pos,
+                                    lambda lg: self.avoid_repeat_or_enforce_pad_for_fine_position(lg, taken, done))
+                taken = torch.cat([taken, ix_pos], dim=1)
+            x_pf = torch.cat((x_pf, ix_pos), dim=1)
+            done = done + (ix_pos == self.fine_position_eos_code)
+            # content rows: the coarse rows once (unshifted coarse positions), then one fine row per step
+            if st.rows_con == 0:
+                st.content_rows(x_pc[:, :n_coarse], cpe)
+            k = st.rows_con - n_coarse                       # fine rows already in the content transformer
+            cl = None
+            while st.rows_con < st.rows_pos:
+                cl = st.content_rows(x_pf[:, k + 1:k + 2], fpe)
+                k += 1
+            if cl is None:                                   # no fine <sos>: the first fine content comes from the last coarse row
+                st.reset_content()
+                cl = st.content_rows(x_pc[:, :n_coarse], cpe)
+            ix = self._draw(cl.unsqueeze(1), temperature, sample, top_k, top_p, lambda lg: self.avoid_special_or_enforce_pad_for_content(lg, done))
+            x_f = torch.cat((x_f, ix), dim=1)
+            if seg:
+                x_sf = torch.cat([x_sf, zeros1 + 1], dim=1)
+        x_c, x_pc = x_c[:, c_coarse.shape[1]:], x_pc[:, c_pos_coarse.shape[1]:]
+        if self.activate_sos_for_fine_sequence:
+            x_f, x_pf = x_f[:, c_fine.shape[1]:], x_pf[:, c_fine.shape[1]:]
+        return x_c, x_f, x_pc, x_pf
+
+    @torch.no_grad()
     def sample_from_scratch(self, c_coarse, c_fine, c_pos_coarse, c_pos_fine, c_seg_coarse, c_seg_fine, temperature=1.0, sample=True,
-                            top_k=None, top_p=None, top_k_pos=None, top_p_pos=None, process=True, fix_fine_position=False):
+                            top_k=None, top_p=None, top_k_pos=None, top_p_pos=None, process=True, fix_fine_position=False,
+                            kv_cache=True):
+        if kv_cache and not self.transformer.training:
+            return self._sample_cached(c_coarse, c_fine, c_pos_coarse, c_pos_fine, c_seg_coarse, c_seg_fine, temperature, sample,
+                                       top_k, top_p, top_k_pos, top_p_pos, fix_fine_position)
         tr = self.transformer
         x_c, x_pc, x_sc = c_coarse, c_pos_coarse, c_seg_coarse
         if self.activate_sos_for_fine_sequence:

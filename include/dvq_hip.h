@@ -333,6 +333,11 @@ int dvq_embed_scatter_add(const int64_t* idx, int64_t idx_bstride, const void* d
  * when dlogits != NULL, dlogits = (softmax - onehot) * gscale_dev[0] (0 on ignored rows and on columns >= V; row stride ldl) */
 int dvq_cross_entropy(const void* logits, int dtype, int64_t rows, int64_t V, int64_t ldl, const int64_t* target, int64_t ignore_index,
                       float* loss_sum, float* count, const float* gscale_dev, void* dlogits, dvq_stream_t stream);
+/* Attention of ONE new query row per sequence over a K/V cache (KV-cached sampling; the reference's sampler recomputes the
+ * whole prefix, stackgpt.py:234-339): q [B][C], kcache / vcache [B][Tmax][C] (C = n_head * head_size), T valid rows incl.
+ * the new one; out [B][C] = softmax(scale * q K^T) V per head. */
+int dvq_attn_decode(const void* q, const void* kcache, const void* vcache, int dtype, int64_t B, int64_t n_head, int64_t head_size,
+                    int64_t T, int64_t Tmax, float scale, void* out, dvq_stream_t stream);
 /* nn.Dropout(p) with a counter-based hash RNG: y = x * keep / (1-p); the same (seed) reproduces the mask for the backward */
 int dvq_dropout(const void* x, int dtype, int64_t n, float p, uint64_t seed, void* y, dvq_stream_t stream);
 

@@ -226,8 +226,9 @@ def _sampler_model(dev, order):
     return model
 
 
+@pytest.mark.parametrize("kv_cache", [True, False])
 @pytest.mark.parametrize("order", ["region-first", "row-first"])
-def test_sampler_greedy_golden(dev, order):
+def test_sampler_greedy_golden(dev, order, kv_cache):
     """Dualformer.sample_from_scratch (greedy + top-k, so no RNG) reproduces the reference's sequences token for token in both
     fine-position modes, and the decoded code maps"""
     from dynamicvectorquantization_amd import runtime as rt
@@ -237,8 +238,9 @@ def test_sampler_greedy_golden(dev, order):
         model = _sampler_model(dev, order)
         c = model.encode_to_c(torch.zeros(3, 3, 64, 64, device=dev))
         for fix in (False, True):
+            # kv_cache=True: one new row per step through K/V caches; False: the reference's whole-prefix recomputation
             res = model.sample_from_scratch(*c, temperature=1.0, sample=False, top_k=50, top_p=None, top_k_pos=None, top_p_pos=None,
-                                            process=False, fix_fine_position=fix)
+                                            process=False, fix_fine_position=fix, kv_cache=kv_cache)
             for name, r in zip(("coarse_content", "fine_content", "coarse_position", "fine_position"), res):
                 assert np.array_equal(r.cpu().numpy(), g[f"{tag}_{int(fix)}_{name}"]), (fix, name)
             codes = model.permuter.forward_back(*res)
