@@ -50,6 +50,7 @@ TARGET_ALIASES = {
     "models.stage1.utils.Scheduler_LinearWarmup_CosineDecay": (_P + "trainer", "scheduler_linear_warmup_cosine_decay"),
     "modules.dynamic_modules.stackgpt.StackGPT": (_P + "stackgpt", "StackGPT"),
     "models.stage2_dynamic.dqtransformer_uncond_entropy.Dualformer": (_P + "stage2", "Dualformer"),
+    "models.stage2_dynamic.dqtransformer_class2_entropy.Dualformer": (_P + "stage2", "ClassDualformer"),
     "models.stage2.utils.learning_rate_schedule": (_P + "trainer", "scheduler_linear_warmup_cosine_decay"),
     "modules.dynamic_modules.permuter.DualGrainSeperatePermuter": (_P + "stage2", "DualGrainSeperatePermuter"),
     "modules.dynamic_modules.label_provider.PositionAwareSOSProvider": (_P + "stage2", "PositionAwareSOSProvider"),

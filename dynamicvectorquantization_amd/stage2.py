@@ -167,9 +167,9 @@ class Dualformer(_SamplerMixinBase, nn.Module):
         self.activate_segment = transformer_config["params"]["segment_size"] > 0
         pp, up = permuter_config["params"], uncond_stage_config["params"]
         self.content_pad_code, self.content_eos_code = pp["content_pad_code"], pp["content_eos_code"]
-        self.content_sos_code = up["coarse_sos"]
+        self.content_sos_code = up.get("coarse_sos")
         self.coarse_position_eos_code, self.coarse_position_pad_code = pp["coarse_position_eos_code"], pp["coarse_position_pad_code"]
-        self.fine_position_sos_code = up["fine_pos_sos"]
+        self.fine_position_sos_code = up.get("fine_pos_sos")
         self.fine_position_eos_code, self.fine_position_pad_code = pp["fine_position_eos_code"], pp["fine_position_pad_code"]
         self.hw1, self.fine_hw = pp["coarse_hw"], pp["fine_hw"]
         self.hw2 = self.fine_hw // self.hw1
@@ -362,20 +362,23 @@ class _SamplerMixin:
         drawn.scatter_(1, torch.where(alive, pos.clamp(0, n - 1), torch.full_like(pos, n)), 1)
         return drawn[:, :n].reshape(-1, self.hw1, self.hw1)
 
-    def _fine_positions_of(self, cell_flags):
+    def _fine_prefix(self, coarse_position):
+        """first column of the transferred fine-position stream: the fine <sos> position code (unconditional model)"""
+        return torch.full_like(coarse_position[:, :1], self.fine_position_sos_code)
+
+    def _fine_positions_of(self, cell_flags, coarse_position):
         """fine-position stream (<eos>-terminated, padded) of the cells flagged 1, in the permuter's fine order"""
         dummy = torch.zeros(cell_flags.shape[0], self.fine_hw, self.fine_hw, dtype=torch.long, device=cell_flags.device)
         fp = self.permuter(indices=dummy, grain_indices=cell_flags)["fine_position"]
         if self.activate_sos_for_fine_sequence:
-            sos = torch.full((fp.shape[0], 1), self.fine_position_sos_code, dtype=torch.long, device=fp.device)
-            fp = torch.cat([sos, fp], dim=1)
+            fp = torch.cat([self._fine_prefix(coarse_position), fp], dim=1)
         return fp
 
     def transfer_sampled_coarse_position_to_sampled_fine_position(self, coarse_position):
-        return self._fine_positions_of(self._coarse_cells_drawn(coarse_position))
+        return self._fine_positions_of(self._coarse_cells_drawn(coarse_position), coarse_position)
 
     def transfer_sampled_coarse_position_to_remain_fine_position(self, coarse_position):
-        return self._fine_positions_of(1 - self._coarse_cells_drawn(coarse_position))
+        return self._fine_positions_of(1 - self._coarse_cells_drawn(coarse_position), coarse_position)
 
     @staticmethod
     def _draw(logits, temperature, sample, k, p, constrain):
@@ -543,3 +546,39 @@ class _SamplerMixin:
 for _name, _fn in list(vars(_SamplerMixin).items()):
     if not _name.startswith("__"):
         setattr(_SamplerMixinBase, _name, _fn)
+
+
+class ClassDualformer(Dualformer):
+    """models/stage2_dynamic/dqtransformer_class2_entropy.py: class-conditional variant.  The start tokens are the class
+    label shifted above the code / position vocabularies (ClassAwareSOSProvider), so the sampler masks every id above
+    <eos> instead of a single <sos> id, and the transferred fine-position stream starts with the label's position token."""
+
+    def __init__(self, transformer_config, first_stage_config, class_cond_stage_config, permuter_config=None, **kw):
+        super().__init__(transformer_config, first_stage_config, uncond_stage_config=class_cond_stage_config,
+                         permuter_config=permuter_config, **kw)
+        self.cond_stage_key = "class_label"
+        del self.content_sos_code, self.fine_position_sos_code
+
+    def get_xc(self, batch, N=None):
+        x, c = self.get_input(batch, self.first_stage_key), batch[self.cond_stage_key]
+        if N is not None:
+            x, c = x[:N], c[:N]
+        return x, c
+
+    def _fine_prefix(self, coarse_position):
+        return coarse_position[:, :1]
+
+    def avoid_repeat_or_enforce_pad_for_fine_position(self, logits, sampled_position, flag):
+        forbid = torch.zeros_like(logits, dtype=torch.bool)
+        forbid.scatter_(1, sampled_position, True)
+        forbid[:, self.fine_position_pad_code] = True
+        out = _mask_rows(logits, flag, forbid, self.fine_position_eos_code, self.fine_position_pad_code)
+        live = ~flag.bool().view(-1)
+        out[live, self.fine_position_eos_code + 1:] = -float("Inf")      # the class-label ids sit above <eos>
+        return out
+
+    def avoid_special_or_enforce_pad_for_content(self, logits, flag):
+        forbid = torch.zeros_like(logits, dtype=torch.bool)
+        forbid[:, self.content_pad_code] = True
+        forbid[:, self.content_eos_code:] = True                          # <eos> and every class-label id
+        return _mask_rows(logits, flag, forbid, None, self.content_pad_code)

@@ -263,3 +263,38 @@ def test_sampler_constraints_and_filters_golden(dev):
     assert np.array_equal(model.avoid_special_or_enforce_pad_for_content(lgc, flag).cpu().numpy(), g["h_content"])
     assert np.array_equal(stage2.top_k_logits(lgc, 20).cpu().numpy(), g["h_topk"])
     np.testing.assert_allclose(stage2.top_p_logits(torch.softmax(lgc, -1), 0.6).cpu().numpy(), g["h_topp"], rtol=1e-5, atol=1e-8)
+
+
+def test_class_conditional_dualformer(dev):
+    """dqtransformer_class2_entropy variant: class-label start tokens, a train step, and the sampler never emits an id above
+    <eos> (content) / above <eos> (fine positions)"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    from dynamicvectorquantization_amd.trainer import Trainer
+    cfg = dualformer_config()
+    p = cfg["params"]
+    p["transformer_config"]["params"].update(vocab_size=524, coarse_position_size=28, fine_position_size=76, embd_pdrop=0.0,
+                                             resid_pdrop=0.0, attn_pdrop=0.0)
+    p["class_cond_stage_config"] = {"target": "modules.dynamic_modules.label_provider.ClassAwareSOSProvider", "params": dict(
+        n_classes=10, threshold_content=514, threshold_coarse_position=18, threshold_fine_position=66, coarse_seg_sos=0, fine_seg_sos=1)}
+    del p["uncond_stage_config"]
+    cfg["target"] = "models.stage2_dynamic.dqtransformer_class2_entropy.Dualformer"
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        torch.manual_seed(1)
+        model = instantiate_from_config(cfg).to(dev)
+        model.learning_rate, model.min_learning_rate, model.training_steps, model.steps_per_epoch = 1e-3, 0.0, 100, 10
+        model.train()
+        x = torch.from_numpy(synth.half_flat_images(3, 64, seed=5)).to(dev)
+        lab = torch.tensor([1, 4, 9], device=dev)
+        tr = Trainer(model, max_steps=2)
+        l0 = tr.train_step({"image": x, "class_label": lab}, 0)
+        assert torch.isfinite(l0[0])
+        model.eval()
+        c = model.encode_to_c(lab)
+        assert c[0].view(-1).tolist() == [515, 518, 523] and c[2].view(-1).tolist() == [19, 22, 27]
+        for fix in (False, True):
+            cc, fc, cp, fp = model.sample_from_scratch(*c, sample=True, top_k=20, top_k_pos=10, process=False, fix_fine_position=fix)
+            assert int(cc.max()) <= 513 and int(fc.max()) <= 513 and int(fp.max()) <= 65 and int(cp.max()) <= 17
+            img = model.decode_to_img(cc, fc, cp, fp)
+            assert bool(torch.isfinite(img).all())
