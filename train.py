@@ -90,9 +90,18 @@ def run(rank, world, opt, unknown):
     trainer = Trainer(model, max_steps=total, log_every=10 if rank == 0 else 0)
     pool = [torch.from_numpy(synth.half_flat_images(bs, size, seed=opt.seed + 977 * rank + i)).to(dev) for i in range(4)]
 
+    image_key = getattr(model, "image_key", None) or getattr(model, "first_stage_key", "image")
+    n_classes = None
+    if getattr(model, "cond_stage_key", None) == "class_label":         # class-conditional stage 2: synthetic labels
+        n_classes = int(getattr(model.cond_stage_model, "n_classes", 1000))
+
     def batch_fn(step):
         model.current_epoch = step // opt.steps_per_epoch
-        return {model.image_key: pool[step % len(pool)]}
+        batch = {image_key: pool[step % len(pool)]}
+        if n_classes is not None:
+            g = torch.Generator().manual_seed(opt.seed + step)
+            batch["class_label"] = torch.randint(0, n_classes, (bs,), generator=g).to(dev)
+        return batch
 
     trainer.fit(batch_fn)
     if rank == 0:
