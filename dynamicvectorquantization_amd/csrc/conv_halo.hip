@@ -43,6 +43,7 @@ struct HaloParams {
     float act_slope;     // output activation v > 0 ? v : act_slope * v (1: none, 0: ReLU, 0.2: LeakyReLU), applied last
     int res_mask;        // 1: R is not added but gates the result: v *= (R > 0 ? 1 : mask_slope)  (backward of ReLU / LeakyReLU)
     float mask_slope;
+    int dbg;             // profiling experiments only (DVQ_HALO_DBG): 1 = skip the epilogue, 2 = skip the MFMA loop
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int swzB = (l31 >> 1) & 7;
-    const int nchunks = p.Cin >> 6;
+    const int nchunks = p.dbg == 2 ? 0 : (p.Cin >> 6);
     for (int c = 0; c < nchunks; ++c) {
         const int c0 = c * 64;
         issue_halo(c0);                 // safe: the barrier that ended the previous chunk's last tap is behind us
@@ -196,6 +197,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
     }
 
     // ---- epilogue: stage the 256 px x 128 co tile as bf16 rows of 256 B, then 16-byte global stores -----------
+    // (measured alternatives, both slower: 4-byte stores straight from the accumulators after a DPP lane-pair exchange;
+    //  staggering the first wave of workgroups so that epilogues and MFMA loops of CU neighbours interleave)
+    if (p.dbg == 1) {
+        if (acc[0][0][0] == 12345.678f) p.Y[0] = 0;       // keep the accumulators alive
+        return;
+    }
     bf16_t* st = reinterpret_cast<bf16_t*>(smem);
     const bool early_act = p.R == nullptr || p.res_mask;     // no residual add between the accumulator and the activation
 #pragma unroll
@@ -305,6 +312,11 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     p.up = up;
     p.gn_ss = gn_ss; p.out_stats = out_stats; p.out_groups = out_groups;
     p.act_slope = act_slope; p.res_mask = res_mask; p.mask_slope = mask_slope;
+    static const int dbg_env = [] {
+        const char* e = getenv("DVQ_HALO_DBG");
+        return e != nullptr ? atoi(e) : 0;
+    }();
+    p.dbg = dbg_env;
     const int64_t blocks = N * p.tiles_y * p.tiles_x * p.gn;
     if (blocks >= (1ll << 31)) return 0;
     static const int nw_env = [] {
