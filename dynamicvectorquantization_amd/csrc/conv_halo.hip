@@ -197,8 +197,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
     }
 
     // ---- epilogue: stage the 256 px x 128 co tile as bf16 rows of 256 B, then 16-byte global stores -----------
-    // (measured alternatives, both slower: 4-byte stores straight from the accumulators after a DPP lane-pair exchange;
-    //  staggering the first wave of workgroups so that epilogues and MFMA loops of CU neighbours interleave)
+    // (measured alternatives, all slower: 4-byte stores straight from the accumulators after a DPP lane-pair exchange;
+    //  staggering the first wave of workgroups so that epilogues and MFMA loops of CU neighbours interleave; 8 waves x
+    //  (1 x 4) tiles at 4 waves per SIMD -- 5 fragment reads per 4 MFMAs instead of 6 per 8 makes the loop LDS-bound.
+    //  DVQ_HALO_DBG=1/2 splits the time: at 128 -> 128 channels, 256^2, B=64 the MFMA loop takes 1.29 ms and this
+    //  epilogue 0.35 ms of 1.63 ms, i.e. they do not overlap across the two workgroups of a CU.)
     if (p.dbg == 1) {
         if (acc[0][0][0] == 12345.678f) p.Y[0] = 0;       // keep the accumulators alive
         return;
