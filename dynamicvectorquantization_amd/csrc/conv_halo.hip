@@ -226,59 +226,44 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
     float gs[8], gq[8];                 // output statistics of this thread's 8 channels (chunk tid & 15 in every iteration)
 #pragma unroll
     for (int k = 0; k < 8; ++k) gs[k] = gq[k] = 0.f;
-    // groups of 4 iterations: the staged rows and the residual / mask rows of a whole group are requested before any of them is
-    // consumed (one load-latency wait per group instead of one per 16-byte chunk)
-    constexpr int ITERS = 256 * CPRW / NTH, GRP = 4;
 #pragma unroll
-    for (int i0 = 0; i0 < ITERS; i0 += GRP) {
-        uint4 vv[GRP], rr[GRP];
-        int64_t oo[GRP];
-        bool okk[GRP];
+    for (int i = 0; i < 256 * CPRW / NTH; ++i) {
+        const int q = tid + NTH * i;
+        const int lp = q / CPRW, ch = q % CPRW;
+        const int col = n0 + ch * 8;
+        if (col >= p.Cout) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(smem + lp * (CO_T * 2) + ch * 16);
+        const int64_t o = ((img + (int64_t)(y0 + (lp >> 5)) * p.W + x0 + (lp & 31)) * p.Cout) + col;
+        if (p.R) {
+            const uint4 rv = *reinterpret_cast<const uint4*>(p.R + o);
+            unsigned* pv = &v.x;
+            const unsigned* pr = &rv.x;
 #pragma unroll
-        for (int g = 0; g < GRP; ++g) {
-            const int q = tid + NTH * (i0 + g);
-            const int lp = q / CPRW, ch = q % CPRW;
-            const int col = n0 + ch * 8;
-            okk[g] = col < p.Cout;
-            oo[g] = ((img + (int64_t)(y0 + (lp >> 5)) * p.W + x0 + (lp & 31)) * p.Cout) + col;
-            vv[g] = *reinterpret_cast<const uint4*>(smem + lp * (CO_T * 2) + ch * 16);
-            rr[g] = uint4{0, 0, 0, 0};
-            if (p.R != nullptr && okk[g]) rr[g] = *reinterpret_cast<const uint4*>(p.R + oo[g]);
-        }
-#pragma unroll
-        for (int g = 0; g < GRP; ++g) {
-            if (!okk[g]) continue;
-            uint4 v = vv[g];
-            if (p.R) {
-                unsigned* pv = &v.x;
-                const unsigned* pr = &rr[g].x;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float lo = __uint_as_float(pv[k] << 16), hi = __uint_as_float(pv[k] & 0xffff0000u);
-                    const float rlo = __uint_as_float(pr[k] << 16), rhi = __uint_as_float(pr[k] & 0xffff0000u);
-                    if (p.res_mask) {
-                        lo *= rlo > 0.f ? 1.f : p.mask_slope;
-                        hi *= rhi > 0.f ? 1.f : p.mask_slope;
-                    } else {
-                        lo += rlo;
-                        hi += rhi;
-                        lo = lo > 0.f ? lo : lo * p.act_slope;
-                        hi = hi > 0.f ? hi : hi * p.act_slope;
-                    }
-                    pv[k] = pack_bf16x2(lo, hi);
+            for (int k = 0; k < 4; ++k) {
+                float lo = __uint_as_float(pv[k] << 16), hi = __uint_as_float(pv[k] & 0xffff0000u);
+                const float rlo = __uint_as_float(pr[k] << 16), rhi = __uint_as_float(pr[k] & 0xffff0000u);
+                if (p.res_mask) {
+                    lo *= rlo > 0.f ? 1.f : p.mask_slope;
+                    hi *= rhi > 0.f ? 1.f : p.mask_slope;
+                } else {
+                    lo += rlo;
+                    hi += rhi;
+                    lo = lo > 0.f ? lo : lo * p.act_slope;
+                    hi = hi > 0.f ? hi : hi * p.act_slope;
                 }
+                pv[k] = pack_bf16x2(lo, hi);
             }
-            *reinterpret_cast<uint4*>(p.Y + oo[g]) = v;
-            if (p.out_stats != nullptr) {
-                const unsigned* pv = &v.x;
+        }
+        *reinterpret_cast<uint4*>(p.Y + o) = v;
+        if (p.out_stats != nullptr) {
+            const unsigned* pv = &v.x;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float lo = __uint_as_float(pv[k] << 16), hi = __uint_as_float(pv[k] & 0xffff0000u);
-                    gs[2 * k] += lo;
-                    gq[2 * k] = fmaf(lo, lo, gq[2 * k]);
-                    gs[2 * k + 1] += hi;
-                    gq[2 * k + 1] = fmaf(hi, hi, gq[2 * k + 1]);
-                }
+            for (int k = 0; k < 4; ++k) {
+                const float lo = __uint_as_float(pv[k] << 16), hi = __uint_as_float(pv[k] & 0xffff0000u);
+                gs[2 * k] += lo;
+                gq[2 * k] = fmaf(lo, lo, gq[2 * k]);
+                gs[2 * k + 1] += hi;
+                gq[2 * k + 1] = fmaf(hi, hi, gq[2 * k + 1]);
             }
         }
     }
