@@ -538,6 +538,130 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Wide NT GEMM (bf16): 256 x 256 macro tile, 8 waves x (2 x 4) 32x32x16 MFMA tiles, 64-element K slabs double-buffered through
+// LDS-DMA (2 x 64 KiB), one workgroup per CU.  Six fragment reads feed eight MFMAs (the 128 x 128 kernel above needs four
+// per four) and every operand byte fetched from L2 feeds twice as many flops: used for the large plain GEMMs (StackGPT
+// linears and their input gradients, attention score products).  Same swizzle / zero-page conventions as above.
+// -------------------------------------------------------------------------------------------------
+constexpr int WT = 256;                       // macro tile (rows and columns)
+constexpr int WOPB = WT * GROW;               // 32 KiB per operand slab
+constexpr int WSTAGEB = 2 * WOPB;             // 64 KiB per stage
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_wide_kernel(NtParams p) {
+    using T = bf16_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                 // 4 x 2 waves: 64 rows x 128 columns each
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wi = xcd_remap(blockIdx.x, p.gm * p.gn);
+    const int m0 = (wi / p.gn) * WT, n0 = (wi % p.gn) * WT;
+    const int64_t bz = blockIdx.z;
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
+    const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
+    const T* zero = reinterpret_cast<const T*>(g_zero_page);
+    const int lrow = lane >> 3, cpos = lane & 7;
+    int64_t aoff[4], boff[4];
+    bool aok[4], bok[4];
+    int cg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int trow = wave * 32 + i * 8 + lrow;
+        cg[i] = cpos ^ ((trow >> 1) & 7);
+        aok[i] = m0 + trow < p.M;
+        bok[i] = n0 + trow < p.Ncols;
+        aoff[i] = (int64_t)(aok[i] ? m0 + trow : 0) * p.lda;
+        boff[i] = (int64_t)(bok[i] ? n0 + trow : 0) * p.ldb;
+    }
+    auto issue = [&](int j, int buf) {
+        char* sa = smem + buf * WSTAGEB + wave * 32 * GROW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ke = (j * 8 + cg[i]) * 8;
+            const bool kok = ke < p.Ktot;
+            const T* srcA = (kok && aok[i]) ? Ag + aoff[i] + ke : zero;
+            const T* srcB = (kok && bok[i]) ? Bg + boff[i] + ke : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcA,
+                                             (__attribute__((address_space(3))) void*)(sa + i * 8 * GROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcB,
+                                             (__attribute__((address_space(3))) void*)(sa + WOPB + i * 8 * GROW), 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int swz = (l31 >> 1) & 7;                           // rows differ from l31 by multiples of 32: same swizzle
+    const int nk = (p.Ktot + 63) / 64;
+    issue(0, 0);
+    __syncthreads();
+    for (int j = 0; j < nk; ++j) {
+        const int buf = j & 1;
+        if (j + 1 < nk) issue(j + 1, buf ^ 1);
+        const char* pa = smem + buf * WSTAGEB + (wm * 64 + l31) * GROW;
+        const char* pb = smem + buf * WSTAGEB + WOPB + (wn * 128 + l31) * GROW;
+        bf16x8 a[2][2], b[2][4];
+        auto load_frags = [&](int ks, int slot) {
+            const int off = ((ks * 2 + half) ^ swz) << 4;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[slot][t] = *reinterpret_cast<const bf16x8*>(pa + t * 32 * GROW + off);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[slot][t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * GROW + off);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) load_frags(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][mt], b[ks & 1][nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    // epilogue: the 256 x 256 tile is staged as bf16 (128 KiB = both stages) and leaves in 16-byte stores
+    T* st = reinterpret_cast<T*>(smem);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int lc = wn * 128 + nt * 32 + l31;
+        const float bcol = (p.bias_mode == 1 && n0 + lc < p.Ncols) ? p.bias[n0 + lc] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[mt][nt][r] * p.alpha + bcol;
+                if (p.bias_mode == 2 && m0 + lr < p.M) v += p.bias[m0 + lr];
+                v = v > 0.f ? v : v * p.act_slope;
+                st[lr * WT + lc] = f32_to_bf16(v);
+            }
+    }
+    __syncthreads();
+    T* __restrict__ Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
+#pragma unroll 4
+    for (int i = 0; i < (WT * WT / 8) / 512; ++i) {
+        const int q = tid + 512 * i;
+        const int lr = q >> 5, ch = q & 31;
+        const int row = m0 + lr, col = n0 + ch * 8;
+        if (row >= p.M || col >= p.Ncols) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * (WT * 2) + ch * 16);
+        T* dst = Cg + (int64_t)row * p.ldc + col;
+        if (col + 8 <= p.Ncols) {
+            *reinterpret_cast<uint4*>(dst) = v;
+        } else {
+            const T* sv = reinterpret_cast<const T*>(&v);
+            for (int k = 0; k < 8 && col + k < p.Ncols; ++k) dst[k] = sv[k];
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // TN kernel (wgrad / generic).  C fp32, accumulated with atomics; grid.y splits the reduction.
 // -------------------------------------------------------------------------------------------------
 struct TnParams;
@@ -1042,11 +1166,28 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
     p.gn = (int)cdiv64(p.Ncols, TILE);
     bool mfma_ok = p.Ktot % VN == 0 && p.ldb % VN == 0 && p.lda % VN == 0 && (p.stride == 1 || p.stride == 2);
     if (p.mode == MODE_GEMM) mfma_ok = mfma_ok && (p.sA % VN == 0) && (p.sB % VN == 0);
-    DVQ_REQUIRE(!(impl >= 2 && !mfma_ok), DVQ_ESHAPE,
+    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && !mfma_ok), DVQ_ESHAPE,
                 "igemm_nt: MFMA path needs K, lda, ldb multiples of %d (K=%d lda=%lld ldb=%lld) and stride 1/2", VN,
                 p.Ktot, (long long)p.lda, (long long)p.ldb);
     DVQ_REQUIRE(!(impl == 3 && !mfma_ok), DVQ_ESHAPE, "igemm_nt: register-staged MFMA path unsupported for this shape");
-    const bool use_mfma = impl == 2 || impl == 3 || (impl == 0 && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
+    const bool use_mfma = impl == 2 || impl == 3 || ((impl == 0 || impl == 5) && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
+    if constexpr (sizeof(T) == 2) {
+        // 256 x 256 macro tiles pay off on long reductions that fill the chip for several rounds (8192^3: 1036 vs 812 TFLOP/s);
+        // on the StackGPT shapes (K = 1024 .. 4096, 324 .. 1296 tiles) the 128 x 128 kernel is faster (tools/gemm_probe.py),
+        // so the automatic choice is conservative.  impl == 5 forces the wide kernel (tests).
+        if ((impl == 0 || impl == 5) && mfma_ok && p.mode == MODE_GEMM && p.R == nullptr && p.ldc % VN == 0 && p.M >= 256 &&
+            p.Ncols >= 256) {
+            const int64_t wgm = cdiv64(p.M, WT), wgn = cdiv64(p.Ncols, WT);
+            if (impl == 5 || (p.Ktot >= 8192 && wgm * wgn * batch >= 768)) {
+                p.gm = (int)wgm;
+                p.gn = (int)wgn;
+                dvq_ensure_dynamic_lds((const void*)gemm_nt_wide_kernel, 2 * WSTAGEB);
+                gemm_nt_wide_kernel<<<dim3((unsigned)(wgm * wgn), 1, (unsigned)batch), dim3(512), 2 * WSTAGEB, s>>>(p);
+                DVQ_CHECK_LAUNCH("gemm_nt_wide");
+                return DVQ_OK;
+            }
+        }
+    }
     if (use_mfma && impl != 3) {
         dim3 grid((unsigned)(p.gm * p.gn), 1, (unsigned)batch);
         const bool tapu = p.mode != MODE_GEMM && ((p.lda / VN) % 8) == 0;
@@ -1079,7 +1220,7 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
     constexpr int VN = Vec<T>::N;
     constexpr int BK = Vec<T>::BK;
     bool mfma_ok = p.lda % VN == 0 && p.ldb % VN == 0 && p.sA % VN == 0 && p.sB % VN == 0;
-    DVQ_REQUIRE(!(impl >= 2 && !mfma_ok), DVQ_ESHAPE, "igemm_tn: MFMA path needs lda, ldb multiples of %d", VN);
+    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && !mfma_ok), DVQ_ESHAPE, "igemm_tn: MFMA path needs lda, ldb multiples of %d", VN);
     const bool use_mfma = impl >= 2 || (impl == 0 && mfma_ok && (int64_t)p.Mred >= 256);
     if (use_mfma) {
         p.itiles = (int)cdiv64(p.I, TILE);

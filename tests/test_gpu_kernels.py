@@ -365,6 +365,29 @@ def test_conv3x3_thin_input_kernel(dev, cout):
         assert derr < 1e-2, f"dgrad rel-to-max error {derr}"
 
 
+@pytest.mark.parametrize("shape", [(3, 600, 520, 200, 1), (1, 2048, 1032, 512, 2), (2, 1296, 648, 128, 0)])
+def test_gemm_nt_wide_kernel(dev, shape):
+    """256 x 256 macro-tile GEMM (bf16; impl 5 forces it, auto-selected only for very large plain GEMMs): ragged M / N / K tails, bias per column / row,
+    batches -- against an fp32 torch product of the same bf16-rounded operands"""
+    from dynamicvectorquantization_amd import kernels as K
+    b, m, n, k, bias_mode = shape
+    rs = np.random.RandomState(m + n)
+    a = bf16_round(rs.standard_normal((b, m, k)).astype(np.float32))
+    w = bf16_round(rs.standard_normal((b, n, k)).astype(np.float32) / np.sqrt(k))
+    bias = rs.standard_normal(n if bias_mode == 1 else m).astype(np.float32) if bias_mode else None
+    ref = torch.from_numpy(a) @ torch.from_numpy(w).transpose(1, 2)
+    if bias_mode == 1:
+        ref = ref + torch.from_numpy(bias)[None, None, :]
+    elif bias_mode == 2:
+        ref = ref + torch.from_numpy(bias)[None, :, None]
+    at, wt_ = T(a, dev, torch.bfloat16).reshape(-1), T(w, dev, torch.bfloat16).reshape(-1)
+    bt = T(bias, dev) if bias_mode else None
+    out = K.gemm_nt(at, wt_, m, n, k, k, k, n, batch=b, sa=m * k, sb=n * k, sc=m * n, bias=bt, bias_mode=bias_mode, impl=5)
+    got = out.view(b, m, n).float().cpu()
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1e-2, err
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("impl", [1, 2])
 def test_gemm_nt_tn(dev, dtype, impl):
