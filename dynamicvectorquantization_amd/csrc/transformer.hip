@@ -109,6 +109,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
             }
         }
     }
+    // combine the four waves of the workgroup in LDS first: one global atomic per channel and WORKGROUP (cross-XCD fp32
+    // atomics are slow; 2 x C of them per wave dominated this kernel)
+    extern __shared__ __attribute__((aligned(16))) char ln_smem[];
+    float* sg = reinterpret_cast<float*>(ln_smem);          // [C] dgamma partial
+    float* sb = sg + C;                                      // [C] dbeta partial
+    for (int c = threadIdx.x; c < 2 * C; c += 256) sg[c] = 0.f;
+    __syncthreads();
     if (r0 < r1) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
@@ -116,10 +123,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
             if (c8 < C8)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    atomicAdd(&dgamma[c8 * 8 + j], ag[i][j]);
-                    atomicAdd(&dbeta[c8 * 8 + j], ab[i][j]);
+                    atomicAdd(&sg[c8 * 8 + j], ag[i][j]);
+                    atomicAdd(&sb[c8 * 8 + j], ab[i][j]);
                 }
         }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(&dgamma[c], sg[c]);
+        atomicAdd(&dbeta[c], sb[c]);
     }
 }
 
@@ -299,10 +311,10 @@ int dvq_layernorm_bwd(const void* x, const void* dy, int dtype, int64_t rows, in
                       void* dx, float* dgamma, float* dbeta, dvq_stream_t stream) {
     DVQ_REQUIRE(x && dy && mean_rstd && gamma && dx && dgamma && dbeta && rows > 0 && C > 0 && C % 8 == 0 && C <= 4096, DVQ_EINVAL,
                 "dvq_layernorm_bwd: bad arguments (C %% 8 == 0, C <= 4096)");
-    int rpw = (int)cdiv64(rows, 1024);                // ~1024 waves (one per SIMD): few, long runs keep the dgamma/dbeta atomics rare
+    int rpw = (int)cdiv64(rows, 1024);                // ~1024 waves (256 workgroups): long runs keep the dgamma/dbeta atomics rare
     if (rpw < 1) rpw = 1;
     const int64_t waves = cdiv64(rows, rpw);
-    DVQ_DISPATCH_DTYPE(dtype, T, ln_bwd_kernel<T><<<dim3((unsigned)cdiv64(waves, 4)), dim3(256), 0, (hipStream_t)stream>>>(
+    DVQ_DISPATCH_DTYPE(dtype, T, ln_bwd_kernel<T><<<dim3((unsigned)cdiv64(waves, 4)), dim3(256), (size_t)(2 * C * sizeof(float)), (hipStream_t)stream>>>(
                                      (const T*)x, (const T*)dy, rows, (int)(C / 8), mean_rstd, gamma, (T*)dx, dgamma, dbeta, rpw););
     DVQ_CHECK_LAUNCH("layernorm_bwd");
     return DVQ_OK;
