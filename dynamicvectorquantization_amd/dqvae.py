@@ -489,6 +489,7 @@ class DualGrainVQModel(nn.Module):
         self.training_steps, self.steps_per_epoch, self.max_epoch = 1, 1, 1
         self.current_epoch, self.global_step = 0, 0
         self._logged = {}
+        self._grad_hook = None        # set by the Trainer under data parallelism (gradient exchange overlapped with backward)
 
     def init_from_ckpt(self, path, ignore_keys=list()):
         sd = torch.load(path, map_location="cpu")["state_dict"]
@@ -551,6 +552,8 @@ class DualGrainVQModel(nn.Module):
         g = self.post_quant_conv.bwd(g, tape.child("pqc"))
         g = self.quantize.bwd(g, g_qloss, tape.child("vq"))
         g = self.quant_conv.bwd(g, tape.child("qc"))
+        if self._grad_hook is not None:            # data parallel: decoder-side gradients are final -> start their all-reduce
+            self._grad_hook("decoder_side_done")
         self.encoder.bwd(g, tape.child("enc"), g_gate)
 
     # -- reference API ------------------------------------------------------------------------------

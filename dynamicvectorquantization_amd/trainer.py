@@ -155,22 +155,60 @@ class GradBuckets:
         self.pg = process_group
         n = self.fp.flat_g.numel()
         step = max(1, bucket_bytes // 4)
+        self.bucket_elems = step
         self.flat = [self.fp.flat_g[i:min(n, i + step)] for i in range(0, n, step)]
         self.params = self.fp.params
+        self._pending, self._done = [], []
 
     def zero(self):
         self.fp.zero_grad()
 
-    def reduce(self, async_op=True):
-        """average gradients over ranks (no-op for world size 1); returns work handles"""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.pg) == 1:
-            return []
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
+
+    def reduce_range(self, lo, hi):
+        """start averaging flat_g[lo:hi] over ranks NOW (asynchronously, on RCCL's stream) -- called from inside the
+        backward as soon as that part of the gradient is final, so the exchange overlaps the rest of the backward"""
+        if not self._active() or hi <= lo:
+            return
         ws = dist.get_world_size(self.pg)
-        self.fp.flat_g.div_(ws)
-        works = []
-        for f in reversed(self.flat):
-            works.append(dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op))
-        return [w for w in works if w is not None]
+        seg = self.fp.flat_g[lo:hi]
+        seg.div_(ws)
+        step = max(1, self.bucket_elems)
+        for a in range(lo, hi, step):
+            b = min(hi, a + step)
+            self._pending.append(dist.all_reduce(self.fp.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self._done.append((lo, hi))
+
+    def reduce(self, async_op=True):
+        """average the ranges that reduce_range() has not covered yet (no-op for world size 1); returns ALL work handles"""
+        if not self._active():
+            return []
+        n = self.fp.flat_g.numel()
+        covered = sorted(self._done)
+        pos = 0
+        gaps = []
+        for lo, hi in covered:
+            if lo > pos:
+                gaps.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < n:
+            gaps.append((pos, n))
+        for lo, hi in reversed(gaps):              # last layers first
+            self.reduce_range(lo, hi)
+        works, self._pending, self._done = [w for w in self._pending if w is not None], [], []
+        return works
+
+    def param_range(self, params):
+        """[lo, hi) of the flat buffer covered by `params` (they must be contiguous in the optimizer's order)"""
+        ids = {id(p) for p in params}
+        off, lo, hi = 0, None, None
+        for p in self.fp.params:
+            if id(p) in ids:
+                lo = off if lo is None else lo
+                hi = off + p.numel()
+            off += p.numel()
+        return (lo or 0), (hi or 0)
 
 
 class DataModuleFromConfig:
@@ -201,6 +239,7 @@ class Trainer:
         K.arena_reset(self.buckets[0].fp.flat_g.device)
         for oi, opt in enumerate(self.opts):
             self.buckets[oi].zero()
+            self._arm_overlap(oi)
             loss = m.training_step(batch, batch_idx, oi) if self._takes_opt_idx else m.training_step(batch, batch_idx)
             if loss.requires_grad:
                 loss.backward()
@@ -212,6 +251,20 @@ class Trainer:
             losses.append(loss.detach())
         m.global_step += 1
         return losses
+
+    def _arm_overlap(self, oi):
+        """autoencoder optimizer: the decoder-side gradients (decoder, quant convs) are final before the encoder's backward
+        starts -- their all-reduce is launched from inside the backward (model._grad_hook) and overlaps the encoder backward"""
+        m = self.model
+        if not hasattr(m, "_grad_hook"):
+            return
+        m._grad_hook = None
+        gb = self.buckets[oi]
+        if oi == 0 and gb._active() and hasattr(m, "encoder"):
+            lo, hi = gb.param_range([p for p in m.encoder.parameters() if p.requires_grad])
+            n = gb.fp.flat_g.numel()
+            if lo == 0 and 0 < hi < n:
+                m._grad_hook = lambda tag: gb.reduce_range(hi, n) if tag == "decoder_side_done" else None
 
     def fit(self, batch_fn):
         self.model.train()

@@ -147,7 +147,10 @@ def _dp_worker(rank, world, port, q):
         assert torch.equal(p.detach(), w0[i])         # flattening keeps the values, .data/.grad become views
         assert p.grad.data_ptr() >= gb.fp.flat_g.data_ptr()
         p.grad.add_(float(rank + 1) * (i + 1))        # kernels accumulate in place into bucket views
-    for w in gb.reduce():
+    lo, hi = gb.param_range(params[:2])
+    assert (lo, hi) == (0, 26)
+    gb.reduce_range(hi, gb.fp.flat_g.numel())          # "decoder side" first, from inside the backward ...
+    for w in gb.reduce():                              # ... the rest afterwards; every element averaged exactly once
         w.wait()
     ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params))
     stats = torch.full((8, 5), float(rank + 1))
