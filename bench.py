@@ -104,6 +104,24 @@ OBJECTIVES = {
 }
 
 
+def _pmc_traffic(family):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/*_bench_pmc.json)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_bench_pmc.json")))
+    if not files:
+        return None
+    try:
+        rec = json.load(open(files[-1]))
+        ks = {k: v for k, v in rec["kernels"].items() if k.startswith(family)}
+        if not ks:
+            return None
+        n = sum(v["launches"] for v in ks.values())
+        return {"hbm_bytes_per_launch": round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks.values()) / n),
+                "source": "profiles/" + os.path.basename(files[-1]) + ": " + rec.get("_method", "")}
+    except Exception:
+        return None
+
+
 def vq_microbench(dev, reps=20):
     """VQ argmin at the BASELINE shape (N=65536, D=256, K=1024): algorithmic GB/s, inputs resident in HBM."""
     from dynamicvectorquantization_amd import kernels as K
@@ -248,7 +266,14 @@ def main():
                         "frac": round(ach / (PEAK_BF16 / 1e12), 4), "traffic": None,
                         "launches": v["launches"], "avg_launch_ms": round(v["ms_per_launch"], 4),
                         "alg_flops_per_launch": v["flops"] / max(1, v["launches"]),
+                        "alg_bytes_per_launch": v["bytes"] / max(1, v["launches"]),
                         "timed": "HIP events around every launch of this kernel during the last timed step"}
+            # HBM traffic per launch: PMC counters cannot be collected from inside this process; the figure comes from the
+            # committed rocprofv3 --pmc passes over this same command (tools/gpu_pmc_bench.sh -> tools/pmc_summarise.py)
+            pmc = _pmc_traffic(dom)
+            if pmc is not None and args.objective == "full" and args.bs == 64:
+                roofline["traffic"] = pmc["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = pmc["source"]
         out = {
             "metric": METRIC, "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt_ / args.steps * 1e3, 3), "higher_is_better": True,
