@@ -112,7 +112,7 @@ def _pmc_traffic(family):
         return None
     try:
         rec = json.load(open(files[-1]))
-        ks = {k: v for k, v in rec["kernels"].items() if k.startswith(family)}
+        ks = {k: v for k, v in rec["kernels"].items() if k == family or k.startswith(family + "<")}
         if not ks:
             return None
         n = sum(v["launches"] for v in ks.values())
