@@ -494,3 +494,69 @@ def test_resnet_block_fused_groupnorm_bf16(dev, cin, cout):
         e_u = float(np.abs(res["unfused"][key] - ref[key]).max()) / s_
         assert e_f < 4e-2, f"fused {key}: rel-to-max error {e_f} (unfused {e_u})"
         assert e_u < 4e-2, f"unfused {key}: rel-to-max error {e_u}"
+
+
+# ---- BASELINE-size property tests (size-independent identities, no CPU reference needed) -----------------------------
+@pytest.mark.parametrize("shape", [(64, 256, 128, 128), (64, 64, 256, 256), (64, 32, 512, 512), (128, 256, 64, 64), (64, 256, 128, 3)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_conv3x3_adjoint_identities_full_size(dev, shape):
+    """<conv(x), dy> = <x, dgrad(dy)> = <w, wgrad(x, dy)> (+ bias term) at the BASELINE batch / resolution: the three conv
+    kernels of a layer are mutually consistent on the full-size launch geometry (tile tails, XCD remap, split-K)"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d, Tape
+    n, h, cin, cout = shape
+    torch.manual_seed(n + h + cin + cout)
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        conv = Conv2d(cin, cout, 3, 1, 1).to(dev)
+        with torch.no_grad():
+            conv.weight.copy_(conv.weight.to(torch.bfloat16).float())       # bf16-representable parameters
+            conv.bias.zero_()
+        cin_p, cout_p = conv._padded(torch.bfloat16)
+        x = torch.randn(n, h, h, cin_p, device=dev).to(torch.bfloat16)
+        dy = torch.randn(n, h, h, cout_p, device=dev).to(torch.bfloat16)
+        if cout_p != cout:
+            dy[..., cout:] = 0
+        tape = Tape()
+        y = conv.fwd(x, tape)
+        conv.weight.grad = torch.zeros_like(conv.weight)
+        conv.bias.grad = torch.zeros_like(conv.bias)
+        dx = conv.bwd(dy, tape)
+        a = float((y.double() * dy.double()).sum())
+        b = float((x.double() * dx.double()).sum())
+        c = float((conv.weight.detach().double() * conv.weight.grad.double()).sum())
+        scale = float(y.double().pow(2).sum().sqrt() * dy.double().pow(2).sum().sqrt())
+        # y and dx are rounded to bf16 once (relative 2^-9 per element, random sign): the inner products agree to ~1e-4 of
+        # the Cauchy-Schwarz scale; wgrad accumulates in fp32 and is exact up to summation order
+        assert abs(a - b) < 2e-4 * scale, (a, b, scale)
+        assert abs(a - c) < 2e-4 * scale, (a, c, scale)
+        # linearity in the input at full size: conv(2x) = 2 conv(x) exactly in bf16 (power-of-two scaling)
+        y2 = conv.fwd(K.add(x, x), None)
+        assert torch.equal(y2, K.add(y, y))
+        # the bias gradient is the plain sum of dy
+        db = dy[..., :cout].double().sum(dim=(0, 1, 2))
+        assert float((conv.bias.grad.double() - db).abs().max()) <= 1e-3 * float(db.abs().max() + 1)
+
+
+def test_groupnorm_and_lpips_properties_full_size(dev):
+    """GroupNorm output of the BASELINE-size tensor has zero mean / unit variance per (image, group); backward of a constant
+    upstream gradient through a plain GroupNorm is zero; LPIPS(x, x) = 0 with zero gradient"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.losses import LPIPS
+    torch.manual_seed(0)
+    n, h, c = 64, 256, 128
+    x = (torch.randn(n, h, h, c, device=dev) * 3 + 1.5).to(torch.bfloat16)
+    gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+    y, mr = K.gn_forward(x, gamma, beta, 32, 1e-6, 0)
+    yg = y.float().view(n, h * h, 32, c // 32)
+    assert float(yg.mean(dim=(1, 3)).abs().max()) < 2e-3 and float((yg.var(dim=(1, 3), unbiased=False) - 1).abs().max()) < 5e-3
+    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    dx = K.gn_backward(x, torch.ones_like(x), mr, gamma, beta, dg, db, 32, 0)
+    assert float(dx.float().abs().max()) < 2e-2                        # d/dx of sum(GroupNorm(x)) vanishes
+    np.testing.assert_allclose(db.cpu().numpy(), np.full(c, n * h * h, dtype=np.float32), rtol=1e-6)
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        lp = LPIPS().to(dev)
+        img = K.nchw_to_nhwc_pad(torch.rand(8, 3, 256, 256, device=dev) * 2 - 1, 8, torch.bfloat16)
+        val, d = lp.fwd(img, img.clone(), gscale=1.0)
+        assert float(val.abs().max()) < 1e-12 and float(d.float().abs().max()) < 1e-9     # bf16 feature noise floor is ~1e-5
