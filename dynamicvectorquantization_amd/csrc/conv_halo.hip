@@ -411,11 +411,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_wgrad_reduce_kernel(WgParams
     }
 }
 
+// THIN (Cout <= 32, e.g. the 3-channel output conv): only the first 32-channel sub-tile carries data, so instead of four
+// waves owning four co sub-tiles (three of them empty) the four waves of a ci half split the PIXEL steps of every tile among
+// themselves and each flushes its partial of the few real output channels with atomics.
+template <bool THIN>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mt = wave & 3, nt = wave >> 2;
+    const int mt = THIN ? 0 : (wave & 3), nt = wave >> 2;
+    const int st_lo = THIN ? 2 * (wave & 3) : 0, st_hi = THIN ? st_lo + 2 : 8;     // pixel steps (16 px each) of this wave
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(h_zero_page);
 
     int wi = xcd_remap(blockIdx.x, p.gi * p.gj * p.nsplit);
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
                 if (t + 1 < tend) issue(t + 1, buf ^ 1);     // prefetch after the barrier: it would otherwise drain the DMA
             }
 #pragma unroll 2
-            for (int st = 0; st < 8; ++st) {               // 16 pixels per step: image row rr, half hs
+            for (int st = st_lo; st < st_hi; ++st) {       // 16 pixels per step: image row rr, half hs
                 const int rr = st >> 1, hs = st & 1;
                 bf16x8 a;
                 {
@@ -619,12 +624,18 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
     int64_t ws_bytes = 0;
     char* wsp = (char*)dvq_workspace(&ws_bytes);
     const int64_t need = nblk * (9ll * 128 * 64 + 128) * 4;
-    if (wsp != nullptr && ws_bytes >= need && p.nsplit > 1) {
+    const bool thin = Cout <= 32;
+    if (wsp != nullptr && ws_bytes >= need && p.nsplit > 1 && !thin) {
         p.ws = (float*)wsp;
         p.ws_bias = (float*)(wsp + nblk * 9ll * 128 * 64 * 4);
     }
-    dvq_ensure_dynamic_lds((const void*)conv3x3_halo_wgrad_kernel, 2 * WSTAGE);
-    conv3x3_halo_wgrad_kernel<<<dim3((unsigned)nblk), dim3(512), 2 * WSTAGE, stream>>>(p);
+    if (thin) {
+        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_wgrad_kernel<true>, 2 * WSTAGE);
+        conv3x3_halo_wgrad_kernel<true><<<dim3((unsigned)nblk), dim3(512), 2 * WSTAGE, stream>>>(p);
+    } else {
+        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_wgrad_kernel<false>, 2 * WSTAGE);
+        conv3x3_halo_wgrad_kernel<false><<<dim3((unsigned)nblk), dim3(512), 2 * WSTAGE, stream>>>(p);
+    }
     if (p.ws != nullptr) {
         const int64_t work = (int64_t)p.gi * p.gj * 9 * 128 * 64;
         conv3x3_halo_wgrad_reduce_kernel<<<dim3((unsigned)cdiv64(work, 256)), dim3(256), 0, stream>>>(p);
