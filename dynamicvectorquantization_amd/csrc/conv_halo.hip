@@ -771,3 +771,77 @@ int dvq_conv3x3_thin_k_try(const void* x, const void* w, const float* bias, void
     }
     return 1;
 }
+
+// =================================================================================================
+// Thin-output transposed 4x4 / stride-2 / pad-1 convolution: the input gradient of the PatchGAN's first conv
+// (modules/discriminator/model.py:33): dy [N,OH,OW,Cout] -> dx [N,2*OH,2*OW,8] (3 real image channels).  Every output
+// pixel receives exactly 2 x 2 of the 16 taps (those matching its parity).  Output-thin and tiny in flops (768 FMAs per
+// pixel): plain VALU dot products, weights of the real channels as fp32 in LDS, one image row segment per workgroup; the
+// generic implicit-GEMM dgrad needed 1.95 ms for it (a 128-wide tile for 8 columns, 3/4 of the taps masked out).
+// =================================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void tconv4x4s2_thin_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wt,
+                                                              bf16_t* __restrict__ dx, int64_t N, int OH, int OW, int Cout,
+                                                              int creal) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ws = reinterpret_cast<float*>(smem);              // [creal][16][Cout]
+    const int H = 2 * OH, W = 2 * OW;
+    for (int i = threadIdx.x; i < creal * 16 * Cout; i += 256) ws[i] = bf16_to_f32(wt[i]);      // wt rows: [c][kh][kw][co]
+    __syncthreads();
+    const int64_t total = N * H * W;
+    for (int64_t px = (int64_t)blockIdx.x * 256 + threadIdx.x; px < total; px += (int64_t)gridDim.x * 256) {
+        const int x = (int)(px % W);
+        const int y = (int)((px / W) % H);
+        const int64_t n = px / ((int64_t)W * H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int kh = ((y + 1) & 1) + 2 * a;
+            const int oh = (y + 1 - kh) >> 1;
+            if ((unsigned)oh >= (unsigned)OH) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int kw = ((x + 1) & 1) + 2 * b;
+                const int ow = (x + 1 - kw) >> 1;
+                if ((unsigned)ow >= (unsigned)OW) continue;
+                const bf16_t* src = dy + ((n * OH + oh) * (int64_t)OW + ow) * Cout;
+                const float* w0 = ws + (kh * 4 + kw) * Cout;
+                for (int c8 = 0; c8 < Cout; c8 += 8) {
+                    float v[8];
+                    load8(src + c8, v);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < creal) {
+                            const float* wc = w0 + c * 16 * Cout + c8;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[c] = fmaf(v[j], wc[j], acc[c]);
+                        }
+                }
+            }
+        }
+        float o[8] = {acc[0], acc[1], acc[2], acc[3], 0.f, 0.f, 0.f, 0.f};
+        store8(dx + px * 8, o);
+    }
+}
+
+}  // namespace
+
+// 1 = handled, 0 = not eligible.  dy [N,OH,OW,Cout] bf16, wt [8][4][4][Cout] bf16 (rows >= creal zero), dx [N,2OH,2OW,8]
+int dvq_tconv4x4s2_thin_try(const void* dy, const void* wt, void* dx, int64_t N, int64_t OH, int64_t OW, int64_t Cout, int creal,
+                            hipStream_t stream) {
+    if (Cout % 8 != 0 || creal < 1 || creal > 4 || creal * 16 * Cout * 4 > 64 * 1024) return 0;
+    const int lds = (int)(creal * 16 * Cout * sizeof(float));
+    const int64_t total = N * 4 * OH * OW;
+    int64_t blocks = cdiv64(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    dvq_ensure_dynamic_lds((const void*)tconv4x4s2_thin_kernel, lds);
+    tconv4x4s2_thin_kernel<<<dim3((unsigned)blocks), dim3(256), lds, stream>>>((const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, N,
+                                                                             (int)OH, (int)OW, (int)Cout, creal);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        dvq_set_error("tconv4x4s2_thin: launch failed: %s", hipGetErrorString(e));
+        return DVQ_ELAUNCH;
+    }
+    return 1;
+}

@@ -1291,6 +1291,9 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
 int dvq_conv3x3_thin_k_try(const void* x, const void* w, const float* bias, void* y, int64_t N, int64_t H, int64_t W, int64_t Cout,
                            int flip, float act_slope, hipStream_t stream);
 
+int dvq_tconv4x4s2_thin_try(const void* dy, const void* wt, void* dx, int64_t N, int64_t OH, int64_t OW, int64_t Cout, int creal,
+                            hipStream_t stream);
+
 static float act_slope_of(int act) { return act == DVQ_ACT_RELU ? 0.f : act == DVQ_ACT_LRELU ? 0.2f : 1.f; }
 
 static bool halo_eligible(const dvq_conv_desc* d) {
@@ -1377,6 +1380,12 @@ int dvq_conv2d_dgrad_mask(const dvq_conv_desc* d, const void* dy, const void* wt
     DVQ_REQUIRE(mask == nullptr || ((mask_act == DVQ_ACT_RELU || mask_act == DVQ_ACT_LRELU) && !d->upsample), DVQ_EINVAL,
                 "dvq_conv2d_dgrad_mask: mask needs act in {relu, lrelu} and no folded upsample");
     DVQ_REQUIRE(dy && wt && dx && (!d->upsample || ws), DVQ_EINVAL, "dvq_conv2d_dgrad: null pointer");
+    if (d->dtype == DVQ_BF16 && d->impl == 0 && d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad_t == 1 && d->pad_l == 1 &&
+        d->Cin == 8 && !d->upsample && mask == nullptr && d->H == 2 * d->OH && d->W == 2 * d->OW) {
+        // input gradient of the PatchGAN's first conv (3 image channels): thin transposed conv
+        const int rc = dvq_tconv4x4s2_thin_try(dy, wt, dx, d->N, d->OH, d->OW, d->Cout, 4, (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : DVQ_OK;
+    }
     if (halo_eligible(d) && d->impl == 0 && d->Cout == 8 && !d->upsample && mask == nullptr) {
         // dgrad of the 3-channel output conv: 8 gradient channels in, Cin out, taps reversed
         const int rc = dvq_conv3x3_thin_k_try(dy, wt, nullptr, dx, d->N, d->H, d->W, d->Cin, 1, 1.f, (hipStream_t)stream);

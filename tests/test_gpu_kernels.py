@@ -365,6 +365,38 @@ def test_conv3x3_thin_input_kernel(dev, cout):
         assert derr < 1e-2, f"dgrad rel-to-max error {derr}"
 
 
+@pytest.mark.parametrize("case", [(64, 2, 16, 24), (64, 1, 64, 64), (32, 3, 6, 10)], ids=lambda c: "-".join(map(str, c)))
+def test_tconv4x4s2_thin_kernel(dev, case):
+    """input gradient of the PatchGAN's first conv (4x4 / s2 / p1, 3 image channels) on the thin transposed-conv kernel"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d, Tape
+    cout, n, h, w_ = case
+    rs = np.random.RandomState(cout + h)
+    x = bf16_round(rs.standard_normal((n, 3, h, w_)).astype(np.float32))
+    wt = bf16_round((rs.standard_normal((cout, 3, 4, 4)) / np.sqrt(48)).astype(np.float32))
+    go = bf16_round(rs.standard_normal((n, cout, h // 2, w_ // 2)).astype(np.float32))
+    xr = torch.from_numpy(x).requires_grad_(True)
+    (F.conv2d(xr, torch.from_numpy(wt), None, stride=2, padding=1) * torch.from_numpy(go)).sum().backward()
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        mod = Conv2d(3, cout, 4, 2, 1).to(dev)
+        with torch.no_grad():
+            mod.weight.copy_(T(wt, dev))
+        tape = Tape()
+        mod.fwd(K.nchw_to_nhwc_pad(T(x, dev), 8, torch.bfloat16), tape)
+        outs = []
+        for impl in (0, 2):          # thin kernel (auto) and the generic implicit-GEMM dgrad
+            tape.s["d"].impl = impl
+            dx = mod.bwd(T(go, dev, torch.bfloat16).permute(0, 2, 3, 1).contiguous(), tape, need_dw=False)
+            outs.append(dx.float().permute(0, 3, 1, 2).cpu().numpy())
+    dref = xr.grad.numpy()
+    for got in outs:
+        assert np.all(got[:, 3:] == 0), "pad channels must stay zero"
+        derr = np.abs(got[:, :3] - dref).max() / np.abs(dref).max()
+        assert derr < 1e-2, f"dgrad rel-to-max error {derr}"
+    assert np.abs(outs[0] - outs[1]).max() / np.abs(dref).max() < 1e-2
+
+
 @pytest.mark.parametrize("shape", [(3, 600, 520, 200, 1), (1, 2048, 1032, 512, 2), (2, 1296, 648, 128, 0)])
 def test_gemm_nt_wide_kernel(dev, shape):
     """256 x 256 macro-tile GEMM (bf16; impl 5 forces it, auto-selected only for very large plain GEMMs): ragged M / N / K tails, bias per column / row,
