@@ -121,6 +121,24 @@ __device__ __forceinline__ T wave_max(T v) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// dropout decisions: keep element `idx` iff dvq_hash32(lo32(idx) * rm + ra + hi32(idx) * 0x9E3779B1) >= p * 2^32, with the
+// odd multiplier rm and the offset ra derived from the 64-bit seed (different seeds are not shifted copies of each other).
+// Shared by dvq_dropout and the fused attention kernels (same seed + same element index = same mask).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ unsigned dvq_hash32(unsigned x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+static inline void dvq_dropout_seed(uint64_t seed, unsigned* rm, unsigned* ra) {
+    *rm = dvq_hash32((unsigned)seed ^ 0x9E3779B9u) | 1u;
+    *ra = dvq_hash32((unsigned)(seed >> 32) + 0x85ebca6bu) ^ dvq_hash32((unsigned)seed + 0xc2b2ae35u);
+}
+
 __device__ __forceinline__ float swishf(float z) { return z / (1.0f + __expf(-z)); }
 // d/dz [z * sigmoid(z)] = s * (1 + z * (1 - s))
 __device__ __forceinline__ float swish_grad(float z) {

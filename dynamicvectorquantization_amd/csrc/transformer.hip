@@ -266,30 +266,20 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const T* __restrict_
     }
 }
 
-// ---- dropout: keep = hash(seed, element index) >= p; y = x * keep / (1 - p).  The same call with the same (seed, offset)
-// applies the same mask to a gradient. ------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned hash32(unsigned long long k) {
-    k ^= k >> 33;
-    k *= 0xff51afd7ed558ccdULL;
-    k ^= k >> 33;
-    k *= 0xc4ceb9fe1a85ec53ULL;
-    k ^= k >> 33;
-    return (unsigned)k;
-}
-
+// ---- dropout: y = x * keep / (1 - p), keep decided by dvq_hash32 of (seed, element index) (dvq_common.h).  The same call
+// with the same seed applies the same mask to a gradient. ---------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, int64_t n8, float p, unsigned long long seed,
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, int64_t n8, float p, unsigned rm, unsigned ra,
                                                       T* __restrict__ y) {
     const float scale = 1.f / (1.f - p);
-    const unsigned thr = (unsigned)(p * 4294967296.0);
+    const unsigned thr = (unsigned)((double)p * 4294967296.0);
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
         float v[8];
         load8(x + e * 8, v);
+        const unsigned long long i0 = (unsigned long long)e * 8;
+        const unsigned base = ra + (unsigned)(i0 >> 32) * 0x9E3779B1u;      // 8 | i0: the 8 elements share the high word
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned h = hash32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)(e * 8 + j));
-            v[j] = h >= thr ? v[j] * scale : 0.f;
-        }
+        for (int j = 0; j < 8; ++j) v[j] = dvq_hash32(((unsigned)i0 + j) * rm + base) >= thr ? v[j] * scale : 0.f;
         store8(y + e * 8, v);
     }
 }
@@ -378,8 +368,10 @@ int dvq_cross_entropy(const void* logits, int dtype, int64_t rows, int64_t V, in
 
 int dvq_dropout(const void* x, int dtype, int64_t n, float p, uint64_t seed, void* y, dvq_stream_t stream) {
     DVQ_REQUIRE(x && y && n > 0 && n % 8 == 0 && p >= 0.f && p < 1.f, DVQ_EINVAL, "dvq_dropout: bad arguments");
+    unsigned rm, ra;
+    dvq_dropout_seed(seed, &rm, &ra);
     DVQ_DISPATCH_DTYPE(dtype, T, dropout_kernel<T><<<dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream>>>(
-                                     (const T*)x, n / 8, p, (unsigned long long)seed, (T*)y););
+                                     (const T*)x, n / 8, p, rm, ra, (T*)y););
     DVQ_CHECK_LAUNCH("dropout");
     return DVQ_OK;
 }

@@ -57,9 +57,8 @@ class DualGrainFixedEntropyRouter(nn.Module):
 
     def forward(self, h_fine=None, h_coarse=None, entropy=None):
         """entropy [B,h,w] fp32 -> gate int64 [B,h,w,2] = [coarse, fine]"""
-        t = torch.tensor(self.fine_grain_threshold, dtype=torch.float32, device=entropy.device)
-        fine = entropy > t
-        return torch.stack([~fine, fine], dim=-1).long()
+        t = float(self.fine_grain_threshold)      # a Python scalar: no host->device copy (= no sync) per forward
+        return torch.stack([entropy <= t, entropy > t], dim=-1).long()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -293,11 +292,15 @@ class FourierPositionEmbedding(nn.Module):
 
     def __init__(self, coord_size, hidden_size, integer_values=False):
         super().__init__()
-        self.coord = convert_to_coord_format(1, coord_size, coord_size, "cpu", integer_values)
+        # constant grid: a non-persistent buffer so that it moves with the module (an H2D copy per forward would be a
+        # pageable-memory copy, i.e. a host<->device synchronisation in the middle of every step)
+        self.register_buffer("coord", convert_to_coord_format(1, coord_size, coord_size, "cpu", integer_values), persistent=False)
         self.lff = LFF(hidden_size)
 
     def bias_hwc(self, device):
-        coord = self.coord.to(device)[0]                                     # [2,h,w]
+        if self.coord.device != torch.device(device):
+            self.coord = self.coord.to(device)
+        coord = self.coord[0]                                                # [2,h,w]
         w = self.lff.ffm.conv.weight[:, :, 0, 0]                             # [C,2]
         # 2 input channels: two broadcast multiply-adds (no GEMM library call)
         pre = (coord[0].unsqueeze(-1) * w[:, 0] + coord[1].unsqueeze(-1) * w[:, 1]) + self.lff.ffm.conv.bias

@@ -86,6 +86,7 @@ class CausalSelfAttention(nn.Module):
             mask[:config.n_unmasked, :config.n_unmasked] = 1
         self.register_buffer("mask", mask.view(1, 1, config.block_size, config.block_size))     # state_dict parity only
         self.n_head = config.n_head
+        self._n_unmasked = int(getattr(config, "n_unmasked", 0) or 0)
 
     def fwd(self, x2d, b, t, tape):
         c = x2d.shape[1]
@@ -93,17 +94,27 @@ class CausalSelfAttention(nn.Module):
         k = self.key.fwd(x2d, _child(tape, "k"))
         q = self.query.fwd(x2d, _child(tape, "q"))
         v = self.value.fwd(x2d, _child(tape, "v"))
-        s = torch.empty(b * nh * t * t, dtype=x2d.dtype, device=x2d.device)
-        qf, kf = q.reshape(-1), k.reshape(-1)
-        for h in range(nh):
-            K.gemm_nt(qf[h * hs:], kf[h * hs:], t, t, hs, c, c, t, batch=b, sa=t * c, sb=t * c, sc=nh * t * t, out=s[h * t * t:])
-        p = K.softmax_causal_(s, b * nh * t, t, t, 0, 1.0 / math.sqrt(hs))
-        pd = _drop(p, self.attn_drop.p, self.training, tape, "adrop")
-        vt = K.transpose(v, b, t, c).reshape(-1)                                  # [B, C, T]
-        y = torch.empty(b * t, c, dtype=x2d.dtype, device=x2d.device)
-        yf = y.reshape(-1)
-        for h in range(nh):
-            K.gemm_nt(pd[h * t * t:], vt[h * hs * t:], t, hs, t, t, t, c, batch=b, sa=nh * t * t, sb=c * t, sc=t * c, out=yf[h * hs:])
+        fused = K.attn_causal_ok(x2d, nh, b, t) and hs == 64 and not self._n_unmasked
+        if fused:
+            # one kernel per direction, scores stay in registers (csrc/attention.hip)
+            p_drop = self.attn_drop.p if self.training else 0.0
+            seed = _next_seed() if p_drop > 0.0 else 0
+            y, lse = K.attn_causal_fwd(q, k, v, b, t, nh, 1.0 / math.sqrt(hs), p_drop, seed)
+            if tape is not None:
+                tape.s.update(fused=(p_drop, seed), y=y, lse=lse)
+            p = pd = None
+        else:
+            s = torch.empty(b * nh * t * t, dtype=x2d.dtype, device=x2d.device)
+            qf, kf = q.reshape(-1), k.reshape(-1)
+            for h in range(nh):
+                K.gemm_nt(qf[h * hs:], kf[h * hs:], t, t, hs, c, c, t, batch=b, sa=t * c, sb=t * c, sc=nh * t * t, out=s[h * t * t:])
+            p = K.softmax_causal_(s, b * nh * t, t, t, 0, 1.0 / math.sqrt(hs))
+            pd = _drop(p, self.attn_drop.p, self.training, tape, "adrop")
+            vt = K.transpose(v, b, t, c).reshape(-1)                                  # [B, C, T]
+            y = torch.empty(b * t, c, dtype=x2d.dtype, device=x2d.device)
+            yf = y.reshape(-1)
+            for h in range(nh):
+                K.gemm_nt(pd[h * t * t:], vt[h * hs * t:], t, hs, t, t, t, c, batch=b, sa=nh * t * t, sb=c * t, sc=t * c, out=yf[h * hs:])
         out = self.proj.fwd(y, _child(tape, "proj"))
         out = _drop(out, self.resid_drop.p, self.training, tape, "rdrop")
         if tape is not None:
@@ -117,6 +128,12 @@ class CausalSelfAttention(nn.Module):
         nh, hs = self.n_head, c // self.n_head
         dout = _drop_bwd(dout, tape, "rdrop")
         dy = self.proj.bwd(dout, tape.child("proj"))
+        if "fused" in s_:
+            p_drop, seed = s_["fused"]
+            dq, dk, dv = K.attn_causal_bwd(q, k, v, s_["y"], dy, s_["lse"], b, t, nh, 1.0 / math.sqrt(hs), p_drop, seed)
+            dx = self.query.bwd(dq, tape.child("q"))
+            dx = K.add(dx, self.key.bwd(dk, tape.child("k")))
+            return K.add(dx, self.value.bwd(dv, tape.child("v")))
         dyf, vf, qf = dy.reshape(-1), v.reshape(-1), q.reshape(-1)
         dp = torch.empty_like(p)
         dv32 = torch.zeros(b * t * c, dtype=torch.float32, device=dy.device)

@@ -1,0 +1,114 @@
+"""GPU parity of the fused causal attention kernels (csrc/attention.hip: bf16, head size 64) against an fp32 torch
+restatement of CausalSelfAttention.forward (/root/reference/modules/dynamic_modules/stackgpt.py:41-69) and against the
+package's own unfused per-head GEMM path.  Tolerance: rel-to-max 2e-2 (bf16 operands, fp32 accumulation)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(a):
+    return torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+
+
+def _reference(q, k, v, dout, b, t, nh, mask=None):
+    """fp32 autograd restatement; q, k, v, dout numpy [b*t, nh*64]; mask [b, nh, t, t] multiplicative (dropout) or None"""
+    hs = 64
+    qs, ks, vs = (torch.from_numpy(a).double().view(b, t, nh, hs).transpose(1, 2).requires_grad_(True) for a in (q, k, v))
+    att = (qs @ ks.transpose(-2, -1)) * (1.0 / math.sqrt(hs))
+    causal = torch.tril(torch.ones(t, t, dtype=torch.bool))
+    att = att.masked_fill(~causal, float("-inf")).softmax(dim=-1)
+    if mask is not None:
+        att = att * torch.from_numpy(mask).double()
+    y = (att @ vs).transpose(1, 2).reshape(b * t, nh * hs)
+    (y * torch.from_numpy(dout).double()).sum().backward()
+    un = lambda g: g.transpose(1, 2).reshape(b * t, nh * hs).numpy()
+    return y.detach().numpy(), un(qs.grad), un(ks.grad), un(vs.grad)
+
+
+def _rel(got, ref):
+    return float(np.abs(got - ref).max() / max(1e-9, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 72, 2), (1, 32, 1), (3, 200, 4), (1, 648, 2)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+def test_fused_attention_vs_fp64_reference(dev, shape, p_drop):
+    from dynamicvectorquantization_amd import kernels as K
+    b, t, nh = shape
+    c = nh * 64
+    rs = np.random.RandomState(b * 1000 + t)
+    q, k, v, dout = (_bf16(rs.standard_normal((b * t, c)).astype(np.float32) * s) for s in (1.5, 1.5, 1.0, 1.0))
+    seed = 0x1234_5678_9ABC + t
+    mask = None
+    if p_drop > 0:
+        # the attention-dropout mask is DEFINED as dvq_dropout's mask over the flat [b, nh, t, t] probability tensor
+        ones = torch.ones(b * nh * t * t, dtype=torch.bfloat16, device=dev)
+        mask = (K.dropout(ones, p_drop, seed).float() > 0).float().view(b, nh, t, t).cpu().numpy() / (1.0 - p_drop)
+        keep = float((mask > 0).mean())
+        assert abs(keep - (1 - p_drop)) < 0.02, keep
+    yr, dqr, dkr, dvr = _reference(q, k, v, dout, b, t, nh, mask)
+    dq_, dk_, dv_, do_ = (torch.from_numpy(a).to(dev, torch.bfloat16) for a in (q, k, v, dout))
+    assert K.attn_causal_ok(dq_, nh, b, t)
+    y, lse = K.attn_causal_fwd(dq_, dk_, dv_, b, t, nh, 1.0 / 8.0, p_drop, seed)
+    gq, gk, gv = K.attn_causal_bwd(dq_, dk_, dv_, y, do_, lse, b, t, nh, 1.0 / 8.0, p_drop, seed)
+    torch.cuda.synchronize()
+    assert _rel(y.float().cpu().numpy(), yr) < 2e-2
+    # log-sum-exp of the scaled causal scores (saved for the backward)
+    sc = (torch.from_numpy(q).view(b, t, nh, 64).transpose(1, 2) @ torch.from_numpy(k).view(b, t, nh, 64).transpose(1, 2).transpose(-2, -1)) / 8.0
+    sc = sc.masked_fill(~torch.tril(torch.ones(t, t, dtype=torch.bool)), float("-inf"))
+    np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(sc, dim=-1).numpy(), rtol=2e-3, atol=2e-3)
+    for name, got, ref in (("dq", gq, dqr), ("dk", gk, dkr), ("dv", gv, dvr)):
+        assert _rel(got.float().cpu().numpy(), ref) < 2e-2, name
+
+
+def test_fused_attention_rejects_unsupported_geometry(dev):
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd._lib import DvqError
+    x = torch.zeros(2 * 36, 64, dtype=torch.bfloat16, device=dev)
+    assert not K.attn_causal_ok(x, 1, 2, 36)              # T % 8 != 0
+    assert not K.attn_causal_ok(x.float(), 1, 2, 36)
+    with pytest.raises(DvqError):
+        K.attn_causal_fwd(x, x, x, 2, 36, 1, 0.125)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_attention_module_fused_equals_unfused_full_size(dev, train):
+    """CausalSelfAttention of the p6c18 transformer (1024 channels, 16 heads, T = 648), forward + backward: the fused kernels
+    against the per-head GEMM path on identical weights, inputs and dropout seeds"""
+    from types import SimpleNamespace
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd import stackgpt as sg
+    from dynamicvectorquantization_amd.layers import Tape
+    cfg = SimpleNamespace(n_embd=1024, n_head=16, attn_pdrop=0.1, resid_pdrop=0.1, block_size=648)
+    b, t = 2, 648
+    torch.manual_seed(5)
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        attn = sg.CausalSelfAttention(cfg).to(dev)
+        attn.train(train)
+        x = (torch.randn(b * t, 1024, device=dev) * 1.0).to(torch.bfloat16)
+        dy = torch.randn(b * t, 1024, device=dev).to(torch.bfloat16)
+        res = []
+        for fused in (True, False):
+            os.environ["DVQ_NO_FUSED_ATTN"] = "0" if fused else "1"
+            try:
+                sg._seed_counter[0] = 77
+                for p_ in attn.parameters():
+                    p_.grad = None
+                tape = Tape()
+                y = attn.fwd(x, b, t, tape)
+                assert ("fused" in tape.s) == fused
+                dx = attn.bwd(dy, tape)
+                grads = [sg._grad_buf(p_).clone() for p_ in (attn.query.weight, attn.key.weight, attn.value.weight)]
+                for p_ in attn.parameters():
+                    sg._grad_buf(p_).zero_()
+                res.append([y.float().cpu().numpy(), dx.float().cpu().numpy()] + [g.float().cpu().numpy() for g in grads])
+            finally:
+                os.environ.pop("DVQ_NO_FUSED_ATTN", None)
+    for name, a, r in zip(("y", "dx", "dWq", "dWk", "dWv"), *res):
+        # two bf16 pipelines of the same arithmetic: L2 agreement (isolated bf16 rounding flips aside)
+        err = float(np.linalg.norm(a - r) / max(1e-9, np.linalg.norm(r)))
+        assert err < 2e-2, f"{name}: relative L2 difference {err}"
