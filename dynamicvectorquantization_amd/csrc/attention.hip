@@ -1,4 +1,4 @@
-// Fused causal multi-head self-attention of the stage-2 transformer (bf16, head size 64), forward and backward:
+// Fused causal multi-head self-attention of the stage-2 transformer (bf16, head size 64 or 128), forward and backward:
 //   CausalSelfAttention.forward   modules/dynamic_modules/stackgpt.py:41-69
 //       att = softmax(mask(q k^T / sqrt(hs)));  att = attn_drop(att);  y = att v
 // The unfused path (per-head GEMMs + softmax + dropout kernels, stackgpt.py of this package) moves the [B, nh, T, T] score
@@ -22,11 +22,10 @@
 
 namespace {
 
-constexpr int HS = 64;                       // head size
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct AttnParams {
-    const bf16_t *q, *k, *v, *o, *dout;      // [B*T][C] row-major, C = nh * 64
+    const bf16_t *q, *k, *v, *o, *dout;      // [B*T][C] row-major, C = nh * HS
     const bf16_t *qt, *kt, *vt, *dot;        // [B][C][T] channel-major copies
     bf16_t *out, *dq, *dk, *dv;
     float* lse;                              // [B][nh][T]: log-sum-exp of the scaled, masked scores (natural log)
@@ -78,11 +77,12 @@ __device__ __forceinline__ f32x16 zero16() {
 // accumulator register r of half `half` -> row offset inside the 32-row tile
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// [ch][row] accumulators (two 32-channel tiles) -> row-major [row][64 channels] bf16: lane = row, 4 consecutive channels
+// [ch][row] accumulators (NM 32-channel tiles) -> row-major [row][HS channels] bf16: lane = row, 4 consecutive channels
 // per register quad (8-byte stores)
-__device__ __forceinline__ void store_ct(bf16_t* dst /* row base + head offset */, const f32x16 (&acc)[2], int half, float mul) {
+template <int NM>
+__device__ __forceinline__ void store_ct(bf16_t* dst /* row base + head offset */, const f32x16 (&acc)[NM], int half, float mul) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < NM; ++mt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 w;
@@ -95,7 +95,9 @@ __device__ __forceinline__ void store_ct(bf16_t* dst /* row base + head offset *
 // ------------------------------------------------------------------------------------------------------------------
 // forward: one wave per 32 queries
 // ------------------------------------------------------------------------------------------------------------------
+template <int HS>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+    constexpr int NS = HS / 16, NM = HS / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int T = p.T, C = p.C;
@@ -107,10 +109,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     const bool qok = qrow < T;
     const int64_t rowbase = (int64_t)b * T;
     const bf16_t* qp = p.q + (rowbase + qrow) * C + h * HS + 8 * half;
-    bf16x8 qf[4];
+    bf16x8 qf[NS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = ldfrag(qp + 16 * s, qok);
-    f32x16 oacc[2] = {zero16(), zero16()};
+    for (int s = 0; s < NS; ++s) qf[s] = ldfrag(qp + 16 * s, qok);
+    f32x16 oacc[NM];
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt) oacc[mt] = zero16();
     float m_run = -INFINITY, l_run = 0.f;                       // running max (log2 domain) and sum
     const float c2 = p.scale * LOG2E;
     const unsigned idx_row = (unsigned)(((int64_t)bh * T + qrow) * T);
@@ -121,11 +125,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         const bf16_t* kp = p.k + (rowbase + krow) * C + h * HS + 8 * half;
         f32x16 s = zero16();
 #pragma unroll
-        for (int st = 0; st < 4; ++st) s = MFMA(ldfrag(kp + 16 * st, kok), qf[st], s);
+        for (int st = 0; st < NS; ++st) s = MFMA(ldfrag(kp + 16 * st, kok), qf[st], s);
         // V^T fragments of this key tile (issued early: independent of the softmax arithmetic)
-        bf16x8 vf[2][2];
+        bf16x8 vf[NM][2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < NM; ++mt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) vf[mt][s2] = ldfrag_t(vtp + (int64_t)32 * mt * T, k0 + 16 * s2 + 4 * half, T);
         float mx = m_run;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         l_run = l_run * alpha + rs;
         m_run = mx;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < NM; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
         if (p.thr != 0) {
@@ -170,16 +174,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8 pf = pack8(s, s2);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) oacc[mt] = MFMA(vf[mt][s2], pf, oacc[mt]);
+            for (int mt = 0; mt < NM; ++mt) oacc[mt] = MFMA(vf[mt][s2], pf, oacc[mt]);
         }
     }
     if (qok) {
-        store_ct(p.out + (rowbase + qrow) * C + h * HS, oacc, half, 1.f / l_run);
+        store_ct<NM>(p.out + (rowbase + qrow) * C + h * HS, oacc, half, 1.f / l_run);
         if (half == 0) p.lse[(int64_t)bh * T + qrow] = (m_run + __builtin_amdgcn_logf(l_run)) * (1.f / LOG2E);
     }
 }
 
 // dsum[b][h][t] = sum_ch dO * O    (one thread per (row, head))
+template <int HS>
 __global__ __launch_bounds__(256) void attn_rowdot_kernel(AttnParams p, int64_t rows) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= rows * p.nh) return;
@@ -203,7 +208,9 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(AttnParams p, int64_t 
 // ------------------------------------------------------------------------------------------------------------------
 // backward, dQ: one wave per 32 queries (same layout as the forward)
 // ------------------------------------------------------------------------------------------------------------------
+template <int HS>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+    constexpr int NS = HS / 16, NM = HS / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int T = p.T, C = p.C;
@@ -216,15 +223,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     const int64_t rowbase = (int64_t)b * T;
     const bf16_t* qp = p.q + (rowbase + qrow) * C + h * HS + 8 * half;
     const bf16_t* dop = p.dout + (rowbase + qrow) * C + h * HS + 8 * half;
-    bf16x8 qf[4], dof[4];
+    bf16x8 qf[NS], dof[NS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < NS; ++s) {
         qf[s] = ldfrag(qp + 16 * s, qok);
         dof[s] = ldfrag(dop + 16 * s, qok);
     }
     const float lq = qok ? p.lse[(int64_t)bh * T + qrow] * LOG2E : 0.f;
     const float dq_ = qok ? p.dsum[(int64_t)bh * T + qrow] : 0.f;
-    f32x16 acc[2] = {zero16(), zero16()};                        // dQ^T [ch][query]
+    f32x16 acc[NM];                                              // dQ^T [ch][query]
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt) acc[mt] = zero16();
     const float c2 = p.scale * LOG2E;
     const unsigned idx_row = (unsigned)(((int64_t)bh * T + qrow) * T);
     const bf16_t* ktp = p.kt + ((int64_t)b * C + h * HS + l31) * T;
@@ -235,13 +244,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         const bf16_t* vp = p.v + (rowbase + krow) * C + h * HS + 8 * half;
         f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        for (int st = 0; st < NS; ++st) {
             s = MFMA(ldfrag(kp + 16 * st, kok), qf[st], s);
             dp = MFMA(ldfrag(vp + 16 * st, kok), dof[st], dp);
         }
-        bf16x8 kf[2][2];
+        bf16x8 kf[NM][2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < NM; ++mt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) kf[mt][s2] = ldfrag_t(ktp + (int64_t)32 * mt * T, k0 + 16 * s2 + 4 * half, T);
         const bool diag = kt == qt;
@@ -258,16 +267,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8 df = pack8(s, s2);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) acc[mt] = MFMA(kf[mt][s2], df, acc[mt]);
+            for (int mt = 0; mt < NM; ++mt) acc[mt] = MFMA(kf[mt][s2], df, acc[mt]);
         }
     }
-    if (qok) store_ct(p.dq + (rowbase + qrow) * C + h * HS, acc, half, p.scale);
+    if (qok) store_ct<NM>(p.dq + (rowbase + qrow) * C + h * HS, acc, half, p.scale);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // backward, dK and dV: one wave per 32 keys, looping over the query tiles at or below the diagonal
 // ------------------------------------------------------------------------------------------------------------------
+template <int HS>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+    constexpr int NS = HS / 16, NM = HS / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int T = p.T, C = p.C;
@@ -280,13 +291,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     const int64_t rowbase = (int64_t)b * T;
     const bf16_t* kp = p.k + (rowbase + krow) * C + h * HS + 8 * half;
     const bf16_t* vp = p.v + (rowbase + krow) * C + h * HS + 8 * half;
-    bf16x8 kf[4], vf[4];
+    bf16x8 kf[NS], vf[NS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < NS; ++s) {
         kf[s] = ldfrag(kp + 16 * s, kok);
         vf[s] = ldfrag(vp + 16 * s, kok);
     }
-    f32x16 dv[2] = {zero16(), zero16()}, dk[2] = {zero16(), zero16()};      // dV^T, dK^T [ch][key]
+    f32x16 dv[NM], dk[NM];                                       // dV^T, dK^T [ch][key]
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt) dv[mt] = dk[mt] = zero16();
     const float c2 = p.scale * LOG2E;
     const bf16_t* qtp = p.qt + ((int64_t)b * C + h * HS + l31) * T;
     const bf16_t* dotp = p.dot + ((int64_t)b * C + h * HS + l31) * T;
@@ -299,13 +312,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         const bf16_t* dop = p.dout + (rowbase + qrow) * C + h * HS + 8 * half;
         f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        for (int st = 0; st < NS; ++st) {
             s = MFMA(ldfrag(qp + 16 * st, qok), kf[st], s);
             dp = MFMA(ldfrag(dop + 16 * st, qok), vf[st], dp);
         }
-        bf16x8 qa[2][2], da[2][2];
+        bf16x8 qa[NM][2], da[NM][2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < NM; ++mt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 qa[mt][s2] = ldfrag_t(qtp + (int64_t)32 * mt * T, q0 + 16 * s2 + 4 * half, T);
@@ -343,27 +356,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8 pf = pack8(pd, s2), df = pack8(s, s2);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < NM; ++mt) {
                 dv[mt] = MFMA(da[mt][s2], pf, dv[mt]);
                 dk[mt] = MFMA(qa[mt][s2], df, dk[mt]);
             }
         }
     }
     if (kok) {
-        store_ct(p.dv + (rowbase + krow) * C + h * HS, dv, half, 1.f);
-        store_ct(p.dk + (rowbase + krow) * C + h * HS, dk, half, p.scale);
+        store_ct<NM>(p.dv + (rowbase + krow) * C + h * HS, dv, half, 1.f);
+        store_ct<NM>(p.dk + (rowbase + krow) * C + h * HS, dk, half, p.scale);
     }
 }
 
 int fill_params(AttnParams& p, const char* who, int dtype, int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop,
                 uint64_t seed) {
-    DVQ_REQUIRE(dtype == DVQ_BF16 && head_dim == HS, DVQ_ESHAPE, "%s: bf16 with head size 64 only (use the per-head GEMM path otherwise)",
-                who);
+    DVQ_REQUIRE(dtype == DVQ_BF16 && (head_dim == 64 || head_dim == 128), DVQ_ESHAPE,
+                "%s: bf16 with head size 64 or 128 only (use the per-head GEMM path otherwise)", who);
     DVQ_REQUIRE(B > 0 && T > 0 && T % 8 == 0 && n_head > 0 && B * n_head <= 65535 && p_drop >= 0.f && p_drop < 1.f, DVQ_ESHAPE,
                 "%s: bad geometry (T %% 8 == 0, B * n_head <= 65535)", who);
     DVQ_REQUIRE((double)B * n_head * (double)T * (double)T < 4294967296.0, DVQ_ESHAPE,
                 "%s: B * n_head * T * T must stay below 2^32 (dropout element index)", who);
-    p.T = (int)T; p.nh = n_head; p.C = n_head * HS;
+    p.T = (int)T; p.nh = n_head; p.C = n_head * head_dim;
     p.scale = scale;
     p.inv_keep = 1.f / (1.f - p_drop);
     p.thr = (unsigned)((double)p_drop * 4294967296.0);
@@ -392,7 +405,9 @@ int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, 
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.vt = (const bf16_t*)scratch;
     p.out = (bf16_t*)out; p.lse = lse;
     const int nqt = (int)((T + 31) / 32);
-    attn_fwd_kernel<<<dim3((unsigned)((nqt + 3) / 4), (unsigned)(B * n_head)), dim3(256), 0, (hipStream_t)stream>>>(p);
+    const dim3 grid((unsigned)((nqt + 3) / 4), (unsigned)(B * n_head));
+    if (head_dim == 64) attn_fwd_kernel<64><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
+    else attn_fwd_kernel<128><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
     DVQ_CHECK_LAUNCH("attn_causal_fwd");
     return DVQ_OK;
 }
@@ -417,13 +432,16 @@ int dvq_attn_causal_bwd(const void* q, const void* k, const void* v, const void*
     p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
     p.lse = const_cast<float*>(lse); p.dsum = dsum;
     const int64_t rows = B * T;
-    attn_rowdot_kernel<<<dim3((unsigned)cdiv64(rows * n_head, 256)), dim3(256), 0, (hipStream_t)stream>>>(p, rows);
+    if (head_dim == 64) attn_rowdot_kernel<64><<<dim3((unsigned)cdiv64(rows * n_head, 256)), dim3(256), 0, (hipStream_t)stream>>>(p, rows);
+    else attn_rowdot_kernel<128><<<dim3((unsigned)cdiv64(rows * n_head, 256)), dim3(256), 0, (hipStream_t)stream>>>(p, rows);
     DVQ_CHECK_LAUNCH("attn_rowdot");
     const int nt = (int)((T + 31) / 32);
     const dim3 grid((unsigned)((nt + 3) / 4), (unsigned)(B * n_head));
-    attn_bwd_dkv_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
+    if (head_dim == 64) attn_bwd_dkv_kernel<64><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
+    else attn_bwd_dkv_kernel<128><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
     DVQ_CHECK_LAUNCH("attn_causal_bwd_dkv");
-    attn_bwd_dq_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
+    if (head_dim == 64) attn_bwd_dq_kernel<64><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
+    else attn_bwd_dq_kernel<128><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
     DVQ_CHECK_LAUNCH("attn_causal_bwd_dq");
     return DVQ_OK;
 }

@@ -703,14 +703,14 @@ def dropout(x, p, seed):
 
 
 def attn_causal_ok(x, n_head, b, t):
-    """eligibility of the fused attention kernels (include/dvq_hip.h: bf16, head size 64, T % 8 == 0, index range)"""
+    """eligibility of the fused attention kernels (include/dvq_hip.h: bf16, head size 64 / 128, T % 8 == 0, index range)"""
     c = x.shape[-1]
-    return (x.dtype == torch.bfloat16 and c == n_head * 64 and t % 8 == 0 and b * n_head <= 65535 and b * n_head * t * t < (1 << 32)
+    return (x.dtype == torch.bfloat16 and c in (n_head * 64, n_head * 128) and t % 8 == 0 and b * n_head <= 65535 and b * n_head * t * t < (1 << 32)
             and os.environ.get("DVQ_NO_FUSED_ATTN", "0") != "1")
 
 
 def _attn_scratch(q, b, t, n_head, backward):
-    nbytes = lib().dvq_attn_causal_scratch_bytes(b, t, n_head, 64, int(backward))
+    nbytes = lib().dvq_attn_causal_scratch_bytes(b, t, n_head, q.shape[-1] // n_head, int(backward))
     return torch.empty(nbytes, dtype=torch.uint8, device=q.device)
 
 
@@ -719,7 +719,7 @@ def attn_causal_fwd(q, k, v, b, t, n_head, scale, p_drop=0.0, seed=0):
     out = torch.empty_like(q)
     lse = torch.empty(b, n_head, t, dtype=torch.float32, device=q.device)
     scratch = _attn_scratch(q, b, t, n_head, False)
-    check(lib().dvq_attn_causal_fwd(_p(q), _p(k), _p(v), dt(q), b, t, n_head, 64, float(scale), float(p_drop),
+    check(lib().dvq_attn_causal_fwd(_p(q), _p(k), _p(v), dt(q), b, t, n_head, q.shape[-1] // n_head, float(scale), float(p_drop),
                                     int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out), _p(lse), _p(scratch), _s()), "dvq_attn_causal_fwd")
     return out, lse
 
@@ -727,7 +727,7 @@ def attn_causal_fwd(q, k, v, b, t, n_head, scale, p_drop=0.0, seed=0):
 def attn_causal_bwd(q, k, v, out, dout, lse, b, t, n_head, scale, p_drop=0.0, seed=0):
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     scratch = _attn_scratch(q, b, t, n_head, True)
-    check(lib().dvq_attn_causal_bwd(_p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), dt(q), b, t, n_head, 64, float(scale),
+    check(lib().dvq_attn_causal_bwd(_p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), dt(q), b, t, n_head, q.shape[-1] // n_head, float(scale),
                                     float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(dq), _p(dk), _p(dv), _p(scratch), _s()),
           "dvq_attn_causal_bwd")
     return dq, dk, dv

@@ -94,7 +94,7 @@ class CausalSelfAttention(nn.Module):
         k = self.key.fwd(x2d, _child(tape, "k"))
         q = self.query.fwd(x2d, _child(tape, "q"))
         v = self.value.fwd(x2d, _child(tape, "v"))
-        fused = K.attn_causal_ok(x2d, nh, b, t) and hs == 64 and not self._n_unmasked
+        fused = K.attn_causal_ok(x2d, nh, b, t) and not self._n_unmasked
         if fused:
             # one kernel per direction, scores stay in registers (csrc/attention.hip)
             p_drop = self.attn_drop.p if self.training else 0.0

@@ -333,13 +333,13 @@ int dvq_embed_scatter_add(const int64_t* idx, int64_t idx_bstride, const void* d
  * when dlogits != NULL, dlogits = (softmax - onehot) * gscale_dev[0] (0 on ignored rows and on columns >= V; row stride ldl) */
 int dvq_cross_entropy(const void* logits, int dtype, int64_t rows, int64_t V, int64_t ldl, const int64_t* target, int64_t ignore_index,
                       float* loss_sum, float* count, const float* gscale_dev, void* dlogits, dvq_stream_t stream);
-/* Fused causal multi-head self-attention (bf16, head_dim == 64) -- CausalSelfAttention.forward, stackgpt.py:41-69:
+/* Fused causal multi-head self-attention (bf16, head_dim 64 or 128) -- CausalSelfAttention.forward, stackgpt.py:41-69:
  *   out = attn_drop(softmax(causal_mask(q k^T * scale))) v      per (batch, head), scores never materialised.
- * q, k, v, out, dout, dq, dk, dv: [B*T][n_head*64] row-major (head h = columns h*64 .. h*64+63); T % 8 == 0;
+ * q, k, v, out, dout, dq, dk, dv: [B*T][n_head*head_dim] row-major (head h = columns h*head_dim ..); T % 8 == 0;
  * lse: fp32 [B][n_head][T] (forward output, backward input); p_drop / seed: attention dropout (element index of the
  * [B][n_head][T][T] probability tensor, same generator as dvq_dropout; p_drop == 0: none).
- * scratch: dvq_attn_causal_scratch_bytes(B, T, n_head, 64, backward) bytes of device memory (channel-major operand copies).
- * DVQ_ESHAPE when dtype / head_dim are not bf16 / 64: callers use the per-head GEMM path then. */
+ * scratch: dvq_attn_causal_scratch_bytes(B, T, n_head, head_dim, backward) bytes of device memory (channel-major operand copies).
+ * DVQ_ESHAPE when dtype / head_dim are not bf16 / 64 or 128: callers use the per-head GEMM path then. */
 int64_t dvq_attn_causal_scratch_bytes(int64_t B, int64_t T, int n_head, int head_dim, int backward);
 int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, int64_t B, int64_t T, int n_head, int head_dim,
                         float scale, float p_drop, uint64_t seed, void* out, float* lse, void* scratch, dvq_stream_t stream);

@@ -1,6 +1,6 @@
-"""GPU parity of the fused causal attention kernels (csrc/attention.hip: bf16, head size 64) against an fp32 torch
+"""GPU parity of the fused causal attention kernels (csrc/attention.hip: bf16, head size 64 / 128) against an fp32 torch
 restatement of CausalSelfAttention.forward (/root/reference/modules/dynamic_modules/stackgpt.py:41-69) and against the
-package's own unfused per-head GEMM path.  Tolerance: rel-to-max 2e-2 (bf16 operands, fp32 accumulation)."""
+package's own unfused per-head GEMM path; head sizes 64 and 128 (the shipped p6c18 configs use 8 heads of 128).  Tolerance: rel-to-max 2e-2 (bf16 operands, fp32 accumulation)."""
 import math
 import os
 
@@ -15,9 +15,8 @@ def _bf16(a):
     return torch.from_numpy(a).to(torch.bfloat16).float().numpy()
 
 
-def _reference(q, k, v, dout, b, t, nh, mask=None):
-    """fp32 autograd restatement; q, k, v, dout numpy [b*t, nh*64]; mask [b, nh, t, t] multiplicative (dropout) or None"""
-    hs = 64
+def _reference(q, k, v, dout, b, t, nh, mask=None, hs=64):
+    """fp64 autograd restatement; q, k, v, dout numpy [b*t, nh*hs]; mask [b, nh, t, t] multiplicative (dropout) or None"""
     qs, ks, vs = (torch.from_numpy(a).double().view(b, t, nh, hs).transpose(1, 2).requires_grad_(True) for a in (q, k, v))
     att = (qs @ ks.transpose(-2, -1)) * (1.0 / math.sqrt(hs))
     causal = torch.tril(torch.ones(t, t, dtype=torch.bool))
@@ -36,10 +35,12 @@ def _rel(got, ref):
 
 @pytest.mark.parametrize("shape", [(2, 72, 2), (1, 32, 1), (3, 200, 4), (1, 648, 2)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("p_drop", [0.0, 0.25])
-def test_fused_attention_vs_fp64_reference(dev, shape, p_drop):
+@pytest.mark.parametrize("hs", [64, 128])
+def test_fused_attention_vs_fp64_reference(dev, shape, p_drop, hs):
     from dynamicvectorquantization_amd import kernels as K
     b, t, nh = shape
-    c = nh * 64
+    c = nh * hs
+    scale = 1.0 / math.sqrt(hs)
     rs = np.random.RandomState(b * 1000 + t)
     q, k, v, dout = (_bf16(rs.standard_normal((b * t, c)).astype(np.float32) * s) for s in (1.5, 1.5, 1.0, 1.0))
     seed = 0x1234_5678_9ABC + t
@@ -50,15 +51,15 @@ def test_fused_attention_vs_fp64_reference(dev, shape, p_drop):
         mask = (K.dropout(ones, p_drop, seed).float() > 0).float().view(b, nh, t, t).cpu().numpy() / (1.0 - p_drop)
         keep = float((mask > 0).mean())
         assert abs(keep - (1 - p_drop)) < 0.02, keep
-    yr, dqr, dkr, dvr = _reference(q, k, v, dout, b, t, nh, mask)
+    yr, dqr, dkr, dvr = _reference(q, k, v, dout, b, t, nh, mask, hs)
     dq_, dk_, dv_, do_ = (torch.from_numpy(a).to(dev, torch.bfloat16) for a in (q, k, v, dout))
     assert K.attn_causal_ok(dq_, nh, b, t)
-    y, lse = K.attn_causal_fwd(dq_, dk_, dv_, b, t, nh, 1.0 / 8.0, p_drop, seed)
-    gq, gk, gv = K.attn_causal_bwd(dq_, dk_, dv_, y, do_, lse, b, t, nh, 1.0 / 8.0, p_drop, seed)
+    y, lse = K.attn_causal_fwd(dq_, dk_, dv_, b, t, nh, scale, p_drop, seed)
+    gq, gk, gv = K.attn_causal_bwd(dq_, dk_, dv_, y, do_, lse, b, t, nh, scale, p_drop, seed)
     torch.cuda.synchronize()
     assert _rel(y.float().cpu().numpy(), yr) < 2e-2
     # log-sum-exp of the scaled causal scores (saved for the backward)
-    sc = (torch.from_numpy(q).view(b, t, nh, 64).transpose(1, 2) @ torch.from_numpy(k).view(b, t, nh, 64).transpose(1, 2).transpose(-2, -1)) / 8.0
+    sc = (torch.from_numpy(q).view(b, t, nh, hs).transpose(1, 2) @ torch.from_numpy(k).view(b, t, nh, hs).transpose(1, 2).transpose(-2, -1)) * scale
     sc = sc.masked_fill(~torch.tril(torch.ones(t, t, dtype=torch.bool)), float("-inf"))
     np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(sc, dim=-1).numpy(), rtol=2e-3, atol=2e-3)
     for name, got, ref in (("dq", gq, dqr), ("dk", gk, dkr), ("dv", gv, dvr)):
@@ -71,19 +72,21 @@ def test_fused_attention_rejects_unsupported_geometry(dev):
     x = torch.zeros(2 * 36, 64, dtype=torch.bfloat16, device=dev)
     assert not K.attn_causal_ok(x, 1, 2, 36)              # T % 8 != 0
     assert not K.attn_causal_ok(x.float(), 1, 2, 36)
+    assert not K.attn_causal_ok(x, 2, 2, 40)              # head size 32
     with pytest.raises(DvqError):
         K.attn_causal_fwd(x, x, x, 2, 36, 1, 0.125)
 
 
 @pytest.mark.parametrize("train", [False, True])
-def test_attention_module_fused_equals_unfused_full_size(dev, train):
-    """CausalSelfAttention of the p6c18 transformer (1024 channels, 16 heads, T = 648), forward + backward: the fused kernels
+@pytest.mark.parametrize("n_head", [8, 16])
+def test_attention_module_fused_equals_unfused_full_size(dev, train, n_head):
+    """CausalSelfAttention of the p6c18 transformer (1024 channels, 8 heads of 128; also 16 x 64; T = 648), fwd + bwd: the fused kernels
     against the per-head GEMM path on identical weights, inputs and dropout seeds"""
     from types import SimpleNamespace
     from dynamicvectorquantization_amd import runtime as rt
     from dynamicvectorquantization_amd import stackgpt as sg
     from dynamicvectorquantization_amd.layers import Tape
-    cfg = SimpleNamespace(n_embd=1024, n_head=16, attn_pdrop=0.1, resid_pdrop=0.1, block_size=648)
+    cfg = SimpleNamespace(n_embd=1024, n_head=n_head, attn_pdrop=0.1, resid_pdrop=0.1, block_size=648)
     b, t = 2, 648
     torch.manual_seed(5)
     with rt.compute_dtype_ctx(torch.bfloat16):
