@@ -16,8 +16,11 @@
 // The second GEMM's k index is PERMUTED to the accumulator's register order (k = 8 * half + j  <->  register 8 * s + j,
 // i.e. row (j & 3) + 8 * (2 s + (j >> 2)) + 4 * half): the B operand is then the accumulator itself (converted to bf16) and
 // the A operand -- read from a channel-major (transposed) copy of V / K / Q / dO -- is two 8-byte loads of 4 consecutive
-// rows.  Operands come straight from global memory (L1/L2 resident: one head's K, V are 2 x 81 KiB); no LDS.
-// One wave per 32-row tile, 4 waves (4 tiles of the same batch x head) per workgroup, heavy tiles first.
+// rows.
+// One wave per 32-row tile; the 4 waves of a workgroup own 4 neighbouring tiles of the same (batch, head) and walk the
+// other sequence axis together: each 32-row operand tile is fetched from global memory ONCE per workgroup into registers
+// (issued one tile ahead), published through double-buffered LDS (one barrier per tile) and read by all four waves as MFMA
+// fragments (padded rows: conflict-free ds_read_b128 / ds_read_b64).  Waves beyond their causal range idle for <= 3 tiles.
 #include "dvq_common.h"
 
 namespace {
@@ -42,17 +45,70 @@ union Frag {
     uint2 h[2];
 };
 
-__device__ __forceinline__ bf16x8 ldfrag(const bf16_t* p, bool ok) {
+// LDS tile geometry: row-major tiles [32 rows][HS channels] (K, V, Q, dO) and channel-major tiles [HS channels][32 rows]
+// (V^T, K^T, Q^T, dO^T); row strides padded by 16 bytes
+template <int HS>
+struct Geo {
+    static constexpr int RROW = HS * 2 + 16;          // bytes per row of a row-major tile
+    static constexpr int CROW = 64 + 16;              // bytes per channel of a channel-major tile
+    static constexpr int RTILE = 32 * RROW;
+    static constexpr int CTILE = HS * CROW;
+    static constexpr int NCH = HS / 64;               // 16-byte chunks per thread and tile (256 threads)
+};
+
+// global -> registers: rows r0 .. r0+31 of a row-major [.., C] matrix (head slice of HS channels); rows >= T read as zero
+template <int HS>
+__device__ __forceinline__ void gload_rows(const bf16_t* base, int64_t rowbase, int r0, int T, int C, int tid, uint4 (&reg)[HS / 64]) {
+#pragma unroll
+    for (int i = 0; i < HS / 64; ++i) {
+        const int id = tid + 256 * i, row = id / (HS / 8), cc = id % (HS / 8);
+        reg[i] = r0 + row < T ? *reinterpret_cast<const uint4*>(base + (rowbase + r0 + row) * C + cc * 8) : make_uint4(0, 0, 0, 0);
+    }
+}
+template <int HS>
+__device__ __forceinline__ void swrite_rows(char* tile, int tid, const uint4 (&reg)[HS / 64]) {
+#pragma unroll
+    for (int i = 0; i < HS / 64; ++i) {
+        const int id = tid + 256 * i, row = id / (HS / 8), cc = id % (HS / 8);
+        *reinterpret_cast<uint4*>(tile + row * Geo<HS>::RROW + cc * 16) = reg[i];
+    }
+}
+// global -> registers: columns r0 .. r0+31 of a channel-major [HS channels][T] slice; columns >= T read as zero (T % 8 == 0)
+template <int HS>
+__device__ __forceinline__ void gload_cols(const bf16_t* base, int r0, int T, int tid, uint4 (&reg)[HS / 64]) {
+#pragma unroll
+    for (int i = 0; i < HS / 64; ++i) {
+        const int id = tid + 256 * i, ch = id >> 2, kc = id & 3;
+        reg[i] = r0 + kc * 8 < T ? *reinterpret_cast<const uint4*>(base + (int64_t)ch * T + r0 + kc * 8) : make_uint4(0, 0, 0, 0);
+    }
+}
+template <int HS>
+__device__ __forceinline__ void swrite_cols(char* tile, int tid, const uint4 (&reg)[HS / 64]) {
+#pragma unroll
+    for (int i = 0; i < HS / 64; ++i) {
+        const int id = tid + 256 * i, ch = id >> 2, kc = id & 3;
+        *reinterpret_cast<uint4*>(tile + ch * Geo<HS>::CROW + kc * 16) = reg[i];
+    }
+}
+
+// MFMA fragments from LDS tiles.  Row-major tile: lane -> row l31, channels 16 st + 8 half .. +7
+template <int HS>
+__device__ __forceinline__ bf16x8 frag_r(const char* tile, int l31, int half, int st) {
+    return *reinterpret_cast<const bf16x8*>(tile + l31 * Geo<HS>::RROW + (16 * st + 8 * half) * 2);
+}
+// channel-major tile, permuted-k A operand: lane -> channel 32 mt + l31, rows 16 s2 + 4 half + {0..3, 8..11}
+template <int HS>
+__device__ __forceinline__ bf16x8 frag_c(const char* tile, int l31, int half, int mt, int s2) {
+    const char* q = tile + (32 * mt + l31) * Geo<HS>::CROW + (16 * s2 + 4 * half) * 2;
     Frag f;
-    f.u = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+    f.h[0] = *reinterpret_cast<const uint2*>(q);
+    f.h[1] = *reinterpret_cast<const uint2*>(q + 16);
     return f.v;
 }
 
-// A operand of the permuted-k GEMMs: rows r0 .. r0+3 and r0+8 .. r0+11 of a channel-major row (8-byte loads; T % 4 == 0)
-__device__ __forceinline__ bf16x8 ldfrag_t(const bf16_t* p, int r0, int T) {
+__device__ __forceinline__ bf16x8 ldfrag(const bf16_t* p, bool ok) {
     Frag f;
-    f.h[0] = r0 < T ? *reinterpret_cast<const uint2*>(p + r0) : make_uint2(0, 0);
-    f.h[1] = r0 + 8 < T ? *reinterpret_cast<const uint2*>(p + r0 + 8) : make_uint2(0, 0);
+    f.u = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
     return f.v;
 }
 
@@ -93,89 +149,110 @@ __device__ __forceinline__ void store_ct(bf16_t* dst /* row base + head offset *
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// forward: one wave per 32 queries
+// forward: one wave per 32 queries; the workgroup walks the key tiles 0 .. (its last query tile)
 // ------------------------------------------------------------------------------------------------------------------
 template <int HS>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
-    constexpr int NS = HS / 16, NM = HS / 32;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    using G = Geo<HS>;
+    constexpr int NS = HS / 16, NM = HS / 32, STAGE = G::RTILE + G::CTILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int T = p.T, C = p.C;
     const int bh = blockIdx.y, b = bh / p.nh, h = bh - b * p.nh;
     const int nqt = (T + 31) / 32;
-    const int qt = nqt - 1 - (blockIdx.x * 4 + wave);          // late (long) query tiles first
-    if (qt < 0) return;
+    const int qt_max = nqt - 1 - blockIdx.x * 4;                 // late (long) query tiles first; wave 0 owns the last one
+    const int qt = qt_max - wave;
+    const bool active = qt >= 0;
     const int q0 = qt * 32, qrow = q0 + l31;
-    const bool qok = qrow < T;
+    const bool qok = active && qrow < T;
     const int64_t rowbase = (int64_t)b * T;
-    const bf16_t* qp = p.q + (rowbase + qrow) * C + h * HS + 8 * half;
     bf16x8 qf[NS];
+    {
+        const bf16_t* qp = p.q + (rowbase + qrow) * C + h * HS + 8 * half;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) qf[s] = ldfrag(qp + 16 * s, qok);
+        for (int s = 0; s < NS; ++s) qf[s] = ldfrag(qp + 16 * s, qok);
+    }
     f32x16 oacc[NM];
 #pragma unroll
     for (int mt = 0; mt < NM; ++mt) oacc[mt] = zero16();
     float m_run = -INFINITY, l_run = 0.f;                       // running max (log2 domain) and sum
     const float c2 = p.scale * LOG2E;
     const unsigned idx_row = (unsigned)(((int64_t)bh * T + qrow) * T);
-    const bf16_t* vtp = p.vt + ((int64_t)b * C + h * HS + l31) * T;
-    for (int kt = 0; kt <= qt; ++kt) {
-        const int k0 = kt * 32, krow = k0 + l31;
-        const bool kok = krow < T;
-        const bf16_t* kp = p.k + (rowbase + krow) * C + h * HS + 8 * half;
-        f32x16 s = zero16();
+    const bf16_t* kbase = p.k + h * HS;
+    const bf16_t* vtbase = p.vt + ((int64_t)b * C + h * HS) * T;
+    uint4 rk[G::NCH], rv[G::NCH];
+    gload_rows<HS>(kbase, rowbase, 0, T, C, tid, rk);
+    gload_cols<HS>(vtbase, 0, T, tid, rv);
+    swrite_rows<HS>(smem, tid, rk);
+    swrite_cols<HS>(smem + G::RTILE, tid, rv);
+    __syncthreads();
+    for (int kt = 0; kt <= qt_max; ++kt) {
+        const char* kl = smem + (kt & 1) * STAGE;
+        const char* vl = kl + G::RTILE;
+        const bool more = kt < qt_max;
+        if (more) {
+            gload_rows<HS>(kbase, rowbase, 32 * (kt + 1), T, C, tid, rk);
+            gload_cols<HS>(vtbase, 32 * (kt + 1), T, tid, rv);
+        }
+        if (active && kt <= qt) {
+            const int k0 = kt * 32;
+            f32x16 s = zero16();
 #pragma unroll
-        for (int st = 0; st < NS; ++st) s = MFMA(ldfrag(kp + 16 * st, kok), qf[st], s);
-        // V^T fragments of this key tile (issued early: independent of the softmax arithmetic)
-        bf16x8 vf[NM][2];
+            for (int st = 0; st < NS; ++st) s = MFMA(frag_r<HS>(kl, l31, half, st), qf[st], s);
+            float mx = m_run;
+            if (kt == qt) {                                      // diagonal tile: causal mask (also hides keys >= T)
 #pragma unroll
-        for (int mt = 0; mt < NM; ++mt)
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + crow(r, half);
+                    s[r] = (key <= qrow && key < T) ? s[r] * c2 : -INFINITY;
+                    mx = fmaxf(mx, s[r]);
+                }
+            } else {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) vf[mt][s2] = ldfrag_t(vtp + (int64_t)32 * mt * T, k0 + 16 * s2 + 4 * half, T);
-        float mx = m_run;
-        if (kt == qt) {                                          // diagonal tile: causal mask (also hides keys >= T)
+                for (int r = 0; r < 16; ++r) {
+                    s[r] *= c2;
+                    mx = fmaxf(mx, s[r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mref = mx == -INFINITY ? 0.f : mx;       // rows without any valid key (padding rows only)
+            const float alpha = __builtin_amdgcn_exp2f(m_run - mref);
+            float rs = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = k0 + crow(r, half);
-                s[r] = (key <= qrow && key < T) ? s[r] * c2 : -INFINITY;
-                mx = fmaxf(mx, s[r]);
+                s[r] = __builtin_amdgcn_exp2f(s[r] - mref);
+                rs += s[r];
             }
-        } else {
+            rs += __shfl_xor(rs, 32, 64);
+            l_run = l_run * alpha + rs;
+            m_run = mx;
+            if (!__all(alpha == 1.f)) {                          // the running maximum settles after a few tiles
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] *= c2;
-                mx = fmaxf(mx, s[r]);
+                for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
             }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mref = mx == -INFINITY ? 0.f : mx;           // rows without any valid key (padding rows only)
-        const float alpha = __builtin_amdgcn_exp2f(m_run - mref);
-        float rs = 0.f;
+            if (p.thr != 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = __builtin_amdgcn_exp2f(s[r] - mref);
-            rs += s[r];
-        }
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = mx;
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned idx = idx_row + (unsigned)(k0 + crow(r, half));
+                    s[r] = dvq_hash32(idx * p.rm + p.ra) >= p.thr ? s[r] * p.inv_keep : 0.f;
+                }
+            }
 #pragma unroll
-        for (int mt = 0; mt < NM; ++mt)
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(s, s2);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
-        if (p.thr != 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned idx = idx_row + (unsigned)(k0 + crow(r, half));
-                s[r] = dvq_hash32(idx * p.rm + p.ra) >= p.thr ? s[r] * p.inv_keep : 0.f;
+                for (int mt = 0; mt < NM; ++mt) oacc[mt] = MFMA(frag_c<HS>(vl, l31, half, mt, s2), pf, oacc[mt]);
             }
         }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pf = pack8(s, s2);
-#pragma unroll
-            for (int mt = 0; mt < NM; ++mt) oacc[mt] = MFMA(vf[mt][s2], pf, oacc[mt]);
+        if (more) {
+            char* nl = smem + ((kt + 1) & 1) * STAGE;
+            swrite_rows<HS>(nl, tid, rk);
+            swrite_cols<HS>(nl + G::RTILE, tid, rv);
         }
+        __syncthreads();
     }
     if (qok) {
         store_ct<NM>(p.out + (rowbase + qrow) * C + h * HS, oacc, half, 1.f / l_run);
@@ -206,28 +283,33 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(AttnParams p, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// backward, dQ: one wave per 32 queries (same layout as the forward)
+// backward, dQ: one wave per 32 queries (same walk as the forward); LDS stage = K, V (row-major) and K^T tiles
 // ------------------------------------------------------------------------------------------------------------------
 template <int HS>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
-    constexpr int NS = HS / 16, NM = HS / 32;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    using G = Geo<HS>;
+    constexpr int NS = HS / 16, NM = HS / 32, STAGE = 2 * G::RTILE + G::CTILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int T = p.T, C = p.C;
     const int bh = blockIdx.y, b = bh / p.nh, h = bh - b * p.nh;
     const int nqt = (T + 31) / 32;
-    const int qt = nqt - 1 - (blockIdx.x * 4 + wave);
-    if (qt < 0) return;
+    const int qt_max = nqt - 1 - blockIdx.x * 4;
+    const int qt = qt_max - wave;
+    const bool active = qt >= 0;
     const int q0 = qt * 32, qrow = q0 + l31;
-    const bool qok = qrow < T;
+    const bool qok = active && qrow < T;
     const int64_t rowbase = (int64_t)b * T;
-    const bf16_t* qp = p.q + (rowbase + qrow) * C + h * HS + 8 * half;
-    const bf16_t* dop = p.dout + (rowbase + qrow) * C + h * HS + 8 * half;
     bf16x8 qf[NS], dof[NS];
+    {
+        const bf16_t* qp = p.q + (rowbase + qrow) * C + h * HS + 8 * half;
+        const bf16_t* dop = p.dout + (rowbase + qrow) * C + h * HS + 8 * half;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        qf[s] = ldfrag(qp + 16 * s, qok);
-        dof[s] = ldfrag(dop + 16 * s, qok);
+        for (int s = 0; s < NS; ++s) {
+            qf[s] = ldfrag(qp + 16 * s, qok);
+            dof[s] = ldfrag(dop + 16 * s, qok);
+        }
     }
     const float lq = qok ? p.lse[(int64_t)bh * T + qrow] * LOG2E : 0.f;
     const float dq_ = qok ? p.dsum[(int64_t)bh * T + qrow] : 0.f;
@@ -236,136 +318,204 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     for (int mt = 0; mt < NM; ++mt) acc[mt] = zero16();
     const float c2 = p.scale * LOG2E;
     const unsigned idx_row = (unsigned)(((int64_t)bh * T + qrow) * T);
-    const bf16_t* ktp = p.kt + ((int64_t)b * C + h * HS + l31) * T;
-    for (int kt = 0; kt <= qt; ++kt) {
-        const int k0 = kt * 32, krow = k0 + l31;
-        const bool kok = krow < T;
-        const bf16_t* kp = p.k + (rowbase + krow) * C + h * HS + 8 * half;
-        const bf16_t* vp = p.v + (rowbase + krow) * C + h * HS + 8 * half;
-        f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            s = MFMA(ldfrag(kp + 16 * st, kok), qf[st], s);
-            dp = MFMA(ldfrag(vp + 16 * st, kok), dof[st], dp);
+    const bf16_t* kbase = p.k + h * HS;
+    const bf16_t* vbase = p.v + h * HS;
+    const bf16_t* ktbase = p.kt + ((int64_t)b * C + h * HS) * T;
+    uint4 rk[G::NCH], rv[G::NCH], rt[G::NCH];
+    gload_rows<HS>(kbase, rowbase, 0, T, C, tid, rk);
+    gload_rows<HS>(vbase, rowbase, 0, T, C, tid, rv);
+    gload_cols<HS>(ktbase, 0, T, tid, rt);
+    swrite_rows<HS>(smem, tid, rk);
+    swrite_rows<HS>(smem + G::RTILE, tid, rv);
+    swrite_cols<HS>(smem + 2 * G::RTILE, tid, rt);
+    __syncthreads();
+    for (int kt = 0; kt <= qt_max; ++kt) {
+        const char* kl = smem + (kt & 1) * STAGE;
+        const char* vl = kl + G::RTILE;
+        const char* tl = kl + 2 * G::RTILE;
+        const bool more = kt < qt_max;
+        if (more) {
+            gload_rows<HS>(kbase, rowbase, 32 * (kt + 1), T, C, tid, rk);
+            gload_rows<HS>(vbase, rowbase, 32 * (kt + 1), T, C, tid, rv);
+            gload_cols<HS>(ktbase, 32 * (kt + 1), T, tid, rt);
         }
-        bf16x8 kf[NM][2];
+        if (active && kt <= qt) {
+            const int k0 = kt * 32;
+            f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-        for (int mt = 0; mt < NM; ++mt)
+            for (int st = 0; st < NS; ++st) {
+                s = MFMA(frag_r<HS>(kl, l31, half, st), qf[st], s);
+                dp = MFMA(frag_r<HS>(vl, l31, half, st), dof[st], dp);
+            }
+            const bool diag = kt == qt;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) kf[mt][s2] = ldfrag_t(ktp + (int64_t)32 * mt * T, k0 + 16 * s2 + 4 * half, T);
-        const bool diag = kt == qt;
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + crow(r, half);
+                const bool valid = !diag || (key <= qrow && key < T);
+                const float pr = valid ? __builtin_amdgcn_exp2f(s[r] * c2 - lq) : 0.f;
+                float g = dp[r];
+                if (p.thr != 0) g = dvq_hash32((idx_row + (unsigned)key) * p.rm + p.ra) >= p.thr ? g * p.inv_keep : 0.f;
+                s[r] = pr * (g - dq_);                            // d loss / d (scaled score)
+            }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + crow(r, half);
-            const bool valid = !diag || (key <= qrow && key < T);
-            const float pr = valid ? __builtin_amdgcn_exp2f(s[r] * c2 - lq) : 0.f;
-            float g = dp[r];
-            if (p.thr != 0) g = dvq_hash32((idx_row + (unsigned)key) * p.rm + p.ra) >= p.thr ? g * p.inv_keep : 0.f;
-            s[r] = pr * (g - dq_);                                // d loss / d (scaled score)
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 df = pack8(s, s2);
+#pragma unroll
+                for (int mt = 0; mt < NM; ++mt) acc[mt] = MFMA(frag_c<HS>(tl, l31, half, mt, s2), df, acc[mt]);
+            }
         }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 df = pack8(s, s2);
-#pragma unroll
-            for (int mt = 0; mt < NM; ++mt) acc[mt] = MFMA(kf[mt][s2], df, acc[mt]);
+        if (more) {
+            char* nl = smem + ((kt + 1) & 1) * STAGE;
+            swrite_rows<HS>(nl, tid, rk);
+            swrite_rows<HS>(nl + G::RTILE, tid, rv);
+            swrite_cols<HS>(nl + 2 * G::RTILE, tid, rt);
         }
+        __syncthreads();
     }
     if (qok) store_ct<NM>(p.dq + (rowbase + qrow) * C + h * HS, acc, half, p.scale);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// backward, dK and dV: one wave per 32 keys, looping over the query tiles at or below the diagonal
+// backward, dK and dV: one wave per 32 keys; the workgroup walks the query tiles from its first key tile to the end;
+// LDS stage = Q, dO (row-major) and Q^T, dO^T tiles
 // ------------------------------------------------------------------------------------------------------------------
 template <int HS>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
-    constexpr int NS = HS / 16, NM = HS / 32;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    using G = Geo<HS>;
+    constexpr int NS = HS / 16, NM = HS / 32, STAGE = 2 * G::RTILE + 2 * G::CTILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int T = p.T, C = p.C;
     const int bh = blockIdx.y, b = bh / p.nh, h = bh - b * p.nh;
     const int nt = (T + 31) / 32;
-    const int kt = blockIdx.x * 4 + wave;                         // early (long) key tiles first
-    if (kt >= nt) return;
+    const int kt_min = blockIdx.x * 4;                            // early (long) key tiles first
+    const int kt = kt_min + wave;
+    const bool active = kt < nt;
     const int k0 = kt * 32, krow = k0 + l31;
-    const bool kok = krow < T;
+    const bool kok = active && krow < T;
     const int64_t rowbase = (int64_t)b * T;
-    const bf16_t* kp = p.k + (rowbase + krow) * C + h * HS + 8 * half;
-    const bf16_t* vp = p.v + (rowbase + krow) * C + h * HS + 8 * half;
     bf16x8 kf[NS], vf[NS];
+    {
+        const bf16_t* kp = p.k + (rowbase + krow) * C + h * HS + 8 * half;
+        const bf16_t* vp = p.v + (rowbase + krow) * C + h * HS + 8 * half;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        kf[s] = ldfrag(kp + 16 * s, kok);
-        vf[s] = ldfrag(vp + 16 * s, kok);
+        for (int s = 0; s < NS; ++s) {
+            kf[s] = ldfrag(kp + 16 * s, kok);
+            vf[s] = ldfrag(vp + 16 * s, kok);
+        }
     }
-    f32x16 dv[NM], dk[NM];                                       // dV^T, dK^T [ch][key]
+    f32x16 dv[NM], dk[NM];                                        // dV^T, dK^T [ch][key]
 #pragma unroll
     for (int mt = 0; mt < NM; ++mt) dv[mt] = dk[mt] = zero16();
     const float c2 = p.scale * LOG2E;
-    const bf16_t* qtp = p.qt + ((int64_t)b * C + h * HS + l31) * T;
-    const bf16_t* dotp = p.dot + ((int64_t)b * C + h * HS + l31) * T;
+    const bf16_t* qbase = p.q + h * HS;
+    const bf16_t* dobase = p.dout + h * HS;
+    const bf16_t* qtbase = p.qt + ((int64_t)b * C + h * HS) * T;
+    const bf16_t* dotbase = p.dot + ((int64_t)b * C + h * HS) * T;
     const float* lsep = p.lse + (int64_t)bh * T;
     const float* dsp = p.dsum + (int64_t)bh * T;
-    for (int qt = kt; qt < nt; ++qt) {
-        const int q0 = qt * 32, qrow = q0 + l31;
-        const bool qok = qrow < T;
-        const bf16_t* qp = p.q + (rowbase + qrow) * C + h * HS + 8 * half;
-        const bf16_t* dop = p.dout + (rowbase + qrow) * C + h * HS + 8 * half;
-        f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            s = MFMA(ldfrag(qp + 16 * st, qok), kf[st], s);
-            dp = MFMA(ldfrag(dop + 16 * st, qok), vf[st], dp);
+    uint4 rq[G::NCH], rd[G::NCH], rqt[G::NCH], rdt[G::NCH];
+    gload_rows<HS>(qbase, rowbase, 32 * kt_min, T, C, tid, rq);
+    gload_rows<HS>(dobase, rowbase, 32 * kt_min, T, C, tid, rd);
+    gload_cols<HS>(qtbase, 32 * kt_min, T, tid, rqt);
+    gload_cols<HS>(dotbase, 32 * kt_min, T, tid, rdt);
+    swrite_rows<HS>(smem, tid, rq);
+    swrite_rows<HS>(smem + G::RTILE, tid, rd);
+    swrite_cols<HS>(smem + 2 * G::RTILE, tid, rqt);
+    swrite_cols<HS>(smem + 2 * G::RTILE + G::CTILE, tid, rdt);
+    __syncthreads();
+    for (int qt = kt_min; qt < nt; ++qt) {
+        const char* ql = smem + ((qt - kt_min) & 1) * STAGE;
+        const char* dl = ql + G::RTILE;
+        const char* qtl = ql + 2 * G::RTILE;
+        const char* dtl = qtl + G::CTILE;
+        const bool more = qt + 1 < nt;
+        if (more) {
+            gload_rows<HS>(qbase, rowbase, 32 * (qt + 1), T, C, tid, rq);
+            gload_rows<HS>(dobase, rowbase, 32 * (qt + 1), T, C, tid, rd);
+            gload_cols<HS>(qtbase, 32 * (qt + 1), T, tid, rqt);
+            gload_cols<HS>(dotbase, 32 * (qt + 1), T, tid, rdt);
         }
-        bf16x8 qa[NM][2], da[NM][2];
+        if (active && qt >= kt) {
+            const int q0 = qt * 32;
+            f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-        for (int mt = 0; mt < NM; ++mt)
+            for (int st = 0; st < NS; ++st) {
+                s = MFMA(frag_r<HS>(ql, l31, half, st), kf[st], s);
+                dp = MFMA(frag_r<HS>(dl, l31, half, st), vf[st], dp);
+            }
+            // per-query statistics of the 16 accumulator rows of this half: 4 groups of 4 consecutive queries
+            float lq[16], dq_[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qq = q0 + 8 * g + 4 * half;
+                const bool ok = qq < T;                           // T % 4 == 0: a group is entirely in or out
+                const float4 a = ok ? *reinterpret_cast<const float4*>(lsep + qq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 d = ok ? *reinterpret_cast<const float4*>(dsp + qq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                lq[4 * g + 0] = a.x; lq[4 * g + 1] = a.y; lq[4 * g + 2] = a.z; lq[4 * g + 3] = a.w;
+                dq_[4 * g + 0] = d.x; dq_[4 * g + 1] = d.y; dq_[4 * g + 2] = d.z; dq_[4 * g + 3] = d.w;
+            }
+            const bool diag = qt == kt;
+            f32x16 pd;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int query = q0 + crow(r, half);
+                const bool valid = query < T && (!diag || krow <= query);
+                const float pr = valid ? __builtin_amdgcn_exp2f(s[r] * c2 - lq[r] * LOG2E) : 0.f;
+                float g = dp[r], pk = pr;
+                if (p.thr != 0) {
+                    const unsigned idx = (unsigned)(((int64_t)bh * T + query) * T) + (unsigned)krow;
+                    const bool keep = dvq_hash32(idx * p.rm + p.ra) >= p.thr;
+                    g = keep ? g * p.inv_keep : 0.f;
+                    pk = keep ? pr * p.inv_keep : 0.f;
+                }
+                pd[r] = pk;                                       // dropped-out probabilities: dV
+                s[r] = pr * (g - dq_[r]);                         // d loss / d (scaled score): dK
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                qa[mt][s2] = ldfrag_t(qtp + (int64_t)32 * mt * T, q0 + 16 * s2 + 4 * half, T);
-                da[mt][s2] = ldfrag_t(dotp + (int64_t)32 * mt * T, q0 + 16 * s2 + 4 * half, T);
-            }
-        // per-query statistics of the 16 accumulator rows of this half: 4 groups of 4 consecutive queries
-        float lq[16], dq_[16];
+                const bf16x8 pf = pack8(pd, s2), df = pack8(s, s2);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int qq = q0 + 8 * g + 4 * half;
-            const bool ok = qq < T;                               // T % 4 == 0: a group is entirely in or out
-            const float4 a = ok ? *reinterpret_cast<const float4*>(lsep + qq) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 d = ok ? *reinterpret_cast<const float4*>(dsp + qq) : make_float4(0.f, 0.f, 0.f, 0.f);
-            lq[4 * g + 0] = a.x; lq[4 * g + 1] = a.y; lq[4 * g + 2] = a.z; lq[4 * g + 3] = a.w;
-            dq_[4 * g + 0] = d.x; dq_[4 * g + 1] = d.y; dq_[4 * g + 2] = d.z; dq_[4 * g + 3] = d.w;
-        }
-        const bool diag = qt == kt;
-        f32x16 pd;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int query = q0 + crow(r, half);
-            const bool valid = query < T && (!diag || krow <= query);
-            const float pr = valid ? __builtin_amdgcn_exp2f(s[r] * c2 - lq[r] * LOG2E) : 0.f;
-            float g = dp[r], pk = pr;
-            if (p.thr != 0) {
-                const unsigned idx = (unsigned)(((int64_t)bh * T + query) * T) + (unsigned)krow;
-                const bool keep = dvq_hash32(idx * p.rm + p.ra) >= p.thr;
-                g = keep ? g * p.inv_keep : 0.f;
-                pk = keep ? pr * p.inv_keep : 0.f;
-            }
-            pd[r] = pk;                                           // dropped-out probabilities: dV
-            s[r] = pr * (g - dq_[r]);                             // d loss / d (scaled score): dK
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pf = pack8(pd, s2), df = pack8(s, s2);
-#pragma unroll
-            for (int mt = 0; mt < NM; ++mt) {
-                dv[mt] = MFMA(da[mt][s2], pf, dv[mt]);
-                dk[mt] = MFMA(qa[mt][s2], df, dk[mt]);
+                for (int mt = 0; mt < NM; ++mt) {
+                    dv[mt] = MFMA(frag_c<HS>(dtl, l31, half, mt, s2), pf, dv[mt]);
+                    dk[mt] = MFMA(frag_c<HS>(qtl, l31, half, mt, s2), df, dk[mt]);
+                }
             }
         }
+        if (more) {
+            char* nl = smem + ((qt + 1 - kt_min) & 1) * STAGE;
+            swrite_rows<HS>(nl, tid, rq);
+            swrite_rows<HS>(nl + G::RTILE, tid, rd);
+            swrite_cols<HS>(nl + 2 * G::RTILE, tid, rqt);
+            swrite_cols<HS>(nl + 2 * G::RTILE + G::CTILE, tid, rdt);
+        }
+        __syncthreads();
     }
     if (kok) {
         store_ct<NM>(p.dv + (rowbase + krow) * C + h * HS, dv, half, 1.f);
         store_ct<NM>(p.dk + (rowbase + krow) * C + h * HS, dk, half, p.scale);
     }
+}
+
+template <int HS>
+int launch_fwd(const AttnParams& p, dim3 grid, hipStream_t stream) {
+    using G = Geo<HS>;
+    const int lds = 2 * (G::RTILE + G::CTILE);
+    dvq_ensure_dynamic_lds((const void*)attn_fwd_kernel<HS>, lds);
+    attn_fwd_kernel<HS><<<grid, dim3(256), lds, stream>>>(p);
+    return 0;
+}
+template <int HS>
+int launch_bwd(const AttnParams& p, dim3 grid, int64_t rows, hipStream_t stream) {
+    using G = Geo<HS>;
+    attn_rowdot_kernel<HS><<<dim3((unsigned)cdiv64(rows * p.nh, 256)), dim3(256), 0, stream>>>(p, rows);
+    const int lds_kv = 2 * (2 * G::RTILE + 2 * G::CTILE), lds_q = 2 * (2 * G::RTILE + G::CTILE);
+    dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS>, lds_kv);
+    dvq_ensure_dynamic_lds((const void*)attn_bwd_dq_kernel<HS>, lds_q);
+    attn_bwd_dkv_kernel<HS><<<grid, dim3(256), lds_kv, stream>>>(p);
+    attn_bwd_dq_kernel<HS><<<grid, dim3(256), lds_q, stream>>>(p);
+    return 0;
 }
 
 int fill_params(AttnParams& p, const char* who, int dtype, int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop,
@@ -406,8 +556,8 @@ int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, 
     p.out = (bf16_t*)out; p.lse = lse;
     const int nqt = (int)((T + 31) / 32);
     const dim3 grid((unsigned)((nqt + 3) / 4), (unsigned)(B * n_head));
-    if (head_dim == 64) attn_fwd_kernel<64><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
-    else attn_fwd_kernel<128><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
+    if (head_dim == 64) launch_fwd<64>(p, grid, (hipStream_t)stream);
+    else launch_fwd<128>(p, grid, (hipStream_t)stream);
     DVQ_CHECK_LAUNCH("attn_causal_fwd");
     return DVQ_OK;
 }
@@ -431,18 +581,11 @@ int dvq_attn_causal_bwd(const void* q, const void* k, const void* v, const void*
     p.qt = qt; p.kt = kt; p.dot = dot;
     p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
     p.lse = const_cast<float*>(lse); p.dsum = dsum;
-    const int64_t rows = B * T;
-    if (head_dim == 64) attn_rowdot_kernel<64><<<dim3((unsigned)cdiv64(rows * n_head, 256)), dim3(256), 0, (hipStream_t)stream>>>(p, rows);
-    else attn_rowdot_kernel<128><<<dim3((unsigned)cdiv64(rows * n_head, 256)), dim3(256), 0, (hipStream_t)stream>>>(p, rows);
-    DVQ_CHECK_LAUNCH("attn_rowdot");
     const int nt = (int)((T + 31) / 32);
     const dim3 grid((unsigned)((nt + 3) / 4), (unsigned)(B * n_head));
-    if (head_dim == 64) attn_bwd_dkv_kernel<64><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
-    else attn_bwd_dkv_kernel<128><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
-    DVQ_CHECK_LAUNCH("attn_causal_bwd_dkv");
-    if (head_dim == 64) attn_bwd_dq_kernel<64><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
-    else attn_bwd_dq_kernel<128><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
-    DVQ_CHECK_LAUNCH("attn_causal_bwd_dq");
+    if (head_dim == 64) launch_bwd<64>(p, grid, B * T, (hipStream_t)stream);
+    else launch_bwd<128>(p, grid, B * T, (hipStream_t)stream);
+    DVQ_CHECK_LAUNCH("attn_causal_bwd");
     return DVQ_OK;
 }
 

@@ -53,17 +53,15 @@ void* dvq_workspace(int64_t* bytes);
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 
-// round-to-nearest-even; NaN kept quiet
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-
+// round-to-nearest-even: gfx950's v_cvt_pk_bf16_f32 (one instruction per pair instead of ~6 integer ops per element)
+typedef __attribute__((ext_vector_type(2))) float dvq_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 dvq_bf16x2;
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+    const dvq_f32x2 v = {lo, hi};
+    const dvq_bf16x2 r = __builtin_convertvector(v, dvq_bf16x2);
+    return __builtin_bit_cast(unsigned, r);
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T>
 struct ElemIO;
