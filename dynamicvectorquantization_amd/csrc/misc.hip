@@ -185,6 +185,40 @@ __global__ __launch_bounds__(256) void sum_batch_kernel(const T* __restrict__ x,
     }
 }
 
+// 16-byte variant (inner % 8 == 0): a workgroup covers cvb x 8 columns with 256 / cvb row lanes, combines the row lanes in
+// LDS and issues one atomic per column and batch chunk
+template <typename T>
+__global__ __launch_bounds__(256) void sum_batch_vec_kernel(const T* __restrict__ x, int64_t batch, int64_t inner8,
+                                                            float* __restrict__ out, int64_t rows_per_chunk, int cvb_log2) {
+    __shared__ float red[256 * 8];
+    const int cvb = 1 << cvb_log2, rlanes = 256 >> cvb_log2;
+    const int cv = threadIdx.x & (cvb - 1), rl = threadIdx.x >> cvb_log2;
+    const int64_t c8 = (int64_t)blockIdx.x * cvb + cv;
+    const int64_t b0 = (int64_t)blockIdx.y * rows_per_chunk, b1 = min(batch, b0 + rows_per_chunk);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c8 < inner8) {
+        for (int64_t b = b0 + rl; b < b1; b += rlanes) {
+            float v[8];
+            load8(x + (b * inner8 + c8) * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[(rl * cvb + cv) * 8 + j] = acc[j];
+    __syncthreads();
+    const int ncol = cvb * 8;                                   // <= 256
+    if ((int)threadIdx.x < ncol) {
+        float t = 0.f;
+        for (int r = 0; r < rlanes; ++r) t += red[r * ncol + threadIdx.x];
+        const int64_t col = (int64_t)blockIdx.x * ncol + threadIdx.x;
+        if (col < inner8 * 8) {
+            if (gridDim.y == 1) out[col] += t;
+            else atomicAdd(&out[col], t);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ in, int64_t N, int64_t h, int64_t w,
                                                          int64_t C, T* __restrict__ out) {
@@ -456,6 +490,22 @@ int dvq_add_bias_bcast(const void* x, const float* bias, int dtype, int64_t batc
 
 int dvq_sum_batch(const void* x, int dtype, int64_t batch, int64_t inner, float* out, dvq_stream_t stream) {
     DVQ_REQUIRE(x && out && batch > 0 && inner > 0, DVQ_EINVAL, "dvq_sum_batch: bad arguments");
+    if (inner % 8 == 0 && batch >= 64) {
+        const int64_t inner8 = inner / 8;
+        int lg = 2;
+        while (lg < 5 && (1 << lg) < inner8) ++lg;               // 4 .. 32 column vectors per workgroup
+        const int64_t gx = cdiv64(inner8, 1 << lg);
+        int64_t chunks = gx >= 512 ? 1 : cdiv64(512, gx);
+        if (chunks > cdiv64(batch, 64)) chunks = cdiv64(batch, 64);
+        const int64_t rpc = cdiv64(batch, chunks);
+        chunks = cdiv64(batch, rpc);
+        if (gx <= 65535 && chunks <= 65535) {
+            DVQ_DISPATCH_DTYPE(dtype, T, sum_batch_vec_kernel<T><<<dim3((unsigned)gx, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(
+                                             (const T*)x, batch, inner8, out, rpc, lg););
+            DVQ_CHECK_LAUNCH("sum_batch");
+            return DVQ_OK;
+        }
+    }
     // enough workgroups to fill the chip: split the batch when there are few columns
     const int64_t col_blocks = cdiv64(inner, 256);
     int64_t chunks = col_blocks >= 1024 ? 1 : cdiv64(1024, col_blocks);

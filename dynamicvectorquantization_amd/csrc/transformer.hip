@@ -225,6 +225,53 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
     }
 }
 
+// Same sum, organised by TABLE ROW: workgroup (v, split) scans its share of the token ids, lists the tokens that hit row v
+// in LDS and accumulates their gradient rows in registers (thread = 8 channels): one atomic per channel and workgroup
+// instead of one per channel and TOKEN (position / segment tables have a few hundred rows hit by 20k tokens: the
+// per-token atomics serialised on them, 0.8 ms per call).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_scatter_rows_kernel(const int64_t* __restrict__ idx, const T* __restrict__ dout, int64_t B,
+                                                                 int64_t len, int64_t Ttot, int64_t t0, int C8, int64_t padding_idx,
+                                                                 int64_t idx_bstride, float* __restrict__ dtable,
+                                                                 int64_t tok_per_split) {
+    __shared__ int list[1024];
+    __shared__ int cnt;
+    const int64_t v = blockIdx.x;
+    if (v == padding_idx) return;
+    const int64_t ntok = B * len;
+    const int64_t n0 = (int64_t)blockIdx.y * tok_per_split, n1 = min(ntok, n0 + tok_per_split);
+    const int c8 = threadIdx.x;
+    const bool own = c8 < C8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool any = false;
+    for (int64_t w0 = n0; w0 < n1; w0 += 1024) {
+        if (threadIdx.x == 0) cnt = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1024 && w0 + i < n1; i += 256) {
+            const int64_t n = w0 + i, b = n / len, j = n - b * len;
+            if (idx[b * idx_bstride + j] == v) list[atomicAdd(&cnt, 1)] = i;
+        }
+        __syncthreads();
+        const int m = cnt;
+        if (own && m > 0) {
+            any = true;
+            for (int e = 0; e < m; ++e) {
+                const int64_t n = w0 + list[e], b = n / len, j = n - b * len;
+                float g[8];
+                load8(dout + ((b * Ttot + t0 + j) * C8 + c8) * 8, g);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += g[k];
+            }
+        }
+        __syncthreads();
+    }
+    if (own && any) {
+        float* dst = dtable + (v * C8 + c8) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(dst + k, acc[k]);
+    }
+}
+
 // ---- cross entropy over V columns of rows with stride ldl; one wave per row --------------------------------------
 // loss_sum += sum over non-ignored rows of (logsumexp - logit[target]); cnt += number of them;
 // dlogits (optional) = (softmax - onehot) * gscale[0]  (0 for ignored rows and for the padding columns >= V)
@@ -346,9 +393,20 @@ int dvq_embed_gather(const int64_t* idx, int64_t idx_bstride, const float* table
 }
 
 int dvq_embed_scatter_add(const int64_t* idx, int64_t idx_bstride, const void* dout, int dtype, int64_t B, int64_t len, int64_t Ttot,
-                          int64_t t0, int64_t C, int64_t padding_idx, float* dtable, dvq_stream_t stream) {
+                          int64_t t0, int64_t C, int64_t padding_idx, int64_t V, float* dtable, dvq_stream_t stream) {
     DVQ_REQUIRE(idx && dout && dtable && B > 0 && len > 0 && t0 >= 0 && t0 + len <= Ttot && C > 0 && C % 8 == 0, DVQ_EINVAL,
                 "dvq_embed_scatter_add: bad arguments");
+    if (V > 0 && V <= 65535 && C <= 2048) {
+        const int64_t ntok = B * len;
+        int64_t splits = V >= 512 ? 1 : cdiv64(512, V);
+        if (splits > cdiv64(ntok, 128)) splits = cdiv64(ntok, 128);
+        const int64_t tps = cdiv64(ntok, splits);
+        splits = cdiv64(ntok, tps);
+        DVQ_DISPATCH_DTYPE(dtype, T, embed_scatter_rows_kernel<T><<<dim3((unsigned)V, (unsigned)splits), dim3(256), 0, (hipStream_t)stream>>>(
+                                         idx, (const T*)dout, B, len, Ttot, t0, (int)(C / 8), padding_idx, idx_bstride, dtable, tps););
+        DVQ_CHECK_LAUNCH("embed_scatter_add");
+        return DVQ_OK;
+    }
     DVQ_DISPATCH_DTYPE(dtype, T, embed_scatter_kernel<T><<<dim3(nblk(B * len * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream>>>(
                                      idx, (const T*)dout, B, len, Ttot, t0, (int)(C / 8), padding_idx, idx_bstride, dtable););
     DVQ_CHECK_LAUNCH("embed_scatter_add");

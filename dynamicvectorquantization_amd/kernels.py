@@ -684,7 +684,7 @@ def embed_scatter_add(idx, dout, dtable, t0, padding_idx=-1, bstride=None):
     b, ttot, c = dout.shape
     ln = idx.shape[-1]
     bs = ln if bstride is None else bstride
-    check(lib().dvq_embed_scatter_add(_p(idx), bs, _p(dout), dt(dout), b, ln, ttot, t0, c, padding_idx, _p(dtable), _s()),
+    check(lib().dvq_embed_scatter_add(_p(idx), bs, _p(dout), dt(dout), b, ln, ttot, t0, c, padding_idx, dtable.shape[0], _p(dtable), _s()),
           "dvq_embed_scatter_add")
 
 

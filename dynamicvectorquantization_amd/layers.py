@@ -163,6 +163,15 @@ class Linear(nn.Module):
         self._wcache = ((ep, dtype), w, b)
         return w, b
 
+    def _wt(self, w):
+        """transposed compute-dtype weight for the input-gradient GEMM, cached with (and invalidated by) `_w`'s entry"""
+        hit = getattr(self, "_wtcache", None)
+        if hit is not None and hit[0] is w:
+            return hit[1]
+        wt = K.transpose(w, 1, self.out_p, self.in_features)
+        self._wtcache = (w, wt)
+        return wt
+
     def _w_uncached(self, dtype):
         w = K.cast(self.weight.detach().contiguous(), dtype)
         b = self.bias.detach() if self.bias is not None else None
@@ -201,7 +210,7 @@ class Linear(nn.Module):
                 _grad_buf(self.bias).add_(db[: self.out_features])
         if not need_dx:
             return None
-        wt = K.transpose(w, 1, self.out_p, self.in_features)                 # [in, out_p]
+        wt = self._wt(w)                                                     # [in, out_p]
         dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self.out_p, self.in_features)
         return dx.view(m, self.in_features)
 

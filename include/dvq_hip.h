@@ -324,11 +324,12 @@ int dvq_gelu_bwd(const void* x, const void* dy, int dtype, int64_t n, void* dx, 
 int dvq_softmax_causal(const void* s, int dtype, int64_t rows, int64_t L, int64_t Tq, int64_t offset, float scale, void* p,
                        dvq_stream_t stream);
 /* nn.Embedding forward: out[b][t0+j][:] (+)= table[idx[b*idx_bstride + j]][:], j < len; out is [B][Ttot][C] of `dtype`,
- * table fp32 [V][C].  Backward: dtable[idx] += dout rows, skipping idx == padding_idx (fp32 atomics). */
+ * table fp32 [V][C].  Backward: dtable[idx] += dout rows, skipping idx == padding_idx (fp32 atomics; V = table rows selects
+ * the per-table-row kernel, V == 0 the per-token one). */
 int dvq_embed_gather(const int64_t* idx, int64_t idx_bstride, const float* table, int dtype, int64_t B, int64_t len, int64_t Ttot,
                      int64_t t0, int64_t C, int accumulate, void* out, dvq_stream_t stream);
 int dvq_embed_scatter_add(const int64_t* idx, int64_t idx_bstride, const void* dout, int dtype, int64_t B, int64_t len, int64_t Ttot,
-                          int64_t t0, int64_t C, int64_t padding_idx, float* dtable, dvq_stream_t stream);
+                          int64_t t0, int64_t C, int64_t padding_idx, int64_t V, float* dtable, dvq_stream_t stream);
 /* F.cross_entropy(logits[:, :V], target, ignore_index) pieces: loss_sum / count (fp32 device scalars, accumulated) and,
  * when dlogits != NULL, dlogits = (softmax - onehot) * gscale_dev[0] (0 on ignored rows and on columns >= V; row stride ldl) */
 int dvq_cross_entropy(const void* logits, int dtype, int64_t rows, int64_t V, int64_t ldl, const int64_t* target, int64_t ignore_index,

@@ -365,6 +365,23 @@ def test_conv3x3_thin_input_kernel(dev, cout):
         assert derr < 1e-2, f"dgrad rel-to-max error {derr}"
 
 
+@pytest.mark.parametrize("shape", [(20736, 1024), (4097, 136), (100, 8), (63, 64), (3000, 12), (5, 4096)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sum_batch(dev, shape, dtype):
+    """bias-gradient column sums (accumulating): the 16-byte kernel (inner % 8 == 0, batch >= 64) and the scalar one"""
+    from dynamicvectorquantization_amd import kernels as K
+    rows, inner = shape
+    rs = np.random.RandomState(rows + inner)
+    x = rs.standard_normal((rows, inner)).astype(np.float32)
+    if dtype == torch.bfloat16:
+        x = bf16_round(x)
+    init = rs.standard_normal(inner).astype(np.float32)
+    out = T(init, dev)
+    K.sum_batch(T(x, dev, dtype), out)
+    ref = init.astype(np.float64) + x.astype(np.float64).sum(axis=0)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.sqrt(rows))
+
+
 @pytest.mark.parametrize("case", [(64, 2, 16, 24), (64, 1, 64, 64), (32, 3, 6, 10)], ids=lambda c: "-".join(map(str, c)))
 def test_tconv4x4s2_thin_kernel(dev, case):
     """input gradient of the PatchGAN's first conv (4x4 / s2 / p1, 3 image channels) on the thin transposed-conv kernel"""
