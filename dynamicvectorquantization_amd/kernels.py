@@ -119,8 +119,19 @@ def profile_stop():
     return out
 
 
+_shape_tags = os.environ.get("DVQ_PROFILE_SHAPES", "0") == "1"    # debug: split the families by call geometry
+_cur_tag = [None]
+
+
+def _tag(d, mode):
+    if _shape_tags:
+        _cur_tag[0] = f"{mode} N{d.N} {d.H}x{d.W} {d.Cin}->{d.Cout} k{d.KH}s{d.stride}{'u' if d.upsample else ''}"
+
+
 def _timed(name, flops, nbytes, fn):
     global _count
+    if _shape_tags and _cur_tag[0] is not None:
+        name, _cur_tag[0] = f"{name} | {_cur_tag[0]}", None
     if _count is not None:
         _count += 1
     if _prof is None or len(_pool) < 2:
@@ -319,6 +330,7 @@ ACT_NONE, ACT_SWISH, ACT_LRELU, ACT_RELU = 0, 1, 2, 3      # include/dvq_hip.h D
 def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None, gn_ss=None, out_stats=None, out_groups=0, act=ACT_NONE):
     y = torch.empty(d.N, d.OH, d.OW, d.Cout, dtype=x.dtype, device=x.device)
     fl, nb = _conv_cost(d, x.element_size())
+    _tag(d, "fwd")
     if act != ACT_NONE:
         assert residual is None and gn_ss is None and out_stats is None
         _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 else "igemm_nt_glds_kernel", fl, nb, lambda: check(
@@ -340,6 +352,7 @@ def conv2d_dgrad(d: ConvDesc, dy, wt, mask=None, mask_act=ACT_NONE):
     dx = torch.empty(d.N, sh, sw, d.Cin, dtype=dy.dtype, device=dy.device)
     ws = torch.empty(d.N, d.H, d.W, d.Cin, dtype=dy.dtype, device=dy.device) if d.upsample else None
     fl, nb = _conv_cost(d, dy.element_size())
+    _tag(d, "dgrad")
     _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 and d.Cout % 64 == 0 else "igemm_nt_glds_kernel", fl, nb,
            lambda: check(
         lib().dvq_conv2d_dgrad_mask(C.byref(d), _p(dy), _p(wt), _p(dx), _p(ws), _p(mask), mask_act, _s()),
@@ -374,6 +387,7 @@ def conv2d_wgrad_oihw(d: ConvDesc, x, dy, cin_real, cout_real, grad_oihw, db=Non
     gn_ss: the fused GroupNorm+swish of the forward is re-applied to x inside the kernel"""
     fl, nb = _conv_cost(d, x.element_size())
     ensure_workspace(x.device)
+    _tag(d, "wgrad")
     if gn_ss is not None:
         _timed("conv3x3_halo_wgrad_kernel", fl, nb, lambda: check(
             lib().dvq_conv2d_wgrad_oihw_ex(C.byref(d), _p(x), _p(dy), cin_real, cout_real, _praw(grad_oihw), _p(db),
