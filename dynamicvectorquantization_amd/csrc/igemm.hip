@@ -681,6 +681,8 @@ struct TnParams {
     int Jc;          // columns per tap of C (<= J; smaller when the operand channels are padded)
     int64_t sA, sB, sC;
     int batch_in_z;
+    int thin;        // conv, J == 8 (image-channel inputs): the B tile's 16 chunks are the TAPS (column = tap * 8 + channel), one
+                     //   workgroup accumulates every tap instead of a 1/16-full tile per tap
 };
 
 __device__ __forceinline__ int64_t tn_c_offset(const TnParams& p, int row, int tap, int col) {
@@ -897,7 +899,8 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_tr_kernel(TnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int per_split = p.itiles * p.jtiles * p.taps;
+    const bool thin = CONV && p.thin != 0;
+    const int per_split = p.itiles * p.jtiles * (thin ? 1 : p.taps);
     int bx = xcd_remap(blockIdx.x, per_split * p.nsplit);
     const int split = bx / per_split;
     bx -= split * per_split;
@@ -912,13 +915,21 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_tr_kernel(TnParams p) {
     const T* zero = reinterpret_cast<const T*>(g_zero_page);
     const int mbeg = split * p.m_per_split;
     const int mend = min(p.Mred, mbeg + p.m_per_split);
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    int kh = tap / p.KW, kw = tap - kh * p.KW;
 
     // ---- loader: DMA piece i of this wave = stage rows (wave*4 + i)*4 .. +3, lane -> (row lr, chunk position) ----
     const int lr = lane >> 4, cpos = lane & 15;
     const int cg = cpos ^ (lr << 2);               // source chunk of this lane (stage rows of a piece are 4-aligned)
-    const int colA = i0 + cg * 8, colB = j0 + cg * 8;
-    const bool cokA = colA < p.I, cokB = colB < p.J;
+    const int colA = i0 + cg * 8;
+    int colB = j0 + cg * 8;
+    const bool cokA = colA < p.I;
+    bool cokB = colB < p.J;
+    if (thin) {                                    // this lane's chunk is tap `cg`: all 8 (padded) input channels of one tap
+        kh = cg / p.KW;
+        kw = cg - kh * p.KW;
+        colB = 0;
+        cokB = cg < p.taps;
+    }
     int gn[4], gy[4], gx[4];
     if constexpr (CONV) {
         const int hw = p.DH * p.DW;
@@ -1039,14 +1050,19 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_tr_kernel(TnParams p) {
     const int l31 = lane & 31, half = lane >> 5;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int col = j0 + wn * 64 + nt * 32 + l31;
+        int col = j0 + wn * 64 + nt * 32 + l31, ctap = tap;
+        if (thin) {
+            ctap = col >> 3;
+            col &= 7;
+            if (ctap >= p.taps) continue;
+        }
         if (col >= p.Jc) continue;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < p.I) atomicAdd(Cg + tn_c_offset(p, row, tap, col), acc[mt][nt][r]);
+                if (row < p.I) atomicAdd(Cg + tn_c_offset(p, row, ctap, col), acc[mt][nt][r]);
             }
     }
     if (do_bias) {
@@ -1225,9 +1241,12 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
     if (use_mfma) {
         p.itiles = (int)cdiv64(p.I, TILE);
         p.jtiles = (int)cdiv64(p.J, TILE);
-        const int64_t tiles = (int64_t)p.itiles * p.jtiles * p.taps * batch;
+        p.thin = (p.conv && sizeof(T) == 2 && impl != 3 && p.J == 8 && p.taps <= 16 && p.taps > 1) ? 1 : 0;
+        const int tapblk = p.thin ? 1 : p.taps;
+        const int64_t tiles = (int64_t)p.itiles * p.jtiles * tapblk * batch;
         // 512 resident workgroups (2 per CU): aim at two full rounds, never slightly more than a round
-        int64_t splits = 1024 / tiles;
+        // (thin: every workgroup ends with I x taps x 8 atomics on one small tile -- one round of 256 is enough)
+        int64_t splits = (p.thin ? 256 : 1024) / tiles;
         const int64_t max_splits = cdiv64(p.Mred, 4 * BK);
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
@@ -1235,7 +1254,7 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
         splits = cdiv64(p.Mred, mps);
         p.m_per_split = (int)mps;
         p.nsplit = (int)splits;
-        dim3 grid((unsigned)(p.itiles * p.jtiles * p.taps * splits), 1, (unsigned)batch);
+        dim3 grid((unsigned)(p.itiles * p.jtiles * tapblk * splits), 1, (unsigned)batch);
         if (sizeof(T) == 2 && impl != 3) {      // LDS-DMA + transpose-read kernel
             if (p.conv) {
                 dvq_ensure_dynamic_lds((const void*)igemm_tn_tr_kernel<true>, 2 * TSTAGEB);

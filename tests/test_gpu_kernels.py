@@ -347,6 +347,16 @@ def test_conv3x3_thin_input_kernel(dev, cout):
         y = mod.fwd(xp, None, act=K.ACT_RELU)
         err = np.abs(y.float().permute(0, 3, 1, 2).cpu().numpy()[:, :cout] - yr).max() / np.abs(yr).max()
         assert err < 1e-2, f"forward rel-to-max error {err}"
+        # weight / bias gradient of the 3-channel input conv (taps-as-columns tile of the TN kernel)
+        gy = bf16_round(rs.standard_normal((n, cout, h, w_)).astype(np.float32))
+        wr_, br_ = torch.from_numpy(wt).requires_grad_(True), torch.from_numpy(b).requires_grad_(True)
+        (F.conv2d(torch.from_numpy(x), wr_, br_, padding=1) * torch.from_numpy(gy)).sum().backward()
+        tp = Tape()
+        mod.fwd(xp, tp)
+        mod.bwd(T(gy, dev, torch.bfloat16).permute(0, 2, 3, 1).contiguous(), tp, need_dw=True)
+        for name, got, ref in (("dw", mod.weight.grad, wr_.grad), ("db", mod.bias.grad, br_.grad)):
+            e = np.abs(got.float().cpu().numpy() - ref.numpy()).max() / np.abs(ref.numpy()).max()
+            assert e < 1e-2, f"{name} rel-to-max error {e}"
         # dgrad of cout -> 3: gradient [n,h,w,8 (3 real)] -> [n,h,w,cout]
         mod2 = Conv2d(cout, 3, 3, 1, 1).to(dev)
         w2 = bf16_round((rs.standard_normal((3, cout, 3, 3)) / np.sqrt(cout * 9)).astype(np.float32))
@@ -401,11 +411,17 @@ def test_tconv4x4s2_thin_kernel(dev, case):
             mod.weight.copy_(T(wt, dev))
         tape = Tape()
         mod.fwd(K.nchw_to_nhwc_pad(T(x, dev), 8, torch.bfloat16), tape)
-        outs = []
-        for impl in (0, 2):          # thin kernel (auto) and the generic implicit-GEMM dgrad
+        outs, dws = [], []
+        for impl in (0, 3):          # thin kernels (auto) and the generic implicit-GEMM dgrad / per-tap weight gradient
             tape.s["d"].impl = impl
-            dx = mod.bwd(T(go, dev, torch.bfloat16).permute(0, 2, 3, 1).contiguous(), tape, need_dw=False)
+            mod.weight.grad = None
+            dx = mod.bwd(T(go, dev, torch.bfloat16).permute(0, 2, 3, 1).contiguous(), tape, need_dw=True)
             outs.append(dx.float().permute(0, 3, 1, 2).cpu().numpy())
+            dws.append(mod.weight.grad.float().cpu().numpy().copy())
+    wr = torch.from_numpy(wt).requires_grad_(True)
+    (F.conv2d(torch.from_numpy(x), wr, None, stride=2, padding=1) * torch.from_numpy(go)).sum().backward()
+    for dw in dws:              # weight gradient of the 3-channel input conv: taps-as-columns tile of the TN kernel
+        assert np.abs(dw - wr.grad.numpy()).max() / np.abs(wr.grad.numpy()).max() < 1e-2
     dref = xr.grad.numpy()
     for got in outs:
         assert np.all(got[:, 3:] == 0), "pad channels must stay zero"
