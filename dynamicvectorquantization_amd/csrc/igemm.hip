@@ -47,7 +47,17 @@ struct NtParams {
     float act_slope;     // output activation v > 0 ? v : act_slope * v (1: none, 0: ReLU, 0.2: LeakyReLU), applied last
     int res_mask;        // 1: R gates instead of adds: v *= (R > 0 ? 1 : mask_slope) (ReLU / LeakyReLU backward)
     float mask_slope;
+    int par;             // TCONV, stride 2: GEMM rows are grouped by output-pixel parity class (y & 1, x & 1); a tile then
+    int par_tiles;       //   contracts only over the taps that reach its class (1/4 of a 4x4 kernel) -- M tiles per class
 };
+
+// parity-class row order of the stride-2 input gradient: class-local index m -> (image, y, x) of class pc = 2 * (y & 1) + (x & 1)
+__device__ __forceinline__ int64_t par_out_row(const NtParams& p, int pc, int m) {
+    const int hw2 = (p.DH >> 1) * (p.DW >> 1), w2 = p.DW >> 1;
+    const int n = m / hw2, rem = m - n * hw2;
+    const int yy = rem / w2, xx = rem - yy * w2;
+    return ((int64_t)n * p.DH + 2 * yy + (pc >> 1)) * p.DW + 2 * xx + (pc & 1);
+}
 
 // XCD-aware work-item order (MI355X: block b is dispatched to XCD b % 8, each XCD has a private 4-MiB L2):
 // remap the linear block id so that every XCD walks one CONTIGUOUS range of work items; neighbouring items
@@ -159,7 +169,7 @@ __device__ __forceinline__ float nt_res(const NtParams& p, float v, float r) {
 
 template <typename T>
 __device__ __forceinline__ void nt_epilogue_vec(const NtParams& p, f32x16 (&acc)[2][2], char* smem, int m0, int n0,
-                                                int64_t bz, int wm, int wn, int tid) {
+                                                int64_t bz, int wm, int wn, int tid, int pc = -1) {
     constexpr int VN = Vec<T>::N;
     constexpr int ROW = TILE * (int)sizeof(T);          // staged row bytes (256 / 512)
     const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -190,9 +200,9 @@ __device__ __forceinline__ void nt_epilogue_vec(const NtParams& p, f32x16 (&acc)
         const int q = tid + 256 * i;
         const int lr = q / CPR, ch = q % CPR;
         const int row = m0 + lr, col = n0 + ch * VN;
-        if (row >= p.M || col >= p.Ncols) continue;
+        if (row >= (pc < 0 ? p.M : p.M >> 2) || col >= p.Ncols) continue;
         uint4 v = *reinterpret_cast<const uint4*>(smem + lr * ROW + ch * 16);
-        const int64_t o = (int64_t)row * p.ldc + col;
+        const int64_t o = (pc < 0 ? (int64_t)row : par_out_row(p, pc, row)) * p.ldc + col;
         if (col + VN <= p.Ncols) {
             if (Rg) {
                 const uint4 rv = *reinterpret_cast<const uint4*>(Rg + o);
@@ -422,7 +432,23 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int wi = xcd_remap(blockIdx.x, p.gm * p.gn);
-    const int m0 = (wi / p.gn) * TILE, n0 = (wi % p.gn) * TILE;
+    int mtile = wi / p.gn;
+    const int n0 = (wi % p.gn) * TILE;
+    // stride-2 input gradient by parity class (p.par): tiles [pc * par_tiles, (pc + 1) * par_tiles) hold the pixels of class pc
+    const bool par = MODE == MODE_TCONV && TAPU && p.par != 0;
+    int pc = -1, Mrows = p.M, khc = 0, kwc = 0, nkw = 1, Kcls = p.Ktot;
+    if (par) {
+        pc = mtile / p.par_tiles;
+        mtile -= pc * p.par_tiles;
+        Mrows = p.M >> 2;
+        khc = ((pc >> 1) + p.pad_t) & 1;
+        kwc = ((pc & 1) + p.pad_l) & 1;
+        const int khn = p.Ktot / (int)p.lda / p.KW;              // KH
+        const int nkh = (khn - khc + 1) >> 1;
+        nkw = (p.KW - kwc + 1) >> 1;
+        Kcls = nkh * nkw * (int)p.lda;
+    }
+    const int m0 = mtile * TILE;
     const int64_t bz = blockIdx.z;
     const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
     const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
@@ -439,15 +465,20 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
         const int trow = wave * 32 + i * 8 + lrow;
         cg[i] = cpos ^ ((trow >> 1) & 7);          // which 16-B chunk of the row this lane fetches
         const int m = m0 + trow;
-        rok[i] = m < p.M;
+        rok[i] = m < Mrows;
         const int mm = rok[i] ? m : 0;
         if constexpr (MODE == MODE_GEMM) {
             rn[i] = mm;
             ra[i] = rb[i] = 0;
         } else {
-            const int hw = p.DH * p.DW;
+            const int dw_ = par ? p.DW >> 1 : p.DW;
+            const int hw = par ? (p.DH >> 1) * dw_ : p.DH * p.DW;
             const int n = mm / hw, rem = mm - n * hw;
-            const int y = rem / p.DW, x = rem - y * p.DW;
+            int y = rem / dw_, x = rem - y * dw_;
+            if (par) {
+                y = 2 * y + (pc >> 1);
+                x = 2 * x + (pc & 1);
+            }
             rn[i] = n * p.SH * p.SW;                // source pixel base of image n
             if constexpr (MODE == MODE_FWD) {
                 ra[i] = y * p.stride - p.pad_t;
@@ -472,14 +503,20 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
         if constexpr (MODE != MODE_GEMM && tap_uniform) {
             const int tap = (j * 8) / cpt;
             cu0 = j * 8 - tap * cpt;
-            kh0 = tap / p.KW;
-            kw0 = tap - kh0 * p.KW;
+            if (par) {                                   // tap-th VALID tap of this parity class
+                const int a = tap / nkw;
+                kh0 = khc + 2 * a;
+                kw0 = kwc + 2 * (tap - a * nkw);
+            } else {
+                kh0 = tap / p.KW;
+                kw0 = tap - kh0 * p.KW;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int u = j * 8 + cg[i];
-            const int ke = u * VN;
-            const bool kok = ke < p.Ktot;
+            int ke = u * VN;
+            const bool kok = ke < Kcls;
             bool ok = kok && rok[i];
             int64_t off = 0;
             if constexpr (MODE == MODE_GEMM) {
@@ -502,6 +539,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
                     const int oh = t >> sshift, ow = v >> sshift;
                     ok = ok && oh < p.LH && ow < p.LW;
                     off = (int64_t)(rn[i] + oh * p.SW + ow) * p.lda + c0;
+                    if (par) ke = (kh * p.KW + kw) * (int)p.lda + c0;      // weight columns of the real tap
                 }
             }
             const T* srcA = ok ? Ag + off : zero;
@@ -521,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk = (p.Ktot + BK - 1) / BK;
+    const int nk = (Kcls + BK - 1) / BK;
     issue(0, 0);
     __syncthreads();                 // drains the DMA (vmcnt(0)) and publishes the stage
     for (int j = 0; j < nk; ++j) {
@@ -531,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
         __syncthreads();
     }
     if ((p.ldc % VN) == 0) {
-        nt_epilogue_vec<T>(p, acc, smem, m0, n0, bz, wm, wn, tid);     // LDS-staged, 16-byte global accesses
+        nt_epilogue_vec<T>(p, acc, smem, m0, n0, bz, wm, wn, tid, pc);     // LDS-staged, 16-byte global accesses
     } else {
         nt_epilogue<T>(p, acc, m0, n0, bz, wm, wn, lane);
     }
@@ -1205,8 +1243,14 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
         }
     }
     if (use_mfma && impl != 3) {
-        dim3 grid((unsigned)(p.gm * p.gn), 1, (unsigned)batch);
         const bool tapu = p.mode != MODE_GEMM && ((p.lda / VN) % 8) == 0;
+        if (p.mode == MODE_TCONV && p.stride == 2 && p.up == 0 && tapu && p.DH % 2 == 0 && p.DW % 2 == 0 && p.ldc % VN == 0) {
+            // stride-2 input gradient: rows grouped by output parity class, each class contracts over its own taps only
+            p.par = 1;
+            p.par_tiles = (int)cdiv64(p.M / 4, TILE);
+            p.gm = 4 * p.par_tiles;
+        }
+        dim3 grid((unsigned)(p.gm * p.gn), 1, (unsigned)batch);
         auto go = [&](auto kern) {
             dvq_ensure_dynamic_lds((const void*)kern, 2 * GSTAGEB);
             kern<<<grid, dim3(256), 2 * GSTAGEB, s>>>(p);

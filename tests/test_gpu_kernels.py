@@ -215,6 +215,8 @@ CONV_CASES = [
     (64, 3, 3, "same", 16, 16, 2),
     (256, 256, 3, "same", 16, 16, 1),
     (16, 32, 4, "s2p1", 16, 16, 2),
+    (64, 128, 4, "s2p1", 24, 16, 3),       # stride-2 input gradient by parity class (Cout % 64 == 0)
+    (128, 64, 3, "down", 20, 24, 2),
 ]
 
 
