@@ -40,6 +40,8 @@ struct HaloParams {
                          //   the halo tile is transformed in LDS once per chunk (zero padding stays zero)
     double* out_stats;   // optional GroupNorm statistics of the OUTPUT: fp64 [N][G][2] += (sum, sum of squares)
     int out_groups;      //   of the values as stored (after bias / residual / bf16 rounding)
+    float* stat_part;    // when set: per-tile partials fp32 [N][G][tiles][2] (plain stores; a finalize kernel adds them to
+                         //   out_stats) instead of 64 contended fp64 atomics per workgroup
     float act_slope;     // output activation v > 0 ? v : act_slope * v (1: none, 0: ReLU, 0.2: LeakyReLU), applied last
     int res_mask;        // 1: R is not added but gates the result: v *= (R > 0 ? 1 : mask_slope)  (backward of ReLU / LeakyReLU)
     float mask_slope;
@@ -268,30 +270,67 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
         }
     }
     if (p.out_stats != nullptr) {
-        // combine within the workgroup in LDS (fp32 per channel), then one fp64 atomic pair per group
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);            // [128][2]
-        for (int i = tid; i < 256; i += NTH) red[i] = 0.f;
-        __syncthreads();
-        const int ch = tid % CPRW;
+        // lanes l, l + CPRW, l + 2 CPRW, ... of a wave hold partials of the same 8 channels: fold them with shuffles, park one
+        // row per wave in LDS, add the NW rows per channel, fold the channels of a group (a power of two, lanes adjacent)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            atomicAdd(&red[(ch * 8 + k) * 2], gs[k]);
-            atomicAdd(&red[(ch * 8 + k) * 2 + 1], gq[k]);
+        for (int off = CPRW; off < 64; off <<= 1)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                gs[k] += __shfl_xor(gs[k], off, 64);
+                gq[k] += __shfl_xor(gq[k], off, 64);
+            }
+        __syncthreads();                                        // the staged output tile has been consumed
+        float* red = reinterpret_cast<float*>(smem);            // [NW][CO_T][2]
+        if (lane < CPRW) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                red[((wave * CO_T) + lane * 8 + k) * 2] = gs[k];
+                red[((wave * CO_T) + lane * 8 + k) * 2 + 1] = gq[k];
+            }
         }
         __syncthreads();
-        const int cpg = p.Cout / p.out_groups;                  // channels per group
-        const int ng = CO_T / cpg;                              // groups covered by this workgroup's output channels
-        if (tid < ng && n0 + tid * cpg < p.Cout) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-                s1 += (double)red[c * 2];
-                s2 += (double)red[c * 2 + 1];
+        if (tid < CO_T) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                s1 += red[(w * CO_T + tid) * 2];
+                s2 += red[(w * CO_T + tid) * 2 + 1];
             }
-            const int g = (n0 + tid * cpg) / cpg;
-            atomicAdd(&p.out_stats[((int64_t)n * p.out_groups + g) * 2], s1);
-            atomicAdd(&p.out_stats[((int64_t)n * p.out_groups + g) * 2 + 1], s2);
+            const int cpg = p.Cout / p.out_groups;              // channels per group: power of two <= 32 (launcher)
+            for (int off = 1; off < cpg; off <<= 1) {
+                s1 += __shfl_xor(s1, off, 64);
+                s2 += __shfl_xor(s2, off, 64);
+            }
+            if ((tid & (cpg - 1)) == 0 && n0 + tid < p.Cout) {
+                const int g = (n0 + tid) / cpg;
+                if (p.stat_part != nullptr) {
+                    const int ntiles = p.tiles_y * p.tiles_x;
+                    float* dst = p.stat_part + ((((int64_t)n * p.out_groups + g) * ntiles) + ty * p.tiles_x + tx) * 2;
+                    dst[0] = s1;
+                    dst[1] = s2;
+                } else {
+                    atomicAdd(&p.out_stats[((int64_t)n * p.out_groups + g) * 2], (double)s1);
+                    atomicAdd(&p.out_stats[((int64_t)n * p.out_groups + g) * 2 + 1], (double)s2);
+                }
+            }
         }
+    }
+}
+
+// out_stats[n][g] += sum over the tiles of one image of the per-tile partials (one wave per (n, g))
+__global__ __launch_bounds__(64) void halo_stats_finalize_kernel(const float* __restrict__ part, int ntiles, double* __restrict__ out) {
+    const float* src = part + (int64_t)blockIdx.x * ntiles * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 64) {
+        const float2 v = *reinterpret_cast<const float2*>(src + 2 * t);
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (threadIdx.x == 0) {
+        out[2 * (int64_t)blockIdx.x] += s1;
+        out[2 * (int64_t)blockIdx.x + 1] += s2;
     }
 }
 
@@ -306,6 +345,10 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     if (H % TH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
     const int cot = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;          // output-channel tile of the kernel instance
     if (out_stats != nullptr && (out_groups <= 0 || Cout % out_groups != 0 || cot % (Cout / out_groups) != 0)) return 0;
+    if (out_stats != nullptr) {
+        const int64_t cpg = Cout / out_groups;                      // the in-kernel group fold walks adjacent lanes
+        if ((cpg & (cpg - 1)) != 0 || cpg > 32) return 0;
+    }
     if (N * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31) || Cout * 9 * Cin >= (1ll << 31)) return 0;
     HaloParams p{};
     p.X = (const bf16_t*)x; p.Wt = (const bf16_t*)w; p.Y = (bf16_t*)y; p.R = (const bf16_t*)residual; p.bias = bias;
@@ -320,6 +363,12 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
         return e != nullptr ? atoi(e) : 0;
     }();
     p.dbg = dbg_env;
+    const int ntiles = p.tiles_y * p.tiles_x;
+    if (out_stats != nullptr) {
+        int64_t ws_bytes = 0;
+        void* ws = dvq_workspace(&ws_bytes);
+        if (ws != nullptr && ws_bytes >= N * out_groups * ntiles * 2 * (int64_t)sizeof(float)) p.stat_part = (float*)ws;
+    }
     const int64_t blocks = N * p.tiles_y * p.tiles_x * p.gn;
     if (blocks >= (1ll << 31)) return 0;
     static const int nw_env = [] {
@@ -339,6 +388,8 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
         dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 1>, LDSB);
         conv3x3_halo_kernel<4, 1><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
     }
+    if (p.stat_part != nullptr)
+        halo_stats_finalize_kernel<<<dim3((unsigned)(N * out_groups)), dim3(64), 0, stream>>>(p.stat_part, ntiles, out_stats);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         dvq_set_error("conv3x3_halo: launch failed: %s", hipGetErrorString(e));

@@ -331,6 +331,8 @@ def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None, gn_ss=None, out_stats=Non
     y = torch.empty(d.N, d.OH, d.OW, d.Cout, dtype=x.dtype, device=x.device)
     fl, nb = _conv_cost(d, x.element_size())
     _tag(d, "fwd")
+    if out_stats is not None:
+        ensure_workspace(x.device)        # per-tile statistics partials of the halo kernel
     if act != ACT_NONE:
         assert residual is None and gn_ss is None and out_stats is None
         _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 else "igemm_nt_glds_kernel", fl, nb, lambda: check(
