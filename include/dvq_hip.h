@@ -334,6 +334,9 @@ int dvq_embed_scatter_add(const int64_t* idx, int64_t idx_bstride, const void* d
  * when dlogits != NULL, dlogits = (softmax - onehot) * gscale_dev[0] (0 on ignored rows and on columns >= V; row stride ldl) */
 int dvq_cross_entropy(const void* logits, int dtype, int64_t rows, int64_t V, int64_t ldl, const int64_t* target, int64_t ignore_index,
                       float* loss_sum, float* count, const float* gscale_dev, void* dlogits, dvq_stream_t stream);
+/* 1 if large plain bf16 dvq_gemm_nt calls (impl 0, batch 1, bias per column or none, M >= 1024, N, K >= 256) are served by
+ * hipBLASLt (bound with dlopen at first use; DVQ_NO_HIPBLASLT=1 disables), 0 if they run on the library's own kernel. */
+int dvq_blaslt_available(void);
 /* Fused causal multi-head self-attention (bf16, head_dim 64 or 128) -- CausalSelfAttention.forward, stackgpt.py:41-69:
  *   out = attn_drop(softmax(causal_mask(q k^T * scale))) v      per (batch, head), scores never materialised.
  * q, k, v, out, dout, dq, dk, dv: [B*T][n_head*head_dim] row-major (head h = columns h*head_dim ..); T % 8 == 0;

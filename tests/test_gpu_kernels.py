@@ -455,6 +455,34 @@ def test_gemm_nt_wide_kernel(dev, shape):
     assert err < 1e-2, err
 
 
+@pytest.mark.parametrize("shape", [(2048, 1024, 1024, 1), (1304, 1032, 512, 0), (20736, 1024, 4096, 1), (1024, 256, 264, 1)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_gemm_nt_library_path(dev, shape):
+    """large plain bf16 products (impl 0, batch 1, bias per column or none): hipBLASLt when present (csrc/blaslt.hip), else the own
+    kernel -- both against an fp32 product of the same bf16-rounded operands, and against each other (impl 2 = own kernel)"""
+    from dynamicvectorquantization_amd import kernels as K
+    m, n, k, with_bias = shape
+    rs = np.random.RandomState(m + n + k)
+    a = bf16_round(rs.standard_normal((m, k)).astype(np.float32))
+    w = bf16_round(rs.standard_normal((n, k)).astype(np.float32) / np.sqrt(k))
+    bias = rs.standard_normal(n).astype(np.float32) if with_bias else None
+    ref = torch.from_numpy(a) @ torch.from_numpy(w).t()
+    if with_bias:
+        ref = ref + torch.from_numpy(bias)[None, :]
+    at, wt_ = T(a, dev, torch.bfloat16).reshape(-1), T(w, dev, torch.bfloat16).reshape(-1)
+    bt = T(bias, dev) if with_bias else None
+    assert K.lib().dvq_blaslt_available() in (0, 1)
+    outs = []
+    for impl in (0, 2):
+        out = K.gemm_nt(at, wt_, m, n, k, k, k, n, bias=bt, bias_mode=1 if with_bias else 0, alpha=0.5 if not with_bias else 1.0, impl=impl)
+        outs.append(out.view(m, n).float().cpu())
+    if not with_bias:
+        ref = ref * 0.5
+    for got in outs:
+        assert float((got - ref).abs().max()) / float(ref.abs().max()) < 1e-2
+    assert float((outs[0] - outs[1]).abs().max()) / float(ref.abs().max()) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("impl", [1, 2])
 def test_gemm_nt_tn(dev, dtype, impl):
