@@ -1114,6 +1114,57 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_tr_kernel(TnParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Skinny NT GEMM (bf16, M <= 32 rows): the single-token Linear layers of K/V-cached sampling.  The product is bound by
+// streaming the weight matrix B [N][K] once, so the tiling is by WEIGHT ROWS: a workgroup owns 32 rows of B, its waves split K,
+// and each wave feeds 32x32x16 MFMAs straight from global memory -- MFMA A operand = 32 weight rows x 16 k (one 16-byte load
+// per lane), B operand = the (zero-padded) 32 activation rows x 16 k (L1/L2 resident) -- no LDS staging, no tile of 128 rows
+// that is 75 - 97% padding.  The waves' partial accumulators are added in LDS.  (The 128 x 128 kernel put these products on
+// 8 - 32 workgroups for 20 - 85 us each; 24 layers x 6 products made the sampler GPU-bound at 8 ms per token.)
+// -------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(NtParams p) {
+    using T = bf16_t;
+    __shared__ float red[NW][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B);
+    const int ksteps = (p.Ktot + 15) / 16;
+    const int per = (ksteps + NW - 1) / NW;
+    const int ks0 = wave * per, ks1 = min(ksteps, ks0 + per);
+    const bool wok = n0 + l31 < p.Ncols, xok = l31 < p.M;
+    const T* wrow = Bg + (int64_t)(wok ? n0 + l31 : 0) * p.ldb + 8 * half;
+    const T* xrow = Ag + (int64_t)(xok ? l31 : 0) * p.lda + 8 * half;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll 4
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int k = ks * 16 + 8 * half;
+        const bool kok = k < p.Ktot;                                   // K % 8 == 0: a lane's 8 elements are all in or out
+        const uint4 wv = (wok && kok) ? *reinterpret_cast<const uint4*>(wrow + ks * 16) : z;
+        const uint4 xv = (xok && kok) ? *reinterpret_cast<const uint4*>(xrow + ks * 16) : z;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, xv), acc, 0, 0, 0);
+    }
+    // acc[r]: weight row (r & 3) + 8 (r >> 2) + 4 half, activation row l31
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 64 * NW) {
+        const int m = e >> 5, nn = e & 31;                              // consecutive threads -> consecutive output columns
+        if (m >= p.M || n0 + nn >= p.Ncols) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][nn][m];
+        v *= p.alpha;
+        if (p.bias_mode == 1) v += p.bias[n0 + nn];
+        reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + n0 + nn] = f32_to_bf16(v);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // naive kernels (any shape; used for validation, tiny shapes and as the loud fallback of impl=1)
 // -------------------------------------------------------------------------------------------------
 template <typename T>
@@ -1561,6 +1612,15 @@ int dvq_gemm_nt(const void* A, const void* B, void* C, int dtype, int64_t M, int
     p.alpha = alpha; p.bias_mode = bias_mode;
     p.act_slope = 1.f;
     p.sA = sA; p.sB = sB; p.sC = sC;
+    if (dtype == DVQ_BF16 && impl == 0 && batch == 1 && bias_mode != 2 && M <= 32 && N >= 64 && K >= 64 && K % 8 == 0 && lda % 8 == 0 &&
+        ldb % 8 == 0) {
+        // single-token Linear layers of the sampler: weight-streaming kernel
+        const unsigned blocks = (unsigned)cdiv64(N, 32);
+        if (K >= 2048) gemm_nt_skinny_kernel<8><<<dim3(blocks), dim3(512), 0, (hipStream_t)stream>>>(p);
+        else gemm_nt_skinny_kernel<4><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(p);
+        DVQ_CHECK_LAUNCH("gemm_nt_skinny");
+        return DVQ_OK;
+    }
     if (dtype == DVQ_F32) return launch_nt<float>(p, batch, impl, (hipStream_t)stream);
     if (dtype == DVQ_BF16) return launch_nt<bf16_t>(p, batch, impl, (hipStream_t)stream);
     dvq_set_error("dvq_gemm_nt: bad dtype");

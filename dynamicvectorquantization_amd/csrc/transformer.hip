@@ -437,23 +437,39 @@ int dvq_dropout(const void* x, int dtype, int64_t n, float p, uint64_t seed, voi
 }  // extern "C"
 
 // ---- single-query attention over a K/V cache (sampling with a cache: one new row per step) ----------------------------
-// q [B][C], kcache / vcache [B][Tmax][C], T = number of valid cache rows (the new row included); out [B][C].
-// One workgroup per (batch, head): scores by wave-wide dot products, softmax in LDS, then the value mix column-parallel.
+// q [B][C], kcache / vcache [B][Tmax][C]; out [B][C].  Host-indexed form: T = number of valid cache rows (the new row
+// included, already stored).  Device-indexed form (t_dev != null; what a captured hipGraph replays for every token): the
+// row index t is READ FROM DEVICE MEMORY, the kernel first stores the new K / V row into cache row t and then attends over
+// rows [0, t].  One workgroup per (batch, head): scores by wave-wide dot products, softmax in LDS, value mix with the cache
+// rows split over the four waves.
 namespace {
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
-                                                          int nh, int hs, int Tlen, int64_t Tmax, float scale, T* __restrict__ out) {
+__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ q, T* __restrict__ kc, T* __restrict__ vc,
+                                                          const T* __restrict__ knew, const T* __restrict__ vnew,
+                                                          const int64_t* __restrict__ t_dev, int nh, int hs, int Tlen, int Tcap,
+                                                          int64_t Tmax, float scale, T* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sc = reinterpret_cast<float*>(smem);          // [Tlen] scores -> probabilities
-    float* qs = sc + Tlen;                               // [hs]
+    float* sc = reinterpret_cast<float*>(smem);          // [Tcap] scores -> probabilities
+    float* qs = sc + Tcap;                               // [hs]
+    float* part = qs + hs;                               // [4][hs] per-wave partial value mixes
     __shared__ float red[8];
     const int b = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t C = (int64_t)nh * hs;
+    T* kb = kc + (int64_t)b * Tmax * C + h * hs;
+    T* vb = vc + (int64_t)b * Tmax * C + h * hs;
+    if (t_dev != nullptr) {
+        const int64_t t = *t_dev;
+        if (t < 0 || t >= Tmax || t >= Tcap) return;     // never write outside the cache
+        Tlen = (int)t + 1;
+        for (int d = tid; d < hs; d += 256) {
+            kb[t * C + d] = knew[b * C + h * hs + d];
+            vb[t * C + d] = vnew[b * C + h * hs + d];
+        }
+    }
     for (int d = tid; d < hs; d += 256) qs[d] = ElemIO<T>::load(q + b * C + h * hs + d);
-    __syncthreads();
-    const T* kb = kc + (int64_t)b * Tmax * C + h * hs;
+    __syncthreads();                                     // also publishes the appended row to the whole workgroup
     for (int t = wave; t < Tlen; t += 4) {
         float acc = 0.f;
         for (int d = lane; d < hs; d += 64) acc = fmaf(qs[d], ElemIO<T>::load(kb + (int64_t)t * C + d), acc);
@@ -477,11 +493,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     if (lane == 0) red[4 + wave] = s;
     __syncthreads();
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
-    const T* vb = vc + (int64_t)b * Tmax * C + h * hs;
-    for (int d = tid; d < hs; d += 256) {
+    for (int d0 = 0; d0 < hs; d0 += 64) {
+        const int d = d0 + lane;
         float acc = 0.f;
-        for (int t = 0; t < Tlen; ++t) acc = fmaf(sc[t], ElemIO<T>::load(vb + (int64_t)t * C + d), acc);
-        ElemIO<T>::store(out + b * C + h * hs + d, acc * inv);
+        if (d < hs)
+            for (int t = wave; t < Tlen; t += 4) acc = fmaf(sc[t], ElemIO<T>::load(vb + (int64_t)t * C + d), acc);
+        if (d < hs) part[wave * hs + d] = acc;
+    }
+    __syncthreads();
+    for (int d = tid; d < hs; d += 256)
+        ElemIO<T>::store(out + b * C + h * hs + d, (part[d] + part[hs + d] + part[2 * hs + d] + part[3 * hs + d]) * inv);
+}
+
+// hidden[b][t][:] <- x[b][:] (store != 0) or x[b][:] <- hidden[b][t][:], t read from device memory; then t_inc (if given) += 1
+template <typename T>
+__global__ __launch_bounds__(256) void rows_dev_kernel(T* __restrict__ x, T* __restrict__ hidden, int64_t B, int64_t C, int64_t Tmax,
+                                                       const int64_t* __restrict__ t_dev, int store) {
+    const int64_t t = *t_dev;
+    if (t < 0 || t >= Tmax) return;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < B * C; e += (int64_t)gridDim.x * 256) {
+        const int64_t b = e / C, c = e - b * C;
+        if (store) hidden[(b * Tmax + t) * C + c] = x[e];
+        else x[e] = hidden[(b * Tmax + t) * C + c];
     }
 }
 
@@ -489,13 +522,36 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
 
 extern "C" int dvq_attn_decode(const void* q, const void* kcache, const void* vcache, int dtype, int64_t B, int64_t n_head, int64_t head_size,
                                int64_t T, int64_t Tmax, float scale, void* out, dvq_stream_t stream) {
-    DVQ_REQUIRE(q && kcache && vcache && out && B > 0 && n_head > 0 && head_size > 0 && T > 0 && T <= Tmax && T <= 16000 &&
+    DVQ_REQUIRE(q && kcache && vcache && out && B > 0 && n_head > 0 && head_size > 0 && T > 0 && T <= Tmax && T <= 12000 &&
                     B * n_head < (1ll << 31),
                 DVQ_EINVAL, "dvq_attn_decode: bad arguments");
-    const int lds = (int)((T + head_size) * sizeof(float));
+    const int lds = (int)((T + 5 * head_size) * sizeof(float));
     DVQ_DISPATCH_DTYPE(dtype, TT, attn_decode_kernel<TT><<<dim3((unsigned)(B * n_head)), dim3(256), lds, (hipStream_t)stream>>>(
-                                      (const TT*)q, (const TT*)kcache, (const TT*)vcache, (int)n_head, (int)head_size, (int)T, Tmax, scale,
-                                      (TT*)out););
+                                      (const TT*)q, (TT*)const_cast<void*>(kcache), (TT*)const_cast<void*>(vcache), nullptr, nullptr, nullptr,
+                                      (int)n_head, (int)head_size, (int)T, (int)T, Tmax, scale, (TT*)out););
     DVQ_CHECK_LAUNCH("attn_decode");
+    return DVQ_OK;
+}
+
+extern "C" int dvq_attn_decode_dev(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, int dtype, int64_t B,
+                                   int64_t n_head, int64_t head_size, const int64_t* t_dev, int64_t Tmax, float scale, void* out,
+                                   dvq_stream_t stream) {
+    DVQ_REQUIRE(q && k_new && v_new && kcache && vcache && t_dev && out && B > 0 && n_head > 0 && head_size > 0 && Tmax > 0 &&
+                    Tmax <= 12000 && B * n_head < (1ll << 31),
+                DVQ_EINVAL, "dvq_attn_decode_dev: bad arguments");
+    const int lds = (int)((Tmax + 5 * head_size) * sizeof(float));
+    DVQ_DISPATCH_DTYPE(dtype, TT, attn_decode_kernel<TT><<<dim3((unsigned)(B * n_head)), dim3(256), lds, (hipStream_t)stream>>>(
+                                      (const TT*)q, (TT*)kcache, (TT*)vcache, (const TT*)k_new, (const TT*)v_new, t_dev, (int)n_head,
+                                      (int)head_size, 0, (int)Tmax, Tmax, scale, (TT*)out););
+    DVQ_CHECK_LAUNCH("attn_decode_dev");
+    return DVQ_OK;
+}
+
+extern "C" int dvq_rows_dev(void* x, void* hidden, int dtype, int64_t B, int64_t C, int64_t Tmax, const int64_t* t_dev, int store,
+                            dvq_stream_t stream) {
+    DVQ_REQUIRE(x && hidden && t_dev && B > 0 && C > 0 && Tmax > 0, DVQ_EINVAL, "dvq_rows_dev: bad arguments");
+    DVQ_DISPATCH_DTYPE(dtype, TT, rows_dev_kernel<TT><<<dim3(nblk(B * C, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+                                      (TT*)x, (TT*)hidden, B, C, Tmax, t_dev, store););
+    DVQ_CHECK_LAUNCH("rows_dev");
     return DVQ_OK;
 }

@@ -749,6 +749,22 @@ def attn_causal_bwd(q, k, v, out, dout, lse, b, t, n_head, scale, p_drop=0.0, se
     return dq, dk, dv
 
 
+def attn_decode_dev(q, k_new, v_new, kcache, vcache, n_head, t_dev, scale):
+    """device-indexed form (graph replay): append (k_new, v_new) at cache row t_dev[0], attend over rows [0, t]"""
+    b, c = q.shape
+    out = torch.empty_like(q)
+    check(lib().dvq_attn_decode_dev(_p(q), _p(k_new), _p(v_new), _p(kcache), _p(vcache), dt(q), b, n_head, c // n_head, _p(t_dev),
+                                    kcache.shape[1], scale, _p(out), _s()), "dvq_attn_decode_dev")
+    return out
+
+
+def rows_dev(x, hidden, t_dev, store):
+    """hidden[:, t_dev[0]] <- x (store) or x <- hidden[:, t_dev[0]]; x [B, C], hidden [B, Tmax, C]"""
+    b, c = x.shape
+    check(lib().dvq_rows_dev(_p(x), _p(hidden), dt(x), b, c, hidden.shape[1], _p(t_dev), int(store), _s()), "dvq_rows_dev")
+    return x
+
+
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     check(lib().dvq_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, _s()), "dvq_adamw")
 

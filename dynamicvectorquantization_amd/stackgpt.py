@@ -13,6 +13,7 @@ walks the tapes (gradients accumulate in place into .grad / the flat optimizer b
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -223,6 +224,21 @@ def _block_append(blk, x2d, b, n, cache, t0):
     return K.add(x1, m)
 
 
+def _block_append_dev(blk, x2d, cache, t_dev):
+    """_block_append for ONE new row per sequence whose cache row index lives in device memory (t_dev, int64 [1]): nothing in the
+    launch sequence depends on the position, so the whole pass can be captured once as a hipGraph and replayed per token"""
+    attn = blk.attn
+    c = x2d.shape[1]
+    h = blk.ln1.fwd(x2d, None)
+    k = attn.key.fwd(h, None)
+    q = attn.query.fwd(h, None)
+    v = attn.value.fwd(h, None)
+    y = K.attn_decode_dev(q, k, v, cache[0], cache[1], attn.n_head, t_dev, 1.0 / math.sqrt(c // attn.n_head))
+    x1 = K.add(x2d, attn.proj.fwd(y, None))
+    m = blk.mlp[2].fwd(K.gelu(blk.mlp[0].fwd(blk.ln2.fwd(x1, None), None)), None)
+    return K.add(x1, m)
+
+
 class DecodeState:
     """K/V caches of both transformers + the position-transformer hidden rows of one sampling run (eval mode, no dropout).
     The position transformer's row r is (content_r, position_r [, segment_r]); the content transformer's row r is that
@@ -238,9 +254,82 @@ class DecodeState:
         self.hidden = torch.zeros(batch, max_rows, c, dtype=cd, device=dev)
         self.rows_pos = 0
         self.rows_con = 0
+        # single-row steps: row counters in device memory + one captured hipGraph per (transformer, position table) -- the
+        # sampler is launch-bound (24 layers x ~12 small kernels per token), a replay costs one launch.  DVQ_DECODE_GRAPH=0: eager
+        self.t_pos = torch.zeros(1, dtype=torch.long, device=dev)
+        self.t_con = torch.zeros(1, dtype=torch.long, device=dev)
+        self.use_graph = os.environ.get("DVQ_DECODE_GRAPH", "1") != "0"
+        self._steps = {}
+        self._sig = self._weights_signature()
+
+    def _weights_signature(self):
+        g = self.gpt
+        ps = [g.position_transformer[0].attn.key.weight, g.content_transformer[-1].mlp[2].weight, g.content_head[1].weight]
+        return tuple((rt.param_epoch(p_), p_._version, p_.data_ptr()) for p_ in ps)
+
+    def reset(self):
+        """start a new sampling run on the same buffers (rows are always written before they are read)"""
+        self.rows_pos = self.rows_con = 0
+        self.t_pos.zero_()
+        self.t_con.zero_()
+        sig = self._weights_signature()
+        if sig != self._sig:              # the captured graphs point at the previous compute-dtype weight copies
+            self._steps.clear()
+            self._sig = sig
 
     def reset_content(self):
         self.rows_con = 0
+        self.t_con.zero_()
+
+    def _step(self, key, body, inputs):
+        """run `body(*static_inputs)`: eagerly the first time (creates weight caches, kernel attributes), then captured once and
+        replayed"""
+        ent = self._steps.get(key)
+        if ent is None:
+            ent = self._steps[key] = {"static": [None if t is None else t.clone() for t in inputs], "graph": None, "calls": 0}
+        for st_, t in zip(ent["static"], inputs):
+            if st_ is not None:
+                st_.copy_(t)
+        ent["calls"] += 1
+        if not self.use_graph or ent["calls"] == 1:
+            return body(*ent["static"])
+        if ent["graph"] is None:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                ent["out"] = body(*ent["static"])
+            ent["graph"] = gr
+        ent["graph"].replay()
+        return ent["out"].clone()
+
+    def _position_row_body(self, pos_table):
+        g, b = self.gpt, self.b
+
+        def body(content_tok, pos_tok, seg_tok):
+            pieces = [(g.content_emb.weight, content_tok, 0, None, False), (g.pos_emb, self.t_pos, 0, None, True),
+                      (pos_table, pos_tok, 0, None, False)]
+            if seg_tok is not None:
+                pieces.append((g.seg_emb.weight, seg_tok, 0, None, False))
+            x = g._embed(pieces, b, 1, None, "").view(b, -1)
+            for blk, cache in zip(g.position_transformer, self.pos_cache):
+                x = _block_append_dev(blk, x, cache, self.t_pos)
+            K.rows_dev(x, self.hidden, self.t_pos, True)
+            logits = g._head(g.position_head, x, None, "ph")[:, : g.config.fine_position_size].float()
+            self.t_pos.add_(1)
+            return logits
+        return body
+
+    def _content_row_body(self, upd_table):
+        g, b = self.gpt, self.b
+
+        def body(upd_tok):
+            upd = g._embed([(upd_table, upd_tok, 0, None, False)], b, 1, None, "").view(b, -1)
+            x = K.add(K.rows_dev(torch.empty_like(upd), self.hidden, self.t_con, False), upd)
+            for blk, cache in zip(g.content_transformer, self.con_cache):
+                x = _block_append_dev(blk, x, cache, self.t_con)
+            logits = g._head(g.content_head, x, None, "ch")[:, : g.config.vocab_size].float()
+            self.t_con.add_(1)
+            return logits
+        return body
 
     @torch.no_grad()
     def position_rows(self, content_tok, pos_tok, pos_table, pos_pad, seg_tok=None):
@@ -248,6 +337,12 @@ class DecodeState:
         g, b = self.gpt, self.b
         n, t0 = content_tok.shape[1], self.rows_pos
         assert t0 + n <= self.max_rows, "DecodeState: increase max_rows"
+        if n == 1:
+            use_seg = g.activate_segment and seg_tok is not None
+            out = self._step(("pos", id(pos_table), use_seg), self._position_row_body(pos_table),
+                             [content_tok.contiguous(), pos_tok.contiguous(), seg_tok.contiguous() if use_seg else None])
+            self.rows_pos = t0 + 1
+            return out
         ar = torch.arange(t0, t0 + n, device=content_tok.device)
         pieces = [(g.content_emb.weight, content_tok.contiguous(), 0, None, False), (g.pos_emb, ar, 0, None, True),
                   (pos_table, pos_tok.contiguous(), 0, None, False)]
@@ -258,6 +353,7 @@ class DecodeState:
             x = _block_append(blk, x, b, n, cache, t0)
         self.hidden[:, t0:t0 + n].copy_(x.view(b, n, -1))
         self.rows_pos = t0 + n
+        self.t_pos.fill_(self.rows_pos)
         last = x.view(b, n, -1)[:, -1].contiguous()
         return g._head(g.position_head, last, None, "ph")[:, : g.config.fine_position_size].float()
 
@@ -268,11 +364,16 @@ class DecodeState:
         g, b = self.gpt, self.b
         n, t0 = upd_tok.shape[1], self.rows_con
         assert t0 + n <= self.rows_pos, "content rows cannot run ahead of the position transformer"
+        if n == 1:
+            out = self._step(("con", id(upd_table)), self._content_row_body(upd_table), [upd_tok.contiguous()])
+            self.rows_con = t0 + 1
+            return out
         upd = g._embed([(upd_table, upd_tok.contiguous(), 0, None, False)], b, n, None, "")
         x = K.add(self.hidden[:, t0:t0 + n].contiguous().view(b * n, -1), upd.view(b * n, -1))
         for blk, cache in zip(g.content_transformer, self.con_cache):
             x = _block_append(blk, x, b, n, cache, t0)
         self.rows_con = t0 + n
+        self.t_con.fill_(self.rows_con)
         last = x.view(b, n, -1)[:, -1].contiguous()
         return g._head(g.content_head, last, None, "ch")[:, : g.config.vocab_size].float()
 

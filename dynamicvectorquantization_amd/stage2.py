@@ -303,9 +303,8 @@ class Dualformer(_SamplerMixinBase, nn.Module):
 # ---- sampling (dqtransformer_uncond_entropy.py:302-561, models/stage2/utils.py:22-40) ---------------------------------------
 def top_k_logits(logits, k):
     v, _ = torch.topk(logits, k)
-    out = logits.clone()
-    out[out < v[..., [-1]]] = -float("Inf")
-    return out
+    # same values as the reference's `out[out < v[..., [-1]]] = -inf` without the host sync of boolean-mask assignment
+    return torch.where(logits < v[..., -1:], torch.full_like(logits, -float("Inf")), logits)
 
 
 def top_p_logits(probs, p):
@@ -344,7 +343,8 @@ class _SamplerMixin:
         forbid[:, self.fine_position_pad_code] = True
         out = _mask_rows(logits, flag, forbid, self.fine_position_eos_code, self.fine_position_pad_code)
         live = ~flag.bool().view(-1)
-        out[live, self.fine_position_sos_code] = -float("Inf")         # applied after <eos> was restored (reference order)
+        col = out[:, self.fine_position_sos_code]                      # applied after <eos> was restored (reference order)
+        out[:, self.fine_position_sos_code] = torch.where(live, torch.full_like(col, -float("Inf")), col)
         return out
 
     def avoid_special_or_enforce_pad_for_content(self, logits, flag):
@@ -407,7 +407,14 @@ class _SamplerMixin:
         else:
             x_f, x_pf, x_sf = c_fine[:, :0], c_pos_fine[:, :0], (c_seg_fine[:, :0] if c_seg_fine is not None else None)
         b, dev = x_c.size(0), x_c.device
-        st = DecodeState(tr, b, self.hw1 * self.hw1 + self.fine_hw * self.fine_hw + 8)
+        # buffers and captured per-token graphs are kept across sampling runs of the same batch size
+        rows = self.hw1 * self.hw1 + self.fine_hw * self.fine_hw + 8
+        pool = self.__dict__.setdefault("_decode_states", {})
+        st = pool.get((b, rows, str(dev)))
+        if st is None or st.gpt is not tr:
+            pool.clear()                                      # one resident state: the K/V caches are the big allocation
+            st = pool[(b, rows, str(dev))] = DecodeState(tr, b, rows)
+        st.reset()
         zeros1 = torch.zeros(b, 1, dtype=torch.long, device=dev)
         # ---- coarse stream
         done = torch.zeros(b, 1, device=dev)

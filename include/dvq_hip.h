@@ -355,6 +355,14 @@ int dvq_attn_causal_bwd(const void* q, const void* k, const void* v, const void*
  * the new one; out [B][C] = softmax(scale * q K^T) V per head. */
 int dvq_attn_decode(const void* q, const void* kcache, const void* vcache, int dtype, int64_t B, int64_t n_head, int64_t head_size,
                     int64_t T, int64_t Tmax, float scale, void* out, dvq_stream_t stream);
+/* Device-indexed forms for a captured hipGraph (one graph replayed for every sampled token): the cache row index t is read
+ * from device memory.  dvq_attn_decode_dev stores k_new / v_new [B][C] into cache row t and attends over rows [0, t];
+ * dvq_rows_dev copies x [B][C] into hidden[b][t][:] (store != 0) or back.  Calls with t outside [0, Tmax) do nothing. */
+int dvq_attn_decode_dev(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, int dtype, int64_t B,
+                        int64_t n_head, int64_t head_size, const int64_t* t_dev, int64_t Tmax, float scale, void* out,
+                        dvq_stream_t stream);
+int dvq_rows_dev(void* x, void* hidden, int dtype, int64_t B, int64_t C, int64_t Tmax, const int64_t* t_dev, int store,
+                 dvq_stream_t stream);
 /* nn.Dropout(p) with a counter-based hash RNG: y = x * keep / (1-p); the same (seed) reproduces the mask for the backward */
 int dvq_dropout(const void* x, int dtype, int64_t n, float p, uint64_t seed, void* y, dvq_stream_t stream);
 

@@ -455,6 +455,27 @@ def test_gemm_nt_wide_kernel(dev, shape):
     assert err < 1e-2, err
 
 
+@pytest.mark.parametrize("shape", [(8, 1024, 1024, 1), (1, 1032, 1024, 0), (32, 4096, 1024, 1), (8, 1024, 4096, 1), (13, 72, 200, 1), (32, 264, 64, 0)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_gemm_nt_skinny_kernel(dev, shape):
+    """weight-streaming kernel of the single-token Linear layers (bf16, M <= 32, impl 0) against the 128 x 128 kernel (impl 2) and fp32"""
+    from dynamicvectorquantization_amd import kernels as K
+    m, n, k, with_bias = shape
+    rs = np.random.RandomState(m * 7 + n + k)
+    a = bf16_round(rs.standard_normal((m, k)).astype(np.float32))
+    w = bf16_round(rs.standard_normal((n, k)).astype(np.float32) / np.sqrt(k))
+    bias = rs.standard_normal(n).astype(np.float32) if with_bias else None
+    ref = torch.from_numpy(a) @ torch.from_numpy(w).t()
+    if with_bias:
+        ref = ref + torch.from_numpy(bias)[None, :]
+    at, wt_ = T(a, dev, torch.bfloat16).reshape(-1), T(w, dev, torch.bfloat16).reshape(-1)
+    bt = T(bias, dev) if with_bias else None
+    for impl in (0, 2):
+        out = K.gemm_nt(at, wt_, m, n, k, k, k, n, bias=bt, bias_mode=1 if with_bias else 0, impl=impl)
+        got = out.view(m, n).float().cpu()
+        assert float((got - ref).abs().max()) / float(ref.abs().max()) < 1e-2, impl
+
+
 @pytest.mark.parametrize("shape", [(2048, 1024, 1024, 1), (1304, 1032, 512, 0), (20736, 1024, 4096, 1), (1024, 256, 264, 1)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_gemm_nt_library_path(dev, shape):
