@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = reinterpret_cast<float*>(smem);          // [Tcap] scores -> probabilities
     float* qs = sc + Tcap;                               // [hs]
-    float* part = qs + hs;                               // [4][hs] per-wave partial value mixes
+    float* part = qs + hs;                               // [256 * 8] per-row-group partial value mixes
     __shared__ float red[8];
     const int b = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -470,11 +470,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     }
     for (int d = tid; d < hs; d += 256) qs[d] = ElemIO<T>::load(q + b * C + h * hs + d);
     __syncthreads();                                     // also publishes the appended row to the whole workgroup
-    for (int t = wave; t < Tlen; t += 4) {
+    // scores: one cache row per thread, hs / 8 independent 16-byte loads in flight (a wave-per-row loop exposed one global
+    // load latency per row: 160 us at T = 640)
+    const int nv = hs >> 3;
+    for (int t = tid; t < Tlen; t += 256) {
+        const T* kr = kb + (int64_t)t * C;
         float acc = 0.f;
-        for (int d = lane; d < hs; d += 64) acc = fmaf(qs[d], ElemIO<T>::load(kb + (int64_t)t * C + d), acc);
-        acc = wave_sum(acc);
-        if (lane == 0) sc[t] = acc * scale;
+        for (int i = 0; i < nv; ++i) {
+            float kv[8];
+            load8(kr + i * 8, kv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(qs[i * 8 + j], kv[j], acc);
+        }
+        sc[t] = acc * scale;
     }
     __syncthreads();
     float m = -INFINITY;
@@ -493,16 +501,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     if (lane == 0) red[4 + wave] = s;
     __syncthreads();
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
-    for (int d0 = 0; d0 < hs; d0 += 64) {
-        const int d = d0 + lane;
-        float acc = 0.f;
-        if (d < hs)
-            for (int t = wave; t < Tlen; t += 4) acc = fmaf(sc[t], ElemIO<T>::load(vb + (int64_t)t * C + d), acc);
-        if (d < hs) part[wave * hs + d] = acc;
-    }
+    // value mix: thread = (row group, 8-channel chunk); the row groups are combined in LDS
+    const int ngrp = 256 / nv;                           // nv = 2 .. 32 chunks -> 128 .. 8 row groups
+    const int ch = tid % nv, grp = tid / nv;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (grp < ngrp)
+        for (int t = grp; t < Tlen; t += ngrp) {
+            float vv[8];
+            load8(vb + (int64_t)t * C + ch * 8, vv);
+            const float pt = sc[t];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(pt, vv[j], acc[j]);
+        }
+    __syncthreads();                                     // sc is dead: reuse nothing, but part must not alias live data
+    if (grp < ngrp)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[grp * hs + ch * 8 + j] = acc[j];
     __syncthreads();
-    for (int d = tid; d < hs; d += 256)
-        ElemIO<T>::store(out + b * C + h * hs + d, (part[d] + part[hs + d] + part[2 * hs + d] + part[3 * hs + d]) * inv);
+    for (int d = tid; d < hs; d += 256) {
+        float v = 0.f;
+        for (int g = 0; g < ngrp; ++g) v += part[g * hs + d];
+        ElemIO<T>::store(out + b * C + h * hs + d, v * inv);
+    }
 }
 
 // hidden[b][t][:] <- x[b][:] (store != 0) or x[b][:] <- hidden[b][t][:], t read from device memory; then t_inc (if given) += 1
@@ -522,10 +542,10 @@ __global__ __launch_bounds__(256) void rows_dev_kernel(T* __restrict__ x, T* __r
 
 extern "C" int dvq_attn_decode(const void* q, const void* kcache, const void* vcache, int dtype, int64_t B, int64_t n_head, int64_t head_size,
                                int64_t T, int64_t Tmax, float scale, void* out, dvq_stream_t stream) {
-    DVQ_REQUIRE(q && kcache && vcache && out && B > 0 && n_head > 0 && head_size > 0 && T > 0 && T <= Tmax && T <= 12000 &&
-                    B * n_head < (1ll << 31),
-                DVQ_EINVAL, "dvq_attn_decode: bad arguments");
-    const int lds = (int)((T + 5 * head_size) * sizeof(float));
+    DVQ_REQUIRE(q && kcache && vcache && out && B > 0 && n_head > 0 && head_size > 0 && head_size % 8 == 0 && head_size <= 256 && T > 0 &&
+                    T <= Tmax && T <= 12000 && B * n_head < (1ll << 31),
+                DVQ_EINVAL, "dvq_attn_decode: bad arguments (head_size %% 8 == 0, <= 256)");
+    const int lds = (int)((T + head_size + 2048) * sizeof(float));
     DVQ_DISPATCH_DTYPE(dtype, TT, attn_decode_kernel<TT><<<dim3((unsigned)(B * n_head)), dim3(256), lds, (hipStream_t)stream>>>(
                                       (const TT*)q, (TT*)const_cast<void*>(kcache), (TT*)const_cast<void*>(vcache), nullptr, nullptr, nullptr,
                                       (int)n_head, (int)head_size, (int)T, (int)T, Tmax, scale, (TT*)out););
@@ -536,10 +556,10 @@ extern "C" int dvq_attn_decode(const void* q, const void* kcache, const void* vc
 extern "C" int dvq_attn_decode_dev(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, int dtype, int64_t B,
                                    int64_t n_head, int64_t head_size, const int64_t* t_dev, int64_t Tmax, float scale, void* out,
                                    dvq_stream_t stream) {
-    DVQ_REQUIRE(q && k_new && v_new && kcache && vcache && t_dev && out && B > 0 && n_head > 0 && head_size > 0 && Tmax > 0 &&
-                    Tmax <= 12000 && B * n_head < (1ll << 31),
-                DVQ_EINVAL, "dvq_attn_decode_dev: bad arguments");
-    const int lds = (int)((Tmax + 5 * head_size) * sizeof(float));
+    DVQ_REQUIRE(q && k_new && v_new && kcache && vcache && t_dev && out && B > 0 && n_head > 0 && head_size > 0 && head_size % 8 == 0 &&
+                    head_size <= 256 && Tmax > 0 && Tmax <= 12000 && B * n_head < (1ll << 31),
+                DVQ_EINVAL, "dvq_attn_decode_dev: bad arguments (head_size %% 8 == 0, <= 256)");
+    const int lds = (int)((Tmax + head_size + 2048) * sizeof(float));
     DVQ_DISPATCH_DTYPE(dtype, TT, attn_decode_kernel<TT><<<dim3((unsigned)(B * n_head)), dim3(256), lds, (hipStream_t)stream>>>(
                                       (const TT*)q, (TT*)kcache, (TT*)vcache, (const TT*)k_new, (const TT*)v_new, t_dev, (int)n_head,
                                       (int)head_size, 0, (int)Tmax, Tmax, scale, (TT*)out););
