@@ -3,7 +3,7 @@
 
     python bench_extra.py --workload triple   [--bs 32] [--steps K] [--warmup W]      # dqvae-triple-r-03-03 complete step
     python bench_extra.py --workload stage2   [--bs 32]                               # DQ-Transformer p6c18 train step
-    python bench_extra.py --workload sampling [--bs 8]                                # AR sampling tokens/s (no KV cache)
+    python bench_extra.py --workload sampling [--bs 8]                                # AR sampling token-steps/s (K/V caches + graphs; prefix recompute)
 
 Each prints one JSON line {"workload", "metric", "value", "unit", "ms_per_step", ...}.  Synthetic 256x256 half-flat images,
 random-init weights of the shipped YAML architectures, bf16 compute / fp32 master weights, inputs resident in HBM.
