@@ -410,10 +410,12 @@ class _SamplerMixin:
         # buffers and captured per-token graphs are kept across sampling runs of the same batch size
         rows = self.hw1 * self.hw1 + self.fine_hw * self.fine_hw + 8
         pool = self.__dict__.setdefault("_decode_states", {})
-        st = pool.get((b, rows, str(dev)))
+        from . import runtime as _rt
+        key = (b, rows, str(dev), str(_rt.compute_dtype()))
+        st = pool.get(key)
         if st is None or st.gpt is not tr:
             pool.clear()                                      # one resident state: the K/V caches are the big allocation
-            st = pool[(b, rows, str(dev))] = DecodeState(tr, b, rows)
+            st = pool[key] = DecodeState(tr, b, rows)
         st.reset()
         zeros1 = torch.zeros(b, 1, dtype=torch.long, device=dev)
         # ---- coarse stream

@@ -249,6 +249,41 @@ def test_sampler_greedy_golden(dev, order, kv_cache):
         assert tuple(img.shape) == (3, 3, 64, 64) and bool(torch.isfinite(img).all())
 
 
+def test_sampler_token_step_graphs(dev):
+    """K/V-cached sampling replays one captured hipGraph per (transformer, position table) for the single-row steps: the graph
+    path must draw exactly the tokens of the eager path (greedy), run after run on the cached state, and must drop its
+    graphs when the weights change"""
+    from dynamicvectorquantization_amd import runtime as rt
+    with rt.compute_dtype_ctx(torch.float32):
+        model = _sampler_model(dev, "region-first")
+        c = model.encode_to_c(torch.zeros(3, 3, 64, 64, device=dev))
+        kw = dict(temperature=1.0, sample=False, top_k=50, top_p=None, top_k_pos=None, top_p_pos=None, process=False,
+                  fix_fine_position=False, kv_cache=True)
+        first = [r.cpu().numpy() for r in model.sample_from_scratch(*c, **kw)]
+        st = next(iter(model._decode_states.values()))
+        assert st.use_graph and any(e["graph"] is not None for e in st._steps.values()), "token steps were not captured"
+        again = [r.cpu().numpy() for r in model.sample_from_scratch(*c, **kw)]          # replays only
+        assert all(np.array_equal(a, b) for a, b in zip(first, again))
+        st.use_graph = False
+        st._steps.clear()
+        eager = [r.cpu().numpy() for r in model.sample_from_scratch(*c, **kw)]
+        assert all(np.array_equal(a, b) for a, b in zip(first, eager))
+        # weights change -> the captured graphs (which hold the old compute-dtype copies) are discarded on the next run
+        st.use_graph = True
+        model.sample_from_scratch(*c, **kw)
+        model.sample_from_scratch(*c, **kw)
+        assert any(e["graph"] is not None for e in st._steps.values())
+        with torch.no_grad():
+            model.transformer.content_head[1].weight.mul_(-1.0)
+        flipped = [r.cpu().numpy() for r in model.sample_from_scratch(*c, **kw)]
+        st2 = next(iter(model._decode_states.values()))
+        st2.use_graph = False
+        st2._steps.clear()
+        flipped_eager = [r.cpu().numpy() for r in model.sample_from_scratch(*c, **kw)]
+        assert all(np.array_equal(a, b) for a, b in zip(flipped, flipped_eager))
+        assert not all(np.array_equal(a, b) for a, b in zip(first, flipped)), "negated content head must change the draws"
+
+
 def test_sampler_constraints_and_filters_golden(dev):
     from dynamicvectorquantization_amd import stage2
     g = load_golden("sampler")
