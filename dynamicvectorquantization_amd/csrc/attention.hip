@@ -151,8 +151,9 @@ __device__ __forceinline__ void store_ct(bf16_t* dst /* row base + head offset *
 // ------------------------------------------------------------------------------------------------------------------
 // forward: one wave per 32 queries; the workgroup walks the key tiles 0 .. (its last query tile)
 // ------------------------------------------------------------------------------------------------------------------
+// (two workgroups per CU: without the explicit bound the compiler spreads into AGPRs and settles for one wave per SIMD)
 template <int HS>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     using G = Geo<HS>;
     constexpr int NS = HS / 16, NM = HS / 32, STAGE = G::RTILE + G::CTILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(AttnParams p, int64_t 
 // backward, dQ: one wave per 32 queries (same walk as the forward); LDS stage = K, V (row-major) and K^T tiles
 // ------------------------------------------------------------------------------------------------------------------
 template <int HS>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     using G = Geo<HS>;
     constexpr int NS = HS / 16, NM = HS / 32, STAGE = 2 * G::RTILE + G::CTILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -379,8 +380,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 // backward, dK and dV: one wave per 32 keys; the workgroup walks the query tiles from its first key tile to the end;
 // LDS stage = Q, dO (row-major) and Q^T, dO^T tiles
 // ------------------------------------------------------------------------------------------------------------------
+// (head size 128 keeps one wave per SIMD: 128 accumulator + 64 resident operand registers do not fit 256 without spilling)
 template <int HS>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, HS == 64 ? 2 : 1) void attn_bwd_dkv_kernel(AttnParams p) {
     using G = Geo<HS>;
     constexpr int NS = HS / 16, NM = HS / 32, STAGE = 2 * G::RTILE + 2 * G::CTILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
