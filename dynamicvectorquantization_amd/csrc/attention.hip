@@ -447,41 +447,49 @@ __global__ __launch_bounds__(256, HS == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Att
                 s = MFMA(frag_r<HS>(ql, l31, half, st), kf[st], s);
                 dp = MFMA(frag_r<HS>(dl, l31, half, st), vf[st], dp);
             }
-            // per-query statistics of the 16 accumulator rows of this half: 4 groups of 4 consecutive queries
-            float lq[16], dq_[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int qq = q0 + 8 * g + 4 * half;
-                const bool ok = qq < T;                           // T % 4 == 0: a group is entirely in or out
-                const float4 a = ok ? *reinterpret_cast<const float4*>(lsep + qq) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 d = ok ? *reinterpret_cast<const float4*>(dsp + qq) : make_float4(0.f, 0.f, 0.f, 0.f);
-                lq[4 * g + 0] = a.x; lq[4 * g + 1] = a.y; lq[4 * g + 2] = a.z; lq[4 * g + 3] = a.w;
-                dq_[4 * g + 0] = d.x; dq_[4 * g + 1] = d.y; dq_[4 * g + 2] = d.z; dq_[4 * g + 3] = d.w;
-            }
+            // element-wise pass and second GEMMs in two halves (registers 8 s2 .. 8 s2 + 7 = two groups of 4 consecutive
+            // queries each): only 8 probabilities / 8 score gradients and 8 per-query statistics are live at a time
             const bool diag = qt == kt;
-            f32x16 pd;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int query = q0 + crow(r, half);
-                const bool valid = query < T && (!diag || krow <= query);
-                const float pr = valid ? __builtin_amdgcn_exp2f(s[r] * c2 - lq[r] * LOG2E) : 0.f;
-                float g = dp[r], pk = pr;
-                if (p.thr != 0) {
-                    const unsigned idx = (unsigned)(((int64_t)bh * T + query) * T) + (unsigned)krow;
-                    const bool keep = dvq_hash32(idx * p.rm + p.ra) >= p.thr;
-                    g = keep ? g * p.inv_keep : 0.f;
-                    pk = keep ? pr * p.inv_keep : 0.f;
-                }
-                pd[r] = pk;                                       // dropped-out probabilities: dV
-                s[r] = pr * (g - dq_[r]);                         // d loss / d (scaled score): dK
-            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pf = pack8(pd, s2), df = pack8(s, s2);
+                Frag pf, df;
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int g = 2 * s2 + gg;
+                    const int qq = q0 + 8 * g + 4 * half;
+                    const bool ok = qq < T;                       // T % 4 == 0: a group is entirely in or out
+                    const float4 l4 = ok ? *reinterpret_cast<const float4*>(lsep + qq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 d4 = ok ? *reinterpret_cast<const float4*>(dsp + qq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq_[4] = {d4.x, d4.y, d4.z, d4.w};
+                    float pk[4], ds[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * g + i;
+                        const int query = qq + i;
+                        const bool valid = ok && (!diag || krow <= query);
+                        const float pr = valid ? __builtin_amdgcn_exp2f(s[r] * c2 - lq[i] * LOG2E) : 0.f;
+                        float gr = dp[r];
+                        pk[i] = pr;
+                        if (p.thr != 0) {
+                            const unsigned idx = (unsigned)(((int64_t)bh * T + query) * T) + (unsigned)krow;
+                            const bool keep = dvq_hash32(idx * p.rm + p.ra) >= p.thr;
+                            gr = keep ? gr * p.inv_keep : 0.f;
+                            pk[i] = keep ? pr * p.inv_keep : 0.f;
+                        }
+                        ds[i] = pr * (gr - dq_[i]);               // d loss / d (scaled score): dK;  pk: dropped-out probabilities: dV
+                    }
+                    const unsigned p0 = pack_bf16x2(pk[0], pk[1]), p1 = pack_bf16x2(pk[2], pk[3]);
+                    const unsigned d0 = pack_bf16x2(ds[0], ds[1]), d1 = pack_bf16x2(ds[2], ds[3]);
+                    if (gg == 0) {
+                        pf.u.x = p0; pf.u.y = p1; df.u.x = d0; df.u.y = d1;
+                    } else {
+                        pf.u.z = p0; pf.u.w = p1; df.u.z = d0; df.u.w = d1;
+                    }
+                }
 #pragma unroll
                 for (int mt = 0; mt < NM; ++mt) {
-                    dv[mt] = MFMA(frag_c<HS>(dtl, l31, half, mt, s2), pf, dv[mt]);
-                    dk[mt] = MFMA(frag_c<HS>(qtl, l31, half, mt, s2), df, dk[mt]);
+                    dv[mt] = MFMA(frag_c<HS>(dtl, l31, half, mt, s2), pf.v, dv[mt]);
+                    dk[mt] = MFMA(frag_c<HS>(qtl, l31, half, mt, s2), df.v, dk[mt]);
                 }
             }
         }
