@@ -39,7 +39,7 @@ struct Plan {
     bool ok = false;
 };
 
-using Key = std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int>;
+using Key = std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int>;
 
 std::mutex g_mu;
 Api g_api;
@@ -79,15 +79,17 @@ Api& api() {
     return g_api;
 }
 
-Plan& plan_for(Api& a, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool bias) {
-    const Key key{M, N, K, lda, ldb, ldc, bias ? 1 : 0};
+Plan& plan_for(Api& a, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool bias, bool b_kn) {
+    const Key key{M, N, K, lda, ldb, ldc, bias ? 1 : 0, b_kn ? 1 : 0};
     auto it = g_plans.find(key);
     if (it != g_plans.end()) return it->second;
     Plan p;
-    // row-major C[M][N] = A[M][K] B[N][K]^T  ==  column-major D (N x M) = op_T(B as K x N) * (A as K x M)
+    // row-major C[M][N] = A[M][K] B[N][K]^T  ==  column-major D (N x M) = op_T(B as K x N) * (A as K x M);
+    // with B stored [K][N] (b_kn, the weight matrix of an input gradient as it lies in memory) the first operand is the
+    // column-major N x K matrix itself: no transposed copy of the weights is ever made
     const int32_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
     bool ok = a.desc_create(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
-    ok = ok && a.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)) == HIPBLAS_STATUS_SUCCESS;
+    ok = ok && a.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, b_kn ? &opN : &opT, sizeof(opT)) == HIPBLAS_STATUS_SUCCESS;
     ok = ok && a.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opN, sizeof(opN)) == HIPBLAS_STATUS_SUCCESS;
     if (ok && bias) {
         const uint32_t epi = HIPBLASLT_EPILOGUE_BIAS;
@@ -95,7 +97,8 @@ Plan& plan_for(Api& a, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb
         ok = a.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) == HIPBLAS_STATUS_SUCCESS &&
              a.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &btype, sizeof(btype)) == HIPBLAS_STATUS_SUCCESS;
     }
-    ok = ok && a.layout_create(&p.la, HIP_R_16BF, (uint64_t)K, (uint64_t)N, ldb) == HIPBLAS_STATUS_SUCCESS;
+    ok = ok && (b_kn ? a.layout_create(&p.la, HIP_R_16BF, (uint64_t)N, (uint64_t)K, ldb)
+                     : a.layout_create(&p.la, HIP_R_16BF, (uint64_t)K, (uint64_t)N, ldb)) == HIPBLAS_STATUS_SUCCESS;
     ok = ok && a.layout_create(&p.lb, HIP_R_16BF, (uint64_t)K, (uint64_t)M, lda) == HIPBLAS_STATUS_SUCCESS;
     ok = ok && a.layout_create(&p.lc, HIP_R_16BF, (uint64_t)N, (uint64_t)M, ldc) == HIPBLAS_STATUS_SUCCESS;
     if (ok) {
@@ -119,13 +122,13 @@ Plan& plan_for(Api& a, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb
 }  // namespace
 
 // 1 = done by hipBLASLt, 0 = not taken (library absent / shape declined): the caller runs its own kernel.
-// C[M][N] (bf16, row stride ldc) = alpha * A[M][K] B[N][K]^T (+ bias[N] fp32)
-int dvq_blaslt_gemm_nt_try(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                           int64_t ldc, float alpha, const float* bias, hipStream_t stream) {
+// C[M][N] (bf16, row stride ldc) = alpha * A[M][K] op(B) (+ bias[N] fp32);  b_kn == 0: B is [N][K] (NT), 1: B is [K][N] (NN)
+int dvq_blaslt_gemm_try(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                        int64_t ldc, float alpha, const float* bias, int b_kn, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_mu);
     Api& a = api();
     if (!a.ok) return 0;
-    Plan& p = plan_for(a, M, N, K, lda, ldb, ldc, bias != nullptr);
+    Plan& p = plan_for(a, M, N, K, lda, ldb, ldc, bias != nullptr, b_kn != 0);
     if (!p.ok) return 0;
     if (bias != nullptr &&
         a.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS)
@@ -134,6 +137,22 @@ int dvq_blaslt_gemm_nt_try(const void* A, const void* B, void* C, int64_t M, int
     const hipblasStatus_t st = a.matmul(a.handle, p.desc, &alpha, B, p.la, A, p.lb, &beta, C, p.lc, C, p.lc, &p.algo, a.workspace, p.ws,
                                         stream);
     return st == HIPBLAS_STATUS_SUCCESS ? 1 : 0;
+}
+
+int dvq_blaslt_gemm_nt_try(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                           int64_t ldc, float alpha, const float* bias, hipStream_t stream) {
+    return dvq_blaslt_gemm_try(A, B, C, M, N, K, lda, ldb, ldc, alpha, bias, 0, stream);
+}
+
+// C[M][N] = A[M][K] B[K][N], bf16, library path only (the caller transposes B and uses dvq_gemm_nt when this declines)
+extern "C" int dvq_gemm_nn_lib(const void* A, const void* B, void* C, int dtype, int64_t M, int64_t N, int64_t K, int64_t lda,
+                               int64_t ldb, int64_t ldc, dvq_stream_t stream) {
+    DVQ_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, DVQ_EINVAL, "dvq_gemm_nn_lib: bad arguments");
+    DVQ_REQUIRE(dtype == DVQ_BF16 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && N % 8 == 0 && K % 8 == 0, DVQ_ESHAPE,
+                "dvq_gemm_nn_lib: bf16 with 16-byte aligned rows only");
+    if (dvq_blaslt_gemm_try(A, B, C, M, N, K, lda, ldb, ldc, 1.f, nullptr, 1, (hipStream_t)stream) == 1) return DVQ_OK;
+    dvq_set_error("dvq_gemm_nn_lib: hipBLASLt is not available or declined the shape (transpose B and call dvq_gemm_nt)");
+    return DVQ_ESHAPE;
 }
 
 extern "C" int dvq_blaslt_available(void) {

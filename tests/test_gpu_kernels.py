@@ -455,6 +455,36 @@ def test_gemm_nt_wide_kernel(dev, shape):
     assert err < 1e-2, err
 
 
+@pytest.mark.parametrize("shape", [(2048, 1024, 1024), (1304, 512, 1032), (20736, 4096, 1024)], ids=lambda s: "x".join(map(str, s)))
+def test_linear_input_gradient_library_nn(dev, shape):
+    """Linear.bwd's input gradient dx = dy W: the library NN product on W as stored (no transposed weight copy) against the
+    transpose + own-kernel route (DVQ impl 2) and an fp32 product"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Linear, Tape
+    m, n_in, n_out = shape
+    rs = np.random.RandomState(m + n_in)
+    x = bf16_round(rs.standard_normal((m, n_in)).astype(np.float32))
+    dy = bf16_round(rs.standard_normal((m, n_out)).astype(np.float32))
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        lin = Linear(n_in, n_out).to(dev)
+        with torch.no_grad():
+            lin.weight.copy_(lin.weight.to(torch.bfloat16).float())
+        wref = lin.weight.detach().float().cpu()
+        ref = torch.from_numpy(dy)[:, :n_out] @ wref
+        outs = []
+        for impl in (0, 2):
+            with rt.impl_ctx(impl):
+                tape = Tape()
+                lin.fwd(T(x, dev, torch.bfloat16), tape)
+                dyp = torch.zeros(m, lin.out_p, dtype=torch.bfloat16, device=dev)
+                dyp[:, :n_out] = T(dy, dev, torch.bfloat16)
+                outs.append(lin.bwd(dyp, tape).float().cpu())
+    for got in outs:
+        assert float((got - ref).abs().max()) / float(ref.abs().max()) < 1e-2
+    assert float((outs[0] - outs[1]).abs().max()) / float(ref.abs().max()) < 1e-2
+
+
 @pytest.mark.parametrize("shape", [(8, 1024, 1024, 1), (1, 1032, 1024, 0), (32, 4096, 1024, 1), (8, 1024, 4096, 1), (13, 72, 200, 1), (32, 264, 64, 0)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_gemm_nt_skinny_kernel(dev, shape):
