@@ -473,7 +473,10 @@ def norm_swish_conv(norm, conv, x, tape, nname, cname, residual=None):
     """GroupNorm -> swish -> conv3x3 (model.py:119-129).  On shapes the halo kernel takes, the normalised activation
     is never materialised: the conv applies scale/shift + swish to its LDS input tile and also emits the GroupNorm
     statistics of its output for whoever normalises it next."""
-    if rt.fuse_gn_prologue() and conv.fused_ok(x):
+    # with a backward to come the weight-gradient kernel would have to re-apply the transform (measured: as expensive as the
+    # gn_apply pass it saves), so the prologue fusion is used for tape-less forwards only: inference, and the discriminator
+    # step's second autoencoder forward (DVQ_FUSE_GN=1 forces it everywhere)
+    if (rt.fuse_gn_prologue() or (tape is None and rt.fuse_gn_inference())) and conv.fused_ok(x):
         ss = norm.prep(x, _child(tape, nname))
         return conv.fwd(x, _child(tape, cname), residual=residual, gn_ss=ss, want_stats=True)
     a = norm.fwd(x, _child(tape, nname), silu=True)

@@ -74,6 +74,14 @@ def fuse_gn_prologue() -> bool:
     return _fuse_gn
 
 
+_fuse_gn_inference = os.environ.get("DVQ_FUSE_GN_INFERENCE", "1") == "1"
+
+
+def fuse_gn_inference() -> bool:
+    """GroupNorm+swish applied inside the consuming 3x3 conv on forwards that record no tape"""
+    return _fuse_gn_inference
+
+
 def set_fuse_gn_prologue(v: bool):
     global _fuse_gn
     _fuse_gn = bool(v)
