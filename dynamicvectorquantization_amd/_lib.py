@@ -39,6 +39,7 @@ SIGNATURES = {
     "dvq_vq_ema_stats": (i32, [vp, i32, vp, i64, i64, i64, vp, vp]),
     "dvq_vq_ema_apply": (i32, [vp, vp, f32, f32, i64, i64, vp, vp, vp, vp, vp]),
     "dvq_patch_entropy_gate": (i32, [vp, i64, i64, i64, i32, f32, vp, vp, vp]),
+    "dvq_patch_entropy_gate_range": (i32, [vp, i64, i64, i64, i32, f32, f32, f32, vp, vp, vp]),
     "dvq_gn_stats": (i32, [vp, i32, i64, i64, i64, i32, vp, vp]),
     "dvq_gn_apply": (i32, [vp, i32, i64, i64, i64, i32, f32, vp, vp, vp, i32, vp, vp, vp]),
     "dvq_gn_bwd_reduce": (i32, [vp, vp, i32, i64, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]),

@@ -13,7 +13,7 @@ namespace {
 constexpr int NBINS = 32;
 
 __global__ __launch_bounds__(256) void patch_entropy_kernel(const float* __restrict__ img, int64_t B, int64_t H,
-                                                            int64_t W, int patch, float threshold,
+                                                            int64_t W, int patch, float lo, float hi, float threshold,
                                                             float* __restrict__ entropy, int64_t* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int P2 = patch * patch;
@@ -34,9 +34,11 @@ __global__ __launch_bounds__(256) void patch_entropy_kernel(const float* __restr
     __syncthreads();
     {
         const int bin = threadIdx.x & 31, slice = threadIdx.x >> 5;     // 8 slices
-        // torch.linspace(-1,1,32): start + i*step for the lower half, end - (31-i)*step for the upper
-        const float step = 2.0f / 31.0f;
-        const float bv = bin < 16 ? (-1.0f + step * (float)bin) : (1.0f - step * (float)(31 - bin));
+        // torch.linspace(lo,hi,32): start + i*step for the lower half, end - (31-i)*step for the upper
+        // (lo, hi) = (-1, 1) in the model (dqvae_dual_entropy.py:61); (0, 1) in the reference's calibration script
+        // (scripts/tools/calculate_entropy_thresholds.py:74)
+        const float step = (hi - lo) / 31.0f;
+        const float bv = bin < 16 ? (lo + step * (float)bin) : (hi - step * (float)(31 - bin));
         float acc = 0.f;
         for (int t = slice; t < P2; t += 8) {
             const float r = (vals[t] - bv) / 0.01f;
@@ -75,16 +77,27 @@ __global__ __launch_bounds__(256) void patch_entropy_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int dvq_patch_entropy_gate(const float* img, int64_t B, int64_t H, int64_t W, int patch, float threshold,
-                                      float* entropy, int64_t* gate, dvq_stream_t stream) {
+static int entropy_launch(const float* img, int64_t B, int64_t H, int64_t W, int patch, float lo, float hi, float threshold,
+                          float* entropy, int64_t* gate, dvq_stream_t stream) {
     DVQ_REQUIRE(img && entropy, DVQ_EINVAL, "dvq_patch_entropy_gate: null pointer");
     DVQ_REQUIRE(patch > 0 && H % patch == 0 && W % patch == 0 && patch * patch <= 4096, DVQ_ESHAPE,
                 "dvq_patch_entropy_gate: H=%lld W=%lld not divisible by patch=%d", (long long)H, (long long)W, patch);
+    DVQ_REQUIRE(hi > lo, DVQ_EINVAL, "dvq_patch_entropy_gate: empty bin range");
     const int64_t npatch = B * (H / patch) * (W / patch);
     DVQ_REQUIRE(npatch > 0 && npatch < (1ll << 31), DVQ_ESHAPE, "dvq_patch_entropy_gate: bad patch count");
     size_t lds = (size_t)(patch * patch + 8 * NBINS + NBINS) * sizeof(float);
-    patch_entropy_kernel<<<dim3((unsigned)npatch), dim3(256), lds, (hipStream_t)stream>>>(img, B, H, W, patch, threshold,
+    patch_entropy_kernel<<<dim3((unsigned)npatch), dim3(256), lds, (hipStream_t)stream>>>(img, B, H, W, patch, lo, hi, threshold,
                                                                                        entropy, gate);
     DVQ_CHECK_LAUNCH("patch_entropy");
     return DVQ_OK;
+}
+
+extern "C" int dvq_patch_entropy_gate(const float* img, int64_t B, int64_t H, int64_t W, int patch, float threshold,
+                                      float* entropy, int64_t* gate, dvq_stream_t stream) {
+    return entropy_launch(img, B, H, W, patch, -1.0f, 1.0f, threshold, entropy, gate, stream);
+}
+
+extern "C" int dvq_patch_entropy_gate_range(const float* img, int64_t B, int64_t H, int64_t W, int patch, float bin_lo, float bin_hi,
+                                            float threshold, float* entropy, int64_t* gate, dvq_stream_t stream) {
+    return entropy_launch(img, B, H, W, patch, bin_lo, bin_hi, threshold, entropy, gate, stream);
 }

@@ -227,16 +227,20 @@ def vq_ema_apply(stats, restart_rows, decay, eps, cluster_size_ema, embed_ema, w
 # ---------------------------------------------------------------------------------------------
 # entropy / gate
 # ---------------------------------------------------------------------------------------------
-def patch_entropy_gate(img: torch.Tensor, patch: int, threshold: float | None):
-    """img NCHW fp32 [B,3,H,W] -> (entropy [B,h,w] fp32, gate int64 [B,h,w,2] or None)"""
+def patch_entropy_gate(img: torch.Tensor, patch: int, threshold: float | None, bins=(-1.0, 1.0)):
+    """img NCHW fp32 [B,3,H,W] -> (entropy [B,h,w] fp32, gate int64 [B,h,w,2] or None); bins = range of the 32 histogram bins"""
     b, c, h, w = img.shape
     assert c == 3 and img.dtype == torch.float32
     ent = torch.empty(b, h // patch, w // patch, dtype=torch.float32, device=img.device)
     gate = None
     if threshold is not None:
         gate = torch.empty(b, h // patch, w // patch, 2, dtype=torch.int64, device=img.device)
-    check(lib().dvq_patch_entropy_gate(_p(img), b, h, w, patch, float(threshold or 0.0), _p(ent), _p(gate), _s()),
-          "dvq_patch_entropy_gate")
+    if tuple(bins) == (-1.0, 1.0):
+        check(lib().dvq_patch_entropy_gate(_p(img), b, h, w, patch, float(threshold or 0.0), _p(ent), _p(gate), _s()),
+              "dvq_patch_entropy_gate")
+    else:
+        check(lib().dvq_patch_entropy_gate_range(_p(img), b, h, w, patch, float(bins[0]), float(bins[1]), float(threshold or 0.0),
+                                                 _p(ent), _p(gate), _s()), "dvq_patch_entropy_gate_range")
     return ent, gate
 
 

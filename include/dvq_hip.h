@@ -89,6 +89,11 @@ int dvq_vq_ema_apply(const float* stats, const float* restart_rows, float decay,
  * ---------------------------------------------------------------------------------------------- */
 int dvq_patch_entropy_gate(const float* img, int64_t B, int64_t H, int64_t W, int patch, float threshold,
                            float* entropy, int64_t* gate, dvq_stream_t stream);
+/* Same with the 32 histogram bins on linspace(bin_lo, bin_hi, 32) instead of the model's (-1, 1): the reference's threshold
+ * calibration script bins on (0, 1) (scripts/tools/calculate_entropy_thresholds.py:74) -- scripts/tools of this repo can
+ * reproduce either table. */
+int dvq_patch_entropy_gate_range(const float* img, int64_t B, int64_t H, int64_t W, int patch, float bin_lo, float bin_hi,
+                                 float threshold, float* entropy, int64_t* gate, dvq_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm(32, eps) + swish.  Replaces Normalize + nonlinearity

@@ -17,14 +17,15 @@ import numpy as np
 import torch
 
 
-def patch_entropy(x: np.ndarray, patch: int = 16, nbins: int = 32, sigma: float = 0.01) -> np.ndarray:
-    """x [B,3,H,W] fp32 -> entropy [B,H/p,W/p] fp32 (torch-CPU fp32 arithmetic, denormals kept)."""
+def patch_entropy(x: np.ndarray, patch: int = 16, nbins: int = 32, sigma: float = 0.01, bins=(-1.0, 1.0)) -> np.ndarray:
+    """x [B,3,H,W] fp32 -> entropy [B,H/p,W/p] fp32 (torch-CPU fp32 arithmetic, denormals kept).  bins: range of the histogram
+    (the model: (-1, 1); the reference's calibration script scripts/tools/calculate_entropy_thresholds.py:74: (0, 1))."""
     xt = torch.as_tensor(np.asarray(x, dtype=np.float32))
     b, _, h, w = xt.shape
     gh, gw = h // patch, w // patch
     gray = 0.2989 * xt[:, 0] + 0.5870 * xt[:, 1] + 0.1140 * xt[:, 2]            # [B,H,W]
     v = gray.reshape(b, gh, patch, gw, patch).permute(0, 1, 3, 2, 4).reshape(b * gh * gw, patch * patch)
-    bins = torch.linspace(-1, 1, nbins)
+    bins = torch.linspace(float(bins[0]), float(bins[1]), nbins)
     eps = 1e-40
     out = torch.empty(v.shape[0], dtype=torch.float32)
     step = 4096
@@ -51,3 +52,11 @@ def entropy_gate(entropy: np.ndarray, threshold: float) -> np.ndarray:
     t = np.float32(threshold)
     fine = (entropy > t)
     return np.stack([~fine, fine], axis=-1).astype(np.int64)
+
+
+def threshold_table(entropies: np.ndarray) -> dict:
+    """The percentile table of /root/reference/scripts/tools/calculate_entropy_thresholds.py:99-110: sort all patch
+    entropies ascending; entry "i" (i = 1..99) = sorted[(size * i) // 100] as a Python float."""
+    e = np.sort(np.asarray(entropies, dtype=np.float32).reshape(-1))
+    size = e.shape[0]
+    return {str(i + 1): float(e[int((size * (i + 1)) // 100)]) for i in range(99)}
