@@ -63,3 +63,17 @@ def test_script_end_to_end(dev, tmp_path):
     x = synth.half_flat_images(8, 64, patch=16, seed=2021)
     ref = oe.threshold_table(oe.patch_entropy(x, 16).reshape(-1))
     assert max(abs(t[k] - ref[k]) for k in t) < 1e-4
+
+
+def test_visualize_dual_grain_script(dev, tmp_path):
+    """scripts/tools/visualize_dual_grain.py on the shipped entropy-dual YAML (random weights): half-flat images route exactly half
+    of the 16 x 16 cells to the fine grain -> 128 + 4 * 128 = 640 tokens per image"""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "scripts/tools/visualize_dual_grain.py"), "--yaml_path",
+                        "configs/stage1/dqvae-entropy-dual-r05_imagenet.yml", "--synthetic", "4", "--batch_size", "2",
+                        "--image_save_path", str(tmp_path)], capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = dict(ln.split(":") for ln in r.stdout.strip().splitlines() if ":" in ln)
+    assert float(lines["mean"]) == 640.0 and float(lines["variance"]) == 0.0
+    assert int(lines["max"]) == 640 and int(lines["min"]) == 640
+    g = np.load(os.path.join(str(tmp_path), "grain_indices.npy"))
+    assert g.shape == (4, 16, 16) and set(np.unique(g)) == {0, 1}
