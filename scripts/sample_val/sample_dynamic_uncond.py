@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Unconditional sampling with a DQ-Transformer -- the reference's scripts/sample_val/sample_dynamic_uncond.py (:21-118) on the
+HIP path (K/V-cached sampler, captured token-step graphs): same flags, same output layout
+(`<model>_<time>_Num-<n>/[fixed_]TopK-<k>-<kp>_TopP-<p>-<pp>_Temp-<t>_{pickle,image}/samples_(<i>_<total>).pkl`, pickled
+numpy [B,3,H,W] in [0,1]).  --model_path may be omitted (random weights: plumbing / throughput runs); --out_dir overrides
+the directory derived from the checkpoint name.
+
+    python scripts/sample_val/sample_dynamic_uncond.py --yaml_path configs/stage2/uncond_imagenet_p6c18.yml \\
+        --model_path last.ckpt --batch_size 50 --sample_num 5000 --top_k 300 --top_k_pos 1024 --save_image
+"""
+import argparse
+import datetime
+import os
+import pickle
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def save_pickle(fname, data):
+    with open(fname, "wb") as fp:
+        pickle.dump(data, fp, pickle.HIGHEST_PROTOCOL)
+
+
+def save_image_grid(x, path, nrow=8, padding=2):
+    """torchvision.utils.save_image for [N,3,H,W] in [0,1] (zero padding between tiles)"""
+    import numpy as np
+    from PIL import Image
+    n, c, h, w = x.shape
+    cols = min(nrow, n)
+    rows = (n + cols - 1) // cols
+    grid = np.zeros((c, rows * (h + padding) + padding, cols * (w + padding) + padding), dtype=np.float32)
+    for i in range(n):
+        r, q = divmod(i, cols)
+        y0, x0 = padding + r * (h + padding), padding + q * (w + padding)
+        grid[:, y0:y0 + h, x0:x0 + w] = x[i]
+    Image.fromarray((grid.transpose(1, 2, 0) * 255.0 + 0.5).clip(0, 255).astype("uint8")).save(path)
+
+
+def get_parser():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--yaml_path", type=str, default="")
+    parser.add_argument("--model_path", type=str, default="")
+    parser.add_argument("--sample_with_fixed_pos", action="store_true", default=False)
+    parser.add_argument("--save_image", action="store_true", default=False)
+    parser.add_argument("--batch_size", type=int, default=50)
+    parser.add_argument("--temperature", type=float, default=1.0)
+    parser.add_argument("--top_k", type=int, default=300)
+    parser.add_argument("--top_k_pos", type=int, default=1024)
+    parser.add_argument("--top_p", type=float, default=1.0)
+    parser.add_argument("--top_p_pos", type=float, default=1.0)
+    parser.add_argument("--sample_num", type=int, default=5000)
+    parser.add_argument("--out_dir", type=str, default="")
+    parser.add_argument("--dtype", type=str, default="bf16")
+    parser.add_argument("--seed", type=int, default=None)
+    return parser
+
+
+def main():
+    opt, _ = get_parser().parse_known_args()
+    import time
+
+    import torch
+    from dynamicvectorquantization_amd import config as cfg, runtime as rt
+    now = datetime.datetime.utcnow().strftime("%m-%dT%H-%M-%S")
+    base = opt.out_dir or (opt.model_path.replace(".ckpt", "") if opt.model_path else "samples") + "_{}_Num-{}/".format(now, opt.sample_num)
+    tag = "TopK-{}-{}_TopP-{}-{}_Temp-{}".format(opt.top_k, opt.top_k_pos, opt.top_p, opt.top_p_pos, opt.temperature)
+    if opt.sample_with_fixed_pos:
+        tag = "fixed_" + tag
+    dir_img, dir_pkl = os.path.join(base, tag + "_image"), os.path.join(base, tag + "_pickle")
+    if opt.save_image:
+        os.makedirs(dir_img, exist_ok=True)
+    os.makedirs(dir_pkl, exist_ok=True)
+
+    rt.set_compute_dtype(opt.dtype)
+    if opt.seed is not None:
+        torch.manual_seed(opt.seed)
+    model = cfg.instantiate_from_config(cfg.load_yaml(opt.yaml_path).model)
+    if opt.model_path:
+        sd = torch.load(opt.model_path, map_location="cpu")
+        model.load_state_dict(sd["state_dict"] if "state_dict" in sd else sd)
+    model = model.eval().cuda()
+
+    total_batch = (opt.sample_num + opt.batch_size - 1) // opt.batch_size
+    batch_size, steps, t0 = opt.batch_size, 0, time.perf_counter()
+    with torch.no_grad():
+        for i in range(total_batch):
+            if opt.sample_num % opt.batch_size != 0 and i == total_batch - 1:
+                batch_size = opt.sample_num % opt.batch_size
+            x0 = torch.randn(batch_size, device="cuda")
+            c = model.encode_to_c(x0)
+            seqs = model.sample_from_scratch(*c, temperature=opt.temperature, sample=True, top_k=opt.top_k, top_p=opt.top_p,
+                                             top_k_pos=opt.top_k_pos, top_p_pos=opt.top_p_pos, process=False,
+                                             fix_fine_position=opt.sample_with_fixed_pos)
+            steps += batch_size * int(seqs[0].shape[1] + seqs[1].shape[1])
+            img = torch.clamp(model.decode_to_img(*seqs).float() * 0.5 + 0.5, 0, 1).cpu().numpy()
+            if opt.save_image:
+                save_image_grid(img, os.path.join(dir_img, "batch_{}.png".format(i)))
+            save_pickle(os.path.join(dir_pkl, "samples_({}_{}).pkl".format(i, total_batch)), img)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("sampled {} images, {} token steps in {:.2f} s ({:.0f} token-steps/s) -> {}".format(opt.sample_num, steps, dt, steps / dt, dir_pkl))
+
+
+if __name__ == "__main__":
+    main()

@@ -333,3 +333,30 @@ def test_class_conditional_dualformer(dev):
             assert int(cc.max()) <= 513 and int(fc.max()) <= 513 and int(fp.max()) <= 65 and int(cp.max()) <= 17
             img = model.decode_to_img(cc, fc, cp, fp)
             assert bool(torch.isfinite(img).all())
+
+
+def test_sampling_script_end_to_end(dev, tmp_path):
+    """scripts/sample_val/sample_dynamic_uncond.py (the reference's flags and output layout) on the shipped p6c18 YAML with random
+    weights: 3 samples in batches of 2, fixed fine positions -> two pickles of [B,3,256,256] images in [0,1] and a PNG grid"""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "scripts/sample_val/sample_dynamic_uncond.py"), "--yaml_path",
+                        "configs/stage2/uncond_imagenet_p6c18.yml", "--batch_size", "2", "--sample_num", "3", "--top_k", "300",
+                        "--top_k_pos", "100", "--sample_with_fixed_pos", "--save_image", "--seed", "3", "--out_dir", str(tmp_path)],
+                       capture_output=True, text=True, timeout=900, cwd=repo)
+    assert r.returncode == 0, r.stderr[-3000:]
+    tag = "fixed_TopK-300-100_TopP-1.0-1.0_Temp-1.0"
+    pk = sorted(os.listdir(os.path.join(str(tmp_path), tag + "_pickle")))
+    assert pk == ["samples_(0_2).pkl", "samples_(1_2).pkl"]
+    shapes = []
+    for f in pk:
+        with open(os.path.join(str(tmp_path), tag + "_pickle", f), "rb") as fp:
+            a = pickle.load(fp)
+        assert a.dtype == np.float32 and a.min() >= 0.0 and a.max() <= 1.0 and np.isfinite(a).all()
+        shapes.append(a.shape)
+    assert shapes == [(2, 3, 256, 256), (1, 3, 256, 256)]
+    assert sorted(os.listdir(os.path.join(str(tmp_path), tag + "_image"))) == ["batch_0.png", "batch_1.png"]
+    assert "token-steps/s" in r.stdout
