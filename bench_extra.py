@@ -22,8 +22,56 @@ sys.path.insert(0, REPO)
 import torch  # noqa: E402
 
 
+def _stage2_cpu_worker(threads, lc, lf):
+    """child process: the oracle's StackGPT teacher-forced step (forward + losses + backward, torch CPU) at bs = 1 on `threads`
+    host threads; random-init weights of the p6c18 architecture, random tokens of the benchmark's sequence lengths"""
+    torch.set_num_threads(threads)
+    from dynamicvectorquantization_amd import config as cfg
+    from oracle import stackgpt as osg
+    c = cfg.load_yaml(os.path.join(REPO, "configs/stage2/uncond_imagenet_p6c18.yml"))
+    tp = c.model.params.transformer_config
+    gpt = cfg.instantiate_from_config(tp)                       # parameters only (CPU tensors); the compute below is the oracle's
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in gpt.state_dict().items() if not k.endswith(".mask")}
+    n_head = int(tp.params.n_head)
+    g = torch.Generator().manual_seed(0)
+    ri = lambda hi, n: torch.randint(0, hi, (1, n), generator=g)
+    cc, fc, cp, fp = ri(1024, lc), ri(1024, lf), ri(256, lc), ri(1024, lf)
+    cs, fs = torch.zeros(1, lc, dtype=torch.long), torch.ones(1, lf, dtype=torch.long)
+    content_target = torch.cat([cc, fc], dim=1)[:, 1:]
+    t0 = time.time()
+    n = 0
+    while True:
+        out = osg.forward(sd, n_head, cc, fc, cp, fp, cs, fs, content_target=content_target, coarse_position_target=cp[:, 1:],
+                          fine_position_target=fp)
+        (out["position_loss"] + out["content_loss"]).backward()
+        for v in sd.values():
+            v.grad = None
+        n += 1
+        if time.time() - t0 > 15.0 or n >= 3:
+            break
+    print(json.dumps({"n": n, "sec": time.time() - t0, "tokens": lc + lf - 1}), flush=True)
+
+
+def stage2_cpu_baseline(lc, lf, timeout_s=240):
+    import subprocess
+    threads = max(1, min(16, os.cpu_count() or 1))
+    cmd = [sys.executable, os.path.abspath(__file__), "--stage2-cpu-worker", str(threads), str(lc), str(lf)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"value": round(rec["n"] * rec["tokens"] / rec["sec"], 2), "unit": "tokens/sec", "cores": threads, "kind": "port",
+                "sample": f"{rec['n']} teacher-forced step(s) (forward + losses + backward) of the torch-CPU oracle StackGPT p6c18 at bs=1, "
+                          f"T={rec['tokens']}, {threads} threads of {os.cpu_count()} host cores, {rec['sec']:.1f} s"}
+    except Exception as e:                                      # the GPU numbers must not depend on the host baseline
+        return {"value": None, "unit": "tokens/sec", "cores": threads, "kind": "port", "sample": f"failed: {type(e).__name__}"}
+
+
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--stage2-cpu-worker":
+        return _stage2_cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
     ap = argparse.ArgumentParser()
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", required=True, choices=["triple", "stage2", "sampling"])
     ap.add_argument("--bs", type=int, default=None)
     ap.add_argument("--steps", type=int, default=4)
@@ -89,6 +137,8 @@ def main():
                               "transformer_params": n_par, "dropout": 0.1},
                    "mfma_frac_est": round(flops * args.steps / dt / 2.5e15, 4),
                    "steps": args.steps, "warmup": args.warmup, "dtype": "bf16", "data": "synthetic"}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = stage2_cpu_baseline(int(z["coarse_content"].shape[1]), int(z["fine_content"].shape[1]))
         else:
             bs = args.bs or 8
             model.eval()
