@@ -267,28 +267,64 @@ __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __
         __syncthreads();
         double best = __builtin_inf();
         int bi = 0x7fffffff;
-        for (int64_t k0 = (int64_t)wave * 8; k0 < K; k0 += NW * 8) {
-            const int64_t k = k0 + grp;
-            double acc = 0.0;
-            if (k < K) {
-                for (int64_t d = sub; d < D; d += 8) {          // generic D; 8 lanes cover 8 consecutive dims
-                    double t = xs[d] - (double)cb[k * D + d];
-                    acc = fma(t, t, acc);
+        int first_combine = 8;
+        if ((D & 15) == 0) {
+            // two lanes per code (float4 loads of alternating 4-dim chunks), 32 codes per wave and pass: K = 1024 is two passes
+            // of independent loads per lane instead of eight short ones -- the kernel is latency-, not flop-bound
+            const int g2 = lane >> 1, s2 = lane & 1;
+            first_combine = 2;
+            for (int64_t k0 = (int64_t)wave * 32; k0 < K; k0 += NW * 32) {
+                const int64_t k = k0 + g2;
+                double a0 = 0.0, a1 = 0.0;
+                if (k < K) {
+                    const float* cr = cb + k * D + 4 * s2;
+                    for (int64_t d = 0; d < D; d += 16) {           // this lane: dims d + 4 s2 .. +3 and d + 8 + 4 s2 .. +3
+                        const float4 c0 = *reinterpret_cast<const float4*>(cr + d);
+                        const float4 c1 = *reinterpret_cast<const float4*>(cr + d + 8);
+                        const double* xa = xs + d + 4 * s2;
+                        double t;
+                        t = xa[0] - (double)c0.x; a0 = fma(t, t, a0);
+                        t = xa[1] - (double)c0.y; a0 = fma(t, t, a0);
+                        t = xa[2] - (double)c0.z; a0 = fma(t, t, a0);
+                        t = xa[3] - (double)c0.w; a0 = fma(t, t, a0);
+                        t = xa[8] - (double)c1.x; a1 = fma(t, t, a1);
+                        t = xa[9] - (double)c1.y; a1 = fma(t, t, a1);
+                        t = xa[10] - (double)c1.z; a1 = fma(t, t, a1);
+                        t = xa[11] - (double)c1.w; a1 = fma(t, t, a1);
+                    }
+                } else {
+                    a0 = __builtin_inf();
                 }
-            } else {
-                acc = __builtin_inf();
+                double acc = a0 + a1;
+                acc += __shfl_xor(acc, 1, 64);
+                if (acc < best) {    // k increasing per lane pair -> first minimum kept
+                    best = acc;
+                    bi = (int)k;
+                }
             }
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 4, 64);
-            if (acc < best) {    // k increasing per lane group -> first minimum kept
-                best = acc;
-                bi = (int)k;
+        } else {
+            for (int64_t k0 = (int64_t)wave * 8; k0 < K; k0 += NW * 8) {
+                const int64_t k = k0 + grp;
+                double acc = 0.0;
+                if (k < K) {
+                    for (int64_t d = sub; d < D; d += 8) {          // generic D; 8 lanes cover 8 consecutive dims
+                        double t = xs[d] - (double)cb[k * D + d];
+                        acc = fma(t, t, acc);
+                    }
+                } else {
+                    acc = __builtin_inf();
+                }
+                acc += __shfl_xor(acc, 1, 64);
+                acc += __shfl_xor(acc, 2, 64);
+                acc += __shfl_xor(acc, 4, 64);
+                if (acc < best) {    // k increasing per lane group -> first minimum kept
+                    best = acc;
+                    bi = (int)k;
+                }
             }
         }
-        // combine the 8 groups of the wave (lexicographic on (distance, index))
-#pragma unroll
-        for (int o = 8; o < 64; o <<= 1) {
+        // combine the code groups of the wave (lexicographic on (distance, index))
+        for (int o = first_combine; o < 64; o <<= 1) {
             double ob = __shfl_xor(best, o, 64);
             int oi = __shfl_xor(bi, o, 64);
             if (ob < best || (ob == best && oi < bi)) {
@@ -497,7 +533,7 @@ static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_
         DVQ_CHECK_LAUNCH("vq_flag_all");
     }
     size_t lds = (size_t)D * 8 + 16 * 8 + 16 * 4;
-    int64_t blocks = use_mfma ? 2048 : (N < 65535 ? N : 65535);
+    int64_t blocks = use_mfma ? 512 : (N < 65535 ? N : 65535);      // flagged rows are ~0.5 %: grid-stride over the list
     vq_rerank_fp64_kernel<XT><<<dim3((unsigned)blocks), dim3(RR_THREADS), lds, s>>>(x, cb, K, D, idx, ws);
     DVQ_CHECK_LAUNCH("vq_rerank_fp64");
     return DVQ_OK;
