@@ -266,9 +266,37 @@ class Trainer:
             if lo == 0 and 0 < hi < n:
                 m._grad_hook = lambda tag: gb.reduce_range(hi, n) if tag == "decoder_side_done" else None
 
+    # ---- checkpoint / resume (train.py:153-185, 270 + `-r`: Lightning's last.ckpt carries the model state_dict, the optimizer
+    # and scheduler states and the global step; same top-level keys here so that `state_dict` stays loadable by the reference) ----
+    def state_dict(self):
+        opt_states = []
+        for o in self.opts:
+            st = o._fstate
+            opt_states.append({"step": int(st["step"]), "exp_avg": st["m"].detach().cpu(), "exp_avg_sq": st["v"].detach().cpu()})
+        return {"state_dict": self.model.state_dict(), "global_step": int(self.model.global_step),
+                "optimizer_states": opt_states, "lr_schedulers": [s["scheduler"].state_dict() for s in self.scheds]}
+
+    @torch.no_grad()
+    def load_state_dict(self, ckpt, strict=True):
+        """resume: parameters are written THROUGH the flat-buffer views (copy_), the packed compute-dtype copies are
+        invalidated, Adam moments / step counts / LambdaLR positions restored when the checkpoint has them"""
+        self.model.load_state_dict(ckpt["state_dict"], strict=strict)
+        for b in self.buckets:
+            b.fp.attach_grads()
+        rt.bump_weights_epoch()
+        for o, st in zip(self.opts, ckpt.get("optimizer_states", [])):
+            o._fstate["step"] = int(st["step"])
+            o._fstate["m"].copy_(st["exp_avg"].to(o._fstate["m"].device))
+            o._fstate["v"].copy_(st["exp_avg_sq"].to(o._fstate["v"].device))
+        for s, st in zip(self.scheds, ckpt.get("lr_schedulers", [])):
+            s["scheduler"].load_state_dict(st)
+            for g, lr in zip(s["scheduler"].optimizer.param_groups, s["scheduler"].get_last_lr()):
+                g["lr"] = lr
+        self.model.global_step = int(ckpt.get("global_step", 0))
+
     def fit(self, batch_fn):
         self.model.train()
-        for step in range(self.max_steps):
+        for step in range(int(self.model.global_step), self.max_steps):
             losses = self.train_step(batch_fn(step), step)
             if self.log_every and step % self.log_every == 0:
                 print(f"step {step}: " + " ".join(f"{float(l):.5f}" for l in losses), flush=True)

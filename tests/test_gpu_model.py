@@ -151,3 +151,44 @@ def test_packed_weights_follow_the_optimizer(dev):
                 assert torch.equal(ent["bias"][: m.out_channels], m.bias.detach()), name
                 checked += 1
         assert checked >= 1
+
+
+def test_trainer_checkpoint_resume(dev):
+    """Trainer.state_dict / load_state_dict (train.py -r): a fresh process state restored from the checkpoint continues the run --
+    same parameters, Adam moments, LR-schedule position, step counter, VQ-EMA and BatchNorm buffers -> same next losses"""
+    import copy
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.trainer import Trainer
+
+    def make(seed):
+        torch.manual_seed(seed)
+        model, _ = build("small", dev, "spread", loss="full")
+        model.learning_rate, model.training_steps, model.steps_per_epoch = 1e-3, 100, 10
+        model.train()
+        return model, Trainer(model, max_steps=8)
+
+    xs = [torch.from_numpy(synth.half_flat_images(2, 64, seed=20 + i)).to(dev) for i in range(4)]
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        model, tr = make(0)
+        for i in range(2):
+            tr.train_step({"image": xs[i]}, i)
+        ckpt = copy.deepcopy(tr.state_dict())
+        assert ckpt["global_step"] == 2 and len(ckpt["optimizer_states"]) == 2 and ckpt["optimizer_states"][0]["step"] == 2
+        ref_losses = [[float(l) for l in tr.train_step({"image": xs[i]}, i)] for i in (2, 3)]
+        ref_w = model.decoder.conv_out.weight.detach().float().cpu().clone()
+        ref_lr = [g["lr"] for o in tr.opts for g in o.param_groups]
+
+        model2, tr2 = make(123)                                   # different init: everything must come from the checkpoint
+        with torch.no_grad():
+            for p_ in model2.parameters():
+                p_.add_(0.01)
+        tr2.load_state_dict(ckpt)
+        assert model2.global_step == 2
+        for a, b in zip(model.state_dict().keys(), model2.state_dict().keys()):
+            assert a == b
+        got_losses = [[float(l) for l in tr2.train_step({"image": xs[i]}, i)] for i in (2, 3)]
+        got_w = model2.decoder.conv_out.weight.detach().float().cpu()
+        got_lr = [g["lr"] for o in tr2.opts for g in o.param_groups]
+    assert got_lr == ref_lr
+    np.testing.assert_allclose(np.array(got_losses), np.array(ref_losses), rtol=2e-2, atol=2e-3)
+    assert float((got_w - ref_w).abs().max()) / float(ref_w.abs().max()) < 2e-2

@@ -103,12 +103,17 @@ def run(rank, world, opt, unknown):
             batch["class_label"] = torch.randint(0, n_classes, (bs,), generator=g).to(dev)
         return batch
 
+    if opt.resume:                                   # -r <logdir | checkpoint> (train.py:73-89 of the reference)
+        path = opt.resume if os.path.isfile(opt.resume) else os.path.join(opt.resume, "checkpoints", "last.ckpt")
+        trainer.load_state_dict(torch.load(path, map_location="cpu"))
+        if rank == 0:
+            print(f"resumed from {path} at global step {model.global_step}")
     trainer.fit(batch_fn)
     if rank == 0:
         now = datetime.datetime.now().strftime("%Y-%m-%dT%H-%M-%S")
         ckptdir = os.path.join(opt.logdir, now + ("_" + opt.name if opt.name else "") + opt.postfix, "checkpoints")
         os.makedirs(ckptdir, exist_ok=True)
-        torch.save({"state_dict": model.state_dict(), "global_step": model.global_step}, os.path.join(ckptdir, "last.ckpt"))
+        torch.save(trainer.state_dict(), os.path.join(ckptdir, "last.ckpt"))
         print("saved", os.path.join(ckptdir, "last.ckpt"))
     if world > 1:
         dist.barrier()
