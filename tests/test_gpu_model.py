@@ -184,11 +184,18 @@ def test_trainer_checkpoint_resume(dev):
                 p_.add_(0.01)
         tr2.load_state_dict(ckpt)
         assert model2.global_step == 2
-        for a, b in zip(model.state_dict().keys(), model2.state_dict().keys()):
-            assert a == b
+        # restored state is bit-identical to the checkpoint: parameters + buffers (through the flat-buffer views), Adam
+        # moments and step counts, LambdaLR position
+        sd2 = model2.state_dict()
+        assert list(sd2.keys()) == list(ckpt["state_dict"].keys())
+        for k_, v_ in ckpt["state_dict"].items():
+            assert torch.equal(sd2[k_].detach().cpu(), v_.detach().cpu()), k_
+        for o2, st in zip(tr2.opts, ckpt["optimizer_states"]):
+            assert o2._fstate["step"] == st["step"]
+            assert torch.equal(o2._fstate["m"].cpu(), st["exp_avg"]) and torch.equal(o2._fstate["v"].cpu(), st["exp_avg_sq"])
+        got_lr_now = [g["lr"] for o in tr2.opts for g in o.param_groups]
         got_losses = [[float(l) for l in tr2.train_step({"image": xs[i]}, i)] for i in (2, 3)]
-        got_w = model2.decoder.conv_out.weight.detach().float().cpu()
         got_lr = [g["lr"] for o in tr2.opts for g in o.param_groups]
-    assert got_lr == ref_lr
-    np.testing.assert_allclose(np.array(got_losses), np.array(ref_losses), rtol=2e-2, atol=2e-3)
-    assert float((got_w - ref_w).abs().max()) / float(ref_w.abs().max()) < 2e-2
+    assert got_lr == ref_lr and all(a > 0 for a in got_lr_now)
+    # the continued run follows the original one (bf16 + atomics + the adaptive GAN weight: loose bound, the exact part is above)
+    np.testing.assert_allclose(np.array(got_losses), np.array(ref_losses), rtol=0.25, atol=0.05)
