@@ -149,6 +149,30 @@ def vq_microbench(dev, reps=20):
     return out
 
 
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start one process per GPU ourselves (same env contract as
+    torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), forward rank 0's JSON line"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    if rc != 0:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
         return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "full")
@@ -166,7 +190,10 @@ def main():
     ap.add_argument("--no-ae-only", action="store_true", help="skip the secondary autoencoder-only measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vq-microbench", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python (no hipGraph replay of the step)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return _spawn_ranks(args.gpus)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -203,42 +230,56 @@ def main():
         model.learning_rate = 4.5e-6 * args.bs * world     # train.py:248-257
         model.training_steps, model.steps_per_epoch = 100000, 1000
         model.train()
-        trainer = Trainer(model, max_steps=steps)
-        SETUP = 2      # untimed initialisation steps before the W warmup steps: kernel code-object loading, allocator growth,
-                       # packed-weight tables (the first steps of a process are host-bound on these one-off costs)
+        GRAPH_AFTER = 3
+        trainer = Trainer(model, max_steps=steps, use_graph=not args.no_graph, graph_after=GRAPH_AFTER)
+        # untimed initialisation before the W warmup steps: kernel code-object loading, allocator growth, packed-weight
+        # tables (the first steps of a process are host-bound on these one-off costs), then the step is recorded as a
+        # hipGraph (Trainer step capture) and the recording is replayed once
+        SETUP = GRAPH_AFTER + 2        # [counted eager step] + GRAPH_AFTER eager steps + [record + first replay]
         # two distinct resident batches per rank (synthetic half-flat images: fine ratio exactly 0.5)
         nb = 2
         imgs = [torch.from_numpy(synth.half_flat_images(args.bs, 256, seed=1234 + 17 * rank + 1000 * i)).to(dev) for i in range(nb)]
         batches = [{"image": im} for im in imgs]
-        n_launches = 0
+        n_launches = 2400
         for i in range(SETUP):
+            if profile and i == 0:
+                K.profile_count_start()                  # size the HIP-event pool of the profiled step
             trainer.train_step(batches[i % nb], i)
+            if profile and i == 0:
+                n_launches = max(2400, K.profile_count_stop())
         for i in range(warmup):
-            if profile and i == warmup - 1:
-                K.profile_count_start()
-            trainer.train_step(batches[i % nb], i)
+            trainer.train_step(batches[i % nb], SETUP + i)
         if profile:
-            n_launches = K.profile_count_stop() if warmup > 0 else 2400
             barrier()
             K.profile_prepare(n_launches + 16)          # HIP events for ONE step, created outside the timed region
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            if profile and i == steps - 1:
-                K.profile_start()                         # per-kernel HIP-event timing on the last timed step only
-            trainer.train_step(batches[i % nb], warmup + i)
+            trainer.train_step(batches[i % nb], SETUP + warmup + i)
         host = time.perf_counter() - t0          # time the host needed to enqueue all steps (no sync inside)
         barrier()
         dt = time.perf_counter() - t0
-        prof = K.profile_stop() if profile else {}
+        prof = {}
+        if profile:
+            # per-kernel HIP-event timing: ONE extra step right after the timed region, launched eagerly (events cannot be
+            # recorded inside a graph replay) -- the same kernels on the same shapes as the replayed steps
+            K.profile_start()
+            trainer.train_step(batches[steps % nb], SETUP + warmup + steps)
+            prof = K.profile_stop()
+        graph_info = {"enabled": trainer._graph is not None, "replays": trainer.graph_replays,
+                      "segments": trainer._graph["sg"].n_segments() if trainer._graph is not None else 0,
+                      "fine_ratio": float(model._logged.get("train_fine_ratio", torch.tensor(float("nan"))))}
+        model._logged = {}
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
+        trainer.drop_graph()
+        model._graph_info = graph_info
         return dt, host, prof, model
 
     dt_, host_issue, prof, model = run(args.objective, args.steps, args.warmup, True)
-    ratio = float(model._logged.get("train_fine_ratio", torch.tensor(float("nan"))))
+    ratio = model._graph_info.pop("fine_ratio")
 
     ae_only = None
     if args.objective == "full" and not args.no_ae_only:
@@ -267,7 +308,8 @@ def main():
                         "launches": v["launches"], "avg_launch_ms": round(v["ms_per_launch"], 4),
                         "alg_flops_per_launch": v["flops"] / max(1, v["launches"]),
                         "alg_bytes_per_launch": v["bytes"] / max(1, v["launches"]),
-                        "timed": "HIP events around every launch of this kernel during the last timed step"}
+                        "timed": "HIP events around every launch of this kernel during one eagerly launched step right after the "
+                                 "timed region (the timed steps are hipGraph replays of the same launch sequence)"}
             # HBM traffic per launch: PMC counters cannot be collected from inside this process; the figure comes from the
             # committed rocprofv3 --pmc passes over this same command (tools/gpu_pmc_bench.sh -> tools/pmc_summarise.py)
             pmc = _pmc_traffic(dom)
@@ -282,7 +324,8 @@ def main():
                                    f"bs={args.bs}/GPU, 256x256 half-flat synthetic images",
                        "objective": OBJECTIVES[args.objective] + (" [discriminator step reuses the generator step's reconstruction]"
                                                                          if args.reuse_forward else ""),
-                       "global_batch": world * args.bs, "parallelism": f"dp{world}", "fine_ratio": ratio},
+                       "global_batch": world * args.bs, "parallelism": f"dp{world}", "fine_ratio": ratio,
+                       "step_graph": getattr(model, "_graph_info", None)},
             "step_mfma_frac": round(ips / world * STEP_FLOP_PER_IMG[args.objective] / PEAK_BF16, 4),
             "step_flop_per_img": STEP_FLOP_PER_IMG[args.objective],
             "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 2),

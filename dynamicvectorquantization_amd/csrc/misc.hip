@@ -379,6 +379,65 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Adam / AdamW whose hyper-parameters are READ FROM DEVICE MEMORY: hyper = {lr / bias_corr1, beta1, beta2, eps,
+// 1 / sqrt(bias_corr2), 1 - lr * weight_decay, -, -}.  No per-step launch argument changes, so a training step captured as a
+// hipGraph replays with the schedule's current learning rate (the host rewrites `hyper` before the replay, dvq_set_f32x8).
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                       const float* __restrict__ hyper) {
+    const float step_size = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], inv_sqrt_bc2 = hyper[4],
+                decay_mul = hyper[5];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float gv = g[e];
+        const float mm = beta1 * m[e] + (1.f - beta1) * gv;
+        const float vv = beta2 * v[e] + (1.f - beta2) * gv * gv;
+        m[e] = mm;
+        v[e] = vv;
+        p[e] = p[e] * decay_mul - step_size * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+    }
+}
+
+struct F32x8 {
+    float v[8];
+};
+
+__global__ void set_f32x8_kernel(float* __restrict__ dst, F32x8 vals) {
+    if (threadIdx.x < 8) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+
+// k distinct pseudo-random row indices in [0, n): the first k values of a keyed permutation of [0, n) -- a 4-round balanced
+// Feistel network on the next even number of bits, cycle-walked back into range (a bijection on [0, n)).  The key lives in
+// device memory and is advanced by a second kernel, so the draw is graph-replay safe (no host RNG state in the launch).
+__device__ __forceinline__ uint64_t feistel_perm(uint64_t v, int hbits, uint64_t key) {
+    const uint32_t mask = (hbits >= 32) ? 0xffffffffu : ((1u << hbits) - 1u);
+    uint32_t l = (uint32_t)(v >> hbits) & mask, r = (uint32_t)v & mask;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t k = (uint32_t)(key >> (16 * i)) ^ (uint32_t)(key >> 32) ^ (0x9E3779B9u * (i + 1));
+        const uint32_t f = dvq_hash32(r ^ k) & mask;
+        const uint32_t nl = r;
+        r = l ^ f;
+        l = nl;
+    }
+    return ((uint64_t)l << hbits) | r;
+}
+
+__global__ __launch_bounds__(256) void sample_rows_kernel(int64_t* __restrict__ out, int64_t k, int64_t n, int hbits,
+                                                          const uint64_t* __restrict__ state) {
+    const uint64_t key = state[0] * 0x9E3779B97F4A7C15ull + state[1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < k; i += (int64_t)gridDim.x * 256) {
+        uint64_t v = (uint64_t)i;
+        do {
+            v = feistel_perm(v, hbits, key);
+        } while (v >= (uint64_t)n);
+        out[i] = (int64_t)v;
+    }
+}
+
+__global__ void bump_state_kernel(uint64_t* state) {
+    if (threadIdx.x == 0) state[1] += 1;
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, float v, int64_t n) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) p[e] = v;
 }
@@ -617,6 +676,33 @@ int dvq_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                                                                              beta2, eps, (float)(1.0 / sqrt(bc2)),
                                                                              1.f - lr * weight_decay);
     DVQ_CHECK_LAUNCH("adamw");
+    return DVQ_OK;
+}
+
+int dvq_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, dvq_stream_t stream) {
+    DVQ_REQUIRE(p && g && m && v && hyper && n > 0, DVQ_EINVAL, "dvq_adamw_dev: bad arguments");
+    adam_dev_kernel<<<dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper);
+    DVQ_CHECK_LAUNCH("adamw_dev");
+    return DVQ_OK;
+}
+
+int dvq_set_f32x8(float* dst, float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                  dvq_stream_t stream) {
+    DVQ_REQUIRE(dst != nullptr, DVQ_EINVAL, "dvq_set_f32x8: null pointer");
+    F32x8 vals{{v0, v1, v2, v3, v4, v5, v6, v7}};
+    set_f32x8_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(dst, vals);
+    DVQ_CHECK_LAUNCH("set_f32x8");
+    return DVQ_OK;
+}
+
+int dvq_sample_rows(int64_t* out, int64_t k, int64_t n, uint64_t* state, dvq_stream_t stream) {
+    DVQ_REQUIRE(out && state && k > 0 && n >= k && n < (1ll << 62), DVQ_EINVAL, "dvq_sample_rows: need 0 < k <= n");
+    int bits = 2;
+    while (bits < 62 && (1ll << bits) < n) bits += 2;          // even bit count >= log2(n): at most 4x over-range -> <= 4 walks on average
+    sample_rows_kernel<<<dim3(nblocks(k, 256)), dim3(256), 0, (hipStream_t)stream>>>(out, k, n, bits / 2, state);
+    DVQ_CHECK_LAUNCH("sample_rows");
+    bump_state_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(state);
+    DVQ_CHECK_LAUNCH("sample_rows_bump");
     return DVQ_OK;
 }
 

@@ -464,6 +464,7 @@ class DualGrainVQModel(nn.Module):
 
     USES_ENTROPY = True          # dqvae_dual_entropy: per-patch entropy feeds the fixed router; the *_feat models have none
     N_GRAINS = 2
+    GRAPH_SAFE = True            # the training step has a static launch sequence: the Trainer may record it as a hipGraph
 
     def __init__(self, encoderconfig, decoderconfig, lossconfig, vqconfig, quant_before_dim, quant_after_dim,
                  quant_sample_temperature=0., ckpt_path=None, ignore_keys=[], image_key="image", monitor=None,
@@ -679,6 +680,17 @@ class DualGrainVQModel(nn.Module):
 
     def get_last_layer(self):
         return self.decoder.conv_out.weight
+
+    def graph_signature(self):
+        """host-side state that decides which kernels a training step launches (Trainer step capture); None = do not capture"""
+        cb = getattr(self.quantize, "codebook", None)
+        if getattr(cb, "restart_perm", None) is not None or getattr(self.encoder, "gumbel_exponential", None) is not None:
+            return None                      # injected test noise lives on the host
+        step = self.current_epoch if self.loss_with_epoch else self.global_step
+        disc_on = None
+        if hasattr(self.loss, "discriminator_iter_start"):
+            disc_on = bool(step >= self.loss.discriminator_iter_start)
+        return (disc_on, bool(self.reuse_generator_forward), self.feature_routed, self.N_GRAINS)
 
     def get_code_emb_with_depth(self, code):
         return self.quantize.get_codebook_entry(code)

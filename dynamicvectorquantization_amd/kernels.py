@@ -77,6 +77,11 @@ _pool = []            # pre-created timing events (hipEventCreate is slow on som
 _count = None         # launch counter (sizing pass)
 
 
+def profiling_active() -> bool:
+    """True while per-launch HIP-event timing or launch counting is on (such a step must run eagerly, not as a graph replay)"""
+    return _prof is not None or _count is not None
+
+
 def profile_count_start():
     """count timed launches without recording anything (used to size the event pool)"""
     global _count
@@ -771,6 +776,24 @@ def rows_dev(x, hidden, t_dev, store):
 
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     check(lib().dvq_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, _s()), "dvq_adamw")
+
+
+def adamw_dev(p, g, m, v, hyper):
+    """AdamW step with the hyper-parameters read from device memory (hyper fp32 [8], see include/dvq_hip.h)"""
+    check(lib().dvq_adamw_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _s()), "dvq_adamw_dev")
+
+
+def set_f32x8(dst, values):
+    """dst[0:8] <- values (by-value launch arguments: safe to call with the host running many steps ahead)"""
+    vals = [float(x) for x in values] + [0.0] * (8 - len(values))
+    check(lib().dvq_set_f32x8(_p(dst), *vals, _s()), "dvq_set_f32x8")
+
+
+def sample_rows(k, n, state):
+    """k distinct pseudo-random indices in [0, n) (device-resident RNG state uint64-as-int64 [2]: replayable in a hipGraph)"""
+    out = torch.empty(k, dtype=torch.int64, device=state.device)
+    check(lib().dvq_sample_rows(_p(out), k, n, _p(state), _s()), "dvq_sample_rows")
+    return out
 
 
 def attn_decode(q, kcache, vcache, n_head, t, scale):

@@ -7,10 +7,12 @@ padding row, requires_grad False under EMA) and return signatures.  Differences 
   * the argmin is the mathematically exact one (oracle/vq.py), lowest index on ties;
   * the two data-parallel all-reduces (:86-88) are ONE all-reduce of a fused [K, D+1] buffer, and the
     restart broadcast (:99-100) is kept (rank 0's rows) -- see SURVEY.md section 5/8e;
-  * RNG: the restart candidate rows come from torch.randperm on the device generator unless
-    `restart_perm` is injected (tests), since the reference's CPU/CUDA streams cannot be reproduced.
+  * RNG: the restart candidate rows are k distinct rows drawn by dvq_sample_rows (keyed Feistel permutation, state in
+    device memory) unless `restart_perm` is injected (tests): the reference's randperm stream cannot be reproduced.
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 import torch
@@ -20,6 +22,8 @@ import torch.nn as nn
 from . import kernels as K
 from . import runtime as rt
 from .layers import Tape, to_nchw, to_nhwc
+
+_FORCE_DP = os.environ.get("DVQ_FORCE_DP", "0") == "1"     # exchange even in a one-rank group (single-GPU test of the DP path)
 
 
 class VQEmbedding(nn.Embedding):
@@ -72,6 +76,15 @@ class VQEmbedding(nn.Embedding):
         return idx.reshape(inputs.shape[:-1])
 
     # -- EMA ------------------------------------------------------------------------------------------
+    def _rng(self, device):
+        """device-resident {seed, counter} of the restart-row sampler (seeded from torch's seed; the counter advances on the
+        stream, so the draw needs no host state and replays inside a captured training step)"""
+        st = getattr(self, "_rng_state", None)
+        if st is None or st.device != device:
+            st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64).to(device)
+            self._rng_state = st
+        return st
+
     @torch.no_grad()
     def _update_buffers(self, vectors, idxs):
         """quantize2_mask.py:66-105.  vectors [N,D] (compute dtype), idxs [N]."""
@@ -93,7 +106,7 @@ class VQEmbedding(nn.Embedding):
             if self.restart_perm is not None:
                 perm = self.restart_perm.to(vectors.device)[:k]
             else:
-                perm = torch.randperm(n, device=vectors.device)[:k]
+                perm = K.sample_rows(k, n, self._rng(vectors.device))     # = randperm(n)[:k]: k distinct rows
             restart = K.vq_embed(src.contiguous(), perm)
         stats, restart = self._exchange(stats, restart)
         K.vq_ema_apply(stats, restart, self.decay, self.eps, self.cluster_size_ema, self.embed_ema, self.weight.data)
@@ -104,10 +117,12 @@ class VQEmbedding(nn.Embedding):
         """Data-parallel step of the EMA update: ONE all-reduce(SUM) of the fused [K, D+1] statistics
         (reference: two, quantize2_mask.py:86-88) and the rank-0 broadcast of the restart rows (:99-100).
         Device-agnostic (tested on CPU tensors over gloo)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-            if restart is not None:
-                dist.broadcast(restart, 0)
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_DP):
+            def exchange():          # eager even inside a captured training step (runtime.graph_break)
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+                if restart is not None:
+                    dist.broadcast(restart, 0)
+            rt.graph_break(exchange)
         return stats, restart
 
     def forward(self, inputs):

@@ -105,3 +105,94 @@ def impl_ctx(v: int):
         yield
     finally:
         set_impl(old)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Training-step capture (hipGraph).  The step's launch sequence is static (fixed shapes, no host-side data dependence), so
+# the Trainer records it once and replays it: ~2400 ctypes launches per step become a handful of graph launches.  The
+# captured sequence is cut at every point where something must run eagerly (RCCL collectives): `graph_break(fn)` ends the
+# current capture segment, runs `fn` now and remembers it, then starts the next segment -- on replay the segments and
+# the remembered callables run in recorded order.  Outside a capture `graph_break(fn)` is just `fn()`.
+# ---------------------------------------------------------------------------------------------------------------
+_capture = None
+
+
+def capturing() -> bool:
+    return _capture is not None
+
+
+def graph_break(fn):
+    if _capture is None:
+        return fn()
+    return _capture.brk(fn)
+
+
+class StepGraph:
+    """A recorded training step: hipGraph segments interleaved with eager callables, sharing one private memory pool
+    (segments are replayed in capture order, never concurrently, so blocks freed in one segment may be reused by the next)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.items = []                       # ("graph", torch.cuda.CUDAGraph) | ("eager", callable)
+        self.stream = torch.cuda.Stream(self.device)
+        self.pool = torch.cuda.graph_pool_handle()
+        self._g = None
+        self._tick = torch.zeros(1, dtype=torch.int32, device=self.device)   # first node of every segment: no empty graphs
+        # RCCL's watchdog thread polls events while we capture: only this thread's unsafe calls may invalidate the capture
+        self._mode = "thread_local"
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self.pool, capture_error_mode=self._mode)
+        self._g = g
+        self._tick.add_(1)
+
+    def _end(self):
+        self._g.capture_end()
+        self.items.append(("graph", self._g))
+        self._g = None
+
+    def brk(self, fn):
+        self._end()
+        out = fn()
+        self.items.append(("eager", fn))
+        self._begin()
+        return out
+
+    @contextlib.contextmanager
+    def capture(self):
+        """everything launched inside runs in capture mode on a side stream (kernels are recorded, not executed)"""
+        global _capture
+        assert _capture is None, "nested step capture"
+        import gc
+        torch.cuda.synchronize(self.device)
+        gc.collect()
+        torch.cuda.empty_cache()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            _capture = self
+            ok = False
+            try:
+                self._begin()
+                yield self
+                ok = True
+            finally:
+                _capture = None
+                if self._g is not None:
+                    try:
+                        self._end()
+                    except Exception:
+                        if ok:
+                            raise
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        torch.cuda.synchronize(self.device)
+
+    def replay(self):
+        for kind, it in self.items:
+            if kind == "graph":
+                it.replay()
+            else:
+                it()
+
+    def n_segments(self):
+        return sum(1 for k, _ in self.items if k == "graph")

@@ -13,11 +13,15 @@ from __future__ import annotations
 import math
 from functools import partial
 
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import kernels as K
 from . import runtime as rt
+
+_FORCE_DP = os.environ.get("DVQ_FORCE_DP", "0") == "1"
 
 
 # ---- LR schedules (models/stage1/utils.py:6-24) ----------------------------------------------------
@@ -114,19 +118,37 @@ class HipAdam(torch.optim.Optimizer):
             for p in self.flat.params:
                 p._dvq_group = id(self)
             self._fstate = {"step": 0, "m": torch.zeros_like(self.flat.flat_p), "v": torch.zeros_like(self.flat.flat_p)}
+            # per-group hyper-parameters in DEVICE memory (dvq_adamw_dev): the launch has no step-dependent argument, so a
+            # captured training step follows the LR schedule -- the host rewrites this table before each step
+            self._hyper = torch.zeros(len(self.param_groups), 8, dtype=torch.float32, device=self.flat.flat_p.device)
+            self._prepared = False
         return self.flat
+
+    @torch.no_grad()
+    def prepare_step(self):
+        """upload the hyper-parameters of the NEXT step() (lr from the schedule, bias corrections of step count + 1).  Called
+        by the Trainer at the top of every step, outside any capture; step() calls it itself when nobody did."""
+        t = self._fstate["step"] + 1
+        for gi, g in enumerate(self.param_groups):
+            b1, b2 = g["betas"]
+            lr = float(g["lr"])
+            bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+            K.set_f32x8(self._hyper[gi], [lr / bc1, b1, b2, g["eps"], 1.0 / math.sqrt(bc2), 1.0 - lr * g.get("weight_decay", 0.0)])
+        self._prepared = True
 
     @torch.no_grad()
     def step(self, closure=None):
         if self.flat is not None:
             st = self._fstate
+            if not self._prepared:
+                self.prepare_step()
+            self._prepared = False
             st["step"] += 1
-            for g, (off, n) in zip(self.param_groups, self._segments):
+            for gi, (off, n) in enumerate(self._segments):
                 if n == 0:
                     continue
                 sl = slice(off, off + n)
-                K.adamw_step(self.flat.flat_p[sl], self.flat.flat_g[sl], st["m"][sl], st["v"][sl], g["lr"], g["betas"][0],
-                             g["betas"][1], g["eps"], g.get("weight_decay", 0.0), st["step"])
+                K.adamw_dev(self.flat.flat_p[sl], self.flat.flat_g[sl], st["m"][sl], st["v"][sl], self._hyper[gi])
             rt.bump_group_epoch(id(self))      # only this optimizer's packed weights are stale
             return
         for group in self.param_groups:
@@ -159,12 +181,14 @@ class GradBuckets:
         self.flat = [self.fp.flat_g[i:min(n, i + step)] for i in range(0, n, step)]
         self.params = self.fp.params
         self._pending, self._done = [], []
+        self.launched = 0                 # all-reduce launches so far (tests: every bucket exactly once per step)
 
     def zero(self):
         self.fp.zero_grad()
 
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
+        # DVQ_FORCE_DP=1: exchange even in a one-rank group (exercises the RCCL / capture-break path on a single GPU)
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.pg) > 1 or _FORCE_DP)
 
     def reduce_range(self, lo, hi):
         """start averaging flat_g[lo:hi] over ranks NOW (asynchronously, on RCCL's stream) -- called from inside the
@@ -175,9 +199,13 @@ class GradBuckets:
         seg = self.fp.flat_g[lo:hi]
         seg.div_(ws)
         step = max(1, self.bucket_elems)
-        for a in range(lo, hi, step):
-            b = min(hi, a + step)
-            self._pending.append(dist.all_reduce(self.fp.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        chunks = [self.fp.flat_g[a:min(hi, a + step)] for a in range(lo, hi, step)]
+
+        def launch():        # eager even when the step is being captured (rt.graph_break): RCCL runs on its own stream
+            for c in chunks:
+                self._pending.append(dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self.launched += len(chunks)
+        rt.graph_break(launch)
         self._done.append((lo, hi))
 
     def reduce(self, async_op=True):
@@ -196,8 +224,17 @@ class GradBuckets:
             gaps.append((pos, n))
         for lo, hi in reversed(gaps):              # last layers first
             self.reduce_range(lo, hi)
-        works, self._pending, self._done = [w for w in self._pending if w is not None], [], []
-        return works
+        self._done = []
+        return list(self._pending)
+
+    def wait(self):
+        """make the current stream wait for every exchange launched so far (eager; a graph break inside a capture)"""
+        def _wait():
+            for w in self._pending:
+                if w is not None:
+                    w.wait()
+            self._pending.clear()
+        rt.graph_break(_wait)
 
     def param_range(self, params):
         """[lo, hi) of the flat buffer covered by `params` (they must be contiguous in the optimizer's order)"""
@@ -223,34 +260,154 @@ class DataModuleFromConfig:
 
 
 class Trainer:
-    """fit loop for a DualGrainVQModel-like module on batches produced by `batch_fn(step) -> dict`."""
+    """fit loop for a DualGrainVQModel-like module on batches produced by `batch_fn(step) -> dict`.
 
-    def __init__(self, model, max_steps, log_every=0):
+    Step capture: after `graph_after` eager steps with an unchanged signature (batch shapes, train flag, loss phase, runtime
+    switches) the step is recorded once as hipGraph segments (runtime.StepGraph) and replayed from then on; collectives
+    stay eager between segments, the optimizer reads its hyper-parameters from device memory, batches are copied into
+    static input buffers.  `DVQ_STEP_GRAPH=0` (or use_graph=False) keeps every step eager."""
+
+    def __init__(self, model, max_steps, log_every=0, use_graph=None, graph_after=3):
         self.model, self.max_steps, self.log_every = model, max_steps, log_every
         self.opts, self.scheds = model.configure_optimizers()
         self.buckets = [GradBuckets(o.flatten()) for o in self.opts]
         import inspect
         # Lightning passes optimizer_idx only to modules that declare it (two-optimizer stage 1); stage 2 has one optimizer
         self._takes_opt_idx = "optimizer_idx" in inspect.signature(model.training_step).parameters
+        if use_graph is None:
+            use_graph = os.environ.get("DVQ_STEP_GRAPH", "1") != "0"
+        self.use_graph = bool(use_graph) and bool(getattr(model, "GRAPH_SAFE", False))
+        self.graph_after = graph_after
+        self._graph = None            # dict(sg, sig, static, losses)
+        self._last_sig, self._stable = None, 0
+        self.graph_replays = 0
 
+    # ---- one step ------------------------------------------------------------------------------------------------
     def train_step(self, batch, batch_idx):
+        if not self.use_graph:
+            return self._eager_step(batch, batch_idx)
+        sig = self._signature(batch)
+        if sig is None:                            # profiled step / injected host-side noise: eager, the recording stays valid
+            return self._eager_step(batch, batch_idx)
+        g = self._graph
+        if g is not None and g["sig"] == sig:
+            return self._replay(batch)
+        if g is not None:
+            self._graph = None                     # the recorded control flow no longer applies
+        self._stable = self._stable + 1 if sig == self._last_sig else 0
+        self._last_sig = sig
+        if self._stable >= self.graph_after:       # `graph_after` eager steps with this signature have run
+            if self._capture(batch, batch_idx, sig):
+                return self._replay(batch)
+        return self._eager_step(batch, batch_idx)
+
+    def _eager_step(self, batch, batch_idx):
+        for o in self.opts:
+            o.prepare_step()                       # hyper-parameters of this step -> device memory
+        return self._step_body(batch, batch_idx)
+
+    def _step_body(self, batch, batch_idx):
+        """the capturable part: every launch of the two-optimizer step (collectives are graph breaks)"""
         m = self.model
         losses = []
         K.arena_reset(self.buckets[0].fp.flat_g.device)
-        for oi, opt in enumerate(self.opts):
-            self.buckets[oi].zero()
-            self._arm_overlap(oi)
-            loss = m.training_step(batch, batch_idx, oi) if self._takes_opt_idx else m.training_step(batch, batch_idx)
-            if loss.requires_grad:
-                loss.backward()
-            works = self.buckets[oi].reduce()
-            for w in works:
-                w.wait()
-            opt.step()
-            self.scheds[oi]["scheduler"].step()
-            losses.append(loss.detach())
+        # single-threaded autograd: the backward's launches come from this thread (one capture thread, no thread hops)
+        with torch.autograd.set_multithreading_enabled(False):
+            for oi, opt in enumerate(self.opts):
+                self.buckets[oi].zero()
+                self._arm_overlap(oi)
+                loss = m.training_step(batch, batch_idx, oi) if self._takes_opt_idx else m.training_step(batch, batch_idx)
+                if loss.requires_grad:
+                    loss.backward()
+                self.buckets[oi].reduce()
+                self.buckets[oi].wait()
+                opt.step()
+                self.scheds[oi]["scheduler"].step()
+                losses.append(loss.detach())
         m.global_step += 1
         return losses
+
+    # ---- capture / replay ----------------------------------------------------------------------------------------
+    def _signature(self, batch):
+        """everything host-side that shapes the step's launch sequence; None = this step cannot be captured"""
+        m = self.model
+        if K.profiling_active() or rt.capturing():
+            return None
+        extra = m.graph_signature() if hasattr(m, "graph_signature") else ()
+        if extra is None:
+            return None
+        items = []
+        for k in sorted(batch):
+            v = batch[k]
+            if torch.is_tensor(v):
+                if not v.is_cuda:
+                    return None
+                items.append((k, tuple(v.shape), v.dtype, v.device.index))
+            else:
+                items.append((k, repr(v)))
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        return (tuple(items), bool(m.training), rt.compute_dtype(), rt.impl(), rt.fuse_gn_prologue(), world, extra)
+
+    def _py_state(self):
+        return ([o._fstate["step"] for o in self.opts], [s["scheduler"].state_dict() for s in self.scheds],
+                [[g["lr"] for g in o.param_groups] for o in self.opts], int(self.model.global_step))
+
+    def _set_py_state(self, st):
+        steps, scheds, lrs, gstep = st
+        for o, t, lr in zip(self.opts, steps, lrs):
+            o._fstate["step"] = t
+            for g, v in zip(o.param_groups, lr):
+                g["lr"] = v
+        for s, sd in zip(self.scheds, scheds):
+            s["scheduler"].load_state_dict(sd)
+        self.model.global_step = gstep
+
+    def _capture(self, batch, batch_idx, sig) -> bool:
+        """record one step (a dry run: captured kernels do not execute, the Python-side counters are put back)"""
+        dev = self.buckets[0].fp.flat_g.device
+        static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        saved = self._py_state()
+        logged = dict(getattr(self.model, "_logged", {}))
+        for o in self.opts:
+            o.prepare_step()
+        sg = rt.StepGraph(dev)
+        try:
+            with sg.capture():
+                losses = self._step_body(static, batch_idx)
+        except Exception as e:          # a launch sequence that cannot be captured: stay eager, say why once
+            import warnings
+            warnings.warn(f"training-step capture failed ({type(e).__name__}: {e}); continuing with eager launches")
+            self.use_graph = False
+            self._set_py_state(saved)
+            for o in self.opts:
+                o._prepared = False
+            return False
+        self._set_py_state(saved)
+        if hasattr(self.model, "_logged"):
+            # the step's log tensors now live in the graph's pool and are refreshed by every replay
+            self.model._logged = {**logged, **self.model._logged}
+        self._graph = {"sg": sg, "sig": sig, "static": static, "losses": losses}
+        return True
+
+    def _replay(self, batch):
+        g = self._graph
+        for k, v in batch.items():
+            if torch.is_tensor(v) and v.data_ptr() != g["static"][k].data_ptr():
+                g["static"][k].copy_(v, non_blocking=True)
+        for o in self.opts:
+            o.prepare_step()
+        g["sg"].replay()
+        # host-side bookkeeping the recorded launches do not carry
+        for o, sc in zip(self.opts, self.scheds):
+            o._fstate["step"] += 1
+            o._prepared = False
+            sc["scheduler"].step()
+        self.model.global_step += 1
+        self.graph_replays += 1
+        return g["losses"]
+
+    def drop_graph(self):
+        self._graph, self._stable, self._last_sig = None, 0, None
 
     def _arm_overlap(self, oi):
         """autoencoder optimizer: the decoder-side gradients (decoder, quant convs) are final before the encoder's backward

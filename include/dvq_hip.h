@@ -376,6 +376,17 @@ int dvq_rows_dev(void* x, void* hidden, int dtype, int64_t B, int64_t C, int64_t
 /* nn.Dropout(p) with a counter-based hash RNG: y = x * keep / (1-p); the same (seed) reproduces the mask for the backward */
 int dvq_dropout(const void* x, int dtype, int64_t n, float p, uint64_t seed, void* y, dvq_stream_t stream);
 
+/* AdamW step whose hyper-parameters are read from DEVICE memory (so that a step captured as a hipGraph follows the LR schedule):
+ * hyper[8] = {lr / (1 - beta1^t), beta1, beta2, eps, 1 / sqrt(1 - beta2^t), 1 - lr * weight_decay, unused, unused}.
+ * Same update as dvq_adamw (models/stage1_dynamic/dqvae_dual_entropy.py:228-232 Adam, dqtransformer_uncond_entropy.py:92-128 AdamW). */
+int dvq_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, dvq_stream_t stream);
+/* dst[0..7] <- the eight scalars (passed by value in the launch: no pageable host copy, no host buffer to keep alive) */
+int dvq_set_f32x8(float* dst, float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                  dvq_stream_t stream);
+/* k distinct pseudo-random indices in [0, n) = prefix of a keyed Feistel permutation (replaces torch.randperm(n)[:k] of
+ * quantize2_mask.py:93-98); state = uint64[2] {seed, counter} in device memory, the counter is advanced on the stream. */
+int dvq_sample_rows(int64_t* out, int64_t k, int64_t n, uint64_t* state, dvq_stream_t stream);
+
 int dvq_fill_f32(float* p, float v, int64_t n, dvq_stream_t stream);
 
 #ifdef __cplusplus

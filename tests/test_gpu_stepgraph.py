@@ -1,0 +1,147 @@
+"""Training-step capture (runtime.StepGraph / Trainer): a step replayed from recorded hipGraph segments must do what the
+eager step does -- same losses, parameters, Adam state, LR-schedule position -- including with the data-parallel exchange
+points (RCCL all-reduces between graph segments), exercised here on ONE GPU through a one-rank nccl group.  `pytest -m gpu`."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from dynamicvectorquantization_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(dev, use_graph, loss="full", graph_after=2, seed=0):
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    from dynamicvectorquantization_amd.trainer import Trainer
+    from test_gpu_model import GEOM, model_config
+    torch.manual_seed(seed)
+    model = instantiate_from_config(model_config(**GEOM["small"], loss=loss)).to(dev)
+    # a schedule that moves every step (warm-up then cosine): the replayed optimizer must follow it from device memory
+    model.learning_rate, model.min_learning_rate = 2e-4, 1e-5
+    model.training_steps, model.steps_per_epoch, model.warmup_epochs = 12, 4, 1
+    model.train()
+    return model, Trainer(model, max_steps=12, use_graph=use_graph, graph_after=graph_after)
+
+
+def _run(dev, use_graph, steps, loss="full"):
+    from dynamicvectorquantization_amd import runtime as rt
+    xs = [torch.from_numpy(synth.half_flat_images(2, 64, seed=40 + i)).to(dev) for i in range(3)]
+    with rt.compute_dtype_ctx(torch.float32):
+        model, tr = _make(dev, use_graph, loss)
+        losses = []
+        for i in range(steps):
+            out = tr.train_step({"image": xs[i % 3]}, i)
+            losses.append([float(l) for l in out])
+        torch.cuda.synchronize()
+    return model, tr, np.array(losses)
+
+
+@pytest.mark.parametrize("loss", ["ae", "full"])
+def test_step_graph_matches_eager(dev, loss):
+    steps = 8
+    m_e, tr_e, l_e = _run(dev, False, steps, loss)
+    m_g, tr_g, l_g = _run(dev, True, steps, loss)
+    assert tr_e.graph_replays == 0
+    assert tr_g._graph is not None and tr_g.graph_replays == steps - 2, (tr_g.use_graph, tr_g.graph_replays)
+    assert tr_g._graph["sg"].n_segments() == 1            # one rank: the whole two-optimizer step is ONE graph
+    # host-side bookkeeping the replay has to carry by hand
+    assert m_g.global_step == m_e.global_step == steps
+    for og, oe in zip(tr_g.opts, tr_e.opts):
+        assert og._fstate["step"] == oe._fstate["step"] == steps
+        assert [g["lr"] for g in og.param_groups] == [g["lr"] for g in oe.param_groups]
+    # same trajectory (fp32 kernels; atomics order is the only difference between two runs)
+    np.testing.assert_allclose(l_g, l_e, rtol=2e-3, atol=2e-4)
+    for (n1, p1), (_, p2) in zip(m_g.named_parameters(), m_e.named_parameters()):
+        a, b = p1.detach().float(), p2.detach().float()
+        assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-6, n1
+    for og, oe in zip(tr_g.opts, tr_e.opts):
+        assert float((og._fstate["m"] - oe._fstate["m"]).norm()) <= 5e-3 * float(oe._fstate["m"].norm()) + 1e-9
+    for k in ("quantize.codebook.cluster_size_ema", "quantize.codebook.embed_ema"):
+        a, b = m_g.state_dict()[k].float(), m_e.state_dict()[k].float()
+        assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-6, k
+    if loss == "full":     # BatchNorm running statistics / batch counters of the discriminator advance inside the graph
+        nb_g = m_g.state_dict()["loss.discriminator.main.3.num_batches_tracked"]
+        nb_e = m_e.state_dict()["loss.discriminator.main.3.num_batches_tracked"]
+        assert int(nb_g) == int(nb_e) > 0
+    # logged scalars are refreshed by the replays
+    assert abs(float(m_g._logged["train_fine_ratio"]) - float(m_e._logged["train_fine_ratio"])) < 1e-6
+
+
+def test_step_graph_signature_change_falls_back(dev):
+    """a different batch shape (or an eval/profile step) must not replay the recorded step"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        model, tr = _make(dev, True, "ae")
+        x2 = torch.from_numpy(synth.half_flat_images(2, 64, seed=1)).to(dev)
+        x4 = torch.from_numpy(synth.half_flat_images(4, 64, seed=2)).to(dev)
+        for i in range(4):
+            tr.train_step({"image": x2}, i)
+        assert tr._graph is not None and tr.graph_replays == 2
+        out = tr.train_step({"image": x4}, 4)                   # other batch size: eager, recorded graph dropped
+        assert tr._graph is None and tr.graph_replays == 2 and all(bool(torch.isfinite(l)) for l in out)
+        for i in range(5, 9):
+            tr.train_step({"image": x4}, i)
+        assert tr._graph is not None and tr.graph_replays >= 4
+        K.profile_count_start()                                 # a profiled step runs eagerly (per-launch HIP events)
+        r0 = tr.graph_replays
+        tr.train_step({"image": x4}, 9)
+        assert K.profile_count_stop() > 50 and tr.graph_replays == r0
+        torch.cuda.synchronize()
+
+
+def test_sample_rows_is_a_permutation_prefix(dev):
+    from dynamicvectorquantization_amd import kernels as K
+    st = torch.tensor([1234, 0], dtype=torch.int64, device=dev)
+    for n, k in ((65536, 1024), (1000, 1000), (5, 3), (70000, 8192)):
+        a = K.sample_rows(k, n, st).cpu().numpy()
+        assert a.min() >= 0 and a.max() < n and len(np.unique(a)) == k
+        b = K.sample_rows(k, n, st).cpu().numpy()               # the device counter advanced: another draw
+        assert len(np.unique(b)) == k and (n < 10 or not np.array_equal(a, b))
+    assert int(st[1]) == 8
+    # roughly uniform over [0, n)
+    a = K.sample_rows(8192, 65536, st).cpu().numpy()
+    assert abs(a.mean() / 65536 - 0.5) < 0.02
+
+
+_DP_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1)
+from dynamicvectorquantization_amd import runtime as rt, synth
+import test_gpu_stepgraph as T
+dev = torch.device("cuda:0")
+m_e, tr_e, l_e = T._run(dev, False, 7, "full")
+m_g, tr_g, l_g = T._run(dev, True, 7, "full")
+sg = tr_g._graph["sg"]
+kinds = [k for k, _ in sg.items]
+assert tr_g.graph_replays == 5, tr_g.graph_replays
+# exchange points cut the step: VQ statistics (2 forwards), decoder-side + encoder-side gradient all-reduce + wait, discriminator
+assert kinds.count("eager") >= 6 and sg.n_segments() == kinds.count("eager") + 1, kinds
+# every bucket exactly once per step and optimizer, eager and replayed alike
+# (the recording pass runs the exchange callables once more: 7 steps + 1)
+for bg, be in zip(tr_g.buckets, tr_e.buckets):
+    assert be.launched > 0 and bg.launched * 7 == be.launched * 8, (bg.launched, be.launched)
+np.testing.assert_allclose(l_g, l_e, rtol=2e-3, atol=2e-4)
+for (n1, p1), (_, p2) in zip(m_g.named_parameters(), m_e.named_parameters()):
+    assert float((p1.float() - p2.float()).norm()) <= 2e-3 * float(p2.float().norm()) + 1e-6, n1
+dist.destroy_process_group()
+print("DP_GRAPH_OK", kinds.count("eager"), sg.n_segments())
+"""
+
+
+def test_step_graph_with_exchange_breaks_one_rank_nccl(dev):
+    """the data-parallel step (RCCL all-reduces launched between graph segments, one of them from inside the backward) on
+    a ONE-rank nccl group: same results as the eager data-parallel step, every bucket reduced exactly once per step"""
+    env = dict(os.environ, DVQ_FORCE_DP="1", MASTER_ADDR="127.0.0.1")
+    port = 29500 + (os.getpid() % 1000)
+    r = subprocess.run([sys.executable, "-c", _DP_SCRIPT.format(repo=REPO, port=port)], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "DP_GRAPH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
