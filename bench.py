@@ -122,15 +122,23 @@ def _pmc_traffic(family):
         return None
 
 
-def vq_microbench(dev, reps=20):
-    """VQ argmin at the BASELINE shape (N=65536, D=256, K=1024): algorithmic GB/s, inputs resident in HBM."""
+def vq_microbench(dev, reps=20, in_training=None):
+    """VQ argmin at the BASELINE shape (N=65536, D=256, K=1024): algorithmic GB/s, inputs resident in HBM.  Cases: N(0,1) rows
+    and codes ("normal", fp32 and bf16 rows), the untrained-encoder distribution (|z|^2 ~ 12, codebook U(+-1/1024): tiny score
+    gaps, many fp64 re-ranks), and -- when given -- the rows and codebook the training run of this process just saw."""
     from dynamicvectorquantization_amd import kernels as K
     from dynamicvectorquantization_amd import synth
     out = {}
-    for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
-        x, cb = synth.vq_inputs(65536, 256, 1024, "normal", 0)
-        xt = torch.from_numpy(x).to(dev).to(dtype)
-        cbt = torch.from_numpy(cb).to(dev)
+    cases = [("f32", "normal", torch.float32), ("bf16", "normal", torch.bfloat16), ("encoder_bf16", "encoder", torch.bfloat16)]
+    for tag, dist_, dtype in cases + ([("in_training_bf16", None, None)] if in_training is not None else []):
+        if dist_ is None:
+            xt, cbt = in_training
+        else:
+            x, cb = synth.vq_inputs(65536, 256, 1024, dist_, 0)
+            xt = torch.from_numpy(x).to(dev).to(dtype)
+            cbt = torch.from_numpy(cb).to(dev)
+        n, d = xt.shape
+        k = cbt.shape[0]
         prep = K.vq_prepare(cbt)
         for _ in range(3):
             K.vq_argmin(xt, cbt, prep, impl=2)
@@ -142,10 +150,13 @@ def vq_microbench(dev, reps=20):
         e.record()
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / reps
-        nbytes = 65536 * 256 * xt.element_size() + 1024 * 256 * 4 + 65536 * 8
+        nbytes = n * d * xt.element_size() + k * d * 4 + n * 8
+        passes = 3 if xt.dtype == torch.float32 else 2          # bf16 MFMA passes of the split product
         out[tag] = {"ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 2), "frac_hbm_peak": round(nbytes / (ms * 1e-3) / PEAK_HBM, 4),
-                    "TFLOPs_equiv": round(2 * 65536 * 1024 * 256 / ms / 1e9, 2), "rerank_rows": int(flagged.item()),
-                    "alg_bytes": nbytes}
+                    "TFLOPs_equiv": round(2 * n * k * d / ms / 1e9, 2),
+                    "mfma_frac": round(passes * 2 * n * k * d / (ms * 1e-3) / PEAK_BF16, 4), "mfma_passes": passes,
+                    "rerank_rows_full": int(flagged[0].item()), "rerank_rows_candidates": int(flagged[1].item()),
+                    "alg_bytes": nbytes, "shape": [n, d, k]}
     return out
 
 
@@ -263,9 +274,20 @@ def main():
         if profile:
             # per-kernel HIP-event timing: ONE extra step right after the timed region, launched eagerly (events cannot be
             # recorded inside a graph replay) -- the same kernels on the same shapes as the replayed steps
+            vq_seen = {}
+            orig_fwd = model.quantize.fwd
+
+            def spy(h, mask, tape):         # the rows / codebook the quantiser sees at this point of training (VQ micro-benchmark)
+                if "x" not in vq_seen:
+                    vq_seen["x"] = h.reshape(-1, h.shape[-1]).detach().clone()
+                    vq_seen["cb"] = model.quantize.codebook._codebook().clone()
+                return orig_fwd(h, mask, tape)
+            model.quantize.fwd = spy
             K.profile_start()
             trainer.train_step(batches[steps % nb], SETUP + warmup + steps)
             prof = K.profile_stop()
+            model.quantize.fwd = orig_fwd
+            model._vq_seen = (vq_seen["x"], vq_seen["cb"]) if "x" in vq_seen else None
         graph_info = {"enabled": trainer._graph is not None, "replays": trainer.graph_replays,
                       "segments": trainer._graph["sg"].n_segments() if trainer._graph is not None else 0,
                       "fine_ratio": float(model._logged.get("train_fine_ratio", torch.tensor(float("nan"))))}
@@ -280,6 +302,7 @@ def main():
 
     dt_, host_issue, prof, model = run(args.objective, args.steps, args.warmup, True)
     ratio = model._graph_info.pop("fine_ratio")
+    graph_info, vq_seen = model._graph_info, getattr(model, "_vq_seen", None)
 
     ae_only = None
     if args.objective == "full" and not args.no_ae_only:
@@ -325,7 +348,7 @@ def main():
                        "objective": OBJECTIVES[args.objective] + (" [discriminator step reuses the generator step's reconstruction]"
                                                                          if args.reuse_forward else ""),
                        "global_batch": world * args.bs, "parallelism": f"dp{world}", "fine_ratio": ratio,
-                       "step_graph": getattr(model, "_graph_info", None)},
+                       "step_graph": graph_info},
             "step_mfma_frac": round(ips / world * STEP_FLOP_PER_IMG[args.objective] / PEAK_BF16, 4),
             "step_flop_per_img": STEP_FLOP_PER_IMG[args.objective],
             "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 2),
@@ -335,7 +358,7 @@ def main():
         }
         out["ae_only"] = ae_only
         if not args.no_vq_microbench:
-            out["vq_argmin"] = vq_microbench(dev)
+            out["vq_argmin"] = vq_microbench(dev, in_training=vq_seen)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.objective)
         print(json.dumps(out), flush=True)

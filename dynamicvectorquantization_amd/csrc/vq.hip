@@ -6,9 +6,12 @@
 // Exactness scheme (DESIGN.md "VQ argmin"):
 //   score_k = |e_k|^2 - 2 x.e_k.  The dot product runs on bf16 MFMA with x and e each split into
 //   bf16 planes (x = x1 + x2 + r, e = e1 + e2 + r', |r| <= 2^-18 |x|): x1.e1 + x1.e2 + x2.e1,
-//   fp32 accumulate.  Every row keeps best and second-best score; when their gap is not larger
-//   than a sound bound on the evaluation error the row is re-ranked in fp64 over all K codes
-//   (a few 0.1 % of rows).  The result is the mathematically exact argmin, lowest index on ties.
+//   fp32 accumulate.  Every lane keeps best and second-best score of ITS residue class of codes (k mod 32); a row
+//   whose best score is not separated from every other code by more than a sound bound tau on the evaluation error is
+//   re-ranked in fp64 -- over the CANDIDATES only (the codes whose approximate score is within tau of the best: the
+//   lanes' class winners say which they are, typically 2-3 codes), or over all K codes in the rare case that one
+//   class holds two candidates or there are more than VQ_MAXC of them.  The result is the mathematically exact
+//   argmin, lowest index on ties.
 #include <type_traits>
 
 #include "dvq_common.h"
@@ -64,11 +67,15 @@ __global__ void vq_prepare_kernel(const float* __restrict__ cb, int64_t K, int64
     }
 }
 
+constexpr int VQ_MAXC = 6;          // candidate codes kept per ambiguous row (an entry is {row, n, idx[6]} = 32 B)
 struct VqWs {
-    int count;      // flagged rows
-    int pad[63];
-    int list[1];    // [N]
+    int count;      // rows to re-rank over ALL codes
+    int ccount;     // rows to re-rank over their candidate list
+    int pad[62];
+    int list[1];    // [N] full-rerank rows, then [N][8] candidate entries
 };
+__host__ __device__ inline int* vq_cand_entries(VqWs* ws, int64_t N) { return ws->list + N; }
+__host__ __device__ inline const int* vq_cand_entries(const VqWs* ws, int64_t N) { return ws->list + N; }
 
 // ---------------------------------------------------------------------------------------------
 // main kernel: 4 waves x 32 rows per block, x fragments live in registers, codebook streams
@@ -199,49 +206,97 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_kernel(const XT* __rest
 #undef VQ_G1
 #undef VQ_S1
 
-    // ---- reduce over the 32 code lanes of each half ----------------------------------------------
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
-            float ob1 = __shfl_xor(b1[r], o, 64);
-            float ob2 = __shfl_xor(b2[r], o, 64);
-            int oi1 = __shfl_xor(i1[r], o, 64);
-            bool take = (ob1 < b1[r]) || (ob1 == b1[r] && oi1 < i1[r]);
-            float loser = take ? b1[r] : ob1;
-            float m2 = b2[r] < ob2 ? b2[r] : ob2;
-            b2[r] = loser < m2 ? loser : m2;
-            b1[r] = take ? ob1 : b1[r];
-            i1[r] = take ? oi1 : i1[r];
-        }
-    }
-    if (l31 == 0) {
+    // ---- per row: global best over the 32 class winners, candidate set = classes within tau of it -------------------
+    {
         const float emax = *pv.emax;
         // error bound of one score: split residual 3*2^-18, accumulate D*2^-23 (relative to |x||e|),
         // norm rounding + final fma 4*2^-24; two scores are compared -> factor 2, -2x.e -> factor 2.
         const float coefA = 4.0f * (3.0f * 3.8147e-6f + (float)D * 1.1921e-7f);
         const float coefB = 8.0f * 5.9605e-8f;
+        int* cand = vq_cand_entries(ws, N);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            float gb = b1[r];
+            int gi = i1[r];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const float ob = __shfl_xor(gb, o, 64);
+                const int oi = __shfl_xor(gi, o, 64);
+                const bool take = (ob < gb) || (ob == gb && oi < gi);
+                gb = take ? ob : gb;
+                gi = take ? oi : gi;
+            }
             const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
             const int64_t row = row0 + rl;
+            const float xn = xnorm[wave * 32 + rl];
+            const float tau = coefA * xn * emax + coefB * (emax * emax + 2.0f * xn * emax + xn * xn) + 1e-37f;
+            // a code whose exact score is minimal has an approximate score <= gb + tau: it is the winner of a class with
+            // b1 <= gb + tau (is_c), unless that class holds two such codes (b2 <= gb + tau: over -> full re-rank)
+            const bool is_c = !(b1[r] - gb > tau);
+            const bool over = !(b2[r] - gb > tau);
+            const unsigned long long mc = __ballot(is_c), mo = __ballot(over);
+            const unsigned mh = half ? (unsigned)(mc >> 32) : (unsigned)mc;
+            const unsigned oh = half ? (unsigned)(mo >> 32) : (unsigned)mo;
             if (row < N) {
-                idx_out[row] = (int64_t)i1[r];
-                const float xn = xnorm[wave * 32 + rl];
-                const float tau = coefA * xn * emax + coefB * (emax * emax + 2.0f * xn * emax + xn * xn) + 1e-37f;
-                const float gap = b2[r] - b1[r];
-                if (!(gap > tau)) {
-                    int pos = atomicAdd(&ws->count, 1);
-                    ws->list[pos] = (int)row;
+                const int nc = __popc(mh);
+                if (l31 == 0) idx_out[row] = (int64_t)gi;
+                if (oh != 0u || nc > VQ_MAXC) {
+                    if (l31 == 0) {
+                        const int pos = atomicAdd(&ws->count, 1);
+                        ws->list[pos] = (int)row;
+                    }
+                } else if (nc >= 2) {
+                    int pos = 0;
+                    if (l31 == 0) pos = atomicAdd(&ws->ccount, 1);
+                    pos = __shfl(pos, half * 32, 64);
+                    int* ent = cand + (int64_t)pos * 8;
+                    if (l31 == 0) {
+                        ent[0] = (int)row;
+                        ent[1] = nc;
+                    }
+                    if (is_c) ent[2 + __popc(mh & ((1u << l31) - 1u))] = i1[r];
                 }
             }
         }
     }
 }
 
+// fp64 re-rank of a row over its candidate codes only: one wave per entry {row, n, idx[n]}
+template <typename XT>
+__global__ __launch_bounds__(256) void vq_rerank_cand_kernel(const XT* __restrict__ x, const float* __restrict__ cb, int64_t N,
+                                                             int64_t D, int64_t* __restrict__ idx_out, const VqWs* ws) {
+    const int cnt = ws->ccount;
+    const int* cand = vq_cand_entries(ws, N);
+    const int lane = threadIdx.x & 63;
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < cnt; e += gridDim.x * 4) {
+        const int* ent = cand + (int64_t)e * 8;
+        const int64_t row = ent[0];
+        const int nc = ent[1];
+        double best = __builtin_inf();
+        int bi = 0x7fffffff;
+        for (int c = 0; c < nc; ++c) {
+            const int k = ent[2 + c];
+            double acc = 0.0;
+            for (int64_t d = lane; d < D; d += 64) {
+                const double t = (double)ElemIO<XT>::load(x + row * D + d) - (double)cb[(int64_t)k * D + d];
+                acc = fma(t, t, acc);
+            }
+            acc = wave_sum(acc);
+            if (acc < best || (acc == best && k < bi)) {
+                best = acc;
+                bi = k;
+            }
+        }
+        if (lane == 0) idx_out[row] = (int64_t)bi;
+    }
+}
+
 __global__ void vq_flag_all_kernel(VqWs* ws, int64_t N) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) ws->count = (int)N;
+    if (i == 0) {
+        ws->count = (int)N;
+        ws->ccount = 0;
+    }
     if (i < N) ws->list[i] = (int)i;
 }
 
@@ -533,7 +588,12 @@ static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_
         DVQ_CHECK_LAUNCH("vq_flag_all");
     }
     size_t lds = (size_t)D * 8 + 16 * 8 + 16 * 4;
-    int64_t blocks = use_mfma ? 512 : (N < 65535 ? N : 65535);      // flagged rows are ~0.5 %: grid-stride over the list
+    if (use_mfma) {
+        // ambiguous rows with a short candidate list (the usual case): a few fp64 distances each
+        vq_rerank_cand_kernel<XT><<<dim3(512), dim3(256), 0, s>>>(x, cb, N, D, idx, ws);
+        DVQ_CHECK_LAUNCH("vq_rerank_cand");
+    }
+    int64_t blocks = use_mfma ? 256 : (N < 65535 ? N : 65535);      // full re-rank rows are rare: grid-stride over the list
     vq_rerank_fp64_kernel<XT><<<dim3((unsigned)blocks), dim3(RR_THREADS), lds, s>>>(x, cb, K, D, idx, ws);
     DVQ_CHECK_LAUNCH("vq_rerank_fp64");
     return DVQ_OK;
@@ -560,7 +620,7 @@ int dvq_vq_prepare(const float* codebook, int64_t K, int64_t D, void* prep, dvq_
     return DVQ_OK;
 }
 
-size_t dvq_vq_argmin_workspace_bytes(int64_t N) { return (size_t)(256 + 4 * (N + 1)); }
+size_t dvq_vq_argmin_workspace_bytes(int64_t N) { return (size_t)(256 + 4 * (N + 1) + 32 * (N + 1)); }
 
 int dvq_vq_argmin(const void* x, int x_dtype, const float* codebook, const void* prep, int64_t N, int64_t K,
                   int64_t D, int64_t* idx, void* ws, int impl, dvq_stream_t stream) {

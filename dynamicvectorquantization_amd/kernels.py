@@ -187,7 +187,7 @@ def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, prep: torch.Tensor | None
     _timed("vq_argmin", 2 * n * k * d, nbytes, lambda: check(
         lib().dvq_vq_argmin(_p(x), dt(x), _p(codebook), _p(prep), n, k, d, _p(idx), _p(ws), impl, _s()), "dvq_vq_argmin"))
     if return_flagged:
-        return idx, ws[:4].view(torch.int32)
+        return idx, ws[:8].view(torch.int32)      # rows re-ranked in fp64: [over all K codes, over their candidate list]
     return idx
 
 
@@ -208,17 +208,18 @@ def vq_backward(g_xq, x, codebook, idx, mask, coef_dev):
     return dx
 
 
-def vq_embed(codebook, idx, dtype=torch.float32):
+def vq_embed(codebook, idx, dtype=torch.float32, out=None):
     d = codebook.shape[1]
     flat = idx.reshape(-1).contiguous()
-    out = torch.empty(flat.numel(), d, dtype=dtype, device=codebook.device)
+    if out is None:
+        out = torch.empty(flat.numel(), d, dtype=dtype, device=codebook.device)
     check(lib().dvq_vq_embed(_p(codebook), _p(flat), flat.numel(), d, dt(dtype), _p(out), _s()), "dvq_vq_embed")
     return out.reshape(*idx.shape, d)
 
 
-def vq_ema_stats(x, idx, k):
+def vq_ema_stats(x, idx, k, out=None):
     n, d = x.shape
-    stats = torch.empty(k, d + 1, dtype=torch.float32, device=x.device)
+    stats = torch.empty(k, d + 1, dtype=torch.float32, device=x.device) if out is None else out
     check(lib().dvq_vq_ema_stats(_p(x), dt(x), _p(idx), n, k, d, _p(stats), _s()), "dvq_vq_ema_stats")
     return stats
 

@@ -315,11 +315,17 @@ class Conv2d(HipModule):
         PACKS.register(self, dtype)
         return ent
 
+    def _pack_key(self):
+        """what the packed copies were made from: the runtime's parameter epochs (optimizer steps, whole-model
+        load_state_dict) AND the tensors' own version counters (submodule load_state_dict, weights_init-style or manual
+        in-place edits after a first forward)"""
+        return (rt.param_epoch(self.weight), self.weight._version, None if self.bias is None else self.bias._version)
+
     def packed(self, dtype):
         ent = self._packs.get(dtype)
         if ent is None or ent["w"].device != self.weight.device or ent["master"] != self.weight.data_ptr():
             ent = self._alloc_pack(dtype)
-        ep = rt.param_epoch(self.weight)
+        ep = self._pack_key()
         if ent["epoch"] != ep:
             if ent["epoch"] != -1:
                 # ONE launch refreshes every registered conv of this dtype / device / optimizer group
@@ -429,7 +435,7 @@ class _PackRegistry:
             self.tables[key] = tab
         K.pack_weights_multi(tab["table"], tab["n"], tab["total"])
         for m in live:
-            m._packs[dtype]["epoch"] = rt.param_epoch(m.weight)
+            m._packs[dtype]["epoch"] = m._pack_key()
 
 
 PACKS = _PackRegistry()

@@ -228,6 +228,49 @@ class LPIPS(nn.Module):
         for p in self.parameters():
             p.requires_grad = False
         self._aff = None
+        self.pretrained_loaded = self._try_load_pretrained()
+
+    # -- pretrained weights (lpips.py:16, 23-27 + torchvision vgg16(pretrained=True), lpips.py:79) -----------------------------
+    ENV_VGG, ENV_LIN = "DVQ_VGG16_WEIGHTS", "DVQ_LPIPS_LIN_WEIGHTS"
+
+    def _try_load_pretrained(self) -> bool:
+        """The reference builds LPIPS from torchvision's ImageNet VGG16 and the `vgg.pth` lin layers; neither can be fetched
+        offline, so they are taken from files: $DVQ_VGG16_WEIGHTS (torchvision `vgg16-397923af.pth`, keys `features.N.*`) and
+        $DVQ_LPIPS_LIN_WEIGHTS (`vgg.pth`, keys `linK.model.1.weight`), else the usual cache locations.  Returns whether BOTH
+        were loaded; without them the perceptual term is computed with random features (the caller warns)."""
+        import os
+        vgg_candidates = [os.environ.get(self.ENV_VGG), os.path.expanduser("~/.cache/torch/hub/checkpoints/vgg16-397923af.pth")]
+        lin_candidates = [os.environ.get(self.ENV_LIN), "modules/lpips/vgg.pth",
+                          os.path.expanduser("~/.cache/taming/modules/autoencoder/lpips/vgg.pth")]
+        vgg = next((c for c in vgg_candidates if c and os.path.isfile(c)), None)
+        lin = next((c for c in lin_candidates if c and os.path.isfile(c)), None)
+        if vgg is None or lin is None:
+            return False
+        self.load_pretrained(vgg, lin)
+        return True
+
+    @torch.no_grad()
+    def load_pretrained(self, vgg16_path, lin_path):
+        """copy torchvision VGG16 feature weights and the LPIPS lin layers into this module (shapes checked, strict)"""
+        sd = torch.load(vgg16_path, map_location="cpu", weights_only=True)
+        for name, idxs, _ in vgg16.SLICES:
+            seq = getattr(self.net, name)
+            for i in idxs:
+                conv = seq[[str(j) for j in idxs].index(str(i))]
+                w, b = sd[f"features.{i}.weight"], sd[f"features.{i}.bias"]
+                if tuple(w.shape) != tuple(conv.weight.shape):
+                    raise ValueError(f"features.{i}.weight: {tuple(w.shape)} != {tuple(conv.weight.shape)}")
+                conv.weight.copy_(w)
+                conv.bias.copy_(b)
+        lin_sd = torch.load(lin_path, map_location="cpu", weights_only=True)
+        for k in range(len(self.chns)):
+            w = lin_sd[f"lin{k}.model.1.weight"]
+            tgt = getattr(self, f"lin{k}").model[-1].weight
+            if tuple(w.shape) != tuple(tgt.shape):
+                raise ValueError(f"lin{k}.model.1.weight: {tuple(w.shape)} != {tuple(tgt.shape)}")
+            tgt.copy_(w)
+        rt.bump_weights_epoch()
+        self.pretrained_loaded = True
 
     def _affine(self, dtype, device):
         key = (dtype, device, self.scaling_layer.scale.data_ptr())
@@ -348,6 +391,13 @@ class VQLPIPSWithDiscriminator(nn.Module):
         self.perceptual_weight = perceptual_weight
         if perceptual_weight > 0:
             self.perceptual_loss = LPIPS().eval()
+            if not self.perceptual_loss.pretrained_loaded:
+                import warnings
+                warnings.warn(
+                    "VQLPIPSWithDiscriminator: perceptual_weight > 0 but no pretrained LPIPS weights were found -- the perceptual "
+                    "term (and with it the adaptive discriminator weight) is computed with a RANDOM frozen VGG16.  Point "
+                    f"${LPIPS.ENV_VGG} at torchvision's vgg16-397923af.pth and ${LPIPS.ENV_LIN} at the LPIPS vgg.pth (or load a "
+                    "checkpoint that carries loss.perceptual_loss.*) before training for quality.", stacklevel=2)
         self.discriminator_iter_start = disc_start
         self.discriminator = instantiate_from_config(disc_config)
         if disc_init:

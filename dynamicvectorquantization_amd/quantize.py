@@ -42,7 +42,7 @@ class VQEmbedding(nn.Embedding):
         self._prep = None          # (version, prep buffer)
         self._cb_version = 0       # bumped by every in-place codebook rewrite (EMA); conv packs are unaffected
         self.restart_perm = None   # optional injected permutation (tests)
-        self.last_flagged = None   # device int32 scalar: rows re-ranked in fp64 by the last search
+        self.last_flagged = None   # device int32 [2]: rows re-ranked in fp64 by the last search (all codes, candidate list)
 
     # -- search -------------------------------------------------------------------------------------
     def _codebook(self):
@@ -91,7 +91,13 @@ class VQEmbedding(nn.Embedding):
         k, d = self.n_embed, self.weight.shape[-1]
         vectors = vectors.reshape(-1, d)
         idxs = idxs.reshape(-1)
-        stats = K.vq_ema_stats(vectors, idxs, k)                      # [K, D+1] = (sums | count)
+        # the exchanged buffers are persistent (one pair per module): stable addresses for RCCL and for a recorded step
+        xb = getattr(self, "_xchg", None)
+        if xb is None or xb[0].device != vectors.device:
+            xb = (torch.empty(k, d + 1, dtype=torch.float32, device=vectors.device),
+                  torch.empty(k, d, dtype=torch.float32, device=vectors.device))
+            self._xchg = xb
+        stats = K.vq_ema_stats(vectors, idxs, k, out=xb[0])           # [K, D+1] = (sums | count)
         restart = None
         if self.restart_unused_codes:
             n = vectors.shape[0]
@@ -107,7 +113,7 @@ class VQEmbedding(nn.Embedding):
                 perm = self.restart_perm.to(vectors.device)[:k]
             else:
                 perm = K.sample_rows(k, n, self._rng(vectors.device))     # = randperm(n)[:k]: k distinct rows
-            restart = K.vq_embed(src.contiguous(), perm)
+            restart = K.vq_embed(src.contiguous(), perm, out=xb[1])
         stats, restart = self._exchange(stats, restart)
         K.vq_ema_apply(stats, restart, self.decay, self.eps, self.cluster_size_ema, self.embed_ema, self.weight.data)
         self._cb_version += 1

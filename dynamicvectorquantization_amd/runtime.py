@@ -115,6 +115,7 @@ def impl_ctx(v: int):
 # the remembered callables run in recorded order.  Outside a capture `graph_break(fn)` is just `fn()`.
 # ---------------------------------------------------------------------------------------------------------------
 _capture = None
+_GRAPH_DEBUG = os.environ.get("DVQ_GRAPH_DEBUG", "0") == "1"
 
 
 def capturing() -> bool:
@@ -141,7 +142,12 @@ class StepGraph:
         # RCCL's watchdog thread polls events while we capture: only this thread's unsafe calls may invalidate the capture
         self._mode = "thread_local"
 
+    def _dbg(self, *a):
+        if _GRAPH_DEBUG:
+            print("[stepgraph]", *a, flush=True)
+
     def _begin(self):
+        self._dbg("begin segment", len(self.items))
         g = torch.cuda.CUDAGraph()
         g.capture_begin(pool=self.pool, capture_error_mode=self._mode)
         self._g = g
@@ -154,7 +160,11 @@ class StepGraph:
 
     def brk(self, fn):
         self._end()
+        self._dbg("eager item", len(self.items), getattr(fn, "__qualname__", fn))
         out = fn()
+        if _GRAPH_DEBUG:
+            torch.cuda.synchronize(self.device)
+            self._dbg("eager item done")
         self.items.append(("eager", fn))
         self._begin()
         return out
@@ -188,11 +198,14 @@ class StepGraph:
         torch.cuda.synchronize(self.device)
 
     def replay(self):
-        for kind, it in self.items:
+        for i, (kind, it) in enumerate(self.items):
             if kind == "graph":
                 it.replay()
             else:
                 it()
+            if _GRAPH_DEBUG:                     # localise a faulting segment: finish every item before the next one
+                torch.cuda.synchronize(self.device)
+                self._dbg("replayed item", i, kind)
 
     def n_segments(self):
         return sum(1 for k, _ in self.items if k == "graph")

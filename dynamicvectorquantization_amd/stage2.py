@@ -3,7 +3,9 @@
 Mirrors /root/reference/modules/dynamic_modules/permuter.py:6-135 (DualGrainSeperatePermuter) and
 modules/dynamic_modules/label_provider.py:4-92 (SOS providers).  The permutation is integer compaction / scatter work done
 by dvq_permute_dual / dvq_permute_dual_back (one workgroup per image); results are bit-exact with the reference, including
-its sequential edge semantics (missing EOS, duplicate positions).  StackGPT itself (stackgpt.py) is not on the HIP path yet.
+its sequential edge semantics (missing EOS, duplicate positions).  The transformer itself (`stackgpt.StackGPT`: fused causal
+attention, LayerNorm / GELU / embedding / cross-entropy kernels, K/V-cached graph-replayed sampling) and `Dualformer` (below) run on
+the same library.
 """
 from __future__ import annotations
 

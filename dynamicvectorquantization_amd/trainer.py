@@ -229,6 +229,9 @@ class GradBuckets:
 
     def wait(self):
         """make the current stream wait for every exchange launched so far (eager; a graph break inside a capture)"""
+        if not self._active():
+            return
+
         def _wait():
             for w in self._pending:
                 if w is not None:
@@ -423,37 +426,108 @@ class Trainer:
             if lo == 0 and 0 < hi < n:
                 m._grad_hook = lambda tag: gb.reduce_range(hi, n) if tag == "decoder_side_done" else None
 
-    # ---- checkpoint / resume (train.py:153-185, 270 + `-r`: Lightning's last.ckpt carries the model state_dict, the optimizer
-    # and scheduler states and the global step; same top-level keys here so that `state_dict` stays loadable by the reference) ----
+    # ---- checkpoint / resume (train.py:153-185, 270 + `-r`) --------------------------------------------------------------------
+    # Lightning's last.ckpt layout: {"state_dict", "optimizer_states": [torch Optimizer.state_dict()...], "lr_schedulers",
+    # "global_step", "epoch"}.  The optimizer states are written in torch's own format (per-parameter exp_avg / exp_avg_sq in
+    # the parameter's logical shape, indices over the optimizer's full parameter list, `param_groups`), so the file resumes
+    # here AND under the reference; the round-1 private format ({"step","exp_avg","exp_avg_sq"} over the flat buffer) still loads.
+    def _optimizer_state_dict(self, o):
+        st, flat = o._fstate, o.flat
+        offs, off = {}, 0
+        for p in flat.params:
+            offs[id(p)] = off
+            off += p.numel()
+        state, groups, idx = {}, [], 0
+        for g in o.param_groups:
+            ids = []
+            for p in g["params"]:
+                if id(p) in offs and st["step"] > 0:
+                    state[idx] = {"step": torch.tensor(float(st["step"])),
+                                  "exp_avg": FlatParams._view(st["m"], offs[id(p)], p).detach().cpu().contiguous().clone(),
+                                  "exp_avg_sq": FlatParams._view(st["v"], offs[id(p)], p).detach().cpu().contiguous().clone()}
+                ids.append(idx)
+                idx += 1
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def _load_optimizer_state(self, o, sd):
+        st, flat = o._fstate, o.flat
+        if "state" not in sd:                             # round-1 private format: flat buffers
+            n = st["m"].numel()
+            if sd["exp_avg"].numel() != n or sd["exp_avg_sq"].numel() != n:
+                raise ValueError(f"optimizer state holds {sd['exp_avg'].numel()} elements, this optimizer has {n} "
+                                 "(a different parameter set, e.g. disc_factor=0 dropping the discriminator?)")
+            st["step"] = int(sd["step"])
+            st["m"].copy_(sd["exp_avg"].to(st["m"].device))
+            st["v"].copy_(sd["exp_avg_sq"].to(st["v"].device))
+            return
+        offs, off = {}, 0
+        for p in flat.params:
+            offs[id(p)] = off
+            off += p.numel()
+        full = [p for g in o.param_groups for p in g["params"]]
+        n_saved = sum(len(g["params"]) for g in sd.get("param_groups", []))
+        if n_saved and n_saved != len(full):
+            raise ValueError(f"optimizer state lists {n_saved} parameters, this optimizer has {len(full)}")
+        step = 0
+        st["m"].zero_()
+        st["v"].zero_()
+        for idx, p in enumerate(full):
+            ps = sd["state"].get(idx, sd["state"].get(str(idx)))
+            if ps is None or id(p) not in offs:
+                continue
+            if tuple(ps["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state of parameter {idx}: shape {tuple(ps['exp_avg'].shape)} != {tuple(p.shape)}")
+            FlatParams._view(st["m"], offs[id(p)], p).copy_(ps["exp_avg"].to(st["m"].device))
+            FlatParams._view(st["v"], offs[id(p)], p).copy_(ps["exp_avg_sq"].to(st["v"].device))
+            step = max(step, int(float(ps["step"])))
+        st["step"] = step
+
     def state_dict(self):
-        opt_states = []
-        for o in self.opts:
-            st = o._fstate
-            opt_states.append({"step": int(st["step"]), "exp_avg": st["m"].detach().cpu(), "exp_avg_sq": st["v"].detach().cpu()})
         return {"state_dict": self.model.state_dict(), "global_step": int(self.model.global_step),
-                "optimizer_states": opt_states, "lr_schedulers": [s["scheduler"].state_dict() for s in self.scheds]}
+                "epoch": int(getattr(self.model, "current_epoch", 0)),
+                "optimizer_states": [self._optimizer_state_dict(o) for o in self.opts],
+                "lr_schedulers": [s["scheduler"].state_dict() for s in self.scheds]}
 
     @torch.no_grad()
     def load_state_dict(self, ckpt, strict=True):
         """resume: parameters are written THROUGH the flat-buffer views (copy_), the packed compute-dtype copies are
-        invalidated, Adam moments / step counts / LambdaLR positions restored when the checkpoint has them"""
+        invalidated, Adam moments / step counts / LambdaLR positions restored when the checkpoint has them (torch / Lightning
+        optimizer-state format or the round-1 flat format; a checkpoint whose optimizers do not match raises)"""
         self.model.load_state_dict(ckpt["state_dict"], strict=strict)
         for b in self.buckets:
             b.fp.attach_grads()
         rt.bump_weights_epoch()
-        for o, st in zip(self.opts, ckpt.get("optimizer_states", [])):
-            o._fstate["step"] = int(st["step"])
-            o._fstate["m"].copy_(st["exp_avg"].to(o._fstate["m"].device))
-            o._fstate["v"].copy_(st["exp_avg_sq"].to(o._fstate["v"].device))
-        for s, st in zip(self.scheds, ckpt.get("lr_schedulers", [])):
+        saved = ckpt.get("optimizer_states", [])
+        if saved and len(saved) != len(self.opts):
+            import warnings
+            warnings.warn(f"checkpoint has {len(saved)} optimizer states, the model configures {len(self.opts)}: "
+                          "optimizer moments are NOT restored (weights are)")
+            saved = []
+        for o, st in zip(self.opts, saved):
+            self._load_optimizer_state(o, st)
+            o._prepared = False
+        for s, st in zip(self.scheds, ckpt.get("lr_schedulers", []) if saved else []):
             s["scheduler"].load_state_dict(st)
             for g, lr in zip(s["scheduler"].optimizer.param_groups, s["scheduler"].get_last_lr()):
                 g["lr"] = lr
         self.model.global_step = int(ckpt.get("global_step", 0))
 
-    def fit(self, batch_fn):
+    def save_checkpoint(self, path):
+        """atomic write (temp file + rename): a crash while saving never destroys the previous last.ckpt"""
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        tmp = path + ".tmp"
+        torch.save(self.state_dict(), tmp)
+        os.replace(tmp, path)
+
+    def fit(self, batch_fn, ckpt_path=None, save_every=0, is_rank0=True):
+        """`ckpt_path` + `save_every` (steps): rank 0 rewrites last.ckpt periodically, so a preempted run resumes with `-r`"""
         self.model.train()
         for step in range(int(self.model.global_step), self.max_steps):
             losses = self.train_step(batch_fn(step), step)
             if self.log_every and step % self.log_every == 0:
                 print(f"step {step}: " + " ".join(f"{float(l):.5f}" for l in losses), flush=True)
+            if ckpt_path and save_every and is_rank0 and (step + 1) % save_every == 0 and step + 1 < self.max_steps:
+                self.save_checkpoint(ckpt_path)
+        if ckpt_path and is_rank0:
+            self.save_checkpoint(ckpt_path)

@@ -49,8 +49,9 @@ size_t dvq_vq_prep_bytes(int64_t K, int64_t D);
 int dvq_vq_prepare(const float* codebook, int64_t K, int64_t D, void* prep, dvq_stream_t stream);
 
 /* idx[n] = argmin_k |x[n,:] - codebook[k,:]|^2.  x is [N,D] (row stride D) of `x_dtype`.
- * ws: dvq_vq_argmin_workspace_bytes(N) bytes.  impl: 0 = auto, 1 = force generic VALU kernel,
- * 2 = force MFMA kernel (DVQ_ESHAPE if unsupported). */
+ * ws: dvq_vq_argmin_workspace_bytes(N) bytes; after the call its first two int32 hold the number of rows that were
+ * re-ranked in fp64 over all K codes and over their short candidate list.  impl: 0 = auto, 1 = force generic VALU
+ * kernel, 2 = force MFMA kernel (DVQ_ESHAPE if unsupported). */
 size_t dvq_vq_argmin_workspace_bytes(int64_t N);
 int dvq_vq_argmin(const void* x, int x_dtype, const float* codebook, const void* prep, int64_t N, int64_t K,
                   int64_t D, int64_t* idx, void* ws, int impl, dvq_stream_t stream);

@@ -38,8 +38,16 @@ def test_vq_argmin_golden(dev, ci, impl):
     idx = idx.cpu().numpy()
     exact = g[f"case{ci}_exact_idx"]
     assert np.array_equal(idx, exact), f"{(idx != exact).sum()} / {n} rows differ from the exact argmin"
+    # ... and versus the REFERENCE's own CPU indices (VQEmbedding.find_nearest_embedding, fp32 addmm): the device result may
+    # differ only where the reference's answer is fp32 rounding noise -- at most 2 rows per case, each a near tie whose
+    # exact best / second-best gap (recorded in the fixture) is below 4e-7 * (|x|^2 + 1)
+    ref = g[f"case{ci}_ref_idx"]
+    bad = np.nonzero(idx != ref)[0]
+    assert len(bad) <= 2, f"{len(bad)} rows differ from the reference indices"
+    scale = (x[bad].astype(np.float64) ** 2).sum(axis=1) + 1.0
+    assert np.all(g[f"case{ci}_gap"][bad] < 4e-7 * scale), (g[f"case{ci}_gap"][bad], scale)
     if impl == 0 and d in (64, 128, 256):
-        frac = int(flagged.item()) / n
+        frac = int(flagged.sum().item()) / n
         assert frac < 0.2, f"fp64 re-rank fraction {frac} unexpectedly high"
 
 
@@ -49,18 +57,26 @@ def test_vq_argmin_ties(dev):
     for impl in (0, 1):
         idx = K.vq_argmin(T(g["tie_x"], dev), T(g["tie_cb"], dev), impl=impl).cpu().numpy()
         assert np.array_equal(idx, g["tie_exact_idx"])
+        # exact ties are where the reference (first minimum of its fp32 distances) is BLAS-noise dependent: at most one row
+        assert (idx != g["tie_ref_idx"]).sum() <= 1
     # duplicated codes on the MFMA path (D = 64)
     rs = np.random.RandomState(5)
     cb = rs.standard_normal((96, 64)).astype(np.float32)
     cb[50] = cb[3]
     cb[95] = cb[3]
+    cb[67] = cb[3]          # 64 apart: same residue class mod 32 as code 3 -> two candidates in one lane (full re-rank path)
+    cb[40] = cb[8] + np.float32(1e-7)   # near-duplicate in the same class
     x = rs.standard_normal((300, 64)).astype(np.float32)
     x[:10] = cb[3] + 1e-3 * rs.standard_normal((10, 64)).astype(np.float32)
     from oracle import vq as ovq
     exact = ovq.argmin_exact(x, cb)
-    idx = K.vq_argmin(T(x, dev), T(cb, dev), impl=2).cpu().numpy()
+    x[10:20] = cb[8] + 1e-3 * rs.standard_normal((10, 64)).astype(np.float32)
+    exact = ovq.argmin_exact(x, cb)
+    idx, flagged = K.vq_argmin(T(x, dev), T(cb, dev), impl=2, return_flagged=True)
+    idx = idx.cpu().numpy()
     assert np.array_equal(idx, exact)
     assert np.all(idx[:10] == 3)
+    assert int(flagged[0]) >= 10            # the rows nearest to the same-class duplicates took the all-codes re-rank
 
 
 @pytest.mark.parametrize("k", [1024, 8192])
@@ -76,7 +92,9 @@ def test_vq_argmin_full_size_properties(dev, k):
         idx = idx.cpu().numpy()
         sample = np.random.RandomState(1).choice(n, 2048, replace=False)
         assert np.array_equal(idx[sample], ovq.argmin_exact(x[sample], cb))
-        assert int(flagged.item()) < 0.1 * n
+        assert int(flagged.sum().item()) < 0.1 * n
+        # ambiguous rows are settled among their few candidate codes; the all-codes re-rank is the rare exception
+        assert int(flagged[0]) <= 0.25 * int(flagged.sum()) + 16, flagged.cpu().numpy()
         # idempotence: quantising code vectors returns their own index
         self_idx = K.vq_argmin(cbt, cbt, impl=2).cpu().numpy()
         assert np.array_equal(self_idx, np.arange(k))

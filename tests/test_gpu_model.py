@@ -173,7 +173,15 @@ def test_trainer_checkpoint_resume(dev):
         for i in range(2):
             tr.train_step({"image": xs[i]}, i)
         ckpt = copy.deepcopy(tr.state_dict())
-        assert ckpt["global_step"] == 2 and len(ckpt["optimizer_states"]) == 2 and ckpt["optimizer_states"][0]["step"] == 2
+        assert ckpt["global_step"] == 2 and len(ckpt["optimizer_states"]) == 2
+        # optimizer states are written in torch's own (= Lightning's) format: they load into a plain torch.optim.Adam built
+        # over the same parameter list, i.e. the reference can resume from this file
+        os0 = ckpt["optimizer_states"][0]
+        assert float(os0["state"][0]["step"]) == 2 and os0["param_groups"][0]["betas"] == (0.5, 0.9)
+        probe = torch.optim.Adam([torch.nn.Parameter(torch.empty_like(p_)) for p_ in model.ae_parameters()], lr=1e-3, betas=(0.5, 0.9))
+        probe.load_state_dict(copy.deepcopy(os0))
+        n_state = sum(1 for p_ in model.ae_parameters() if p_.requires_grad)
+        assert len(os0["state"]) == n_state and tuple(os0["state"][0]["exp_avg"].shape) == tuple(model.ae_parameters()[0].shape)
         ref_losses = [[float(l) for l in tr.train_step({"image": xs[i]}, i)] for i in (2, 3)]
         ref_w = model.decoder.conv_out.weight.detach().float().cpu().clone()
         ref_lr = [g["lr"] for o in tr.opts for g in o.param_groups]
@@ -190,9 +198,19 @@ def test_trainer_checkpoint_resume(dev):
         assert list(sd2.keys()) == list(ckpt["state_dict"].keys())
         for k_, v_ in ckpt["state_dict"].items():
             assert torch.equal(sd2[k_].detach().cpu(), v_.detach().cpu()), k_
-        for o2, st in zip(tr2.opts, ckpt["optimizer_states"]):
-            assert o2._fstate["step"] == st["step"]
-            assert torch.equal(o2._fstate["m"].cpu(), st["exp_avg"]) and torch.equal(o2._fstate["v"].cpu(), st["exp_avg_sq"])
+        for o2, o1, st in zip(tr2.opts, tr.opts, ckpt["optimizer_states"]):
+            assert o2._fstate["step"] == 2
+            back = tr2._optimizer_state_dict(o2)
+            assert sorted(back["state"].keys()) == sorted(st["state"].keys())
+            for i_, ps in st["state"].items():
+                assert torch.equal(back["state"][i_]["exp_avg"], ps["exp_avg"]) and torch.equal(back["state"][i_]["exp_avg_sq"], ps["exp_avg_sq"])
+        # the round-1 flat format still loads; a mismatching parameter set is refused instead of silently truncated
+        legacy = {"step": 2, "exp_avg": tr.opts[0]._fstate["m"].cpu() * 0 + 1.0, "exp_avg_sq": tr.opts[0]._fstate["v"].cpu() * 0 + 2.0}
+        tr2._load_optimizer_state(tr2.opts[0], legacy)
+        assert float(tr2.opts[0]._fstate["m"].mean()) == 1.0 and float(tr2.opts[0]._fstate["v"].mean()) == 2.0
+        with pytest.raises(ValueError):
+            tr2._load_optimizer_state(tr2.opts[0], {"step": 2, "exp_avg": torch.zeros(5), "exp_avg_sq": torch.zeros(5)})
+        tr2.load_state_dict(ckpt)
         got_lr_now = [g["lr"] for o in tr2.opts for g in o.param_groups]
         got_losses = [[float(l) for l in tr2.train_step({"image": xs[i]}, i)] for i in (2, 3)]
         got_lr = [g["lr"] for o in tr2.opts for g in o.param_groups]

@@ -43,7 +43,19 @@ def get_parser():
     p.add_argument("--synthetic", action="store_true", default=True)
     p.add_argument("--precision", type=str, default="bf16", help="compute dtype of the HIP path: bf16 | fp32")
     p.add_argument("--logdir", type=str, default="logs")
+    p.add_argument("--save_every", type=int, default=0,
+                   help="rewrite checkpoints/last.ckpt every N steps (0: once per epoch) -- atomic, rank 0 only")
     return p
+
+
+def _gpu_ids(spec: str, n_visible: int):
+    """--gpus: "-1" = all visible devices, "N" = devices 0..N-1, "a,b,c" = exactly those device ids (train.py:61-62, Lightning)"""
+    spec = spec.strip()
+    if spec == "-1":
+        return list(range(n_visible))
+    if "," in spec:
+        return [int(g) for g in spec.split(",") if g.strip() != ""]
+    return list(range(int(spec)))
 
 
 def run(rank, world, opt, unknown):
@@ -58,7 +70,12 @@ def run(rank, world, opt, unknown):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(rank % max(1, torch.cuda.device_count()))
+    if "LOCAL_RANK" in os.environ:                    # torchrun: the launcher's local rank is the device
+        device_id = int(os.environ["LOCAL_RANK"])
+    else:                                             # own spawn: rank r drives the r-th id of --gpus
+        ids = _gpu_ids(opt.gpus, torch.cuda.device_count())
+        device_id = ids[rank] if rank < len(ids) else rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device_id)
     dev = torch.device("cuda", torch.cuda.current_device())
     rt.set_compute_dtype(opt.precision)
     torch.manual_seed(opt.seed)
@@ -67,7 +84,34 @@ def run(rank, world, opt, unknown):
     ignored = [u for u in unknown if u not in dot]
     if ignored and rank == 0:
         print(f"[train.py] ignoring unsupported Trainer flags: {ignored}")
+    # -r <logdir | checkpoint>: continue IN that logdir with the configs it saved (train.py:73-89 of the reference), -b adds to them
+    resume_ckpt, logdir = None, None
+    if opt.resume:
+        if os.path.isfile(opt.resume):
+            resume_ckpt = opt.resume
+            logdir = os.path.dirname(os.path.dirname(os.path.abspath(opt.resume)))
+        else:
+            logdir = opt.resume.rstrip("/")
+            resume_ckpt = os.path.join(logdir, "checkpoints", "last.ckpt")
+        saved_cfgs = sorted(os.path.join(logdir, "configs", f) for f in os.listdir(os.path.join(logdir, "configs"))) \
+            if os.path.isdir(os.path.join(logdir, "configs")) else []
+        opt.base = saved_cfgs + list(opt.base)
+    if not opt.base:
+        raise SystemExit("-b/--base <config.yaml> is required (or -r <logdir> holding configs/)")
     config = cfg.merge(*[cfg.load_yaml(b) for b in opt.base], cfg.from_dotlist(dot))
+    if logdir is None:
+        now = datetime.datetime.now().strftime("%Y-%m-%dT%H-%M-%S")
+        logdir = os.path.join(opt.logdir, now + ("_" + opt.name if opt.name else "") + opt.postfix)
+    if world > 1:            # every rank must agree on the directory name (timestamps differ): rank 0's wins
+        names = [logdir]
+        dist.broadcast_object_list(names, src=0)
+        logdir = names[0]
+    ckpt_path = os.path.join(logdir, "checkpoints", "last.ckpt")
+    if rank == 0 and not opt.resume:
+        os.makedirs(os.path.join(logdir, "configs"), exist_ok=True)
+        import yaml
+        with open(os.path.join(logdir, "configs", "project.yaml"), "w") as f:
+            yaml.safe_dump(cfg.to_plain(config), f)
     model = cfg.instantiate_from_config(config.model).to(dev)
 
     bs = config.data.params.batch_size
@@ -103,18 +147,15 @@ def run(rank, world, opt, unknown):
             batch["class_label"] = torch.randint(0, n_classes, (bs,), generator=g).to(dev)
         return batch
 
-    if opt.resume:                                   # -r <logdir | checkpoint> (train.py:73-89 of the reference)
-        path = opt.resume if os.path.isfile(opt.resume) else os.path.join(opt.resume, "checkpoints", "last.ckpt")
-        trainer.load_state_dict(torch.load(path, map_location="cpu"))
+    if resume_ckpt:
+        trainer.load_state_dict(torch.load(resume_ckpt, map_location="cpu", weights_only=False))
         if rank == 0:
-            print(f"resumed from {path} at global step {model.global_step}")
-    trainer.fit(batch_fn)
+            print(f"resumed from {resume_ckpt} at global step {model.global_step}")
+    # last.ckpt is rewritten (atomically, rank 0) every --save_every steps / once per epoch and at the end: a crashed or
+    # preempted run continues with `-r <logdir>`
+    trainer.fit(batch_fn, ckpt_path=ckpt_path, save_every=opt.save_every or opt.steps_per_epoch, is_rank0=rank == 0)
     if rank == 0:
-        now = datetime.datetime.now().strftime("%Y-%m-%dT%H-%M-%S")
-        ckptdir = os.path.join(opt.logdir, now + ("_" + opt.name if opt.name else "") + opt.postfix, "checkpoints")
-        os.makedirs(ckptdir, exist_ok=True)
-        torch.save(trainer.state_dict(), os.path.join(ckptdir, "last.ckpt"))
-        print("saved", os.path.join(ckptdir, "last.ckpt"))
+        print("saved", ckpt_path)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -122,13 +163,12 @@ def run(rank, world, opt, unknown):
 
 def main():
     opt, unknown = get_parser().parse_known_args()
-    if not opt.base:
+    if not opt.base and not opt.resume:
         raise SystemExit("-b/--base <config.yaml> is required")
     import torch
     if "WORLD_SIZE" in os.environ:          # launched by torchrun
         return run(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), opt, unknown)
-    ngpu = torch.cuda.device_count() if opt.gpus.strip() == "-1" else (
-        len([g for g in opt.gpus.split(",") if g.strip() != ""]) if "," in opt.gpus else int(opt.gpus))
+    ngpu = len(_gpu_ids(opt.gpus, torch.cuda.device_count()))
     if ngpu <= 1:
         return run(0, 1, opt, unknown)
     import torch.multiprocessing as mp
