@@ -140,7 +140,12 @@ def load():
     return lib
 
 
+_launch_hook = None          # debugging (runtime.StepGraph, DVQ_GRAPH_DEBUG): called with the entry-point name after every call
+
+
 def check(rc: int, what: str = ""):
+    if _launch_hook is not None:
+        _launch_hook(what)
     if rc != 0:
         msg = load().dvq_last_error().decode("utf-8", "replace")
         raise DvqError(f"{what or 'libdvq_hip'} failed (code {rc}): {msg}")

@@ -40,6 +40,22 @@ __host__ __device__ inline VqPrepView prep_view(void* prep, int64_t K, int64_t D
     return v;
 }
 
+// Zero fill as a KERNEL (16-byte aligned buffers, nbytes % 16 == 0).  hipMemsetAsync is avoided on purpose: inside a captured
+// training step it becomes a memset graph node, and replays of multi-segment captures faulted in exactly the segments that
+// carried them (a stale re-rank counter read as a row count) -- a kernel node is ordered like every other launch.
+__global__ __launch_bounds__(256) void vq_zero_kernel(uint4* __restrict__ p, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+}
+__global__ void vq_zero_tail_kernel(float* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
+static inline void vq_zero(void* p, int64_t nbytes, hipStream_t s) {
+    const int64_t n16 = nbytes / 16;
+    int64_t blocks = (n16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    vq_zero_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((uint4*)p, n16);
+}
+
 // one wave per (padded) code
 __global__ void vq_prepare_kernel(const float* __restrict__ cb, int64_t K, int64_t D, void* prep) {
     VqPrepView pv = prep_view(prep, K, D);
@@ -567,10 +583,8 @@ static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_
     DVQ_REQUIRE(!(impl == 2 && !mfma_ok), DVQ_ESHAPE, "dvq_vq_argmin: MFMA path needs D in {64,128,256} and prep");
     const bool use_mfma = impl == 2 || (impl == 0 && mfma_ok);
     if (use_mfma) {
-        if (hipMemsetAsync(ws, 0, 256, s) != hipSuccess) {
-            dvq_set_error("dvq_vq_argmin: memset failed");
-            return DVQ_ELAUNCH;
-        }
+        vq_zero(ws, 256, s);
+        DVQ_CHECK_LAUNCH("vq_zero");
         dim3 grid((unsigned)cdiv64(N, 128)), block(256);
         auto launch = [&](auto ksteps) {
             constexpr int KS = decltype(ksteps)::value;
@@ -610,10 +624,8 @@ size_t dvq_vq_prep_bytes(int64_t K, int64_t D) {
 int dvq_vq_prepare(const float* codebook, int64_t K, int64_t D, void* prep, dvq_stream_t stream) {
     DVQ_REQUIRE(codebook && prep && K > 0 && D > 0, DVQ_EINVAL, "dvq_vq_prepare: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(prep, 0, 256, s) != hipSuccess) {
-        dvq_set_error("dvq_vq_prepare: memset failed");
-        return DVQ_ELAUNCH;
-    }
+    vq_zero(prep, 256, s);
+    DVQ_CHECK_LAUNCH("vq_zero");
     int64_t Kp = align_up(K, 32);
     vq_prepare_kernel<<<dim3((unsigned)cdiv64(Kp, 4)), dim3(256), 0, s>>>(codebook, K, D, prep);
     DVQ_CHECK_LAUNCH("vq_prepare");
@@ -673,9 +685,11 @@ int dvq_vq_ema_stats(const void* x, int dtype, const int64_t* idx, int64_t N, in
     DVQ_REQUIRE(x && idx && stats, DVQ_EINVAL, "dvq_vq_ema_stats: null pointer");
     DVQ_REQUIRE(D <= 1024, DVQ_ESHAPE, "dvq_vq_ema_stats: D > 1024 unsupported");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(stats, 0, (size_t)K * (D + 1) * sizeof(float), s) != hipSuccess) {
-        dvq_set_error("dvq_vq_ema_stats: memset failed");
-        return DVQ_ELAUNCH;
+    {   // K * (D + 1) floats need not be a multiple of 16 bytes: bulk by the vector kernel, the tail by hand below
+        const int64_t nb = K * (D + 1) * (int64_t)sizeof(float);
+        vq_zero(stats, nb / 16 * 16, s);
+        if (nb % 16) vq_zero_tail_kernel<<<dim3(1), dim3(64), 0, s>>>(stats + (nb / 16 * 16) / 4, (int)((nb % 16) / 4));
+        DVQ_CHECK_LAUNCH("vq_zero");
     }
     dim3 grid((unsigned)K, (unsigned)cdiv64(N, EMA_SLICE));
     DVQ_REQUIRE(grid.y <= 65535, DVQ_ESHAPE, "dvq_vq_ema_stats: N too large");

@@ -125,6 +125,8 @@ class VQEmbedding(nn.Embedding):
         Device-agnostic (tested on CPU tensors over gloo)."""
         if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_DP):
             def exchange():          # eager even inside a captured training step (runtime.graph_break)
+                if os.environ.get("DVQ_DP_NOOP_COLLECTIVES", "0") == "1":
+                    return
                 dist.all_reduce(stats, op=dist.ReduceOp.SUM)
                 if restart is not None:
                     dist.broadcast(restart, 0)

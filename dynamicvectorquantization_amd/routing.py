@@ -38,7 +38,7 @@ class _FeatureRouter(nn.Module):
         else:
             raise NotImplementedError()
         self.normalization_type = normalization_type
-        for name in self.HEADS:
+        for name in reversed(self.HEADS):          # registration (= state_dict) order of the reference: fine first
             if normalization_type == "none":
                 setattr(self, f"feature_norm_{name}", nn.Identity())
             elif "group" in normalization_type:

@@ -116,6 +116,8 @@ def impl_ctx(v: int):
 # ---------------------------------------------------------------------------------------------------------------
 _capture = None
 _GRAPH_DEBUG = os.environ.get("DVQ_GRAPH_DEBUG", "0") == "1"
+_BREAK_EVERY = int(os.environ.get("DVQ_GRAPH_BREAK_EVERY", "0"))
+_SEPARATE_POOLS = os.environ.get("DVQ_GRAPH_SEPARATE_POOLS", "0") == "1"     # experiment: one private pool per segment
 
 
 def capturing() -> bool:
@@ -146,19 +148,38 @@ class StepGraph:
         if _GRAPH_DEBUG:
             print("[stepgraph]", *a, flush=True)
 
+    def _on_launch(self, what):
+        """debugging: library calls of the current segment; DVQ_GRAPH_BREAK_EVERY=N cuts a segment every N calls so that a
+        faulting replay can be narrowed down to a handful of launches"""
+        self._names.append(what)
+        if _BREAK_EVERY and len(self._names) >= _BREAK_EVERY and not self._in_brk:
+            self.brk(lambda: None)
+
     def _begin(self):
         self._dbg("begin segment", len(self.items))
+        self._names = []
         g = torch.cuda.CUDAGraph()
+        if _SEPARATE_POOLS:
+            self.pool = torch.cuda.graph_pool_handle()
         g.capture_begin(pool=self.pool, capture_error_mode=self._mode)
         self._g = g
         self._tick.add_(1)
 
     def _end(self):
         self._g.capture_end()
+        if _GRAPH_DEBUG:
+            self._dbg("segment", len(self.items), "calls:", " ".join(getattr(self, "_names", [])))
         self.items.append(("graph", self._g))
         self._g = None
 
     def brk(self, fn):
+        self._in_brk = True
+        try:
+            return self._brk(fn)
+        finally:
+            self._in_brk = False
+
+    def _brk(self, fn):
         self._end()
         self._dbg("eager item", len(self.items), getattr(fn, "__qualname__", fn))
         out = fn()
@@ -179,6 +200,10 @@ class StepGraph:
         gc.collect()
         torch.cuda.empty_cache()
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        from . import _lib
+        if _GRAPH_DEBUG:
+            _lib._launch_hook = self._on_launch
+        self._in_brk, self._names = False, []
         with torch.cuda.stream(self.stream):
             _capture = self
             ok = False
@@ -188,6 +213,7 @@ class StepGraph:
                 ok = True
             finally:
                 _capture = None
+                _lib._launch_hook = None
                 if self._g is not None:
                     try:
                         self._end()

@@ -84,6 +84,11 @@ def half_flat_images(batch: int, size: int = 256, patch: int = 16, seed: int = 1
     return out
 
 
+def ragged_grain_images(size: int = 64, seed: int = 31, fractions=(0.5, 0.25, 0.875)) -> np.ndarray:
+    """one image per fine-patch fraction: their coarse / fine code streams have different lengths (ragged stage-2 batches)"""
+    return np.concatenate([half_flat_images(1, size, seed=seed + i, fine_fraction=f) for i, f in enumerate(fractions)], 0)
+
+
 def vq_inputs(n: int, dim: int, k: int, dist: str = "normal", seed: int = 0):
     """VQ micro-benchmark inputs: x [n,dim], codebook [k,dim], fp32.
 

@@ -22,6 +22,8 @@ from . import kernels as K
 from . import runtime as rt
 
 _FORCE_DP = os.environ.get("DVQ_FORCE_DP", "0") == "1"
+_NOOP_COLL = os.environ.get("DVQ_DP_NOOP_COLLECTIVES", "0") == "1"      # debugging: exchange points without the RCCL calls
+_NO_HOOK = os.environ.get("DVQ_DP_NO_HOOK", "0") == "1"                 # debugging: no all-reduce launch from inside the backward
 
 
 # ---- LR schedules (models/stage1/utils.py:6-24) ----------------------------------------------------
@@ -202,6 +204,9 @@ class GradBuckets:
         chunks = [self.fp.flat_g[a:min(hi, a + step)] for a in range(lo, hi, step)]
 
         def launch():        # eager even when the step is being captured (rt.graph_break): RCCL runs on its own stream
+            if _NOOP_COLL:
+                self.launched += len(chunks)
+                return
             for c in chunks:
                 self._pending.append(dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             self.launched += len(chunks)
@@ -420,7 +425,7 @@ class Trainer:
             return
         m._grad_hook = None
         gb = self.buckets[oi]
-        if oi == 0 and gb._active() and hasattr(m, "encoder"):
+        if oi == 0 and gb._active() and hasattr(m, "encoder") and not _NO_HOOK:
             lo, hi = gb.param_range([p for p in m.encoder.parameters() if p.requires_grad])
             n = gb.fp.flat_g.numel()
             if lo == 0 and 0 < hi < n:

@@ -1,4 +1,6 @@
 """GPU parity of the stage-2 input permutation (integer work: bit-exact) against the reference goldens and the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -160,6 +162,62 @@ def dualformer_config():
             coarse_hw=4, fine_hw=8, content_pad_code=512, content_eos_code=513, coarse_position_pad_code=16,
             coarse_position_eos_code=17, fine_position_pad_code=64, fine_position_eos_code=65, fine_position_order="region-first")},
         weight_decay=0.01, warmup_epochs=0)}
+
+
+@pytest.mark.parametrize("kind", ["uncond", "class"])
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 3e-4, 6e-3), (torch.bfloat16, 3e-2, 1e-1)])
+def test_dualformer_forward_golden(dev, kind, dtype, tol, gtol):
+    """Dualformer.training_step of BOTH stage-2 models (uncond: dqtransformer_uncond_entropy.py:180-234, class-conditional:
+    dqtransformer_class2_entropy.py) against the reference on a ragged image batch: frozen DQ-VAE -> codes -> permuter ->
+    start tokens -> StackGPT.  Sequences bit-exact, the four losses + training loss, transformer gradients, state_dict layout."""
+    from conftest import REPO
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    from golden_cfg import dualformer_cfg
+    from test_oracle_golden import dqvae_state_dict
+    g = load_golden("dualformer")
+    thr_json = os.path.join(REPO, "scripts/tools/thresholds/entropy_thresholds_imagenet_train_patch-16.json")
+    target = {"uncond": "models.stage2_dynamic.dqtransformer_uncond_entropy.Dualformer",
+              "class": "models.stage2_dynamic.dqtransformer_class2_entropy.Dualformer"}[kind]
+    with rt.compute_dtype_ctx(dtype):
+        model = instantiate_from_config({"target": target, "params": dualformer_cfg(kind, thr_json)}).to(dev)
+        # state_dict layout = the reference's, key by key (attention-mask buffers included)
+        own = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        ref = {str(k): tuple(int(x) for x in str(s).split(",")) if str(s) else () for k, s in zip(g[f"{kind}.state_keys"], g[f"{kind}.state_shapes"])}
+        assert own == ref, sorted(set(own) ^ set(ref))[:8]
+        fs_sd = dqvae_state_dict(load_golden("dqvae_small"), "spread", 512, 64)
+        model.first_stage_model.load_state_dict(fs_sd)
+        with torch.no_grad():
+            for n, p in model.transformer.named_parameters():
+                v = synth.det_param(f"dualformer.{kind}." + n, tuple(p.shape))
+                p.copy_(torch.from_numpy(v * (0.3 if n == "pos_emb" else 1.0)).to(dev))
+        rt.bump_weights_epoch()
+        model.train()
+        batch = {"image": torch.from_numpy(synth.ragged_grain_images(64, seed=31)).to(dev),
+                 "class_label": torch.tensor([3, 0, 9], dtype=torch.long, device=dev)}
+        with torch.no_grad():
+            _, z = model.encode_to_z(batch["image"])
+        if dtype == torch.float32:          # the frozen first stage's codes (hence every sequence) are exact in parity mode
+            for k in ("coarse_content", "fine_content", "coarse_position", "fine_position", "coarse_segment", "fine_segment"):
+                assert np.array_equal(z[k].cpu().numpy(), g[f"{kind}.z.{k}"]), k
+        else:                               # bf16 activations may flip a few near-tie codes; positions / lengths never change
+            for k in ("coarse_position", "fine_position", "coarse_segment", "fine_segment"):
+                assert np.array_equal(z[k].cpu().numpy(), g[f"{kind}.z.{k}"]), k
+            assert (z["fine_content"].cpu().numpy() != g[f"{kind}.z.fine_content"]).mean() < 0.05
+        total = model.training_step(batch, 0)
+        for k in ("content_loss", "position_loss", "coarse_position_loss", "fine_position_loss"):
+            np.testing.assert_allclose(float(model._logged["train_" + k]), float(g[f"{kind}.train_{k}"]), rtol=tol)
+        np.testing.assert_allclose(float(total.detach()), float(g[f"{kind}.total"]), rtol=tol)
+        np.testing.assert_allclose(float(model._logged["train_loss"]), float(g[f"{kind}.total"]), rtol=tol)
+        total.backward()
+        params = dict(model.transformer.named_parameters())
+        for key in [k for k in g.files if k.startswith(f"{kind}.grad.")]:
+            ref_g = g[key].astype(np.float64)
+            got = params[key[len(kind) + 6:]].grad.cpu().numpy().astype(np.float64).reshape(ref_g.shape)
+            err = float(np.linalg.norm(got - ref_g)) / max(1e-30, float(np.linalg.norm(ref_g)))
+            assert err < gtol, f"{key}: relative Frobenius error {err}"
+        assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in model.first_stage_model.parameters())
 
 
 def test_dualformer_train_steps_and_round_trip(dev):

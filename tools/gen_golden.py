@@ -797,9 +797,89 @@ def gen_sampler():
     np.savez_compressed(os.path.join(GOLD, "sampler.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from golden_cfg import DUALFORMER_NCLS, dualformer_cfg  # noqa: E402,F401  (shared with tests/test_gpu_stage2.py)
+
+
+def gen_dualformer():
+    """Dualformer.forward / training_step of BOTH stage-2 models (dqtransformer_uncond_entropy.py:180-234 and the class-conditional
+    dqtransformer_class2_entropy.py) on a fixed image batch: frozen DQ-VAE -> codes + grain map -> permuter -> start tokens ->
+    StackGPT -> four losses, the training loss and parameter gradients.  Every parameter is deterministic (synth.det_param by
+    state_dict key, the DQ-VAE's codebook is the `spread` one of dqvae_small.npz), so the fixture holds outputs only."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_oracle_golden import dqvae_state_dict
+    g_small = np.load(os.path.join(GOLD, "dqvae_small.npz"), allow_pickle=False)
+    out = {}
+    x = t(synth.ragged_grain_images(64, seed=31))           # 8 / 4 / 14 fine cells of 16: ragged streams
+    labels = torch.tensor([3, 0, 9], dtype=torch.long)
+    for kind in ("uncond", "class"):
+        if kind == "uncond":
+            from models.stage2_dynamic.dqtransformer_uncond_entropy import Dualformer
+        else:
+            from models.stage2_dynamic.dqtransformer_class2_entropy import Dualformer
+        model = Dualformer(**dualformer_cfg(kind))
+        model.first_stage_model.load_state_dict(dqvae_state_dict(g_small, "spread", 512, 64))
+        with torch.no_grad():
+            for n_, p in model.transformer.named_parameters():
+                v = synth.det_param(f"dualformer.{kind}." + n_, p.shape)
+                p.copy_(t(v * (0.3 if n_ == "pos_emb" else 1.0)))
+        model.train()
+        assert not model.first_stage_model.training
+        logged = {}
+        model.log = lambda name, value, **kw: logged.__setitem__(name, float(value))
+        batch = {"image": x, "class_label": labels}
+        total = model.training_step(batch, 0)
+        total.backward()
+        for k_, v_ in logged.items():
+            out[f"{kind}.{k_}"] = np.float32(v_)
+        out[f"{kind}.total"] = np.float32(total.item())
+        with torch.no_grad():
+            _, z = model.encode_to_z(x)
+        for k_ in ("coarse_content", "fine_content", "coarse_position", "fine_position", "coarse_segment", "fine_segment"):
+            out[f"{kind}.z.{k_}"] = z[k_].numpy()
+        names = ["content_emb.weight", "content_coarse_pos_emb.weight", "content_fine_pos_emb.weight", "pos_emb", "seg_emb.weight",
+                 "position_transformer.0.attn.key.weight", "position_transformer.1.mlp.0.weight", "content_transformer.1.attn.proj.weight",
+                 "content_transformer.0.ln1.weight", "position_head.1.weight", "content_head.1.weight"]
+        params = dict(model.transformer.named_parameters())
+        for n_ in names:
+            out[f"{kind}.grad.{n_}"] = params[n_].grad.numpy().astype(np.float32)
+        assert all(p.grad is None for p in model.first_stage_model.parameters())
+        # validation_step / eval forward of the same batch (no dropout anyway): the four losses again
+        sd = model.state_dict()
+        out[f"{kind}.state_keys"] = np.array(sorted(sd.keys()))
+        out[f"{kind}.state_shapes"] = np.array([",".join(map(str, sd[kk].shape)) for kk in sorted(sd.keys())])
+        lens = [(int((z["coarse_content"][i] != 512).sum()), int((z["fine_content"][i] != 512).sum())) for i in range(3)]
+        print(f"  dualformer {kind}: total {total.item():.5f}  stream lengths {lens}  logged {sorted(logged)}")
+    np.savez_compressed(os.path.join(GOLD, "dualformer.npz"), **out)
+
+
+def gen_ckpt_layout():
+    """Lightning checkpoints of the reference are {"state_dict": model.state_dict(), ...} (dqvae_dual_entropy.py:113-122 loads
+    them non-strict after dropping `ignore_keys`).  For every shipped stage-1 YAML, build the REFERENCE model from the reference's
+    own config file and record the complete key / shape / dtype list -- including `loss.discriminator.*` and
+    `loss.perceptual_loss.*` -- so that tests can prove (a) a reference-produced state_dict loads into this repo's classes and
+    (b) this repo's state_dict loads back into the reference's."""
+    import yaml
+    out = {}
+    for name in ("dqvae-entropy-dual-r05_imagenet", "dqvae-dual-r-05_imagenet", "dqvae-triple-r-03-03_imagenet"):
+        cfg = yaml.safe_load(open(os.path.join(REF, "configs", "stage1", name + ".yml")))
+        from utils.utils import instantiate_from_config
+        model = instantiate_from_config(cfg["model"])
+        sd = model.state_dict()
+        keys = list(sd.keys())                 # registration order (what torch.save writes)
+        out[name + ".keys"] = np.array(keys)
+        out[name + ".shapes"] = np.array([",".join(map(str, sd[k].shape)) for k in keys])
+        out[name + ".dtypes"] = np.array([str(sd[k].dtype).replace("torch.", "") for k in keys])
+        n_loss = sum(1 for k in keys if k.startswith("loss."))
+        print(f"  ckpt layout {name}: {len(keys)} entries ({n_loss} under loss.*), {sum(v.numel() for v in sd.values()) / 1e6:.1f} M elements")
+        del model, sd
+    np.savez_compressed(os.path.join(GOLD, "ckpt_layout.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter,stackgpt,sampler")
+    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter,stackgpt,sampler,dualformer,ckpt_layout")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -807,7 +887,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for name in args.only.split(","):
         print(f"[gen] {name}")
-        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter, "stackgpt": gen_stackgpt, "sampler": gen_sampler}[name]()
+        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter, "stackgpt": gen_stackgpt, "sampler": gen_sampler, "dualformer": gen_dualformer, "ckpt_layout": gen_ckpt_layout}[name]()
     print("done ->", GOLD)
 
 
