@@ -184,6 +184,47 @@ def _spawn_ranks(n):
     sys.exit(rc)
 
 
+def _dry_run(args, world, rank):
+    """the multi-rank launch contract without a GPU: rendezvous (gloo), W untimed + K timed no-op steps between barriers, max over
+    ranks, one JSON line from rank 0 -- what the driver's `--gpus N` command line exercises before any kernel runs"""
+    from dynamicvectorquantization_amd.trainer import reference_learning_rate
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    buf = torch.zeros(1 << 16)
+
+    def step():
+        buf.add_(1.0)
+        if world > 1:
+            dist.all_reduce(buf)
+            buf.div_(world)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": round(world * args.bs * args.steps / float(dt), 2), "unit": "images/sec",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(dt) / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                          "dry_run": True,
+                          "config": {"workload": "DRY RUN (no GPU work): launch / rendezvous / timing contract only",
+                                     "global_batch": world * args.bs, "parallelism": f"dp{world}",
+                                     "learning_rate": reference_learning_rate({"base_learning_rate": 4.5e-6}, world, args.bs)}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
         return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "full")
@@ -202,6 +243,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vq-microbench", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python (no hipGraph replay of the step)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU check of the launch contract only: gloo ranks, barrier + timed loop of no-op steps, one JSON line; no GPU work")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         return _spawn_ranks(args.gpus)
@@ -209,6 +252,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return _dry_run(args, world, rank)
     assert torch.cuda.is_available(), "bench.py measures the HIP path: an MI355X is required"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -238,7 +283,8 @@ def main():
         torch.manual_seed(0)       # identical initial weights on every rank
         model = instantiate_from_config(full_config(objective)).to(dev)
         model.reuse_generator_forward = bool(args.reuse_forward)
-        model.learning_rate = 4.5e-6 * args.bs * world     # train.py:248-257
+        from dynamicvectorquantization_amd.trainer import reference_learning_rate
+        model.learning_rate = reference_learning_rate({"base_learning_rate": 4.5e-6}, world, args.bs)     # train.py:248-257
         model.training_steps, model.steps_per_epoch = 100000, 1000
         model.train()
         GRAPH_AFTER = 3

@@ -33,6 +33,7 @@ SIGNATURES = {
     "dvq_vq_prepare": (i32, [vp, i64, i64, vp, vp]),
     "dvq_vq_argmin_workspace_bytes": (sz, [i64]),
     "dvq_vq_argmin": (i32, [vp, i32, vp, vp, i64, i64, i64, vp, vp, i32, vp]),
+    "dvq_vq_distances": (i32, [vp, i32, vp, i64, i64, i64, vp, vp]),
     "dvq_vq_gather_loss": (i32, [vp, i32, vp, vp, vp, i64, i64, vp, vp, vp]),
     "dvq_vq_backward": (i32, [vp, vp, i32, vp, vp, vp, vp, i64, i64, vp, vp]),
     "dvq_vq_embed": (i32, [vp, vp, i64, i64, i32, vp, vp]),

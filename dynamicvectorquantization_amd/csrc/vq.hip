@@ -573,6 +573,51 @@ __global__ __launch_bounds__(256) void vq_ema_normalize_kernel(const float* __re
     for (int64_t d = threadIdx.x; d < D; d += 256) weight[k * D + d] = s_ema[k * D + d] / norm;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Explicit distance matrix for the ANALYSIS entry points (VQEmbedding.compute_distances, VectorQuantize2.get_soft_codes,
+// quantize2_mask.py:29-48,193-205): out[n][k] = (|x_n|^2 + |e_k|^2) - 2 x_n.e_k in fp32 FMA arithmetic -- the reference's
+// addmm formula.  The training / inference path never forms this matrix (dvq_vq_argmin); callers process row chunks.
+// 64 codes x 16 rows per workgroup, 32-dim slices of both operands staged in LDS (rows padded against bank conflicts).
+// ---------------------------------------------------------------------------------------------
+template <typename XT>
+__global__ __launch_bounds__(256) void vq_distances_kernel(const XT* __restrict__ x, const float* __restrict__ cb, int64_t N,
+                                                           int64_t K, int64_t D, float* __restrict__ out) {
+    __shared__ float se[64][33];
+    __shared__ float sx[16][33];
+    const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;          // this thread: code c, rows g, g + 4, g + 8, g + 12
+    const int64_t k0 = (int64_t)blockIdx.x * 64, n0 = (int64_t)blockIdx.y * 16;
+    float dot[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f}, en = 0.f;
+    for (int64_t d0 = 0; d0 < D; d0 += 32) {
+        for (int i = tid; i < 64 * 32; i += 256) {
+            const int r = i >> 5, dd = i & 31;
+            se[r][dd] = (k0 + r < K && d0 + dd < D) ? cb[(k0 + r) * D + d0 + dd] : 0.f;
+        }
+        for (int i = tid; i < 16 * 32; i += 256) {
+            const int r = i >> 5, dd = i & 31;
+            sx[r][dd] = (n0 + r < N && d0 + dd < D) ? ElemIO<XT>::load(x + (n0 + r) * D + d0 + dd) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int dd = 0; dd < 32; ++dd) {
+            const float e = se[c][dd];
+            en = fmaf(e, e, en);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xv = sx[g + 4 * j][dd];
+                dot[j] = fmaf(xv, e, dot[j]);
+                xn[j] = fmaf(xv, xv, xn[j]);
+            }
+        }
+        __syncthreads();
+    }
+    if (k0 + c < K)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + g + 4 * j;
+            if (n < N) out[n * K + k0 + c] = fmaf(-2.0f, dot[j], xn[j] + en);
+        }
+}
+
 }  // namespace
 
 template <typename XT>
@@ -645,6 +690,17 @@ int dvq_vq_argmin(const void* x, int x_dtype, const float* codebook, const void*
     if (x_dtype == DVQ_BF16) return vq_argmin_impl<bf16_t>((const bf16_t*)x, codebook, prep, N, K, D, idx, ws, impl, s);
     dvq_set_error("dvq_vq_argmin: bad dtype %d", x_dtype);
     return DVQ_EINVAL;
+}
+
+int dvq_vq_distances(const void* x, int x_dtype, const float* codebook, int64_t N, int64_t K, int64_t D, float* out,
+                     dvq_stream_t stream) {
+    DVQ_REQUIRE(x && codebook && out, DVQ_EINVAL, "dvq_vq_distances: null pointer");
+    DVQ_REQUIRE(N > 0 && K > 0 && D > 0 && (N + 15) / 16 <= 65535, DVQ_ESHAPE, "dvq_vq_distances: bad shape (process <= 1M rows per call)");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv64(K, 64), (unsigned)cdiv64(N, 16));
+    DVQ_DISPATCH_DTYPE(x_dtype, T, vq_distances_kernel<T><<<grid, dim3(256), 0, s>>>((const T*)x, codebook, N, K, D, out););
+    DVQ_CHECK_LAUNCH("vq_distances");
+    return DVQ_OK;
 }
 
 int dvq_vq_gather_loss(const void* x, int dtype, const float* codebook, const int64_t* idx, const float* mask,

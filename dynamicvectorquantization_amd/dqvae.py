@@ -108,6 +108,7 @@ class _GrainEncoder(HipModule):
             setattr(self, f"norm_out_{name}", Normalize(width))
             setattr(self, f"conv_out_{name}", Conv2d(width, z_channels, 3, 1, 1))
         self.router = instantiate_from_config(router_config)
+        self._grad_hook = None             # set by the Trainer under data parallelism: called with parameters whose gradients are final
         self.update_router = update_router
         self.feature_routed = isinstance(self.router, _FeatureRouter)
         self.gumbel_exponential = None     # test hook: Exp(1) noise [B,hc,wc,S] replacing the device RNG draw
@@ -175,6 +176,13 @@ class _GrainEncoder(HipModule):
             g = mid.block_2.bwd(g, tape.child(f"m{k}2"))
             g = mid.attn_1.bwd(g, tape.child(f"m{k}a"))
             gt[k] = mid.block_1.bwd(g, tape.child(f"m{k}1"))
+        hook = self._grad_hook
+        if hook is not None:               # heads + router are done: their gradient exchange overlaps the trunk's backward
+            done = list(self.router.parameters())
+            for name in self.HEADS:
+                for mod in (getattr(self, f"mid_{name}"), getattr(self, f"norm_out_{name}"), getattr(self, f"conv_out_{name}")):
+                    done += list(mod.parameters())
+            hook(done)
         g = gt[0]
         for i_level in reversed(range(self.num_resolutions)):
             lvl = self.down[i_level]
@@ -187,6 +195,8 @@ class _GrainEncoder(HipModule):
                 if len(lvl.attn) > 0:
                     g = lvl.attn[i_block].bwd(g, tape.child(f"d{i_level}a{i_block}"))
                 g = lvl.block[i_block].bwd(g, tape.child(f"d{i_level}b{i_block}"))
+            if hook is not None:
+                hook(list(lvl.parameters()))
         self.conv_in.bwd(g, tape.child("conv_in"), need_dx=False)
         return None
 
@@ -557,7 +567,8 @@ class DualGrainVQModel(nn.Module):
         g = self.quantize.bwd(g, g_qloss, tape.child("vq"))
         g = self.quant_conv.bwd(g, tape.child("qc"))
         if self._grad_hook is not None:            # data parallel: decoder-side gradients are final -> start their all-reduce
-            self._grad_hook("decoder_side_done")
+            self._grad_hook(list(self.decoder.parameters()) + list(self.quant_conv.parameters()) +
+                            list(self.post_quant_conv.parameters()))
         self.encoder.bwd(g, tape.child("enc"), g_gate)
 
     # -- reference API ------------------------------------------------------------------------------

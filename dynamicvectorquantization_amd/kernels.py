@@ -191,6 +191,19 @@ def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, prep: torch.Tensor | None
     return idx
 
 
+def vq_distances(x, codebook, out=None):
+    """x [N,D] (fp32/bf16), codebook [K,D] fp32 -> fp32 [N,K] squared distances (the reference's addmm formula); analysis API"""
+    n, d = x.shape
+    k = codebook.shape[0]
+    if out is None:
+        out = torch.empty(n, k, dtype=torch.float32, device=x.device)
+    step = 1 << 19
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        check(lib().dvq_vq_distances(_p(x[a:b]), dt(x), _p(codebook), b - a, k, d, _p(out[a:b]), _s()), "dvq_vq_distances")
+    return out
+
+
 def vq_gather_loss(x, codebook, idx, mask=None):
     n, d = x.shape
     xq = torch.empty_like(x)

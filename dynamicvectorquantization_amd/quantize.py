@@ -58,9 +58,17 @@ class VQEmbedding(nn.Embedding):
 
     @torch.no_grad()
     def compute_distances(self, inputs):
-        raise NotImplementedError(
-            "the HIP path never materialises the [N,K] distance matrix (quantize2_mask.py:29-48); "
-            "use find_nearest_embedding / get_soft_codes on the reference for analysis code")
+        """inputs [..., D] -> fp32 [..., K] squared distances |x|^2 + |e|^2 - 2 x.e (quantize2_mask.py:29-48).  Analysis API:
+        the search itself (find_nearest_embedding, forward) never forms this matrix; here it is what the caller asked for,
+        written by dvq_vq_distances in row chunks."""
+        d = inputs.shape[-1]
+        assert d == self.weight.shape[-1]
+        flat = inputs.reshape(-1, d)
+        if not flat.is_contiguous():
+            flat = flat.contiguous()
+        if flat.dtype not in (torch.float32, torch.bfloat16):
+            flat = flat.float()
+        return K.vq_distances(flat, self._codebook()).reshape(*inputs.shape[:-1], -1)
 
     @torch.no_grad()
     def find_nearest_embedding(self, inputs):
@@ -202,7 +210,17 @@ class VectorQuantize2(nn.Module):
 
     @torch.no_grad()
     def get_soft_codes(self, x, temp=1.0, stochastic=False):
-        raise NotImplementedError("get_soft_codes materialises the [N,K] matrix; not on the HIP path")
+        """quantize2_mask.py:193-205: soft_code = softmax(-distances / temp); code = a multinomial draw (device RNG) or the
+        nearest code.  x [..., D] like the reference (it passes x straight to compute_distances)."""
+        distances = self.codebook.compute_distances(x)
+        k = distances.shape[-1]
+        flat = distances.reshape(-1, k)
+        soft = K.softmax_rows(flat, flat.shape[0], k, -1.0 / float(temp)).reshape(distances.shape)
+        if stochastic:
+            code = torch.multinomial(soft.reshape(-1, k), 1).reshape(*soft.shape[:-1])
+        else:
+            code = self.codebook.find_nearest_embedding(x)      # the exact nearest code (= argmin of the distances up to fp32 ties)
+        return soft, code
 
     def get_codebook_entry(self, indices, *kwargs):
         return self.codebook.embed(indices)   # (batch, height, width, channel)

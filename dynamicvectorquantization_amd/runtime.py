@@ -138,6 +138,7 @@ class StepGraph:
         self.device = torch.device(device)
         self.items = []                       # ("graph", torch.cuda.CUDAGraph) | ("eager", callable)
         self.stream = torch.cuda.Stream(self.device)
+        self.aux = torch.cuda.Stream(self.device)       # eager items of the recording pass (see _brk)
         self.pool = torch.cuda.graph_pool_handle()
         self._g = None
         self._tick = torch.zeros(1, dtype=torch.int32, device=self.device)   # first node of every segment: no empty graphs
@@ -182,7 +183,13 @@ class StepGraph:
     def _brk(self, fn):
         self._end()
         self._dbg("eager item", len(self.items), getattr(fn, "__qualname__", fn))
-        out = fn()
+        # While recording, the eager callable runs on a stream that is NEVER captured: RCCL keeps events of its work (its
+        # watchdog thread polls them), and HIP refuses to query an event whose last record was on a stream that is capturing
+        # at query time (hipErrorCapturedEvent) -- which the recording stream is again a moment later.
+        self.aux.wait_stream(self.stream)
+        with torch.cuda.stream(self.aux):
+            out = fn()
+        self.stream.wait_stream(self.aux)
         if _GRAPH_DEBUG:
             torch.cuda.synchronize(self.device)
             self._dbg("eager item done")

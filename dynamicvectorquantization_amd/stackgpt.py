@@ -408,6 +408,7 @@ class StackGPT(nn.Module):
         self.position_head = nn.Sequential(LayerNorm(n_embd), Linear(n_embd, fine_position_size, bias=False))
         self.content_head = nn.Sequential(LayerNorm(n_embd), Linear(n_embd, vocab_size, bias=False))
         self.apply(self._init_weights)
+        self._grad_hook = None             # set by the Trainer under data parallelism (per-block gradient exchange, see _run_bwd)
 
     def get_block_size(self):
         return self.block_size
@@ -448,8 +449,11 @@ class StackGPT(nn.Module):
         return x2d
 
     def _run_bwd(self, blocks, g, tape, name):
+        hook = getattr(self, "_grad_hook", None)
         for i in reversed(range(len(blocks))):
             g = blocks[i].bwd(g, tape.child(f"{name}{i}"))
+            if hook is not None:           # data parallel: this block's gradients are final -> their all-reduce starts now
+                hook(list(blocks[i].parameters()))
         return g
 
     def _head(self, head, x2d, tape, name):

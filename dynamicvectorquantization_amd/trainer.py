@@ -213,6 +213,35 @@ class GradBuckets:
         rt.graph_break(launch)
         self._done.append((lo, hi))
 
+    def reduce_params(self, params, min_bytes=1 << 20):
+        """gradients of `params` are final: start the all-reduce of the contiguous flat ranges they cover (called from inside the
+        backward, per block / level / segment, so that the exchange overlaps the rest of the backward).  Runs shorter than
+        `min_bytes` are left to the closing reduce() -- a latency-bound collective per bias vector helps nobody."""
+        if not self._active():
+            return
+        offs = self._offsets()
+        spans = sorted((offs[id(p)], offs[id(p)] + p.numel()) for p in params if id(p) in offs)
+        runs = []
+        for lo, hi in spans:
+            if runs and lo <= runs[-1][1]:
+                runs[-1][1] = max(runs[-1][1], hi)
+            else:
+                runs.append([lo, hi])
+        for lo, hi in runs:
+            if (hi - lo) * 4 < min_bytes or any(lo < d_hi and d_lo < hi for d_lo, d_hi in self._done):
+                continue
+            self.reduce_range(lo, hi)
+
+    def _offsets(self):
+        offs = getattr(self, "_offs", None)
+        if offs is None:
+            offs, off = {}, 0
+            for p in self.fp.params:
+                offs[id(p)] = off
+                off += p.numel()
+            self._offs = offs
+        return offs
+
     def reduce(self, async_op=True):
         """average the ranges that reduce_range() has not covered yet (no-op for world size 1); returns ALL work handles"""
         if not self._active():
@@ -256,6 +285,51 @@ class GradBuckets:
         return (lo or 0), (hi or 0)
 
 
+def reference_learning_rate(model_cfg, world, batch_size):
+    """train.py:248-257 of the reference: lr = ngpu * batch_size * base_learning_rate when the config gives a base rate, else
+    the absolute `learning_rate`"""
+    if "base_learning_rate" in model_cfg:
+        return world * batch_size * model_cfg["base_learning_rate"]
+    if "learning_rate" in model_cfg:
+        return model_cfg["learning_rate"]
+    raise NotImplementedError("Please set learning rate!")
+
+
+def _replicated_tensors(model):
+    """(name, tensor) of everything that must be IDENTICAL on all ranks: parameters and buffers, except the statistics of
+    the discriminator's BatchNorm layers, which DDP keeps per rank (modules/discriminator/model.py:31)"""
+    from .layers import BatchNorm2d
+    skip = set()
+    for mn, mod in model.named_modules():
+        if isinstance(mod, BatchNorm2d):
+            skip.update(f"{mn}.{bn}" for bn, _ in mod.named_buffers(recurse=False))
+    for n, p in model.named_parameters():
+        yield n, p.detach()
+    for n, b in model.named_buffers():
+        if n not in skip:
+            yield n, b
+
+
+def broadcast_model(model, src=0):
+    """DDP's initial synchronisation: rank `src`'s parameters and buffers everywhere (one broadcast per tensor at start-up)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return
+    for _, t in _replicated_tensors(model):
+        dist.broadcast(t, src)
+    rt.bump_weights_epoch()
+
+
+def replicas_equal(model):
+    """debug check (DVQ_DP_CHECK_EVERY=k): True iff every replicated tensor has the same checksum on all ranks"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return True
+    sums = torch.stack([t.double().sum() + t.double().abs().sum() * 3.0 for _, t in _replicated_tensors(model)])
+    lo, hi = sums.clone(), sums.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi))
+
+
 class DataModuleFromConfig:
     """data/build.py:16-90 stand-in: BASELINE configs run on synthetic batches (SURVEY section 2 #5)."""
 
@@ -279,6 +353,8 @@ class Trainer:
         self.model, self.max_steps, self.log_every = model, max_steps, log_every
         self.opts, self.scheds = model.configure_optimizers()
         self.buckets = [GradBuckets(o.flatten()) for o in self.opts]
+        broadcast_model(model)             # identical start on every rank (DDP's parameter / buffer broadcast), not just equal seeds
+        self.check_every = int(os.environ.get("DVQ_DP_CHECK_EVERY", "0"))
         import inspect
         # Lightning passes optimizer_idx only to modules that declare it (two-optimizer stage 1); stage 2 has one optimizer
         self._takes_opt_idx = "optimizer_idx" in inspect.signature(model.training_step).parameters
@@ -292,6 +368,12 @@ class Trainer:
 
     # ---- one step ------------------------------------------------------------------------------------------------
     def train_step(self, batch, batch_idx):
+        out = self._train_step(batch, batch_idx)
+        if self.check_every and (int(self.model.global_step) % self.check_every) == 0 and not replicas_equal(self.model):
+            raise RuntimeError(f"data-parallel replicas diverged at global step {self.model.global_step}")
+        return out
+
+    def _train_step(self, batch, batch_idx):
         if not self.use_graph:
             return self._eager_step(batch, batch_idx)
         sig = self._signature(batch)
@@ -418,18 +500,16 @@ class Trainer:
         self._graph, self._stable, self._last_sig = None, 0, None
 
     def _arm_overlap(self, oi):
-        """autoencoder optimizer: the decoder-side gradients (decoder, quant convs) are final before the encoder's backward
-        starts -- their all-reduce is launched from inside the backward (model._grad_hook) and overlaps the encoder backward"""
-        m = self.model
-        if not hasattr(m, "_grad_hook"):
-            return
-        m._grad_hook = None
+        """Gradient exchange overlapped with the backward: every module of the model that declares `_grad_hook` calls it with the
+        parameters whose gradients just became final (decoder side / encoder heads / each encoder level of the DQ-VAE, each
+        block of StackGPT); under data parallelism that starts the all-reduce of their flat ranges right away
+        (GradBuckets.reduce_params), the closing reduce() covers what is left.  Only the optimizer whose backward is about to
+        run is armed."""
         gb = self.buckets[oi]
-        if oi == 0 and gb._active() and hasattr(m, "encoder") and not _NO_HOOK:
-            lo, hi = gb.param_range([p for p in m.encoder.parameters() if p.requires_grad])
-            n = gb.fp.flat_g.numel()
-            if lo == 0 and 0 < hi < n:
-                m._grad_hook = lambda tag: gb.reduce_range(hi, n) if tag == "decoder_side_done" else None
+        armed = gb._active() and not _NO_HOOK
+        for mod in self.model.modules():
+            if hasattr(mod, "_grad_hook"):
+                mod._grad_hook = gb.reduce_params if armed else None
 
     # ---- checkpoint / resume (train.py:153-185, 270 + `-r`) --------------------------------------------------------------------
     # Lightning's last.ckpt layout: {"state_dict", "optimizer_states": [torch Optimizer.state_dict()...], "lr_schedulers",

@@ -53,6 +53,10 @@ int dvq_vq_prepare(const float* codebook, int64_t K, int64_t D, void* prep, dvq_
  * re-ranked in fp64 over all K codes and over their short candidate list.  impl: 0 = auto, 1 = force generic VALU
  * kernel, 2 = force MFMA kernel (DVQ_ESHAPE if unsupported). */
 size_t dvq_vq_argmin_workspace_bytes(int64_t N);
+/* Analysis entry point (VQEmbedding.compute_distances, quantize2_mask.py:29-48): out[n][k] = (|x_n|^2 + |e_k|^2) - 2 x_n.e_k
+ * (fp32 FMA arithmetic, the reference's addmm formula), out fp32 [N][K] caller-owned; at most 2^20 rows per call. */
+int dvq_vq_distances(const void* x, int x_dtype, const float* codebook, int64_t N, int64_t K, int64_t D, float* out,
+                     dvq_stream_t stream);
 int dvq_vq_argmin(const void* x, int x_dtype, const float* codebook, const void* prep, int64_t N, int64_t K,
                   int64_t D, int64_t* idx, void* ws, int impl, dvq_stream_t stream);
 /* Diagnostic: after the call, the first int32 of `ws` holds the number of rows that took the fp64

@@ -104,6 +104,31 @@ def test_vq_argmin_full_size_properties(dev, k):
         assert np.array_equal(idxb, ovq.argmin_exact(xb.float().cpu().numpy(), cb))
 
 
+def test_vq_distances_and_soft_codes_golden(dev):
+    """the analysis entry points of SURVEY 8(b): VQEmbedding.compute_distances and VectorQuantize2.get_soft_codes vs the reference"""
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    g = load_golden("vq_distances")
+    k, d = (int(v) for v in g["meta"])
+    vq = VectorQuantize2(codebook_size=k, codebook_dim=d).to(dev).eval()
+    with torch.no_grad():
+        vq.codebook.weight.copy_(T(synth.det_param("vqdist.codebook", (k + 1, d)) * 4.0, dev))
+    x = T(synth.det_param("vqdist.x", (2, 5, 3, d)) * 6.0, dev)
+    dist = vq.codebook.compute_distances(x)
+    assert tuple(dist.shape) == g["distances"].shape and dist.dtype == torch.float32
+    np.testing.assert_allclose(dist.cpu().numpy(), g["distances"], rtol=2e-5, atol=2e-4)
+    for temp in (1.0, 0.25):
+        soft, code = vq.get_soft_codes(x, temp=temp, stochastic=False)
+        np.testing.assert_allclose(soft.cpu().numpy(), g[f"soft_{temp}"], rtol=2e-3, atol=1e-6)
+        assert np.array_equal(code.cpu().numpy(), g["code"])
+    soft, code = vq.get_soft_codes(x, temp=1.0, stochastic=True)          # multinomial draw: device RNG, only its support is checked
+    assert tuple(code.shape) == (2, 5, 3) and bool((soft.gather(-1, code.unsqueeze(-1)) > 0).all())
+    # bf16 rows (perf mode) and a row count that is not a multiple of the tile
+    xb = x.reshape(-1, d)[:29].to(torch.bfloat16).contiguous()
+    db = vq.codebook.compute_distances(xb)
+    ref = ((xb.float()[:, None, :] - vq.codebook.weight[:-1][None]) ** 2).sum(-1)
+    np.testing.assert_allclose(db.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
 def test_vq_forward_golden(dev):
     from dynamicvectorquantization_amd.quantize import VectorQuantize2
     g = load_golden("vq_forward")

@@ -45,6 +45,21 @@ def model_config(ch, resolution, latent, zc, k, attn_enc, attn_dec, loss="dummy"
         image_size=resolution)}
 
 
+# code indices that may differ from the reference's at ITS OWN initialisation (codebook U(+-1/K): every score gap is at fp32
+# rounding level, so both the reference's fp32 argmin and 1e-6 activation differences flip near ties).  Bounds = 2x the counts
+# measured on MI355X (DESIGN.md section 5 lists them); every differing row must ALSO have a recorded exact gap < 1e-4.
+REFINIT_MISMATCH_BOUND = {"small": 13, "c1": 13}
+
+
+def _report(kind, **kw):
+    """append a measurement to gpurun_out/test_reports.jsonl when that scratch directory exists (GPU box runs)"""
+    import json
+    d = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "test_reports.jsonl"), "a") as f:
+            f.write(json.dumps(dict(kind=kind, **kw)) + "\n")
+
+
 GEOM = {"small": dict(ch=32, resolution=64, latent=8, zc=64, k=512, attn_enc=[4, 8], attn_dec=[8]),
         "c1": dict(ch=128, resolution=64, latent=8, zc=256, k=1024, attn_enc=[4, 8], attn_dec=[8])}
 
@@ -99,7 +114,9 @@ def test_dqvae_forward_backward_golden(dev, tag, impl):
             else:
                 # reference-init codebook U(+-1/K): near ties.  Differences are only allowed on rows whose
                 # exact top-2 gap (recorded from the reference's own activations) is at fp32-noise level
-                assert len(bad) <= 0.1 * codes.size
+                _report("refinit_code_mismatch", tag=tag, impl=impl, mismatched=int(len(bad)), total=int(codes.size),
+                        max_gap=float(g[f"{variant}_gap"][bad].max()) if len(bad) else 0.0)
+                assert len(bad) <= REFINIT_MISMATCH_BOUND[tag], f"{len(bad)} of {codes.size} code indices differ from the reference"
                 assert np.all(g[f"{variant}_gap"][bad] < 1e-4), g[f"{variant}_gap"][bad]
 
 

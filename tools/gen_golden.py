@@ -854,6 +854,26 @@ def gen_dualformer():
     np.savez_compressed(os.path.join(GOLD, "dualformer.npz"), **out)
 
 
+def gen_vq_distances():
+    """VQEmbedding.compute_distances / VectorQuantize2.get_soft_codes of the reference (quantize2_mask.py:29-48,193-205) on a small
+    channel-last input: the explicit [.., K] distance matrix, the soft codes at two temperatures and the deterministic codes"""
+    from modules.vector_quantization.quantize2_mask import VectorQuantize2
+    k, d = 96, 64
+    vq = VectorQuantize2(codebook_size=k, codebook_dim=d).eval()
+    w = synth.det_param("vqdist.codebook", (k + 1, d)) * 4.0
+    with torch.no_grad():
+        vq.codebook.weight.copy_(t(w))
+    x = synth.det_param("vqdist.x", (2, 5, 3, d)) * 6.0                  # [B,h,w,D]: compute_distances reduces over the last axis
+    dist = vq.codebook.compute_distances(t(x))
+    out = {"meta": np.array([k, d]), "distances": dist.numpy()}
+    for temp in (1.0, 0.25):
+        soft, code = vq.get_soft_codes(t(x), temp=temp, stochastic=False)
+        out[f"soft_{temp}"] = soft.numpy()
+        out["code"] = code.numpy()
+    np.savez_compressed(os.path.join(GOLD, "vq_distances.npz"), **out)
+    print("  vq distances", dist.shape, "codes", out["code"].shape)
+
+
 def gen_ckpt_layout():
     """Lightning checkpoints of the reference are {"state_dict": model.state_dict(), ...} (dqvae_dual_entropy.py:113-122 loads
     them non-strict after dropping `ignore_keys`).  For every shipped stage-1 YAML, build the REFERENCE model from the reference's
@@ -879,7 +899,7 @@ def gen_ckpt_layout():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter,stackgpt,sampler,dualformer,ckpt_layout")
+    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter,stackgpt,sampler,dualformer,ckpt_layout,vq_distances")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -887,7 +907,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for name in args.only.split(","):
         print(f"[gen] {name}")
-        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter, "stackgpt": gen_stackgpt, "sampler": gen_sampler, "dualformer": gen_dualformer, "ckpt_layout": gen_ckpt_layout}[name]()
+        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter, "stackgpt": gen_stackgpt, "sampler": gen_sampler, "dualformer": gen_dualformer, "ckpt_layout": gen_ckpt_layout, "vq_distances": gen_vq_distances}[name]()
     print("done ->", GOLD)
 
 
