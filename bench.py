@@ -243,6 +243,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vq-microbench", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python (no hipGraph replay of the step)")
+    ap.add_argument("--vq-only", action="store_true", help="only the VQ-argmin micro-benchmark (kernel iteration); prints its JSON")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU check of the launch contract only: gloo ranks, barrier + timed loop of no-op steps, one JSON line; no GPU work")
     args = ap.parse_args()
@@ -271,6 +272,10 @@ def main():
     _lib.check(_lib.load().dvq_check_device(), "dvq_check_device")
     rt.set_compute_dtype(args.dtype)
     rt.set_impl(int(os.environ.get("DVQ_IMPL", "0")))     # 0 auto; 2 LDS-DMA MFMA kernels; 3 register-staged (A/B)
+
+    if args.vq_only:
+        print(json.dumps({"vq_argmin": vq_microbench(dev, reps=50)}), flush=True)
+        return
 
     def barrier():
         if world > 1:

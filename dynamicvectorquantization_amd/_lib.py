@@ -107,6 +107,8 @@ SIGNATURES = {
     "dvq_rows_dev": (i32, [vp, vp, i32, i64, i64, i64, vp, i32, vp]),
     "dvq_dropout": (i32, [vp, i32, i64, f32, C.c_uint64, vp, vp]),
     "dvq_fill_f32": (i32, [vp, f32, i64, vp]),
+    "dvq_image_desc_bytes": (sz, []),
+    "dvq_image_batch_transform": (i32, [vp, vp, vp, vp, i64, i32, i32, vp, vp]),
     "dvq_adamw_dev": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "dvq_set_f32x8": (i32, [vp, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
     "dvq_sample_rows": (i32, [vp, i64, i64, vp, vp]),

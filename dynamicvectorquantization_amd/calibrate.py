@@ -58,11 +58,11 @@ def _eval_transform(img, size: int) -> np.ndarray:
     from PIL import Image
     if img.mode != "RGB":
         img = img.convert("RGB")
+    from .data import resized_size
     w, h = img.size
-    s = size / min(w, h)                                  # transforms.Resize(size): shorter side -> size (bilinear, antialiased)
-    nw, nh = (size, max(size, int(round(h * s)))) if w <= h else (max(size, int(round(w * s))), size)
+    nw, nh = resized_size(w, h, size)                     # transforms.Resize(size): shorter side -> size, longer int(size * long / short)
     img = img.resize((nw, nh), Image.BILINEAR)
-    left, top = (nw - size) // 2, (nh - size) // 2        # transforms.CenterCrop(size)
+    left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))        # transforms.CenterCrop(size)
     img = img.crop((left, top, left + size, top + size))
     a = np.asarray(img, dtype=np.float32) / 255.0          # ToTensor
     return ((a - 0.5) / 0.5).transpose(2, 0, 1)            # Normalize(0.5, 0.5)

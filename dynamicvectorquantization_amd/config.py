@@ -58,7 +58,10 @@ TARGET_ALIASES = {
         (_P + "stage2", "ClassForContentOnlyPositionAwareSOSProvider"),
     "modules.dynamic_modules.label_provider.ClassAwareSOSProvider": (_P + "stage2", "ClassAwareSOSProvider"),
     "utils.utils.instantiate_from_config": (_P + "config", "instantiate_from_config"),
-    "data.build.DataModuleFromConfig": (_P + "trainer", "DataModuleFromConfig"),
+    "data.build.DataModuleFromConfig": (_P + "data", "DataModuleFromConfig"),
+    "data.imagenet.ImageNetTrain": (_P + "data", "ImageNetTrain"),
+    "data.imagenet.ImageNetValidation": (_P + "data", "ImageNetValidation"),
+    "data.imagenet_base.ImagePaths": (_P + "data", "ImagePaths"),
 }
 
 

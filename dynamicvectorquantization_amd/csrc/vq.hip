@@ -93,6 +93,66 @@ struct VqWs {
 __host__ __device__ inline int* vq_cand_entries(VqWs* ws, int64_t N) { return ws->list + N; }
 __host__ __device__ inline const int* vq_cand_entries(const VqWs* ws, int64_t N) { return ws->list + N; }
 
+// ---- per row: global best over the 32 class winners, candidate set = classes within tau of it ---------------------------
+// (shared tail of the main kernels: b1 / b2 / i1 = best, second-best score and best index of this lane's residue class of codes
+//  for the 16 accumulator rows of the lane)
+template <int D>
+__device__ __forceinline__ void vq_select_rows(float (&b1)[16], float (&b2)[16], int (&i1)[16], const float* xnorm, const float emax,
+                                               const int wave, const int half, const int l31, const int64_t row0, const int64_t N,
+                                               int64_t* __restrict__ idx_out, VqWs* ws) {
+    {
+        // error bound of one score: split residual 3*2^-18, accumulate D*2^-23 (relative to |x||e|),
+        // norm rounding + final fma 4*2^-24; two scores are compared -> factor 2, -2x.e -> factor 2.
+        const float coefA = 4.0f * (3.0f * 3.8147e-6f + (float)D * 1.1921e-7f);
+        const float coefB = 8.0f * 5.9605e-8f;
+        int* cand = vq_cand_entries(ws, N);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float gb = b1[r];
+            int gi = i1[r];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const float ob = __shfl_xor(gb, o, 64);
+                const int oi = __shfl_xor(gi, o, 64);
+                const bool take = (ob < gb) || (ob == gb && oi < gi);
+                gb = take ? ob : gb;
+                gi = take ? oi : gi;
+            }
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int64_t row = row0 + rl;
+            const float xn = xnorm[wave * 32 + rl];
+            const float tau = coefA * xn * emax + coefB * (emax * emax + 2.0f * xn * emax + xn * xn) + 1e-37f;
+            // a code whose exact score is minimal has an approximate score <= gb + tau: it is the winner of a class with
+            // b1 <= gb + tau (is_c), unless that class holds two such codes (b2 <= gb + tau: over -> full re-rank)
+            const bool is_c = !(b1[r] - gb > tau);
+            const bool over = !(b2[r] - gb > tau);
+            const unsigned long long mc = __ballot(is_c), mo = __ballot(over);
+            const unsigned mh = half ? (unsigned)(mc >> 32) : (unsigned)mc;
+            const unsigned oh = half ? (unsigned)(mo >> 32) : (unsigned)mo;
+            if (row < N) {
+                const int nc = __popc(mh);
+                if (l31 == 0) idx_out[row] = (int64_t)gi;
+                if (oh != 0u || nc > VQ_MAXC) {
+                    if (l31 == 0) {
+                        const int pos = atomicAdd(&ws->count, 1);
+                        ws->list[pos] = (int)row;
+                    }
+                } else if (nc >= 2) {
+                    int pos = 0;
+                    if (l31 == 0) pos = atomicAdd(&ws->ccount, 1);
+                    pos = __shfl(pos, half * 32, 64);
+                    int* ent = cand + (int64_t)pos * 8;
+                    if (l31 == 0) {
+                        ent[0] = (int)row;
+                        ent[1] = nc;
+                    }
+                    if (is_c) ent[2 + __popc(mh & ((1u << l31) - 1u))] = i1[r];
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // main kernel: 4 waves x 32 rows per block, x fragments live in registers, codebook streams
 // through LDS in 32-code stages (double buffered, register-staged prefetch).
@@ -222,89 +282,203 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_kernel(const XT* __rest
 #undef VQ_G1
 #undef VQ_S1
 
-    // ---- per row: global best over the 32 class winners, candidate set = classes within tau of it -------------------
+    vq_select_rows<D>(b1, b2, i1, xnorm, *pv.emax, wave, half, l31, row0, N, idx_out, ws);
+}
+
+// ---------------------------------------------------------------------------------------------
+// main kernel, software-pipelined (default): same tiling (4 waves x 32 rows, x fragments in registers, 32-code stages) but
+//   * the codebook planes are DMA'd straight into LDS (global_load_lds, 1 KiB per wave-instruction; no staging registers, no
+//     ds_write) with an XOR swizzle on the SOURCE chunk instead of row padding: conflict-free b128 fragment reads;
+//   * three independent accumulators (x1.e1 | x1.e2 | x2.e1): no MFMA waits on the accumulator of the MFMA just before it;
+//   * the best / second-best bookkeeping of stage c-1 (VALU, one accumulator row per k-step) is issued between the MFMAs of
+//     stage c (two accumulator sets, compile-time parity): with one wave per SIMD the VALU work runs in the MFMAs' shadow
+//     instead of after them.
+// ---------------------------------------------------------------------------------------------
+// NW = waves per workgroup (32 rows each).  Every workgroup streams the WHOLE codebook (both bf16 planes: 4 bytes per element)
+// from L2 through LDS, so the L2 -> LDS traffic is K * D * 4 bytes per 32 * NW rows: at NW = 4 that stream (0.5 GB at the
+// BASELINE shape) bounded the kernel; 8 waves (two per SIMD, <= 256 registers each, no second accumulator set) halve it.
+template <int KSTEPS, typename XT, int dbg = 0, bool PIPE = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 1) void vq_argmin_mfma_pipe_kernel(const XT* __restrict__ x, const void* prep_c, int64_t N,
+                                                                     int64_t K, int64_t* __restrict__ idx_out, VqWs* ws) {
+    constexpr int D = KSTEPS * 16;
+    constexpr bool XBF16 = sizeof(XT) == 2;
+    constexpr int NACC = XBF16 ? 2 : 3;
+    // bf16 rows (2 waves per SIMD, 256 registers each): no second accumulator set -- the other wave's MFMAs cover this wave's
+    // bookkeeping; fp32 rows (x needs 128 fragment registers: 1 wave per SIMD): bookkeeping of stage c - 1 inside stage c.
+    constexpr int ROWB = D * 2;               // LDS bytes per code row (unpadded, swizzled)
+    constexpr int CPR = ROWB / 16;            // 16-byte chunks per row: 8 / 16 / 32
+    constexpr int PIECE = 32 * ROWB;          // one bf16 plane of a 32-code stage
+    constexpr int STAGE = 2 * PIECE;
+    constexpr int RPP = 1024 / ROWB;          // code rows per 1-KiB DMA piece: 8 / 4 / 2
+    constexpr int PPP = 32 / RPP;             // DMA pieces per plane: 4 / 8 / 16
+    constexpr int RPK = 16 / KSTEPS;          // accumulator rows retired per k-step: 4 / 2 / 1
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xnorm = reinterpret_cast<float*>(smem + 2 * STAGE);   // [32 * NW]
+
+    VqPrepView pv = prep_view(const_cast<void*>(prep_c), K, D);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * (32 * NW) + wave * 32;
+
+    // ---- load + split x fragments -------------------------------------------------------------
+    bf16x8 xa1[KSTEPS];
+    bf16x8 xa2[XBF16 ? 1 : KSTEPS];
+    float sq = 0.f;
     {
-        const float emax = *pv.emax;
-        // error bound of one score: split residual 3*2^-18, accumulate D*2^-23 (relative to |x||e|),
-        // norm rounding + final fma 4*2^-24; two scores are compared -> factor 2, -2x.e -> factor 2.
-        const float coefA = 4.0f * (3.0f * 3.8147e-6f + (float)D * 1.1921e-7f);
-        const float coefB = 8.0f * 5.9605e-8f;
-        int* cand = vq_cand_entries(ws, N);
+        const int64_t r = row0 + l31;
+        const bool ok = r < N;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float gb = b1[r];
-            int gi = i1[r];
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            float v[8];
+            if (ok) {
+                load8(x + r * D + ks * 16 + half * 8, v);
+            } else {
 #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) {
-                const float ob = __shfl_xor(gb, o, 64);
-                const int oi = __shfl_xor(gi, o, 64);
-                const bool take = (ob < gb) || (ob == gb && oi < gi);
-                gb = take ? ob : gb;
-                gi = take ? oi : gi;
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
             }
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int64_t row = row0 + rl;
-            const float xn = xnorm[wave * 32 + rl];
-            const float tau = coefA * xn * emax + coefB * (emax * emax + 2.0f * xn * emax + xn * xn) + 1e-37f;
-            // a code whose exact score is minimal has an approximate score <= gb + tau: it is the winner of a class with
-            // b1 <= gb + tau (is_c), unless that class holds two such codes (b2 <= gb + tau: over -> full re-rank)
-            const bool is_c = !(b1[r] - gb > tau);
-            const bool over = !(b2[r] - gb > tau);
-            const unsigned long long mc = __ballot(is_c), mo = __ballot(over);
-            const unsigned mh = half ? (unsigned)(mc >> 32) : (unsigned)mc;
-            const unsigned oh = half ? (unsigned)(mo >> 32) : (unsigned)mo;
-            if (row < N) {
-                const int nc = __popc(mh);
-                if (l31 == 0) idx_out[row] = (int64_t)gi;
-                if (oh != 0u || nc > VQ_MAXC) {
-                    if (l31 == 0) {
-                        const int pos = atomicAdd(&ws->count, 1);
-                        ws->list[pos] = (int)row;
-                    }
-                } else if (nc >= 2) {
-                    int pos = 0;
-                    if (l31 == 0) pos = atomicAdd(&ws->ccount, 1);
-                    pos = __shfl(pos, half * 32, 64);
-                    int* ent = cand + (int64_t)pos * 8;
-                    if (l31 == 0) {
-                        ent[0] = (int)row;
-                        ent[1] = nc;
-                    }
-                    if (is_c) ent[2 + __popc(mh & ((1u << l31) - 1u))] = i1[r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sq = fmaf(v[j], v[j], sq);
+                bf16_t h = f32_to_bf16(v[j]);
+                xa1[ks][j] = __builtin_bit_cast(__bf16, h);
+                if constexpr (!XBF16) {
+                    float rr = v[j] - bf16_to_f32(h);
+                    xa2[ks][j] = __builtin_bit_cast(__bf16, f32_to_bf16(rr));
                 }
             }
         }
     }
-}
+    sq += __shfl_xor(sq, 32, 64);
+    if (half == 0) xnorm[wave * 32 + l31] = sqrtf(sq) * 1.000001f;
 
-// fp64 re-rank of a row over its candidate codes only: one wave per entry {row, n, idx[n]}
-template <typename XT>
-__global__ __launch_bounds__(256) void vq_rerank_cand_kernel(const XT* __restrict__ x, const float* __restrict__ cb, int64_t N,
-                                                             int64_t D, int64_t* __restrict__ idx_out, const VqWs* ws) {
-    const int cnt = ws->ccount;
-    const int* cand = vq_cand_entries(ws, N);
-    const int lane = threadIdx.x & 63;
-    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < cnt; e += gridDim.x * 4) {
-        const int* ent = cand + (int64_t)e * 8;
-        const int64_t row = ent[0];
-        const int nc = ent[1];
-        double best = __builtin_inf();
-        int bi = 0x7fffffff;
-        for (int c = 0; c < nc; ++c) {
-            const int k = ent[2 + c];
-            double acc = 0.0;
-            for (int64_t d = lane; d < D; d += 64) {
-                const double t = (double)ElemIO<XT>::load(x + row * D + d) - (double)cb[(int64_t)k * D + d];
-                acc = fma(t, t, acc);
+    // swizzle of the 16-B chunk index within a code row (conflict-free for the b128 lane groups of a 32-row fragment read)
+    auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : (row & 15); };
+
+    static_assert((2 * PPP) % NW == 0, "DMA pieces of a stage must split evenly over the waves");
+    // ---- stage loader: this wave DMAs pieces wave, wave + NW, ... of the 2 * PPP pieces of a stage -------------------------------
+    const int prow = (lane * 16) / ROWB;           // row within a piece
+    const int pslot = (lane * 16 % ROWB) / 16;     // chunk position within that row
+    const int nstage = (int)(pv.Kp / 32);
+    auto issue_stage = [&](int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2 * PPP / NW; ++i) {
+            const int pc = wave + NW * i;              // 0 .. 2 PPP - 1
+            const int plane = pc / PPP, pp = pc - plane * PPP;
+            const int row = pp * RPP + prow;           // code row within the stage (0..31)
+            const int chunk = pslot ^ swz(row);        // the chunk of the row that lives at this LDS position
+            const bf16_t* src = (plane ? pv.e2 : pv.e1) + ((int64_t)c * 32 + row) * D + chunk * 8;
+            char* dst = smem + buf * STAGE + plane * PIECE + pp * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    float b1[16], b2[16];
+    int i1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        b1[r] = __builtin_inff();
+        b2[r] = __builtin_inff();
+        i1[r] = 0x7fffffff;
+    }
+    f32x16 accA[NACC], accB[NACC];
+
+    const int fsw = swz(l31);
+    // best / second best of accumulator row r of the retired stage (codes kidx = 32 * stage + l31, norm en)
+    auto retire_row = [&](const f32x16 (&acc)[NACC], int r, float en, int kidx) {
+        float dot = acc[0][r] + acc[1][r];
+        if constexpr (!XBF16) dot += acc[2][r];
+        const float sc = fmaf(-2.0f, dot, en);
+        const bool lt = sc < b1[r];
+        b2[r] = __builtin_amdgcn_fmed3f(b1[r], b2[r], sc);      // second best of {b1, b2, sc} once b1 takes the minimum
+        i1[r] = lt ? kidx : i1[r];
+        b1[r] = fminf(b1[r], sc);
+    };
+    // MFMAs of stage c into `cur`, bookkeeping of stage c - 1 from `prev` in their shadow
+    float en_carry = 0.f;                     // |e|^2 of this lane's code of the stage being multiplied: retired one stage later
+    constexpr int PF = KSTEPS < 4 ? KSTEPS : (PIPE ? 4 : (XBF16 ? 2 : 1));      // fragment reads run PF k-steps ahead of their MFMAs
+    auto stage_body = [&](f32x16 (&cur)[NACC], const f32x16 (&prev)[NACC], int c, bool have_prev) {
+        const int buf = c & 1;
+        const float en_prev = en_carry;
+        const int kprev = (c - 1) * 32 + l31;
+        en_carry = pv.en[c * 32 + l31];       // requested BEFORE the DMAs below: waiting for it never waits for them (in-order vmcnt)
+        if (c + 1 < nstage && !(dbg & 4)) issue_stage(c + 1, buf ^ 1);
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cur[a][r] = 0.f;
+        const char* bbase = smem + buf * STAGE + l31 * ROWB;
+        bf16x8 f1[KSTEPS], f2[KSTEPS];
+        auto frag = [&](int ks) {
+            f1[ks] = *reinterpret_cast<const bf16x8*>(bbase + (((ks * 2 + half) ^ fsw) << 4));
+            f2[ks] = *reinterpret_cast<const bf16x8*>(bbase + PIECE + (((ks * 2 + half) ^ fsw) << 4));
+        };
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) frag(ks);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if (ks + PF < KSTEPS) frag(ks + PF);
+            if constexpr (!(dbg & 2)) {      // (dbg: timing experiments only -- DVQ_VQ_DBG bit 0 no bookkeeping, bit 1 no MFMA, bit 2 no DMA)
+                cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1[ks], f1[ks], cur[0], 0, 0, 0);
+                cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1[ks], f2[ks], cur[1], 0, 0, 0);
+                if constexpr (!XBF16) cur[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa2[ks], f1[ks], cur[2], 0, 0, 0);
+            } else {
+                cur[0][ks & 15] += __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, f1[ks][0]) << 16) +
+                                   __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, f2[ks][0]) << 16);
             }
-            acc = wave_sum(acc);
-            if (acc < best || (acc == best && k < bi)) {
-                best = acc;
-                bi = k;
+            if constexpr (PIPE) {
+                if (have_prev && !(dbg & 1)) {
+#pragma unroll
+                    for (int j = 0; j < RPK; ++j) retire_row(prev, ks * RPK + j, en_prev, kprev);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the k-steps (and their VALU fillers) in this order
             }
         }
-        if (lane == 0) idx_out[row] = (int64_t)bi;
+        if constexpr (!PIPE) {
+            if (!(dbg & 1)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) retire_row(cur, r, en_carry, c * 32 + l31);
+            }
+        }
+        __syncthreads();                            // vmcnt(0): stage c + 1 has landed; everyone is done reading stage c
+    };
+
+    issue_stage(0, 0);
+    __syncthreads();
+    if constexpr (!PIPE) {
+        for (int c = 0; c < nstage; ++c) stage_body(accA, accA, c, false);
+    } else {
+        int c = 0;
+        if (nstage > 0) {
+            stage_body(accA, accB, 0, false);
+            c = 1;
+        }
+        for (; c + 1 < nstage; c += 2) {
+            stage_body(accB, accA, c, true);
+            stage_body(accA, accB, c + 1, true);
+        }
+        bool lastA = true;                              // which set holds the stage that is still to be retired
+        if (c < nstage) {
+            stage_body(accB, accA, c, true);
+            lastA = false;
+            ++c;
+        }
+        if (nstage > 0) {
+            const float en_last = en_carry;
+            const int klast = (nstage - 1) * 32 + l31;
+            if (lastA) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) retire_row(accA, r, en_last, klast);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) retire_row(accB, r, en_last, klast);
+            }
+        }
     }
+    vq_select_rows<D>(b1, b2, i1, xnorm, *pv.emax, wave, half, l31, row0, N, idx_out, ws);
 }
 
 __global__ void vq_flag_all_kernel(VqWs* ws, int64_t N) {
@@ -321,8 +495,8 @@ __global__ void vq_flag_all_kernel(VqWs* ws, int64_t N) {
 constexpr int RR_THREADS = 1024;
 template <typename XT>
 __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __restrict__ x,
-                                                                    const float* __restrict__ cb, int64_t K, int64_t D,
-                                                                    int64_t* __restrict__ idx_out, const VqWs* ws) {
+                                                                    const float* __restrict__ cb, int64_t N, int64_t K, int64_t D,
+                                                                    int64_t* __restrict__ idx_out, const VqWs* ws, int do_cand) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* xs = reinterpret_cast<double*>(smem);            // [D]
     double* wbest = xs + D;                                  // [16]
@@ -349,7 +523,8 @@ __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __
                 double a0 = 0.0, a1 = 0.0;
                 if (k < K) {
                     const float* cr = cb + k * D + 4 * s2;
-                    for (int64_t d = 0; d < D; d += 16) {           // this lane: dims d + 4 s2 .. +3 and d + 8 + 4 s2 .. +3
+#pragma unroll 8
+                    for (int64_t d = 0; d < D; d += 16) {           // this lane: dims d + 4 s2 .. +3 and d + 8 + 4 s2 .. +3 (loads batched)
                         const float4 c0 = *reinterpret_cast<const float4*>(cr + d);
                         const float4 c1 = *reinterpret_cast<const float4*>(cr + d + 8);
                         const double* xa = xs + d + 4 * s2;
@@ -417,6 +592,33 @@ __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __
                     i = widx[w];
                 }
             idx_out[row] = (int64_t)i;
+        }
+    }
+    // ambiguous rows with a short candidate list (the usual case): one wave per entry {row, n, idx[n]}, a few fp64 distances each
+    // (same launch as the all-codes rows above: their latency hides behind this work and one launch is saved)
+    if (do_cand) {
+        const int ccnt = ws->ccount;
+        const int* cand = vq_cand_entries(ws, N);
+        for (int e = blockIdx.x * NW + wave; e < ccnt; e += gridDim.x * NW) {
+            const int* ent = cand + (int64_t)e * 8;
+            const int64_t row = ent[0];
+            const int nc = ent[1];
+            double best = __builtin_inf();
+            int bi = 0x7fffffff;
+            for (int c = 0; c < nc; ++c) {
+                const int k = ent[2 + c];
+                double acc = 0.0;
+                for (int64_t d = lane; d < D; d += 64) {
+                    const double t = (double)ElemIO<XT>::load(x + row * D + d) - (double)cb[(int64_t)k * D + d];
+                    acc = fma(t, t, acc);
+                }
+                acc = wave_sum(acc);
+                if (acc < best || (acc == best && k < bi)) {
+                    best = acc;
+                    bi = k;
+                }
+            }
+            if (lane == 0) idx_out[row] = (int64_t)bi;
         }
     }
 }
@@ -631,12 +833,36 @@ static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_
         vq_zero(ws, 256, s);
         DVQ_CHECK_LAUNCH("vq_zero");
         dim3 grid((unsigned)cdiv64(N, 128)), block(256);
+        static const bool v1 = [] {
+            const char* e = getenv("DVQ_VQ_V1");          // A/B switch: the register-staged kernel of round 1
+            return e != nullptr && atoi(e) != 0;
+        }();
         auto launch = [&](auto ksteps) {
             constexpr int KS = decltype(ksteps)::value;
             constexpr int Dc = KS * 16;
-            size_t lds = 2 * (2 * 32 * (Dc * 2 + 16)) + 128 * 4;
-            dvq_ensure_dynamic_lds((const void*)vq_argmin_mfma_kernel<KS, XT>, (int)lds);
-            vq_argmin_mfma_kernel<KS, XT><<<grid, block, lds, s>>>(x, prep, N, K, idx, ws);
+            if (v1) {
+                size_t lds = 2 * (2 * 32 * (Dc * 2 + 16)) + 128 * 4;
+                dvq_ensure_dynamic_lds((const void*)vq_argmin_mfma_kernel<KS, XT>, (int)lds);
+                vq_argmin_mfma_kernel<KS, XT><<<grid, block, lds, s>>>(x, prep, N, K, idx, ws);
+            } else {
+                // variants: default = 8 waves x 32 rows per workgroup (two waves per SIMD); DVQ_VQ_VARIANT=1: 4 waves, bookkeeping
+                // of stage c - 1 pipelined into stage c (fp32 rows: one wave per SIMD), =2: 4 waves unpipelined (A/B measurements)
+                static const int variant = [] {
+                    const char* e = getenv("DVQ_VQ_VARIANT");
+                    return e != nullptr ? atoi(e) : 0;
+                }();
+                auto go = [&](auto pipe, auto nw) {
+                    constexpr bool P = decltype(pipe)::value;
+                    constexpr int W = decltype(nw)::value;
+                    const size_t lds = 2 * (2 * 32 * (Dc * 2)) + 32 * W * 4;
+                    dvq_ensure_dynamic_lds((const void*)vq_argmin_mfma_pipe_kernel<KS, XT, 0, P, W>, (int)lds);
+                    vq_argmin_mfma_pipe_kernel<KS, XT, 0, P, W><<<dim3((unsigned)cdiv64(N, 32 * W)), dim3(64 * W), lds, s>>>(
+                        x, prep, N, K, idx, ws);
+                };
+                if (variant == 1) go(std::true_type{}, std::integral_constant<int, 4>{});
+                else if (variant == 2) go(std::false_type{}, std::integral_constant<int, 4>{});
+                else go(std::false_type{}, std::integral_constant<int, 8>{});
+            }
         };
         if (D == 64) launch(std::integral_constant<int, 4>{});
         else if (D == 128) launch(std::integral_constant<int, 8>{});
@@ -647,13 +873,9 @@ static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_
         DVQ_CHECK_LAUNCH("vq_flag_all");
     }
     size_t lds = (size_t)D * 8 + 16 * 8 + 16 * 4;
-    if (use_mfma) {
-        // ambiguous rows with a short candidate list (the usual case): a few fp64 distances each
-        vq_rerank_cand_kernel<XT><<<dim3(512), dim3(256), 0, s>>>(x, cb, N, D, idx, ws);
-        DVQ_CHECK_LAUNCH("vq_rerank_cand");
-    }
-    int64_t blocks = use_mfma ? 256 : (N < 65535 ? N : 65535);      // full re-rank rows are rare: grid-stride over the list
-    vq_rerank_fp64_kernel<XT><<<dim3((unsigned)blocks), dim3(RR_THREADS), lds, s>>>(x, cb, K, D, idx, ws);
+    // one launch settles both kinds of ambiguous rows: all-codes re-ranks (rare) and candidate-list re-ranks (the usual case)
+    int64_t blocks = use_mfma ? 256 : (N < 65535 ? N : 65535);
+    vq_rerank_fp64_kernel<XT><<<dim3((unsigned)blocks), dim3(RR_THREADS), lds, s>>>(x, cb, N, K, D, idx, ws, use_mfma ? 1 : 0);
     DVQ_CHECK_LAUNCH("vq_rerank_fp64");
     return DVQ_OK;
 }

@@ -462,7 +462,9 @@ class VQLPIPSWithDiscriminator(nn.Module):
                 raise RuntimeError("adaptive discriminator weight needs the decoder's last-layer weight-gradient closure "
                                    "(`last_layer._dvq_wgrad`, published by DualGrainVQModel.ae_fwd)")
             nll_grads, g_grads = hook(g_nll), hook(g_g)
-            d_weight = (torch.linalg.vector_norm(nll_grads) / (torch.linalg.vector_norm(g_grads) + 1e-4)).clamp_(0.0, 1e4)
+            n_nll, n_g = torch.linalg.vector_norm(nll_grads), torch.linalg.vector_norm(g_grads)
+            self.last_adaptive_norms = (n_nll, n_g)          # device scalars, kept for diagnostics / precision tests
+            d_weight = (n_nll / (n_g + 1e-4)).clamp_(0.0, 1e4)
             d_weight = d_weight * self.discriminator_weight
             if self.disc_weight_max is not None:
                 d_weight = d_weight.clamp(max=self.disc_weight_max)

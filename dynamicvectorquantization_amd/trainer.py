@@ -330,17 +330,6 @@ def replicas_equal(model):
     return bool(torch.equal(lo, hi))
 
 
-class DataModuleFromConfig:
-    """data/build.py:16-90 stand-in: BASELINE configs run on synthetic batches (SURVEY section 2 #5)."""
-
-    def __init__(self, batch_size, train=None, validation=None, test=None, wrap=False, num_workers=None, **kw):
-        self.batch_size = batch_size
-        self.cfg = dict(train=train, validation=validation, test=test)
-
-    def prepare_data(self):
-        pass
-
-
 class Trainer:
     """fit loop for a DualGrainVQModel-like module on batches produced by `batch_fn(step) -> dict`.
 

@@ -394,6 +394,17 @@ int dvq_sample_rows(int64_t* out, int64_t k, int64_t n, uint64_t* state, dvq_str
 
 int dvq_fill_f32(float* p, float v, int64_t n, dvq_stream_t stream);
 
+/* ---- input pipeline (data/imagenet_base.py:16-32: Resize(256) -> Random/CenterCrop(256) -> RandomHorizontalFlip -> ToTensor ->
+ * Normalize(0.5, 0.5)) on DECODED uint8 RGB images of one batch.  `src`: the images packed back to back ([h][w][3] each);
+ * `desc`: B records of dvq_image_desc_bytes() bytes (layout: ImgDesc in csrc/imgproc.hip, mirrored by data._Desc) giving per
+ * image its size, crop window in the resized image, flip flag, the input-row window of the vertical pass and offsets into
+ * `tables` (Pillow's antialiased-bilinear bounds + 22-bit fixed-point coefficients, computed by the caller for the crop's columns
+ * and rows only); `tmp`: scratch for the horizontally resampled rows; `out`: fp32 [B][3][S][S] in [-1, 1].  Bit-exact with
+ * Pillow 9.4 / torchvision 0.14 on the same decoded pixels. */
+size_t dvq_image_desc_bytes(void);
+int dvq_image_batch_transform(const uint8_t* src, const void* desc, const int32_t* tables, uint8_t* tmp, int64_t B, int S,
+                              int max_rows, float* out, dvq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

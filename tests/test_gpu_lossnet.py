@@ -209,3 +209,32 @@ def test_full_objective_train_step(dev):
         assert torch.equal(v0, model.loss.perceptual_loss.net.slice1[0].weight.detach())      # VGG16 is frozen
         assert 0.0 <= float(model._logged["train_d_weight"]) <= 0.75
         assert int(model.loss.discriminator.main[3].num_batches_tracked) == 6                  # 3 D passes per step
+
+
+def test_adaptive_weight_bf16_vs_fp32_full_width(dev):
+    """bf16 is the precision the headline number is measured in: on the full-width model (BASELINE config 1 geometry: ch 128,
+    K = 1024, D = 256, PatchGAN ndf 64, 64x64 images) the generator branch's adaptive GAN weight -- a RATIO of two last-layer
+    gradient norms -- and both norms must agree between the bf16 and the fp32 instantiation of the same HIP kernels"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from test_gpu_model import _report, build
+    x = torch.from_numpy(synth.half_flat_images(4, 64, seed=77)).to(dev)
+    res = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        with rt.compute_dtype_ctx(dtype):
+            torch.manual_seed(0)
+            model, _ = build("c1", dev, "spread", loss="full")
+            model.loss.disc_weight_max = None                 # the unclamped ratio is the sensitive quantity
+            model.train()
+            loss = model.training_step({"image": x}, 0, 0)
+            n_nll, n_g = model.loss.last_adaptive_norms
+            res[dtype] = dict(d_weight=float(model._logged["train_d_weight"]), nll=float(n_nll), g=float(n_g),
+                              loss=float(loss.detach()), p=float(model._logged["train_p_loss"]), g_loss=float(model._logged["train_g_loss"]))
+    a, b = res[torch.float32], res[torch.bfloat16]
+    rel = {k: abs(b[k] - a[k]) / max(1e-12, abs(a[k])) for k in a}
+    _report("adaptive_weight_bf16_vs_fp32", fp32=a, bf16=b, rel=rel)
+    # measured on MI355X (DESIGN.md section 5): nll-gradient norm 0.35 %, GAN-gradient norm 5.6 %, d_weight 5.0 %, loss 0.75 %.
+    # The GAN branch is the sensitive one: d(-mean D(xrec)) / d logits is a CONSTANT map, so after the last conv the gradient is
+    # nearly constant per channel and BatchNorm's backward subtracts its mean -- what is left is a small residual of values that
+    # were stored as bf16.  Bounds = 1.5x the measurement.
+    assert rel["nll"] <= 1e-2 and rel["g"] <= 8e-2 and rel["d_weight"] <= 8e-2, (rel, a, b)
+    assert rel["loss"] <= 2e-2 and rel["p"] <= 1e-2, (rel, a, b)

@@ -48,7 +48,7 @@ def model_config(ch, resolution, latent, zc, k, attn_enc, attn_dec, loss="dummy"
 # code indices that may differ from the reference's at ITS OWN initialisation (codebook U(+-1/K): every score gap is at fp32
 # rounding level, so both the reference's fp32 argmin and 1e-6 activation differences flip near ties).  Bounds = 2x the counts
 # measured on MI355X (DESIGN.md section 5 lists them); every differing row must ALSO have a recorded exact gap < 1e-4.
-REFINIT_MISMATCH_BOUND = {"small": 13, "c1": 13}
+REFINIT_MISMATCH_BOUND = {"small": 1, "c1": 2}       # measured: 0 / 128 (shrunken model), 1 / 128 with gap 6.1e-8 (full width)
 
 
 def _report(kind, **kw):
@@ -117,7 +117,7 @@ def test_dqvae_forward_backward_golden(dev, tag, impl):
                 _report("refinit_code_mismatch", tag=tag, impl=impl, mismatched=int(len(bad)), total=int(codes.size),
                         max_gap=float(g[f"{variant}_gap"][bad].max()) if len(bad) else 0.0)
                 assert len(bad) <= REFINIT_MISMATCH_BOUND[tag], f"{len(bad)} of {codes.size} code indices differ from the reference"
-                assert np.all(g[f"{variant}_gap"][bad] < 1e-4), g[f"{variant}_gap"][bad]
+                assert np.all(g[f"{variant}_gap"][bad] < 1e-6), g[f"{variant}_gap"][bad]
 
 
 def test_train_step_bf16_smoke(dev):

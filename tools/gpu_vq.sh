@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -p no:cacheprovider --tb=short -rf --timeout 600 -k "vq" > gpurun_out/pytest_sel.log 2>&1; echo "pytest exit $?"; tail -n 4 gpurun_out/pytest_sel.log | cut -c1-300
+for v in 0 1; do DVQ_VQ_V1=$v timeout 200 python bench.py --vq-only 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])['vq_argmin']
+print('V1=$v', {k:(v['ms'], v['mfma_frac']) for k,v in d.items()})"; done
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_vq -o vq -- python $OLDPWD/bench.py --vq-only > /dev/null 2>&1; cd $OLDPWD
+f=$(find gpurun_out/prof_vq -name "*kernel_stats.csv" | head -1); head -8 "$f" | cut -c1-260
