@@ -297,7 +297,8 @@ def main():
         # untimed initialisation before the W warmup steps: kernel code-object loading, allocator growth, packed-weight
         # tables (the first steps of a process are host-bound on these one-off costs), then the step is recorded as a
         # hipGraph (Trainer step capture) and the recording is replayed once
-        SETUP = GRAPH_AFTER + 2        # [counted eager step] + GRAPH_AFTER eager steps + [record + first replay]
+        # [counted eager step] + GRAPH_AFTER eager steps + [record + first replay]; two eager steps when nothing is recorded
+        SETUP = GRAPH_AFTER + 2 if not args.no_graph else 2
         # two distinct resident batches per rank (synthetic half-flat images: fine ratio exactly 0.5)
         nb = 2
         imgs = [torch.from_numpy(synth.half_flat_images(args.bs, 256, seed=1234 + 17 * rank + 1000 * i)).to(dev) for i in range(nb)]

@@ -87,6 +87,32 @@ def main():
     os.chdir(REPO)
     torch.manual_seed(0)
 
+    PEAK_BF16, PEAK_HBM = 2.5e15, 8.0e12
+
+    def roofline_of_step(trainer, batch, idx):
+        """per-kernel-family HIP-event timing of ONE eagerly launched step (like bench.py): the family the step spends most
+        time in, its algorithmic flop / byte rate against the MI355X peaks"""
+        from dynamicvectorquantization_amd import kernels as K
+        K.profile_count_start()
+        trainer.train_step(batch, idx)
+        n = K.profile_count_stop()
+        K.profile_prepare(n + 16)
+        K.profile_start()
+        trainer.train_step(batch, idx + 1)
+        prof = K.profile_stop()
+        if not prof:
+            return None, {}
+        fam = {k: dict(launches=v["launches"], ms_per_step=round(v["ms"], 3),
+                       TFLOPs=round(v["flops"] / max(1e-9, v["ms"] * 1e-3) / 1e12, 2),
+                       GBps=round(v["bytes"] / max(1e-9, v["ms"] * 1e-3) / 1e9, 1)) for k, v in prof.items()}
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        v = prof[dom]
+        ach = v["flops"] / (v["ms"] * 1e-3)
+        return {"kernel": dom, "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16, 4), "traffic": None, "launches": v["launches"],
+                "avg_launch_ms": round(v["ms"] / max(1, v["launches"]), 4),
+                "timed": "HIP events around every launch of this kernel family during one eagerly launched step after the timed steps"}, fam
+
     def timed_steps(trainer, batches, steps, warmup):
         for i in range(warmup):
             trainer.train_step(batches[i % len(batches)], i)
@@ -109,11 +135,14 @@ def main():
         batches = [{"image": torch.from_numpy(synth.half_flat_images(bs, 256, seed=77 + i)).to(dev)} for i in range(2)]
         dt = timed_steps(tr, batches, args.steps, args.warmup)
         ind = model._last["grain"]
+        hist = torch.bincount(ind.reshape(-1), minlength=3).tolist()
+        roof, fam = roofline_of_step(tr, batches[0], args.warmup + args.steps)
         out = {"workload": "triple", "metric": "images/sec (256x256) DQ-VAE triple-grain train step, complete two-optimizer objective",
                "value": round(bs * args.steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / args.steps * 1e3, 2),
                "config": {"yaml": "configs/stage1/dqvae-triple-r-03-03_imagenet.yml", "bs": bs,
                           "codebook": int(c.model.params.vqconfig.params.codebook_size),
-                          "grain_histogram": torch.bincount(ind.reshape(-1), minlength=3).tolist()},
+                          "grain_histogram": hist, "step_graph_replays": tr.graph_replays},
+               "roofline": roof, "kernel_families": fam,
                "steps": args.steps, "warmup": args.warmup, "dtype": "bf16", "data": "synthetic"}
     else:
         c = cfg.load_yaml(os.path.join(REPO, "configs/stage2/uncond_imagenet_p6c18.yml"))
@@ -130,12 +159,13 @@ def main():
             t_len = z["coarse_content"].shape[1] + z["fine_content"].shape[1] + 1
             n_par = sum(p.numel() for p in model.transformer.parameters())
             flops = 6.0 * n_par * bs * t_len + 12.0 * 24 * bs * t_len * t_len * 1024      # weights + attention (full square)
+            roof, fam = roofline_of_step(tr, batches[0], args.warmup + args.steps)
             out = {"workload": "stage2", "metric": "images/sec DQ-Transformer (StackGPT p6c18) train step over frozen DQ-VAE codes",
                    "value": round(bs * args.steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / args.steps * 1e3, 2),
                    "tokens_per_sec": round(bs * t_len * args.steps / dt, 1),
                    "config": {"yaml": "configs/stage2/uncond_imagenet_p6c18.yml", "bs": bs, "seq_len": int(t_len),
                               "transformer_params": n_par, "dropout": 0.1},
-                   "mfma_frac_est": round(flops * args.steps / dt / 2.5e15, 4),
+                   "mfma_frac_est": round(flops * args.steps / dt / 2.5e15, 4), "roofline": roof, "kernel_families": fam,
                    "steps": args.steps, "warmup": args.warmup, "dtype": "bf16", "data": "synthetic"}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = stage2_cpu_baseline(int(z["coarse_content"].shape[1]), int(z["fine_content"].shape[1]))

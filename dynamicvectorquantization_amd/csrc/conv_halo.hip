@@ -56,13 +56,18 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 
 // NW = waves per workgroup: 4 -> each wave owns 2 image rows (2 x 4 accumulator tiles of 32x32, 2 waves per SIMD);
 //                           2 -> each wave owns 4 image rows (4 x 4 tiles = 256 accumulator registers, 1 wave per SIMD,
-//                                one third less LDS fragment traffic per MFMA: 8 fragment reads feed 16 MFMAs).
+//                                one third less LDS fragment traffic per MFMA: 8 fragment reads feed 16 MFMAs);
+//                           8 -> (WN = 2) the 128 output channels are split over two wave columns: a wave owns 2 image rows x
+//                                64 channels (2 x 2 tiles = 64 accumulator registers, <= 128 registers in all): FOUR waves per
+//                                SIMD keep the MFMA pipe fed across fragment-read latencies and the per-tap barrier, at 4
+//                                fragment reads per 4 MFMAs instead of 6 per 8.
 // NT = 32-channel output tiles per wave (4 -> 128 output channels per workgroup; 2 / 1 for Cout <= 64 / 32 so that thin
 // layers -- VGG16's 64-channel block, the 3-channel image head -- do not pay for a mostly empty 128-wide tile).
-template <int NW, int NT>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(HaloParams p) {
-    constexpr int MT = 8 / NW;          // image rows (32-pixel m-tiles) per wave
-    constexpr int CO_T = 32 * NT;       // output channels per workgroup
+// WN = wave columns over the output channels (1, or 2 with NW = 8): CO_T = 32 * NT * WN.
+template <int NW, int NT, int WN = 1>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x3_halo_kernel(HaloParams p) {   // (threads, waves per SIMD)
+    constexpr int MT = 8 * WN / NW;     // image rows (32-pixel m-tiles) per wave
+    constexpr int CO_T = 32 * NT * WN;  // output channels per workgroup
     constexpr int CPRW = CO_T / 8;      // 16-byte chunks per staged output row
     constexpr int NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
     float* ssl = reinterpret_cast<float*>(smem + HALOB + 2 * BSTAGE);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % (NW / WN), wn = wave / (NW / WN);     // wave row (image rows MT * wm ..) and wave column (channels)
     const int l31 = lane & 31, half = lane >> 5;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(h_zero_page);
 
@@ -166,11 +172,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
             int sa[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int hp = (MT * wave + mt + kh) * HW_ + l31 + kw;
+                const int hp = (MT * wm + mt + kh) * HW_ + l31 + kw;
                 pa[mt] = halo + hp * ROWB;
                 sa[mt] = (hp >> 1) & 7;
             }
-            const char* pb = bst + buf * BSTAGE + l31 * ROWB;
+            const char* pb = bst + buf * BSTAGE + (wn * NT * 32 + l31) * ROWB;
             // software-pipelined k-steps: the fragments of step ks+1 are requested before the MFMAs of step ks are issued
             // (the compiler otherwise parks their ds_reads behind the MFMA group and waits on them right away)
             bf16x8 a[2][MT], b[2][NT];
@@ -212,13 +218,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_halo_kernel(
     const bool early_act = p.R == nullptr || p.res_mask;     // no residual add between the accumulator and the activation
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int lc = nt * 32 + l31;
+        const int lc = (wn * NT + nt) * 32 + l31;
         const float bcol = (p.bias != nullptr && n0 + lc < p.Cout) ? p.bias[n0 + lc] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int lp = (MT * wave + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int lp = (MT * wm + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v = acc[mt][nt][r] + bcol;
                 if (early_act) v = v > 0.f ? v : v * p.act_slope;
                 st[lp * CO_T + lc] = f32_to_bf16(v);
@@ -375,7 +381,10 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
         const char* e = getenv("DVQ_HALO_WAVES");
         return e != nullptr ? atoi(e) : 0;
     }();
-    if (nw_env == 2 && cot == 128) {   // experiment: 2 waves x (4 x 4 tiles); measured 2x slower (1 wave per SIMD)
+    if (nw_env == 8 && cot == 128) {   // experiment: 8 waves x (2 x 2 tiles), four waves per SIMD
+        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<8, 2, 2>, LDSB);
+        conv3x3_halo_kernel<8, 2, 2><<<dim3((unsigned)blocks), dim3(512), LDSB, stream>>>(p);
+    } else if (nw_env == 2 && cot == 128) {   // experiment: 2 waves x (4 x 4 tiles); measured 2x slower (1 wave per SIMD)
         dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<2, 4>, LDSB);
         conv3x3_halo_kernel<2, 4><<<dim3((unsigned)blocks), dim3(128), LDSB, stream>>>(p);
     } else if (cot == 128) {

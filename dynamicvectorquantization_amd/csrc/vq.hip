@@ -83,7 +83,9 @@ __global__ void vq_prepare_kernel(const float* __restrict__ cb, int64_t K, int64
     }
 }
 
-constexpr int VQ_MAXC = 6;          // candidate codes kept per ambiguous row (an entry is {row, n, idx[6]} = 32 B)
+constexpr int VQ_MAXC = 5;          // candidate codes kept per ambiguous row: an entry is {row, n, idx[5], class mask} = 32 B; a set
+                                    // bit l of the mask = residue class l (codes k = l mod 32) holds MORE than one candidate, so
+                                    // all K / 32 codes of that class are re-ranked too
 struct VqWs {
     int count;      // rows to re-rank over ALL codes
     int ccount;     // rows to re-rank over their candidate list
@@ -132,12 +134,12 @@ __device__ __forceinline__ void vq_select_rows(float (&b1)[16], float (&b2)[16],
             if (row < N) {
                 const int nc = __popc(mh);
                 if (l31 == 0) idx_out[row] = (int64_t)gi;
-                if (oh != 0u || nc > VQ_MAXC) {
+                if (nc > VQ_MAXC) {
                     if (l31 == 0) {
                         const int pos = atomicAdd(&ws->count, 1);
                         ws->list[pos] = (int)row;
                     }
-                } else if (nc >= 2) {
+                } else if (nc >= 2 || oh != 0u) {
                     int pos = 0;
                     if (l31 == 0) pos = atomicAdd(&ws->ccount, 1);
                     pos = __shfl(pos, half * 32, 64);
@@ -145,6 +147,7 @@ __device__ __forceinline__ void vq_select_rows(float (&b1)[16], float (&b2)[16],
                     if (l31 == 0) {
                         ent[0] = (int)row;
                         ent[1] = nc;
+                        ent[7] = (int)oh;
                     }
                     if (is_c) ent[2 + __popc(mh & ((1u << l31) - 1u))] = i1[r];
                 }
@@ -594,8 +597,9 @@ __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __
             idx_out[row] = (int64_t)i;
         }
     }
-    // ambiguous rows with a short candidate list (the usual case): one wave per entry {row, n, idx[n]}, a few fp64 distances each
-    // (same launch as the all-codes rows above: their latency hides behind this work and one launch is saved)
+    // ambiguous rows with a short candidate list (the usual case): one wave per entry {row, n, idx[n], class mask}: a few fp64
+    // distances each, plus the K / 32 codes of every residue class that holds more than one candidate (same launch as the
+    // all-codes rows above: one launch for both)
     if (do_cand) {
         const int ccnt = ws->ccount;
         const int* cand = vq_cand_entries(ws, N);
@@ -603,19 +607,49 @@ __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __
             const int* ent = cand + (int64_t)e * 8;
             const int64_t row = ent[0];
             const int nc = ent[1];
+            unsigned mask = (unsigned)ent[7];
             double best = __builtin_inf();
             int bi = 0x7fffffff;
-            for (int c = 0; c < nc; ++c) {
-                const int k = ent[2 + c];
+            // 32 codes at a time, two lanes per code (alternating 4-dim chunks: all loads of a lane are independent), then a
+            // lexicographic (distance, index) minimum over the wave -- the re-rank is latency-, not flop-bound
+            const int slot = lane >> 1, s2 = lane & 1;
+            auto eval32 = [&](int k) {                 // k: this lane pair's code, or -1
                 double acc = 0.0;
-                for (int64_t d = lane; d < D; d += 64) {
-                    const double t = (double)ElemIO<XT>::load(x + row * D + d) - (double)cb[(int64_t)k * D + d];
-                    acc = fma(t, t, acc);
+                if (k >= 0) {
+                    const float* cr = cb + (int64_t)k * D;
+                    const XT* xr = x + row * D;
+                    for (int64_t d = 4 * s2; d + 3 < D; d += 8) {
+                        const float4 c4 = *reinterpret_cast<const float4*>(cr + d);
+                        double t;
+                        t = (double)ElemIO<XT>::load(xr + d) - (double)c4.x; acc = fma(t, t, acc);
+                        t = (double)ElemIO<XT>::load(xr + d + 1) - (double)c4.y; acc = fma(t, t, acc);
+                        t = (double)ElemIO<XT>::load(xr + d + 2) - (double)c4.z; acc = fma(t, t, acc);
+                        t = (double)ElemIO<XT>::load(xr + d + 3) - (double)c4.w; acc = fma(t, t, acc);
+                    }
                 }
-                acc = wave_sum(acc);
-                if (acc < best || (acc == best && k < bi)) {
-                    best = acc;
-                    bi = k;
+                acc += __shfl_xor(acc, 1, 64);
+                double bb = k >= 0 ? acc : __builtin_inf();
+                int ii = k >= 0 ? k : 0x7fffffff;
+                for (int o = 2; o < 64; o <<= 1) {
+                    const double ob = __shfl_xor(bb, o, 64);
+                    const int oi = __shfl_xor(ii, o, 64);
+                    if (ob < bb || (ob == bb && oi < ii)) {
+                        bb = ob;
+                        ii = oi;
+                    }
+                }
+                if (bb < best || (bb == best && ii < bi)) {
+                    best = bb;
+                    bi = ii;
+                }
+            };
+            eval32(slot < nc ? ent[2 + slot] : -1);
+            while (mask) {
+                const int l = __ffs((int)mask) - 1;
+                mask &= mask - 1;
+                for (int64_t j0 = 0; j0 * 32 + l < K; j0 += 32) {
+                    const int64_t k = (j0 + slot) * 32 + l;
+                    eval32(k < K ? (int)k : -1);
                 }
             }
             if (lane == 0) idx_out[row] = (int64_t)bi;

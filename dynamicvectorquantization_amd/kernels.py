@@ -478,8 +478,10 @@ def gemm_nt(a, b, m, n, k, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, alpha=1.0, 
     """C[b][m][n] = alpha * sum_k A[b][m][k] B[b][n][k] (+bias).  a, b, out are flat device tensors."""
     if out is None:
         out = torch.empty(batch * m * ldc if sc == 0 else batch * sc, dtype=a.dtype, device=a.device)
-    check(lib().dvq_gemm_nt(_p(a), _p(b), _p(out), dt(a), m, n, k, lda, ldb, ldc, batch, sa, sb, sc, alpha, _p(bias),
-                            bias_mode, impl, _s()), "dvq_gemm_nt")
+    es = a.element_size()
+    _timed("gemm_nt", 2 * batch * m * n * k, es * batch * (m * k + n * k + m * n), lambda: check(
+        lib().dvq_gemm_nt(_p(a), _p(b), _p(out), dt(a), m, n, k, lda, ldb, ldc, batch, sa, sb, sc, alpha, _p(bias),
+                          bias_mode, impl, _s()), "dvq_gemm_nt"))
     return out
 
 
@@ -487,9 +489,19 @@ def gemm_tn(a, b, mred, i, j, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, out=None
     """C[b][i][j] (fp32) += sum_m A[b][m][i] B[b][m][j]"""
     if out is None:
         out = torch.zeros(batch * (sc if sc else i * ldc), dtype=torch.float32, device=a.device)
-    check(lib().dvq_gemm_tn(_p(a), _p(b), _p(out), dt(a), mred, i, j, lda, ldb, ldc, batch, sa, sb, sc, impl, _s()),
-          "dvq_gemm_tn")
+    es = a.element_size()
+    _timed("gemm_tn", 2 * batch * mred * i * j, es * batch * mred * (i + j) + 4 * batch * i * j, lambda: check(
+        lib().dvq_gemm_tn(_p(a), _p(b), _p(out), dt(a), mred, i, j, lda, ldb, ldc, batch, sa, sb, sc, impl, _s()),
+        "dvq_gemm_tn"))
     return out
+
+
+def gemm_nn_lib(dy, w, m, n, k):
+    """dx [m, n] = dy [m, k] @ w [k, n] with w as stored (library NN product, csrc/blaslt.hip); None if the library declines"""
+    dx = torch.empty(m, n, dtype=dy.dtype, device=dy.device)
+    rc = _timed("gemm_nn_lib", 2 * m * n * k, dy.element_size() * (m * k + n * k + m * n), lambda: lib().dvq_gemm_nn_lib(
+        _p(dy), _p(w), _p(dx), dt(dy), m, n, k, k, n, n, _s()))
+    return dx if rc == 0 else None
 
 
 def softmax_rows(s, rows, length, scale):
@@ -758,17 +770,21 @@ def attn_causal_fwd(q, k, v, b, t, n_head, scale, p_drop=0.0, seed=0):
     out = torch.empty_like(q)
     lse = torch.empty(b, n_head, t, dtype=torch.float32, device=q.device)
     scratch = _attn_scratch(q, b, t, n_head, False)
-    check(lib().dvq_attn_causal_fwd(_p(q), _p(k), _p(v), dt(q), b, t, n_head, q.shape[-1] // n_head, float(scale), float(p_drop),
-                                    int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out), _p(lse), _p(scratch), _s()), "dvq_attn_causal_fwd")
+    c = q.shape[-1]
+    _timed("attn_causal_fwd", 2 * b * t * t * c, 4 * q.numel() * q.element_size(), lambda: check(
+        lib().dvq_attn_causal_fwd(_p(q), _p(k), _p(v), dt(q), b, t, n_head, c // n_head, float(scale), float(p_drop),
+                                  int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out), _p(lse), _p(scratch), _s()), "dvq_attn_causal_fwd"))
     return out, lse
 
 
 def attn_causal_bwd(q, k, v, out, dout, lse, b, t, n_head, scale, p_drop=0.0, seed=0):
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     scratch = _attn_scratch(q, b, t, n_head, True)
-    check(lib().dvq_attn_causal_bwd(_p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), dt(q), b, t, n_head, q.shape[-1] // n_head, float(scale),
-                                    float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(dq), _p(dk), _p(dv), _p(scratch), _s()),
-          "dvq_attn_causal_bwd")
+    c = q.shape[-1]
+    _timed("attn_causal_bwd", 5 * b * t * t * c, 8 * q.numel() * q.element_size(), lambda: check(
+        lib().dvq_attn_causal_bwd(_p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), dt(q), b, t, n_head, c // n_head, float(scale),
+                                  float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(dq), _p(dk), _p(dv), _p(scratch), _s()),
+        "dvq_attn_causal_bwd"))
     return dq, dk, dv
 
 

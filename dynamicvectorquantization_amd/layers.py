@@ -214,10 +214,8 @@ class Linear(nn.Module):
         if (dy.dtype == torch.bfloat16 and m >= 1024 and self.in_features % 8 == 0 and self.in_features >= 256 and self.out_p >= 256
                 and rt.impl() == 0 and os.environ.get('DVQ_NO_GEMM_NN', '0') != '1' and K.lib().dvq_blaslt_available()):
             # dx = dy W with W as it lies in memory ([out, in]): library NN product, no transposed weight copy per step
-            dx = torch.empty(m, self.in_features, dtype=dy.dtype, device=dy.device)
-            rc = K.lib().dvq_gemm_nn_lib(K._p(dy), K._p(w), K._p(dx), K.dt(dy), m, self.in_features, self.out_p, self.out_p,
-                                         self.in_features, self.in_features, K._s())
-            if rc == 0:
+            dx = K.gemm_nn_lib(dy, w, m, self.in_features, self.out_p)
+            if dx is not None:
                 return dx
         wt = self._wt(w)                                                     # [in, out_p]
         dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self.out_p, self.in_features)

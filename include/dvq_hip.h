@@ -8,7 +8,12 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (incl. workspaces); the library allocates
- *     nothing, keeps no mutable global state, launches only on `stream`, never synchronises;
+ *     nothing, launches only on `stream`, never synchronises.  Process-wide state is limited to, and listed here:
+ *     the scratch registration of dvq_set_workspace() (ONE caller-owned buffer per process, i.e. per rank / device:
+ *     set it once before the first call that uses it; calls that find it too small fall back to atomics), caches of
+ *     one-off hipFuncSetAttribute calls, and the hipBLASLt handle / plan cache / 32-MiB workspace of csrc/blaslt.hip;
+ *   - every entry point issues KERNEL launches only (no memset / memcpy nodes), so a sequence of calls can be recorded by
+ *     HIP stream capture after its first eager execution and replayed (the training step and the sampler do);
  *   - activations are NHWC ("pixel-major"): element (n,h,w,c) at ((n*H+h)*W+w)*C+c;
  *   - conv weights are OHWI: element (co,kh,kw,ci) at ((co*KH+kh)*KW+kw)*Cin+ci
  *     (= torch.channels_last storage of the reference's [Cout,Cin,KH,KW] parameter);
@@ -33,7 +38,7 @@ enum { DVQ_F32 = 0, DVQ_BF16 = 1 };
 enum { DVQ_OK = 0, DVQ_EINVAL = -1, DVQ_ESHAPE = -2, DVQ_EARCH = -3, DVQ_ELAUNCH = -4, DVQ_EWORKSPACE = -5 };
 
 const char* dvq_last_error(void);
-int dvq_version(void);
+int dvq_version(void);     /* 102: round 2 (device-hyper AdamW, image pipeline, distance matrix, row sampler) */
 /* 0 if the current HIP device is gfx950, DVQ_EARCH otherwise */
 int dvq_check_device(void);
 

@@ -162,3 +162,46 @@ def test_triple_full_objective_train_step_bf16(dev):
         assert len(l0) == 2 and all(torch.isfinite(l).all() for l in l0 + l1)
         assert not torch.equal(w0, model.encoder.router.gate[0].weight.detach())
         assert "train_budget_loss" in model._logged and "train_fine_radio" in model._logged
+
+
+def test_config4_triple_k8192_full_size_properties(dev):
+    """BASELINE config 4 AS STATED: dqvae-triple-r-03-03 (F = 32/16/8) with an 8192-entry codebook, bs 32, 256x256, bf16 (the
+    shipped YAML says codebook_size 1024; BASELINE.json quotes 8192 -- overridden here).  Full-size properties: complete
+    two-optimizer steps (recorded + replayed as a hipGraph from the third on) with finite losses, code indices < 8192 at all
+    three grains, EMA buffers of the 8192 codes updated, grain histogram consistent with the codebook mask, quantising the
+    codebook's own rows returns their index"""
+    import os
+    import warnings
+    from conftest import REPO
+    from dynamicvectorquantization_amd import config as cfg
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.trainer import Trainer
+    os.chdir(REPO)
+    c = cfg.load_yaml(os.path.join(REPO, "configs/stage1/dqvae-triple-r-03-03_imagenet.yml"))
+    c.model.params.vqconfig.params.codebook_size = 8192
+    bs = 32
+    with rt.compute_dtype_ctx(torch.bfloat16), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(0)
+        model = cfg.instantiate_from_config(c.model).to(dev)
+        model.learning_rate, model.training_steps, model.steps_per_epoch = 4.5e-6 * bs, 1000, 100
+        model.train()
+        cb = model.quantize.codebook
+        assert tuple(cb.weight.shape) == (8193, 256) and tuple(cb.embed_ema.shape) == (8192, 256)
+        tr = Trainer(model, max_steps=5, graph_after=2)
+        xs = [torch.from_numpy(synth.half_flat_images(bs, 256, seed=500 + i)).to(dev) for i in range(2)]
+        n0 = cb.cluster_size_ema.clone()
+        losses = [[float(l) for l in tr.train_step({"image": xs[i % 2]}, i)] for i in range(4)]
+        assert np.isfinite(np.array(losses)).all() and tr.graph_replays == 2, (losses, tr.graph_replays)
+        out = model._last
+        codes, grain, mask = out["codes"], out["grain"], out["mask"]
+        assert tuple(codes.shape) == (bs, 32, 32) and int(codes.min()) >= 0 and int(codes.max()) < 8192
+        assert tuple(grain.shape) == (bs, 8, 8) and set(torch.unique(grain).tolist()) <= {0, 1, 2}
+        # codebook mask weights 1/16, 1/4, 1 follow the grain map (EncoderTriple.py:165-176)
+        want = torch.tensor([1.0 / 16, 0.25, 1.0], device=dev)[grain].repeat_interleave(4, 1).repeat_interleave(4, 2)
+        assert torch.allclose(mask.reshape(bs, 32, 32), want)
+        assert not torch.equal(n0, cb.cluster_size_ema) and bool(torch.isfinite(cb.embed_ema).all())
+        model.eval()
+        with torch.no_grad():
+            w = cb.weight[:-1].detach()
+            assert torch.equal(cb.find_nearest_embedding(w), torch.arange(8192, device=dev))

@@ -76,7 +76,7 @@ def test_vq_argmin_ties(dev):
     idx = idx.cpu().numpy()
     assert np.array_equal(idx, exact)
     assert np.all(idx[:10] == 3)
-    assert int(flagged[0]) >= 10            # the rows nearest to the same-class duplicates took the all-codes re-rank
+    assert int(flagged.sum()) >= 20         # the rows nearest to the duplicated codes were re-ranked (same-class duplicates: whole class)
 
 
 @pytest.mark.parametrize("k", [1024, 8192])
@@ -93,8 +93,9 @@ def test_vq_argmin_full_size_properties(dev, k):
         sample = np.random.RandomState(1).choice(n, 2048, replace=False)
         assert np.array_equal(idx[sample], ovq.argmin_exact(x[sample], cb))
         assert int(flagged.sum().item()) < 0.1 * n
-        # ambiguous rows are settled among their few candidate codes; the all-codes re-rank is the rare exception
-        assert int(flagged[0]) <= 0.25 * int(flagged.sum()) + 16, flagged.cpu().numpy()
+        # ambiguous rows are settled among their few candidate codes (+ whole residue classes); the all-codes re-rank (more
+        # than VQ_MAXC candidate classes) is the rare exception
+        assert int(flagged[0]) <= 0.05 * int(flagged.sum()) + 4, flagged.cpu().numpy()
         # idempotence: quantising code vectors returns their own index
         self_idx = K.vq_argmin(cbt, cbt, impl=2).cpu().numpy()
         assert np.array_equal(self_idx, np.arange(k))

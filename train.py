@@ -41,6 +41,9 @@ def get_parser():
     p.add_argument("--max_steps", type=int, default=-1)
     p.add_argument("--steps_per_epoch", type=int, default=100, help="synthetic data: batches per epoch")
     p.add_argument("--synthetic", action="store_true", default=True)
+    p.add_argument("--real_data", action="store_true",
+                   help="instantiate the config's `data:` section (data.build.DataModuleFromConfig -> GPU input pipeline, "
+                        "$DVQ_IMAGENET_ROOT/train|val) instead of synthetic batches")
     p.add_argument("--precision", type=str, default="bf16", help="compute dtype of the HIP path: bf16 | fp32")
     p.add_argument("--logdir", type=str, default="logs")
     p.add_argument("--save_every", type=int, default=0,
@@ -135,8 +138,31 @@ def run(rank, world, opt, unknown):
     if getattr(model, "cond_stage_key", None) == "class_label":         # class-conditional stage 2: synthetic labels
         n_classes = int(getattr(model.cond_stage_model, "n_classes", 1000))
 
+    real_iter = None
+    if opt.real_data:
+        # the YAML's own `data:` section through the plugin boundary: host threads decode, resize / crop / flip / normalise run
+        # on the GPU (dynamicvectorquantization_amd/data.py); each rank shuffles with its own seed (weak scaling, bs per GPU)
+        config.data.params["device"] = str(dev)
+        config.data.params["size"] = size
+        dm = cfg.instantiate_from_config(config.data)
+        loader = dm.train_dataloader()
+        loader.rng = __import__("numpy").random.default_rng(opt.seed + 977 * rank)
+        opt.steps_per_epoch = model.steps_per_epoch = len(loader)
+        model.training_steps = len(loader) * opt.max_epochs
+        total = model.training_steps if opt.max_steps < 0 else min(opt.max_steps, model.training_steps)
+        trainer.max_steps = total
+
+        def _batches():
+            while True:
+                for b in loader:
+                    yield {k: v for k, v in b.items() if torch.is_tensor(v)}      # strings (paths, synsets) stay on the host side
+        real_iter = _batches()
+
     def batch_fn(step):
         model.current_epoch = step // opt.steps_per_epoch
+        if real_iter is not None:
+            b = next(real_iter)
+            return {image_key: b["image"], **({"class_label": b["class_label"]} if "class_label" in b and n_classes is not None else {})}
         batch = {image_key: pool[step % len(pool)]}
         if n_classes is not None:
             g = torch.Generator().manual_seed(opt.seed + step)
