@@ -610,27 +610,43 @@ __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __
             unsigned mask = (unsigned)ent[7];
             double best = __builtin_inf();
             int bi = 0x7fffffff;
-            // 32 codes at a time, two lanes per code (alternating 4-dim chunks: all loads of a lane are independent), then a
-            // lexicographic (distance, index) minimum over the wave -- the re-rank is latency-, not flop-bound
-            const int slot = lane >> 1, s2 = lane & 1;
-            auto eval32 = [&](int k) {                 // k: this lane pair's code, or -1
+            // LPC lanes per code (64 / LPC codes per wave pass), each lane sums 4-dim chunks LPC apart: 16-byte codebook loads,
+            // 8- / 16-byte row loads, all independent -- the re-rank is latency-, not flop-bound.  Then a lexicographic
+            // (distance, index) minimum over the wave.  8 lanes per code for the (<= 5) listed candidates, 2 for class scans.
+            const XT* xr = x + row * D;
+            auto eval = [&](auto lpc_tag, int k) {      // k: the code of this lane's slot, or -1
+                constexpr int LPC = decltype(lpc_tag)::value;
+                const int sub = lane & (LPC - 1);
                 double acc = 0.0;
                 if (k >= 0) {
                     const float* cr = cb + (int64_t)k * D;
-                    const XT* xr = x + row * D;
-                    for (int64_t d = 4 * s2; d + 3 < D; d += 8) {
+#pragma unroll 4
+                    for (int64_t d = 4 * sub; d + 3 < D; d += 4 * LPC) {
                         const float4 c4 = *reinterpret_cast<const float4*>(cr + d);
+                        float xv[4];
+                        if constexpr (sizeof(XT) == 2) {
+                            const uint2 u = *reinterpret_cast<const uint2*>(xr + d);
+                            xv[0] = __uint_as_float(u.x << 16);
+                            xv[1] = __uint_as_float(u.x & 0xffff0000u);
+                            xv[2] = __uint_as_float(u.y << 16);
+                            xv[3] = __uint_as_float(u.y & 0xffff0000u);
+                        } else {
+                            const float4 x4 = *reinterpret_cast<const float4*>(xr + d);
+                            xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+                        }
                         double t;
-                        t = (double)ElemIO<XT>::load(xr + d) - (double)c4.x; acc = fma(t, t, acc);
-                        t = (double)ElemIO<XT>::load(xr + d + 1) - (double)c4.y; acc = fma(t, t, acc);
-                        t = (double)ElemIO<XT>::load(xr + d + 2) - (double)c4.z; acc = fma(t, t, acc);
-                        t = (double)ElemIO<XT>::load(xr + d + 3) - (double)c4.w; acc = fma(t, t, acc);
+                        t = (double)xv[0] - (double)c4.x; acc = fma(t, t, acc);
+                        t = (double)xv[1] - (double)c4.y; acc = fma(t, t, acc);
+                        t = (double)xv[2] - (double)c4.z; acc = fma(t, t, acc);
+                        t = (double)xv[3] - (double)c4.w; acc = fma(t, t, acc);
                     }
                 }
-                acc += __shfl_xor(acc, 1, 64);
+#pragma unroll
+                for (int o = 1; o < LPC; o <<= 1) acc += __shfl_xor(acc, o, 64);
                 double bb = k >= 0 ? acc : __builtin_inf();
                 int ii = k >= 0 ? k : 0x7fffffff;
-                for (int o = 2; o < 64; o <<= 1) {
+#pragma unroll
+                for (int o = LPC; o < 64; o <<= 1) {
                     const double ob = __shfl_xor(bb, o, 64);
                     const int oi = __shfl_xor(ii, o, 64);
                     if (ob < bb || (ob == bb && oi < ii)) {
@@ -643,13 +659,13 @@ __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __
                     bi = ii;
                 }
             };
-            eval32(slot < nc ? ent[2 + slot] : -1);
+            eval(std::integral_constant<int, 8>{}, (lane >> 3) < nc ? ent[2 + (lane >> 3)] : -1);
             while (mask) {
                 const int l = __ffs((int)mask) - 1;
                 mask &= mask - 1;
                 for (int64_t j0 = 0; j0 * 32 + l < K; j0 += 32) {
-                    const int64_t k = (j0 + slot) * 32 + l;
-                    eval32(k < K ? (int)k : -1);
+                    const int64_t k = (j0 + (lane >> 1)) * 32 + l;
+                    eval(std::integral_constant<int, 2>{}, k < K ? (int)k : -1);
                 }
             }
             if (lane == 0) idx_out[row] = (int64_t)bi;

@@ -73,3 +73,49 @@ def test_loader_end_to_end(dev, tmp_path, monkeypatch):
         assert float(b["image"].min()) >= -1.0 and float(b["image"].max()) <= 1.0 and b["image"].shape[0] == 4
         n += 1
     assert n == 3
+
+
+def test_train_py_real_data_checkpoint_resume(dev, tmp_path):
+    """`train.py` end to end on image files: the YAML's `data:` section through the GPU input pipeline (--real_data), periodic
+    atomic last.ckpt (--save_every), saved project config, and `-r <logdir>` continuing IN that logdir from the saved configs"""
+    import os
+    import subprocess
+    import sys
+    import yaml
+    from PIL import Image
+    from conftest import REPO
+    from test_gpu_model import GEOM, model_config
+    for split in ("train", "val"):
+        for ci, c in enumerate(("n01", "n02")):
+            d = tmp_path / "imgs" / split / c
+            d.mkdir(parents=True)
+            for j in range(6):
+                Image.fromarray(_img(70 + 5 * j, 90 + 7 * ci, ci * 10 + j), "RGB").save(d / f"img{j}.png")
+    mc = model_config(**GEOM["small"], loss="ae")
+    mc["base_learning_rate"] = 1e-5
+    cfg_path = tmp_path / "tiny.yml"
+    yaml.safe_dump({"model": mc, "data": {"target": "data.build.DataModuleFromConfig", "params": {
+        "batch_size": 4, "num_workers": 2,
+        "train": {"target": "data.imagenet.ImageNetTrain", "params": {"config": {"is_eval": False, "size": 64}}},
+        "validation": {"target": "data.imagenet.ImageNetValidation", "params": {"config": {"is_eval": True, "size": 64}}}}}},
+        open(cfg_path, "w"))
+    env = dict(os.environ, DVQ_IMAGENET_ROOT=str(tmp_path / "imgs"))
+    logs = tmp_path / "logs"
+    cmd = [sys.executable, os.path.join(REPO, "train.py"), "-b", str(cfg_path), "--real_data", "--max_epochs", "2", "--max_steps", "5", "--save_every", "2",
+           "--logdir", str(logs), "-n", "t"]
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    run = [d for d in os.listdir(logs)]
+    assert len(run) == 1 and run[0].endswith("_t")
+    ck = torch.load(logs / run[0] / "checkpoints" / "last.ckpt", map_location="cpu", weights_only=False)
+    assert ck["global_step"] == 5 and len(ck["optimizer_states"]) == 1 and "encoder.conv_in.weight" in ck["state_dict"]
+    assert os.path.isfile(logs / run[0] / "configs" / "project.yaml")
+    assert not os.path.exists(str(logs / run[0] / "checkpoints" / "last.ckpt") + ".tmp")
+    # resume: no -b needed (configs come from the logdir), the run continues to step 6 (3 batches per epoch x 2 epochs) in place
+    r2 = subprocess.run([sys.executable, os.path.join(REPO, "train.py"), "-r", str(logs / run[0]), "--real_data", "--max_epochs", "2"],
+                        env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and "resumed from" in r2.stdout, r2.stdout[-2000:] + r2.stderr[-3000:]
+    ck2 = torch.load(logs / run[0] / "checkpoints" / "last.ckpt", map_location="cpu", weights_only=False)
+    assert ck2["global_step"] == 6 and len(os.listdir(logs)) == 1
+    w1, w2 = ck["state_dict"]["decoder.conv_out.weight"], ck2["state_dict"]["decoder.conv_out.weight"]
+    assert not torch.equal(w1, w2)

@@ -203,5 +203,8 @@ def test_config4_triple_k8192_full_size_properties(dev):
         assert not torch.equal(n0, cb.cluster_size_ema) and bool(torch.isfinite(cb.embed_ema).all())
         model.eval()
         with torch.no_grad():
+            # quantising the codebook's own rows: each row finds ITSELF or -- dead codes restarted from bit-identical encoder
+            # outputs (flat image regions) are exact duplicates -- the lowest-index copy of itself
             w = cb.weight[:-1].detach()
-            assert torch.equal(cb.find_nearest_embedding(w), torch.arange(8192, device=dev))
+            found = cb.find_nearest_embedding(w)
+            assert bool((found <= torch.arange(8192, device=dev)).all()) and torch.equal(w[found], w)
