@@ -34,6 +34,8 @@ struct AttnParams {
     float* lse;                              // [B][nh][T]: log-sum-exp of the scaled, masked scores (natural log)
     float* dsum;                             // [B][nh][T]: rowsum(dO * O)
     int T, nh, C;
+    int causal;                              // 1: stage-2 causal attention; 0: full attention (AttnBlock of the DQ-VAE: one head of size
+                                             //    C, every query sees every key; T % 32 == 0)
     float scale;                             // 1 / sqrt(hs)
     float inv_keep;                          // 1 / (1 - p)
     unsigned thr, rm, ra;                    // dropout: keep iff dvq_hash32(idx * rm + ra) >= thr (thr == 0: no dropout)
@@ -153,7 +155,7 @@ __device__ __forceinline__ void store_ct(bf16_t* dst /* row base + head offset *
 // ------------------------------------------------------------------------------------------------------------------
 // (two workgroups per CU: without the explicit bound the compiler spreads into AGPRs and settles for one wave per SIMD)
 template <int HS>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void attn_fwd_kernel(AttnParams p) {
     using G = Geo<HS>;
     constexpr int NS = HS / 16, NM = HS / 32, STAGE = G::RTILE + G::CTILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -188,21 +190,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     swrite_rows<HS>(smem, tid, rk);
     swrite_cols<HS>(smem + G::RTILE, tid, rv);
     __syncthreads();
-    for (int kt = 0; kt <= qt_max; ++kt) {
+    const int kt_last = p.causal ? qt_max : nqt - 1;            // full attention: every query tile walks all key tiles
+    for (int kt = 0; kt <= kt_last; ++kt) {
         const char* kl = smem + (kt & 1) * STAGE;
         const char* vl = kl + G::RTILE;
-        const bool more = kt < qt_max;
+        const bool more = kt < kt_last;
         if (more) {
             gload_rows<HS>(kbase, rowbase, 32 * (kt + 1), T, C, tid, rk);
             gload_cols<HS>(vtbase, 32 * (kt + 1), T, tid, rv);
         }
-        if (active && kt <= qt) {
+        if (active && (!p.causal || kt <= qt)) {
             const int k0 = kt * 32;
             f32x16 s = zero16();
 #pragma unroll
             for (int st = 0; st < NS; ++st) s = MFMA(frag_r<HS>(kl, l31, half, st), qf[st], s);
             float mx = m_run;
-            if (kt == qt) {                                      // diagonal tile: causal mask (also hides keys >= T)
+            if (p.causal && kt == qt) {                          // diagonal tile: causal mask (also hides keys >= T)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = k0 + crow(r, half);
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(AttnParams p, int64_t 
 // backward, dQ: one wave per 32 queries (same walk as the forward); LDS stage = K, V (row-major) and K^T tiles
 // ------------------------------------------------------------------------------------------------------------------
 template <int HS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void attn_bwd_dq_kernel(AttnParams p) {
     using G = Geo<HS>;
     constexpr int NS = HS / 16, NM = HS / 32, STAGE = 2 * G::RTILE + G::CTILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -330,17 +333,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     swrite_rows<HS>(smem + G::RTILE, tid, rv);
     swrite_cols<HS>(smem + 2 * G::RTILE, tid, rt);
     __syncthreads();
-    for (int kt = 0; kt <= qt_max; ++kt) {
+    const int kt_last = p.causal ? qt_max : nqt - 1;
+    for (int kt = 0; kt <= kt_last; ++kt) {
         const char* kl = smem + (kt & 1) * STAGE;
         const char* vl = kl + G::RTILE;
         const char* tl = kl + 2 * G::RTILE;
-        const bool more = kt < qt_max;
+        const bool more = kt < kt_last;
         if (more) {
             gload_rows<HS>(kbase, rowbase, 32 * (kt + 1), T, C, tid, rk);
             gload_rows<HS>(vbase, rowbase, 32 * (kt + 1), T, C, tid, rv);
             gload_cols<HS>(ktbase, 32 * (kt + 1), T, tid, rt);
         }
-        if (active && kt <= qt) {
+        if (active && (!p.causal || kt <= qt)) {
             const int k0 = kt * 32;
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
                 s = MFMA(frag_r<HS>(kl, l31, half, st), qf[st], s);
                 dp = MFMA(frag_r<HS>(vl, l31, half, st), dof[st], dp);
             }
-            const bool diag = kt == qt;
+            const bool diag = p.causal && kt == qt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + crow(r, half);
@@ -381,8 +385,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 // LDS stage = Q, dO (row-major) and Q^T, dO^T tiles
 // ------------------------------------------------------------------------------------------------------------------
 // (head size 128 keeps one wave per SIMD: 128 accumulator + 64 resident operand registers do not fit 256 without spilling)
-template <int HS>
+// MODE 0: dK and dV together; 1: dV only; 2: dK only.  Head size 256 runs as two launches (1, then 2): 2 x 128 accumulator
+// registers next to 2 x 64 resident operand registers and the staged tiles do not fit one wave (measured: 1220 B/lane of
+// scratch); the score tile is then computed by both launches (1.25x the flops of this kernel).
+template <int HS, int MODE = 0>
 __global__ __launch_bounds__(256, HS == 64 ? 2 : 1) void attn_bwd_dkv_kernel(AttnParams p) {
+    constexpr bool DO_DV = MODE != 2, DO_DK = MODE != 1;
     using G = Geo<HS>;
     constexpr int NS = HS / 16, NM = HS / 32, STAGE = 2 * G::RTILE + 2 * G::CTILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(256, HS == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Att
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             kf[s] = ldfrag(kp + 16 * s, kok);
-            vf[s] = ldfrag(vp + 16 * s, kok);
+            if constexpr (DO_DK) vf[s] = ldfrag(vp + 16 * s, kok);
         }
     }
     f32x16 dv[NM], dk[NM];                                        // dV^T, dK^T [ch][key]
@@ -418,38 +426,39 @@ __global__ __launch_bounds__(256, HS == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Att
     const float* lsep = p.lse + (int64_t)bh * T;
     const float* dsp = p.dsum + (int64_t)bh * T;
     uint4 rq[G::NCH], rd[G::NCH], rqt[G::NCH], rdt[G::NCH];
-    gload_rows<HS>(qbase, rowbase, 32 * kt_min, T, C, tid, rq);
-    gload_rows<HS>(dobase, rowbase, 32 * kt_min, T, C, tid, rd);
-    gload_cols<HS>(qtbase, 32 * kt_min, T, tid, rqt);
-    gload_cols<HS>(dotbase, 32 * kt_min, T, tid, rdt);
+    const int qt_first = p.causal ? kt_min : 0;                   // full attention: every key tile walks all query tiles
+    gload_rows<HS>(qbase, rowbase, 32 * qt_first, T, C, tid, rq);
+    if constexpr (DO_DK) gload_rows<HS>(dobase, rowbase, 32 * qt_first, T, C, tid, rd);
+    if constexpr (DO_DK) gload_cols<HS>(qtbase, 32 * qt_first, T, tid, rqt);
+    if constexpr (DO_DV) gload_cols<HS>(dotbase, 32 * qt_first, T, tid, rdt);
     swrite_rows<HS>(smem, tid, rq);
-    swrite_rows<HS>(smem + G::RTILE, tid, rd);
-    swrite_cols<HS>(smem + 2 * G::RTILE, tid, rqt);
-    swrite_cols<HS>(smem + 2 * G::RTILE + G::CTILE, tid, rdt);
+    if constexpr (DO_DK) swrite_rows<HS>(smem + G::RTILE, tid, rd);
+    if constexpr (DO_DK) swrite_cols<HS>(smem + 2 * G::RTILE, tid, rqt);
+    if constexpr (DO_DV) swrite_cols<HS>(smem + 2 * G::RTILE + G::CTILE, tid, rdt);
     __syncthreads();
-    for (int qt = kt_min; qt < nt; ++qt) {
-        const char* ql = smem + ((qt - kt_min) & 1) * STAGE;
+    for (int qt = qt_first; qt < nt; ++qt) {
+        const char* ql = smem + ((qt - qt_first) & 1) * STAGE;
         const char* dl = ql + G::RTILE;
         const char* qtl = ql + 2 * G::RTILE;
         const char* dtl = qtl + G::CTILE;
         const bool more = qt + 1 < nt;
         if (more) {
             gload_rows<HS>(qbase, rowbase, 32 * (qt + 1), T, C, tid, rq);
-            gload_rows<HS>(dobase, rowbase, 32 * (qt + 1), T, C, tid, rd);
-            gload_cols<HS>(qtbase, 32 * (qt + 1), T, tid, rqt);
-            gload_cols<HS>(dotbase, 32 * (qt + 1), T, tid, rdt);
+            if constexpr (DO_DK) gload_rows<HS>(dobase, rowbase, 32 * (qt + 1), T, C, tid, rd);
+            if constexpr (DO_DK) gload_cols<HS>(qtbase, 32 * (qt + 1), T, tid, rqt);
+            if constexpr (DO_DV) gload_cols<HS>(dotbase, 32 * (qt + 1), T, tid, rdt);
         }
-        if (active && qt >= kt) {
+        if (active && (!p.causal || qt >= kt)) {
             const int q0 = qt * 32;
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
                 s = MFMA(frag_r<HS>(ql, l31, half, st), kf[st], s);
-                dp = MFMA(frag_r<HS>(dl, l31, half, st), vf[st], dp);
+                if constexpr (DO_DK) dp = MFMA(frag_r<HS>(dl, l31, half, st), vf[st], dp);
             }
             // element-wise pass and second GEMMs in two halves (registers 8 s2 .. 8 s2 + 7 = two groups of 4 consecutive
             // queries each): only 8 probabilities / 8 score gradients and 8 per-query statistics are live at a time
-            const bool diag = qt == kt;
+            const bool diag = p.causal && qt == kt;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 Frag pf, df;
@@ -488,23 +497,23 @@ __global__ __launch_bounds__(256, HS == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Att
                 }
 #pragma unroll
                 for (int mt = 0; mt < NM; ++mt) {
-                    dv[mt] = MFMA(frag_c<HS>(dtl, l31, half, mt, s2), pf.v, dv[mt]);
-                    dk[mt] = MFMA(frag_c<HS>(qtl, l31, half, mt, s2), df.v, dk[mt]);
+                    if constexpr (DO_DV) dv[mt] = MFMA(frag_c<HS>(dtl, l31, half, mt, s2), pf.v, dv[mt]);
+                    if constexpr (DO_DK) dk[mt] = MFMA(frag_c<HS>(qtl, l31, half, mt, s2), df.v, dk[mt]);
                 }
             }
         }
         if (more) {
-            char* nl = smem + ((qt + 1 - kt_min) & 1) * STAGE;
+            char* nl = smem + ((qt + 1 - qt_first) & 1) * STAGE;
             swrite_rows<HS>(nl, tid, rq);
-            swrite_rows<HS>(nl + G::RTILE, tid, rd);
-            swrite_cols<HS>(nl + 2 * G::RTILE, tid, rqt);
-            swrite_cols<HS>(nl + 2 * G::RTILE + G::CTILE, tid, rdt);
+            if constexpr (DO_DK) swrite_rows<HS>(nl + G::RTILE, tid, rd);
+            if constexpr (DO_DK) swrite_cols<HS>(nl + 2 * G::RTILE, tid, rqt);
+            if constexpr (DO_DV) swrite_cols<HS>(nl + 2 * G::RTILE + G::CTILE, tid, rdt);
         }
         __syncthreads();
     }
     if (kok) {
-        store_ct<NM>(p.dv + (rowbase + krow) * C + h * HS, dv, half, 1.f);
-        store_ct<NM>(p.dk + (rowbase + krow) * C + h * HS, dk, half, p.scale);
+        if constexpr (DO_DV) store_ct<NM>(p.dv + (rowbase + krow) * C + h * HS, dv, half, 1.f);
+        if constexpr (DO_DK) store_ct<NM>(p.dk + (rowbase + krow) * C + h * HS, dk, half, p.scale);
     }
 }
 
@@ -521,17 +530,26 @@ int launch_bwd(const AttnParams& p, dim3 grid, int64_t rows, hipStream_t stream)
     using G = Geo<HS>;
     attn_rowdot_kernel<HS><<<dim3((unsigned)cdiv64(rows * p.nh, 256)), dim3(256), 0, stream>>>(p, rows);
     const int lds_kv = 2 * (2 * G::RTILE + 2 * G::CTILE), lds_q = 2 * (2 * G::RTILE + G::CTILE);
-    dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS>, lds_kv);
     dvq_ensure_dynamic_lds((const void*)attn_bwd_dq_kernel<HS>, lds_q);
-    attn_bwd_dkv_kernel<HS><<<grid, dim3(256), lds_kv, stream>>>(p);
+    if constexpr (HS > 128) {
+        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 1>, lds_kv);
+        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 2>, lds_kv);
+        attn_bwd_dkv_kernel<HS, 1><<<grid, dim3(256), lds_kv, stream>>>(p);
+        attn_bwd_dkv_kernel<HS, 2><<<grid, dim3(256), lds_kv, stream>>>(p);
+    } else {
+        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS>, lds_kv);
+        attn_bwd_dkv_kernel<HS><<<grid, dim3(256), lds_kv, stream>>>(p);
+    }
     attn_bwd_dq_kernel<HS><<<grid, dim3(256), lds_q, stream>>>(p);
     return 0;
 }
 
 int fill_params(AttnParams& p, const char* who, int dtype, int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop,
-                uint64_t seed) {
-    DVQ_REQUIRE(dtype == DVQ_BF16 && (head_dim == 64 || head_dim == 128), DVQ_ESHAPE,
-                "%s: bf16 with head size 64 or 128 only (use the per-head GEMM path otherwise)", who);
+                uint64_t seed, int causal = 1) {
+    DVQ_REQUIRE(dtype == DVQ_BF16 && (head_dim == 64 || head_dim == 128 || (head_dim == 256 && !causal)), DVQ_ESHAPE,
+                "%s: bf16 with head size 64 or 128 (causal) / 256 (full attention) only (use the GEMM path otherwise)", who);
+    DVQ_REQUIRE(causal || T % 32 == 0, DVQ_ESHAPE, "%s: full attention needs T %% 32 == 0", who);
+    p.causal = causal;
     DVQ_REQUIRE(B > 0 && T > 0 && T % 8 == 0 && n_head > 0 && B * n_head <= 65535 && p_drop >= 0.f && p_drop < 1.f, DVQ_ESHAPE,
                 "%s: bad geometry (T %% 8 == 0, B * n_head <= 65535)", who);
     DVQ_REQUIRE((double)B * n_head * (double)T * (double)T < 4294967296.0, DVQ_ESHAPE,
@@ -596,6 +614,52 @@ int dvq_attn_causal_bwd(const void* q, const void* k, const void* v, const void*
     if (head_dim == 64) launch_bwd<64>(p, grid, B * T, (hipStream_t)stream);
     else launch_bwd<128>(p, grid, B * T, (hipStream_t)stream);
     DVQ_CHECK_LAUNCH("attn_causal_bwd");
+    return DVQ_OK;
+}
+
+/* ---- single-head FULL (non-causal) attention of the DQ-VAE's AttnBlock (modules/diffusionmodules/model.py:168-192): same kernels,
+ * one head of size C = 256, every query sees every key, no dropout; scores never reach HBM. ---- */
+int64_t dvq_attn_full_scratch_bytes(int64_t B, int64_t T, int C, int backward) {
+    return dvq_attn_causal_scratch_bytes(B, T, 1, C, backward);
+}
+
+int dvq_attn_full_fwd(const void* q, const void* k, const void* v, int dtype, int64_t B, int64_t T, int C, float scale, void* out,
+                      float* lse, void* scratch, dvq_stream_t stream) {
+    DVQ_REQUIRE(q && k && v && out && lse && scratch, DVQ_EINVAL, "dvq_attn_full_fwd: null pointer");
+    AttnParams p{};
+    int rc = fill_params(p, "dvq_attn_full_fwd", dtype, B, T, 1, C, scale, 0.f, 0, 0);
+    if (rc != DVQ_OK) return rc;
+    rc = dvq_transpose(v, dtype, B, T, p.C, scratch, stream);                        // v^T [B][C][T]
+    if (rc != DVQ_OK) return rc;
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.vt = (const bf16_t*)scratch;
+    p.out = (bf16_t*)out; p.lse = lse;
+    const int nqt = (int)(T / 32);
+    launch_fwd<256>(p, dim3((unsigned)((nqt + 3) / 4), (unsigned)B), (hipStream_t)stream);
+    DVQ_CHECK_LAUNCH("attn_full_fwd");
+    return DVQ_OK;
+}
+
+int dvq_attn_full_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse, int dtype,
+                      int64_t B, int64_t T, int C, float scale, void* dq, void* dk, void* dv, void* scratch, dvq_stream_t stream) {
+    DVQ_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && scratch, DVQ_EINVAL, "dvq_attn_full_bwd: null pointer");
+    AttnParams p{};
+    int rc = fill_params(p, "dvq_attn_full_bwd", dtype, B, T, 1, C, scale, 0.f, 0, 0);
+    if (rc != DVQ_OK) return rc;
+    const int64_t elems = B * T * p.C;
+    bf16_t* qt = (bf16_t*)scratch;
+    bf16_t* kt = qt + elems;
+    bf16_t* dot = kt + elems;
+    float* dsum = reinterpret_cast<float*>(dot + elems);
+    if ((rc = dvq_transpose(q, dtype, B, T, p.C, qt, stream)) != DVQ_OK) return rc;
+    if ((rc = dvq_transpose(k, dtype, B, T, p.C, kt, stream)) != DVQ_OK) return rc;
+    if ((rc = dvq_transpose(dout, dtype, B, T, p.C, dot, stream)) != DVQ_OK) return rc;
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (const bf16_t*)out; p.dout = (const bf16_t*)dout;
+    p.qt = qt; p.kt = kt; p.dot = dot;
+    p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
+    p.lse = const_cast<float*>(lse); p.dsum = dsum;
+    const int nt = (int)(T / 32);
+    launch_bwd<256>(p, dim3((unsigned)((nt + 3) / 4), (unsigned)B), B * T, (hipStream_t)stream);
+    DVQ_CHECK_LAUNCH("attn_full_bwd");
     return DVQ_OK;
 }
 

@@ -138,8 +138,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
     const int nchunks = p.dbg == 2 ? 0 : (p.Cin >> 6);
     for (int c = 0; c < nchunks; ++c) {
         const int c0 = c * 64;
-        issue_halo(c0);                 // safe: the barrier that ended the previous chunk's last tap is behind us
-        issue_b(0, c0, 0);
+        if (c == 0 || p.dbg != 3) issue_halo(c0);      // safe: the barrier that ended the previous chunk's last tap is behind us
+        issue_b(0, c0, 0);                             // (dbg 3 / 4: timing experiments -- halo of chunk 0 / weight stage 0 reused)
         if (p.gn_ss != nullptr && tid < 128) ssl[tid] = p.gn_ss[((int64_t)n * p.Cin + c0) * 2 + tid];
         __syncthreads();                // vmcnt(0) + barrier: halo and first weight stage have landed
         if (p.gn_ss != nullptr) {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
         }
         for (int tap = 0; tap < 9; ++tap) {
             const int buf = tap & 1;
-            if (tap + 1 < 9) issue_b(tap + 1, c0, buf ^ 1);
+            if (tap + 1 < 9 && p.dbg != 4) issue_b(tap + 1, c0, buf ^ 1);
             const int kh = tap / 3, kw = tap - kh * 3;
             const char* pa[MT];
             int sa[MT];

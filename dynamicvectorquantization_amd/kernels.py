@@ -788,6 +788,34 @@ def attn_causal_bwd(q, k, v, out, dout, lse, b, t, n_head, scale, p_drop=0.0, se
     return dq, dk, dv
 
 
+def attn_full_ok(q, t):
+    """eligibility of the fused single-head full attention (AttnBlock): bf16, C = 256, T % 32 == 0"""
+    return (q.dtype == torch.bfloat16 and q.shape[-1] == 256 and t % 32 == 0 and q.shape[0] // max(1, t) <= 65535
+            and os.environ.get("DVQ_NO_FUSED_ATTNBLOCK", "0") != "1")
+
+
+def attn_full_fwd(q, k, v, b, t, scale):
+    """q, k, v [B*T, C] -> (out [B*T, C], lse fp32 [B, T]); softmax over ALL keys of the image (model.py:168-192)"""
+    c = q.shape[-1]
+    out = torch.empty_like(q)
+    lse = torch.empty(b, t, dtype=torch.float32, device=q.device)
+    scratch = torch.empty(lib().dvq_attn_full_scratch_bytes(b, t, c, 0), dtype=torch.uint8, device=q.device)
+    _timed("attn_full_fwd", 4 * b * t * t * c, 4 * q.numel() * q.element_size(), lambda: check(
+        lib().dvq_attn_full_fwd(_p(q), _p(k), _p(v), dt(q), b, t, c, float(scale), _p(out), _p(lse), _p(scratch), _s()),
+        "dvq_attn_full_fwd"))
+    return out, lse
+
+
+def attn_full_bwd(q, k, v, out, dout, lse, b, t, scale):
+    c = q.shape[-1]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    scratch = torch.empty(lib().dvq_attn_full_scratch_bytes(b, t, c, 1), dtype=torch.uint8, device=q.device)
+    _timed("attn_full_bwd", 10 * b * t * t * c, 8 * q.numel() * q.element_size(), lambda: check(
+        lib().dvq_attn_full_bwd(_p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), dt(q), b, t, c, float(scale), _p(dq), _p(dk), _p(dv),
+                                _p(scratch), _s()), "dvq_attn_full_bwd"))
+    return dq, dk, dv
+
+
 def attn_decode_dev(q, k_new, v_new, kcache, vcache, n_head, t_dev, scale):
     """device-indexed form (graph replay): append (k_new, v_new) at cache row t_dev[0], attend over rows [0, t]"""
     b, c = q.shape

@@ -545,6 +545,13 @@ class AttnBlock(HipModule):
         k = self.k.fwd(hn, _child(tape, "k"))
         v = self.v.fwd(hn, _child(tape, "v"))
         impl = rt.impl()
+        if impl == 0 and K.attn_full_ok(q.view(b * n, c), n):
+            # fused single-head attention (flash recurrence, head size C = 256): the [B,N,N] scores never reach HBM
+            o, lse = K.attn_full_fwd(q.view(b * n, c), k.view(b * n, c), v.view(b * n, c), b, n, float(int(c) ** (-0.5)))
+            y = self.proj_out.fwd(o.view(b, h, w, c), _child(tape, "proj"), residual=x)
+            if tape is not None:
+                tape.s.update(q=q, k=k, v=v, o=o, lse=lse, p=None, shape=(b, h, w, c))
+            return y
         s = K.gemm_nt(q, k, n, n, c, c, c, n, batch=b, sa=n * c, sb=n * c, sc=n * n, impl=impl)       # q k^T
         p = K.softmax_rows(s, b * n, n, float(int(c) ** (-0.5)))
         vt = K.transpose(v, b, n, c)                                                                    # [b,c,n]
@@ -562,6 +569,13 @@ class AttnBlock(HipModule):
         q, k, v, p = st["q"], st["k"], st["v"], st["p"]
         impl = rt.impl()
         do = self.proj_out.bwd(dy, tape.child("proj"))
+        if p is None:                                   # fused forward: fused backward (dQ, then dV and dK kernels)
+            dq, dk, dv = K.attn_full_bwd(q.view(b * n, c), k.view(b * n, c), v.view(b * n, c), st["o"], do.view(b * n, c), st["lse"],
+                                         b, n, float(int(c) ** (-0.5)))
+            dh = self.q.bwd(dq.view(b, h, w, c), tape.child("q"))
+            dh = K.add(dh, self.k.bwd(dk.view(b, h, w, c), tape.child("k")))
+            dh = K.add(dh, self.v.bwd(dv.view(b, h, w, c), tape.child("v")))
+            return self.norm.bwd(dh, tape.child("norm"), addend=dy)
         dp = K.gemm_nt(do, v, n, n, c, c, c, n, batch=b, sa=n * c, sb=n * c, sc=n * n, impl=impl)      # dO v^T
         dv32 = K.gemm_tn(p, do, n, n, c, n, c, c, batch=b, sa=n * n, sb=n * c, sc=n * c, impl=impl)    # p^T dO
         ds = K.softmax_rows_bwd(p, dp, b * n, n, float(int(c) ** (-0.5)))

@@ -370,6 +370,15 @@ int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, 
 int dvq_attn_causal_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse, int dtype,
                         int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop, uint64_t seed, void* dq, void* dk,
                         void* dv, void* scratch, dvq_stream_t stream);
+/* Single-head FULL (non-causal) self-attention of the DQ-VAE's AttnBlock (modules/diffusionmodules/model.py:168-192:
+ * w = softmax_j(q^T k * C^-1/2), h = v w^T) for C = 256 (bf16, T %% 32 == 0): the same flash kernels as above with one head of
+ * size C, no mask, no dropout; q, k, v, out [B*T][C]; lse fp32 [B][T].  The [B,T,T] score tensor never reaches HBM.  Other
+ * shapes (C = 512) return DVQ_ESHAPE: the caller keeps the GEMM + softmax path for them. */
+int64_t dvq_attn_full_scratch_bytes(int64_t B, int64_t T, int C, int backward);
+int dvq_attn_full_fwd(const void* q, const void* k, const void* v, int dtype, int64_t B, int64_t T, int C, float scale, void* out,
+                      float* lse, void* scratch, dvq_stream_t stream);
+int dvq_attn_full_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse, int dtype,
+                      int64_t B, int64_t T, int C, float scale, void* dq, void* dk, void* dv, void* scratch, dvq_stream_t stream);
 /* Attention of ONE new query row per sequence over a K/V cache (KV-cached sampling; the reference's sampler recomputes the
  * whole prefix, stackgpt.py:234-339): q [B][C], kcache / vcache [B][Tmax][C] (C = n_head * head_size), T valid rows incl.
  * the new one; out [B][C] = softmax(scale * q K^T) V per head. */

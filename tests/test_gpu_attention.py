@@ -115,3 +115,58 @@ def test_attention_module_fused_equals_unfused_full_size(dev, train, n_head):
         # two bf16 pipelines of the same arithmetic: L2 agreement (isolated bf16 rounding flips aside)
         err = float(np.linalg.norm(a - r) / max(1e-9, np.linalg.norm(r)))
         assert err < 2e-2, f"{name}: relative L2 difference {err}"
+
+
+def _reference_full(q, k, v, dout, b, t):
+    """fp64 restatement of AttnBlock's attention (modules/diffusionmodules/model.py:173-187): one head of size C, softmax over
+    all keys of the image, scale C^-1/2"""
+    c = q.shape[1]
+    qs, ks, vs = (torch.from_numpy(a).double().view(b, t, c).requires_grad_(True) for a in (q, k, v))
+    att = (qs @ ks.transpose(-2, -1)) * (float(c) ** -0.5)
+    y = (att.softmax(dim=-1) @ vs).reshape(b * t, c)
+    (y * torch.from_numpy(dout).double()).sum().backward()
+    return y.detach().numpy(), qs.grad.reshape(b * t, c).numpy(), ks.grad.reshape(b * t, c).numpy(), vs.grad.reshape(b * t, c).numpy()
+
+
+@pytest.mark.parametrize("shape", [(2, 256), (1, 32), (3, 1024), (2, 160)], ids=lambda s: "x".join(map(str, s)))
+def test_fused_full_attention_vs_fp64_reference(dev, shape):
+    """single-head full attention with head size 256 (the AttnBlocks at 32x32 / 16x16 maps of 256 channels): forward, dQ, dK, dV"""
+    from dynamicvectorquantization_amd import kernels as K
+    b, t = shape
+    c = 256
+    rs = np.random.RandomState(b * 100 + t)
+    q, k, v, dout = (_bf16(rs.standard_normal((b * t, c)).astype(np.float32) * s) for s in (2.0, 2.0, 1.0, 1.0))
+    yr, dqr, dkr, dvr = _reference_full(q, k, v, dout, b, t)
+    dq_, dk_, dv_, do_ = (torch.from_numpy(a).to(dev, torch.bfloat16) for a in (q, k, v, dout))
+    assert K.attn_full_ok(dq_, t)
+    y, lse = K.attn_full_fwd(dq_, dk_, dv_, b, t, float(c) ** -0.5)
+    gq, gk, gv = K.attn_full_bwd(dq_, dk_, dv_, y, do_, lse, b, t, float(c) ** -0.5)
+    torch.cuda.synchronize()
+    assert _rel(y.float().cpu().numpy(), yr) < 2e-2
+    lse_ref = torch.logsumexp((torch.from_numpy(q).double().view(b, t, c) @ torch.from_numpy(k).double().view(b, t, c).transpose(1, 2))
+                              * (float(c) ** -0.5), dim=-1).numpy()
+    assert float(np.abs(lse.cpu().numpy() - lse_ref).max()) < 2e-2
+    assert _rel(gq.float().cpu().numpy(), dqr) < 3e-2 and _rel(gk.float().cpu().numpy(), dkr) < 3e-2
+    assert _rel(gv.float().cpu().numpy(), dvr) < 3e-2
+
+
+def test_attnblock_fused_equals_unfused_path(dev, monkeypatch):
+    """AttnBlock (C = 256, 32x32 map): the fused path and the GEMM + softmax path agree on output, input gradient and
+    parameter gradients (bf16 tolerance); C = 512 blocks stay on the GEMM path"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import AttnBlock
+    res = {}
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        for tag, off in (("fused", "0"), ("gemm", "1")):
+            monkeypatch.setenv("DVQ_NO_FUSED_ATTNBLOCK", off)
+            torch.manual_seed(0)
+            blk = AttnBlock(256).to(dev)
+            x = torch.randn(2, 256, 32, 32, device=dev).requires_grad_(True)
+            y = blk(x)
+            (y * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum().backward()
+            res[tag] = (y.detach().float(), x.grad.float(), blk.q.weight.grad.float().clone(), blk.v.weight.grad.float().clone(),
+                        blk.proj_out.weight.grad.float().clone())
+        assert not K.attn_full_ok(torch.empty(64, 512, dtype=torch.bfloat16, device=dev), 64)
+    for a, b_ in zip(res["fused"], res["gemm"]):
+        assert float((a - b_).abs().max()) <= 3e-2 * float(b_.abs().max()) + 1e-6
