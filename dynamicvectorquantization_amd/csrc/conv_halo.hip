@@ -11,6 +11,7 @@
 // 16-B chunk c of row r sits at chunk position c ^ ((r >> 1) & 7) (conflict-free b128 fragment reads for any
 // row offset), applied on the DMA source address.  Epilogue: tile staged through LDS, 16-byte stores.
 #include "dvq_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -64,7 +65,12 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // NT = 32-channel output tiles per wave (4 -> 128 output channels per workgroup; 2 / 1 for Cout <= 64 / 32 so that thin
 // layers -- VGG16's 64-channel block, the 3-channel image head -- do not pay for a mostly empty 128-wide tile).
 // WN = wave columns over the output channels (1, or 2 with NW = 8): CO_T = 32 * NT * WN.
-template <int NW, int NT, int WN = 1>
+// PIPE (NW = 4): the main loop is software-pipelined ACROSS taps and its memory instructions are pinned into the shadow of the
+//   MFMAs (sched_group_barrier): every 16-k step issues its 8 MFMAs with the next step's 6 fragment reads -- and, in the first two
+//   steps of a tap, the next tap's weight DMA -- slotted between them; the per-tap barrier sits before the LAST step, whose MFMAs
+//   then cover the first fragment reads of the next tap.  Without it the wave issues [4 DMA + address math][12 reads][wait][8 MFMA]
+//   [6 reads][8 MFMA]... and roughly a third of every tap is spent outside the MFMA pipe.
+template <int NW, int NT, int WN = 1, bool PIPE = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x3_halo_kernel(HaloParams p) {   // (threads, waves per SIMD)
     constexpr int MT = 8 * WN / NW;     // image rows (32-pixel m-tiles) per wave
     constexpr int CO_T = 32 * NT * WN;  // output channels per workgroup
@@ -136,6 +142,142 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
 
     const int swzB = (l31 >> 1) & 7;
     const int nchunks = p.dbg == 2 ? 0 : (p.Cin >> 6);
+    if constexpr (PIPE) {
+        static_assert(WN == 1 && NW == 4, "pipelined main loop: 4 waves, one wave column");
+        constexpr int NP = CO_T / NW / 8;           // weight DMA pieces per wave and tap
+        constexpr int NM = MT * NT, NDS = MT + NT;  // MFMAs / fragment reads per 16-k step
+        int boff[NP];                               // element offset of this lane's 16 bytes of piece i at tap 0, channel 0 (-1: no row)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = wave * (CO_T / NW) + i * 8 + lrow;
+            boff[i] = n0 + row < p.Cout ? (n0 + row) * 9 * p.Cin + (cpos ^ ((row >> 1) & 7)) * 8 : -1;
+        }
+        auto issue_b_piece = [&](int i, int tapx, int c0, int buf) {
+            const int tb = p.flip ? 8 - tapx : tapx;
+            const bf16_t* src = boff[i] >= 0 ? p.Wt + (boff[i] + tb * p.Cin + c0) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(bst + buf * BSTAGE + (wave * (CO_T / NW) + i * 8) * ROWB),
+                                             16, 0, 0);
+        };
+        const char* pa[MT];
+        const char* pb;
+        int sa[MT];
+        auto set_tap = [&](int tapx, int buf) {
+            const int kh = tapx / 3, kw = tapx - kh * 3;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int hp = (MT * wm + mt + kh) * HW_ + l31 + kw;
+                pa[mt] = halo + hp * ROWB;
+                sa[mt] = (hp >> 1) & 7;
+            }
+            pb = bst + buf * BSTAGE + l31 * ROWB;
+        };
+        bf16x8 a[2][MT], b[2][NT];
+        auto load_frags = [&](int ks, int slot) {      // in the order the MFMAs consume them
+            a[slot][0] = *reinterpret_cast<const bf16x8*>(pa[0] + (((ks * 2 + half) ^ sa[0]) << 4));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                b[slot][nt] = *reinterpret_cast<const bf16x8*>(pb + nt * 32 * ROWB + (((ks * 2 + half) ^ swzB) << 4));
+#pragma unroll
+            for (int mt = 1; mt < MT; ++mt)
+                a[slot][mt] = *reinterpret_cast<const bf16x8*>(pa[mt] + (((ks * 2 + half) ^ sa[mt]) << 4));
+        };
+        // the NM MFMAs of one step, then the issue order of the region: MFMA, fragment read(s), ..., DMA pieces behind the last MFMAs
+        auto mfma_step = [&](int slot, auto nds_tag, auto nvm_tag) {
+            constexpr int DS = decltype(nds_tag)::value, VM = decltype(nvm_tag)::value;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[slot][nt], a[slot][mt], acc[mt][nt], 0, 0, 0);
+            // behind MFMA i: one DMA piece while there are any (they precede the reads in program order: the scheduler keeps
+            // LDS-DMA writes and LDS reads in order), then the fragment reads spread over the remaining MFMAs
+            constexpr int S = NM - VM > 0 ? NM - VM : 1;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < VM) {
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                } else {
+#pragma unroll
+                    for (int r = (i - VM) * DS / S; r < (i - VM + 1) * DS / S; ++r) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using IDS = std::integral_constant<int, NDS>;
+        using IV0 = std::integral_constant<int, (NP + 1) / 2>;
+        using IV1 = std::integral_constant<int, NP / 2>;
+
+        if (nchunks > 0) {
+            issue_halo(0);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) issue_b_piece(i, 0, 0, 0);
+        }
+        int g = 0;                                      // taps done: weight stage of tap g is g & 1
+        for (int c = 0; c < nchunks; ++c) {
+            const int c0 = c * 64;
+            if (p.gn_ss != nullptr && tid < 128) ssl[tid] = p.gn_ss[((int64_t)n * p.Cin + c0) * 2 + tid];
+            __syncthreads();                            // vmcnt(0) + barrier: this chunk's halo (and its first weight stage) have landed
+        if (p.gn_ss != nullptr) {
+            // fused GroupNorm + swish: y = z * sigmoid(z), z = x * scale[c] + shift[c], applied in place to the halo tile
+            for (int q = tid; q < HROWS * 8; q += NTH) {
+                const int hp = q >> 3, cp = q & 7;
+                const int hy = hp / HW_, hx = hp - hy * HW_;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                if ((unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) continue;   // padding stays zero
+                const int cg = cp ^ ((hp >> 1) & 7);                  // channel chunk stored at this position
+                uint4* ptr = reinterpret_cast<uint4*>(halo + hp * ROWB + cp * 16);
+                uint4 v = *ptr;
+                unsigned* pv = &v.x;
+                const float* sc = ssl + cg * 16;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = swishf(fmaf(__uint_as_float(pv[k] << 16), sc[4 * k + 0], sc[4 * k + 1]));
+                    const float hi = swishf(fmaf(__uint_as_float(pv[k] & 0xffff0000u), sc[4 * k + 2], sc[4 * k + 3]));
+                    pv[k] = pack_bf16x2(lo, hi);
+                }
+                *ptr = v;
+            }
+            __syncthreads();
+        }
+            set_tap(0, g & 1);
+            load_frags(0, 0);
+            auto tap_body = [&](int tap, auto last_tag) {
+                constexpr bool LAST = decltype(last_tag)::value;      // tap 8: what follows is the next chunk (or the epilogue)
+                const int buf = g & 1;
+                const int tapn = LAST ? 0 : tap + 1;
+                const int c0n = LAST ? (c + 1 < nchunks ? c0 + 64 : 0) : c0;     // (after the last chunk: a harmless re-fetch)
+                __builtin_amdgcn_sched_barrier(0);
+                // step 0: reads of step 1, first half of the next tap's weight pieces (their stage was last read in tap g - 1)
+#pragma unroll
+                for (int i = 0; i < (NP + 1) / 2; ++i) issue_b_piece(i, tapn, c0n, buf ^ 1);
+                load_frags(1, 1);
+                mfma_step(0, IDS{}, IV0{});
+#pragma unroll
+                for (int i = (NP + 1) / 2; i < NP; ++i) issue_b_piece(i, tapn, c0n, buf ^ 1);
+                load_frags(2, 0);
+                mfma_step(1, IDS{}, IV1{});
+                load_frags(3, 1);
+                mfma_step(0, IDS{}, I0{});
+                // every wave has all its reads of this tap behind it and its share of the next tap's weights landed
+                __syncthreads();
+                if constexpr (!LAST) {
+                    set_tap(tap + 1, buf ^ 1);
+                    load_frags(0, 0);
+                    mfma_step(1, IDS{}, I0{});
+                } else {
+                    if (c + 1 < nchunks) issue_halo(c0 + 64);      // the halo tile is dead: refill it under the last MFMAs
+                    mfma_step(1, I0{}, I0{});
+                }
+                ++g;
+            };
+#pragma unroll 1
+            for (int tap = 0; tap < 8; ++tap) tap_body(tap, std::false_type{});
+            tap_body(8, std::true_type{});
+        }
+    } else {
     for (int c = 0; c < nchunks; ++c) {
         const int c0 = c * 64;
         if (c == 0 || p.dbg != 3) issue_halo(c0);      // safe: the barrier that ended the previous chunk's last tap is behind us
@@ -197,11 +339,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][mt], b[ks & 1][nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks & 1][nt], a[ks & 1][mt], acc[mt][nt], 0, 0, 0);   // (W X^T): channels on the register axis
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
         }
+    }
+
     }
 
     // ---- epilogue: stage the 256 px x 128 co tile as bf16 rows of 256 B, then 16-byte global stores -----------
@@ -214,36 +358,64 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
         if (acc[0][0][0] == 12345.678f) p.Y[0] = 0;       // keep the accumulators alive
         return;
     }
-    bf16_t* st = reinterpret_cast<bf16_t*>(smem);
     const bool early_act = p.R == nullptr || p.res_mask;     // no residual add between the accumulator and the activation
+    // The MFMAs computed (W X^T): a lane holds ONE pixel (l31) and, in registers 4j .. 4j+3 of tile nt, the 4 consecutive output
+    // channels nt*32 + 8j + 4*half ..: packed pairs (v_cvt_pk_bf16_f32) and 8-byte LDS stores, 32 per lane instead of 128
+    // 2-byte ones.  Staged rows are unpadded (CO_T * 2 bytes); 16-byte chunk c of pixel row lp sits at position c ^ swz(lp) so
+    // that both the column-wise 8-byte stores here and the row-wise 16-byte reads below are bank-conflict free.
+    constexpr int ITERS = 256 * CPRW / NTH;
+    constexpr int SWZ_SH = CPRW == 16 ? 0 : CPRW == 8 ? 1 : 2;
+    uint4 rpre[ITERS];      // residual / gate tile, requested before the staging so that its latency hides behind it
+    if (p.R != nullptr) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int q = tid + NTH * i;
+            const int lp = q / CPRW, ch = q % CPRW;
+            const int col = n0 + ch * 8;
+            const int64_t o = ((img + (int64_t)(y0 + (lp >> 5)) * p.W + x0 + (lp & 31)) * p.Cout) + col;
+            rpre[i] = col < p.Cout ? *reinterpret_cast<const uint4*>(p.R + o) : uint4{0, 0, 0, 0};
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int lc = (wn * NT + nt) * 32 + l31;
-        const float bcol = (p.bias != nullptr && n0 + lc < p.Cout) ? p.bias[n0 + lc] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int j = 0; j < 4; ++j) {
+            const int lc = (wn * NT + nt) * 32 + 8 * j + 4 * half;      // first of this lane's 4 channels
+            float4 bq = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias != nullptr && n0 + lc < p.Cout) bq = *reinterpret_cast<const float4*>(p.bias + n0 + lc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lp = (MT * wm + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = acc[mt][nt][r] + bcol;
-                if (early_act) v = v > 0.f ? v : v * p.act_slope;
-                st[lp * CO_T + lc] = f32_to_bf16(v);
+            for (int mt = 0; mt < MT; ++mt) {
+                const int lp = (MT * wm + mt) * 32 + l31;
+                float v0 = acc[mt][nt][4 * j] + bq.x, v1 = acc[mt][nt][4 * j + 1] + bq.y;
+                float v2 = acc[mt][nt][4 * j + 2] + bq.z, v3 = acc[mt][nt][4 * j + 3] + bq.w;
+                if (early_act) {
+                    v0 = v0 > 0.f ? v0 : v0 * p.act_slope;
+                    v1 = v1 > 0.f ? v1 : v1 * p.act_slope;
+                    v2 = v2 > 0.f ? v2 : v2 * p.act_slope;
+                    v3 = v3 > 0.f ? v3 : v3 * p.act_slope;
+                }
+                const int chunk = ((wn * NT + nt) * 4 + j) ^ ((lp >> SWZ_SH) & (CPRW - 1));
+                uint2 pk;
+                pk.x = pack_bf16x2(v0, v1);
+                pk.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(smem + lp * (CO_T * 2) + chunk * 16 + half * 8) = pk;
             }
+        }
     }
     __syncthreads();
     float gs[8], gq[8];                 // output statistics of this thread's 8 channels (chunk tid & 15 in every iteration)
 #pragma unroll
     for (int k = 0; k < 8; ++k) gs[k] = gq[k] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 256 * CPRW / NTH; ++i) {
+    for (int i = 0; i < ITERS; ++i) {
         const int q = tid + NTH * i;
         const int lp = q / CPRW, ch = q % CPRW;
         const int col = n0 + ch * 8;
         if (col >= p.Cout) continue;
-        uint4 v = *reinterpret_cast<const uint4*>(smem + lp * (CO_T * 2) + ch * 16);
+        uint4 v = *reinterpret_cast<const uint4*>(smem + lp * (CO_T * 2) + ((ch ^ ((lp >> SWZ_SH) & (CPRW - 1))) << 4));
         const int64_t o = ((img + (int64_t)(y0 + (lp >> 5)) * p.W + x0 + (lp & 31)) * p.Cout) + col;
         if (p.R) {
-            const uint4 rv = *reinterpret_cast<const uint4*>(p.R + o);
+            const uint4 rv = rpre[i];
             unsigned* pv = &v.x;
             const unsigned* pr = &rv.x;
 #pragma unroll
@@ -381,21 +553,36 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
         const char* e = getenv("DVQ_HALO_WAVES");
         return e != nullptr ? atoi(e) : 0;
     }();
+    static const int pipe_env = [] {
+        const char* e = getenv("DVQ_HALO_PIPE");
+        return e != nullptr ? atoi(e) : 1;
+    }();
     if (nw_env == 8 && cot == 128) {   // experiment: 8 waves x (2 x 2 tiles), four waves per SIMD
         dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<8, 2, 2>, LDSB);
         conv3x3_halo_kernel<8, 2, 2><<<dim3((unsigned)blocks), dim3(512), LDSB, stream>>>(p);
     } else if (nw_env == 2 && cot == 128) {   // experiment: 2 waves x (4 x 4 tiles); measured 2x slower (1 wave per SIMD)
         dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<2, 4>, LDSB);
         conv3x3_halo_kernel<2, 4><<<dim3((unsigned)blocks), dim3(128), LDSB, stream>>>(p);
+    } else if (pipe_env == 0) {        // DVQ_HALO_PIPE=0: the un-pipelined main loop (A/B timing)
+        if (cot == 128) {
+            dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 4>, LDSB);
+            conv3x3_halo_kernel<4, 4><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+        } else if (cot == 64) {
+            dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 2>, LDSB);
+            conv3x3_halo_kernel<4, 2><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+        } else {
+            dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 1>, LDSB);
+            conv3x3_halo_kernel<4, 1><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+        }
     } else if (cot == 128) {
-        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 4>, LDSB);
-        conv3x3_halo_kernel<4, 4><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 4, 1, true>, LDSB);
+        conv3x3_halo_kernel<4, 4, 1, true><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
     } else if (cot == 64) {
-        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 2>, LDSB);
-        conv3x3_halo_kernel<4, 2><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 2, 1, true>, LDSB);
+        conv3x3_halo_kernel<4, 2, 1, true><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
     } else {
-        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 1>, LDSB);
-        conv3x3_halo_kernel<4, 1><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 1, 1, true>, LDSB);
+        conv3x3_halo_kernel<4, 1, 1, true><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
     }
     if (p.stat_part != nullptr)
         halo_stats_finalize_kernel<<<dim3((unsigned)(N * out_groups)), dim3(64), 0, stream>>>(p.stat_part, ntiles, out_stats);
