@@ -46,7 +46,8 @@ struct HaloParams {
     float act_slope;     // output activation v > 0 ? v : act_slope * v (1: none, 0: ReLU, 0.2: LeakyReLU), applied last
     int res_mask;        // 1: R is not added but gates the result: v *= (R > 0 ? 1 : mask_slope)  (backward of ReLU / LeakyReLU)
     float mask_slope;
-    int dbg;             // profiling experiments only (DVQ_HALO_DBG): 1 = skip the epilogue, 2 = skip the MFMA loop
+    int dbg;             // profiling experiments only (DVQ_HALO_DBG): 1 = skip the epilogue, 2 = skip the MFMA loop, 5 = print the
+                         //   shader clock and the duration of one workgroup's main loop
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
         }
     };
 
+    const unsigned long long dbg_c0 = p.dbg == 5 ? __builtin_readcyclecounter() : 0, dbg_w0 = p.dbg == 5 ? wall_clock64() : 0;
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -146,15 +148,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
         static_assert(WN == 1 && NW == 4, "pipelined main loop: 4 waves, one wave column");
         constexpr int NP = CO_T / NW / 8;           // weight DMA pieces per wave and tap
         constexpr int NM = MT * NT, NDS = MT + NT;  // MFMAs / fragment reads per 16-k step
-        int boff[NP];                               // element offset of this lane's 16 bytes of piece i at tap 0, channel 0 (-1: no row)
+        int boff[NP];                               // element offset of this lane's 16 bytes of piece i at tap 0, channel 0
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int row = wave * (CO_T / NW) + i * 8 + lrow;
-            boff[i] = n0 + row < p.Cout ? (n0 + row) * 9 * p.Cin + (cpos ^ ((row >> 1) & 7)) * 8 : -1;
+            // rows past Cout re-read the last real row: their output channels are never stored nor counted in the statistics
+            boff[i] = min(n0 + row, p.Cout - 1) * 9 * p.Cin + (cpos ^ ((row >> 1) & 7)) * 8;
         }
         auto issue_b_piece = [&](int i, int tapx, int c0, int buf) {
             const int tb = p.flip ? 8 - tapx : tapx;
-            const bf16_t* src = boff[i] >= 0 ? p.Wt + (boff[i] + tb * p.Cin + c0) : zero;
+            const bf16_t* src = p.Wt + (boff[i] + tb * p.Cin + c0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(bst + buf * BSTAGE + (wave * (CO_T / NW) + i * 8) * ROWB),
                                              16, 0, 0);
@@ -357,6 +360,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
     if (p.dbg == 1) {
         if (acc[0][0][0] == 12345.678f) p.Y[0] = 0;       // keep the accumulators alive
         return;
+    }
+    if (p.dbg == 5 && tid == 0 && (blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x / 2 + 1)) {   // shader clock during the main loop
+        const unsigned long long dc = __builtin_readcyclecounter() - dbg_c0, dw = wall_clock64() - dbg_w0;
+        printf("halo main loop of block %u: %llu shader cycles in %llu x 10 ns -> %.0f MHz\n", blockIdx.x, dc, dw, 100.0 * (double)dc / (double)dw);
     }
     const bool early_act = p.R == nullptr || p.res_mask;     // no residual add between the accumulator and the activation
     // The MFMAs computed (W X^T): a lane holds ONE pixel (l31) and, in registers 4j .. 4j+3 of tile nt, the 4 consecutive output
@@ -661,6 +668,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_wgrad_reduce_kernel(WgParams
 // THIN (Cout <= 32, e.g. the 3-channel output conv): only the first 32-channel sub-tile carries data, so instead of four
 // waves owning four co sub-tiles (three of them empty) the four waves of a ci half split the PIXEL steps of every tile among
 // themselves and each flushes its partial of the few real output channels with atomics.
+// (Measured and dropped: transpose reads two taps ahead of their MFMA through rotating fragment slots plus one hand-issued DMA piece
+// of the next tile per 16-pixel step -- which also removes the s_waitcnt vmcnt(0) the compiler puts before the first
+// ds_read_b64_tr after an LDS-DMA: 1.34 ms against 1.30 ms at 128 -> 128, 256^2, B = 64.)
 template <bool THIN>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
