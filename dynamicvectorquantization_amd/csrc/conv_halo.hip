@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
     const int swzB = (l31 >> 1) & 7;
     const int nchunks = p.dbg == 2 ? 0 : (p.Cin >> 6);
     if constexpr (PIPE) {
-        static_assert(WN == 1 && NW == 4, "pipelined main loop: 4 waves, one wave column");
+        static_assert(WN == 1 && (NW == 4 || NW == 2), "pipelined main loop: 4 (or, experimentally, 2) waves, one wave column");
         constexpr int NP = CO_T / NW / 8;           // weight DMA pieces per wave and tap
         constexpr int NM = MT * NT, NDS = MT + NT;  // MFMAs / fragment reads per 16-k step
         int boff[NP];                               // element offset of this lane's 16 bytes of piece i at tap 0, channel 0
@@ -193,26 +193,24 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[slot][nt], a[slot][mt], acc[mt][nt], 0, 0, 0);
-            // behind MFMA i: one DMA piece while there are any (they precede the reads in program order: the scheduler keeps
-            // LDS-DMA writes and LDS reads in order), then the fragment reads spread over the remaining MFMAs
-            constexpr int S = NM - VM > 0 ? NM - VM : 1;
+            // issue order of the region: the fragment reads of the next step two by two right behind the first MFMAs (they have
+            // landed long before that step starts), then one DMA piece behind each following MFMA
+            constexpr int I0V = (DS + 1) / 2;
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < VM) {
-                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-                } else {
-#pragma unroll
-                    for (int r = (i - VM) * DS / S; r < (i - VM + 1) * DS / S; ++r) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
+                if (2 * i + 2 <= DS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else if (2 * i < DS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                else if (i - I0V < VM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
         using I0 = std::integral_constant<int, 0>;
         using IDS = std::integral_constant<int, NDS>;
-        using IV0 = std::integral_constant<int, (NP + 1) / 2>;
-        using IV1 = std::integral_constant<int, NP / 2>;
-
+        constexpr int NPH = (NP + 1) / 2;               // pieces [0, NPH) of a tap's weights are fetched during the LAST step of the tap
+        using IVA = std::integral_constant<int, NPH>;   //   two before it (its stage is free from that tap's barrier on), the others
+        using IVB = std::integral_constant<int, NP - NPH>;   // during the first step of the tap before it: a whole tap of MFMAs lies
+                                                        //   between the last DMA and the barrier that waits for it
         if (nchunks > 0) {
             issue_halo(0);
 #pragma unroll
@@ -247,21 +245,24 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
         }
             set_tap(0, g & 1);
             load_frags(0, 0);
+            if (c == 0) {                               // first half of tap 1 (later chunks: issued by the previous chunk's last tap)
+#pragma unroll
+                for (int i = 0; i < NPH; ++i) issue_b_piece(i, 1, 0, 1);
+            }
             auto tap_body = [&](int tap, auto last_tag) {
                 constexpr bool LAST = decltype(last_tag)::value;      // tap 8: what follows is the next chunk (or the epilogue)
                 const int buf = g & 1;
-                const int tapn = LAST ? 0 : tap + 1;
-                const int c0n = LAST ? (c + 1 < nchunks ? c0 + 64 : 0) : c0;     // (after the last chunk: a harmless re-fetch)
+                // taps g + 1 and g + 2 (past the last chunk: harmless re-fetches of chunk 0 into dead stages)
+                const int c0x = c + 1 < nchunks ? c0 + 64 : 0;
+                const int tap1 = LAST ? 0 : tap + 1, c01 = LAST ? c0x : c0;
+                const int tap2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9, c02 = tap + 2 < 9 ? c0 : c0x;
                 __builtin_amdgcn_sched_barrier(0);
-                // step 0: reads of step 1, first half of the next tap's weight pieces (their stage was last read in tap g - 1)
-#pragma unroll
-                for (int i = 0; i < (NP + 1) / 2; ++i) issue_b_piece(i, tapn, c0n, buf ^ 1);
                 load_frags(1, 1);
-                mfma_step(0, IDS{}, IV0{});
 #pragma unroll
-                for (int i = (NP + 1) / 2; i < NP; ++i) issue_b_piece(i, tapn, c0n, buf ^ 1);
+                for (int i = NPH; i < NP; ++i) issue_b_piece(i, tap1, c01, buf ^ 1);
+                mfma_step(0, IDS{}, IVB{});
                 load_frags(2, 0);
-                mfma_step(1, IDS{}, IV1{});
+                mfma_step(1, IDS{}, I0{});
                 load_frags(3, 1);
                 mfma_step(0, IDS{}, I0{});
                 // every wave has all its reads of this tap behind it and its share of the next tap's weights landed
@@ -269,10 +270,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
                 if constexpr (!LAST) {
                     set_tap(tap + 1, buf ^ 1);
                     load_frags(0, 0);
-                    mfma_step(1, IDS{}, I0{});
+#pragma unroll
+                    for (int i = 0; i < NPH; ++i) issue_b_piece(i, tap2, c02, buf);
+                    mfma_step(1, IDS{}, IVA{});
                 } else {
                     if (c + 1 < nchunks) issue_halo(c0 + 64);      // the halo tile is dead: refill it under the last MFMAs
-                    mfma_step(1, I0{}, I0{});
+#pragma unroll
+                    for (int i = 0; i < NPH; ++i) issue_b_piece(i, tap2, c02, buf);
+                    mfma_step(1, I0{}, IVA{});
                 }
                 ++g;
             };
@@ -567,9 +572,14 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     if (nw_env == 8 && cot == 128) {   // experiment: 8 waves x (2 x 2 tiles), four waves per SIMD
         dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<8, 2, 2>, LDSB);
         conv3x3_halo_kernel<8, 2, 2><<<dim3((unsigned)blocks), dim3(512), LDSB, stream>>>(p);
-    } else if (nw_env == 2 && cot == 128) {   // experiment: 2 waves x (4 x 4 tiles); measured 2x slower (1 wave per SIMD)
-        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<2, 4>, LDSB);
-        conv3x3_halo_kernel<2, 4><<<dim3((unsigned)blocks), dim3(128), LDSB, stream>>>(p);
+    } else if (nw_env == 2 && cot == 128) {   // experiment: 2 waves x (4 x 4 tiles), 1 wave per SIMD: 2x slower un-pipelined
+        if (pipe_env != 0) {
+            dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<2, 4, 1, true>, LDSB);
+            conv3x3_halo_kernel<2, 4, 1, true><<<dim3((unsigned)blocks), dim3(128), LDSB, stream>>>(p);
+        } else {
+            dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<2, 4>, LDSB);
+            conv3x3_halo_kernel<2, 4><<<dim3((unsigned)blocks), dim3(128), LDSB, stream>>>(p);
+        }
     } else if (pipe_env == 0) {        // DVQ_HALO_PIPE=0: the un-pipelined main loop (A/B timing)
         if (cot == 128) {
             dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 4>, LDSB);

@@ -700,6 +700,159 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_wide_kernel(NtParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// The same 256 x 256 NT GEMM with the main loop pipelined like conv_halo.hip's: per 16-k step the 8 MFMAs of a wave are issued
+// with the next step's 6 fragment reads and (in the first two steps of a K slab) the next slab's 8 DMA pieces slotted between
+// them (sched_group_barrier); the slab barrier sits before the LAST step, whose MFMAs cover the first fragment reads of the next
+// slab.  The MFMAs compute (B A^T), so a lane ends up with 4 CONSECUTIVE output columns of one row per register quad: the tile
+// is staged with packed 8-byte LDS stores (64 per lane instead of 128 2-byte ones; 16-byte chunk c of row r at c ^ (r & 31)).
+// Rows past M / Ncols re-read the last real row (never stored) instead of a zero page.  Needs Ncols % 8 == 0.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_nt_wide_pipe_kernel(NtParams p) {
+    using T = bf16_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                 // 4 x 2 waves: 64 rows x 128 columns each
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wi = xcd_remap(blockIdx.x, p.gm * p.gn);
+    const int m0 = (wi / p.gn) * WT, n0 = (wi % p.gn) * WT;
+    const int64_t bz = blockIdx.z;
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
+    const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
+    const T* zero = reinterpret_cast<const T*>(g_zero_page);
+    const int lrow = lane >> 3, cpos = lane & 7;
+    int64_t aoff[4], boff[4];
+    int cg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int trow = wave * 32 + i * 8 + lrow;
+        cg[i] = cpos ^ ((trow >> 1) & 7);
+        aoff[i] = (int64_t)min(m0 + trow, p.M - 1) * p.lda + cg[i] * 8;
+        boff[i] = (int64_t)min(n0 + trow, p.Ncols - 1) * p.ldb + cg[i] * 8;
+    }
+    auto issue_pair = [&](int i, int j, int buf) {           // A and B piece i of K slab j
+        char* sa = smem + buf * WSTAGEB + wave * 32 * GROW + i * 8 * GROW;
+        const int ke = j * 64;
+        const bool kok = ke + cg[i] * 8 < p.Ktot;
+        const T* srcA = kok ? Ag + aoff[i] + ke : zero;
+        const T* srcB = kok ? Bg + boff[i] + ke : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcA,
+                                         (__attribute__((address_space(3))) void*)sa, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcB,
+                                         (__attribute__((address_space(3))) void*)(sa + WOPB), 16, 0, 0);
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int swz = (l31 >> 1) & 7;                           // rows differ from l31 by multiples of 32: same swizzle
+    const int nk = (p.Ktot + 63) / 64;
+    const char* pa;
+    const char* pb;
+    auto set_stage = [&](int buf) {
+        pa = smem + buf * WSTAGEB + (wm * 64 + l31) * GROW;
+        pb = smem + buf * WSTAGEB + WOPB + (wn * 128 + l31) * GROW;
+    };
+    bf16x8 a[2][2], b[2][4];
+    auto load_frags = [&](int ks, int slot) {                 // in the order the MFMAs consume them
+        const int off = ((ks * 2 + half) ^ swz) << 4;
+        a[slot][0] = *reinterpret_cast<const bf16x8*>(pa + off);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[slot][t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * GROW + off);
+        a[slot][1] = *reinterpret_cast<const bf16x8*>(pa + 32 * GROW + off);
+    };
+    // the 8 MFMAs of a step and the issue order around them: the 6 fragment reads of the next step right behind the first three
+    // MFMAs (they have landed long before the next step starts), then one DMA instruction behind each following MFMA
+    auto mfma_step = [&](int slot, auto vm_tag) {
+        constexpr int VM = decltype(vm_tag)::value, NM = 8;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[slot][nt], a[slot][mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else if (i - 3 < VM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using V0 = std::integral_constant<int, 0>;
+    using V4 = std::integral_constant<int, 4>;
+    // K slab j + 1 is fetched in two halves: pieces 0, 1 during the last step of slab j - 1 (its stage is free from the barrier of
+    // that slab on), pieces 2, 3 during the first step of slab j: a full slab of MFMAs lies between the last DMA and the barrier
+    // that waits for it.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_pair(i, 0, 0);
+    __syncthreads();
+    set_stage(0);
+    load_frags(0, 0);
+    issue_pair(0, nk > 1 ? 1 : 0, 1);
+    issue_pair(1, nk > 1 ? 1 : 0, 1);
+#pragma unroll 1
+    for (int j = 0; j < nk; ++j) {
+        const int buf = j & 1;
+        const int jn = j + 1 < nk ? j + 1 : nk - 1;           // (past the end: harmless re-fetches into dead stages)
+        const int jnn = j + 2 < nk ? j + 2 : nk - 1;
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(1, 1);
+        issue_pair(2, jn, buf ^ 1);
+        issue_pair(3, jn, buf ^ 1);
+        mfma_step(0, V4{});
+        load_frags(2, 0);
+        mfma_step(1, V0{});
+        load_frags(3, 1);
+        mfma_step(0, V0{});
+        __syncthreads();          // every wave has its reads of this slab behind it and its pieces of the next one landed
+        set_stage(buf ^ 1);
+        load_frags(0, 0);
+        issue_pair(0, jnn, buf);
+        issue_pair(1, jnn, buf);
+        mfma_step(1, V4{});
+    }
+    __syncthreads();              // (the last iteration's look-ahead reads)
+    // epilogue: the 256 x 256 tile is staged as bf16 (128 KiB = both stages) and leaves in 16-byte stores
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+            const int lc = wn * 128 + nt * 32 + 8 * jq + 4 * half;      // first of this lane's 4 columns
+            float4 bq = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias_mode == 1 && n0 + lc < p.Ncols) bq = *reinterpret_cast<const float4*>(p.bias + n0 + lc);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int lr = wm * 64 + mt * 32 + l31;
+                const float brow = (p.bias_mode == 2 && m0 + lr < p.M) ? p.bias[m0 + lr] : 0.f;
+                float v[4] = {acc[mt][nt][4 * jq] * p.alpha + bq.x + brow, acc[mt][nt][4 * jq + 1] * p.alpha + bq.y + brow,
+                              acc[mt][nt][4 * jq + 2] * p.alpha + bq.z + brow, acc[mt][nt][4 * jq + 3] * p.alpha + bq.w + brow};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.act_slope;
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                const int chunk = (wn * 16 + nt * 4 + jq) ^ (lr & 31);
+                *reinterpret_cast<uint2*>(smem + lr * (WT * 2) + chunk * 16 + half * 8) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    T* __restrict__ Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
+#pragma unroll 4
+    for (int i = 0; i < (WT * WT / 8) / 512; ++i) {
+        const int q = tid + 512 * i;
+        const int lr = q >> 5, ch = q & 31;
+        const int row = m0 + lr, col = n0 + ch * 8;
+        if (row >= p.M || col >= p.Ncols) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * (WT * 2) + ((ch ^ (lr & 31)) << 4));
+        *reinterpret_cast<uint4*>(Cg + (int64_t)row * p.ldc + col) = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // TN kernel (wgrad / generic).  C fp32, accumulated with atomics; grid.y splits the reduction.
 // -------------------------------------------------------------------------------------------------
 struct TnParams;
@@ -1271,18 +1424,28 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
     p.gn = (int)cdiv64(p.Ncols, TILE);
     bool mfma_ok = p.Ktot % VN == 0 && p.ldb % VN == 0 && p.lda % VN == 0 && (p.stride == 1 || p.stride == 2);
     if (p.mode == MODE_GEMM) mfma_ok = mfma_ok && (p.sA % VN == 0) && (p.sB % VN == 0);
-    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && !mfma_ok), DVQ_ESHAPE,
+    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && impl != 6 && !mfma_ok), DVQ_ESHAPE,
                 "igemm_nt: MFMA path needs K, lda, ldb multiples of %d (K=%d lda=%lld ldb=%lld) and stride 1/2", VN,
                 p.Ktot, (long long)p.lda, (long long)p.ldb);
     DVQ_REQUIRE(!(impl == 3 && !mfma_ok), DVQ_ESHAPE, "igemm_nt: register-staged MFMA path unsupported for this shape");
-    const bool use_mfma = impl == 2 || impl == 3 || ((impl == 0 || impl == 5) && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
+    const bool use_mfma = impl == 2 || impl == 3 || ((impl == 0 || impl == 5 || impl == 6) && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
     if constexpr (sizeof(T) == 2) {
         // 256 x 256 macro tiles pay off on long reductions that fill the chip for several rounds (8192^3: 1036 vs 812 TFLOP/s);
         // on the StackGPT shapes (K = 1024 .. 4096, 324 .. 1296 tiles) the 128 x 128 kernel is faster (tools/gemm_probe.py),
         // so the automatic choice is conservative.  impl == 5 forces the wide kernel (tests).
-        if ((impl == 0 || impl == 5) && mfma_ok && p.mode == MODE_GEMM && p.R == nullptr && p.ldc % VN == 0 && p.M >= 256 &&
+        if ((impl == 0 || impl == 5 || impl == 6) && mfma_ok && p.mode == MODE_GEMM && p.R == nullptr && p.ldc % VN == 0 && p.M >= 256 &&
             p.Ncols >= 256) {
             const int64_t wgm = cdiv64(p.M, WT), wgn = cdiv64(p.Ncols, WT);
+            // pipelined main loop: faster than both the 128 x 128 kernel and the plain wide one on every tools/gemm_probe.py
+            // shape (679 / 775 / 865 / 870 / 1141 against 575 / 640 / 594 / 779 / 840 and 535 / 593 / 636 / 695 / 1050 TFLOP/s)
+            if ((impl == 6 || (impl == 0 && wgm * wgn * batch >= 128)) && p.Ncols % 8 == 0) {
+                p.gm = (int)wgm;
+                p.gn = (int)wgn;
+                dvq_ensure_dynamic_lds((const void*)gemm_nt_wide_pipe_kernel, 2 * WSTAGEB);
+                gemm_nt_wide_pipe_kernel<<<dim3((unsigned)(wgm * wgn), 1, (unsigned)batch), dim3(512), 2 * WSTAGEB, s>>>(p);
+                DVQ_CHECK_LAUNCH("gemm_nt_wide_pipe");
+                return DVQ_OK;
+            }
             if (impl == 5 || (p.Ktot >= 8192 && wgm * wgn * batch >= 768)) {
                 p.gm = (int)wgm;
                 p.gn = (int)wgn;
@@ -1331,7 +1494,7 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
     constexpr int VN = Vec<T>::N;
     constexpr int BK = Vec<T>::BK;
     bool mfma_ok = p.lda % VN == 0 && p.ldb % VN == 0 && p.sA % VN == 0 && p.sB % VN == 0;
-    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && !mfma_ok), DVQ_ESHAPE, "igemm_tn: MFMA path needs lda, ldb multiples of %d", VN);
+    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && impl != 6 && !mfma_ok), DVQ_ESHAPE, "igemm_tn: MFMA path needs lda, ldb multiples of %d", VN);
     const bool use_mfma = impl >= 2 || (impl == 0 && mfma_ok && (int64_t)p.Mred >= 256);
     if (use_mfma) {
         p.itiles = (int)cdiv64(p.I, TILE);

@@ -476,10 +476,12 @@ def test_tconv4x4s2_thin_kernel(dev, case):
     assert np.abs(outs[0] - outs[1]).max() / np.abs(dref).max() < 1e-2
 
 
-@pytest.mark.parametrize("shape", [(3, 600, 520, 200, 1), (1, 2048, 1032, 512, 2), (2, 1296, 648, 128, 0)])
-def test_gemm_nt_wide_kernel(dev, shape):
-    """256 x 256 macro-tile GEMM (bf16; impl 5 forces it, auto-selected only for very large plain GEMMs): ragged M / N / K tails, bias per column / row,
-    batches -- against an fp32 torch product of the same bf16-rounded operands"""
+@pytest.mark.parametrize("impl", [5, 6], ids=["plain", "pipelined"])
+@pytest.mark.parametrize("shape", [(3, 600, 520, 200, 1), (1, 2048, 1032, 512, 2), (2, 1296, 648, 128, 0), (1, 300, 264, 64, 1)])
+def test_gemm_nt_wide_kernel(dev, shape, impl):
+    """256 x 256 macro-tile GEMMs (bf16; impl 5 = plain main loop, impl 6 = the software-pipelined one the automatic dispatch uses
+    for large plain products the library does not take): ragged M / N / K tails, a single K slab, bias per column / row, batches --
+    against an fp32 torch product of the same bf16-rounded operands"""
     from dynamicvectorquantization_amd import kernels as K
     b, m, n, k, bias_mode = shape
     rs = np.random.RandomState(m + n)
@@ -493,7 +495,7 @@ def test_gemm_nt_wide_kernel(dev, shape):
         ref = ref + torch.from_numpy(bias)[None, :, None]
     at, wt_ = T(a, dev, torch.bfloat16).reshape(-1), T(w, dev, torch.bfloat16).reshape(-1)
     bt = T(bias, dev) if bias_mode else None
-    out = K.gemm_nt(at, wt_, m, n, k, k, k, n, batch=b, sa=m * k, sb=n * k, sc=m * n, bias=bt, bias_mode=bias_mode, impl=5)
+    out = K.gemm_nt(at, wt_, m, n, k, k, k, n, batch=b, sa=m * k, sb=n * k, sc=m * n, bias=bt, bias_mode=bias_mode, impl=impl)
     got = out.view(b, m, n).float().cpu()
     err = float((got - ref).abs().max()) / float(ref.abs().max())
     assert err < 1e-2, err
