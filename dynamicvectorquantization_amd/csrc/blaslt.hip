@@ -1,10 +1,10 @@
-// Plain library GEMMs: the large bias-only NT products of the stage-2 transformer's Linear layers (no fused prologue /
-// epilogue beyond the bias, nothing convolutional) are handed to hipBLASLt when the library is present -- the one place
-// where a vendor GEMM is the right tool (its register-staged 256 x 256 kernels reach 0.85 - 1.2 PFLOP/s on these shapes,
-// tools/gemm_probe.py, against 0.55 - 0.8 for the 128 x 128 LDS-DMA kernel of igemm.hip, which stays the implementation of
-// every fused / implicit-GEMM / batched product and the fallback when hipBLASLt is absent or declines a shape).
+// OPTIONAL library GEMMs (DVQ_USE_HIPBLASLT=1): the large bias-only NT / NN products of the stage-2 transformer's Linear layers can
+// be handed to hipBLASLt for comparison.  The default is the hand-written path -- the software-pipelined 256 x 256 / 192 x 256
+// kernels of igemm.hip (gemm_nt_wide_pipe_kernel: 760 - 1105 TFLOP/s on the StackGPT shapes of tools/gemm_probe.py against the
+// library's 840 - 1210; the whole stage-2 step is 5 % slower without the library, profiles/r02_*) -- and the own TN kernel for the
+// weight gradients, which beats the library's on every probe shape.
 // The library is bound at run time with dlopen / dlsym (the copy already mapped into the process if there is one), so
-// libdvq_hip.so has no link-time dependency on it.  DVQ_NO_HIPBLASLT=1 disables the path.
+// libdvq_hip.so has no link-time dependency on it.
 #include <dlfcn.h>
 #include <hipblaslt/hipblaslt.h>
 
@@ -49,8 +49,8 @@ std::map<Key, Plan> g_plans;
 Api& api() {
     if (g_tried) return g_api;
     g_tried = true;
-    const char* off = getenv("DVQ_NO_HIPBLASLT");
-    if (off != nullptr && off[0] == '1') return g_api;
+    const char* on = getenv("DVQ_USE_HIPBLASLT");
+    if (on == nullptr || on[0] != '1') return g_api;
     void* h = dlopen("libhipblaslt.so.1", RTLD_NOW | RTLD_NOLOAD);      // the copy the process already uses (PyTorch's), if any
     if (h == nullptr) h = dlopen("libhipblaslt.so.1", RTLD_NOW | RTLD_LOCAL);
     if (h == nullptr) h = dlopen("/opt/rocm/lib/libhipblaslt.so.1", RTLD_NOW | RTLD_LOCAL);

@@ -705,47 +705,75 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_wide_kernel(NtParams p) {
 // them (sched_group_barrier); the slab barrier sits before the LAST step, whose MFMAs cover the first fragment reads of the next
 // slab.  The MFMAs compute (B A^T), so a lane ends up with 4 CONSECUTIVE output columns of one row per register quad: the tile
 // is staged with packed 8-byte LDS stores (64 per lane instead of 128 2-byte ones; 16-byte chunk c of row r at c ^ (r & 31)).
-// Rows past M / Ncols re-read the last real row (never stored) instead of a zero page.  Needs Ncols % 8 == 0.
+// Rows past M / Ncols re-read the last real row (never stored) instead of a zero page.  Needs Ncols % 8 == 0, Ktot % 64 == 0.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void gemm_nt_wide_pipe_kernel(NtParams p) {
+// WMW x WNW waves of MT x (8 / WNW) MFMA tiles each:
+//   4 x 2 x (2 x 4): 256-row tile, two waves per SIMD (the default);
+//   2 x 2 x (4 x 4): 256-row tile, 256 accumulator registers, ONE wave per SIMD -- 8 fragment reads feed 16 MFMAs instead of 6
+//                    feeding 8; measured no faster;
+//   2 x 2 x (3 x 4): 192-row tile for shapes whose 256-row tiling fills the last round badly: 20736 tokens x 1024 columns are 324
+//                    tiles of 256 rows -- two rounds on 256 CUs, the second a quarter full -- but 432 of 192 rows: two rounds of
+//                    0.75.  (Six waves of 2 x 4 tiles would load the four SIMDs 2 : 2 : 1 : 1.)
+template <int WMW, int WNW, int MT>
+__global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW == 4 ? 1 : 2) void gemm_nt_wide_pipe_kernel(NtParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (buffer-descriptor builtins exist in the device pass only; the host pass needs just the stub)
     using T = bf16_t;
+    constexpr int NWV = WMW * WNW, NTH = 64 * NWV;
+    constexpr int NT = WT / 32 / WNW;                        // MFMA tiles per wave: MT x NT
+    constexpr int TM = WMW * MT * 32;                        // tile rows (256 or 192); tile columns: WT = 256
+    constexpr int NM = MT * NT, DS = MT + NT;                // MFMAs / fragment reads per 16-k step
+    constexpr int NPA = TM / 8 / NWV;                        // DMA pieces (8 rows) per wave and K slab: A
+    constexpr int NPB = (WT / 8 + NWV - 1) / NWV;            //   and B (6 waves: 36 for 32 pieces, the last one sent repeatedly)
+    constexpr int AOPB = TM * GROW;                          // bytes of an A slab; a stage = A slab + B slab
+    constexpr int STG = AOPB + WOPB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;                 // 4 x 2 waves: 64 rows x 128 columns each
+    const int wm = wave / WNW, wn = wave % WNW;
     const int l31 = lane & 31, half = lane >> 5;
+    // tile order: the 32 workgroups an XCD runs at a time (consecutive indices after xcd_remap) cover a block of 8 tile rows x 4
+    // tile columns -- 12 operand slabs per K step through that XCD's L2 instead of the 33 of a row-major strip
     const int wi = xcd_remap(blockIdx.x, p.gm * p.gn);
-    const int m0 = (wi / p.gn) * WT, n0 = (wi % p.gn) * WT;
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * p.gn;
+    const int grp = wi / per_group, rem = wi - grp * per_group;
+    const int gsz = min(p.gm - grp * GROUP_M, GROUP_M);
+    const int m0 = (grp * GROUP_M + rem % gsz) * TM, n0 = (rem / gsz) * WT;
     const int64_t bz = blockIdx.z;
     const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
     const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
-    const T* zero = reinterpret_cast<const T*>(g_zero_page);
     const int lrow = lane >> 3, cpos = lane & 7;
-    int64_t aoff[4], boff[4];
-    int cg[4];
+    // DMA through buffer descriptors: the operand base lives in SGPRs, a lane contributes one 32-bit byte offset (fixed for the
+    // whole kernel) and the K slab is the scalar offset -- no per-piece address arithmetic and half the address traffic of
+    // global_load_lds with 64-bit lane addresses.  (Launcher: Ktot % 64 == 0, operands below 2 GiB.)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Bg), 0, 0x7fffffff, 0x00020000);
+    int aoff[NPA], boff[NPB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int trow = wave * 32 + i * 8 + lrow;
-        cg[i] = cpos ^ ((trow >> 1) & 7);
-        aoff[i] = (int64_t)min(m0 + trow, p.M - 1) * p.lda + cg[i] * 8;
-        boff[i] = (int64_t)min(n0 + trow, p.Ncols - 1) * p.ldb + cg[i] * 8;
+    for (int i = 0; i < NPA; ++i) {
+        const int trow = (wave * NPA + i) * 8 + lrow;
+        aoff[i] = (int)(((int64_t)min(m0 + trow, p.M - 1) * p.lda + (cpos ^ ((trow >> 1) & 7)) * 8) * 2);
     }
-    auto issue_pair = [&](int i, int j, int buf) {           // A and B piece i of K slab j
-        char* sa = smem + buf * WSTAGEB + wave * 32 * GROW + i * 8 * GROW;
-        const int ke = j * 64;
-        const bool kok = ke + cg[i] * 8 < p.Ktot;
-        const T* srcA = kok ? Ag + aoff[i] + ke : zero;
-        const T* srcB = kok ? Bg + boff[i] + ke : zero;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcA,
-                                         (__attribute__((address_space(3))) void*)sa, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcB,
-                                         (__attribute__((address_space(3))) void*)(sa + WOPB), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int trow = min(wave * NPB + i, WT / 8 - 1) * 8 + lrow;
+        boff[i] = (int)(((int64_t)min(n0 + trow, p.Ncols - 1) * p.ldb + (cpos ^ ((trow >> 1) & 7)) * 8) * 2);
+    }
+    constexpr int ND = NPA + NPB;
+    auto issue_one = [&](int q, int j, int buf) {            // DMA instruction q of K slab j: A piece q, or B piece q - NPA
+        if (q < NPA)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsA, (__attribute__((address_space(3))) void*)(smem + buf * STG + (wave * NPA + q) * 8 * GROW), 16, aoff[q], j * 128, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsB, (__attribute__((address_space(3))) void*)(smem + buf * STG + AOPB + min(wave * NPB + q - NPA, WT / 8 - 1) * 8 * GROW),
+                16, boff[q - NPA], j * 128, 0, 0);
     };
-    f32x16 acc[2][4];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int swz = (l31 >> 1) & 7;                           // rows differ from l31 by multiples of 32: same swizzle
@@ -753,46 +781,50 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_wide_pipe_kernel(NtParams p) {
     const char* pa;
     const char* pb;
     auto set_stage = [&](int buf) {
-        pa = smem + buf * WSTAGEB + (wm * 64 + l31) * GROW;
-        pb = smem + buf * WSTAGEB + WOPB + (wn * 128 + l31) * GROW;
+        pa = smem + buf * STG + (wm * (MT * 32) + l31) * GROW;
+        pb = smem + buf * STG + AOPB + (wn * (NT * 32) + l31) * GROW;
     };
-    bf16x8 a[2][2], b[2][4];
+    bf16x8 a[2][MT], b[2][NT];
     auto load_frags = [&](int ks, int slot) {                 // in the order the MFMAs consume them
         const int off = ((ks * 2 + half) ^ swz) << 4;
         a[slot][0] = *reinterpret_cast<const bf16x8*>(pa + off);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[slot][t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * GROW + off);
-        a[slot][1] = *reinterpret_cast<const bf16x8*>(pa + 32 * GROW + off);
+        for (int t = 0; t < NT; ++t) b[slot][t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * GROW + off);
+#pragma unroll
+        for (int t = 1; t < MT; ++t) a[slot][t] = *reinterpret_cast<const bf16x8*>(pa + t * 32 * GROW + off);
     };
-    // the 8 MFMAs of a step and the issue order around them: the 6 fragment reads of the next step right behind the first three
+    // the MFMAs of a step and the issue order around them: the fragment reads of the next step two by two right behind the first
     // MFMAs (they have landed long before the next step starts), then one DMA instruction behind each following MFMA
     auto mfma_step = [&](int slot, auto vm_tag) {
-        constexpr int VM = decltype(vm_tag)::value, NM = 8;
+        constexpr int VM = decltype(vm_tag)::value;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[slot][nt], a[slot][mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            else if (i - 3 < VM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            if (2 * i < DS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else if (i - DS / 2 < VM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    // The DMA instructions of K slab j + 1 are spread over THREE steps -- the last step of slab j - 1 (the stage is free from
+    // that slab's barrier on), and the first two of slab j -- so that the texture-address path sees ~3 KiB per wave and step instead
+    // of bursts of 4 KiB, and two more steps of MFMAs lie between the last DMA and the barrier that waits for it.
+    constexpr int Q0 = (ND + 2) / 3, Q1 = Q0 + (ND - Q0 + 1) / 2;     // [0, Q0) | [Q0, Q1) | [Q1, ND)
     using V0 = std::integral_constant<int, 0>;
-    using V4 = std::integral_constant<int, 4>;
-    // K slab j + 1 is fetched in two halves: pieces 0, 1 during the last step of slab j - 1 (its stage is free from the barrier of
-    // that slab on), pieces 2, 3 during the first step of slab j: a full slab of MFMAs lies between the last DMA and the barrier
-    // that waits for it.
+    using VA = std::integral_constant<int, Q0>;
+    using VB = std::integral_constant<int, Q1 - Q0>;
+    using VC = std::integral_constant<int, ND - Q1>;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_pair(i, 0, 0);
+    for (int q = 0; q < ND; ++q) issue_one(q, 0, 0);
     __syncthreads();
     set_stage(0);
     load_frags(0, 0);
-    issue_pair(0, nk > 1 ? 1 : 0, 1);
-    issue_pair(1, nk > 1 ? 1 : 0, 1);
+#pragma unroll
+    for (int q = 0; q < Q0; ++q) issue_one(q, nk > 1 ? 1 : 0, 1);
 #pragma unroll 1
     for (int j = 0; j < nk; ++j) {
         const int buf = j & 1;
@@ -800,32 +832,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_wide_pipe_kernel(NtParams p) {
         const int jnn = j + 2 < nk ? j + 2 : nk - 1;
         __builtin_amdgcn_sched_barrier(0);
         load_frags(1, 1);
-        issue_pair(2, jn, buf ^ 1);
-        issue_pair(3, jn, buf ^ 1);
-        mfma_step(0, V4{});
+#pragma unroll
+        for (int q = Q0; q < Q1; ++q) issue_one(q, jn, buf ^ 1);
+        mfma_step(0, VB{});
         load_frags(2, 0);
-        mfma_step(1, V0{});
+#pragma unroll
+        for (int q = Q1; q < ND; ++q) issue_one(q, jn, buf ^ 1);
+        mfma_step(1, VC{});
         load_frags(3, 1);
         mfma_step(0, V0{});
         __syncthreads();          // every wave has its reads of this slab behind it and its pieces of the next one landed
         set_stage(buf ^ 1);
         load_frags(0, 0);
-        issue_pair(0, jnn, buf);
-        issue_pair(1, jnn, buf);
-        mfma_step(1, V4{});
+#pragma unroll
+        for (int q = 0; q < Q0; ++q) issue_one(q, jnn, buf);
+        mfma_step(1, VA{});
     }
     __syncthreads();              // (the last iteration's look-ahead reads)
-    // epilogue: the 256 x 256 tile is staged as bf16 (128 KiB = both stages) and leaves in 16-byte stores
+    // epilogue: the TM x 256 tile is staged as bf16 (512-byte rows, inside the two stages) and leaves in 16-byte stores
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
         for (int jq = 0; jq < 4; ++jq) {
-            const int lc = wn * 128 + nt * 32 + 8 * jq + 4 * half;      // first of this lane's 4 columns
+            const int lc = (wn * NT + nt) * 32 + 8 * jq + 4 * half;      // first of this lane's 4 columns
             float4 bq = {0.f, 0.f, 0.f, 0.f};
             if (p.bias_mode == 1 && n0 + lc < p.Ncols) bq = *reinterpret_cast<const float4*>(p.bias + n0 + lc);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int lr = wm * 64 + mt * 32 + l31;
+            for (int mt = 0; mt < MT; ++mt) {
+                const int lr = (wm * MT + mt) * 32 + l31;
                 const float brow = (p.bias_mode == 2 && m0 + lr < p.M) ? p.bias[m0 + lr] : 0.f;
                 float v[4] = {acc[mt][nt][4 * jq] * p.alpha + bq.x + brow, acc[mt][nt][4 * jq + 1] * p.alpha + bq.y + brow,
                               acc[mt][nt][4 * jq + 2] * p.alpha + bq.z + brow, acc[mt][nt][4 * jq + 3] * p.alpha + bq.w + brow};
@@ -834,7 +868,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_wide_pipe_kernel(NtParams p) {
                 uint2 pk;
                 pk.x = pack_bf16x2(v[0], v[1]);
                 pk.y = pack_bf16x2(v[2], v[3]);
-                const int chunk = (wn * 16 + nt * 4 + jq) ^ (lr & 31);
+                const int chunk = ((wn * NT + nt) * 4 + jq) ^ (lr & 31);
                 *reinterpret_cast<uint2*>(smem + lr * (WT * 2) + chunk * 16 + half * 8) = pk;
             }
         }
@@ -842,14 +876,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_wide_pipe_kernel(NtParams p) {
     __syncthreads();
     T* __restrict__ Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
 #pragma unroll 4
-    for (int i = 0; i < (WT * WT / 8) / 512; ++i) {
-        const int q = tid + 512 * i;
+    for (int i = 0; i < (TM * WT / 8) / NTH; ++i) {
+        const int q = tid + NTH * i;
         const int lr = q >> 5, ch = q & 31;
         const int row = m0 + lr, col = n0 + ch * 8;
         if (row >= p.M || col >= p.Ncols) continue;
         const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * (WT * 2) + ((ch ^ (lr & 31)) << 4));
         *reinterpret_cast<uint4*>(Cg + (int64_t)row * p.ldc + col) = v;
     }
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1267,6 +1302,190 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_tr_kernel(TnParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Wide TN GEMM (bf16 weight gradients of the Linear layers: C[i][j] += sum_m A[m][i] B[m][j]): 256 x 256 tile, 8 waves x (2 x 4)
+// MFMA tiles, 64 reduction rows per stage (2 x 32 KiB, rows of 512 B), operands in their natural [m][column] layout with the
+// K-contiguous fragments formed by ds_read_b64_tr_b16 (as igemm_tn_tr_kernel), split over m with fp32 atomics.  Main loop pipelined
+// like gemm_nt_wide_pipe_kernel; the DMA is issued from INLINE ASSEMBLY (buffer_load_dwordx4 ... lds through an SGPR descriptor,
+// one fixed 32-bit lane offset per piece, the stage as scalar offset): the compiler orders every ds_read_b64_tr behind all LDS-DMA
+// it knows to be pending (s_waitcnt vmcnt(0) before the first transpose read), which would serialise the prefetch of the next
+// stage with the reads of this one; pieces it does not know of are drained by hand before the barrier that publishes them.
+// Rows past the end of a split read as zero through the descriptor's bound; columns past I / J load neighbouring data that ends
+// up in accumulator columns nobody stores.
+// -------------------------------------------------------------------------------------------------
+constexpr int WTROW = 512;                     // LDS row bytes: 256 bf16 columns
+constexpr int WTOPB = 64 * WTROW;              // 64 reduction rows per stage and operand
+constexpr int WTSTG = 2 * WTOPB;
+typedef int dvq_int32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_wide_pipe_kernel(TnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using T = bf16_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                 // 4 x 2 waves: 64 rows (i) x 128 columns (j) each
+    const int per_split = p.itiles * p.jtiles;
+    int bx = xcd_remap(blockIdx.x, per_split * p.nsplit);
+    const int split = bx / per_split;
+    bx -= split * per_split;
+    const int it = bx % p.itiles, jt = bx / p.itiles;
+    const int i0 = it * 256, j0 = jt * 256;
+    const int64_t bz = blockIdx.z;
+    const T* Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
+    const T* Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
+    const int mbeg = split * p.m_per_split;
+    const int mend = min(p.Mred, mbeg + p.m_per_split);
+    const int nk = (mend - mbeg + 63) / 64;
+
+    auto make_rsrc = [&](const T* base, int64_t bytes) {
+        const unsigned long long a = (unsigned long long)base;
+        dvq_int32x4 r;
+        r.x = (int)(unsigned)a;
+        r.y = (int)(unsigned)(a >> 32);
+        r.z = (int)bytes;                                    // reads at or past this byte offset return zero
+        r.w = 0x00020000;
+        r.x = __builtin_amdgcn_readfirstlane(r.x);
+        r.y = __builtin_amdgcn_readfirstlane(r.y);
+        r.z = __builtin_amdgcn_readfirstlane(r.z);
+        return r;
+    };
+    const dvq_int32x4 rsA = make_rsrc(Ag, (int64_t)mend * p.lda * 2), rsB = make_rsrc(Bg, (int64_t)mend * p.ldb * 2);
+    // DMA instruction q of this wave: q < 4 -> A, else B; stage rows (wave * 4 + (q & 3)) * 2 + (lane >> 5); a lane at chunk position
+    // pos of its row fetches source chunk pos ^ ((row & 3) << 2) (the swizzle the transpose reads undo)
+    int voff[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int row = (wave * 4 + (q & 3)) * 2 + (lane >> 5);
+        const int cg = (lane & 31) ^ ((row & 3) << 2);
+        voff[q] = q < 4 ? (int)(((int64_t)(mbeg + row) * p.lda + i0 + cg * 8) * 2) : (int)(((int64_t)(mbeg + row) * p.ldb + j0 + cg * 8) * 2);
+    }
+    const int sstepA = (int)(64 * p.lda * 2), sstepB = (int)(64 * p.ldb * 2);      // bytes per stage
+    auto dma = [&](int q, int j, int buf) {
+        char* dst = smem + buf * WTSTG + (q < 4 ? 0 : WTOPB) + (wave * 4 + (q & 3)) * 2 * WTROW;
+        const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)dst);
+        const int so = __builtin_amdgcn_readfirstlane(j * (q < 4 ? sstepA : sstepB));
+        if (q < 4)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(l), "v"(voff[q]), "s"(rsA), "s"(so));
+        else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(l), "v"(voff[q]), "s"(rsB), "s"(so));
+    };
+
+    // fragment addressing (per lane constants, as igemm_tn_tr_kernel): a 16-lane group reads 4 rows x 16 columns per ds_read_b64_tr
+    const int g = lane >> 4, li = lane & 15;
+    const int frow = 8 * (g >> 1) + (li >> 2);                 // + ks*16 (+4 for the second read)
+    const int fz = ((li >> 2) & 3) << 2;
+    int offA[2], offB[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) offA[t] = frow * WTROW + (((wm * 8 + t * 4 + 2 * (g & 1) + ((li & 3) >> 1)) ^ fz) << 4) + (li & 1) * 8;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) offB[t] = frow * WTROW + (((wn * 16 + t * 4 + 2 * (g & 1) + ((li & 3) >> 1)) ^ fz) << 4) + (li & 1) * 8;
+    const bool do_bias = p.colsumA != nullptr && jt == 0 && wn == 0;
+    float bsum[2] = {0.f, 0.f};
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    auto frag = [&](const char* base, int off, int ks) -> bf16x8 {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off + (ks * 16) * WTROW));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off + (ks * 16 + 4) * WTROW));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    bf16x8 a[2][2], b[2][4];
+    // fragments of step ks of stage `buf` into `slot`, in the order the MFMAs consume them, with up to NDMA DMA instructions
+    // (q0, q0 + 1, ...) of K stage jd placed between them (inline assembly keeps its place among the LDS reads)
+    auto load_frags = [&](int buf, int ks, int slot, int q0, int ndma, int jd, int bufd) {
+        const char* sA = smem + buf * WTSTG;
+        const char* sB = sA + WTOPB;
+        a[slot][0] = frag(sA, offA[0], ks);
+        if (ndma > 0) dma(q0, jd, bufd);
+        b[slot][0] = frag(sB, offB[0], ks);
+        if (ndma > 1) dma(q0 + 1, jd, bufd);
+        b[slot][1] = frag(sB, offB[1], ks);
+        if (ndma > 2) dma(q0 + 2, jd, bufd);
+        b[slot][2] = frag(sB, offB[2], ks);
+        b[slot][3] = frag(sB, offB[3], ks);
+        a[slot][1] = frag(sA, offA[1], ks);
+    };
+    auto mfma_step = [&](int slot) {
+        if (do_bias) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint4 u = __builtin_bit_cast(uint4, a[slot][t]);
+                bsum[t] += (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) +
+                           (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u)) +
+                           (__uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u)) +
+                           (__uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u));
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[slot][mt], b[slot][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                          // 12 transpose reads: two behind each of the first six MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (nk > 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dma(q, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        __syncthreads();
+        load_frags(0, 0, 0, 0, 3, nk > 1 ? 1 : 0, 1);          // + DMA 0..2 of stage 1
+#pragma unroll 1
+        for (int j = 0; j < nk; ++j) {
+            const int buf = j & 1;
+            const int jn = j + 1 < nk ? j + 1 : nk - 1;        // (past the end: harmless re-fetches into dead stages)
+            const int jnn = j + 2 < nk ? j + 2 : nk - 1;
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(buf, 1, 1, 3, 3, jn, buf ^ 1);          // DMA 3..5 of the next stage
+            mfma_step(0);
+            load_frags(buf, 2, 0, 6, 2, jn, buf ^ 1);          // DMA 6, 7
+            mfma_step(1);
+            load_frags(buf, 3, 1, 0, 0, 0, 0);
+            mfma_step(0);
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // the hand-issued pieces of the next stage
+            __syncthreads();
+            load_frags(buf ^ 1, 0, 0, 0, 3, jnn, buf);         // first reads of the next stage; DMA 0..2 of the one after it
+            mfma_step(1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    }
+
+    float* __restrict__ Cg = p.C + bz * p.sC;
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = j0 + wn * 128 + nt * 32 + l31;
+        if (col >= p.Jc) continue;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < p.I) atomicAdd(Cg + tn_c_offset(p, row, 0, col), acc[mt][nt][r]);
+            }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);    // the two lane halves hold different m
+            const int col = i0 + wm * 64 + t * 32 + l31;
+            if (half == 0 && col < p.I) atomicAdd(p.colsumA + col, v);
+        }
+    }
+#endif
+}
+
+// -------------------------------------------------------------------------------------------------
 // Skinny NT GEMM (bf16, M <= 32 rows): the single-token Linear layers of K/V-cached sampling.  The product is bound by
 // streaming the weight matrix B [N][K] once, so the tiling is by WEIGHT ROWS: a workgroup owns 32 rows of B, its waves split K,
 // and each wave feeds 32x32x16 MFMAs straight from global memory -- MFMA A operand = 32 weight rows x 16 k (one 16-byte load
@@ -1424,25 +1643,44 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
     p.gn = (int)cdiv64(p.Ncols, TILE);
     bool mfma_ok = p.Ktot % VN == 0 && p.ldb % VN == 0 && p.lda % VN == 0 && (p.stride == 1 || p.stride == 2);
     if (p.mode == MODE_GEMM) mfma_ok = mfma_ok && (p.sA % VN == 0) && (p.sB % VN == 0);
-    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && impl != 6 && !mfma_ok), DVQ_ESHAPE,
+    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && impl != 6 && impl != 7 && impl != 8 && !mfma_ok), DVQ_ESHAPE,
                 "igemm_nt: MFMA path needs K, lda, ldb multiples of %d (K=%d lda=%lld ldb=%lld) and stride 1/2", VN,
                 p.Ktot, (long long)p.lda, (long long)p.ldb);
     DVQ_REQUIRE(!(impl == 3 && !mfma_ok), DVQ_ESHAPE, "igemm_nt: register-staged MFMA path unsupported for this shape");
-    const bool use_mfma = impl == 2 || impl == 3 || ((impl == 0 || impl == 5 || impl == 6) && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
+    const bool use_mfma = impl == 2 || impl == 3 || ((impl == 0 || impl == 5 || impl == 6 || impl == 7 || impl == 8) && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
     if constexpr (sizeof(T) == 2) {
         // 256 x 256 macro tiles pay off on long reductions that fill the chip for several rounds (8192^3: 1036 vs 812 TFLOP/s);
         // on the StackGPT shapes (K = 1024 .. 4096, 324 .. 1296 tiles) the 128 x 128 kernel is faster (tools/gemm_probe.py),
         // so the automatic choice is conservative.  impl == 5 forces the wide kernel (tests).
-        if ((impl == 0 || impl == 5 || impl == 6) && mfma_ok && p.mode == MODE_GEMM && p.R == nullptr && p.ldc % VN == 0 && p.M >= 256 &&
+        if ((impl == 0 || impl == 5 || impl == 6 || impl == 7 || impl == 8) && mfma_ok && p.mode == MODE_GEMM && p.R == nullptr && p.ldc % VN == 0 && p.M >= 256 &&
             p.Ncols >= 256) {
             const int64_t wgm = cdiv64(p.M, WT), wgn = cdiv64(p.Ncols, WT);
             // pipelined main loop: faster than both the 128 x 128 kernel and the plain wide one on every tools/gemm_probe.py
             // shape (679 / 775 / 865 / 870 / 1141 against 575 / 640 / 594 / 779 / 840 and 535 / 593 / 636 / 695 / 1050 TFLOP/s)
-            if ((impl == 6 || (impl == 0 && wgm * wgn * batch >= 128)) && p.Ncols % 8 == 0) {
+            const bool pipe_ok = p.Ncols % 8 == 0 && p.Ktot % 64 == 0 && (int64_t)p.M * p.lda < (1ll << 30) &&
+                                 (int64_t)p.Ncols * p.ldb < (1ll << 30);
+            if (impl == 7 && pipe_ok) {            // experiment: 4 waves x (4 x 4 tiles), one wave per SIMD
                 p.gm = (int)wgm;
                 p.gn = (int)wgn;
-                dvq_ensure_dynamic_lds((const void*)gemm_nt_wide_pipe_kernel, 2 * WSTAGEB);
-                gemm_nt_wide_pipe_kernel<<<dim3((unsigned)(wgm * wgn), 1, (unsigned)batch), dim3(512), 2 * WSTAGEB, s>>>(p);
+                dvq_ensure_dynamic_lds((const void*)gemm_nt_wide_pipe_kernel<2, 2, 4>, 2 * WSTAGEB);
+                gemm_nt_wide_pipe_kernel<2, 2, 4><<<dim3((unsigned)(wgm * wgn), 1, (unsigned)batch), dim3(256), 2 * WSTAGEB, s>>>(p);
+                DVQ_CHECK_LAUNCH("gemm_nt_wide_pipe4");
+                return DVQ_OK;
+            }
+            if ((impl == 6 || impl == 8 || (impl == 0 && wgm * wgn * batch >= 128)) && pipe_ok) {
+                // 256- or 192-row tiles: whichever needs less tile-row-time over the 256 CUs (rounds x rows)
+                const int64_t wgm192 = cdiv64(p.M, 192);
+                const int64_t cost256 = cdiv64(wgm * wgn * batch, 256) * 256, cost192 = cdiv64(wgm192 * wgn * batch, 256) * 192;
+                p.gn = (int)wgn;
+                if (impl == 8 || (impl != 6 && cost192 * 10 < cost256 * 8)) {
+                    p.gm = (int)wgm192;
+                    dvq_ensure_dynamic_lds((const void*)gemm_nt_wide_pipe_kernel<2, 2, 3>, 2 * (192 + 256) * GROW);
+                    gemm_nt_wide_pipe_kernel<2, 2, 3><<<dim3((unsigned)(wgm192 * wgn), 1, (unsigned)batch), dim3(256), 2 * (192 + 256) * GROW, s>>>(p);
+                } else {
+                    p.gm = (int)wgm;
+                    dvq_ensure_dynamic_lds((const void*)gemm_nt_wide_pipe_kernel<4, 2, 2>, 2 * WSTAGEB);
+                    gemm_nt_wide_pipe_kernel<4, 2, 2><<<dim3((unsigned)(wgm * wgn), 1, (unsigned)batch), dim3(512), 2 * WSTAGEB, s>>>(p);
+                }
                 DVQ_CHECK_LAUNCH("gemm_nt_wide_pipe");
                 return DVQ_OK;
             }
@@ -1494,7 +1732,7 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
     constexpr int VN = Vec<T>::N;
     constexpr int BK = Vec<T>::BK;
     bool mfma_ok = p.lda % VN == 0 && p.ldb % VN == 0 && p.sA % VN == 0 && p.sB % VN == 0;
-    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && impl != 6 && !mfma_ok), DVQ_ESHAPE, "igemm_tn: MFMA path needs lda, ldb multiples of %d", VN);
+    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && impl != 6 && impl != 7 && impl != 8 && !mfma_ok), DVQ_ESHAPE, "igemm_tn: MFMA path needs lda, ldb multiples of %d", VN);
     const bool use_mfma = impl >= 2 || (impl == 0 && mfma_ok && (int64_t)p.Mred >= 256);
     if (use_mfma) {
         p.itiles = (int)cdiv64(p.I, TILE);
@@ -1513,6 +1751,24 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
         p.m_per_split = (int)mps;
         p.nsplit = (int)splits;
         dim3 grid((unsigned)(p.itiles * p.jtiles * tapblk * splits), 1, (unsigned)batch);
+        if (sizeof(T) == 2 && (impl == 0 || impl == 6) && !p.conv && p.taps == 1 && p.I >= 256 && p.J >= 256 && p.Mred >= 1024 &&
+            p.I % 8 == 0 && p.J % 8 == 0 && (int64_t)p.Mred * p.lda < (1ll << 30) && (int64_t)p.Mred * p.ldb < (1ll << 30) &&
+            (p.sA * 2) % 4 == 0 && (p.sB * 2) % 4 == 0) {
+            // large plain weight-gradient GEMMs: 256 x 256 tiles, pipelined main loop; ~one resident workgroup per CU
+            p.itiles = (int)cdiv64(p.I, 256);
+            p.jtiles = (int)cdiv64(p.J, 256);
+            const int64_t wtiles = (int64_t)p.itiles * p.jtiles * batch;
+            int64_t wsplits = wtiles >= 256 ? 1 : 256 / wtiles;
+            const int64_t wmax = cdiv64(p.Mred, 4 * BK);
+            if (wsplits > wmax) wsplits = wmax;
+            const int64_t wmps = cdiv64(cdiv64(p.Mred, wsplits), BK) * BK;
+            p.m_per_split = (int)wmps;
+            p.nsplit = (int)cdiv64(p.Mred, wmps);
+            dvq_ensure_dynamic_lds((const void*)gemm_tn_wide_pipe_kernel, 2 * WTSTG);
+            gemm_tn_wide_pipe_kernel<<<dim3((unsigned)(p.itiles * p.jtiles * p.nsplit), 1, (unsigned)batch), dim3(512), 2 * WTSTG, s>>>(p);
+            DVQ_CHECK_LAUNCH("gemm_tn_wide_pipe");
+            return DVQ_OK;
+        }
         if (sizeof(T) == 2 && impl != 3) {      // LDS-DMA + transpose-read kernel
             if (p.conv) {
                 dvq_ensure_dynamic_lds((const void*)igemm_tn_tr_kernel<true>, 2 * TSTAGEB);

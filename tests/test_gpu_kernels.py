@@ -476,7 +476,7 @@ def test_tconv4x4s2_thin_kernel(dev, case):
     assert np.abs(outs[0] - outs[1]).max() / np.abs(dref).max() < 1e-2
 
 
-@pytest.mark.parametrize("impl", [5, 6], ids=["plain", "pipelined"])
+@pytest.mark.parametrize("impl", [5, 6, 7, 8], ids=["plain", "pipelined", "pipelined-4wave", "pipelined-192"])
 @pytest.mark.parametrize("shape", [(3, 600, 520, 200, 1), (1, 2048, 1032, 512, 2), (2, 1296, 648, 128, 0), (1, 300, 264, 64, 1)])
 def test_gemm_nt_wide_kernel(dev, shape, impl):
     """256 x 256 macro-tile GEMMs (bf16; impl 5 = plain main loop, impl 6 = the software-pipelined one the automatic dispatch uses
@@ -503,8 +503,8 @@ def test_gemm_nt_wide_kernel(dev, shape, impl):
 
 @pytest.mark.parametrize("shape", [(2048, 1024, 1024), (1304, 512, 1032), (20736, 4096, 1024)], ids=lambda s: "x".join(map(str, s)))
 def test_linear_input_gradient_library_nn(dev, shape):
-    """Linear.bwd's input gradient dx = dy W: the library NN product on W as stored (no transposed weight copy) against the
-    transpose + own-kernel route (DVQ impl 2) and an fp32 product"""
+    """Linear.bwd's input gradient dx = dy W: the automatic route (pipelined 256-wide NT kernel on a transposed weight copy; the
+    library NN product on W as stored under DVQ_USE_HIPBLASLT=1) against the 128 x 128 kernel (DVQ impl 2) and an fp32 product"""
     from dynamicvectorquantization_amd import kernels as K
     from dynamicvectorquantization_amd import runtime as rt
     from dynamicvectorquantization_amd.layers import Linear, Tape
@@ -752,3 +752,24 @@ def test_groupnorm_and_lpips_properties_full_size(dev):
         img = K.nchw_to_nhwc_pad(torch.rand(8, 3, 256, 256, device=dev) * 2 - 1, 8, torch.bfloat16)
         val, d = lp.fwd(img, img.clone(), gscale=1.0)
         assert float(val.abs().max()) < 1e-12 and float(d.float().abs().max()) < 1e-9     # bf16 feature noise floor is ~1e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 2048, 512, 256), (1, 20736, 1024, 1032), (2, 1300, 264, 520), (1, 4096, 4096, 1024)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_gemm_tn_wide_pipelined_kernel(dev, shape):
+    """256 x 256-tile TN GEMM of the Linear weight gradients (bf16, automatic for I, J >= 256, Mred >= 1024): ragged I / J tiles, a
+    reduction length that is no multiple of the 64-row stage (rows past the end must read as zero), batches -- against the
+    128 x 128 kernel (impl 2) and an fp32 product of the same bf16-rounded operands"""
+    from dynamicvectorquantization_amd import kernels as K
+    b, mred, i, j = shape
+    rs = np.random.RandomState(mred + i)
+    a = bf16_round(rs.standard_normal((b, mred, i)).astype(np.float32))
+    w = bf16_round(rs.standard_normal((b, mred, j)).astype(np.float32))
+    ref = torch.from_numpy(a).transpose(1, 2) @ torch.from_numpy(w)
+    at, wt_ = T(a, dev, torch.bfloat16).reshape(-1), T(w, dev, torch.bfloat16).reshape(-1)
+    outs = []
+    for impl in (0, 2):
+        out = K.gemm_tn(at, wt_, mred, i, j, i, j, j, batch=b, sa=mred * i, sb=mred * j, sc=i * j, impl=impl)
+        outs.append(out.view(b, i, j).cpu())
+    for got in outs:
+        assert float((got - ref).abs().max()) / float(ref.abs().max()) < 2e-3
