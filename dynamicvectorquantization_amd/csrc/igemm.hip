@@ -850,6 +850,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW == 4 ? 1 : 2) void gemm_n
     }
     __syncthreads();              // (the last iteration's look-ahead reads)
     // epilogue: the TM x 256 tile is staged as bf16 (512-byte rows, inside the two stages) and leaves in 16-byte stores
+    const bool early_act = p.R == nullptr || p.res_mask;     // (residual / gate semantics of nt_epilogue_vec)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -863,8 +864,10 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW == 4 ? 1 : 2) void gemm_n
                 const float brow = (p.bias_mode == 2 && m0 + lr < p.M) ? p.bias[m0 + lr] : 0.f;
                 float v[4] = {acc[mt][nt][4 * jq] * p.alpha + bq.x + brow, acc[mt][nt][4 * jq + 1] * p.alpha + bq.y + brow,
                               acc[mt][nt][4 * jq + 2] * p.alpha + bq.z + brow, acc[mt][nt][4 * jq + 3] * p.alpha + bq.w + brow};
+                if (early_act) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.act_slope;
+                    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.act_slope;
+                }
                 uint2 pk;
                 pk.x = pack_bf16x2(v[0], v[1]);
                 pk.y = pack_bf16x2(v[2], v[3]);
@@ -875,14 +878,27 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW == 4 ? 1 : 2) void gemm_n
     }
     __syncthreads();
     T* __restrict__ Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
+    const T* __restrict__ Rg = p.R ? reinterpret_cast<const T*>(p.R) + bz * p.sC : nullptr;
 #pragma unroll 4
     for (int i = 0; i < (TM * WT / 8) / NTH; ++i) {
         const int q = tid + NTH * i;
         const int lr = q >> 5, ch = q & 31;
         const int row = m0 + lr, col = n0 + ch * 8;
         if (row >= p.M || col >= p.Ncols) continue;
-        const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * (WT * 2) + ((ch ^ (lr & 31)) << 4));
-        *reinterpret_cast<uint4*>(Cg + (int64_t)row * p.ldc + col) = v;
+        uint4 v = *reinterpret_cast<const uint4*>(smem + lr * (WT * 2) + ((ch ^ (lr & 31)) << 4));
+        const int64_t o = (int64_t)row * p.ldc + col;
+        if (Rg != nullptr) {
+            const uint4 rv = *reinterpret_cast<const uint4*>(Rg + o);
+            unsigned* pv = &v.x;
+            const unsigned* pr = &rv.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = nt_res(p, __uint_as_float(pv[k] << 16), __uint_as_float(pr[k] << 16));
+                const float hi = nt_res(p, __uint_as_float(pv[k] & 0xffff0000u), __uint_as_float(pr[k] & 0xffff0000u));
+                pv[k] = pack_bf16x2(lo, hi);
+            }
+        }
+        *reinterpret_cast<uint4*>(Cg + o) = v;
     }
 #endif
 }
@@ -1652,8 +1668,11 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
         // 256 x 256 macro tiles pay off on long reductions that fill the chip for several rounds (8192^3: 1036 vs 812 TFLOP/s);
         // on the StackGPT shapes (K = 1024 .. 4096, 324 .. 1296 tiles) the 128 x 128 kernel is faster (tools/gemm_probe.py),
         // so the automatic choice is conservative.  impl == 5 forces the wide kernel (tests).
-        if ((impl == 0 || impl == 5 || impl == 6 || impl == 7 || impl == 8) && mfma_ok && p.mode == MODE_GEMM && p.R == nullptr && p.ldc % VN == 0 && p.M >= 256 &&
-            p.Ncols >= 256) {
+        // a 1 x 1 / stride 1 / unpadded convolution (forward, or input gradient through the transposed pack) IS a plain GEMM
+        const bool conv1x1 = p.mode != MODE_GEMM && p.Ktot == (int)p.lda && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 &&
+                             p.up == 0 && p.LH == p.DH && p.LW == p.DW && p.par == 0;
+        if ((impl == 0 || impl == 5 || impl == 6 || impl == 7 || impl == 8) && mfma_ok && (p.mode == MODE_GEMM || (conv1x1 && impl == 0)) &&
+            (p.R == nullptr || impl == 0 || impl == 6) && p.ldc % VN == 0 && p.M >= 256 && p.Ncols >= 256) {
             const int64_t wgm = cdiv64(p.M, WT), wgn = cdiv64(p.Ncols, WT);
             // pipelined main loop: faster than both the 128 x 128 kernel and the plain wide one on every tools/gemm_probe.py
             // shape (679 / 775 / 865 / 870 / 1141 against 575 / 640 / 594 / 779 / 840 and 535 / 593 / 636 / 695 / 1050 TFLOP/s)
@@ -1684,7 +1703,7 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
                 DVQ_CHECK_LAUNCH("gemm_nt_wide_pipe");
                 return DVQ_OK;
             }
-            if (impl == 5 || (p.Ktot >= 8192 && wgm * wgn * batch >= 768)) {
+            if (p.mode == MODE_GEMM && p.R == nullptr && (impl == 5 || (p.Ktot >= 8192 && wgm * wgn * batch >= 768))) {
                 p.gm = (int)wgm;
                 p.gn = (int)wgn;
                 dvq_ensure_dynamic_lds((const void*)gemm_nt_wide_kernel, 2 * WSTAGEB);
