@@ -395,6 +395,16 @@ def main():
                                  "timed region (the timed steps are hipGraph replays of the same launch sequence)"}
             # HBM traffic per launch: PMC counters cannot be collected from inside this process; the figure comes from the
             # committed rocprofv3 --pmc passes over this same command (tools/gpu_pmc_bench.sh -> tools/pmc_summarise.py)
+            # context for `frac`: `peak` is the nominal dense bf16 rate at the maximum clock; under sustained MFMA load the chip is
+            # power-limited, and how far depends on the operand bit patterns.  The same process measures what a register-only
+            # MFMA loop (no LDS, no memory) sustains with random bf16 operands and with zeros.
+            try:
+                rnd, zer = K.probe_mfma_rate(True), K.probe_mfma_rate(False)
+                roofline["sustained_mfma"] = {"random_operands_TFLOPs": round(rnd[0], 1), "random_operands_MHz": round(rnd[1]),
+                                              "zero_operands_TFLOPs": round(zer[0], 1), "zero_operands_MHz": round(zer[1]),
+                                              "frac_of_random_operand_rate": round(ach / max(rnd[0], 1e-9), 4)}
+            except Exception as e:      # diagnostics only
+                roofline["sustained_mfma"] = {"error": str(e)}
             pmc = _pmc_traffic(dom)
             if pmc is not None and args.objective == "full" and args.bs == 64:
                 roofline["traffic"] = pmc["hbm_bytes_per_launch"]

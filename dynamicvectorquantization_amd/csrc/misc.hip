@@ -4,6 +4,7 @@
 #include <stdarg.h>
 
 #include "dvq_common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // error plumbing
@@ -442,6 +443,32 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, float 
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) p[e] = v;
 }
 
+// Diagnostics (bench.py's roofline context): a register-only v_mfma_f32_32x32x16_bf16 loop, two waves per SIMD on every CU.  What it
+// sustains is the power-limited ceiling of the matrix pipes for the given operand bit patterns -- zeros keep the clock near its
+// maximum, random bf16 operands do not (MFMA power draw follows the number of operand bits that toggle).
+__global__ __launch_bounds__(256) void mfma_rate_kernel(const uint4* __restrict__ src, int iters, float* sink, unsigned long long* clk) {
+    const int tid = threadIdx.x + blockIdx.x * 256;
+    uint4 ua = src[tid % 4096], ub = src[(tid * 7 + 13) % 4096];
+    const bf16x8 a = *reinterpret_cast<bf16x8*>(&ua), b = *reinterpret_cast<bf16x8*>(&ub);
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 123.456f) sink[0] = s;
+    if (tid == 0) {
+        clk[0] = c1 - c0;       // shader clocks
+        clk[1] = w1 - w0;       // 100 MHz reference ticks
+    }
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -711,6 +738,60 @@ int dvq_fill_f32(float* p, float v, int64_t n, dvq_stream_t stream) {
     fill_kernel<<<dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream>>>(p, v, n);
     DVQ_CHECK_LAUNCH("fill");
     return DVQ_OK;
+}
+
+int dvq_probe_mfma_rate(int random_operands, float* tflops, float* mhz, dvq_stream_t stream) {
+    DVQ_REQUIRE(tflops && mhz, DVQ_EINVAL, "dvq_probe_mfma_rate: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int n = 4096, blocks = 512, iters = 40000;
+    uint4* h = (uint4*)malloc(n * sizeof(uint4));
+    uint32_t st = 12345u;
+    for (int i = 0; i < n; ++i) {
+        uint32_t w[4];
+        for (int k = 0; k < 4; ++k) {
+            uint32_t v = 0;
+            for (int hlf = 0; random_operands && hlf < 2; ++hlf) {      // bf16 in (-2, 2): random sign / mantissa, exponent 0x7c .. 0x7f
+                st = st * 1664525u + 1013904223u;
+                const uint32_t r = st >> 8;
+                v |= (((r & 1) << 15) | ((0x7c + ((r >> 1) & 3)) << 7) | ((r >> 3) & 0x7f)) << (16 * hlf);
+            }
+            w[k] = v;
+        }
+        h[i] = uint4{w[0], w[1], w[2], w[3]};
+    }
+    uint4* d = nullptr;
+    float* sink = nullptr;
+    unsigned long long* clk = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = DVQ_OK;
+    if (hipMalloc(&d, n * sizeof(uint4)) != hipSuccess || hipMalloc(&sink, 4) != hipSuccess || hipMalloc(&clk, 16) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess ||
+        hipMemcpyAsync(d, h, n * sizeof(uint4), hipMemcpyHostToDevice, s) != hipSuccess) {
+        dvq_set_error("dvq_probe_mfma_rate: allocation failed");
+        rc = DVQ_ELAUNCH;
+    } else {
+        mfma_rate_kernel<<<dim3(blocks), dim3(256), 0, s>>>(d, 2000, sink, clk);       // warm the clocks
+        hipEventRecord(e0, s);
+        mfma_rate_kernel<<<dim3(blocks), dim3(256), 0, s>>>(d, iters, sink, clk);
+        hipEventRecord(e1, s);
+        unsigned long long hc[2] = {0, 1};
+        float ms = 1.f;
+        if (hipStreamSynchronize(s) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess ||
+            hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost) != hipSuccess) {
+            dvq_set_error("dvq_probe_mfma_rate: kernel failed");
+            rc = DVQ_ELAUNCH;
+        } else {
+            *tflops = (float)((double)blocks * 4 * iters * 4 * 32768.0 / ((double)ms * 1e9));
+            *mhz = (float)(100.0 * (double)hc[0] / (double)hc[1]);
+        }
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (d) hipFree(d);
+    if (sink) hipFree(sink);
+    if (clk) hipFree(clk);
+    free(h);
+    return rc;
 }
 
 }  // extern "C"

@@ -473,6 +473,13 @@ def nhwc_pad_to_nchw(x, c):
 # ---------------------------------------------------------------------------------------------
 # GEMMs / attention pieces
 # ---------------------------------------------------------------------------------------------
+def probe_mfma_rate(random_operands=True):
+    """(TFLOP/s, shader MHz) a register-only bf16 MFMA loop sustains on the current device (diagnostics for bench.py)"""
+    tf, mhz = C.c_float(0.0), C.c_float(0.0)
+    check(lib().dvq_probe_mfma_rate(int(bool(random_operands)), C.byref(tf), C.byref(mhz), _s()), "dvq_probe_mfma_rate")
+    return float(tf.value), float(mhz.value)
+
+
 def gemm_nt(a, b, m, n, k, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, alpha=1.0, bias=None, bias_mode=0, out=None,
             impl=0):
     """C[b][m][n] = alpha * sum_k A[b][m][k] B[b][n][k] (+bias).  a, b, out are flat device tensors."""

@@ -569,6 +569,13 @@ class AttnBlock(HipModule):
         q, k, v, p = st["q"], st["k"], st["v"], st["p"]
         impl = rt.impl()
         do = self.proj_out.bwd(dy, tape.child("proj"))
+        if p is None and os.environ.get("DVQ_ATTNBLOCK_BWD", "gemm") == "gemm":
+            # fused forward, backward on the pipelined batched GEMM kernels: the probabilities are recomputed (q k^T, row softmax)
+            # into scratch that lives only inside this call.  Measured against the flash-style backward kernels at head size 256
+            # (attn_bwd_dq / dkv: one wave per SIMD, 512 registers, 170 TFLOP/s): DESIGN.md section 3.
+            s = K.gemm_nt(q, k, n, n, c, c, c, n, batch=b, sa=n * c, sb=n * c, sc=n * n, impl=impl)
+            p = K.softmax_rows(s, b * n, n, float(int(c) ** (-0.5)))
+            del s
         if p is None:                                   # fused forward: fused backward (dQ, then dV and dK kernels)
             dq, dk, dv = K.attn_full_bwd(q.view(b * n, c), k.view(b * n, c), v.view(b * n, c), st["o"], do.view(b * n, c), st["lse"],
                                          b, n, float(int(c) ** (-0.5)))

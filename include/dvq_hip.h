@@ -41,6 +41,10 @@ const char* dvq_last_error(void);
 int dvq_version(void);     /* 102: round 2 (device-hyper AdamW, image pipeline, distance matrix, row sampler) */
 /* 0 if the current HIP device is gfx950, DVQ_EARCH otherwise */
 int dvq_check_device(void);
+/* Diagnostics for the benchmark's roofline context (allocates, synchronises the stream; NOT for the hot path): TFLOP/s and shader
+ * clock (MHz) that a register-only bf16 MFMA loop sustains on every CU for ~3 ms, with all-zero (random_operands = 0) or random
+ * bf16 operands -- the power-limited ceiling of the matrix pipes, which depends on the operand bit patterns. */
+int dvq_probe_mfma_rate(int random_operands, float* tflops, float* mhz, dvq_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Vector quantisation.  Replaces VQEmbedding.compute_distances + argmin
