@@ -25,7 +25,8 @@ constexpr int ROWB = 128;                      // one 64-channel bf16 chunk
 constexpr int HALOB = HPIECES * 8 * ROWB;      // 44032
 constexpr int BSTAGE = 128 * ROWB;             // 16 KiB: 128 output channels x 64 input channels
 constexpr int SSB = 64 * 2 * 4;                // fused-GN scale/shift of the current 64-channel chunk
-constexpr int LDSB = HALOB + 2 * BSTAGE + SSB; // 77312
+constexpr int BIASB = 128 * 4;                 // bias of the workgroup's output channels (read back by the epilogue)
+constexpr int LDSB = HALOB + 2 * BSTAGE + SSB + BIASB; // 77824
 
 struct HaloParams {
     const bf16_t* X;     // [N,H,W,Cin]
@@ -73,6 +74,7 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 //   [6 reads][8 MFMA]... and roughly a third of every tap is spent outside the MFMA pipe.
 template <int NW, int NT, int WN = 1, bool PIPE = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x3_halo_kernel(HaloParams p) {   // (threads, waves per SIMD)
+#if defined(__HIP_DEVICE_COMPILE__)      // (buffer-descriptor builtins exist in the device pass only; the host pass needs just the stub)
     constexpr int MT = 8 * WN / NW;     // image rows (32-pixel m-tiles) per wave
     constexpr int CO_T = 32 * NT * WN;  // output channels per workgroup
     constexpr int CPRW = CO_T / 8;      // 16-byte chunks per staged output row
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
     char* halo = smem;
     char* bst = smem + HALOB;
     float* ssl = reinterpret_cast<float*>(smem + HALOB + 2 * BSTAGE);
+    float* sbias = reinterpret_cast<float*>(smem + HALOB + 2 * BSTAGE + SSB);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % (NW / WN), wn = wave / (NW / WN);     // wave row (image rows MT * wm ..) and wave column (channels)
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
     const int ty = wi % p.tiles_y;
     const int n = wi / p.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW, n0 = nt_blk * CO_T;
+    if (tid < 128) sbias[tid] = (p.bias != nullptr && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;   // (published by the first barrier)
     const int64_t img = (int64_t)n * p.H * p.W;
     const int SWd = p.W >> p.up;                       // stored input width
     const int64_t simg = (int64_t)n * (p.H >> p.up) * SWd;
@@ -144,6 +148,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
 
     const int swzB = (l31 >> 1) & 7;
     const int nchunks = p.dbg == 2 ? 0 : (p.Cin >> 6);
+    // residual / gate tile of the epilogue (thread q handles 16-byte chunk q % CPRW of pixel row q / CPRW): requested before the
+    // staging of the output tile so that its latency hides behind it
+    constexpr int ITERS = 256 * CPRW / NTH;
+    uint4 rpre[ITERS];
+    auto load_residual = [&]() {
+        if (p.R == nullptr) return;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int q = tid + NTH * i;
+            const int lp = q / CPRW, ch = q % CPRW;
+            const int col = n0 + ch * 8;
+            const int64_t o = ((img + (int64_t)(y0 + (lp >> 5)) * p.W + x0 + (lp & 31)) * p.Cout) + col;
+            rpre[i] = col < p.Cout ? *reinterpret_cast<const uint4*>(p.R + o) : uint4{0, 0, 0, 0};
+        }
+    };
     if constexpr (PIPE) {
         static_assert(WN == 1 && (NW == 4 || NW == 2), "pipelined main loop: 4 (or, experimentally, 2) waves, one wave column");
         constexpr int NP = CO_T / NW / 8;           // weight DMA pieces per wave and tap
@@ -155,12 +174,29 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
             // rows past Cout re-read the last real row: their output channels are never stored nor counted in the statistics
             boff[i] = min(n0 + row, p.Cout - 1) * 9 * p.Cin + (cpos ^ ((row >> 1) & 7)) * 8;
         }
+        // DMA through buffer descriptors (base in SGPRs, one 32-bit lane offset, tap / channel chunk as the scalar offset): no
+        // per-piece 64-bit address arithmetic, and padding pixels are simply out of the descriptor's range (they read as zero)
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Wt), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(Xn), 0, (p.H >> p.up) * SWd * p.Cin * 2, 0x00020000);
         auto issue_b_piece = [&](int i, int tapx, int c0, int buf) {
             const int tb = p.flip ? 8 - tapx : tapx;
-            const bf16_t* src = p.Wt + (boff[i] + tb * p.Cin + c0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(bst + buf * BSTAGE + (wave * (CO_T / NW) + i * 8) * ROWB),
-                                             16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsW, (__attribute__((address_space(3))) void*)(bst + buf * BSTAGE + (wave * (CO_T / NW) + i * 8) * ROWB), 16, boff[i] * 2,
+                (tb * p.Cin + c0) * 2, 0, 0);
+        };
+        auto issue_halo_buf = [&](int c0) {
+#pragma unroll 1
+            for (int pc = wave; pc < HPIECES; pc += NW) {
+                const int hp = pc * 8 + lrow;
+                const int hy = hp / HW_, hx = hp - hy * HW_;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                const bool ok = hp < HROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                const int cg = cpos ^ ((hp >> 1) & 7);
+                const int voff = ok ? (((gy >> p.up) * SWd + (gx >> p.up)) * p.Cin + cg * 8) * 2 : 0x7ffffff0;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(halo + pc * 8 * ROWB), 16, voff,
+                                                         c0 * 2, 0, 0);
+            }
         };
         const char* pa[MT];
         const char* pb;
@@ -212,7 +248,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
         using IVB = std::integral_constant<int, NP - NPH>;   // during the first step of the tap before it: a whole tap of MFMAs lies
                                                         //   between the last DMA and the barrier that waits for it
         if (nchunks > 0) {
-            issue_halo(0);
+            issue_halo_buf(0);
 #pragma unroll
             for (int i = 0; i < NP; ++i) issue_b_piece(i, 0, 0, 0);
         }
@@ -274,10 +310,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
                     for (int i = 0; i < NPH; ++i) issue_b_piece(i, tap2, c02, buf);
                     mfma_step(1, IDS{}, IVA{});
                 } else {
-                    if (c + 1 < nchunks) issue_halo(c0 + 64);      // the halo tile is dead: refill it under the last MFMAs
+                    if (c + 1 < nchunks) {                         // (nothing may be in flight when the epilogue re-uses the LDS)
+                        issue_halo_buf(c0 + 64);                   // the halo tile is dead: refill it under the last MFMAs
 #pragma unroll
-                    for (int i = 0; i < NPH; ++i) issue_b_piece(i, tap2, c02, buf);
-                    mfma_step(1, I0{}, IVA{});
+                        for (int i = 0; i < NPH; ++i) issue_b_piece(i, tap2, c02, buf);
+                    }
+                    mfma_step(1, I0{}, I0{});
                 }
                 ++g;
             };
@@ -375,26 +413,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
     // channels nt*32 + 8j + 4*half ..: packed pairs (v_cvt_pk_bf16_f32) and 8-byte LDS stores, 32 per lane instead of 128
     // 2-byte ones.  Staged rows are unpadded (CO_T * 2 bytes); 16-byte chunk c of pixel row lp sits at position c ^ swz(lp) so
     // that both the column-wise 8-byte stores here and the row-wise 16-byte reads below are bank-conflict free.
-    constexpr int ITERS = 256 * CPRW / NTH;
     constexpr int SWZ_SH = CPRW == 16 ? 0 : CPRW == 8 ? 1 : 2;
-    uint4 rpre[ITERS];      // residual / gate tile, requested before the staging so that its latency hides behind it
-    if (p.R != nullptr) {
-#pragma unroll
-        for (int i = 0; i < ITERS; ++i) {
-            const int q = tid + NTH * i;
-            const int lp = q / CPRW, ch = q % CPRW;
-            const int col = n0 + ch * 8;
-            const int64_t o = ((img + (int64_t)(y0 + (lp >> 5)) * p.W + x0 + (lp & 31)) * p.Cout) + col;
-            rpre[i] = col < p.Cout ? *reinterpret_cast<const uint4*>(p.R + o) : uint4{0, 0, 0, 0};
-        }
-    }
+    load_residual();        // (requesting it under the MFMAs of the last k-step does not fit the registers: measured, no gain)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int lc = (wn * NT + nt) * 32 + 8 * j + 4 * half;      // first of this lane's 4 channels
-            float4 bq = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias != nullptr && n0 + lc < p.Cout) bq = *reinterpret_cast<const float4*>(p.bias + n0 + lc);
+            const float4 bq = *reinterpret_cast<const float4*>(sbias + lc);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int lp = (MT * wm + mt) * 32 + l31;
@@ -505,6 +531,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
             }
         }
     }
+#endif
 }
 
 // out_stats[n][g] += sum over the tiles of one image of the per-tile partials (one wave per (n, g))

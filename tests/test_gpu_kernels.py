@@ -723,8 +723,11 @@ def test_conv3x3_adjoint_identities_full_size(dev, shape):
         assert abs(a - b) < 2e-4 * scale, (a, b, scale)
         assert abs(a - c) < 2e-4 * scale, (a, c, scale)
         # linearity in the input at full size: conv(2x) = 2 conv(x) exactly in bf16 (power-of-two scaling)
-        y2 = conv.fwd(K.add(x, x), None)
-        assert torch.equal(y2, K.add(y, y))
+        # (repeated: an LDS race in the kernel -- e.g. a DMA still in flight when the epilogue re-uses the tile -- shows up as a
+        # handful of wrong elements in one launch out of a few)
+        y_twice = K.add(y, y)
+        for _ in range(4):
+            assert torch.equal(conv.fwd(K.add(x, x), None), y_twice)
         # the bias gradient is the plain sum of dy
         db = dy[..., :cout].double().sum(dim=(0, 1, 2))
         assert float((conv.bias.grad.double() - db).abs().max()) <= 1e-3 * float(db.abs().max() + 1)

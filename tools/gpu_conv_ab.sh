@@ -1,5 +1,6 @@
 #!/bin/bash
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py tests/test_gpu_attention.py -m gpu -q -p no:cacheprovider --tb=short -x --timeout 600 -k "conv or blocks or halo or dqvae or gemm or attnblock" 2>&1 | tail -5 | cut -c1-300
-bash tools/gpu_bench_quick.sh
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -q -p no:cacheprovider --tb=short -x --timeout 600 -k "conv or blocks or halo or dqvae" 2>&1 | tail -4 | cut -c1-300
+timeout 300 python tools/debug/halo_data_probe.py 2>&1 | grep -v amdgpu.ids | tail -7
+PROBE_REPS=20 PROBE_C=256 PROBE_H=64 timeout 300 python tools/conv_probe.py 2>&1 | grep -v amdgpu.ids | tail -1
