@@ -751,10 +751,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
                 src = ok ? p.X + ((int64_t)n * (p.H >> p.up) * SWd + (int64_t)(gy >> p.up) * SWd + (gx >> p.up)) * p.Cin + j0 + cg * 8 : zero;
                 dst = base + WDYB + hc * 8 * ROWB;
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            // issued from inline assembly: the compiler orders every ds_read_b64_tr behind ALL LDS-DMA it knows to be pending
+            // (s_waitcnt vmcnt(0) before the first transpose read of the tile), which would serialise this prefetch of the next
+            // tile with the reads of the current one; the pieces are drained by hand before the barrier that publishes them
+            const unsigned ldst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)dst);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(ldst), "v"(src));
         }
     };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); };
 
     // fragment lane constants (transpose reads: lanes 4r..4r+3 of a 16-lane group address row r, 8 B each)
     const int g = lane >> 4, li = lane & 15;
@@ -773,6 +777,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
 
     if (tbeg < tend) {
         issue(tbeg, 0);
+        dma_wait();
         __syncthreads();
         for (int t = tbeg; t < tend; ++t) {
             const int buf = (t - tbeg) & 1;
@@ -805,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
                     *ptr = v;
                 }
                 __syncthreads();
-                if (t + 1 < tend) issue(t + 1, buf ^ 1);     // prefetch after the barrier: it would otherwise drain the DMA
+                if (t + 1 < tend) issue(t + 1, buf ^ 1);     // prefetch after the barrier
             }
 #pragma unroll 2
             for (int st = st_lo; st < st_hi; ++st) {       // 16 pixels per step: image row rr, half hs
@@ -849,6 +854,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
                     acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
                 }
             }
+            dma_wait();
             __syncthreads();
         }
     }
