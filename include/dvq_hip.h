@@ -11,7 +11,8 @@
  *     nothing, launches only on `stream`, never synchronises.  Process-wide state is limited to, and listed here:
  *     the scratch registration of dvq_set_workspace() (ONE caller-owned buffer per process, i.e. per rank / device:
  *     set it once before the first call that uses it; calls that find it too small fall back to atomics), caches of
- *     one-off hipFuncSetAttribute calls, and the hipBLASLt handle / plan cache / 32-MiB workspace of csrc/blaslt.hip;
+ *     one-off hipFuncSetAttribute calls, and -- only under DVQ_USE_HIPBLASLT=1 -- the hipBLASLt handle / plan cache / 32-MiB
+ *     workspace of csrc/blaslt.hip; dvq_probe_mfma_rate (diagnostics) is the one entry point that allocates and synchronises;
  *   - every entry point issues KERNEL launches only (no memset / memcpy nodes), so a sequence of calls can be recorded by
  *     HIP stream capture after its first eager execution and replayed (the training step and the sampler do);
  *   - activations are NHWC ("pixel-major"): element (n,h,w,c) at ((n*H+h)*W+w)*C+c;
@@ -38,7 +39,8 @@ enum { DVQ_F32 = 0, DVQ_BF16 = 1 };
 enum { DVQ_OK = 0, DVQ_EINVAL = -1, DVQ_ESHAPE = -2, DVQ_EARCH = -3, DVQ_ELAUNCH = -4, DVQ_EWORKSPACE = -5 };
 
 const char* dvq_last_error(void);
-int dvq_version(void);     /* 102: round 2 (device-hyper AdamW, image pipeline, distance matrix, row sampler) */
+int dvq_version(void);     /* 103: round 2 (device-hyper AdamW, image pipeline, distance matrix, row sampler, fused AttnBlock
+                            * attention, MFMA-rate probe; hipBLASLt is opt-in) */
 /* 0 if the current HIP device is gfx950, DVQ_EARCH otherwise */
 int dvq_check_device(void);
 /* Diagnostics for the benchmark's roofline context (allocates, synchronises the stream; NOT for the hot path): TFLOP/s and shader
@@ -354,7 +356,8 @@ int dvq_embed_scatter_add(const int64_t* idx, int64_t idx_bstride, const void* d
 int dvq_cross_entropy(const void* logits, int dtype, int64_t rows, int64_t V, int64_t ldl, const int64_t* target, int64_t ignore_index,
                       float* loss_sum, float* count, const float* gscale_dev, void* dlogits, dvq_stream_t stream);
 /* 1 if large plain bf16 dvq_gemm_nt calls (impl 0, batch 1, bias per column or none, M >= 1024, N, K >= 256) are served by
- * hipBLASLt (bound with dlopen at first use; DVQ_NO_HIPBLASLT=1 disables), 0 if they run on the library's own kernel. */
+ * hipBLASLt -- only when the process runs with DVQ_USE_HIPBLASLT=1 (comparison path, bound with dlopen at first use);
+ * 0 (the default) if they run on the library's own pipelined GEMM kernels. */
 int dvq_blaslt_available(void);
 /* C[M][N] = A[M][K] B[K][N] (bf16, row-major) on hipBLASLt ONLY -- the input gradient of a Linear layer straight from the
  * [out][in] weight matrix, no transposed copy.  DVQ_ESHAPE when the library is absent or declines: the caller then
