@@ -69,7 +69,7 @@ def _cpu_baseline_worker(threads, bs, objective="full"):
         else:
             ots.train_steps(sd, [x], thr, steps=1)
         n += 1
-        if time.time() - t0 > 12.0 or n >= 4:
+        if time.time() - t0 > 15.0 or n >= 10:      # ~15 s of CPU work
             break
     print(json.dumps({"n": n, "sec": time.time() - t0}), flush=True)
 

@@ -923,6 +923,8 @@ struct TnParams {
     int Jc;          // columns per tap of C (<= J; smaller when the operand channels are padded)
     int64_t sA, sB, sC;
     int batch_in_z;
+    float* ws;       // wide pipelined kernel: split partials [nsplit][tiles][256][256] fp32 (+ ws_bias [nsplit][itiles][256]) in the
+    float* ws_bias;  //   registered workspace, folded by gemm_tn_wide_reduce_kernel; null -> fp32 atomics straight into C
     int thin;        // conv, J == 8 (image-channel inputs): the B tile's 16 chunks are the TAPS (column = tap * 8 + channel), one
                      //   workgroup accumulates every tap instead of a 1/16-full tile per tap
 };
@@ -1476,8 +1478,28 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_pipe_kernel(TnParams p) {
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     }
 
-    float* __restrict__ Cg = p.C + bz * p.sC;
     const int l31 = lane & 31, half = lane >> 5;
+    if (p.ws != nullptr) {
+        // Cross-XCD fp32 atomics resolve at the memory side and cost far more than plain stores: with a workspace every workgroup
+        // stores its 256 x 256 partial tile with ordinary coalesced writes and gemm_tn_wide_reduce_kernel folds the splits into C
+        float* tile = p.ws + ((int64_t)split * per_split + it + (int64_t)jt * p.itiles) * 65536;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tile[(wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 256 + wn * 128 + nt * 32 + l31] = acc[mt][nt][r];
+        if (do_bias) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);
+                if (half == 0) p.ws_bias[((int64_t)split * p.itiles + it) * 256 + wm * 64 + t * 32 + l31] = v;
+            }
+        }
+        return;
+    }
+    float* __restrict__ Cg = p.C + bz * p.sC;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int col = j0 + wn * 128 + nt * 32 + l31;
@@ -1499,6 +1521,28 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_pipe_kernel(TnParams p) {
         }
     }
 #endif
+}
+
+// C[i][j] += sum over the splits of the workspace partials (one writer per element: plain read-modify-write, deterministic order)
+__global__ __launch_bounds__(256) void gemm_tn_wide_reduce_kernel(TnParams p) {
+    const int ntile = p.itiles * p.jtiles;
+    const int64_t total = (int64_t)ntile * 65536;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int wi = (int)(e >> 16), q = (int)(e & 65535);
+        const int row = (wi % p.itiles) * 256 + (q >> 8), col = (wi / p.itiles) * 256 + (q & 255);
+        if (row >= p.I || col >= p.Jc) continue;
+        float sum = 0.f;
+        for (int sidx = 0; sidx < p.nsplit; ++sidx) sum += p.ws[((int64_t)sidx * ntile + wi) * 65536 + q];
+        p.C[tn_c_offset(p, row, 0, col)] += sum;
+    }
+    if (p.colsumA != nullptr) {
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < p.itiles * 256; e += gridDim.x * 256) {
+            if (e >= p.I) continue;
+            float sum = 0.f;
+            for (int sidx = 0; sidx < p.nsplit; ++sidx) sum += p.ws_bias[((int64_t)sidx * p.itiles + (e >> 8)) * 256 + (e & 255)];
+            p.colsumA[e] += sum;
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1770,7 +1814,10 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
         p.m_per_split = (int)mps;
         p.nsplit = (int)splits;
         dim3 grid((unsigned)(p.itiles * p.jtiles * tapblk * splits), 1, (unsigned)batch);
-        if (sizeof(T) == 2 && (impl == 0 || impl == 6) && !p.conv && p.taps == 1 && p.I >= 256 && p.J >= 256 && p.Mred >= 1024 &&
+        // the weight gradient of a 1 x 1 / stride 1 / unpadded convolution IS a plain TN product (dy^T x)
+        const bool conv1x1 = p.conv && p.taps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.up == 0 && p.LH == p.DH &&
+                             p.LW == p.DW;
+        if (sizeof(T) == 2 && (impl == 0 || impl == 6) && (!p.conv || (conv1x1 && impl == 0)) && p.taps == 1 && p.I >= 256 && p.J >= 256 && p.Mred >= 1024 &&
             p.I % 8 == 0 && p.J % 8 == 0 && (int64_t)p.Mred * p.lda < (1ll << 30) && (int64_t)p.Mred * p.ldb < (1ll << 30) &&
             (p.sA * 2) % 4 == 0 && (p.sB * 2) % 4 == 0) {
             // large plain weight-gradient GEMMs: 256 x 256 tiles, pipelined main loop; ~one resident workgroup per CU
@@ -1778,14 +1825,26 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
             p.jtiles = (int)cdiv64(p.J, 256);
             const int64_t wtiles = (int64_t)p.itiles * p.jtiles * batch;
             int64_t wsplits = wtiles >= 256 ? 1 : 256 / wtiles;
-            const int64_t wmax = cdiv64(p.Mred, 4 * BK);
+            const int64_t wmax = cdiv64(p.Mred, 16 * BK);       // >= 16 stages per workgroup: prologue, partial-tile store and fold amortised
             if (wsplits > wmax) wsplits = wmax;
             const int64_t wmps = cdiv64(cdiv64(p.Mred, wsplits), BK) * BK;
             p.m_per_split = (int)wmps;
             p.nsplit = (int)cdiv64(p.Mred, wmps);
+            p.conv = 0;
+            int64_t ws_bytes = 0;
+            char* wsp = (char*)dvq_workspace(&ws_bytes);
+            const int64_t need = (int64_t)p.nsplit * wtiles * 65536 * 4 + (int64_t)p.nsplit * p.itiles * 256 * 4;
+            if (wsp != nullptr && ws_bytes >= need && p.nsplit > 2 && batch == 1) {     // many splits per tile: partials + fold, no atomics
+                p.ws = (float*)wsp;
+                p.ws_bias = (float*)(wsp + (int64_t)p.nsplit * wtiles * 65536 * 4);
+            }
             dvq_ensure_dynamic_lds((const void*)gemm_tn_wide_pipe_kernel, 2 * WTSTG);
             gemm_tn_wide_pipe_kernel<<<dim3((unsigned)(p.itiles * p.jtiles * p.nsplit), 1, (unsigned)batch), dim3(512), 2 * WTSTG, s>>>(p);
             DVQ_CHECK_LAUNCH("gemm_tn_wide_pipe");
+            if (p.ws != nullptr) {
+                gemm_tn_wide_reduce_kernel<<<dim3((unsigned)(wtiles * 256)), dim3(256), 0, s>>>(p);
+                DVQ_CHECK_LAUNCH("gemm_tn_wide_reduce");
+            }
             return DVQ_OK;
         }
         if (sizeof(T) == 2 && impl != 3) {      // LDS-DMA + transpose-read kernel
