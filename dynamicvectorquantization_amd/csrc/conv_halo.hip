@@ -676,19 +676,39 @@ struct WgParams {
 // workgroup stores its 9 x 128 x 64 partial tile with ordinary coalesced writes and this kernel folds the splits into
 // the gradient (one writer per element: plain read-modify-write, deterministic summation order).
 __global__ __launch_bounds__(256) void conv3x3_halo_wgrad_reduce_kernel(WgParams p) {
+    // 64 consecutive elements x 4 quarters of the split range per workgroup: ~150 k elements would otherwise be ~2 workgroups per
+    // CU, each thread walking every split by itself -- far too few loads in flight for an HBM-bound fold
+    __shared__ float part[4][64];
     const int ntile = p.gi * p.gj;
     const int64_t per_tile = 9ll * 128 * 64;
     const int64_t total = (int64_t)ntile * per_tile;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int wi = (int)(e / per_tile);
-        const int r = (int)(e - (int64_t)wi * per_tile);
-        const int tap = r / 8192, q = r - tap * 8192;
-        const int co = (wi % p.gi) * 128 + (q >> 6), ci = (wi / p.gi) * 64 + (q & 63);
-        if (co >= p.cout_real || ci >= p.cin_real) continue;
-        float sum = 0.f;
-        for (int sidx = 0; sidx < p.nsplit; ++sidx) sum += p.ws[((int64_t)sidx * ntile + wi) * per_tile + r];
-        const int64_t o = p.c_oihw ? ((int64_t)co * p.cin_real + ci) * 9 + tap : ((int64_t)co * 9 + tap) * p.cin_real + ci;
-        p.DW[o] += sum;
+    const int lx = threadIdx.x & 63, qy = threadIdx.x >> 6;
+    const int64_t sstride = (int64_t)ntile * per_tile;
+    const int sper = (p.nsplit + 3) >> 2, s0 = qy * sper, s1 = min(p.nsplit, s0 + sper);
+    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < total; e0 += (int64_t)gridDim.x * 64) {
+        const int64_t e = e0 + lx;                       // (total is a multiple of 64)
+        const float* src = p.ws + e;                     // element e of split 0: (wi * per_tile + r) == e
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sidx = s0;
+        for (; sidx + 8 <= s1; sidx += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s8[u] += src[(sidx + u) * sstride];
+        }
+        for (; sidx < s1; ++sidx) s8[0] += src[sidx * sstride];
+        part[qy][lx] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        __syncthreads();
+        if (qy == 0) {
+            const int wi = (int)(e / per_tile);
+            const int r = (int)(e - (int64_t)wi * per_tile);
+            const int tap = r / 8192, q = r - tap * 8192;
+            const int co = (wi % p.gi) * 128 + (q >> 6), ci = (wi / p.gi) * 64 + (q & 63);
+            if (co < p.cout_real && ci < p.cin_real) {
+                const float sum = (part[0][lx] + part[1][lx]) + (part[2][lx] + part[3][lx]);
+                const int64_t o = p.c_oihw ? ((int64_t)co * p.cin_real + ci) * 9 + tap : ((int64_t)co * 9 + tap) * p.cin_real + ci;
+                p.DW[o] += sum;
+            }
+        }
+        __syncthreads();
     }
     if (p.DB != nullptr) {
         // bias partials exist once per co-tile: only the ci-chunk 0 blocks (wi / gi == 0) wrote them
@@ -938,7 +958,7 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
     }
     if (p.ws != nullptr) {
         const int64_t work = (int64_t)p.gi * p.gj * 9 * 128 * 64;
-        conv3x3_halo_wgrad_reduce_kernel<<<dim3((unsigned)cdiv64(work, 256)), dim3(256), 0, stream>>>(p);
+        conv3x3_halo_wgrad_reduce_kernel<<<dim3((unsigned)cdiv64(work, 64)), dim3(256), 0, stream>>>(p);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -1531,9 +1531,16 @@ __global__ __launch_bounds__(256) void gemm_tn_wide_reduce_kernel(TnParams p) {
         const int wi = (int)(e >> 16), q = (int)(e & 65535);
         const int row = (wi % p.itiles) * 256 + (q >> 8), col = (wi / p.itiles) * 256 + (q & 255);
         if (row >= p.I || col >= p.Jc) continue;
-        float sum = 0.f;
-        for (int sidx = 0; sidx < p.nsplit; ++sidx) sum += p.ws[((int64_t)sidx * ntile + wi) * 65536 + q];
-        p.C[tn_c_offset(p, row, 0, col)] += sum;
+        const float* src = p.ws + (int64_t)wi * 65536 + q;
+        const int64_t sstride = (int64_t)ntile * 65536;
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // eight loads in flight per thread
+        int sidx = 0;
+        for (; sidx + 8 <= p.nsplit; sidx += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s8[u] += src[(sidx + u) * sstride];
+        }
+        for (; sidx < p.nsplit; ++sidx) s8[0] += src[sidx * sstride];
+        p.C[tn_c_offset(p, row, 0, col)] += ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     }
     if (p.colsumA != nullptr) {
         for (int e = blockIdx.x * 256 + threadIdx.x; e < p.itiles * 256; e += gridDim.x * 256) {
