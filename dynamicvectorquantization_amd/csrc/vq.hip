@@ -493,28 +493,40 @@ __global__ void vq_flag_all_kernel(VqWs* ws, int64_t N) {
     if (i < N) ws->list[i] = (int)i;
 }
 
-// fp64 exact re-rank of flagged rows: one 1024-thread block per flagged row (grid-stride); 8 lanes share a
-// code (each 4 consecutive dims per step -> 128-B coalesced codebook reads), 8 codes per wave at a time.
+// fp64 exact re-rank of flagged rows: one 1024-thread block per FOUR flagged rows (grid-stride; they share every codebook load);
+// 8 lanes share a code (each 4 consecutive dims per step -> 128-B coalesced codebook reads), 8 codes per wave at a time.
 constexpr int RR_THREADS = 1024;
 template <typename XT>
 __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __restrict__ x,
                                                                     const float* __restrict__ cb, int64_t N, int64_t K, int64_t D,
                                                                     int64_t* __restrict__ idx_out, const VqWs* ws, int do_cand) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* xs = reinterpret_cast<double*>(smem);            // [D]
-    double* wbest = xs + D;                                  // [16]
-    int* widx = reinterpret_cast<int*>(wbest + 16);          // [16]
+    double* xs = reinterpret_cast<double*>(smem);            // [4][D]: the rows of a pass
+    double* wbest = xs + 4 * D;                              // [4][16]
+    int* widx = reinterpret_cast<int*>(wbest + 4 * 16);      // [4][16]
     const int cnt = ws->count;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 3, sub = lane & 7;
     constexpr int NW = RR_THREADS / 64;
-    for (int f = blockIdx.x; f < cnt; f += gridDim.x) {
-        const int64_t row = ws->list[f];
+    // RB flagged rows per block and pass share every codebook load: an all-codes row otherwise re-reads the whole codebook (1 MiB at
+    // K = 1024, D = 256) from L2 by itself -- 2500 such rows in an early training step were 2.5 GB of traffic, 0.5 ms
+    constexpr int RB = 4;
+    for (int f0 = blockIdx.x * RB; f0 < cnt; f0 += gridDim.x * RB) {
+        const int nrow = min(RB, cnt - f0);
         __syncthreads();
-        for (int64_t d = threadIdx.x; d < D; d += blockDim.x) xs[d] = (double)ElemIO<XT>::load(x + row * D + d);
+        for (int64_t e = threadIdx.x; e < RB * D; e += blockDim.x) {
+            const int rb = (int)(e / D);
+            const int64_t d = e - (int64_t)rb * D;
+            xs[e] = rb < nrow ? (double)ElemIO<XT>::load(x + (int64_t)ws->list[f0 + rb] * D + d) : 0.0;
+        }
         __syncthreads();
-        double best = __builtin_inf();
-        int bi = 0x7fffffff;
+        double best[RB];
+        int bi[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            best[rb] = __builtin_inf();
+            bi[rb] = 0x7fffffff;
+        }
         int first_combine = 8;
         if ((D & 15) == 0) {
             // two lanes per code (float4 loads of alternating 4-dim chunks), 32 codes per wave and pass: K = 1024 is two passes
@@ -523,78 +535,104 @@ __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __
             first_combine = 2;
             for (int64_t k0 = (int64_t)wave * 32; k0 < K; k0 += NW * 32) {
                 const int64_t k = k0 + g2;
-                double a0 = 0.0, a1 = 0.0;
+                double a0[RB], a1[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) a0[rb] = a1[rb] = 0.0;
                 if (k < K) {
                     const float* cr = cb + k * D + 4 * s2;
-#pragma unroll 8
+#pragma unroll 4
                     for (int64_t d = 0; d < D; d += 16) {           // this lane: dims d + 4 s2 .. +3 and d + 8 + 4 s2 .. +3 (loads batched)
                         const float4 c0 = *reinterpret_cast<const float4*>(cr + d);
                         const float4 c1 = *reinterpret_cast<const float4*>(cr + d + 8);
-                        const double* xa = xs + d + 4 * s2;
-                        double t;
-                        t = xa[0] - (double)c0.x; a0 = fma(t, t, a0);
-                        t = xa[1] - (double)c0.y; a0 = fma(t, t, a0);
-                        t = xa[2] - (double)c0.z; a0 = fma(t, t, a0);
-                        t = xa[3] - (double)c0.w; a0 = fma(t, t, a0);
-                        t = xa[8] - (double)c1.x; a1 = fma(t, t, a1);
-                        t = xa[9] - (double)c1.y; a1 = fma(t, t, a1);
-                        t = xa[10] - (double)c1.z; a1 = fma(t, t, a1);
-                        t = xa[11] - (double)c1.w; a1 = fma(t, t, a1);
+                        const double c00 = (double)c0.x, c01 = (double)c0.y, c02 = (double)c0.z, c03 = (double)c0.w;
+                        const double c10 = (double)c1.x, c11 = (double)c1.y, c12 = (double)c1.z, c13 = (double)c1.w;
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) {
+                            const double* xa = xs + rb * D + d + 4 * s2;
+                            double t;
+                            t = xa[0] - c00; a0[rb] = fma(t, t, a0[rb]);
+                            t = xa[1] - c01; a0[rb] = fma(t, t, a0[rb]);
+                            t = xa[2] - c02; a0[rb] = fma(t, t, a0[rb]);
+                            t = xa[3] - c03; a0[rb] = fma(t, t, a0[rb]);
+                            t = xa[8] - c10; a1[rb] = fma(t, t, a1[rb]);
+                            t = xa[9] - c11; a1[rb] = fma(t, t, a1[rb]);
+                            t = xa[10] - c12; a1[rb] = fma(t, t, a1[rb]);
+                            t = xa[11] - c13; a1[rb] = fma(t, t, a1[rb]);
+                        }
                     }
                 } else {
-                    a0 = __builtin_inf();
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) a0[rb] = __builtin_inf();
                 }
-                double acc = a0 + a1;
-                acc += __shfl_xor(acc, 1, 64);
-                if (acc < best) {    // k increasing per lane pair -> first minimum kept
-                    best = acc;
-                    bi = (int)k;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    double acc = a0[rb] + a1[rb];
+                    acc += __shfl_xor(acc, 1, 64);
+                    if (acc < best[rb]) {    // k increasing per lane pair -> first minimum kept
+                        best[rb] = acc;
+                        bi[rb] = (int)k;
+                    }
                 }
             }
         } else {
             for (int64_t k0 = (int64_t)wave * 8; k0 < K; k0 += NW * 8) {
                 const int64_t k = k0 + grp;
-                double acc = 0.0;
+                double acc[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb] = 0.0;
                 if (k < K) {
                     for (int64_t d = sub; d < D; d += 8) {          // generic D; 8 lanes cover 8 consecutive dims
-                        double t = xs[d] - (double)cb[k * D + d];
-                        acc = fma(t, t, acc);
+                        const double cv = (double)cb[k * D + d];
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) {
+                            const double t = xs[rb * D + d] - cv;
+                            acc[rb] = fma(t, t, acc[rb]);
+                        }
                     }
                 } else {
-                    acc = __builtin_inf();
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_inf();
                 }
-                acc += __shfl_xor(acc, 1, 64);
-                acc += __shfl_xor(acc, 2, 64);
-                acc += __shfl_xor(acc, 4, 64);
-                if (acc < best) {    // k increasing per lane group -> first minimum kept
-                    best = acc;
-                    bi = (int)k;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    double a = acc[rb];
+                    a += __shfl_xor(a, 1, 64);
+                    a += __shfl_xor(a, 2, 64);
+                    a += __shfl_xor(a, 4, 64);
+                    if (a < best[rb]) {    // k increasing per lane group -> first minimum kept
+                        best[rb] = a;
+                        bi[rb] = (int)k;
+                    }
                 }
             }
         }
-        // combine the code groups of the wave (lexicographic on (distance, index))
-        for (int o = first_combine; o < 64; o <<= 1) {
-            double ob = __shfl_xor(best, o, 64);
-            int oi = __shfl_xor(bi, o, 64);
-            if (ob < best || (ob == best && oi < bi)) {
-                best = ob;
-                bi = oi;
+        // combine the code groups of the wave (lexicographic on (distance, index)), then the waves
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            for (int o = first_combine; o < 64; o <<= 1) {
+                double ob = __shfl_xor(best[rb], o, 64);
+                int oi = __shfl_xor(bi[rb], o, 64);
+                if (ob < best[rb] || (ob == best[rb] && oi < bi[rb])) {
+                    best[rb] = ob;
+                    bi[rb] = oi;
+                }
             }
-        }
-        if (lane == 0) {
-            wbest[wave] = best;
-            widx[wave] = bi;
+            if (lane == 0) {
+                wbest[rb * NW + wave] = best[rb];
+                widx[rb * NW + wave] = bi[rb];
+            }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double b = wbest[0];
-            int i = widx[0];
+        if (threadIdx.x < nrow) {
+            const int rb = threadIdx.x;
+            double b = wbest[rb * NW];
+            int i = widx[rb * NW];
             for (int w = 1; w < NW; ++w)
-                if (wbest[w] < b || (wbest[w] == b && widx[w] < i)) {
-                    b = wbest[w];
-                    i = widx[w];
+                if (wbest[rb * NW + w] < b || (wbest[rb * NW + w] == b && widx[rb * NW + w] < i)) {
+                    b = wbest[rb * NW + w];
+                    i = widx[rb * NW + w];
                 }
-            idx_out[row] = (int64_t)i;
+            idx_out[ws->list[f0 + rb]] = (int64_t)i;
         }
     }
     // ambiguous rows with a short candidate list (the usual case): one wave per entry {row, n, idx[n], class mask}: a few fp64
@@ -922,9 +960,9 @@ static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_
         vq_flag_all_kernel<<<dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, s>>>(ws, N);
         DVQ_CHECK_LAUNCH("vq_flag_all");
     }
-    size_t lds = (size_t)D * 8 + 16 * 8 + 16 * 4;
+    size_t lds = 4 * ((size_t)D * 8 + 16 * 8 + 16 * 4);          // four rows per block and pass
     // one launch settles both kinds of ambiguous rows: all-codes re-ranks (rare) and candidate-list re-ranks (the usual case)
-    int64_t blocks = use_mfma ? 256 : (N < 65535 ? N : 65535);
+    int64_t blocks = use_mfma ? 256 : (cdiv64(N, 4) < 65535 ? cdiv64(N, 4) : 65535);
     vq_rerank_fp64_kernel<XT><<<dim3((unsigned)blocks), dim3(RR_THREADS), lds, s>>>(x, cb, N, K, D, idx, ws, use_mfma ? 1 : 0);
     DVQ_CHECK_LAUNCH("vq_rerank_fp64");
     return DVQ_OK;
