@@ -495,7 +495,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
                 gs[k] += __shfl_xor(gs[k], off, 64);
                 gq[k] += __shfl_xor(gq[k], off, 64);
             }
-        __syncthreads();                                        // the staged output tile has been consumed
+        // LDS-only barriers: __syncthreads() would also wait for this wave's global STORES of the tile (vmcnt(0), a round trip to
+        // L2) before the statistics may proceed
+        auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory"); };
+        lds_barrier();                                          // the staged output tile has been consumed
         float* red = reinterpret_cast<float*>(smem);            // [NW][CO_T][2]
         if (lane < CPRW) {
 #pragma unroll
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
                 red[((wave * CO_T) + lane * 8 + k) * 2 + 1] = gq[k];
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < CO_T) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
