@@ -440,7 +440,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
             }
         }
     }
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. make every wave wait for ALL of its residual loads before
+    // the first row may be stored; this way each store waits for its own load only
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
     float gs[8], gq[8];                 // output statistics of this thread's 8 channels (chunk tid & 15 in every iteration)
 #pragma unroll
     for (int k = 0; k < 8; ++k) gs[k] = gq[k] = 0.f;
