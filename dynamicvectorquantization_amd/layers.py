@@ -384,8 +384,12 @@ class Conv2d(HipModule):
         if need_dw:
             db = _grad_buf(self.bias) if self.bias is not None else None
             # weight / bias gradients are accumulated by the kernel straight into the reference-layout .grad buffers
-            K.conv2d_wgrad_oihw(d, x, dy, self.in_channels, self.out_channels, _grad_buf(self.weight), db,
-                                gn_ss=tape.s.get("gn_ss"))
+            gw, gss = _grad_buf(self.weight), tape.s.get("gn_ss")
+            if need_dx and rt.side_wgrad_enabled():
+                # on the side stream: nothing reads this gradient before the optimizer step / its bucket's exchange
+                rt.run_on_side(lambda: K.conv2d_wgrad_oihw(d, x, dy, self.in_channels, self.out_channels, gw, db, gn_ss=gss), x, dy)
+            else:
+                K.conv2d_wgrad_oihw(d, x, dy, self.in_channels, self.out_channels, gw, db, gn_ss=gss)
         if not need_dx:
             return None
         _, wt, _ = self.packed(x.dtype)

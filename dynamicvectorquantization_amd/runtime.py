@@ -125,6 +125,7 @@ def capturing() -> bool:
 
 
 def graph_break(fn):
+    join_side()                # a segment may not end (and an exchange may not start) with weight gradients still on the side stream
     if _capture is None:
         return fn()
     return _capture.brk(fn)
@@ -223,6 +224,8 @@ class StepGraph:
                 _lib._launch_hook = None
                 if self._g is not None:
                     try:
+                        if ok:
+                            join_side(self.device)
                         self._end()
                     except Exception:
                         if ok:
@@ -242,3 +245,73 @@ class StepGraph:
 
     def n_segments(self):
         return sum(1 for k, _ in self.items if k == "graph")
+
+
+# ---------------------------------------------------------------------------------------------
+# Weight gradients on a side stream: wgrad(dy, x) of a convolution has no consumer before the optimizer step (or the gradient
+# exchange of its bucket), while dgrad(dy) heads the chain dx -> GroupNorm backward -> ... of HBM- / VALU-bound kernels.  Issued on
+# a second stream the MFMA-bound weight-gradient kernels fill the matrix pipes while that chain runs.  All weight gradients share
+# ONE side stream, so the registered workspace (split partials) is used by one kernel at a time.
+# ---------------------------------------------------------------------------------------------
+_side = {}
+
+
+_side_on = False
+
+
+def side_wgrad_enabled():
+    return _side_on
+
+
+class side_wgrad:
+    """context: inside, layers.Conv2d.bwd issues its weight gradient on the side stream; on exit the current stream has waited
+    for it.  Only callers that read gradients through join_side() points may switch this on (trainer.Trainer does; code that
+    calls bwd() and then reads .grad directly keeps the single-stream behaviour).  DVQ_SIDE_WGRAD=0 disables it."""
+
+    def __enter__(self):
+        global _side_on
+        self.prev = _side_on
+        # eagerly launched steps only: a hipGraph replay of the two-stream capture ran no faster than the single-stream one on
+        # ROCm 7.2 (179.9 vs 179.1 ms, with 39 ms of host time per launch; DEBUG_HIP_FORCE_GRAPH_QUEUES / packet capture made no
+        # difference), while eager steps gain 2.5 % (174.8 vs 179.3 ms); DVQ_SIDE_WGRAD=graph forces it inside captures too
+        mode = os.environ.get("DVQ_SIDE_WGRAD", "1")
+        _side_on = mode == "graph" or (mode == "1" and not capturing())
+        return self
+
+    def __exit__(self, *exc):
+        global _side_on
+        _side_on = self.prev
+        join_side()
+        return False
+
+
+def side_stream(device=None):
+    dev = torch.device(device if device is not None else torch.cuda.current_device())
+    if dev.type != "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _side:
+        _side[key] = {"stream": torch.cuda.Stream(torch.device("cuda", key)), "dirty": False}
+    return _side[key]
+
+
+def run_on_side(fn, *tensors):
+    """launch fn() on the side stream after everything issued so far on the current stream; `tensors` are what it reads"""
+    st = side_stream(tensors[0].device if tensors else None)
+    cur = torch.cuda.current_stream()
+    st["stream"].wait_stream(cur)
+    with torch.cuda.stream(st["stream"]):
+        fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(st["stream"])
+    st["dirty"] = True
+
+
+def join_side(device=None):
+    """make the current stream wait for the side stream (before gradients are read: optimizer step, gradient exchange, the end
+    of a recorded segment)"""
+    for key, st in _side.items():
+        if st["dirty"] and (device is None or torch.device(device).index in (None, key)):
+            torch.cuda.current_stream(torch.device("cuda", key)).wait_stream(st["stream"])
+            st["dirty"] = False

@@ -395,9 +395,10 @@ class Trainer:
             for oi, opt in enumerate(self.opts):
                 self.buckets[oi].zero()
                 self._arm_overlap(oi)
-                loss = m.training_step(batch, batch_idx, oi) if self._takes_opt_idx else m.training_step(batch, batch_idx)
-                if loss.requires_grad:
-                    loss.backward()
+                with rt.side_wgrad():          # conv weight gradients on a second stream, joined on exit (and at graph breaks)
+                    loss = m.training_step(batch, batch_idx, oi) if self._takes_opt_idx else m.training_step(batch, batch_idx)
+                    if loss.requires_grad:
+                        loss.backward()
                 self.buckets[oi].reduce()
                 self.buckets[oi].wait()
                 opt.step()
