@@ -342,9 +342,17 @@ def main():
                     vq_seen["cb"] = model.quantize.codebook._codebook().clone()
                 return orig_fwd(h, mask, tape)
             model.quantize.fwd = spy
+            # (single stream for the per-kernel events: with the weight gradients of an eager step on their side stream two kernels
+            # share the chip and each one's bracket would also hold the other's time)
+            prev_side = os.environ.get("DVQ_SIDE_WGRAD")
+            os.environ["DVQ_SIDE_WGRAD"] = "0"
             K.profile_start()
             trainer.train_step(batches[steps % nb], SETUP + warmup + steps)
             prof = K.profile_stop()
+            if prev_side is None:
+                os.environ.pop("DVQ_SIDE_WGRAD", None)
+            else:
+                os.environ["DVQ_SIDE_WGRAD"] = prev_side
             model.quantize.fwd = orig_fwd
             model._vq_seen = (vq_seen["x"], vq_seen["cb"]) if "x" in vq_seen else None
         graph_info = {"enabled": trainer._graph is not None, "replays": trainer.graph_replays,

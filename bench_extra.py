@@ -97,9 +97,15 @@ def main():
         trainer.train_step(batch, idx)
         n = K.profile_count_stop()
         K.profile_prepare(n + 16)
+        prev_side = os.environ.get("DVQ_SIDE_WGRAD")
+        os.environ["DVQ_SIDE_WGRAD"] = "0"      # one stream: per-kernel brackets must not hold a concurrent kernel's time
         K.profile_start()
         trainer.train_step(batch, idx + 1)
         prof = K.profile_stop()
+        if prev_side is None:
+            os.environ.pop("DVQ_SIDE_WGRAD", None)
+        else:
+            os.environ["DVQ_SIDE_WGRAD"] = prev_side
         if not prof:
             return None, {}
         fam = {k: dict(launches=v["launches"], ms_per_step=round(v["ms"], 3),
