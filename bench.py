@@ -243,6 +243,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vq-microbench", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python (no hipGraph replay of the step)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "graph", "eager"],
+                    help="how the timed steps are launched: replays of the recorded step (host ~1 ms per step), eager launches "
+                         "(weight gradients on a second stream; ~40-70 ms of host work per step), or -- one GPU only -- whichever "
+                         "three untimed calibration steps show to be faster on this host (default)")
     ap.add_argument("--vq-only", action="store_true", help="only the VQ-argmin micro-benchmark (kernel iteration); prints its JSON")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU check of the launch contract only: gloo ranks, barrier + timed loop of no-op steps, one JSON line; no GPU work")
@@ -310,6 +314,26 @@ def main():
             trainer.train_step(batches[i % nb], i)
             if profile and i == 0:
                 n_launches = max(2400, K.profile_count_stop())
+        launch_mode = "eager" if args.no_graph or trainer._graph is None else "graph"
+        calib = None
+        if args.mode == "eager" and launch_mode == "graph":
+            trainer.use_graph, launch_mode = False, "eager"
+        elif args.mode == "auto" and launch_mode == "graph" and world == 1:
+            # untimed calibration: eager steps run the conv weight gradients on a second stream (a replay of the recorded step
+            # cannot: DESIGN 3a) and win by ~2.5 % when one host core keeps up with the launches; the recorded step wins otherwise
+            def probe(use_graph, n=3):
+                trainer.use_graph = use_graph
+                trainer.train_step(batches[0], SETUP)
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                for j in range(n):
+                    trainer.train_step(batches[j % nb], SETUP)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - tp) / n
+            t_graph, t_eager = probe(True), probe(False)
+            calib = {"graph_ms": round(t_graph * 1e3, 2), "eager_ms": round(t_eager * 1e3, 2)}
+            trainer.use_graph = t_graph <= t_eager * 1.01         # ties go to the recorded step
+            launch_mode = "graph" if trainer.use_graph else "eager"
         for i in range(warmup):
             trainer.train_step(batches[i % nb], SETUP + i)
         if profile:
@@ -355,7 +379,7 @@ def main():
                 os.environ["DVQ_SIDE_WGRAD"] = prev_side
             model.quantize.fwd = orig_fwd
             model._vq_seen = (vq_seen["x"], vq_seen["cb"]) if "x" in vq_seen else None
-        graph_info = {"enabled": trainer._graph is not None, "replays": trainer.graph_replays,
+        graph_info = {"enabled": trainer._graph is not None, "timed_steps": launch_mode, "calibration": calib, "replays": trainer.graph_replays,
                       "host_enqueue_all_ms_per_step": round(enqueue_all / steps * 1e3, 2),
                       "segments": trainer._graph["sg"].n_segments() if trainer._graph is not None else 0,
                       "fine_ratio": float(model._logged.get("train_fine_ratio", torch.tensor(float("nan"))))}

@@ -1,5 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_stepgraph.py tests/test_gpu_model.py tests/test_gpu_lossnet.py tests/test_gpu_data.py -m gpu -q -p no:cacheprovider --tb=short -x --timeout 600 2>&1 | tail -3 | cut -c1-300
-echo "graph (default)"; bash tools/gpu_bench_quick.sh 2>&1 | head -1
-echo "eager (default side on)"; bash tools/gpu_bench_quick.sh --no-graph 2>&1 | head -1
+for m in auto graph eager; do echo "--mode $m"; timeout 400 python bench.py --steps 10 --warmup 3 --mode $m --no-cpu-baseline --no-vq-microbench --no-ae-only 2>gpurun_out/bench_mode.err | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['host_issue_ms_per_step'], d['config']['step_graph'], d['roofline']['frac'])"; done
+tail -3 gpurun_out/bench_mode.err | cut -c1-200
