@@ -323,7 +323,8 @@ def main():
             # cannot: DESIGN 3a) and win by ~2.5 % when one host core keeps up with the launches; the recorded step wins otherwise
             def probe(use_graph, n=3):
                 trainer.use_graph = use_graph
-                trainer.train_step(batches[0], SETUP)
+                for j in range(1 if use_graph else 5):       # eager steps first re-grow the allocator pool the capture emptied
+                    trainer.train_step(batches[j % nb], SETUP)
                 torch.cuda.synchronize()
                 tp = time.perf_counter()
                 for j in range(n):

@@ -291,7 +291,7 @@ def side_stream(device=None):
         dev = torch.device("cuda", torch.cuda.current_device())
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _side:
-        _side[key] = {"stream": torch.cuda.Stream(torch.device("cuda", key)), "dirty": False}
+        _side[key] = {"stream": torch.cuda.Stream(torch.device("cuda", key)), "dirty": False, "keep": []}
     return _side[key]
 
 
@@ -302,9 +302,10 @@ def run_on_side(fn, *tensors):
     st["stream"].wait_stream(cur)
     with torch.cuda.stream(st["stream"]):
         fn()
-    for t in tensors:
-        if t is not None:
-            t.record_stream(st["stream"])
+    # the operands stay referenced until the current stream has waited for the side stream (join_side): freed after that point
+    # they are safe to re-use in stream order.  (Tensor.record_stream would defer the re-use of these -- large -- blocks to an event
+    # query instead and make the allocator grow the pool with synchronising hipMallocs for several steps.)
+    st["keep"].extend(t for t in tensors if t is not None)
     st["dirty"] = True
 
 
@@ -315,3 +316,4 @@ def join_side(device=None):
         if st["dirty"] and (device is None or torch.device(device).index in (None, key)):
             torch.cuda.current_stream(torch.device("cuda", key)).wait_stream(st["stream"])
             st["dirty"] = False
+            st["keep"].clear()
