@@ -588,7 +588,7 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     const int ntiles = p.tiles_y * p.tiles_x;
     if (out_stats != nullptr) {
         int64_t ws_bytes = 0;
-        void* ws = dvq_workspace(&ws_bytes);
+        void* ws = dvq_workspace_stream(stream, &ws_bytes);
         if (ws != nullptr && ws_bytes >= N * out_groups * ntiles * 2 * (int64_t)sizeof(float)) p.stat_part = (float*)ws;
     }
     const int64_t blocks = N * p.tiles_y * p.tiles_x * p.gn;
@@ -947,7 +947,7 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
     p.gn_ss = gn_ss;
     const int64_t nblk = (int64_t)p.gi * p.gj * p.nsplit;
     int64_t ws_bytes = 0;
-    char* wsp = (char*)dvq_workspace(&ws_bytes);
+    char* wsp = (char*)dvq_workspace_stream(stream, &ws_bytes);
     const int64_t need = nblk * (9ll * 128 * 64 + 128) * 4;
     const bool thin = Cout <= 32;
     if (wsp != nullptr && ws_bytes >= need && p.nsplit > 1 && !thin) {

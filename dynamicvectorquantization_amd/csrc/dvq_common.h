@@ -47,6 +47,8 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 void dvq_ensure_dynamic_lds(const void* kernel, int bytes);
 // caller-registered scratch buffer (dvq_set_workspace); null if none
 void* dvq_workspace(int64_t* bytes);
+// the calling stream's slot of that buffer (1/4 of it): concurrent streams never share scratch
+void* dvq_workspace_stream(hipStream_t stream, int64_t* bytes);
 
 // ---------------------------------------------------------------------------------------------
 // bf16 <-> f32 (device)

@@ -904,6 +904,262 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW == 4 ? 1 : 2) void gemm_n
 }
 
 // -------------------------------------------------------------------------------------------------
+// Pipelined implicit-GEMM convolution (bf16): the main loop of gemm_nt_wide_pipe_kernel with the A rows gathered through the
+// convolution geometry -- strided, 4 x 4, 1 x 1 and small-map convolutions (forward: MODE_FWD) and their input gradients
+// (MODE_TCONV; stride 2 by output parity class like igemm_nt_glds_kernel), i.e. everything the 3 x 3 halo kernel does not take.
+// im2col never exists: a K slab is 64 channels of ONE tap, and for every row of the tile the source pixel of tap (u, v) is
+// P(row) + sgn * (u * SW + v) -- a per-lane base offset fixed for the whole kernel plus a per-slab SCALAR offset, which is
+// exactly what buffer_load ... lds takes (voffset / soffset).  Taps that fall outside the image (padding, tile tails) are a
+// per-row bit mask computed once; a masked lane sends a voffset beyond the descriptor's range and the DMA writes zeros.
+//   WMW x WNW waves of MT x NT 32 x 32 MFMA tiles: 4 x 2 x (2 x 4) = 256 rows x 256 columns (Cout >= 256),
+//   4 x 2 x (2 x 2) = 256 x 128 (Cout = 128, or few row tiles), 8 x 1 x (2 x 2) = 512 x 64 (Cout <= 64),
+//   2 x 2 x (2 x 2) = 128 x 128 with two workgroups per CU (short reductions: loads, MFMAs and stores of neighbours overlap).
+// Needs Cs % 64 == 0, Ncols % 8 == 0, ldc % 8 == 0, operands below 2 GiB, at most 32 taps (per parity class).
+// -------------------------------------------------------------------------------------------------
+template <int WMW, int WNW, int MT, int NT, int MODE>
+__global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_nt_pipe_kernel(NtParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using T = bf16_t;
+    constexpr int NWV = WMW * WNW, NTH = 64 * NWV;
+    constexpr int TM = WMW * MT * 32, TN = WNW * NT * 32;   // tile rows (pixels) x columns (output channels)
+    constexpr int NM = MT * NT, DS = MT + NT;                // MFMAs / fragment reads per 16-k step
+    constexpr int NPA = TM / 8 / NWV, NPB = TN / 8 / NWV;    // DMA pieces (8 rows) per wave and K slab
+    static_assert(NPA * 8 * NWV == TM && NPB * 8 * NWV == TN, "tile rows must split evenly over the waves' DMA pieces");
+    constexpr int AOPB = TM * GROW, BOPB = TN * GROW, STG = AOPB + BOPB;
+    constexpr int CPR = TN / 8;                              // 16-byte chunks per staged output row
+    constexpr int VOFF_OOB = 0x7ffffff0;                     // beyond num_records: the DMA writes zeros
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wi = xcd_remap(blockIdx.x, p.gm * p.gn);
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * p.gn;
+    const int grp = wi / per_group, rem = wi - grp * per_group;
+    const int gsz = min(p.gm - grp * GROUP_M, GROUP_M);
+    int mtile = grp * GROUP_M + rem % gsz;
+    const int n0 = (rem / gsz) * TN;
+    const int Cs = (int)p.lda;
+    const int KH = p.Ktot / Cs / p.KW;
+    // class tap grid: all taps, or (stride-2 input gradient) the taps that reach output parity class pc
+    const bool par = MODE == MODE_TCONV && p.par != 0;
+    int pc = -1, Mrows = p.M, khc = 0, kwc = 0, nu = KH, nv = p.KW, qy = 0, qx = 0;
+    if (par) {
+        pc = mtile / p.par_tiles;
+        mtile -= pc * p.par_tiles;
+        Mrows = p.M >> 2;
+        khc = ((pc >> 1) + p.pad_t) & 1;
+        kwc = ((pc & 1) + p.pad_l) & 1;
+        nu = (KH - khc + 1) >> 1;
+        nv = (p.KW - kwc + 1) >> 1;
+        qy = ((pc >> 1) + p.pad_t - khc) >> 1;
+        qx = ((pc & 1) + p.pad_l - kwc) >> 1;
+    }
+    const int m0 = mtile * TM;
+    constexpr int sgn = MODE == MODE_FWD ? 1 : -1;
+    const int Dpix = MODE == MODE_FWD ? p.pad_t * p.SW + p.pad_l : 0;               // makes every lane's base pixel >= 0
+    const int Dtap = MODE == MODE_FWD ? 0 : (nu - 1) * p.SW + nv - 1;                 // makes every tap's shift >= 0
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) - (int64_t)(Dpix + Dtap) * Cs;
+    const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag), 0, 0x7fffffe0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Bg), 0, 0x7fffffff, 0x00020000);
+    const int lrow = lane >> 3, cpos = lane & 7;
+    int aoff[NPA], boff[NPB];
+    unsigned amask[NPA];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int trow = (wave * NPA + i) * 8 + lrow;
+        const int m = m0 + trow;
+        const bool rok = m < Mrows;
+        const int mm = rok ? m : 0;
+        const int dw_ = par ? p.DW >> 1 : p.DW, dh_ = par ? p.DH >> 1 : p.DH;
+        const int hw = dh_ * dw_;
+        const int n = mm / hw, r2 = mm - n * hw;
+        const int y = r2 / dw_, x = r2 - y * dw_;
+        int Py, Px;
+        if constexpr (MODE == MODE_FWD) {
+            Py = y * p.stride - p.pad_t;
+            Px = x * p.stride - p.pad_l;
+        } else {
+            Py = par ? y + qy : y + p.pad_t;
+            Px = par ? x + qx : x + p.pad_l;
+        }
+        const int pix = (n * p.SH + Py) * p.SW + Px + Dpix;
+        aoff[i] = (pix * Cs + (cpos ^ ((trow >> 1) & 7)) * 8) * 2;
+        unsigned xm = 0, msk = 0;
+        for (int v = 0; v < nv; ++v) xm |= ((unsigned)(Px + sgn * v) < (unsigned)p.LW ? 1u : 0u) << v;
+        for (int u = 0; u < nu; ++u)
+            if ((unsigned)(Py + sgn * u) < (unsigned)p.LH) msk |= xm << (u * nv);
+        amask[i] = rok ? msk : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int trow = (wave * NPB + i) * 8 + lrow;
+        boff[i] = (int)(((int64_t)min(n0 + trow, p.Ncols - 1) * p.ldb + (cpos ^ ((trow >> 1) & 7)) * 8) * 2);
+    }
+    // K slab -> (tap t = u * nv + v, 64-channel chunk c): scalar state advanced slab by slab (no divisions in the loop)
+    const int spt = Cs >> 6;
+    const int nk = nu * nv * spt;
+    struct Slab {
+        int t, c, u, v;
+    };
+    auto advance = [&](Slab s) {
+        if (++s.c == spt) {
+            s.c = 0;
+            ++s.t;
+            if (++s.v == nv) {
+                s.v = 0;
+                ++s.u;
+            }
+        }
+        return s;
+    };
+    auto so_a = [&](const Slab& s) { return ((sgn * (s.u * p.SW + s.v) + Dtap) * Cs + s.c * 64) * 2; };
+    auto so_b = [&](const Slab& s) { return (((khc + (par ? 2 : 1) * s.u) * p.KW + kwc + (par ? 2 : 1) * s.v) * Cs + s.c * 64) * 2; };
+    constexpr int ND = NPA + NPB;
+    auto issue_one = [&](int q, const Slab& s, int buf) {    // DMA instruction q of a K slab: A piece q, or B piece q - NPA
+        if (q < NPA) {
+            const int vo = ((amask[q] >> s.t) & 1u) ? aoff[q] : VOFF_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsA, (__attribute__((address_space(3))) void*)(smem + buf * STG + (wave * NPA + q) * 8 * GROW), 16, vo, so_a(s), 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsB, (__attribute__((address_space(3))) void*)(smem + buf * STG + AOPB + (wave * NPB + q - NPA) * 8 * GROW), 16,
+                boff[q - NPA], so_b(s), 0, 0);
+        }
+    };
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int swz = (l31 >> 1) & 7;
+    const char* pa;
+    const char* pb;
+    auto set_stage = [&](int buf) {
+        pa = smem + buf * STG + (wm * (MT * 32) + l31) * GROW;
+        pb = smem + buf * STG + AOPB + (wn * (NT * 32) + l31) * GROW;
+    };
+    bf16x8 a[2][MT], b[2][NT];
+    auto load_frags = [&](int ks, int slot) {                 // in the order the MFMAs consume them
+        const int off = ((ks * 2 + half) ^ swz) << 4;
+        a[slot][0] = *reinterpret_cast<const bf16x8*>(pa + off);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[slot][t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * GROW + off);
+#pragma unroll
+        for (int t = 1; t < MT; ++t) a[slot][t] = *reinterpret_cast<const bf16x8*>(pa + t * 32 * GROW + off);
+    };
+    auto mfma_step = [&](int slot, auto vm_tag) {
+        constexpr int VM = decltype(vm_tag)::value;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[slot][nt], a[slot][mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (2 * i < DS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else if (i - DS / 2 < VM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr int Q0 = (ND + 2) / 3, Q1 = Q0 + (ND - Q0 + 1) / 2;     // DMA of a slab over three steps: [0, Q0) | [Q0, Q1) | [Q1, ND)
+    using V0 = std::integral_constant<int, 0>;
+    using VA = std::integral_constant<int, Q0>;
+    using VB = std::integral_constant<int, Q1 - Q0>;
+    using VC = std::integral_constant<int, ND - Q1>;
+    Slab s1{0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < ND; ++q) issue_one(q, s1, 0);
+    if (nk > 1) s1 = advance(s1);                             // slab j + 1
+    Slab s2 = nk > 2 ? advance(s1) : s1;                      // slab j + 2
+    __syncthreads();
+    set_stage(0);
+    load_frags(0, 0);
+#pragma unroll
+    for (int q = 0; q < Q0; ++q) issue_one(q, s1, 1);
+#pragma unroll 1
+    for (int j = 0; j < nk; ++j) {
+        const int buf = j & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(1, 1);
+#pragma unroll
+        for (int q = Q0; q < Q1; ++q) issue_one(q, s1, buf ^ 1);
+        mfma_step(0, VB{});
+        load_frags(2, 0);
+#pragma unroll
+        for (int q = Q1; q < ND; ++q) issue_one(q, s1, buf ^ 1);
+        mfma_step(1, VC{});
+        load_frags(3, 1);
+        mfma_step(0, V0{});
+        __syncthreads();          // every wave has its reads of this slab behind it and its pieces of the next one landed
+        set_stage(buf ^ 1);
+        load_frags(0, 0);
+#pragma unroll
+        for (int q = 0; q < Q0; ++q) issue_one(q, s2, buf);   // (past the end: harmless re-fetches into dead stages)
+        mfma_step(1, VA{});
+        s1 = s2;
+        if (j + 3 < nk) s2 = advance(s2);
+    }
+    __syncthreads();              // (the last iteration's look-ahead reads and DMA)
+    // epilogue: the TM x TN tile is staged as bf16 (rows of TN * 2 bytes, inside the two stages) and leaves in 16-byte stores
+    const bool early_act = p.R == nullptr || p.res_mask;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+            const int lc = (wn * NT + nt) * 32 + 8 * jq + 4 * half;      // first of this lane's 4 columns
+            float4 bq = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias_mode == 1 && n0 + lc < p.Ncols) bq = *reinterpret_cast<const float4*>(p.bias + n0 + lc);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int lr = (wm * MT + mt) * 32 + l31;
+                float v[4] = {acc[mt][nt][4 * jq] + bq.x, acc[mt][nt][4 * jq + 1] + bq.y, acc[mt][nt][4 * jq + 2] + bq.z,
+                              acc[mt][nt][4 * jq + 3] + bq.w};
+                if (early_act) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.act_slope;
+                }
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                const int chunk = ((wn * NT + nt) * 4 + jq) ^ (lr & (CPR - 1));
+                *reinterpret_cast<uint2*>(smem + lr * (TN * 2) + chunk * 16 + half * 8) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    T* __restrict__ Cg = reinterpret_cast<T*>(p.C);
+    const T* __restrict__ Rg = reinterpret_cast<const T*>(p.R);
+#pragma unroll 4
+    for (int i = 0; i < (TM * CPR) / NTH; ++i) {
+        const int q = tid + NTH * i;
+        const int lr = q / CPR, ch = q % CPR;
+        const int row = m0 + lr, col = n0 + ch * 8;
+        if (row >= Mrows || col >= p.Ncols) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(smem + lr * (TN * 2) + ((ch ^ (lr & (CPR - 1))) << 4));
+        const int64_t o = (par ? par_out_row(p, pc, row) : (int64_t)row) * p.ldc + col;
+        if (Rg != nullptr) {
+            const uint4 rv = *reinterpret_cast<const uint4*>(Rg + o);
+            unsigned* pv = &v.x;
+            const unsigned* pr = &rv.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = nt_res(p, __uint_as_float(pv[k] << 16), __uint_as_float(pr[k] << 16));
+                const float hi = nt_res(p, __uint_as_float(pv[k] & 0xffff0000u), __uint_as_float(pr[k] & 0xffff0000u));
+                pv[k] = pack_bf16x2(lo, hi);
+            }
+        }
+        *reinterpret_cast<uint4*>(Cg + o) = v;
+    }
+#endif
+}
+
+// -------------------------------------------------------------------------------------------------
 // TN kernel (wgrad / generic).  C fp32, accumulated with atomics; grid.y splits the reduction.
 // -------------------------------------------------------------------------------------------------
 struct TnParams;
@@ -1710,11 +1966,11 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
     p.gn = (int)cdiv64(p.Ncols, TILE);
     bool mfma_ok = p.Ktot % VN == 0 && p.ldb % VN == 0 && p.lda % VN == 0 && (p.stride == 1 || p.stride == 2);
     if (p.mode == MODE_GEMM) mfma_ok = mfma_ok && (p.sA % VN == 0) && (p.sB % VN == 0);
-    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && impl != 6 && impl != 7 && impl != 8 && !mfma_ok), DVQ_ESHAPE,
+    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && impl != 6 && impl != 7 && impl != 8 && impl != 9 && !mfma_ok), DVQ_ESHAPE,
                 "igemm_nt: MFMA path needs K, lda, ldb multiples of %d (K=%d lda=%lld ldb=%lld) and stride 1/2", VN,
                 p.Ktot, (long long)p.lda, (long long)p.ldb);
     DVQ_REQUIRE(!(impl == 3 && !mfma_ok), DVQ_ESHAPE, "igemm_nt: register-staged MFMA path unsupported for this shape");
-    const bool use_mfma = impl == 2 || impl == 3 || ((impl == 0 || impl == 5 || impl == 6 || impl == 7 || impl == 8) && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
+    const bool use_mfma = impl == 2 || impl == 3 || ((impl == 0 || impl == 5 || impl == 6 || impl == 7 || impl == 8 || impl == 9) && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
     if constexpr (sizeof(T) == 2) {
         // 256 x 256 macro tiles pay off on long reductions that fill the chip for several rounds (8192^3: 1036 vs 812 TFLOP/s);
         // on the StackGPT shapes (K = 1024 .. 4096, 324 .. 1296 tiles) the 128 x 128 kernel is faster (tools/gemm_probe.py),
@@ -1762,6 +2018,52 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
                 DVQ_CHECK_LAUNCH("gemm_nt_wide");
                 return DVQ_OK;
             }
+        }
+    }
+    if constexpr (sizeof(T) == 2) {
+        // pipelined implicit-GEMM convolution (conv_nt_pipe_kernel): everything with 64-channel K slabs; impl 9 forces it (tests)
+        static const int pipe_env = [] {
+            const char* e = getenv("DVQ_CONV_PIPE");           // 0: off (A/B timing against the 128 x 128 kernel); 1 / 2 / 3: force a tile
+            return e != nullptr ? atoi(e) : -1;
+        }();
+        const int khn = p.mode != MODE_GEMM && p.lda > 0 && p.KW > 0 ? (int)(p.Ktot / p.lda / p.KW) : 0;
+        const bool s2par = p.mode == MODE_TCONV && p.stride == 2;
+        bool pipe_ok = (impl == 0 || impl == 9) && pipe_env != 0 && p.mode != MODE_GEMM && p.up == 0 && p.lda % 64 == 0 && p.ldb == p.Ktot &&
+                       p.Ncols % 8 == 0 && p.ldc % 8 == 0 && (p.stride == 1 || p.stride == 2) && khn >= 1 && khn * p.KW <= 16 &&
+                       (int64_t)khn * p.KW * p.lda == p.Ktot && p.bias_mode != 2 && p.alpha == 1.f &&
+                       ((int64_t)p.SH * p.SW * (p.M / ((int64_t)p.DH * p.DW)) + 2 * (4 * (int64_t)p.SW + 4)) * p.lda * 2 < 0x7fe00000ll &&
+                       (int64_t)p.Ncols * p.ldb * 2 < 0x7fe00000ll && p.M % ((int64_t)p.DH * p.DW) == 0;
+        if (s2par) pipe_ok = pipe_ok && p.DH % 2 == 0 && p.DW % 2 == 0 && p.M % 4 == 0;
+        if (p.mode == MODE_FWD && p.stride == 2) pipe_ok = pipe_ok && true;
+        DVQ_REQUIRE(!(impl == 9 && !pipe_ok), DVQ_ESHAPE, "igemm_nt: shape not eligible for the pipelined convolution kernel");
+        if (pipe_ok) {
+            // tile choice (tools/conv_bench.py sweeps, DVQ_CONV_PIPE=1..4): 256 x 256 when that fills >= 3/4 of a round of 256 CUs,
+            // else 128 x 128 at two workgroups per CU; thin outputs 512 x 64
+            int cfg = p.Ncols <= 16 ? 4 : p.Ncols <= 64 ? 3 : p.Ncols <= 128 ? 4 : (cdiv64(p.M, 256) * cdiv64(p.Ncols, 256) < 192 ? 4 : 1);
+            if (pipe_env >= 1 && pipe_env <= 4) cfg = pipe_env;
+            const int tm = cfg == 3 ? 512 : cfg == 4 ? 128 : 256, tn = cfg == 1 ? 256 : cfg == 3 ? 64 : 128;
+            if (s2par) {
+                p.par = 1;
+                p.par_tiles = (int)cdiv64(p.M / 4, tm);
+                p.gm = 4 * p.par_tiles;
+            } else {
+                p.par = 0;
+                p.gm = (int)cdiv64(p.M, tm);
+            }
+            p.gn = (int)cdiv64(p.Ncols, tn);
+            const int lds = 2 * (tm + tn) * GROW;
+            const dim3 grid((unsigned)((int64_t)p.gm * p.gn));
+            auto go = [&](auto kern) {
+                dvq_ensure_dynamic_lds((const void*)kern, lds);
+                kern<<<grid, dim3(cfg == 4 ? 256 : 512), lds, s>>>(p);
+            };
+            const bool fwd = p.mode == MODE_FWD;
+            if (cfg == 4) fwd ? go(conv_nt_pipe_kernel<2, 2, 2, 2, MODE_FWD>) : go(conv_nt_pipe_kernel<2, 2, 2, 2, MODE_TCONV>);
+            else if (cfg == 1) fwd ? go(conv_nt_pipe_kernel<4, 2, 2, 4, MODE_FWD>) : go(conv_nt_pipe_kernel<4, 2, 2, 4, MODE_TCONV>);
+            else if (cfg == 2) fwd ? go(conv_nt_pipe_kernel<4, 2, 2, 2, MODE_FWD>) : go(conv_nt_pipe_kernel<4, 2, 2, 2, MODE_TCONV>);
+            else fwd ? go(conv_nt_pipe_kernel<8, 1, 2, 2, MODE_FWD>) : go(conv_nt_pipe_kernel<8, 1, 2, 2, MODE_TCONV>);
+            DVQ_CHECK_LAUNCH("conv_nt_pipe");
+            return DVQ_OK;
         }
     }
     if (use_mfma && impl != 3) {
@@ -1832,14 +2134,16 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
             p.jtiles = (int)cdiv64(p.J, 256);
             const int64_t wtiles = (int64_t)p.itiles * p.jtiles * batch;
             int64_t wsplits = wtiles >= 256 ? 1 : 256 / wtiles;
-            const int64_t wmax = cdiv64(p.Mred, 16 * BK);       // >= 16 stages per workgroup: prologue, partial-tile store and fold amortised
+            // >= 16 stages per workgroup: prologue, partial-tile store and fold amortised (8 / 4 / 32 measured slower on the 1 x 1
+            // weight gradients: 60 / 95 / 66 against 52 us at 65536 x 256 x 256)
+            const int64_t wmax = cdiv64(p.Mred, 16 * BK);
             if (wsplits > wmax) wsplits = wmax;
             const int64_t wmps = cdiv64(cdiv64(p.Mred, wsplits), BK) * BK;
             p.m_per_split = (int)wmps;
             p.nsplit = (int)cdiv64(p.Mred, wmps);
             p.conv = 0;
             int64_t ws_bytes = 0;
-            char* wsp = (char*)dvq_workspace(&ws_bytes);
+            char* wsp = (char*)dvq_workspace_stream(s, &ws_bytes);
             const int64_t need = (int64_t)p.nsplit * wtiles * 65536 * 4 + (int64_t)p.nsplit * p.itiles * 256 * 4;
             if (wsp != nullptr && ws_bytes >= need && p.nsplit > 2 && batch == 1) {     // many splits per tile: partials + fold, no atomics
                 p.ws = (float*)wsp;

@@ -480,6 +480,38 @@ void* dvq_workspace(int64_t* bytes) {
     return g_ws_ptr;
 }
 
+// The registered buffer is cut into DVQ_WS_SLOTS equal slots, one per STREAM that asks for scratch (least recently used slot
+// re-assigned when a new stream shows up): kernels that run concurrently on different streams -- weight gradients on the side
+// stream next to the main stream's split GEMMs -- never share partials.  Host-side bookkeeping only; calls come from one thread.
+static constexpr int DVQ_WS_SLOTS = 4;
+static hipStream_t g_ws_stream[DVQ_WS_SLOTS] = {};
+static uint64_t g_ws_used[DVQ_WS_SLOTS] = {};
+static bool g_ws_taken[DVQ_WS_SLOTS] = {};
+static uint64_t g_ws_tick = 0;
+
+void* dvq_workspace_stream(hipStream_t stream, int64_t* bytes) {
+    if (g_ws_ptr == nullptr) {
+        if (bytes) *bytes = 0;
+        return nullptr;
+    }
+    const int64_t slot_bytes = (g_ws_bytes / DVQ_WS_SLOTS) & ~(int64_t)255;
+    int slot = -1;
+    for (int i = 0; i < DVQ_WS_SLOTS && slot < 0; ++i)
+        if (g_ws_taken[i] && g_ws_stream[i] == stream) slot = i;
+    for (int i = 0; i < DVQ_WS_SLOTS && slot < 0; ++i)
+        if (!g_ws_taken[i]) slot = i;
+    if (slot < 0) {
+        slot = 0;
+        for (int i = 1; i < DVQ_WS_SLOTS; ++i)
+            if (g_ws_used[i] < g_ws_used[slot]) slot = i;
+    }
+    g_ws_taken[slot] = true;
+    g_ws_stream[slot] = stream;
+    g_ws_used[slot] = ++g_ws_tick;
+    if (bytes) *bytes = slot_bytes;
+    return (char*)g_ws_ptr + (int64_t)slot * slot_bytes;
+}
+
 extern "C" {
 
 const char* dvq_last_error(void) { return g_err; }
@@ -489,6 +521,7 @@ int dvq_set_workspace(void* ptr, int64_t bytes) {
     DVQ_REQUIRE((ptr == nullptr) == (bytes == 0) && bytes >= 0, DVQ_EINVAL, "dvq_set_workspace: bad arguments");
     g_ws_ptr = ptr;
     g_ws_bytes = bytes;
+    for (int i = 0; i < DVQ_WS_SLOTS; ++i) g_ws_taken[i] = false;
     return DVQ_OK;
 }
 

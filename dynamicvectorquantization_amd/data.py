@@ -286,7 +286,14 @@ class GpuBatchLoader:
                 raise item
             b, ev = item
             if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                # the batch was allocated on the producer's stream: tell the caching allocator that the consumer's stream
+                # reads it too, so that a dropped batch is not handed back to the producer (and overwritten by the next
+                # transform) while the training stream, which runs steps behind the host, still reads it
+                for t in b.values():
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(cur)
             yield b
 
 

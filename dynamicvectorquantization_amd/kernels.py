@@ -155,6 +155,20 @@ def _halo_eligible(d: ConvDesc) -> bool:
             d.OH == d.H and d.OW == d.W and d.impl in (0, 4) and d.W % 32 == 0 and d.Cin % 64 == 0 and d.Cout % 8 == 0)
 
 
+def _nt_family(d: ConvDesc, dgrad: bool) -> str:
+    """mirrors launch_nt() in csrc/igemm.hip: the kernel family a non-halo forward / input-gradient call lands on (timing labels)"""
+    cs, ncols = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
+    if d.dtype != _lib.BF16 or d.impl not in (0, 9):
+        return "igemm_nt_glds_kernel"
+    if (d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad_t == 0 and d.pad_l == 0 and not d.upsample and ncols >= 256 and cs % 64 == 0
+            and d.impl == 0):
+        return "gemm_nt_wide_pipe_kernel"
+    if (cs % 64 == 0 and ncols % 8 == 0 and not d.upsample and d.KH * d.KW <= 16 and
+            (not dgrad or d.stride == 1 or (d.H % 2 == 0 and d.W % 2 == 0))):
+        return "conv_nt_pipe_kernel"
+    return "igemm_nt_glds_kernel"
+
+
 def _conv_cost(d: ConvDesc, esize: int):
     """algorithmic cost of one conv pass: 2*M*K*N flops; bytes = input + weights + output once each"""
     flops = 2 * d.N * d.OH * d.OW * d.Cout * d.KH * d.KW * d.Cin
@@ -358,7 +372,7 @@ def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None, gn_ss=None, out_stats=Non
         ensure_workspace(x.device)        # per-tile statistics partials of the halo kernel
     if act != ACT_NONE:
         assert residual is None and gn_ss is None and out_stats is None
-        _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 else "igemm_nt_glds_kernel", fl, nb, lambda: check(
+        _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 else _nt_family(d, False), fl, nb, lambda: check(
             lib().dvq_conv2d_fwd_act(C.byref(d), _p(x), _p(w), _p(bias), _p(y), act, _s()), "dvq_conv2d_fwd_act"))
         return y
     if gn_ss is not None or out_stats is not None:
@@ -366,7 +380,7 @@ def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None, gn_ss=None, out_stats=Non
             lib().dvq_conv2d_fwd_ex(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), _p(y), _p(gn_ss), _p(out_stats),
                                     out_groups, _s()), "dvq_conv2d_fwd_ex"))
         return y
-    _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 else "igemm_nt_glds_kernel", fl, nb, lambda: check(
+    _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 else _nt_family(d, False), fl, nb, lambda: check(
         lib().dvq_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), _p(y), _s()), "dvq_conv2d_fwd"))
     return y
 
@@ -378,7 +392,7 @@ def conv2d_dgrad(d: ConvDesc, dy, wt, mask=None, mask_act=ACT_NONE):
     ws = torch.empty(d.N, d.H, d.W, d.Cin, dtype=dy.dtype, device=dy.device) if d.upsample else None
     fl, nb = _conv_cost(d, dy.element_size())
     _tag(d, "dgrad")
-    _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 and d.Cout % 64 == 0 else "igemm_nt_glds_kernel", fl, nb,
+    _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 and d.Cout % 64 == 0 else _nt_family(d, True), fl, nb,
            lambda: check(
         lib().dvq_conv2d_dgrad_mask(C.byref(d), _p(dy), _p(wt), _p(dx), _p(ws), _p(mask), mask_act, _s()),
         "dvq_conv2d_dgrad_mask"))
@@ -395,7 +409,9 @@ def conv2d_wgrad(d: ConvDesc, x, dy, db=None):
 
 
 _workspace = {}
-WORKSPACE_BYTES = 80 << 20       # 256 workgroups x (9 x 128 x 64 + 128) fp32 partials of the split-K weight-gradient kernels
+# 4 per-stream slots (csrc/misc.hip: dvq_workspace_stream) of 80 MB: 256 workgroups x (9 x 128 x 64 + 128) fp32 partials of the
+# split-K weight-gradient kernels
+WORKSPACE_BYTES = 4 * (80 << 20)
 
 
 def ensure_workspace(device):

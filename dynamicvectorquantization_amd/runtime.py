@@ -11,7 +11,7 @@ _compute_dtype = torch.float32
 # bumped whenever parameters change in place (optimizer step, load_state_dict): invalidates packed weights
 _weights_epoch = 0
 # 0 auto, 1 naive kernels, 2 generic MFMA kernels (LDS-DMA igemm), 3 register-staged igemm (A/B),
-# 4 require the LDS-resident-halo 3x3 kernel (tests cross-check 1 / 2 / 4 on the GPU)
+# 4 require the LDS-resident-halo 3x3 kernel, 9 require the pipelined implicit-GEMM conv kernel (tests cross-check 1 / 2 / 4 / 9 on the GPU)
 _impl = 0
 
 
@@ -93,7 +93,7 @@ def impl() -> int:
 
 def set_impl(v: int):
     global _impl
-    assert v in (0, 1, 2, 3, 4)
+    assert v in (0, 1, 2, 3, 4, 9)
     _impl = v
 
 

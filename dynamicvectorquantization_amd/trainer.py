@@ -40,7 +40,9 @@ def scheduler_linear_warmup(warmup_steps):
 def _fn_linear_warmup_cosine_decay(warmup_steps, max_steps, multipler_min, step):
     if step < warmup_steps:
         return float(step) / float(max(1, warmup_steps))
-    multipler = 0.5 * (math.cos((step - warmup_steps) / (max_steps - warmup_steps) * math.pi) + 1)
+    # progress clamped to 1: a run that outlives `max_steps` stays at the floor instead of climbing the cosine again
+    progress = min(1.0, (step - warmup_steps) / max(1, max_steps - warmup_steps))
+    multipler = 0.5 * (math.cos(progress * math.pi) + 1)
     return max(multipler, multipler_min)
 
 
@@ -184,6 +186,7 @@ class GradBuckets:
         self.params = self.fp.params
         self._pending, self._done = [], []
         self.launched = 0                 # all-reduce launches so far (tests: every bucket exactly once per step)
+        self._divisor = None              # tests: pre-division factor of a pretended world size in a one-rank group
 
     def zero(self):
         self.fp.zero_grad()
@@ -197,7 +200,11 @@ class GradBuckets:
         backward as soon as that part of the gradient is final, so the exchange overlaps the rest of the backward"""
         if not self._active() or hi <= lo:
             return
-        ws = dist.get_world_size(self.pg)
+        ws = self._divisor if self._divisor is not None else dist.get_world_size(self.pg)
+        # weight gradients of eager steps are accumulated into this range by kernels on the side stream (runtime.side_wgrad):
+        # the pre-division below reads the range on the CURRENT stream, so the side stream is joined first -- not only at the
+        # graph break further down
+        rt.join_side()
         seg = self.fp.flat_g[lo:hi]
         seg.div_(ws)
         step = max(1, self.bucket_elems)

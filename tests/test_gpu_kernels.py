@@ -323,6 +323,76 @@ def test_conv(dev, case, dtype, impl):
         assert err < gtol * 5, f"{name}: rel-to-max error {err}"
 
 
+PIPE_CASES = [
+    # cin, cout, k, kind, H, W, N      -- tile of conv_nt_pipe_kernel the forward / the input gradient lands on
+    (64, 128, 4, "s2p1", 24, 16, 3),       # 128 x 128 / 512 x 64 (parity classes, 64 gradient columns)
+    (128, 128, 3, "down", 16, 12, 2),      # 128 x 128, stride 2 with the asymmetric pad / parity classes with 1, 2, 2, 4 taps
+    (256, 256, 3, "same", 16, 16, 1),      # 16-wide maps (not halo eligible): 128 x 128
+    (256, 512, 4, "s1p1", 12, 13, 2),      # 4 x 4 stride 1 (PatchGAN tail), odd output sizes, row tail inside a tile
+    (512, 8, 4, "s1p1", 10, 9, 2),         # 8 output channels (PatchGAN logits)
+    (64, 256, 3, "down", 128, 128, 3),     # 49152 output pixels x 256 channels: the 256 x 256 tile
+    (128, 64, 1, "same", 20, 24, 2),       # 1 x 1, 64 output columns: 512 x 64
+    (64, 320, 1, "same", 17, 9, 3),        # 1 x 1 with a column tail (320 = 256 + 64) and a row tail
+]
+
+
+@pytest.mark.parametrize("case", PIPE_CASES, ids=lambda c: "-".join(map(str, c)))
+@pytest.mark.parametrize("epi", ["plain", "lrelu+gate"])
+def test_conv_pipelined_igemm_kernel(dev, case, epi):
+    """conv_nt_pipe_kernel (impl 9 = required) against torch's fp32 convolution: forward (+ fused LeakyReLU), input gradient
+    (+ the activation gate of the layer below), with the weight gradient of the same call on the 128 x 128 TN kernel"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd.layers import Conv2d, Tape
+    cin, cout, k, kind, h, w_, n = case
+    rs = np.random.RandomState(cin + 3 * cout + k)
+    x = bf16_round(rs.standard_normal((n, cin, h, w_)).astype(np.float32))
+    wt = bf16_round((rs.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32))
+    b = (0.1 * rs.standard_normal(cout)).astype(np.float32)
+    gate = epi == "lrelu+gate"
+    kw = dict(same=dict(stride=1, padding=(k - 1) // 2), down=dict(stride=2, padding=0, asym_pad=True), s2p1=dict(stride=2, padding=1),
+              s1p1=dict(stride=1, padding=1))[kind]
+    mod = Conv2d(cin, cout, k, **kw).to(dev)
+    with torch.no_grad():
+        mod.weight.copy_(T(wt, dev))
+        mod.bias.copy_(T(b, dev))
+    cout_p = -(-cout // 8) * 8
+    with rt.compute_dtype_ctx(torch.bfloat16), rt.impl_ctx(9):
+        x_nhwc = T(x, dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+        a_in = torch.where(x_nhwc > 0, x_nhwc, (x_nhwc.float() * 0.2).to(torch.bfloat16)) if gate else x_nhwc
+        tape = Tape()
+        y = mod.fwd(a_in, tape, act=K.ACT_LRELU if gate else K.ACT_NONE)
+    # reference: LeakyReLU is piecewise linear -- its slope pattern is taken from the device result, so that pre-activations that
+    # round across zero in bf16 do not turn into O(1) gradient differences
+    xr = torch.from_numpy(x).requires_grad_(True)
+    xin = F.leaky_relu(xr, 0.2) if gate else xr            # the layer below: its gate is applied to dx by the kernel
+    if kind == "down":
+        yr = F.conv2d(F.pad(xin, (0, 1, 0, 1)), torch.from_numpy(wt), torch.from_numpy(b), stride=2)
+    else:
+        yr = F.conv2d(xin, torch.from_numpy(wt), torch.from_numpy(b), stride=kw["stride"], padding=kw["padding"])
+    if gate:
+        slope = torch.where(y[..., :cout].float().cpu().permute(0, 3, 1, 2) > 0, 1.0, 0.2)
+        yr = yr * slope
+    go = bf16_round(rs.standard_normal(tuple(yr.shape)).astype(np.float32))
+    (yr * torch.from_numpy(go)).sum().backward()
+    with rt.compute_dtype_ctx(torch.bfloat16), rt.impl_ctx(9):
+        gy = torch.zeros(n, y.shape[1], y.shape[2], cout_p, device=dev)
+        gy[..., :cout] = T(go, dev).permute(0, 2, 3, 1)
+        if gate:
+            gy = gy * torch.where(y > 0, 1.0, 0.2)          # through the fused LeakyReLU of this layer
+        if cout % 64:
+            tape.s["d"].impl = 0                            # (8 gradient channels: not a 64-channel K slab -- automatic choice)
+        dx = mod.bwd(gy.to(torch.bfloat16), tape, mask=a_in if gate else None, mask_act=K.ACT_LRELU if gate else K.ACT_NONE)
+    ref = yr.detach().permute(0, 2, 3, 1).numpy()
+    got = y.float().cpu().numpy()[..., :cout]
+    err = float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max()))
+    assert err < 2e-2, f"forward: rel-to-max error {err}"
+    dref = xr.grad.permute(0, 2, 3, 1).numpy()
+    dgot = dx.float().cpu().numpy()
+    derr = float(np.abs(dgot - dref).max()) / max(1e-6, float(np.abs(dref).max()))
+    assert derr < 3e-2, f"input gradient: rel-to-max error {derr}"
+
+
 HALO_CASES = [(64, 64, 8, 32, 2), (128, 128, 16, 32, 2), (64, 192, 8, 64, 1), (256, 128, 24, 32, 1), (128, 64, 8, 32, 1),
               (128, 8, 16, 32, 1), (64, 24, 8, 32, 2), (64, 40, 8, 64, 1)]      # thin outputs: 32- / 64-wide channel tiles
 
