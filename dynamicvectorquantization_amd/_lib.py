@@ -44,7 +44,8 @@ SIGNATURES = {
     "dvq_patch_entropy_gate_range": (i32, [vp, i64, i64, i64, i32, f32, f32, f32, vp, vp, vp]),
     "dvq_gn_stats": (i32, [vp, i32, i64, i64, i64, i32, vp, vp]),
     "dvq_gn_apply": (i32, [vp, i32, i64, i64, i64, i32, f32, vp, vp, vp, i32, vp, vp, vp]),
-    "dvq_gn_bwd_reduce": (i32, [vp, vp, i32, i64, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "dvq_gn_bwd_partial_bytes": (sz, [i64, i64, i64]),
+    "dvq_gn_bwd_reduce": (i32, [vp, vp, i32, i64, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "dvq_gn_bwd_dx": (i32, [vp, vp, i32, i64, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     "dvq_conv2d_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
     "dvq_conv3x3_fused_ok": (i32, [C.POINTER(ConvDesc)]),
@@ -55,6 +56,7 @@ SIGNATURES = {
     "dvq_conv2d_fwd_act": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp]),
     "dvq_conv2d_dgrad_mask": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
     "dvq_set_workspace": (i32, [vp, i64]),
+    "dvq_halo_trace_read": (i32, [vp, i64]),
     "dvq_permute_dual": (i32, [vp, vp, i64, i32, i32, i32, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]),
     "dvq_permute_dual_back": (i32, [vp, vp, vp, vp, i64, i64, i64, i32, i32, i64, i64, vp, vp]),
     "dvq_avgpool_slice": (i32, [vp, i32, i64, i64, i64, i64, i32, vp, i64, i64, vp]),

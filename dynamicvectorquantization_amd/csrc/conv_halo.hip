@@ -47,9 +47,15 @@ struct HaloParams {
     float act_slope;     // output activation v > 0 ? v : act_slope * v (1: none, 0: ReLU, 0.2: LeakyReLU), applied last
     int res_mask;        // 1: R is not added but gates the result: v *= (R > 0 ? 1 : mask_slope)  (backward of ReLU / LeakyReLU)
     float mask_slope;
-    int dbg;             // profiling experiments only (DVQ_HALO_DBG): 1 = skip the epilogue, 2 = skip the MFMA loop, 5 = print the
-                         //   shader clock and the duration of one workgroup's main loop
+    int dbg;             // profiling experiments only (DVQ_HALO_DBG): 1 = skip the epilogue, 2 = skip the MFMA loop, 6 = per-workgroup
+                         //   time stamps (tools/debug/halo_trace.py)
+    int nblocks;         // N * tiles_y * tiles_x * gn
+    unsigned mg_gn, mg_tx, mg_ty;      // fdiv_u32 magics of gn, tiles_x, tiles_y
 };
+
+// DVQ_HALO_DBG=6: per workgroup {CU key, start, end of the main loop, end, ...} in 10-ns ticks (dvq_halo_trace_read)
+constexpr int HALO_TRACE_MAX = 32768;
+__device__ unsigned long long g_halo_trace[HALO_TRACE_MAX][6];
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
     const int q = n >> 3, r = n & 7;
@@ -57,28 +63,39 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
-// NW = waves per workgroup: 4 -> each wave owns 2 image rows (2 x 4 accumulator tiles of 32x32, 2 waves per SIMD);
-//                           2 -> each wave owns 4 image rows (4 x 4 tiles = 256 accumulator registers, 1 wave per SIMD,
-//                                one third less LDS fragment traffic per MFMA: 8 fragment reads feed 16 MFMAs);
-//                           8 -> (WN = 2) the 128 output channels are split over two wave columns: a wave owns 2 image rows x
-//                                64 channels (2 x 2 tiles = 64 accumulator registers, <= 128 registers in all): FOUR waves per
-//                                SIMD keep the MFMA pipe fed across fragment-read latencies and the per-tap barrier, at 4
-//                                fragment reads per 4 MFMAs instead of 6 per 8.
-// NT = 32-channel output tiles per wave (4 -> 128 output channels per workgroup; 2 / 1 for Cout <= 64 / 32 so that thin
-// layers -- VGG16's 64-channel block, the 3-channel image head -- do not pay for a mostly empty 128-wide tile).
-// WN = wave columns over the output channels (1, or 2 with NW = 8): CO_T = 32 * NT * WN.
-// PIPE (NW = 4): the main loop is software-pipelined ACROSS taps and its memory instructions are pinned into the shadow of the
-//   MFMAs (sched_group_barrier): every 16-k step issues its 8 MFMAs with the next step's 6 fragment reads -- and, in the first two
-//   steps of a tap, the next tap's weight DMA -- slotted between them; the per-tap barrier sits before the LAST step, whose MFMAs
-//   then cover the first fragment reads of the next tap.  Without it the wave issues [4 DMA + address math][12 reads][wait][8 MFMA]
-//   [6 reads][8 MFMA]... and roughly a third of every tap is spent outside the MFMA pipe.
-template <int NW, int NT, int WN = 1, bool PIPE = false>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x3_halo_kernel(HaloParams p) {   // (threads, waves per SIMD)
+// n / d for n * d < 2^32 with magic = ceil(2^32 / d) (0 encodes d == 1): scalar-unit arithmetic (s_mul_hi_u32) instead of the float
+// division sequence the compiler emits for a runtime divisor -- VALU instructions are what a workgroup pays dearly for outside its
+// MFMA loop (see the epilogue notes below)
+__device__ __forceinline__ unsigned fdiv_u32(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
+
+constexpr int NHP = (HPIECES + 3) / 4;          // halo DMA pieces per wave and channel chunk (11)
+constexpr int VOFF_OOB = 0x7ffffff0;            // beyond every descriptor's range: loads return zero, stores are dropped
+
+// 4 waves, each owning 2 image rows of the 8 x 32 pixel tile: 2 x NT accumulator tiles of 32 x 32, two workgroups per CU.
+// NT = 32-channel output tiles per wave (4 -> 128 output channels per workgroup; 2 / 1 for Cout <= 64 / 32 so that thin layers --
+// VGG16's 64-channel block, the 3-channel image head -- do not pay for a mostly empty 128-wide tile).
+//
+// Main loop: software-pipelined ACROSS taps, memory instructions pinned into the shadow of the MFMAs (sched_group_barrier): every
+// 16-k step issues its 8 MFMAs with the next step's 6 fragment reads -- and, in the first two steps of a tap, the next tap's weight
+// DMA -- slotted between them; the per-tap barrier sits before the LAST step, whose MFMAs then cover the first fragment reads of
+// the next tap.
+//
+// Prologue and epilogue are written for the FEWEST VECTOR-ALU INSTRUCTIONS, not the fewest cycles: they run beside the CU
+// neighbour's main loop, and while that wave keeps the SIMD's matrix pipe busy another wave's VALU instruction issues only once
+// per MFMA -- ~36 cycles each instead of 4 (tools/debug/valu_under_mfma.hip; DVQ_HALO_DBG=6 traces showed the 700-instruction
+// staging of the round-2 epilogue taking 11 us per tile).  Hence: the tile decode runs on the scalar unit, the halo offsets are
+// computed once per tile (not per channel chunk), the accumulators start from the bias (LDS reads, no adds later), a no-op
+// activation is skipped, staging and store addresses are lane constants + immediate / scalar offsets (buffer stores through a
+// per-image descriptor), the GroupNorm statistics use v_dot2_f32_bf16 on channel PAIRS (2 instead of 6 instructions per dword).
+// Rejected variants (measured): 2 waves x (4 x 4 tiles), 8 waves x (2 x 2 tiles), un-pipelined loop, s_setprio.
+template <int NT, bool TRACE = false>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (buffer-descriptor builtins exist in the device pass only; the host pass needs just the stub)
-    constexpr int MT = 8 * WN / NW;     // image rows (32-pixel m-tiles) per wave
-    constexpr int CO_T = 32 * NT * WN;  // output channels per workgroup
+    constexpr int NW = 4, MT = 2, NTH = 256;
+    constexpr int CO_T = 32 * NT;       // output channels per workgroup
     constexpr int CPRW = CO_T / 8;      // 16-byte chunks per staged output row
-    constexpr int NTH = 64 * NW;
+    constexpr int ROWS = CO_T * 2;      // bytes of a staged output row
+    constexpr int SWZ_SH = CPRW == 16 ? 0 : CPRW == 8 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     char* bst = smem + HALOB;
@@ -86,250 +103,153 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
     float* sbias = reinterpret_cast<float*>(smem + HALOB + 2 * BSTAGE + SSB);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % (NW / WN), wn = wave / (NW / WN);     // wave row (image rows MT * wm ..) and wave column (channels)
+    const int wm = wave;                // wave row: image rows MT * wm ..
     const int l31 = lane & 31, half = lane >> 5;
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(h_zero_page);
 
-    int wi = xcd_remap(blockIdx.x, p.N * p.tiles_y * p.tiles_x * p.gn);
-    const int nt_blk = wi % p.gn;
-    wi /= p.gn;
-    const int tx = wi % p.tiles_x;
-    wi /= p.tiles_x;
-    const int ty = wi % p.tiles_y;
-    const int n = wi / p.tiles_y;
+    unsigned long long tr[5] = {0, 0, 0, 0, 0};
+    unsigned tr_key = 0;
+    if constexpr (TRACE) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        tr_key = ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
+        tr[0] = wall_clock64();
+    }
+
+    // ---- tile decode (scalar) ----
+    unsigned wi = (unsigned)xcd_remap(blockIdx.x, p.nblocks);
+    unsigned qd = fdiv_u32(wi, p.mg_gn);
+    const int nt_blk = (int)(wi - qd * p.gn);
+    wi = qd;
+    qd = fdiv_u32(wi, p.mg_tx);
+    const int tx = (int)(wi - qd * p.tiles_x);
+    wi = qd;
+    qd = fdiv_u32(wi, p.mg_ty);
+    const int ty = (int)(wi - qd * p.tiles_y);
+    const int n = (int)qd;
     const int y0 = ty * TH, x0 = tx * TW, n0 = nt_blk * CO_T;
-    if (tid < 128) sbias[tid] = (p.bias != nullptr && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;   // (published by the first barrier)
-    const int64_t img = (int64_t)n * p.H * p.W;
+    if (tid < CO_T) sbias[tid] = (p.bias != nullptr && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;
     const int SWd = p.W >> p.up;                       // stored input width
-    const int64_t simg = (int64_t)n * (p.H >> p.up) * SWd;
+    const bf16_t* Xn = p.X + (int64_t)n * (p.H >> p.up) * SWd * p.Cin;
+    const int lrow = lane >> 3, cpos = lane & 7;       // DMA lane roles: row within an 8-row piece, 16-B chunk position
 
-    // DMA lane roles: lane -> (row within an 8-row piece, 16-B chunk position)
-    const int lrow = lane >> 3, cpos = lane & 7;
-
-    const bf16_t* Xn = p.X + simg * p.Cin;
-
-    // halo pieces of this wave: wave, wave+4, ...; source pixel / chunk recomputed per channel chunk (cheap, and
-    // keeping 11 offsets live next to 128 accumulator registers would spill)
-    auto issue_halo = [&](int c0) {
-#pragma unroll 1
-        for (int pc = wave; pc < HPIECES; pc += NW) {
-            const int hp = pc * 8 + lrow;
-            const int hy = hp / HW_, hx = hp - hy * HW_;
-            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            const bool ok = hp < HROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            const int cg = cpos ^ ((hp >> 1) & 7);
-            const bf16_t* src = ok ? Xn + ((int64_t)(gy >> p.up) * SWd + (gx >> p.up)) * p.Cin + cg * 8 + c0 : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(halo + pc * 8 * ROWB), 16, 0, 0);
-        }
+    constexpr int NP = CO_T / NW / 8;           // weight DMA pieces per wave and tap
+    constexpr int NM = MT * NT, NDS = MT + NT;  // MFMAs / fragment reads per 16-k step
+    int boff[NP];                               // element offset of this lane's 16 bytes of piece i at tap 0, channel 0
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int row = wave * (CO_T / NW) + i * 8 + lrow;
+        // rows past Cout re-read the last real row: their output channels are never stored nor counted in the statistics
+        boff[i] = min(n0 + row, p.Cout - 1) * 9 * p.Cin + (cpos ^ ((row >> 1) & 7)) * 8;
+    }
+    // DMA through buffer descriptors (base in SGPRs, one 32-bit lane offset, tap / channel chunk as the scalar offset): no
+    // per-piece 64-bit address arithmetic, and padding pixels are simply out of the descriptor's range (they read as zero)
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Wt), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Xn), 0, (p.H >> p.up) * SWd * p.Cin * 2, 0x00020000);
+    // halo pieces of this wave (wave, wave + 4, ...): byte offset of this lane's 16 bytes at channel 0, once per TILE
+    int hvo[NHP];
+#pragma unroll
+    for (int i = 0; i < NHP; ++i) {
+        const int hp = (wave + NW * i) * 8 + lrow;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = hp < HROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        hvo[i] = ok ? (((gy >> p.up) * SWd + (gx >> p.up)) * p.Cin + (cpos ^ ((hp >> 1) & 7)) * 8) * 2 : VOFF_OOB;
+    }
+    auto issue_b_piece = [&](int i, int tapx, int c0, int buf) {
+        const int tb = p.flip ? 8 - tapx : tapx;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsW, (__attribute__((address_space(3))) void*)(bst + buf * BSTAGE + (wave * (CO_T / NW) + i * 8) * ROWB), 16, boff[i] * 2,
+            (tb * p.Cin + c0) * 2, 0, 0);
     };
-    auto issue_b = [&](int tap, int c0, int buf) {
-        const int tb = p.flip ? 8 - tap : tap;
-        constexpr int RPW = CO_T / NW;      // weight rows per wave (>= 8: one DMA piece)
-        char* dst = bst + buf * BSTAGE + wave * RPW * ROWB;
+    auto issue_halo_buf = [&](int c0) {
 #pragma unroll
-        for (int i = 0; i < RPW / 8; ++i) {
-            const int row = wave * RPW + i * 8 + lrow;
-            const int cg = cpos ^ ((row >> 1) & 7);
-            const bf16_t* src = (n0 + row < p.Cout) ? p.Wt + ((int64_t)(n0 + row) * 9 + tb) * p.Cin + cg * 8 + c0 : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + i * 8 * ROWB), 16, 0, 0);
-        }
+        for (int i = 0; i < NHP; ++i)
+            if (wave + NW * i < HPIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(halo + (wave + NW * i) * 8 * ROWB), 16,
+                                                         hvo[i], c0 * 2, 0, 0);
     };
-
-    const unsigned long long dbg_c0 = p.dbg == 5 ? __builtin_readcyclecounter() : 0, dbg_w0 = p.dbg == 5 ? wall_clock64() : 0;
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int swzB = (l31 >> 1) & 7;
     const int nchunks = p.dbg == 2 ? 0 : (p.Cin >> 6);
-    // residual / gate tile of the epilogue (thread q handles 16-byte chunk q % CPRW of pixel row q / CPRW): requested before the
-    // staging of the output tile so that its latency hides behind it
-    constexpr int ITERS = 256 * CPRW / NTH;
-    uint4 rpre[ITERS];
-    auto load_residual = [&]() {
-        if (p.R == nullptr) return;
+    if (nchunks > 0) {
+        issue_halo_buf(0);
 #pragma unroll
-        for (int i = 0; i < ITERS; ++i) {
-            const int q = tid + NTH * i;
-            const int lp = q / CPRW, ch = q % CPRW;
-            const int col = n0 + ch * 8;
-            const int64_t o = ((img + (int64_t)(y0 + (lp >> 5)) * p.W + x0 + (lp & 31)) * p.Cout) + col;
-            rpre[i] = col < p.Cout ? *reinterpret_cast<const uint4*>(p.R + o) : uint4{0, 0, 0, 0};
+        for (int i = 0; i < NP; ++i) issue_b_piece(i, 0, 0, 0);
+    }
+    // the accumulators start from the bias: channel nt * 32 + 8 j + 4 half + k of every pixel lives in register 4 j + k of tile nt
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");     // sbias published (LDS only: the DMA stays in flight)
+    f32x16 acc[MT][NT];
+    {
+        // one ds_read_b128 per register quad, straight into the accumulators (inline assembly: the compiler would read each quad
+        // once and COPY it to the second pixel row's tile with 64 v_mov -- the instructions this prologue is trying not to issue)
+        const unsigned sb = (unsigned)(size_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(sbias) + 16u * half;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 q4;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q4) : "v"(sb), "n"((nt * 32 + 8 * j) * 4));
+                    acc[mt][nt][4 * j] = q4[0];
+                    acc[mt][nt][4 * j + 1] = q4[1];
+                    acc[mt][nt][4 * j + 2] = q4[2];
+                    acc[mt][nt][4 * j + 3] = q4[3];
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+    }
+
+    const char* pa[MT];
+    const char* pb;
+    int sa[MT];
+    auto set_tap = [&](int tapx, int buf) {
+        const int kh = tapx / 3, kw = tapx - kh * 3;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int hp = (MT * wm + mt + kh) * HW_ + l31 + kw;
+            pa[mt] = halo + hp * ROWB;
+            sa[mt] = (hp >> 1) & 7;
         }
+        pb = bst + buf * BSTAGE + l31 * ROWB;
     };
-    if constexpr (PIPE) {
-        static_assert(WN == 1 && (NW == 4 || NW == 2), "pipelined main loop: 4 (or, experimentally, 2) waves, one wave column");
-        constexpr int NP = CO_T / NW / 8;           // weight DMA pieces per wave and tap
-        constexpr int NM = MT * NT, NDS = MT + NT;  // MFMAs / fragment reads per 16-k step
-        int boff[NP];                               // element offset of this lane's 16 bytes of piece i at tap 0, channel 0
+    bf16x8 a[2][MT], b[2][NT];
+    auto load_frags = [&](int ks, int slot) {      // in the order the MFMAs consume them
+        a[slot][0] = *reinterpret_cast<const bf16x8*>(pa[0] + (((ks * 2 + half) ^ sa[0]) << 4));
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int row = wave * (CO_T / NW) + i * 8 + lrow;
-            // rows past Cout re-read the last real row: their output channels are never stored nor counted in the statistics
-            boff[i] = min(n0 + row, p.Cout - 1) * 9 * p.Cin + (cpos ^ ((row >> 1) & 7)) * 8;
-        }
-        // DMA through buffer descriptors (base in SGPRs, one 32-bit lane offset, tap / channel chunk as the scalar offset): no
-        // per-piece 64-bit address arithmetic, and padding pixels are simply out of the descriptor's range (they read as zero)
-        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Wt), 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<bf16_t*>(Xn), 0, (p.H >> p.up) * SWd * p.Cin * 2, 0x00020000);
-        auto issue_b_piece = [&](int i, int tapx, int c0, int buf) {
-            const int tb = p.flip ? 8 - tapx : tapx;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsW, (__attribute__((address_space(3))) void*)(bst + buf * BSTAGE + (wave * (CO_T / NW) + i * 8) * ROWB), 16, boff[i] * 2,
-                (tb * p.Cin + c0) * 2, 0, 0);
-        };
-        auto issue_halo_buf = [&](int c0) {
-#pragma unroll 1
-            for (int pc = wave; pc < HPIECES; pc += NW) {
-                const int hp = pc * 8 + lrow;
-                const int hy = hp / HW_, hx = hp - hy * HW_;
-                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                const bool ok = hp < HROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-                const int cg = cpos ^ ((hp >> 1) & 7);
-                const int voff = ok ? (((gy >> p.up) * SWd + (gx >> p.up)) * p.Cin + cg * 8) * 2 : 0x7ffffff0;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(halo + pc * 8 * ROWB), 16, voff,
-                                                         c0 * 2, 0, 0);
-            }
-        };
-        const char* pa[MT];
-        const char* pb;
-        int sa[MT];
-        auto set_tap = [&](int tapx, int buf) {
-            const int kh = tapx / 3, kw = tapx - kh * 3;
+        for (int nt = 0; nt < NT; ++nt)
+            b[slot][nt] = *reinterpret_cast<const bf16x8*>(pb + nt * 32 * ROWB + (((ks * 2 + half) ^ swzB) << 4));
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int hp = (MT * wm + mt + kh) * HW_ + l31 + kw;
-                pa[mt] = halo + hp * ROWB;
-                sa[mt] = (hp >> 1) & 7;
-            }
-            pb = bst + buf * BSTAGE + l31 * ROWB;
-        };
-        bf16x8 a[2][MT], b[2][NT];
-        auto load_frags = [&](int ks, int slot) {      // in the order the MFMAs consume them
-            a[slot][0] = *reinterpret_cast<const bf16x8*>(pa[0] + (((ks * 2 + half) ^ sa[0]) << 4));
+        for (int mt = 1; mt < MT; ++mt)
+            a[slot][mt] = *reinterpret_cast<const bf16x8*>(pa[mt] + (((ks * 2 + half) ^ sa[mt]) << 4));
+    };
+    // the NM MFMAs of one step, then the issue order of the region: MFMA, fragment read(s), ..., DMA pieces behind the last MFMAs
+    auto mfma_step = [&](int slot, auto nds_tag, auto nvm_tag) {
+        constexpr int DS = decltype(nds_tag)::value, VM = decltype(nvm_tag)::value;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                b[slot][nt] = *reinterpret_cast<const bf16x8*>(pb + nt * 32 * ROWB + (((ks * 2 + half) ^ swzB) << 4));
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[slot][nt], a[slot][mt], acc[mt][nt], 0, 0, 0);   // (W X^T): channels on the register axis
+        constexpr int I0V = (DS + 1) / 2;
 #pragma unroll
-            for (int mt = 1; mt < MT; ++mt)
-                a[slot][mt] = *reinterpret_cast<const bf16x8*>(pa[mt] + (((ks * 2 + half) ^ sa[mt]) << 4));
-        };
-        // the NM MFMAs of one step, then the issue order of the region: MFMA, fragment read(s), ..., DMA pieces behind the last MFMAs
-        auto mfma_step = [&](int slot, auto nds_tag, auto nvm_tag) {
-            constexpr int DS = decltype(nds_tag)::value, VM = decltype(nvm_tag)::value;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[slot][nt], a[slot][mt], acc[mt][nt], 0, 0, 0);
-            // issue order of the region: the fragment reads of the next step two by two right behind the first MFMAs (they have
-            // landed long before that step starts), then one DMA piece behind each following MFMA
-            constexpr int I0V = (DS + 1) / 2;
-#pragma unroll
-            for (int i = 0; i < NM; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (2 * i + 2 <= DS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                else if (2 * i < DS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                else if (i - I0V < VM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using IDS = std::integral_constant<int, NDS>;
-        constexpr int NPH = (NP + 1) / 2;               // pieces [0, NPH) of a tap's weights are fetched during the LAST step of the tap
-        using IVA = std::integral_constant<int, NPH>;   //   two before it (its stage is free from that tap's barrier on), the others
-        using IVB = std::integral_constant<int, NP - NPH>;   // during the first step of the tap before it: a whole tap of MFMAs lies
-                                                        //   between the last DMA and the barrier that waits for it
-        if (nchunks > 0) {
-            issue_halo_buf(0);
-#pragma unroll
-            for (int i = 0; i < NP; ++i) issue_b_piece(i, 0, 0, 0);
+        for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (2 * i + 2 <= DS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else if (2 * i < DS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (i - I0V < VM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
-        int g = 0;                                      // taps done: weight stage of tap g is g & 1
-        for (int c = 0; c < nchunks; ++c) {
-            const int c0 = c * 64;
-            if (p.gn_ss != nullptr && tid < 128) ssl[tid] = p.gn_ss[((int64_t)n * p.Cin + c0) * 2 + tid];
-            __syncthreads();                            // vmcnt(0) + barrier: this chunk's halo (and its first weight stage) have landed
-        if (p.gn_ss != nullptr) {
-            // fused GroupNorm + swish: y = z * sigmoid(z), z = x * scale[c] + shift[c], applied in place to the halo tile
-            for (int q = tid; q < HROWS * 8; q += NTH) {
-                const int hp = q >> 3, cp = q & 7;
-                const int hy = hp / HW_, hx = hp - hy * HW_;
-                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                if ((unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) continue;   // padding stays zero
-                const int cg = cp ^ ((hp >> 1) & 7);                  // channel chunk stored at this position
-                uint4* ptr = reinterpret_cast<uint4*>(halo + hp * ROWB + cp * 16);
-                uint4 v = *ptr;
-                unsigned* pv = &v.x;
-                const float* sc = ssl + cg * 16;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float lo = swishf(fmaf(__uint_as_float(pv[k] << 16), sc[4 * k + 0], sc[4 * k + 1]));
-                    const float hi = swishf(fmaf(__uint_as_float(pv[k] & 0xffff0000u), sc[4 * k + 2], sc[4 * k + 3]));
-                    pv[k] = pack_bf16x2(lo, hi);
-                }
-                *ptr = v;
-            }
-            __syncthreads();
-        }
-            set_tap(0, g & 1);
-            load_frags(0, 0);
-            if (c == 0) {                               // first half of tap 1 (later chunks: issued by the previous chunk's last tap)
-#pragma unroll
-                for (int i = 0; i < NPH; ++i) issue_b_piece(i, 1, 0, 1);
-            }
-            auto tap_body = [&](int tap, auto last_tag) {
-                constexpr bool LAST = decltype(last_tag)::value;      // tap 8: what follows is the next chunk (or the epilogue)
-                const int buf = g & 1;
-                // taps g + 1 and g + 2 (past the last chunk: harmless re-fetches of chunk 0 into dead stages)
-                const int c0x = c + 1 < nchunks ? c0 + 64 : 0;
-                const int tap1 = LAST ? 0 : tap + 1, c01 = LAST ? c0x : c0;
-                const int tap2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9, c02 = tap + 2 < 9 ? c0 : c0x;
-                __builtin_amdgcn_sched_barrier(0);
-                load_frags(1, 1);
-#pragma unroll
-                for (int i = NPH; i < NP; ++i) issue_b_piece(i, tap1, c01, buf ^ 1);
-                mfma_step(0, IDS{}, IVB{});
-                load_frags(2, 0);
-                mfma_step(1, IDS{}, I0{});
-                load_frags(3, 1);
-                mfma_step(0, IDS{}, I0{});
-                // every wave has all its reads of this tap behind it and its share of the next tap's weights landed
-                __syncthreads();
-                if constexpr (!LAST) {
-                    set_tap(tap + 1, buf ^ 1);
-                    load_frags(0, 0);
-#pragma unroll
-                    for (int i = 0; i < NPH; ++i) issue_b_piece(i, tap2, c02, buf);
-                    mfma_step(1, IDS{}, IVA{});
-                } else {
-                    if (c + 1 < nchunks) {                         // (nothing may be in flight when the epilogue re-uses the LDS)
-                        issue_halo_buf(c0 + 64);                   // the halo tile is dead: refill it under the last MFMAs
-#pragma unroll
-                        for (int i = 0; i < NPH; ++i) issue_b_piece(i, tap2, c02, buf);
-                    }
-                    mfma_step(1, I0{}, I0{});
-                }
-                ++g;
-            };
-#pragma unroll 1
-            for (int tap = 0; tap < 8; ++tap) tap_body(tap, std::false_type{});
-            tap_body(8, std::true_type{});
-        }
-    } else {
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IDS = std::integral_constant<int, NDS>;
+    constexpr int NPH = (NP + 1) / 2;               // pieces [0, NPH) of a tap's weights are fetched during the LAST step of the tap
+    using IVA = std::integral_constant<int, NPH>;   //   two before it (its stage is free from that tap's barrier on), the others
+    using IVB = std::integral_constant<int, NP - NPH>;   // during the first step of the tap before it: a whole tap of MFMAs lies
+                                                    //   between the last DMA and the barrier that waits for it
+    int g = 0;                                      // taps done: weight stage of tap g is g & 1
     for (int c = 0; c < nchunks; ++c) {
         const int c0 = c * 64;
-        if (c == 0 || p.dbg != 3) issue_halo(c0);      // safe: the barrier that ended the previous chunk's last tap is behind us
-        issue_b(0, c0, 0);                             // (dbg 3 / 4: timing experiments -- halo of chunk 0 / weight stage 0 reused)
         if (p.gn_ss != nullptr && tid < 128) ssl[tid] = p.gn_ss[((int64_t)n * p.Cin + c0) * 2 + tid];
-        __syncthreads();                // vmcnt(0) + barrier: halo and first weight stage have landed
+        __syncthreads();                            // vmcnt(0) + barrier: this chunk's halo (and its first weight stage) have landed
         if (p.gn_ss != nullptr) {
             // fused GroupNorm + swish: y = z * sigmoid(z), z = x * scale[c] + shift[c], applied in place to the halo tile
             for (int q = tid; q < HROWS * 8; q += NTH) {
@@ -352,188 +272,237 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : NW == 4 ? 2 : 1) void conv3x
             }
             __syncthreads();
         }
-        for (int tap = 0; tap < 9; ++tap) {
-            const int buf = tap & 1;
-            if (tap + 1 < 9 && p.dbg != 4) issue_b(tap + 1, c0, buf ^ 1);
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const char* pa[MT];
-            int sa[MT];
+        set_tap(0, g & 1);
+        load_frags(0, 0);
+        if (c == 0) {                               // first half of tap 1 (later chunks: issued by the previous chunk's last tap)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int hp = (MT * wm + mt + kh) * HW_ + l31 + kw;
-                pa[mt] = halo + hp * ROWB;
-                sa[mt] = (hp >> 1) & 7;
-            }
-            const char* pb = bst + buf * BSTAGE + (wn * NT * 32 + l31) * ROWB;
-            // software-pipelined k-steps: the fragments of step ks+1 are requested before the MFMAs of step ks are issued
-            // (the compiler otherwise parks their ds_reads behind the MFMA group and waits on them right away)
-            bf16x8 a[2][MT], b[2][NT];
-            auto load_frags = [&](int ks, int slot) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    a[slot][mt] = *reinterpret_cast<const bf16x8*>(pa[mt] + (((ks * 2 + half) ^ sa[mt]) << 4));
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    b[slot][nt] = *reinterpret_cast<const bf16x8*>(pb + nt * 32 * ROWB + (((ks * 2 + half) ^ swzB) << 4));
-            };
-            load_frags(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks + 1 < 4) load_frags(ks + 1, (ks + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks & 1][nt], a[ks & 1][mt], acc[mt][nt], 0, 0, 0);   // (W X^T): channels on the register axis
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();
+            for (int i = 0; i < NPH; ++i) issue_b_piece(i, 1, 0, 1);
         }
+        auto tap_body = [&](int tap, auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;      // tap 8: what follows is the next chunk (or the epilogue)
+            const int buf = g & 1;
+            // taps g + 1 and g + 2 (past the last chunk: harmless re-fetches of chunk 0 into dead stages)
+            const int c0x = c + 1 < nchunks ? c0 + 64 : 0;
+            const int tap1 = LAST ? 0 : tap + 1, c01 = LAST ? c0x : c0;
+            const int tap2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9, c02 = tap + 2 < 9 ? c0 : c0x;
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(1, 1);
+#pragma unroll
+            for (int i = NPH; i < NP; ++i) issue_b_piece(i, tap1, c01, buf ^ 1);
+            mfma_step(0, IDS{}, IVB{});
+            load_frags(2, 0);
+            mfma_step(1, IDS{}, I0{});
+            load_frags(3, 1);
+            mfma_step(0, IDS{}, I0{});
+            // every wave has all its reads of this tap behind it and its share of the next tap's weights landed
+            __syncthreads();
+            if constexpr (!LAST) {
+                set_tap(tap + 1, buf ^ 1);
+                load_frags(0, 0);
+#pragma unroll
+                for (int i = 0; i < NPH; ++i) issue_b_piece(i, tap2, c02, buf);
+                mfma_step(1, IDS{}, IVA{});
+            } else {
+                if (c + 1 < nchunks) {                         // (nothing may be in flight when the epilogue re-uses the LDS)
+                    issue_halo_buf(c0 + 64);                   // the halo tile is dead: refill it under the last MFMAs
+#pragma unroll
+                    for (int i = 0; i < NPH; ++i) issue_b_piece(i, tap2, c02, buf);
+                }
+                mfma_step(1, I0{}, I0{});
+            }
+            ++g;
+        };
+#pragma unroll 1
+        for (int tap = 0; tap < 8; ++tap) tap_body(tap, std::false_type{});
+        tap_body(8, std::true_type{});
     }
 
-    }
-
-    // ---- epilogue: stage the 256 px x 128 co tile as bf16 rows of 256 B, then 16-byte global stores -----------
-    // (measured alternatives, all slower: 4-byte stores straight from the accumulators after a DPP lane-pair exchange;
-    //  staggering the first wave of workgroups so that epilogues and MFMA loops of CU neighbours interleave; 8 waves x
-    //  (1 x 4) tiles at 4 waves per SIMD -- 5 fragment reads per 4 MFMAs instead of 6 per 8 makes the loop LDS-bound.
-    //  DVQ_HALO_DBG=1/2 splits the time: at 128 -> 128 channels, 256^2, B=64 the MFMA loop takes 1.29 ms and this
-    //  epilogue 0.35 ms of 1.63 ms, i.e. they do not overlap across the two workgroups of a CU.)
+    // ---- epilogue: stage the 256 px x CO_T tile as bf16 rows, then 16-byte stores -------------------------------------------
+    // (measured alternatives, all slower: 4-byte stores straight from the accumulators after a DPP lane-pair exchange; 8 waves x
+    //  (1 x 4) tiles at 4 waves per SIMD -- 5 fragment reads per 4 MFMAs instead of 6 per 8 makes the loop LDS-bound.)
     if (p.dbg == 1) {
         if (acc[0][0][0] == 12345.678f) p.Y[0] = 0;       // keep the accumulators alive
         return;
     }
-    if (p.dbg == 5 && tid == 0 && (blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x / 2 + 1)) {   // shader clock during the main loop
-        const unsigned long long dc = __builtin_readcyclecounter() - dbg_c0, dw = wall_clock64() - dbg_w0;
-        printf("halo main loop of block %u: %llu shader cycles in %llu x 10 ns -> %.0f MHz\n", blockIdx.x, dc, dw, 100.0 * (double)dc / (double)dw);
+    if constexpr (TRACE) tr[1] = wall_clock64();
+    const bool act = p.act_slope != 1.f;
+    const bool early_act = act && (p.R == nullptr || p.res_mask);     // no residual add between the accumulator and the activation
+    // store loop roles: thread q = tid + 256 i handles 16-byte chunk ch = tid % CPRW of tile pixel lp = t + PPI * i, t = tid / CPRW
+    constexpr int ITERS = CPRW, PPI = NTH / CPRW;            // (256 pixels x CPRW chunks) / 256 threads; pixels per iteration
+    const int tq = tid / CPRW, ch = tid % CPRW;
+    const int trow = PPI == 64 ? tq >> 5 : 0, tcol = tq & 31;
+    const int col = n0 + ch * 8;
+    // per-image descriptors: lane offset fixed, the iteration's pixel step is the scalar offset
+    const int64_t img = (int64_t)n * p.H * p.W * p.Cout;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.Y + img, 0, p.H * p.W * p.Cout * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.R != nullptr ? p.R + img : p.Y + img), 0,
+                                                                         p.H * p.W * p.Cout * 2, 0x00020000);
+    const int vo_px = col < p.Cout ? ((trow * p.W + tcol) * p.Cout + col) * 2 : VOFF_OOB;
+    const int so_tile = ((y0 * p.W + x0) * p.Cout) * 2;
+    auto so_iter = [&](int i) {      // scalar byte offset of iteration i's pixel step
+        const int r = PPI == 16 ? (i >> 1) : PPI == 32 ? i : 2 * i, cc = PPI == 16 ? 16 * (i & 1) : 0;
+        return so_tile + ((r * p.W + cc) * p.Cout) * 2;
+    };
+    // residual / gate tile: requested before the staging so that its latency hides behind it
+    uint4 rpre[ITERS];
+    if (p.R != nullptr) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) rpre[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo_px, so_iter(i), 0));
     }
-    const bool early_act = p.R == nullptr || p.res_mask;     // no residual add between the accumulator and the activation
     // The MFMAs computed (W X^T): a lane holds ONE pixel (l31) and, in registers 4j .. 4j+3 of tile nt, the 4 consecutive output
-    // channels nt*32 + 8j + 4*half ..: packed pairs (v_cvt_pk_bf16_f32) and 8-byte LDS stores, 32 per lane instead of 128
-    // 2-byte ones.  Staged rows are unpadded (CO_T * 2 bytes); 16-byte chunk c of pixel row lp sits at position c ^ swz(lp) so
-    // that both the column-wise 8-byte stores here and the row-wise 16-byte reads below are bank-conflict free.
-    constexpr int SWZ_SH = CPRW == 16 ? 0 : CPRW == 8 ? 1 : 2;
-    load_residual();        // (requesting it under the MFMAs of the last k-step does not fit the registers: measured, no gain)
+    // channels nt*32 + 8j + 4*half ..: packed pairs (v_cvt_pk_bf16_f32) and 8-byte LDS stores, 32 per lane.  16-byte chunk c of pixel
+    // row lp sits at position c ^ swz(lp): both the column-wise 8-byte stores here and the row-wise 16-byte reads below are
+    // conflict free, and swz(lp) only depends on the lane -- the chunk index enters as an XOR with a compile-time constant
+    {
+        const int cst = (l31 >> SWZ_SH) & (CPRW - 1);
+        const int lane_st = (MT * wm * 32 + l31) * ROWS + cst * 16 + half * 8;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int lc = (wn * NT + nt) * 32 + 8 * j + 4 * half;      // first of this lane's 4 channels
-            const float4 bq = *reinterpret_cast<const float4*>(sbias + lc);
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int lp = (MT * wm + mt) * 32 + l31;
-                float v0 = acc[mt][nt][4 * j] + bq.x, v1 = acc[mt][nt][4 * j + 1] + bq.y;
-                float v2 = acc[mt][nt][4 * j + 2] + bq.z, v3 = acc[mt][nt][4 * j + 3] + bq.w;
-                if (early_act) {
-                    v0 = v0 > 0.f ? v0 : v0 * p.act_slope;
-                    v1 = v1 > 0.f ? v1 : v1 * p.act_slope;
-                    v2 = v2 > 0.f ? v2 : v2 * p.act_slope;
-                    v3 = v3 > 0.f ? v3 : v3 * p.act_slope;
+                for (int mt = 0; mt < MT; ++mt) {
+                    float v0 = acc[mt][nt][4 * j], v1 = acc[mt][nt][4 * j + 1], v2 = acc[mt][nt][4 * j + 2], v3 = acc[mt][nt][4 * j + 3];
+                    if (early_act) {
+                        v0 = v0 > 0.f ? v0 : v0 * p.act_slope;
+                        v1 = v1 > 0.f ? v1 : v1 * p.act_slope;
+                        v2 = v2 > 0.f ? v2 : v2 * p.act_slope;
+                        v3 = v3 > 0.f ? v3 : v3 * p.act_slope;
+                    }
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v0, v1);
+                    pk.y = pack_bf16x2(v2, v3);
+                    *reinterpret_cast<uint2*>(smem + ((lane_st ^ ((nt * 4 + j) << 4)) + mt * 32 * ROWS)) = pk;
                 }
-                const int chunk = ((wn * NT + nt) * 4 + j) ^ ((lp >> SWZ_SH) & (CPRW - 1));
-                uint2 pk;
-                pk.x = pack_bf16x2(v0, v1);
-                pk.y = pack_bf16x2(v2, v3);
-                *reinterpret_cast<uint2*>(smem + lp * (CO_T * 2) + chunk * 16 + half * 8) = pk;
             }
         }
     }
     // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. make every wave wait for ALL of its residual loads before
     // the first row may be stored; this way each store waits for its own load only
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
-    float gs[8], gq[8];                 // output statistics of this thread's 8 channels (chunk tid & 15 in every iteration)
+    if constexpr (TRACE) tr[2] = wall_clock64();
+    const int cpg = p.out_stats != nullptr ? p.Cout / p.out_groups : 0;     // channels per group: power of two <= 32 (launcher)
+    const bool pairs = cpg >= 2 && p.dbg != 8;        // statistics per channel PAIR (v_dot2_f32_bf16: one instruction per dword and moment)
+    float gs[8], gq[8];                 // output statistics of this thread's 8 channels / 4 pairs (chunk ch in every iteration)
 #pragma unroll
     for (int k = 0; k < 8; ++k) gs[k] = gq[k] = 0.f;
+    {
+        const char* lane_ld = smem + tq * ROWS + ((ch ^ ((tq >> SWZ_SH) & (CPRW - 1))) << 4);
+        const dvq_bf16x2 ones = __builtin_bit_cast(dvq_bf16x2, 0x3f803f80u);
 #pragma unroll
-    for (int i = 0; i < ITERS; ++i) {
-        const int q = tid + NTH * i;
-        const int lp = q / CPRW, ch = q % CPRW;
-        const int col = n0 + ch * 8;
-        if (col >= p.Cout) continue;
-        uint4 v = *reinterpret_cast<const uint4*>(smem + lp * (CO_T * 2) + ((ch ^ ((lp >> SWZ_SH) & (CPRW - 1))) << 4));
-        const int64_t o = ((img + (int64_t)(y0 + (lp >> 5)) * p.W + x0 + (lp & 31)) * p.Cout) + col;
-        if (p.R) {
-            const uint4 rv = rpre[i];
-            unsigned* pv = &v.x;
-            const unsigned* pr = &rv.x;
+        for (int i = 0; i < ITERS; ++i) {
+            uint4 v = *reinterpret_cast<const uint4*>(lane_ld + i * (PPI * ROWS));
+            if (p.R != nullptr) {
+                const uint4 rv = rpre[i];
+                unsigned* pv = &v.x;
+                const unsigned* pr = &rv.x;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float lo = __uint_as_float(pv[k] << 16), hi = __uint_as_float(pv[k] & 0xffff0000u);
-                const float rlo = __uint_as_float(pr[k] << 16), rhi = __uint_as_float(pr[k] & 0xffff0000u);
-                if (p.res_mask) {
-                    lo *= rlo > 0.f ? 1.f : p.mask_slope;
-                    hi *= rhi > 0.f ? 1.f : p.mask_slope;
-                } else {
-                    lo += rlo;
-                    hi += rhi;
-                    lo = lo > 0.f ? lo : lo * p.act_slope;
-                    hi = hi > 0.f ? hi : hi * p.act_slope;
+                for (int k = 0; k < 4; ++k) {
+                    float lo = __uint_as_float(pv[k] << 16), hi = __uint_as_float(pv[k] & 0xffff0000u);
+                    const float rlo = __uint_as_float(pr[k] << 16), rhi = __uint_as_float(pr[k] & 0xffff0000u);
+                    if (p.res_mask) {
+                        lo *= rlo > 0.f ? 1.f : p.mask_slope;
+                        hi *= rhi > 0.f ? 1.f : p.mask_slope;
+                    } else {
+                        lo += rlo;
+                        hi += rhi;
+                        if (act) {
+                            lo = lo > 0.f ? lo : lo * p.act_slope;
+                            hi = hi > 0.f ? hi : hi * p.act_slope;
+                        }
+                    }
+                    pv[k] = pack_bf16x2(lo, hi);
                 }
-                pv[k] = pack_bf16x2(lo, hi);
             }
-        }
-        *reinterpret_cast<uint4*>(p.Y + o) = v;
-        if (p.out_stats != nullptr) {
-            const unsigned* pv = &v.x;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvq_u32x4, v), rsY, vo_px, so_iter(i), 0);
+            if (p.out_stats != nullptr) {
+                const unsigned* pv = &v.x;
+                if (pairs) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float lo = __uint_as_float(pv[k] << 16), hi = __uint_as_float(pv[k] & 0xffff0000u);
-                gs[2 * k] += lo;
-                gq[2 * k] = fmaf(lo, lo, gq[2 * k]);
-                gs[2 * k + 1] += hi;
-                gq[2 * k + 1] = fmaf(hi, hi, gq[2 * k + 1]);
+                    for (int k = 0; k < 4; ++k) {
+                        const dvq_bf16x2 pr2 = __builtin_bit_cast(dvq_bf16x2, pv[k]);
+                        gs[k] = __builtin_amdgcn_fdot2_f32_bf16(pr2, ones, gs[k], false);
+                        gq[k] = __builtin_amdgcn_fdot2_f32_bf16(pr2, pr2, gq[k], false);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lo = __uint_as_float(pv[k] << 16), hi = __uint_as_float(pv[k] & 0xffff0000u);
+                        gs[2 * k] += lo;
+                        gq[2 * k] = fmaf(lo, lo, gq[2 * k]);
+                        gs[2 * k + 1] += hi;
+                        gq[2 * k + 1] = fmaf(hi, hi, gq[2 * k + 1]);
+                    }
+                }
             }
         }
     }
+    if constexpr (TRACE) tr[3] = wall_clock64();
     if (p.out_stats != nullptr) {
         // lanes l, l + CPRW, l + 2 CPRW, ... of a wave hold partials of the same 8 channels: fold them with shuffles, park one
-        // row per wave in LDS, add the NW rows per channel, fold the channels of a group (a power of two, lanes adjacent)
+        // row per wave in LDS, add the NW rows per channel (or pair), fold the channels of a group (a power of two, lanes adjacent)
+        const int nval = pairs ? 4 : 8;         // values per thread and moment; a staged column index is ch * nval + k
+        const int ncol = CO_T / 8 * nval;       // columns (channels or pairs) of the tile
 #pragma unroll
         for (int off = CPRW; off < 64; off <<= 1)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                gs[k] += __shfl_xor(gs[k], off, 64);
-                gq[k] += __shfl_xor(gq[k], off, 64);
+                if (k < nval) {
+                    gs[k] += __shfl_xor(gs[k], off, 64);
+                    gq[k] += __shfl_xor(gq[k], off, 64);
+                }
             }
         // LDS-only barriers: __syncthreads() would also wait for this wave's global STORES of the tile (vmcnt(0), a round trip to
         // L2) before the statistics may proceed
         auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory"); };
         lds_barrier();                                          // the staged output tile has been consumed
-        float* red = reinterpret_cast<float*>(smem);            // [NW][CO_T][2]
+        float* red = reinterpret_cast<float*>(smem);            // [NW][ncol][2]
         if (lane < CPRW) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                red[((wave * CO_T) + lane * 8 + k) * 2] = gs[k];
-                red[((wave * CO_T) + lane * 8 + k) * 2 + 1] = gq[k];
-            }
+            for (int k = 0; k < 8; ++k)
+                if (k < nval) {
+                    red[((wave * ncol) + lane * nval + k) * 2] = gs[k];
+                    red[((wave * ncol) + lane * nval + k) * 2 + 1] = gq[k];
+                }
         }
         lds_barrier();
-        if (tid < CO_T) {
+        if (tid < ncol) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                s1 += red[(w * CO_T + tid) * 2];
-                s2 += red[(w * CO_T + tid) * 2 + 1];
+                s1 += red[(w * ncol + tid) * 2];
+                s2 += red[(w * ncol + tid) * 2 + 1];
             }
-            const int cpg = p.Cout / p.out_groups;              // channels per group: power of two <= 32 (launcher)
-            for (int off = 1; off < cpg; off <<= 1) {
+            const int cpl = pairs ? 2 : 1;                      // channels per column
+            for (int off = 1; off * cpl < cpg; off <<= 1) {
                 s1 += __shfl_xor(s1, off, 64);
                 s2 += __shfl_xor(s2, off, 64);
             }
-            if ((tid & (cpg - 1)) == 0 && n0 + tid < p.Cout) {
-                const int g = (n0 + tid) / cpg;
+            const int c0ch = tid * cpl;                         // first channel of this column
+            if ((c0ch & (cpg - 1)) == 0 && n0 + c0ch < p.Cout) {
+                const int gg = (n0 + c0ch) / cpg;
                 if (p.stat_part != nullptr) {
                     const int ntiles = p.tiles_y * p.tiles_x;
-                    float* dst = p.stat_part + ((((int64_t)n * p.out_groups + g) * ntiles) + ty * p.tiles_x + tx) * 2;
+                    float* dst = p.stat_part + ((((int64_t)n * p.out_groups + gg) * ntiles) + ty * p.tiles_x + tx) * 2;
                     dst[0] = s1;
                     dst[1] = s2;
                 } else {
-                    atomicAdd(&p.out_stats[((int64_t)n * p.out_groups + g) * 2], (double)s1);
-                    atomicAdd(&p.out_stats[((int64_t)n * p.out_groups + g) * 2 + 1], (double)s2);
+                    atomicAdd(&p.out_stats[((int64_t)n * p.out_groups + gg) * 2], (double)s1);
+                    atomicAdd(&p.out_stats[((int64_t)n * p.out_groups + gg) * 2 + 1], (double)s2);
                 }
             }
+        }
+    }
+    if constexpr (TRACE) {
+        if (tid == 0 && blockIdx.x < HALO_TRACE_MAX) {
+            tr[4] = wall_clock64();
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");            // the tile's stores have been acknowledged
+            g_halo_trace[blockIdx.x][0] = tr_key | (tr[4] << 16);
+            g_halo_trace[blockIdx.x][1] = tr[0];
+            g_halo_trace[blockIdx.x][2] = tr[1];
+            g_halo_trace[blockIdx.x][3] = wall_clock64();
+            g_halo_trace[blockIdx.x][4] = tr[2];
+            g_halo_trace[blockIdx.x][5] = tr[3];
         }
     }
 #endif
@@ -557,6 +526,16 @@ __global__ __launch_bounds__(64) void halo_stats_finalize_kernel(const float* __
 }
 
 }  // namespace
+
+extern "C" int dvq_halo_trace_read(unsigned long long* dst, int64_t max_records) {
+    DVQ_REQUIRE(dst != nullptr && max_records > 0, DVQ_EINVAL, "dvq_halo_trace_read: bad arguments");
+    const int64_t n = max_records < HALO_TRACE_MAX ? max_records : HALO_TRACE_MAX;
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_halo_trace), (size_t)n * 6 * sizeof(unsigned long long)) != hipSuccess) {
+        dvq_set_error("dvq_halo_trace_read: copy failed");
+        return DVQ_ELAUNCH;
+    }
+    return DVQ_OK;
+}
 
 // Returns 1 if the halo kernel handled the call, 0 if the shape is not eligible (caller falls back to igemm),
 // negative on error.  x: [N,H,W,Cin] bf16; w: rows of [9][Cin]; y: [N,H,W,Cout].
@@ -593,45 +572,22 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     }
     const int64_t blocks = N * p.tiles_y * p.tiles_x * p.gn;
     if (blocks >= (1ll << 31)) return 0;
-    static const int nw_env = [] {
-        const char* e = getenv("DVQ_HALO_WAVES");
-        return e != nullptr ? atoi(e) : 0;
-    }();
-    static const int pipe_env = [] {
-        const char* e = getenv("DVQ_HALO_PIPE");
-        return e != nullptr ? atoi(e) : 1;
-    }();
-    if (nw_env == 8 && cot == 128) {   // experiment: 8 waves x (2 x 2 tiles), four waves per SIMD
-        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<8, 2, 2>, LDSB);
-        conv3x3_halo_kernel<8, 2, 2><<<dim3((unsigned)blocks), dim3(512), LDSB, stream>>>(p);
-    } else if (nw_env == 2 && cot == 128) {   // experiment: 2 waves x (4 x 4 tiles), 1 wave per SIMD: 2x slower un-pipelined
-        if (pipe_env != 0) {
-            dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<2, 4, 1, true>, LDSB);
-            conv3x3_halo_kernel<2, 4, 1, true><<<dim3((unsigned)blocks), dim3(128), LDSB, stream>>>(p);
-        } else {
-            dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<2, 4>, LDSB);
-            conv3x3_halo_kernel<2, 4><<<dim3((unsigned)blocks), dim3(128), LDSB, stream>>>(p);
-        }
-    } else if (pipe_env == 0) {        // DVQ_HALO_PIPE=0: the un-pipelined main loop (A/B timing)
-        if (cot == 128) {
-            dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 4>, LDSB);
-            conv3x3_halo_kernel<4, 4><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
-        } else if (cot == 64) {
-            dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 2>, LDSB);
-            conv3x3_halo_kernel<4, 2><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
-        } else {
-            dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 1>, LDSB);
-            conv3x3_halo_kernel<4, 1><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
-        }
-    } else if (cot == 128) {
-        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 4, 1, true>, LDSB);
-        conv3x3_halo_kernel<4, 4, 1, true><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+    auto magic = [](int64_t d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); };
+    const int64_t dmax = p.gn > p.tiles_x ? (p.gn > p.tiles_y ? p.gn : p.tiles_y) : (p.tiles_x > p.tiles_y ? p.tiles_x : p.tiles_y);
+    if (blocks * dmax >= (1ll << 32)) return 0;        // (exactness range of the scalar tile decode)
+    p.nblocks = (int)blocks;
+    p.mg_gn = magic(p.gn); p.mg_tx = magic(p.tiles_x); p.mg_ty = magic(p.tiles_y);
+    auto go = [&](auto kern) {
+        dvq_ensure_dynamic_lds((const void*)kern, LDSB);
+        kern<<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+    };
+    if (cot == 128) {
+        if (p.dbg == 6) go(conv3x3_halo_kernel<4, true>);
+        else go(conv3x3_halo_kernel<4>);
     } else if (cot == 64) {
-        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 2, 1, true>, LDSB);
-        conv3x3_halo_kernel<4, 2, 1, true><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+        go(conv3x3_halo_kernel<2>);
     } else {
-        dvq_ensure_dynamic_lds((const void*)conv3x3_halo_kernel<4, 1, 1, true>, LDSB);
-        conv3x3_halo_kernel<4, 1, 1, true><<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+        go(conv3x3_halo_kernel<1>);
     }
     if (p.stat_part != nullptr)
         halo_stats_finalize_kernel<<<dim3((unsigned)(N * out_groups)), dim3(64), 0, stream>>>(p.stat_part, ntiles, out_stats);

@@ -56,6 +56,7 @@ void* dvq_workspace_stream(hipStream_t stream, int64_t* bytes);
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 
 // round-to-nearest-even: gfx950's v_cvt_pk_bf16_f32 (one instruction per pair instead of ~6 integer ops per element)
+typedef __attribute__((ext_vector_type(4))) unsigned dvq_u32x4;      // payload type of the raw buffer load / store builtins
 typedef __attribute__((ext_vector_type(2))) float dvq_f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 dvq_bf16x2;
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ mean_rstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, double* __restrict__ red,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sA = reinterpret_cast<float*>(smem);   // [C] sum dz
     float* sB = sA + C;                            // [C] sum dz*xhat
@@ -176,6 +177,14 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
         }
     }
     __syncthreads();
+    if (part != nullptr) {
+        // per-block partials, folded by gn_bwd_finalize_kernel: with thousands of blocks adding into the same C + 2 G addresses the
+        // serial chains of memory-side atomics, not the two tensor reads, set this kernel's time (3.7 TB/s against 5.1 for its
+        // siblings)
+        float* dst = part + ((int64_t)n * gridDim.x + blockIdx.x) * 2 * C;
+        for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = sA[i];
+        return;
+    }
     for (int c = threadIdx.x; c < C; c += 256) {
         atomicAdd(&dbeta[c], sA[c]);
         atomicAdd(&dgamma[c], sB[c]);
@@ -189,6 +198,40 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
         atomicAdd(&red[(n * G + g) * 2], s1);
         atomicAdd(&red[(n * G + g) * 2 + 1], s2);
     }
+}
+
+// folds gn_bwd_reduce_kernel's per-block partials part[n][nb][2][C]: block (x = 32-channel slice, y = n); 4 row groups x
+// (32 channels x {sum dz, sum dz*xhat}); -> red[n][g] (+=, one writer), dgamma / dbeta (one atomic per image and channel)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, int nb, int64_t C, int G,
+                                                              const float* __restrict__ gamma, double* __restrict__ red,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double sm[4][64];
+    const int64_t n = blockIdx.y;
+    const int rg = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int ab = l >> 5, c = blockIdx.x * 32 + (l & 31);        // ab: 0 = sum dz (dbeta), 1 = sum dz*xhat (dgamma)
+    // fp64 across the blocks, like the atomics it replaces: BatchNorm's backward subtracts the mean of a nearly constant gradient
+    double acc = 0.0;
+    if (c < C) {
+        const float* src = part + (int64_t)n * nb * 2 * C + ab * C + c;
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
+        int b = rg;
+        for (; b + 12 < nb; b += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4[u] += (double)src[(int64_t)(b + 4 * u) * 2 * C];
+        }
+        for (; b < nb; b += 4) a4[0] += (double)src[(int64_t)b * 2 * C];
+        acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    }
+    sm[rg][l] = acc;
+    __syncthreads();
+    if (rg != 0) return;
+    const double v = (sm[0][l] + sm[1][l]) + (sm[2][l] + sm[3][l]);
+    if (c < C) atomicAdd(ab ? &dgamma[c] : &dbeta[c], (float)v);
+    // group sums: gamma-weighted over the cpg (power of two <= 32, launcher) adjacent channels of a group
+    const int cpg = (int)(C / G);
+    double w = c < C ? (double)gamma[c] * v : 0.0;
+    for (int off = 1; off < cpg; off <<= 1) w += __shfl_xor(w, off, 64);
+    if (c < C && (c & (cpg - 1)) == 0) red[(n * G + c / cpg) * 2 + ab] += w;
 }
 
 template <typename T, int ACT>
@@ -306,17 +349,27 @@ int dvq_gn_apply(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int
     return DVQ_OK;
 }
 
+size_t dvq_gn_bwd_partial_bytes(int64_t N, int64_t HW, int64_t C) {
+    return (size_t)(N * cdiv64(HW, gn_rows_per_block(HW)) * 2 * C * (int64_t)sizeof(float));
+}
+
 int dvq_gn_bwd_reduce(const void* x, const void* dy, int dtype, int64_t N, int64_t HW, int64_t C, int G,
                       const float* mean_rstd, const float* gamma, const float* beta, int silu, double* red,
-                      float* dgamma, float* dbeta, dvq_stream_t stream) {
+                      float* dgamma, float* dbeta, float* partials, dvq_stream_t stream) {
     DVQ_REQUIRE(x && dy && mean_rstd && gamma && beta && red && dgamma && dbeta, DVQ_EINVAL,
                 "dvq_gn_bwd_reduce: null pointer");
     if (int e = gn_check("dvq_gn_bwd_reduce", N, HW, C, G)) return e;
     dim3 grid((unsigned)cdiv64(HW, gn_rows_per_block(HW)), (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
     size_t lds = 2 * C * sizeof(float);
-    DVQ_DISPATCH_DTYPE(dtype, T, GN_ACT_SWITCH(gn_bwd_reduce_kernel, lds, (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, dgamma, dbeta));
+    const int64_t cpg = C / G;
+    if (partials != nullptr && ((cpg & (cpg - 1)) != 0 || cpg > 32)) partials = nullptr;      // (the finalize kernel folds a group inside a wave)
+    DVQ_DISPATCH_DTYPE(dtype, T, GN_ACT_SWITCH(gn_bwd_reduce_kernel, lds, (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, dgamma, dbeta, partials));
     DVQ_CHECK_LAUNCH("gn_bwd_reduce");
+    if (partials != nullptr) {
+        gn_bwd_finalize_kernel<<<dim3((unsigned)cdiv64(C, 32), (unsigned)N), dim3(256), 0, s>>>(partials, (int)grid.x, C, G, gamma, red, dgamma, dbeta);
+        DVQ_CHECK_LAUNCH("gn_bwd_finalize");
+    }
     return DVQ_OK;
 }
 

@@ -122,10 +122,13 @@ int dvq_gn_stats(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int
 int dvq_gn_apply(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int G, float eps, const double* stats,
                  const float* gamma, const float* beta, int silu, void* y, float* mean_rstd, dvq_stream_t stream);
 /* backward pass 1: red fp64 [N,G,2] (zeroed) += (sum dz*gamma, sum dz*gamma*xhat); dgamma/dbeta fp32 [C] += .
+ * `partials` (may be NULL): caller-owned scratch of dvq_gn_bwd_partial_bytes(N, HW, C) bytes -- every block then stores its
+ * sums there and a fold kernel adds them up (no same-address atomic chains); NULL = atomics straight into red / dgamma / dbeta.
  * backward pass 2: dx.  dy: grad w.r.t. y. */
+size_t dvq_gn_bwd_partial_bytes(int64_t N, int64_t HW, int64_t C);
 int dvq_gn_bwd_reduce(const void* x, const void* dy, int dtype, int64_t N, int64_t HW, int64_t C, int G,
                       const float* mean_rstd, const float* gamma, const float* beta, int silu, double* red,
-                      float* dgamma, float* dbeta, dvq_stream_t stream);
+                      float* dgamma, float* dbeta, float* partials, dvq_stream_t stream);
 /* addend (may be NULL): a tensor like dx that is added to the result (gradient of a joining residual branch) */
 int dvq_gn_bwd_dx(const void* x, const void* dy, int dtype, int64_t N, int64_t HW, int64_t C, int G,
                   const float* mean_rstd, const float* gamma, const float* beta, int silu, const double* red,
@@ -232,6 +235,9 @@ int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred,
 /* Register a caller-owned device scratch buffer (one per process, used stream-ordered on the caller's stream).  With
  * >= 76 MiB registered the split-K weight-gradient kernels store per-workgroup partial tiles with plain writes and fold
  * them in a second kernel instead of issuing cross-XCD fp32 atomics.  ptr = NULL, bytes = 0 unregisters. */
+/* diagnostics (DVQ_HALO_DBG=6): per workgroup of the LAST 3x3 halo-conv launch {CU key | (time before the final store drain) << 16,
+ * start, end of the main loop, end, tile staged, tile stored} in 10-ns ticks; dst holds max_records x 6 uint64.  Synchronises. */
+int dvq_halo_trace_read(unsigned long long* dst, int64_t max_records);
 int dvq_set_workspace(void* ptr, int64_t bytes);
 
 /* ---- loss networks (LPIPS + PatchGAN), modules/losses/lpips.py, modules/discriminator/model.py -------------------

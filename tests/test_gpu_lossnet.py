@@ -235,6 +235,9 @@ def test_adaptive_weight_bf16_vs_fp32_full_width(dev):
     # measured on MI355X: nll-gradient norm 0.35 %, GAN-gradient norm 5.6 %, d_weight 5.0 %, loss 0.75 %.
     # The GAN branch is the sensitive one: d(-mean D(xrec)) / d logits is a CONSTANT map, so after the last conv the gradient is
     # nearly constant per channel and BatchNorm's backward subtracts its mean -- what is left is a small residual of values that
-    # were stored as bf16.  Bounds = 1.5x the measurement.
-    assert rel["nll"] <= 1e-2 and rel["g"] <= 8e-2 and rel["d_weight"] <= 8e-2, (rel, a, b)
+    # were stored as bf16.  That residual is rounding noise: three bit-different but equally exact builds of the same kernels (bias
+    # added after / before the reduction, GroupNorm statistics per channel / per channel pair) gave 5.6 %, 12.7 % and 15.1 % for the
+    # GAN-gradient norm at an unchanged 0.13 - 0.35 % for the nll-gradient norm.  Bounds: 1.5x the largest of them for the two
+    # noise-dominated numbers, 1.5x the measurement elsewhere.
+    assert rel["nll"] <= 6e-3 and rel["g"] <= 0.23 and rel["d_weight"] <= 0.2, (rel, a, b)
     assert rel["loss"] <= 2e-2 and rel["p"] <= 1e-2, (rel, a, b)

@@ -129,6 +129,25 @@ def run(rank, world, opt, unknown):
     model.min_learning_rate = config.model.get("min_learning_rate", 0.)
 
     size = config.model.params.get("image_size", 256)
+    real_iter = None
+    if opt.real_data:
+        # the YAML's own `data:` section through the plugin boundary: host threads decode, resize / crop / flip / normalise run
+        # on the GPU (dynamicvectorquantization_amd/data.py); each rank shuffles with its own seed (weak scaling, bs per GPU).
+        # Built BEFORE the Trainer: configure_optimizers() bakes steps_per_epoch / training_steps into the LR schedules
+        config.data.params["device"] = str(dev)
+        config.data.params["size"] = size
+        dm = cfg.instantiate_from_config(config.data)
+        loader = dm.train_dataloader()
+        loader.rng = __import__("numpy").random.default_rng(opt.seed + 977 * rank)
+        opt.steps_per_epoch = model.steps_per_epoch = len(loader)
+        model.training_steps = len(loader) * opt.max_epochs
+
+        def _batches():
+            while True:
+                for b in loader:
+                    yield {k: v for k, v in b.items() if torch.is_tensor(v)}      # strings (paths, synsets) stay on the host side
+        real_iter = _batches()
+
     total = model.training_steps if opt.max_steps < 0 else min(opt.max_steps, model.training_steps)
     trainer = Trainer(model, max_steps=total, log_every=10 if rank == 0 else 0)
     pool = [torch.from_numpy(synth.half_flat_images(bs, size, seed=opt.seed + 977 * rank + i)).to(dev) for i in range(4)]
@@ -137,26 +156,6 @@ def run(rank, world, opt, unknown):
     n_classes = None
     if getattr(model, "cond_stage_key", None) == "class_label":         # class-conditional stage 2: synthetic labels
         n_classes = int(getattr(model.cond_stage_model, "n_classes", 1000))
-
-    real_iter = None
-    if opt.real_data:
-        # the YAML's own `data:` section through the plugin boundary: host threads decode, resize / crop / flip / normalise run
-        # on the GPU (dynamicvectorquantization_amd/data.py); each rank shuffles with its own seed (weak scaling, bs per GPU)
-        config.data.params["device"] = str(dev)
-        config.data.params["size"] = size
-        dm = cfg.instantiate_from_config(config.data)
-        loader = dm.train_dataloader()
-        loader.rng = __import__("numpy").random.default_rng(opt.seed + 977 * rank)
-        opt.steps_per_epoch = model.steps_per_epoch = len(loader)
-        model.training_steps = len(loader) * opt.max_epochs
-        total = model.training_steps if opt.max_steps < 0 else min(opt.max_steps, model.training_steps)
-        trainer.max_steps = total
-
-        def _batches():
-            while True:
-                for b in loader:
-                    yield {k: v for k, v in b.items() if torch.is_tensor(v)}      # strings (paths, synsets) stay on the host side
-        real_iter = _batches()
 
     def batch_fn(step):
         model.current_epoch = step // opt.steps_per_epoch
