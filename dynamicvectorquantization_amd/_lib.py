@@ -101,8 +101,6 @@ SIGNATURES = {
     "dvq_embed_scatter_add": (i32, [vp, i64, vp, i32, i64, i64, i64, i64, i64, i64, i64, vp, vp]),
     "dvq_cross_entropy": (i32, [vp, i32, i64, i64, i64, vp, i64, vp, vp, vp, vp, vp]),
     "dvq_attn_decode": (i32, [vp, vp, vp, i32, i64, i64, i64, i64, i64, f32, vp, vp]),
-    "dvq_blaslt_available": (i32, []),
-    "dvq_gemm_nn_lib": (i32, [vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, vp]),
     "dvq_attn_causal_scratch_bytes": (i64, [i64, i64, i32, i32, i32]),
     "dvq_attn_causal_fwd": (i32, [vp, vp, vp, i32, i64, i64, i32, i32, f32, f32, C.c_uint64, vp, vp, vp, vp]),
     "dvq_attn_causal_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i64, i32, i32, f32, f32, C.c_uint64, vp, vp, vp, vp, vp]),

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdvq_hip.so")
-SOURCES = ["vq.hip", "entropy.hip", "groupnorm.hip", "igemm.hip", "conv_halo.hip", "misc.hip", "lossnet.hip", "router.hip", "permuter.hip", "transformer.hip", "attention.hip", "blaslt.hip", "imgproc.hip"]
+SOURCES = ["vq.hip", "entropy.hip", "groupnorm.hip", "igemm.hip", "conv_halo.hip", "misc.hip", "lossnet.hip", "router.hip", "permuter.hip", "transformer.hip", "attention.hip", "imgproc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
@@ -58,7 +58,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 if verbose:
                     print("[dvq build] compiled", os.path.basename(done), flush=True)
     if jobs or force or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
         if verbose:
             print("[dvq build] linked", LIB, flush=True)
     return LIB

@@ -2216,9 +2216,6 @@ int dvq_conv3x3_thin_k_try(const void* x, const void* w, const float* bias, void
 int dvq_tconv4x4s2_thin_try(const void* dy, const void* wt, void* dx, int64_t N, int64_t OH, int64_t OW, int64_t Cout, int creal,
                             hipStream_t stream);
 
-int dvq_blaslt_gemm_nt_try(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                           int64_t ldc, float alpha, const float* bias, hipStream_t stream);
-
 static float act_slope_of(int act) { return act == DVQ_ACT_RELU ? 0.f : act == DVQ_ACT_LRELU ? 0.2f : 1.f; }
 
 static bool halo_eligible(const dvq_conv_desc* d) {
@@ -2405,12 +2402,6 @@ int dvq_gemm_nt(const void* A, const void* B, void* C, int dtype, int64_t M, int
     DVQ_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535 && M < (1ll << 31) && N < (1ll << 31), DVQ_ESHAPE,
                 "dvq_gemm_nt: bad shape");
     DVQ_REQUIRE(bias_mode == 0 || bias != nullptr, DVQ_EINVAL, "dvq_gemm_nt: bias_mode without bias");
-    if (dtype == DVQ_BF16 && impl == 0 && batch == 1 && bias_mode != 2 && M >= 1024 && N >= 256 && K >= 256 && lda % 8 == 0 &&
-        ldb % 8 == 0 && ldc % 8 == 0 && N % 8 == 0 && K % 8 == 0) {
-        // large plain (bias-only) product: library GEMM when hipBLASLt is present (blaslt.hip); otherwise the kernel below
-        if (dvq_blaslt_gemm_nt_try(A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_mode == 1 ? bias : nullptr, (hipStream_t)stream) == 1)
-            return DVQ_OK;
-    }
     NtParams p{};
     p.A = A; p.B = B; p.C = C; p.R = nullptr; p.bias = bias;
     p.mode = MODE_GEMM;

@@ -527,14 +527,6 @@ def gemm_tn(a, b, mred, i, j, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, out=None
     return out
 
 
-def gemm_nn_lib(dy, w, m, n, k):
-    """dx [m, n] = dy [m, k] @ w [k, n] with w as stored (library NN product, csrc/blaslt.hip); None if the library declines"""
-    dx = torch.empty(m, n, dtype=dy.dtype, device=dy.device)
-    rc = _timed("gemm_nn_lib", 2 * m * n * k, dy.element_size() * (m * k + n * k + m * n), lambda: lib().dvq_gemm_nn_lib(
-        _p(dy), _p(w), _p(dx), dt(dy), m, n, k, k, n, n, _s()))
-    return dx if rc == 0 else None
-
-
 def softmax_rows(s, rows, length, scale):
     p = torch.empty_like(s)
     check(lib().dvq_softmax_rows(_p(s), dt(s), rows, length, scale, _p(p), _s()), "dvq_softmax_rows")

@@ -103,9 +103,27 @@ class _ModuleFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
+class _SiluFn(torch.autograd.Function):
+    """x * sigmoid(x) on dvq_silu / dvq_silu_bwd (any shape, fp32 or bf16 device tensor; other dtypes are computed in fp32)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        xin = x.contiguous()
+        xc = xin if xin.dtype in (torch.float32, torch.bfloat16) else xin.float()
+        ctx.save_for_backward(xc)
+        ctx.in_dtype = x.dtype
+        return K.silu(xc).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        return K.silu_bwd(xc, dy.contiguous().to(xc.dtype)).to(ctx.in_dtype)
+
+
 def nonlinearity(x):
-    """swish (model.py:29-31) -- only reachable fused with GroupNorm on the HIP path"""
-    raise NotImplementedError("nonlinearity() is fused into Normalize.fwd(silu=True) on the HIP path")
+    """swish (model.py:29-31) as a standalone differentiable op for reference-side callers; inside the blocks of this package it is
+    fused into Normalize.fwd(silu=True) and never launched on its own"""
+    return _SiluFn.apply(x)
 
 
 class Normalize(HipModule):
@@ -211,12 +229,6 @@ class Linear(nn.Module):
                 _grad_buf(self.bias).add_(db[: self.out_features])
         if not need_dx:
             return None
-        if (dy.dtype == torch.bfloat16 and m >= 1024 and self.in_features % 8 == 0 and self.in_features >= 256 and self.out_p >= 256
-                and rt.impl() == 0 and os.environ.get('DVQ_NO_GEMM_NN', '0') != '1' and K.lib().dvq_blaslt_available()):
-            # dx = dy W with W as it lies in memory ([out, in]): library NN product, no transposed weight copy per step
-            dx = K.gemm_nn_lib(dy, w, m, self.in_features, self.out_p)
-            if dx is not None:
-                return dx
         wt = self._wt(w)                                                     # [in, out_p]
         dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self.out_p, self.in_features)
         return dx.view(m, self.in_features)

@@ -40,9 +40,10 @@ def scheduler_linear_warmup(warmup_steps):
 def _fn_linear_warmup_cosine_decay(warmup_steps, max_steps, multipler_min, step):
     if step < warmup_steps:
         return float(step) / float(max(1, warmup_steps))
-    # progress clamped to 1: a run that outlives `max_steps` stays at the floor instead of climbing the cosine again
-    progress = min(1.0, (step - warmup_steps) / max(1, max_steps - warmup_steps))
-    multipler = 0.5 * (math.cos(progress * math.pi) + 1)
+    # (exactly the reference's expression, pinned bit for bit by tests/golden/losses.npz incl. steps past `max_steps`, where it climbs
+    #  again like the reference's does: train.py keeps that from happening by sizing `training_steps` from the real loader BEFORE
+    #  the schedules are built)
+    multipler = 0.5 * (math.cos((step - warmup_steps) / (max_steps - warmup_steps) * math.pi) + 1)
     return max(multipler, multipler_min)
 
 

@@ -361,15 +361,6 @@ int dvq_embed_scatter_add(const int64_t* idx, int64_t idx_bstride, const void* d
  * when dlogits != NULL, dlogits = (softmax - onehot) * gscale_dev[0] (0 on ignored rows and on columns >= V; row stride ldl) */
 int dvq_cross_entropy(const void* logits, int dtype, int64_t rows, int64_t V, int64_t ldl, const int64_t* target, int64_t ignore_index,
                       float* loss_sum, float* count, const float* gscale_dev, void* dlogits, dvq_stream_t stream);
-/* 1 if large plain bf16 dvq_gemm_nt calls (impl 0, batch 1, bias per column or none, M >= 1024, N, K >= 256) are served by
- * hipBLASLt -- only when the process runs with DVQ_USE_HIPBLASLT=1 (comparison path, bound with dlopen at first use);
- * 0 (the default) if they run on the library's own pipelined GEMM kernels. */
-int dvq_blaslt_available(void);
-/* C[M][N] = A[M][K] B[K][N] (bf16, row-major) on hipBLASLt ONLY -- the input gradient of a Linear layer straight from the
- * [out][in] weight matrix, no transposed copy.  DVQ_ESHAPE when the library is absent or declines: the caller then
- * transposes B and uses dvq_gemm_nt (layers.Linear.bwd does exactly that). */
-int dvq_gemm_nn_lib(const void* A, const void* B, void* C, int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                    int64_t ldc, dvq_stream_t stream);
 /* Fused causal multi-head self-attention (bf16, head_dim 64 or 128) -- CausalSelfAttention.forward, stackgpt.py:41-69:
  *   out = attn_drop(softmax(causal_mask(q k^T * scale))) v      per (batch, head), scores never materialised.
  * q, k, v, out, dout, dq, dk, dv: [B*T][n_head*head_dim] row-major (head h = columns h*head_dim ..); T % 8 == 0;

@@ -1,0 +1,333 @@
+"""VALUE checks at BASELINE size (bs 64, 256 x 256, bf16): the full-size property tests elsewhere (adjoint identities, linearity,
+bit reproducibility) cannot see an indexing bug that is consistent across forward / input gradient / weight gradient -- a wrong
+tile tail, image border or XCD-remap boundary.  Here >= 2048 output elements per kernel are recomputed from the kernel's own
+inputs in float64 on the CPU (torch fp64 on the device for the two reductions over 4 M pixels: a checker, test code only) at
+positions chosen to hit exactly those places: tile corners and edges (8 x 32 pixel tiles, 128-channel tiles), the image border,
+the first / last images and the images either side of an XCD-remap range boundary, plus uniform random positions."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from dynamicvectorquantization_amd import _lib
+    _lib.check(_lib.load().dvq_check_device(), "dvq_check_device")
+    return torch.device("cuda:0")
+
+
+def _positions(rs, n, h, w, c, count, th=8, tw=32, ct=128):
+    """(n, y, x, c) sample: structured positions first (borders, tile seams, batch / XCD range seams), uniform random after"""
+    ns = sorted({0, 1, n // 8 - 1, n // 8, n // 2 - 1, n // 2, n - 2, n - 1} & set(range(n)))
+    ys = sorted({0, 1, th - 1, th, h // 2 - 1, h // 2, h - th - 1, h - th, h - 2, h - 1} & set(range(h)))
+    xs = sorted({0, 1, tw - 1, tw, w // 2 - 1, w // 2, w - tw - 1, w - tw, w - 2, w - 1} & set(range(w)))
+    cs = sorted({0, 1, 7, 8, 31, 32, 63, 64, ct - 1, ct % c, c - 8, c - 1} & set(range(c)))
+    pts = [(a, b, d, e) for a in ns for b in ys for d in xs for e in cs]
+    rs.shuffle(pts)
+    pts = pts[: count // 2]
+    while len(pts) < count:
+        pts.append((int(rs.randint(n)), int(rs.randint(h)), int(rs.randint(w)), int(rs.randint(c))))
+    return np.array(pts, dtype=np.int64)
+
+
+def _patches(t, pos, r=1):
+    """[P, 2r+1, 2r+1, C] zero-padded neighbourhoods of NHWC tensor t around pos[:, :3] (gathered on the device, returned as fp64 CPU)"""
+    n, h, w, c = t.shape
+    p = torch.from_numpy(pos).to(t.device)
+    out = torch.zeros(len(pos), 2 * r + 1, 2 * r + 1, c, dtype=torch.float64)
+    for dy in range(-r, r + 1):
+        for dx in range(-r, r + 1):
+            yy, xx = p[:, 1] + dy, p[:, 2] + dx
+            ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+            v = t[p[:, 0], yy.clamp(0, h - 1), xx.clamp(0, w - 1)].double() * ok[:, None]
+            out[:, dy + r, dx + r] = v.cpu()
+    return out
+
+
+@pytest.mark.parametrize("shape", [(64, 256, 128, 128), (64, 64, 256, 256), (64, 128, 256, 128)], ids=lambda s: "x".join(map(str, s)))
+def test_conv3x3_values_full_size(dev, shape):
+    """3x3 halo convolution at BASELINE size: forward (bias + residual + statistics epilogue), input gradient, weight gradient"""
+    from dynamicvectorquantization_amd import kernels as K, runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d
+    from test_gpu_model import _report
+    n, h, cin, cout = shape
+    rs = np.random.RandomState(h + cin)
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        torch.manual_seed(1)
+        conv = Conv2d(cin, cout, 3, 1, 1).to(dev)
+        with torch.no_grad():
+            conv.bias.normal_(0, 0.5)
+        w, wt, bias = conv.packed(torch.bfloat16)
+        g = torch.randn(n, h, h, cin, device=dev)
+        x = (g * torch.sigmoid(g)).to(torch.bfloat16)
+        del g
+        res = torch.randn(n, h, h, cout, device=dev).to(torch.bfloat16)
+        d = conv._desc(x)
+        K.ensure_workspace(dev)
+        stats = torch.zeros(n, 32, 2, dtype=torch.float64, device=dev)
+        y = K.conv2d_fwd(d, x, w, bias, res, out_stats=stats, out_groups=32)
+        wq = w.double().cpu()                                     # [cout, 3, 3, cin] as the kernel reads it
+        # ---- forward values ----
+        pos = _positions(rs, n, h, h, cout, 2048)
+        px = _patches(x, pos)                                     # [P, 3, 3, cin]
+        ref = (px * wq[pos[:, 3]]).sum(dim=(1, 2, 3)) + bias.double().cpu()[pos[:, 3]] + res[pos[:, 0], pos[:, 1], pos[:, 2], pos[:, 3]].double().cpu()
+        got = y[pos[:, 0], pos[:, 1], pos[:, 2], pos[:, 3]].double().cpu()
+        err_f = float(((got - ref).abs() / (ref.abs() + 1.0)).max())
+        assert err_f < 6e-3, err_f                                # one bf16 rounding of the stored value (2^-8); measured 3.6e-3
+        # ---- statistics epilogue: (sum, sum of squares) of the STORED values of 8 (image, group) pairs ----
+        cpg = cout // 32
+        for (ni, gi) in [(0, 0), (0, 31), (n // 8, 5), (n // 2 - 1, 17), (n // 2, 16), (n - 1, 0), (n - 1, 31), (7, 9)]:
+            v = y[ni, :, :, gi * cpg:(gi + 1) * cpg].double()
+            s_ref = torch.stack([v.sum(), (v * v).sum()]).cpu()
+            s_got = stats[ni, gi].cpu()
+            assert float(((s_got - s_ref).abs() / (s_ref.abs() + 1.0)).max()) < 2e-4, (ni, gi, s_got, s_ref)
+        # ---- input gradient ----
+        dy = torch.randn(n, h, h, cout, device=dev).to(torch.bfloat16)
+        dx = K.conv2d_dgrad(d, dy, wt)
+        pos = _positions(rs, n, h, h, cin, 2048)
+        pdy = _patches(dy, pos)                                   # dy[y + a, x + b], a, b in -1..1  ->  tap (1 - a, 1 - b)
+        wsel = wq[:, :, :, pos[:, 3]].permute(3, 1, 2, 0).flip(1, 2)   # [P, 3, 3, cout] with taps reversed
+        ref = (pdy * wsel).sum(dim=(1, 2, 3))
+        got = dx[pos[:, 0], pos[:, 1], pos[:, 2], pos[:, 3]].double().cpu()
+        err_d = float(((got - ref).abs() / (ref.abs() + 1.0)).max())
+        assert err_d < 4e-3, err_d                                # measured 1.9e-3
+        # ---- weight gradient: 64 output x 32 (input channel, tap) combinations = 2048 elements, each a sum over 4 M pixels ----
+        gw = torch.zeros(cout, 3, 3, cin, dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
+        gb = torch.zeros(cout, dtype=torch.float32, device=dev)
+        K.conv2d_wgrad_oihw(d, x, dy, cin, cout, gw, gb)
+        cos = sorted(set([0, 1, 31, 32, 63, 64, cout - 1, cout - 2] + rs.randint(0, cout, 64).tolist()))[:64]
+        cis = sorted(set([0, 1, 63, 64 % cin, cin - 1] + rs.randint(0, cin, 8).tolist()))[:8]
+        taps = [(0, 0), (0, 2), (1, 1), (2, 1)]
+        ref = torch.zeros(len(cos), len(cis), len(taps), dtype=torch.float64, device=dev)
+        dsel = dy[..., cos].double()                              # [n, h, h, 64]
+        for ti, (kh, kw) in enumerate(taps):
+            xs = torch.zeros(n, h, h, len(cis), dtype=torch.float64, device=dev)
+            y0, y1, x0, x1 = max(0, 1 - kh), min(h, h + 1 - kh), max(0, 1 - kw), min(h, h + 1 - kw)
+            xs[:, y0:y1, x0:x1] = x[:, y0 + kh - 1:y1 + kh - 1, x0 + kw - 1:x1 + kw - 1][..., cis].double()
+            ref[:, :, ti] = torch.einsum("nyxo,nyxi->oi", dsel, xs)
+        got = torch.stack([gw[cos][:, cis, kh, kw] for (kh, kw) in taps], dim=-1).double()
+        scale = float(ref.abs().max())
+        err_w = float((got - ref).abs().max()) / scale
+        assert err_w < 1e-5, err_w                                # fp32 accumulation of 4 M bf16 products per element; measured 1.3e-6
+        err_b = float((gb.double() - dy.double().sum(dim=(0, 1, 2))).abs().max() / dy.double().sum(dim=(0, 1, 2)).abs().max())
+        assert err_b < 3e-6, err_b                                # measured 4e-7
+    _report("conv3x3_values_full_size", shape=list(shape), fwd_rel=err_f, dgrad_rel=err_d, wgrad_rel=err_w, dbias_rel=err_b, samples=2048)
+
+
+def test_groupnorm_values_full_size(dev):
+    """GroupNorm + swish forward / backward at 64 x 256 x 256 x 128: sampled elements of y and dx and the whole dgamma / dbeta against
+    float64 group statistics computed on the CPU for the sampled (image, group) pairs"""
+    from dynamicvectorquantization_amd import kernels as K
+    from test_gpu_model import _report
+    n, h, c, g = 64, 256, 128, 32
+    rs = np.random.RandomState(5)
+    x = (torch.randn(n, h * h, c, device=dev) * 1.5 + 0.3).to(torch.bfloat16)
+    dy = torch.randn(n, h * h, c, device=dev).to(torch.bfloat16)
+    gam, bet = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.1
+    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    y, mr = K.gn_forward(x, gam, bet, g, 1e-6, True)
+    dx = K.gn_backward(x, dy, mr, gam, bet, dg, db, g, True)
+    cpg = c // g
+    worst_y = worst_dx = 0.0
+    count = 0
+    for (ni, gi) in [(0, 0), (0, 31), (7, 3), (8, 11), (31, 16), (32, 15), (63, 0), (63, 31)]:
+        sl = slice(gi * cpg, (gi + 1) * cpg)
+        xv, dv = x[ni, :, sl].double().cpu(), dy[ni, :, sl].double().cpu()
+        ga, be = gam[sl].double().cpu(), bet[sl].double().cpu()
+        mu, var = xv.mean(), xv.var(unbiased=False)
+        rstd = 1.0 / torch.sqrt(var + 1e-6)
+        xh = (xv - mu) * rstd
+        z = xh * ga + be
+        sig = torch.sigmoid(z)
+        yref = z * sig
+        dz = dv * (sig * (1 + z * (1 - sig)))
+        dxh = dz * ga
+        dxref = rstd * (dxh - dxh.mean() - xh * (dxh * xh).mean())
+        rows = np.concatenate([[0, 1, 1023, 1024, h * h - 1025, h * h - 1024, h * h - 2, h * h - 1], rs.randint(0, h * h, 56)])
+        worst_y = max(worst_y, float(((y[ni, rows][:, sl].double().cpu() - yref[rows]).abs() / (yref[rows].abs() + 1.0)).max()))
+        worst_dx = max(worst_dx, float(((dx[ni, rows][:, sl].double().cpu() - dxref[rows]).abs() / (dxref[rows].abs() + 1.0)).max()))
+        count += len(rows) * cpg
+    assert count >= 2048 and worst_y < 4e-3 and worst_dx < 4e-3, (count, worst_y, worst_dx)      # measured 2.1e-3 / 1.8e-3
+    # dgamma / dbeta: sums over all 4 M pixels -- fp64 on the device as the checker
+    mu = mr[:, :, 0].double().repeat_interleave(cpg, 1)[:, None, :]
+    rstd = mr[:, :, 1].double().repeat_interleave(cpg, 1)[:, None, :]
+    dgr, dbr = torch.zeros(c, dtype=torch.float64, device=dev), torch.zeros(c, dtype=torch.float64, device=dev)
+    for ni in range(n):
+        xh = (x[ni].double() - mu[ni]) * rstd[ni]
+        z = xh * gam.double() + bet.double()
+        sig = torch.sigmoid(z)
+        dz = dy[ni].double() * (sig * (1 + z * (1 - sig)))
+        dbr += dz.sum(0)
+        dgr += (dz * xh).sum(0)
+    e_g = float((dg.double() - dgr).abs().max() / dgr.abs().max())
+    e_b = float((db.double() - dbr).abs().max() / dbr.abs().max())
+    assert e_g < 3e-6 and e_b < 3e-6, (e_g, e_b)                  # measured 3e-7 / 2e-7
+    _report("groupnorm_values_full_size", y_rel=worst_y, dx_rel=worst_dx, dgamma_rel=e_g, dbeta_rel=e_b, samples=count)
+
+
+def test_attnblock_flash_values_full_size(dev):
+    """AttnBlock attention (one head of 256 channels over 1024 tokens, B = 64): sampled output rows of the flash forward against a
+    float64 softmax(q K^T / 16) V on the CPU, incl. the first / last query tiles and batch entries either side of the grid's seams"""
+    from dynamicvectorquantization_amd import kernels as K
+    from test_gpu_model import _report
+    b, t, c = 64, 1024, 256
+    rs = np.random.RandomState(11)
+    q = torch.randn(b * t, c, device=dev).to(torch.bfloat16)
+    k = torch.randn(b * t, c, device=dev).to(torch.bfloat16)
+    v = torch.randn(b * t, c, device=dev).to(torch.bfloat16)
+    scale = c ** -0.5
+    assert K.attn_full_ok(q, t)
+    out, lse = K.attn_full_fwd(q, k, v, b, t, scale)
+    worst = 0.0
+    count = 0
+    for bi in [0, 1, 7, 8, 31, 32, 62, 63]:
+        kk, vv = k[bi * t:(bi + 1) * t].double().cpu(), v[bi * t:(bi + 1) * t].double().cpu()
+        rows = np.concatenate([[0, 1, 31, 32, 63, 64, t - 33, t - 32, t - 1], rs.randint(0, t, 23)])
+        qq = q[bi * t + rows].double().cpu()
+        p = torch.softmax(qq @ kk.t() * scale, dim=-1)
+        ref = p @ vv
+        got = out[bi * t + rows].double().cpu()
+        worst = max(worst, float(((got - ref).abs() / (ref.abs() + 0.05)).max()))
+        count += len(rows) * c
+    assert count >= 2048 and worst < 1e-2, (count, worst)          # bf16 probabilities in the second MFMA + bf16 output rounding; measured 5.1e-3
+    _report("attnblock_flash_values_full_size", rel=worst, samples=count)
+
+
+def test_config2_dual_full_size_properties(dev):
+    """BASELINE config 2 as bench.py runs it: DQ-VAE dual F = 16 / 8, codebook 1024 x 256, bs 64, 256 x 256, bf16, the complete
+    two-optimizer objective.  Full-size properties: finite losses over eager + recorded + replayed steps, fine ratio 0.5 of the
+    entropy router (half-flat images), code range, codebook mask consistent with the grain map, EMA buffers moved, and the replayed
+    step reproduces the eager step's losses on the same batch"""
+    import warnings
+    import bench
+    from dynamicvectorquantization_amd import runtime as rt, synth
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    from dynamicvectorquantization_amd.trainer import Trainer
+    from test_gpu_model import _report
+    bs = 64
+    with rt.compute_dtype_ctx(torch.bfloat16), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xs = [torch.from_numpy(synth.half_flat_images(bs, 256, seed=700 + i)).to(dev) for i in range(2)]
+
+        def run(use_graph):
+            torch.manual_seed(0)
+            model = instantiate_from_config(bench.full_config("full")).to(dev)
+            model.learning_rate, model.training_steps, model.steps_per_epoch = 4.5e-6 * bs, 100000, 1000
+            model.train()
+            tr = Trainer(model, max_steps=8, use_graph=use_graph, graph_after=2)
+            losses = [[float(l) for l in tr.train_step({"image": xs[i % 2]}, i)] for i in range(5)]
+            return model, tr, losses
+
+        model, tr, lg = run(True)
+        assert np.isfinite(np.array(lg)).all() and tr.graph_replays >= 2, (lg, tr.graph_replays)
+        out = model._last
+        codes, grain, mask = out["codes"], out["grain"], out["mask"]
+        assert tuple(codes.shape) == (bs, 32, 32) and int(codes.min()) >= 0 and int(codes.max()) < 1024
+        assert tuple(grain.shape) == (bs, 16, 16) and set(torch.unique(grain).tolist()) <= {0, 1}
+        fine = float((grain == 1).float().mean())
+        assert abs(fine - 0.5) < 0.02, fine                       # half of every image is flat: entropy routing at ratio 0.5
+        want = torch.tensor([0.25, 1.0], device=dev)[grain].repeat_interleave(2, 1).repeat_interleave(2, 2)
+        assert torch.allclose(mask.reshape(bs, 32, 32), want)     # codebook-loss weights 1/4 (coarse) and 1 (fine)
+        cb = model.quantize.codebook
+        assert bool(torch.isfinite(cb.embed_ema).all()) and float(cb.cluster_size_ema.sum()) > 0
+        del model, tr
+        torch.cuda.empty_cache()
+        _, _, le = run(False)
+        # same seeds, same batches: recorded / replayed steps against eagerly launched ones (bf16 atomics-free kernels; the
+        # restart rows of dead codes come from the same device-resident generator)
+        rel = float(np.abs(np.array(lg) - np.array(le)).max() / np.abs(np.array(le)).max())
+        rel0 = float(np.abs(np.array(lg[0]) - np.array(le[0])).max() / np.abs(np.array(le[0])).max())
+        _report("config2_full_size", losses_graph=lg, losses_eager=le, rel=rel, rel_first_step=rel0, fine_ratio=fine)
+        # measured: first step 3e-5 (side-stream weight-gradient order); by the fifth step the bf16 GAN objective has amplified that
+        # to 6.6 % on the discriminator loss (Adam sign noise x adaptive weight -- tests/test_gpu_stepgraph.py allows 15 % likewise)
+        assert rel0 < 1e-3 and rel < 0.15, (lg, le)
+
+
+@pytest.mark.parametrize("lc,lf", [(257, 387), (257, 771)], ids=["T643", "T1027"])
+def test_stackgpt_p6c18_geometry(dev, lc, lf):
+    """BASELINE config 5 at its real geometry: StackGPT p6c18 (6 position + 18 content blocks, 1024 wide, 8 heads of 128) at bs 32
+    with T = 643 (fine ratio 0.5: 257 coarse + 387 fine tokens) and T = 1027 (every region fine: the longest sequence).  Finite
+    teacher-forced losses and gradients; fused attention == per-head GEMM path; causality: changing token t leaves every logit
+    before t bit-identical"""
+    import os
+    from conftest import REPO
+    from dynamicvectorquantization_amd import config as cfg, runtime as rt
+    from test_gpu_model import _report
+    bs = 32
+    c = cfg.load_yaml(os.path.join(REPO, "configs/stage2/uncond_imagenet_p6c18.yml"))
+    tp = c.model.params.transformer_config
+    tp.params.embd_pdrop = tp.params.resid_pdrop = tp.params.attn_pdrop = 0.0      # (dropout off: the two attention paths are compared)
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        torch.manual_seed(0)
+        gpt = cfg.instantiate_from_config(tp).to(dev)
+        gpt.train()
+        g = torch.Generator(device="cpu").manual_seed(lc + lf)
+        ri = lambda hi, n: torch.randint(0, hi, (bs, n), generator=g).to(dev)
+        cc, fc, cp, fp = ri(1024, lc), ri(1024, lf), ri(256, lc), ri(1024, lf)
+        cs, fs = torch.zeros(bs, lc, dtype=torch.long, device=dev), torch.ones(bs, lf, dtype=torch.long, device=dev)
+        ct = torch.cat([cc, fc], dim=1)[:, 1:].contiguous()
+        t = lc + lf - 1
+        out = gpt(cc, fc, cp, fp, cs, fs, content_target=ct, coarse_position_target=cp[:, 1:].contiguous(), fine_position_target=fp)
+        loss = out["position_loss"] + out["content_loss"]
+        loss.backward()
+        assert bool(torch.isfinite(loss)) and all(bool(torch.isfinite(p.grad).all()) for p in gpt.parameters() if p.grad is not None)
+        # an untrained transformer predicts ~uniformly: content loss ~ log(1027)
+        assert abs(float(out["content_loss"].detach()) - np.log(1027)) < 0.5, float(out["content_loss"].detach())
+        gpt.eval()
+        with torch.no_grad():
+            ref = gpt(cc, fc, cp, fp, cs, fs)
+            os.environ["DVQ_NO_FUSED_ATTN"] = "1"
+            try:
+                unf = gpt(cc, fc, cp, fp, cs, fs)
+            finally:
+                os.environ.pop("DVQ_NO_FUSED_ATTN", None)
+            d_attn = max(float((ref[k] - unf[k]).abs().max()) for k in ("position_logits", "content_logits"))
+            scale = max(float(ref[k].abs().max()) for k in ("position_logits", "content_logits"))
+            assert d_attn < 3e-2 * scale, (d_attn, scale)
+            # causality: logits at positions < t0 do not depend on the tokens at >= t0
+            t0 = t - 37
+            fc2, fp2 = fc.clone(), fp.clone()
+            j0 = t0 - lc + 1                                      # first changed fine index (stream position t0 consumes fine token j0 - 1 ...)
+            fc2[:, j0:] = (fc2[:, j0:] + 7) % 1024
+            fp2[:, j0 + 1:] = (fp2[:, j0 + 1:] + 11) % 1024
+            alt = gpt(cc, fc2, cp, fp2, cs, fs)
+            assert torch.equal(ref["content_logits"][:, :t0 - 1], alt["content_logits"][:, :t0 - 1])
+            assert torch.equal(ref["position_logits"][:, :t0 - 1], alt["position_logits"][:, :t0 - 1])
+            assert not torch.equal(ref["content_logits"][:, t0 + 1:], alt["content_logits"][:, t0 + 1:])
+    _report("stackgpt_p6c18_geometry", T=t, bs=bs, content_loss=float(out["content_loss"]), position_loss=float(out["position_loss"]),
+            fused_vs_unfused_abs=d_attn, logit_scale=scale)
+
+
+@pytest.mark.parametrize("dist_", ["normal", "encoder"])
+def test_vq_argmin_mismatch_rate_vs_reference_formula(dev, dist_):
+    """north_star asks for index-exactness against the reference; the reference's own answer is the first minimum of its fp32
+    `|x|^2 + |e|^2 - 2 x.e` (quantize2_mask.py:29-55), which deviates from the exact argmin on near ties.  At BASELINE size
+    (N = 65536, K = 1024, D = 256) the HIP indices are compared with that formula evaluated in torch fp32 on the device (a checker,
+    test code only) AND with the float64 argmin on the rows where the two disagree: every disagreement must be a near tie that the
+    HIP path resolved like float64 does.  The rate goes to test_reports.jsonl"""
+    from dynamicvectorquantization_amd import kernels as K, synth
+    from oracle import vq as ovq
+    from test_gpu_model import _report
+    n, d, k = 65536, 256, 1024
+    x, cb = synth.vq_inputs(n, d, k, dist_, 3)
+    xt, cbt = torch.from_numpy(x).to(dev), torch.from_numpy(cb).to(dev)
+    idx = K.vq_argmin(xt, cbt, impl=0)
+    # the reference's formula, in its operation order: addmm(|e|^2 + |x|^2, x, e^T, alpha=-2)
+    dist = torch.addmm((cbt * cbt).sum(1)[None, :] + (xt * xt).sum(1, keepdim=True), xt, cbt.t(), alpha=-2.0)
+    ref_idx = dist.argmin(dim=1)
+    bad = torch.nonzero(idx != ref_idx).reshape(-1).cpu().numpy()
+    exact = ovq.argmin_exact(x[bad], cb) if len(bad) else np.zeros(0, dtype=np.int64)
+    hip_is_exact = int((idx.cpu().numpy()[bad] == exact).sum())
+    gaps = []
+    for r in bad[:256]:
+        dd = ((x[r].astype(np.float64)[None, :] - cb.astype(np.float64)) ** 2).sum(1)
+        s = np.sort(dd)
+        gaps.append(float((s[1] - s[0]) / (float((x[r].astype(np.float64) ** 2).sum()) + 1.0)))
+    _report("vq_argmin_vs_reference_formula", dist=dist_, N=n, K=k, D=d, mismatched=int(len(bad)), rate=float(len(bad)) / n,
+            hip_equals_fp64_on_mismatches=hip_is_exact, max_rel_gap=max(gaps) if gaps else 0.0)
+    assert hip_is_exact == len(bad), "a row that differs from the reference's fp32 formula is not the float64 argmin"
+    assert len(bad) <= 1e-3 * n and (not gaps or max(gaps) < 4e-7), (len(bad), max(gaps) if gaps else 0.0)
