@@ -240,4 +240,5 @@ def test_adaptive_weight_bf16_vs_fp32_full_width(dev):
     # GAN-gradient norm at an unchanged 0.13 - 0.35 % for the nll-gradient norm.  Bounds: 1.5x the largest of them for the two
     # noise-dominated numbers, 1.5x the measurement elsewhere.
     assert rel["nll"] <= 6e-3 and rel["g"] <= 0.23 and rel["d_weight"] <= 0.2, (rel, a, b)
-    assert rel["loss"] <= 2e-2 and rel["p"] <= 1e-2, (rel, a, b)
+    # (the generator loss contains d_weight * g_loss, ~0.22 of 1.07: it follows the adaptive weight's noise at a fifth of its size)
+    assert rel["loss"] <= 0.25 * 0.2 and rel["p"] <= 6e-3, (rel, a, b)
