@@ -225,6 +225,36 @@ def _dry_run(args, world, rank):
         dist.destroy_process_group()
 
 
+def extra_workloads(budget_s):
+    """compact {value, unit, ms_per_step, roofline} blocks of the secondary workloads (BASELINE configs 4 and 5): the triple-grain
+    DQ-VAE step with the 8192-entry codebook, the DQ-Transformer p6c18 train step and K/V-cached sampling, each measured by
+    bench_extra.py in a child process; a workload that does not fit the remaining budget is reported as skipped"""
+    import subprocess
+    t_end = time.time() + budget_s
+    jobs = [("triple_k8192", ["--workload", "triple", "--codebook", "8192", "--steps", "4", "--warmup", "4"]),
+            ("stage2_p6c18", ["--workload", "stage2", "--steps", "3", "--warmup", "2"]),
+            ("sampling_p6c18", ["--workload", "sampling"])]
+    res = {}
+    for name, extra in jobs:
+        left = t_end - time.time()
+        if left < 25.0:
+            res[name] = {"skipped": "time budget"}
+            continue
+        try:
+            r = subprocess.run([sys.executable, os.path.join(REPO, "bench_extra.py"), "--no-cpu-baseline"] + extra, capture_output=True,
+                               text=True, timeout=left)
+            e = json.loads(r.stdout.strip().splitlines()[-1])
+            roof = e.get("roofline") or {}
+            res[name] = {"metric": e.get("metric"), "value": e.get("value"), "unit": e.get("unit"), "ms_per_step": e.get("ms_per_step"),
+                         "config": e.get("config"), "mfma_frac_est": e.get("mfma_frac_est"),
+                         "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")} if roof else None}
+            if "detail" in e:
+                res[name]["detail"] = e["detail"]
+        except Exception as ex:                     # the headline line must not depend on a secondary workload
+            res[name] = {"failed": f"{type(ex).__name__}: {str(ex)[:120]}"}
+    return res
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
         return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "full")
@@ -247,6 +277,8 @@ def main():
                     help="how the timed steps are launched: replays of the recorded step (host ~1 ms per step), eager launches "
                          "(weight gradients on a second stream; ~40-70 ms of host work per step), or -- one GPU only -- whichever "
                          "three untimed calibration steps show to be faster on this host (default)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the compact BASELINE config 4 / 5 blocks (bench_extra.py workloads)")
+    ap.add_argument("--extras-budget", type=float, default=150.0, help="seconds the extra workloads may take in all")
     ap.add_argument("--vq-only", action="store_true", help="only the VQ-argmin micro-benchmark (kernel iteration); prints its JSON")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU check of the launch contract only: gloo ranks, barrier + timed loop of no-op steps, one JSON line; no GPU work")
@@ -262,8 +294,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the HIP path: an MI355X is required"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dp = world == 1 and os.environ.get("DVQ_FORCE_DP", "0") == "1"
+    if world > 1 or force_dp:
+        # DVQ_FORCE_DP=1 on one GPU: a ONE-rank RCCL group, so that the data-parallel step (in-backward bucket launches, exchange
+        # points cutting the recorded step into segments, waits) is what gets timed -- the cost of that machinery without a fabric
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dp:
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -380,7 +417,21 @@ def main():
                 os.environ["DVQ_SIDE_WGRAD"] = prev_side
             model.quantize.fwd = orig_fwd
             model._vq_seen = (vq_seen["x"], vq_seen["cb"]) if "x" in vq_seen else None
+        exposed = None
+        if world > 1 or force_dp:
+            # how long the compute stream sits in the gradient-exchange waits of one step (events around GradBuckets.wait())
+            for gb in trainer.buckets:
+                gb.measure = []
+            was = trainer.use_graph
+            trainer.use_graph = False
+            trainer.train_step(batches[0], SETUP + warmup + steps + 1)
+            torch.cuda.synchronize()
+            exposed = round(sum(a.elapsed_time(b) for gb in trainer.buckets for a, b in gb.measure), 3)
+            for gb in trainer.buckets:
+                gb.measure = None
+            trainer.use_graph = was
         graph_info = {"enabled": trainer._graph is not None, "timed_steps": launch_mode, "calibration": calib, "replays": trainer.graph_replays,
+                      "allreduce_exposed_ms": exposed,
                       "host_enqueue_all_ms_per_step": round(enqueue_all / steps * 1e3, 2),
                       "segments": trainer._graph["sg"].n_segments() if trainer._graph is not None else 0,
                       "fine_ratio": float(model._logged.get("train_fine_ratio", torch.tensor(float("nan"))))}
@@ -424,8 +475,10 @@ def main():
                         "launches": v["launches"], "avg_launch_ms": round(v["ms_per_launch"], 4),
                         "alg_flops_per_launch": v["flops"] / max(1, v["launches"]),
                         "alg_bytes_per_launch": v["bytes"] / max(1, v["launches"]),
-                        "timed": "HIP events around every launch of this kernel during one eagerly launched step right after the "
-                                 "timed region (the timed steps are hipGraph replays of the same launch sequence)"}
+                        "timed": "HIP events around every launch of this kernel during one eagerly launched single-stream step right "
+                                 "after the timed region; the timed steps themselves are " +
+                                 ("hipGraph replays of the same launch sequence" if graph_info["timed_steps"] == "graph" else
+                                  "eager launches of the same sequence with the conv weight gradients on a second stream")}
             # HBM traffic per launch: PMC counters cannot be collected from inside this process; the figure comes from the
             # committed rocprofv3 --pmc passes over this same command (tools/gpu_pmc_bench.sh -> tools/pmc_summarise.py)
             # context for `frac`: `peak` is the nominal dense bf16 rate at the maximum clock; under sustained MFMA load the chip is
@@ -455,6 +508,8 @@ def main():
             "step_mfma_frac": round(ips / world * STEP_FLOP_PER_IMG[args.objective] / PEAK_BF16, 4),
             "step_flop_per_img": STEP_FLOP_PER_IMG[args.objective],
             "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 2),
+            "rccl_ranks": dist.get_world_size() if dist.is_available() and dist.is_initialized() else 0,
+            "allreduce_exposed_ms": graph_info.get("allreduce_exposed_ms"),
             "roofline": roofline,
             "kernel_families": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"], 3),
                                     "TFLOPs": round(v["TFLOPs"], 2)} for k, v in fam.items()},
@@ -464,8 +519,19 @@ def main():
             out["vq_argmin"] = vq_microbench(dev, in_training=vq_seen)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.objective)
+        if world == 1 and not args.no_extras and args.objective == "full" and args.bs == 64:
+            # BASELINE configs 4 / 5 in the same driver command (compact blocks; bench_extra.py prints the full lines): each runs in
+            # its own process after this one has released its memory, inside a time budget
+            del model
+            torch.cuda.empty_cache()
+            out["extra_workloads"] = extra_workloads(args.extras_budget)
+        try:        # RCCL prints its version banner through C stdio: flush it NOW so that the JSON line is the last line of stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
 

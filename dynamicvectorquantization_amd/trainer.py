@@ -188,6 +188,7 @@ class GradBuckets:
         self._pending, self._done = [], []
         self.launched = 0                 # all-reduce launches so far (tests: every bucket exactly once per step)
         self._divisor = None              # tests: pre-division factor of a pretended world size in a one-rank group
+        self.measure = None               # list of (start, end) event pairs around wait() while bench.py measures the exposed time
 
     def zero(self):
         self.fp.zero_grad()
@@ -275,10 +276,16 @@ class GradBuckets:
             return
 
         def _wait():
+            if self.measure is not None:              # bench.py: time the compute stream spends in this wait (HIP events around it)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             for w in self._pending:
                 if w is not None:
                     w.wait()
             self._pending.clear()
+            if self.measure is not None:
+                e1.record()
+                self.measure.append((e0, e1))
         rt.graph_break(_wait)
 
     def param_range(self, params):
