@@ -116,6 +116,7 @@ SIGNATURES = {
     "dvq_adamw_dev": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "dvq_set_f32x8": (i32, [vp, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
     "dvq_sample_rows": (i32, [vp, i64, i64, vp, vp]),
+    "dvq_sample_constrained": (i32, [vp, i32, i64, i64, i64, f32, vp, i64, i64, i64, vp, i64, i64, i64, vp, i32, f32, i32, vp, vp, vp]),
 }
 
 

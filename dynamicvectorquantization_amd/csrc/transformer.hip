@@ -575,3 +575,230 @@ extern "C" int dvq_rows_dev(void* x, void* hidden, int dtype, int64_t B, int64_t
     DVQ_CHECK_LAUNCH("rows_dev");
     return DVQ_OK;
 }
+
+// =================================================================================================
+// Fused constrained sampling of ONE token per row -- Dualformer's sampler tail:
+//   dqtransformer_uncond_entropy.py:522-561 (avoid_repeat_or_enforce_pad_for_{coarse,fine}_position, avoid_special_or_enforce_pad_
+//   for_content), models/stage2/utils.py:22-40 (top_k_logits, top_p_logits), :328 / :350 (softmax + multinomial, or top-1)
+// as one launch instead of ~12 ATen kernels (scatter / masked fills / topk / sort / cumsum / softmax / multinomial) per draw.
+// One workgroup per row.  The row (V <= 2048 logits / temperature, constraint mask applied) is sorted in LDS by (value descending,
+// index ascending) with a bitonic network; in that order
+//   top-k    keeps every value >= the k-th one (ties kept, like `out[out < v[..., [-1]]] = -inf`),
+//   softmax  is exp(v - v_max) / sum over the kept entries,
+//   top-p    removes entry i (i >= 1) when the inclusive cumulative probability of entries 0 .. i-1 is already >= p, renormalises,
+//   the draw is the inverse CDF at u * (kept mass), u uniform from a counter-based generator whose state lives in device memory
+//            (capturable in a hipGraph; advanced by a one-thread kernel after the draw), or entry 0 when sample == 0.
+// Constraint rule of a LIVE row (finished[row] == 0): column c is masked when c >= forbid_from, c is one of forbid_codes[4], or c is
+// listed in forbid_idx[row][0 .. n_forbid); then keep_code gets its logit back; then late_forbid_code is masked.  A FINISHED row keeps
+// pad_code only.
+// =================================================================================================
+namespace {
+
+struct SampleParams {
+    const void* logits;
+    int64_t ldl;
+    int V, N;                       // columns; sort size (power of two >= V)
+    float inv_temperature;
+    const int64_t* forbid_idx;
+    int64_t forbid_ld;
+    int n_forbid;
+    int forbid_from;
+    int codes[4];
+    int keep_code, late_forbid_code, pad_code;
+    const float* finished;
+    int top_k;
+    float top_p;
+    int sample;
+    const uint64_t* state;
+    int64_t* out;
+};
+
+__device__ __forceinline__ bool sample_before(float va, int ia, float vb, int ib) {      // (value descending, index ascending)
+    return va > vb || (va == vb && ia < ib);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sample_constrained_kernel(SampleParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sv = reinterpret_cast<float*>(smem);             // [N] values, then probabilities
+    int* si = reinterpret_cast<int*>(sv + p.N);             // [N] column indices
+    float* scan = reinterpret_cast<float*>(si + p.N);       // [N] inclusive scans
+    unsigned char* flag = reinterpret_cast<unsigned char*>(scan + p.N);     // [N] forbid flags
+    __shared__ float red[8];
+    __shared__ int redi[8];
+    const int tid = threadIdx.x, row = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = p.V, N = p.N;
+    const bool fin = p.finished != nullptr && p.finished[row] != 0.f;
+    for (int c = tid; c < N; c += 256) flag[c] = 0;
+    __syncthreads();
+    if (!fin && p.forbid_idx != nullptr)
+        for (int j = tid; j < p.n_forbid; j += 256) {
+            const int64_t c = p.forbid_idx[(int64_t)row * p.forbid_ld + j];
+            if (c >= 0 && c < V) flag[c] = 1;
+        }
+    __syncthreads();
+    const T* lg = reinterpret_cast<const T*>(p.logits) + (int64_t)row * p.ldl;
+    for (int c = tid; c < N; c += 256) {
+        float v = -INFINITY;
+        if (c < V) {
+            const float x = ElemIO<T>::load(lg + c) * p.inv_temperature;
+            bool masked;
+            if (fin) {
+                masked = c != p.pad_code;
+            } else {
+                masked = flag[c] != 0 || c >= p.forbid_from || c == p.codes[0] || c == p.codes[1] || c == p.codes[2] || c == p.codes[3];
+                if (c == p.keep_code) masked = false;
+                if (c == p.late_forbid_code) masked = true;
+            }
+            v = masked ? -INFINITY : x;
+        }
+        sv[c] = v;
+        si[c] = c;
+    }
+    __syncthreads();
+    // bitonic sort, N / 2 compare-exchanges per step
+    for (int k2 = 2; k2 <= N; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (N >> 1); t += 256) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const bool up = (lo & k2) == 0;                       // this run is ordered "best first"
+                const float va = sv[lo], vb = sv[hi];
+                const int ia = si[lo], ib = si[hi];
+                const bool swap = up ? sample_before(vb, ib, va, ia) : sample_before(va, ia, vb, ib);
+                if (swap) {
+                    sv[lo] = vb; sv[hi] = va;
+                    si[lo] = ib; si[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    // top-k threshold and softmax over the kept entries
+    const float vmax = sv[0];
+    const float thr = (p.top_k > 0 && p.top_k < V) ? sv[p.top_k - 1] : -INFINITY;
+    auto block_sum = [&](float x) {
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = x;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    // inclusive scan of scan[] over positions 0 .. N-1 (each thread owns N / 256 consecutive positions; N >= 256)
+    const int per = N >> 8;
+    auto block_scan = [&]() {
+        float run = 0.f;
+        for (int i = 0; i < per; ++i) {
+            run += scan[tid * per + i];
+            scan[tid * per + i] = run;
+        }
+        // scan of the 256 thread totals: wave-level inclusive scan, then wave offsets
+        float x = run;
+        for (int off = 1; off < 64; off <<= 1) {
+            const float y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        __syncthreads();
+        if (lane == 63) red[wave] = x;
+        __syncthreads();
+        float base = x - run;
+        for (int w = 0; w < wave; ++w) base += red[w];
+        for (int i = 0; i < per; ++i) scan[tid * per + i] += base;
+        __syncthreads();
+    };
+    float part = 0.f;
+    for (int c = tid; c < N; c += 256) {
+        const float v = sv[c];
+        const float e = (v >= thr && v > -INFINITY) ? __expf(v - vmax) : 0.f;
+        sv[c] = e;
+        part += e;
+    }
+    const float z = block_sum(part);
+    for (int c = tid; c < N; c += 256) {
+        sv[c] = sv[c] / z;
+        scan[c] = sv[c];
+    }
+    __syncthreads();
+    float mass = 1.f;
+    if (p.top_p > 0.f && p.top_p < 1.f) {
+        block_scan();
+        part = 0.f;
+        for (int c = tid; c < N; c += 256) {
+            const bool remove = c > 0 && scan[c - 1] >= p.top_p;
+            const float pr = remove ? 0.f : sv[c];
+            part += pr;
+            flag[c] = remove ? 1 : 0;                                  // (re-used: the forbid flags are no longer needed)
+        }
+        __syncthreads();
+        for (int c = tid; c < N; c += 256) {
+            if (flag[c]) sv[c] = 0.f;
+            scan[c] = sv[c];
+        }
+        mass = block_sum(part);
+    }
+    int pick = 0;
+    if (p.sample) {
+        block_scan();                                                   // cumulative kept mass
+        // uniform in [0, 1): splitmix64 of (key, counter, row)
+        uint64_t s = p.state[0] * 0x9E3779B97F4A7C15ull + p.state[1] * 0xD1B54A32D192ED03ull + (uint64_t)row * 0x8CB92BA72F3D8DD7ull;
+        s ^= s >> 30; s *= 0xBF58476D1CE4E5B9ull; s ^= s >> 27; s *= 0x94D049BB133111EBull; s ^= s >> 31;
+        const float u = (float)(s >> 40) * (1.0f / 16777216.0f) * mass;
+        // first position whose inclusive cumulative mass exceeds u (positions with zero probability are never picked)
+        int best = N;
+        for (int c = tid; c < N; c += 256)
+            if (sv[c] > 0.f && scan[c] > u) {
+                best = c;
+                break;                                                  // (positions of a thread ascend)
+            }
+        for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
+        __syncthreads();
+        if (lane == 0) redi[wave] = best;
+        __syncthreads();
+        best = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+        if (best >= N) {                                                // rounding left u at the very top: the last kept entry
+            int last = -1;
+            for (int c = tid; c < N; c += 256)
+                if (sv[c] > 0.f) last = c;
+            for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
+            __syncthreads();
+            if (lane == 0) redi[wave] = last;
+            __syncthreads();
+            best = max(max(redi[0], redi[1]), max(redi[2], redi[3]));
+        }
+        pick = max(best, 0);
+    }
+    if (tid == 0) p.out[row] = (int64_t)si[pick];
+}
+
+__global__ void sample_bump_kernel(uint64_t* state) {
+    if (threadIdx.x == 0) state[1] += 1;
+}
+
+}  // namespace
+
+extern "C" int dvq_sample_constrained(const void* logits, int dtype, int64_t B, int64_t V, int64_t ldl, float temperature,
+                                      const int64_t* forbid_idx, int64_t n_forbid, int64_t forbid_ld, int64_t forbid_from,
+                                      const int64_t* forbid_codes4, int64_t keep_code, int64_t late_forbid_code, int64_t pad_code,
+                                      const float* finished, int top_k, float top_p, int sample, uint64_t* state, int64_t* out,
+                                      dvq_stream_t stream) {
+    DVQ_REQUIRE(logits && out && B > 0 && V > 0 && V <= 2048 && ldl >= V && temperature > 0.f && (!sample || state != nullptr) &&
+                    (forbid_idx == nullptr || (n_forbid >= 0 && forbid_ld >= n_forbid)) && pad_code >= 0 && pad_code < V && top_k >= 0,
+                DVQ_EINVAL, "dvq_sample_constrained: bad arguments (V <= 2048)");
+    SampleParams p{};
+    p.logits = logits; p.ldl = ldl; p.V = (int)V;
+    int n = 256;
+    while (n < V) n <<= 1;
+    p.N = n;
+    p.inv_temperature = 1.f / temperature;
+    p.forbid_idx = forbid_idx; p.forbid_ld = forbid_ld; p.n_forbid = forbid_idx ? (int)n_forbid : 0;
+    p.forbid_from = (int)(forbid_from < 0 || forbid_from > V ? V : forbid_from);
+    for (int i = 0; i < 4; ++i) p.codes[i] = forbid_codes4 ? (int)forbid_codes4[i] : -1;
+    p.keep_code = (int)keep_code; p.late_forbid_code = (int)late_forbid_code; p.pad_code = (int)pad_code;
+    p.finished = finished; p.top_k = top_k; p.top_p = top_p; p.sample = sample; p.state = state; p.out = out;
+    const int lds = n * (4 + 4 + 4 + 1);
+    DVQ_DISPATCH_DTYPE(dtype, TT, sample_constrained_kernel<TT><<<dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream>>>(p););
+    DVQ_CHECK_LAUNCH("sample_constrained");
+    if (sample) {
+        sample_bump_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(state);
+        DVQ_CHECK_LAUNCH("sample_bump");
+    }
+    return DVQ_OK;
+}

@@ -884,3 +884,27 @@ def attn_decode(q, kcache, vcache, n_head, t, scale):
     check(lib().dvq_attn_decode(_p(q), _p(kcache), _p(vcache), dt(q), b, n_head, c // n_head, t, kcache.shape[1], scale, _p(out), _s()),
           "dvq_attn_decode")
     return out
+
+
+def sample_constrained(logits2d, temperature, pad_code, state, forbid_idx=None, forbid_from=None, forbid_codes=(), keep_code=-1,
+                       late_forbid_code=-1, finished=None, top_k=None, top_p=None, sample=True):
+    """one token per row of logits2d [B, V] (V <= 2048) under Dualformer's constraint rules, top-k / top-p, multinomial or top-1:
+    ONE launch (csrc/transformer.hip: dvq_sample_constrained).  forbid_idx int64 [B, L] lists columns to mask per row; finished fp32
+    [B] (non-zero: the row only keeps pad_code); state = int64 [2] device generator state (key, counter).  -> int64 [B, 1]"""
+    b, v = logits2d.shape
+    out = torch.empty(b, 1, dtype=torch.int64, device=logits2d.device)
+    codes = (C.c_int64 * 4)(*([int(c) for c in forbid_codes] + [-1] * (4 - len(forbid_codes))))
+    fi = None
+    n_forbid = ld = 0
+    if forbid_idx is not None and forbid_idx.shape[1] > 0:
+        fi = forbid_idx if forbid_idx.is_contiguous() else forbid_idx.contiguous()
+        n_forbid, ld = fi.shape[1], fi.stride(0)
+    fin = None
+    if finished is not None:
+        fin = finished.reshape(-1).to(torch.float32).contiguous()
+    assert logits2d.is_cuda and logits2d.stride(1) == 1, "row-major logits (a column slice of a padded matrix is fine)"
+    check(lib().dvq_sample_constrained(_praw(logits2d), dt(logits2d), b, v, logits2d.stride(0), float(temperature), _p(fi), n_forbid, ld,
+                                       v if forbid_from is None else int(forbid_from), codes, int(keep_code), int(late_forbid_code),
+                                       int(pad_code), _p(fin), int(top_k or 0), float(top_p or 0.0), int(bool(sample)), _p(state), _p(out),
+                                       _s()), "dvq_sample_constrained")
+    return out

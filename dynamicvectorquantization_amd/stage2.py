@@ -9,6 +9,8 @@ the same library.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -382,6 +384,37 @@ class _SamplerMixin:
     def transfer_sampled_coarse_position_to_remain_fine_position(self, coarse_position):
         return self._fine_positions_of(1 - self._coarse_cells_drawn(coarse_position), coarse_position)
 
+    def _draw_rule(self, logits2d, temperature, sample, k, p, rule):
+        """one token per row under constraint `rule` = (kind, sampled positions or None, done flags): ONE fused launch
+        (kernels.sample_constrained: mask rules + top-k / top-p + softmax + multinomial / top-1) when the logits are on the device;
+        DVQ_SAMPLER=torch (or a vocabulary beyond the kernel's 2048 columns) keeps the op-by-op path the golden tests pin"""
+        kind, sampled, done = rule
+        if logits2d.is_cuda and logits2d.shape[1] <= 2048 and logits2d.dtype in (torch.float32, torch.bfloat16) and \
+                os.environ.get("DVQ_SAMPLER", "fused") != "torch":
+            st = self.__dict__.get("_sampler_state")
+            if st is None or st.device != logits2d.device:
+                st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=logits2d.device)
+                self.__dict__["_sampler_state"] = st
+            kw = self._fused_rule(kind)
+            if kind != "content":
+                kw["forbid_idx"] = sampled
+            return K.sample_constrained(logits2d, temperature, state=st, finished=done, top_k=k, top_p=p, sample=sample, **kw)
+        fn = {"coarse_pos": lambda lg: self.avoid_repeat_or_enforce_pad_for_coarse_position(lg, sampled, done),
+              "fine_pos": lambda lg: self.avoid_repeat_or_enforce_pad_for_fine_position(lg, sampled, done),
+              "content": lambda lg: self.avoid_special_or_enforce_pad_for_content(lg, done)}[kind]
+        return self._draw(logits2d.unsqueeze(1), temperature, sample, k, p, fn)
+
+    def _fused_rule(self, kind):
+        """the three mask rules (avoid_repeat_or_enforce_pad_for_* / avoid_special_or_enforce_pad_for_content above) as arguments of
+        kernels.sample_constrained"""
+        if kind == "coarse_pos":
+            return dict(pad_code=self.coarse_position_pad_code, forbid_from=self.max_coarse_postion_idx,
+                        forbid_codes=(self.coarse_position_pad_code,), keep_code=self.coarse_position_eos_code)
+        if kind == "fine_pos":
+            return dict(pad_code=self.fine_position_pad_code, forbid_codes=(self.fine_position_pad_code,),
+                        keep_code=self.fine_position_eos_code, late_forbid_code=self.fine_position_sos_code)
+        return dict(pad_code=self.content_pad_code, forbid_codes=(self.content_pad_code, self.content_eos_code, self.content_sos_code))
+
     @staticmethod
     def _draw(logits, temperature, sample, k, p, constrain):
         logits = constrain(logits[:, -1, :] / temperature)
@@ -424,12 +457,11 @@ class _SamplerMixin:
         done = torch.zeros(b, 1, device=dev)
         while not torch.all(done.bool()):
             pl = st.position_rows(x_c[:, -1:], x_pc[:, -1:], cpe, None, x_sc[:, -1:] if seg else None)
-            ix_pos = self._draw(pl.unsqueeze(1), temperature, sample, top_k_pos, top_p_pos,
-                                lambda lg: self.avoid_repeat_or_enforce_pad_for_coarse_position(lg, x_pc, done))
+            ix_pos = self._draw_rule(pl, temperature, sample, top_k_pos, top_p_pos, ("coarse_pos", x_pc, done))
             x_pc = torch.cat((x_pc, ix_pos), dim=1)
             done = done + (ix_pos == self.coarse_position_eos_code)
             cl = st.content_rows(ix_pos, cpe)
-            ix = self._draw(cl.unsqueeze(1), temperature, sample, top_k, top_p, lambda lg: self.avoid_special_or_enforce_pad_for_content(lg, done))
+            ix = self._draw_rule(cl, temperature, sample, top_k, top_p, ("content", None, done))
             if seg:
                 x_sc = torch.cat([x_sc, zeros1], dim=1)
             x_c = torch.cat((x_c, ix), dim=1)
@@ -463,8 +495,7 @@ class _SamplerMixin:
                 ix_pos = plan[:, j].unsqueeze(-1)
                 j += 1
             else:
-                ix_pos = self._draw(pl.unsqueeze(1), temperature, sample, top_k_pos, top_p_pos,
-                                    lambda lg: self.avoid_repeat_or_enforce_pad_for_fine_position(lg, taken, done))
+                ix_pos = self._draw_rule(pl, temperature, sample, top_k_pos, top_p_pos, ("fine_pos", taken, done))
                 taken = torch.cat([taken, ix_pos], dim=1)
             x_pf = torch.cat((x_pf, ix_pos), dim=1)
             done = done + (ix_pos == self.fine_position_eos_code)
@@ -479,7 +510,7 @@ class _SamplerMixin:
             if cl is None:                                   # no fine <sos>: the first fine content comes from the last coarse row
                 st.reset_content()
                 cl = st.content_rows(x_pc[:, :n_coarse], cpe)
-            ix = self._draw(cl.unsqueeze(1), temperature, sample, top_k, top_p, lambda lg: self.avoid_special_or_enforce_pad_for_content(lg, done))
+            ix = self._draw_rule(cl, temperature, sample, top_k, top_p, ("content", None, done))
             x_f = torch.cat((x_f, ix), dim=1)
             if seg:
                 x_sf = torch.cat([x_sf, zeros1 + 1], dim=1)
@@ -593,3 +624,11 @@ class ClassDualformer(Dualformer):
         forbid[:, self.content_pad_code] = True
         forbid[:, self.content_eos_code:] = True                          # <eos> and every class-label id
         return _mask_rows(logits, flag, forbid, None, self.content_pad_code)
+
+    def _fused_rule(self, kind):
+        if kind == "fine_pos":       # every id above <eos> (the class labels) is masked on live rows; <eos> keeps its logit
+            return dict(pad_code=self.fine_position_pad_code, forbid_codes=(self.fine_position_pad_code,),
+                        forbid_from=self.fine_position_eos_code + 1, keep_code=self.fine_position_eos_code)
+        if kind == "content":
+            return dict(pad_code=self.content_pad_code, forbid_codes=(self.content_pad_code,), forbid_from=self.content_eos_code)
+        return super()._fused_rule(kind)

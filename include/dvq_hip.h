@@ -361,6 +361,19 @@ int dvq_embed_scatter_add(const int64_t* idx, int64_t idx_bstride, const void* d
  * when dlogits != NULL, dlogits = (softmax - onehot) * gscale_dev[0] (0 on ignored rows and on columns >= V; row stride ldl) */
 int dvq_cross_entropy(const void* logits, int dtype, int64_t rows, int64_t V, int64_t ldl, const int64_t* target, int64_t ignore_index,
                       float* loss_sum, float* count, const float* gscale_dev, void* dlogits, dvq_stream_t stream);
+/* Fused constrained sampling of one token per row (Dualformer's sampler tail: dqtransformer_uncond_entropy.py:522-561 mask rules,
+ * models/stage2/utils.py:22-40 top-k / top-p, :328,350 softmax + multinomial / top-1) in ONE launch.  logits [B][ldl] (V <= 2048
+ * columns used), divided by `temperature`.  A LIVE row (finished == NULL or finished[row] == 0) masks column c when c >= forbid_from
+ * (pass V for none), c is one of forbid_codes4[0..3] (host array, -1 = unused), or c is listed in forbid_idx[row][0 .. n_forbid)
+ * (device, row stride forbid_ld; may be NULL); then keep_code (-1: none) gets its logit back; then late_forbid_code (-1: none) is
+ * masked.  A FINISHED row keeps pad_code only.  top_k == 0 / top_p outside (0, 1): filter off.  sample != 0: a draw from the filtered
+ * distribution with the device-resident generator `state` (uint64 [2]: key, counter; the counter is advanced by the call --
+ * capturable in a hipGraph); sample == 0: the most probable column (lowest index on ties).  out int64 [B]. */
+int dvq_sample_constrained(const void* logits, int dtype, int64_t B, int64_t V, int64_t ldl, float temperature,
+                           const int64_t* forbid_idx, int64_t n_forbid, int64_t forbid_ld, int64_t forbid_from,
+                           const int64_t* forbid_codes4, int64_t keep_code, int64_t late_forbid_code, int64_t pad_code,
+                           const float* finished, int top_k, float top_p, int sample, uint64_t* state, int64_t* out,
+                           dvq_stream_t stream);
 /* Fused causal multi-head self-attention (bf16, head_dim 64 or 128) -- CausalSelfAttention.forward, stackgpt.py:41-69:
  *   out = attn_drop(softmax(causal_mask(q k^T * scale))) v      per (batch, head), scores never materialised.
  * q, k, v, out, dout, dq, dk, dv: [B*T][n_head*head_dim] row-major (head h = columns h*head_dim ..); T % 8 == 0;

@@ -418,3 +418,68 @@ def test_sampling_script_end_to_end(dev, tmp_path):
     assert shapes == [(2, 3, 256, 256), (1, 3, 256, 256)]
     assert sorted(os.listdir(os.path.join(str(tmp_path), tag + "_image"))) == ["batch_0.png", "batch_1.png"]
     assert "token-steps/s" in r.stdout
+
+
+def _torch_draw_probs(df, logits, temperature, k, p, rule):
+    """filtered distribution of the op-by-op path (the reference's arithmetic) for `rule`"""
+    from dynamicvectorquantization_amd.stage2 import top_k_logits, top_p_logits
+    kind, sampled, done = rule
+    fn = {"coarse_pos": lambda lg: df.avoid_repeat_or_enforce_pad_for_coarse_position(lg, sampled, done),
+          "fine_pos": lambda lg: df.avoid_repeat_or_enforce_pad_for_fine_position(lg, sampled, done),
+          "content": lambda lg: df.avoid_special_or_enforce_pad_for_content(lg, done)}[kind]
+    lg = fn(logits / temperature)
+    if k is not None:
+        lg = top_k_logits(lg, k)
+    pr = torch.softmax(lg, dim=-1)
+    if p is not None:
+        pr = top_p_logits(pr, p)
+    return pr
+
+
+def test_fused_constrained_sampler_vs_op_by_op(dev):
+    """dvq_sample_constrained (mask rules + top-k / top-p + softmax + draw in one launch) against the op-by-op path that the sampler
+    goldens pin on the reference: (a) greedy picks are identical for the three rules incl. finished rows; (b) 4000 multinomial draws
+    never leave the filtered support and follow its probabilities (total-variation distance); (c) the generator state advances"""
+    import types
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd.stage2 import _SamplerMixinBase
+    df = _SamplerMixinBase.__new__(_SamplerMixinBase)
+    df.__dict__.update(coarse_position_pad_code=256, coarse_position_eos_code=257, max_coarse_postion_idx=255, fine_position_pad_code=1024,
+                       fine_position_eos_code=1025, fine_position_sos_code=1026, content_pad_code=1024, content_eos_code=1025,
+                       content_sos_code=1026)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    b = 16
+    done = torch.zeros(b, 1, device=dev)
+    done[3] = 1
+    done[11] = 2
+    cases = [("coarse_pos", 259, torch.randint(0, 259, (b, 40), generator=g).to(dev)),
+             ("fine_pos", 1027, torch.randint(0, 1027, (b, 300), generator=g).to(dev)),
+             ("content", 1027, None)]
+    for kind, v, sampled in cases:
+        logits = (torch.randn(b, v, generator=g) * 3).to(dev)
+        rule = (kind, sampled, done)
+        for (k, p) in [(None, None), (50, None), (None, 0.9), (100, 0.85)]:
+            ref = _torch_draw_probs(df, logits, 0.8, k, p, rule)
+            got = df._draw_rule(logits, 0.8, False, k, p, rule).view(-1)
+            assert torch.equal(got, ref.argmax(dim=-1)), (kind, k, p)
+        # multinomial: support and frequencies (row 0: live; row 3: finished -> always the pad code)
+        ref = _torch_draw_probs(df, logits, 1.0, 20, 0.95, rule)
+        n_draws = 4000
+        counts = torch.zeros(b, v, device=dev)
+        s0 = None
+        for _ in range(n_draws):
+            ix = df._draw_rule(logits, 1.0, True, 20, 0.95, rule)
+            counts.scatter_add_(1, ix, torch.ones(b, 1, device=dev))
+            s0 = s0 if s0 is not None else int(df._sampler_state[1])
+        assert int(df._sampler_state[1]) == s0 + n_draws - 1            # one counter tick per draw
+        assert float(counts[ref == 0].sum()) == 0.0, kind               # never outside the filtered support
+        tv = 0.5 * (counts / n_draws - ref).abs().sum(dim=1)
+        assert float(tv.max()) < 0.06, (kind, tv)                       # 20-entry support, 4000 draws: sampling noise ~0.03
+        pad = {"coarse_pos": 256, "fine_pos": 1024, "content": 1024}[kind]
+        assert float(counts[3, pad]) == n_draws and float(counts[11, pad]) == n_draws
+    # bf16 logits and a padded (strided) logits matrix
+    lg = (torch.randn(b, 1032, generator=g) * 2).to(dev).to(torch.bfloat16)
+    rule = ("content", None, done)
+    got = df._draw_rule(lg[:, :1027], 1.0, False, 10, None, rule).view(-1)
+    ref = _torch_draw_probs(df, lg[:, :1027].float(), 1.0, 10, None, rule).argmax(dim=-1)
+    assert torch.equal(got, ref)
