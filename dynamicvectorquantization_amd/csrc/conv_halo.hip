@@ -605,9 +605,13 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     if (blocks * dmax >= (1ll << 32)) return 0;        // (exactness range of the scalar tile decode)
     p.nblocks = (int)blocks;
     p.mg_gn = magic(p.gn); p.mg_tx = magic(p.tiles_x); p.mg_ty = magic(p.tiles_y);
+    static const int lds_pad = [] {      // experiment (DVQ_HALO_LDS_PAD=1): > 80 KB of LDS = ONE workgroup per CU
+        const char* e = getenv("DVQ_HALO_LDS_PAD");
+        return e != nullptr && atoi(e) != 0 ? 90 * 1024 - LDSB : 0;
+    }();
     auto go = [&](auto kern) {
-        dvq_ensure_dynamic_lds((const void*)kern, LDSB);
-        kern<<<dim3((unsigned)blocks), dim3(256), LDSB, stream>>>(p);
+        dvq_ensure_dynamic_lds((const void*)kern, LDSB + lds_pad);
+        kern<<<dim3((unsigned)blocks), dim3(256), LDSB + lds_pad, stream>>>(p);
     };
     if (cot == 128) {
         if (p.dbg == 6) go(conv3x3_halo_kernel<4, true>);
