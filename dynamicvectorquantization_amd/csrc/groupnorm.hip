@@ -92,27 +92,32 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                        const double* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        T* __restrict__ y, float* __restrict__ mean_rstd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* smr = reinterpret_cast<float*>(smem);          // [G][2] mean, rstd
     const GnGeom ge = gn_geom(C, G);
     const int64_t n = blockIdx.y;
     const double cnt = (double)HW * ge.cpg;
-    if (blockIdx.x == 0 && mean_rstd != nullptr) {
-        for (int g = threadIdx.x; g < G; g += 256) {
-            float m, r;
-            gn_mean_rstd(stats, n, G, g, cnt, eps, m, r);
+    // the fp64 division + square root once per GROUP and block (not 8 times per thread: with 64 pixels per thread that setup was
+    // a quarter of the kernel)
+    for (int g = threadIdx.x; g < G; g += 256) {
+        float m, r;
+        gn_mean_rstd(stats, n, G, g, cnt, eps, m, r);
+        smr[2 * g] = m;
+        smr[2 * g + 1] = r;
+        if (blockIdx.x == 0 && mean_rstd != nullptr) {
             mean_rstd[(n * G + g) * 2] = m;
             mean_rstd[(n * G + g) * 2 + 1] = r;
         }
     }
+    __syncthreads();
     const int col = threadIdx.x % ge.ncol, prow = threadIdx.x / ge.ncol;
     if (prow >= ge.rows_per_pass) return;
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int c = col * 8 + j;
-        float m, r;
-        gn_mean_rstd(stats, n, G, c / ge.cpg, cnt, eps, m, r);
-        sc[j] = r * gamma[c];
-        sh[j] = beta[c] - m * sc[j];
+        const int c = col * 8 + j, g = c / ge.cpg;
+        sc[j] = smr[2 * g + 1] * gamma[c];
+        sh[j] = beta[c] - smr[2 * g] * sc[j];
     }
     const int64_t p_end = min((int64_t)(blockIdx.x + 1) * gn_rows_per_block(HW), HW);
     const int64_t off = n * HW * C + col * 8;
@@ -240,11 +245,18 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const double* __restrict__ red, const T* __restrict__ addend,
                                                         T* __restrict__ dx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sm12 = reinterpret_cast<float*>(smem);          // [G][2] mean of dxhat, mean of dxhat * xhat
     const GnGeom ge = gn_geom(C, G);
     const int64_t n = blockIdx.y;
+    const double cnt = (double)HW * ge.cpg;
+    for (int g = threadIdx.x; g < G; g += 256) {           // (fp64 divisions once per group and block, not 16 per thread)
+        sm12[2 * g] = (float)(red[(n * G + g) * 2] / cnt);
+        sm12[2 * g + 1] = (float)(red[(n * G + g) * 2 + 1] / cnt);
+    }
+    __syncthreads();
     const int col = threadIdx.x % ge.ncol, prow = threadIdx.x / ge.ncol;
     if (prow >= ge.rows_per_pass) return;
-    const double cnt = (double)HW * ge.cpg;
     float mu[8], rs[8], ga[8], be[8], m1[8], m2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -253,8 +265,8 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x,
         rs[j] = mean_rstd[(n * G + g) * 2 + 1];
         ga[j] = gamma[c];
         be[j] = beta[c];
-        m1[j] = (float)(red[(n * G + g) * 2] / cnt);
-        m2[j] = (float)(red[(n * G + g) * 2 + 1] / cnt);
+        m1[j] = sm12[2 * g];
+        m2[j] = sm12[2 * g + 1];
     }
     const int64_t p_end = min((int64_t)(blockIdx.x + 1) * gn_rows_per_block(HW), HW);
     const int64_t off = n * HW * C + col * 8;
@@ -344,7 +356,7 @@ int dvq_gn_apply(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int
     if (silu == ACT_SILU) KERN<T, ACT_SILU><<<grid, dim3(256), LDS, s>>>(__VA_ARGS__);              \
     else if (silu == ACT_LRELU) KERN<T, ACT_LRELU><<<grid, dim3(256), LDS, s>>>(__VA_ARGS__);       \
     else KERN<T, ACT_NONE><<<grid, dim3(256), LDS, s>>>(__VA_ARGS__);
-    DVQ_DISPATCH_DTYPE(dtype, T, GN_ACT_SWITCH(gn_apply_kernel, 0, (const T*)x, HW, C, G, eps, stats, gamma, beta, (T*)y, mean_rstd));
+    DVQ_DISPATCH_DTYPE(dtype, T, GN_ACT_SWITCH(gn_apply_kernel, 2 * G * sizeof(float), (const T*)x, HW, C, G, eps, stats, gamma, beta, (T*)y, mean_rstd));
     DVQ_CHECK_LAUNCH("gn_apply");
     return DVQ_OK;
 }
@@ -380,7 +392,7 @@ int dvq_gn_bwd_dx(const void* x, const void* dy, int dtype, int64_t N, int64_t H
     if (int e = gn_check("dvq_gn_bwd_dx", N, HW, C, G)) return e;
     dim3 grid((unsigned)cdiv64(HW, gn_rows_per_block(HW)), (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
-    DVQ_DISPATCH_DTYPE(dtype, T, GN_ACT_SWITCH(gn_bwd_dx_kernel, 0, (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, (const T*)addend, (T*)dx));
+    DVQ_DISPATCH_DTYPE(dtype, T, GN_ACT_SWITCH(gn_bwd_dx_kernel, 2 * G * sizeof(float), (const T*)x, (const T*)dy, HW, C, G, mean_rstd, gamma, beta, red, (const T*)addend, (T*)dx));
     DVQ_CHECK_LAUNCH("gn_bwd_dx");
     return DVQ_OK;
 }
