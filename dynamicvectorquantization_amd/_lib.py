@@ -86,6 +86,7 @@ SIGNATURES = {
     "dvq_dual_merge_bwd": (i32, [vp, vp, i32, i64, i64, i64, i64, vp, vp, vp]),
     "dvq_add": (i32, [vp, vp, i32, i64, vp, vp]),
     "dvq_add_bias_bcast": (i32, [vp, vp, i32, i64, i64, vp, vp]),
+    "dvq_channel_shift_add8": (i32, [vp, vp, i32, i64, i32, vp, vp]),
     "dvq_sum_batch": (i32, [vp, i32, i64, i64, vp, vp]),
     "dvq_sumpool2x2": (i32, [vp, i32, i64, i64, i64, i64, vp, vp]),
     "dvq_cast": (i32, [vp, i32, vp, i32, i64, vp]),

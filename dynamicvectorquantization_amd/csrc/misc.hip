@@ -157,6 +157,22 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
     }
 }
 
+// y[.., c] = a[.., c] + (c >= shift ? b[.., c - shift] : 0) on 8-channel (one 16-byte vector) pixels: two 3-channel image gradients
+// side by side in ONE padded tensor, so that one weight-gradient call of the decoder's output conv serves both
+template <typename T>
+__global__ __launch_bounds__(256) void channel_shift_add8_kernel(const T* __restrict__ a, const T* __restrict__ b, int shift, int64_t npix,
+                                                                 T* __restrict__ y) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < npix; e += (int64_t)gridDim.x * 256) {
+        float u[8], v[8];
+        load8(a + e * 8, u);
+        load8(b + e * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j >= shift) u[j] += v[j - shift];
+        store8(y + e * 8, u);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void add_bias_bcast_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                              int64_t batch, int64_t inner8, T* __restrict__ y) {
@@ -594,6 +610,15 @@ int dvq_add(const void* a, const void* b, int dtype, int64_t n, void* y, dvq_str
     DVQ_DISPATCH_DTYPE(dtype, T, add_kernel<T><<<dim3(nblocks(n / 8, 256)), dim3(256), 0, (hipStream_t)stream>>>(
                                      (const T*)a, (const T*)b, n / 8, (T*)y););
     DVQ_CHECK_LAUNCH("add");
+    return DVQ_OK;
+}
+
+int dvq_channel_shift_add8(const void* a, const void* b, int dtype, int64_t npix, int shift, void* y, dvq_stream_t stream) {
+    DVQ_REQUIRE(a && b && y && npix > 0 && shift >= 0 && shift < 8, DVQ_EINVAL, "dvq_channel_shift_add8: bad arguments");
+    DVQ_REQUIRE(dtype == DVQ_BF16, DVQ_ESHAPE, "dvq_channel_shift_add8: 8-channel bf16 pixels (one 16-byte vector) only");
+    channel_shift_add8_kernel<bf16_t><<<dim3(nblocks(npix, 256)), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, shift,
+                                                                                                   npix, (bf16_t*)y);
+    DVQ_CHECK_LAUNCH("channel_shift_add8");
     return DVQ_OK;
 }
 

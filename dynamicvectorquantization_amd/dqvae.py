@@ -557,7 +557,20 @@ class DualGrainVQModel(nn.Module):
                                 gn_ss=t_co.s.get("gn_ss"))
             return buf
 
+        def wgrad_pair(g_a, g_b):
+            """both gradients from ONE pass over the decoder's last activation (1 GB at bs 64, 256^2: the weight-gradient kernel of
+            this 3-channel conv is bound by reading it): the two 3-channel image gradients ride side by side in the 8-channel
+            padded tensor (channels 0-2 / 3-5), the result rows are split afterwards"""
+            co = conv.out_channels
+            if g_a.dtype != torch.bfloat16 or g_a.shape[-1] != 8 or 2 * co > 8:
+                return wgrad(g_a), wgrad(g_b)
+            both = K.channel_shift_add8(g_a, g_b, co)
+            buf = torch.zeros((2 * co,) + tuple(conv.weight.shape[1:]), dtype=torch.float32, device=g_a.device)
+            K.conv2d_wgrad_oihw(t_co.s["d"], t_co.s["x"], both, conv.in_channels, 2 * co, buf, None, gn_ss=t_co.s.get("gn_ss"))
+            return buf[:co], buf[co:]
+
         conv.weight._dvq_wgrad = wgrad
+        conv.weight._dvq_wgrad_pair = wgrad_pair
 
     def ae_bwd(self, g_rec, g_qloss, tape, g_gate=None):
         cd = rt.compute_dtype()

@@ -573,6 +573,14 @@ def add(a, b):
     return y
 
 
+def channel_shift_add8(a, b, shift):
+    """a, b: [..., 8] bf16 pixels -> a + (b moved up by `shift` channels)"""
+    assert a.shape == b.shape and a.shape[-1] == 8 and a.dtype == torch.bfloat16
+    y = torch.empty_like(a)
+    check(lib().dvq_channel_shift_add8(_p(a), _p(b), dt(a), a.numel() // 8, int(shift), _p(y), _s()), "dvq_channel_shift_add8")
+    return y
+
+
 def add_bias_bcast(x, bias):
     batch = x.shape[0]
     y = torch.empty_like(x)

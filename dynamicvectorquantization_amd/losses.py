@@ -461,7 +461,8 @@ class VQLPIPSWithDiscriminator(nn.Module):
             if hook is None:
                 raise RuntimeError("adaptive discriminator weight needs the decoder's last-layer weight-gradient closure "
                                    "(`last_layer._dvq_wgrad`, published by DualGrainVQModel.ae_fwd)")
-            nll_grads, g_grads = hook(g_nll), hook(g_g)
+            pair = getattr(last_layer, "_dvq_wgrad_pair", None)
+            nll_grads, g_grads = pair(g_nll, g_g) if pair is not None else (hook(g_nll), hook(g_g))
             n_nll, n_g = torch.linalg.vector_norm(nll_grads), torch.linalg.vector_norm(g_grads)
             self.last_adaptive_norms = (n_nll, n_g)          # device scalars, kept for diagnostics / precision tests
             d_weight = (n_nll / (n_g + 1e-4)).clamp_(0.0, 1e4)

@@ -316,6 +316,9 @@ int dvq_dual_merge_bwd(const void* g_dual, const int64_t* grain, int dtype, int6
 int dvq_add(const void* a, const void* b, int dtype, int64_t n, void* y, dvq_stream_t stream);
 int dvq_add_bias_bcast(const void* x, const float* bias, int dtype, int64_t batch, int64_t inner, void* y,
                        dvq_stream_t stream);
+/* 8-channel bf16 pixels: y[p][c] = a[p][c] + (c >= shift ? b[p][c - shift] : 0) -- two 3-channel image gradients side by side in one
+ * padded tensor (calculate_adaptive_weight, vqperceptual_multidisc.py:97-107: both last-layer gradients from ONE weight-gradient call) */
+int dvq_channel_shift_add8(const void* a, const void* b, int dtype, int64_t npix, int shift, void* y, dvq_stream_t stream);
 /* sum over batch: out[inner] (fp32, accumulated) += sum_b x[b][inner] */
 int dvq_sum_batch(const void* x, int dtype, int64_t batch, int64_t inner, float* out, dvq_stream_t stream);
 /* 2x2 sum pool NHWC (backward of nearest x2): out[n,h,w,c] = sum in[n,2h+a,2w+b,c] */
