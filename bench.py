@@ -522,7 +522,7 @@ def main():
         if world == 1 and not args.no_extras and args.objective == "full" and args.bs == 64:
             # BASELINE configs 4 / 5 in the same driver command (compact blocks; bench_extra.py prints the full lines): each runs in
             # its own process after this one has released its memory, inside a time budget
-            del model
+            model = None                           # (already released when the autoencoder-only measurement ran)
             torch.cuda.empty_cache()
             out["extra_workloads"] = extra_workloads(args.extras_budget)
         try:        # RCCL prints its version banner through C stdio: flush it NOW so that the JSON line is the last line of stdout

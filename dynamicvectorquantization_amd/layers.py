@@ -107,17 +107,25 @@ class _SiluFn(torch.autograd.Function):
     """x * sigmoid(x) on dvq_silu / dvq_silu_bwd (any shape, fp32 or bf16 device tensor; other dtypes are computed in fp32)"""
 
     @staticmethod
+    def _flat8(t, dtype):
+        """flat copy in the kernel's dtype, zero-padded to a multiple of 8 elements (one 16-byte vector of bf16)"""
+        f = t.contiguous().reshape(-1).to(dtype)
+        pad = (-f.numel()) % 8
+        return torch.cat([f, f.new_zeros(pad)]) if pad else f
+
+    @staticmethod
     def forward(ctx, x):
-        xin = x.contiguous()
-        xc = xin if xin.dtype in (torch.float32, torch.bfloat16) else xin.float()
+        cd = x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        xc = _SiluFn._flat8(x, cd)
         ctx.save_for_backward(xc)
-        ctx.in_dtype = x.dtype
-        return K.silu(xc).to(x.dtype)
+        ctx.meta = (x.dtype, x.shape, x.numel())
+        return K.silu(xc)[: x.numel()].reshape(x.shape).to(x.dtype)
 
     @staticmethod
     def backward(ctx, dy):
         (xc,) = ctx.saved_tensors
-        return K.silu_bwd(xc, dy.contiguous().to(xc.dtype)).to(ctx.in_dtype)
+        dtype, shape, n = ctx.meta
+        return K.silu_bwd(xc, _SiluFn._flat8(dy, xc.dtype))[:n].reshape(shape).to(dtype)
 
 
 def nonlinearity(x):
