@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
     if constexpr (TRACE) tr[2] = wall_clock64();
     const int cpg = p.out_stats != nullptr ? p.Cout / p.out_groups : 0;     // channels per group: power of two <= 32 (launcher)
-    const bool pairs = cpg >= 2 && p.dbg != 8;        // statistics per channel PAIR (v_dot2_f32_bf16: one instruction per dword and moment)
+    const bool pairs = cpg >= 2 && p.dbg != 8 && p.dbg != 9;        // statistics per channel PAIR (v_dot2_f32_bf16: one instruction per dword and moment)
     float gs[8], gq[8];                 // output statistics of this thread's 8 channels / 4 pairs (chunk ch in every iteration)
 #pragma unroll
     for (int k = 0; k < 8; ++k) gs[k] = gq[k] = 0.f;
@@ -443,7 +443,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
                 }
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvq_u32x4, v), rsY, vo_px, so_iter(i), 0);
-            if (p.out_stats != nullptr) {
+            if (p.out_stats != nullptr && p.dbg == 9 && p.R != nullptr) {
+                // MEASUREMENT ONLY (DVQ_HALO_DBG=9, tools/debug/halo_data_probe.py): the arithmetic a GroupNorm-backward reduction
+                // fused into this epilogue would execute per element -- xhat, z, sigmoid, swish', dz, two accumulations -- on the
+                // staged value (as dy) and the residual tile (as x); the sums land in the statistics buffer (results meaningless)
+                const unsigned* pv = &v.x;
+                const unsigned* px = &rpre[i].x;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const float dyv = __uint_as_float(hh ? (pv[k] & 0xffff0000u) : (pv[k] << 16));
+                        const float xv = __uint_as_float(hh ? (px[k] & 0xffff0000u) : (px[k] << 16));
+                        const float xh = fmaf(xv, p.act_slope, p.mask_slope);          // (x - mean) * rstd as one fma
+                        const float z = fmaf(xh, 1.0625f, 0.03125f);                    // gamma * xhat + beta
+                        const float dz = dyv * swish_grad(z);
+                        gs[2 * k + hh] += dz;
+                        gq[2 * k + hh] = fmaf(dz, xh, gq[2 * k + hh]);
+                    }
+                }
+            } else if (p.out_stats != nullptr) {
                 const unsigned* pv = &v.x;
                 if (pairs) {
 #pragma unroll

@@ -293,6 +293,9 @@ class BatchNorm2d(HipModule):
         return dx.view(s["shape"])
 
 
+_SIDE_AFTER_DGRAD = os.environ.get("DVQ_SIDE_AFTER_DGRAD", "1") != "0"
+
+
 class Conv2d(HipModule):
     """torch.nn.Conv2d-compatible parameters ([Cout,Cin,KH,KW] + bias, same default init) driving the
     implicit-GEMM kernels.  `asym_pad` reproduces Downsample's F.pad(0,1,0,1); `upsample` reads the
@@ -401,17 +404,27 @@ class Conv2d(HipModule):
         """mask / mask_act: output and kind of the activation that produced this conv's input (its gate is applied to dx);
         need_dw=False: frozen parameters (LPIPS' VGG16, the discriminator during the generator update)"""
         x, d = tape.s["x"], tape.s["d"]
+        side = need_dw and need_dx and rt.side_wgrad_enabled()
+        dx = None
+        if need_dx and side and _SIDE_AFTER_DGRAD:
+            # the input gradient FIRST: the side stream then waits for it, so the weight gradient (matrix pipes) runs beside what
+            # follows the input gradient on this stream -- the HBM-bound GroupNorm backward -- instead of beside the input
+            # gradient itself, which wants the same matrix pipes
+            _, wt, _ = self.packed(x.dtype)
+            dx = K.conv2d_dgrad(d, dy, wt, mask=mask, mask_act=mask_act)
         if need_dw:
             db = _grad_buf(self.bias) if self.bias is not None else None
             # weight / bias gradients are accumulated by the kernel straight into the reference-layout .grad buffers
             gw, gss = _grad_buf(self.weight), tape.s.get("gn_ss")
-            if need_dx and rt.side_wgrad_enabled():
+            if side:
                 # on the side stream: nothing reads this gradient before the optimizer step / its bucket's exchange
                 rt.run_on_side(lambda: K.conv2d_wgrad_oihw(d, x, dy, self.in_channels, self.out_channels, gw, db, gn_ss=gss), x, dy)
             else:
                 K.conv2d_wgrad_oihw(d, x, dy, self.in_channels, self.out_channels, gw, db, gn_ss=gss)
         if not need_dx:
             return None
+        if dx is not None:
+            return dx
         _, wt, _ = self.packed(x.dtype)
         return K.conv2d_dgrad(d, dy, wt, mask=mask, mask_act=mask_act)
 

@@ -32,6 +32,16 @@ for (n, h, c, g, act) in [(64, 256, 128, 32, 1), (64, 128, 128, 32, 1), (64, 128
         K._GN_PARTIALS = flag
         us = timeit(lambda: K.gn_backward(x, dy, mr, gam, bet, dg, db, g, act))
         row.append(f"bwd({'partials' if flag else 'atomics'}) {us:7.1f} us {5 * nb / us / 1e6:5.2f} TB/s")
+    # the two passes of the backward on their own (partials path)
+    import ctypes as C
+    from dynamicvectorquantization_amd.kernels import lib, _p, _s, dt, check
+    K._GN_PARTIALS = True
+    red = torch.zeros(n, g, 2, dtype=torch.float64, device=dev)
+    part = torch.empty(lib().dvq_gn_bwd_partial_bytes(n, hw, c), dtype=torch.uint8, device=dev)
+    dxb = torch.empty_like(x)
+    us_r = timeit(lambda: check(lib().dvq_gn_bwd_reduce(_p(x), _p(dy), dt(x), n, hw, c, g, _p(mr), _p(gam), _p(bet), int(act), _p(red), _p(dg), _p(db), _p(part), _s()), "r"))
+    us_d = timeit(lambda: check(lib().dvq_gn_bwd_dx(_p(x), _p(dy), dt(x), n, hw, c, g, _p(mr), _p(gam), _p(bet), int(act), _p(red), None, _p(dxb), _s()), "d"))
+    row.append(f"reduce alone {us_r:7.1f} us  dx alone {us_d:7.1f} us")
     K._GN_PARTIALS = True
     dg.zero_(); db.zero_()
     d1 = K.gn_backward(x, dy, mr, gam, bet, dg, db, g, act); g1, b1 = dg.clone(), db.clone()
