@@ -9,10 +9,11 @@
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (incl. workspaces); the library allocates
  *     nothing, launches only on `stream`, never synchronises.  Process-wide state is limited to, and listed here:
- *     the scratch registration of dvq_set_workspace() (ONE caller-owned buffer per process, i.e. per rank / device:
- *     set it once before the first call that uses it; calls that find it too small fall back to atomics), caches of
- *     one-off hipFuncSetAttribute calls, and -- only under DVQ_USE_HIPBLASLT=1 -- the hipBLASLt handle / plan cache / 32-MiB
- *     workspace of csrc/blaslt.hip; dvq_probe_mfma_rate (diagnostics) is the one entry point that allocates and synchronises;
+ *     the scratch registration of dvq_set_workspace() (one caller-owned buffer per process, i.e. per rank / device, cut into
+ *     four equal slots that are handed to the streams using them, least recently used first: set it once before the first call
+ *     that uses it; calls that find a slot too small fall back to atomics) and caches of one-off hipFuncSetAttribute calls.
+ *     dvq_probe_mfma_rate and dvq_halo_trace_read (diagnostics) are the entry points that allocate or synchronise;
+ *     no vendor BLAS / DNN library is linked or loaded: every product is a kernel of this library;
  *   - every entry point issues KERNEL launches only (no memset / memcpy nodes), so a sequence of calls can be recorded by
  *     HIP stream capture after its first eager execution and replayed (the training step and the sampler do);
  *   - activations are NHWC ("pixel-major"): element (n,h,w,c) at ((n*H+h)*W+w)*C+c;
@@ -39,8 +40,8 @@ enum { DVQ_F32 = 0, DVQ_BF16 = 1 };
 enum { DVQ_OK = 0, DVQ_EINVAL = -1, DVQ_ESHAPE = -2, DVQ_EARCH = -3, DVQ_ELAUNCH = -4, DVQ_EWORKSPACE = -5 };
 
 const char* dvq_last_error(void);
-int dvq_version(void);     /* 103: round 2 (device-hyper AdamW, image pipeline, distance matrix, row sampler, fused AttnBlock
-                            * attention, MFMA-rate probe; hipBLASLt is opt-in) */
+int dvq_version(void);     /* 104: round 3 (fused constrained sampler, GroupNorm-backward partials argument, four workspace slots,
+                            * no vendor-library entry points) */
 /* 0 if the current HIP device is gfx950, DVQ_EARCH otherwise */
 int dvq_check_device(void);
 /* Diagnostics for the benchmark's roofline context (allocates, synchronises the stream; NOT for the hot path): TFLOP/s and shader
@@ -232,13 +233,14 @@ int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred,
                 int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int impl,
                 dvq_stream_t stream);
 
-/* Register a caller-owned device scratch buffer (one per process, used stream-ordered on the caller's stream).  With
- * >= 76 MiB registered the split-K weight-gradient kernels store per-workgroup partial tiles with plain writes and fold
- * them in a second kernel instead of issuing cross-XCD fp32 atomics.  ptr = NULL, bytes = 0 unregisters. */
+/* Register a caller-owned device scratch buffer (one per process; the library cuts it into four slots, one per stream that
+ * uses it, so the side-stream weight gradients and the main stream never share one).  With >= 76 MiB per slot the split-K
+ * weight-gradient kernels store per-workgroup partial tiles with plain writes and fold them in a second kernel instead of
+ * issuing cross-XCD fp32 atomics.  ptr = NULL, bytes = 0 unregisters. */
+int dvq_set_workspace(void* ptr, int64_t bytes);
 /* diagnostics (DVQ_HALO_DBG=6): per workgroup of the LAST 3x3 halo-conv launch {CU key | (time before the final store drain) << 16,
  * start, end of the main loop, end, tile staged, tile stored} in 10-ns ticks; dst holds max_records x 6 uint64.  Synchronises. */
 int dvq_halo_trace_read(unsigned long long* dst, int64_t max_records);
-int dvq_set_workspace(void* ptr, int64_t bytes);
 
 /* ---- loss networks (LPIPS + PatchGAN), modules/losses/lpips.py, modules/discriminator/model.py -------------------
  * BatchNorm2d (training mode) = dvq_gn_* with N=1, HW=N*H*W, G=C (one group per channel over the whole batch). */
