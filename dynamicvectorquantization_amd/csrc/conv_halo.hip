@@ -187,6 +187,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
 
     const int swzB = (l31 >> 1) & 7;
     const int nchunks = p.dbg == 2 ? 0 : (p.Cin >> 6);
+    // Residual add on the MATRIX pipe (128-channel tiles): y = conv + R is computed as acc += I * R^T -- 16 extra MFMAs per wave (3 % of
+    // the tile's) on a residual tile that LDS-DMA drops into the dead halo / weight stages under the last MFMAs of the loop, instead
+    // of ~450 unpack / add / pack vector instructions per lane in the store loop, which issue once per MFMA of the CU neighbour
+    // (fwd + residual at 128 -> 128, 256^2, B = 64: 1.166 ms with the vector adds against 1.011 ms without a residual).  The sum is
+    // rounded once (fp32 accumulator) where the reference rounds the conv output and the sum.  DVQ_HALO_DBG=3 keeps the vector path.
+    const bool res_mfma = NT == 4 && p.R != nullptr && !p.res_mask && p.dbg != 3 && p.dbg != 9;
+    auto issue_residual = [&]() {
+        // wave's own 64 pixels x 128 channels, one 1-KiB DMA per 4 pixels; 16-byte chunk c of pixel px sits at position c ^ (px & 7)
+        const __amdgpu_buffer_rsrc_t rsRd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(p.R + (int64_t)n * p.H * p.W * p.Cout), 0, p.H * p.W * p.Cout * 2, 0x00020000);
+        const int pr = lane >> 4, q = lane & 15;
+        const int ce = n0 + (q ^ pr) * 8, co = n0 + (q ^ (4 + pr)) * 8;
+        const int vo_e = ce < p.Cout ? (pr * p.Cout + ce) * 2 : VOFF_OOB, vo_o = co < p.Cout ? (pr * p.Cout + co) * 2 : VOFF_OOB;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsRd, (__attribute__((address_space(3))) void*)(smem + (wave * 64 + 4 * i) * 256), 16,
+                                                     (i & 1) ? vo_o : vo_e, (((y0 + MT * wm + (i >> 3)) * p.W + x0 + 4 * (i & 7)) * p.Cout) * 2, 0, 0);
+    };
     if (nchunks > 0) {
         issue_halo_buf(0);
 #pragma unroll
@@ -265,7 +283,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
     int g = 0;                                      // taps done: weight stage of tap g is g & 1
     for (int c = 0; c < nchunks; ++c) {
         const int c0 = c * 64;
-        if (p.gn_ss != nullptr && tid < 128) ssl[tid] = p.gn_ss[((int64_t)n * p.Cin + c0) * 2 + tid];
+        // {scale, shift} of channel pair (2 q, 2 q + 1) stored as {scale, scale', shift, shift'}: operands of the packed-fp32 instructions
+        if (p.gn_ss != nullptr && tid < 128)
+            ssl[(tid >> 2) * 4 + (tid & 1) * 2 + ((tid >> 1) & 1)] = p.gn_ss[((int64_t)n * p.Cin + c0) * 2 + tid];
         __syncthreads();                            // vmcnt(0) + barrier: this chunk's halo (and its first weight stage) have landed
         if (p.gn_ss != nullptr) {
             // fused GroupNorm + swish: y = z * sigmoid(z), z = x * scale[c] + shift[c], applied in place to the halo tile
@@ -281,9 +301,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
                 const float* sc = ssl + cg * 16;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float lo = swishf(fmaf(__uint_as_float(pv[k] << 16), sc[4 * k + 0], sc[4 * k + 1]));
-                    const float hi = swishf(fmaf(__uint_as_float(pv[k] & 0xffff0000u), sc[4 * k + 2], sc[4 * k + 3]));
-                    pv[k] = pack_bf16x2(lo, hi);
+                    // both halves of a dword per instruction (v_pk_fma / mul / add_f32): 11 instead of 15 vector instructions per pair, same
+                    // operations and roundings as swishf(fmaf(x, scale, shift)) -- this phase is bound by instruction issue
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 xv = {__uint_as_float(pv[k] << 16), __uint_as_float(pv[k] & 0xffff0000u)};
+                    const f32x2 z = __builtin_elementwise_fma(xv, *reinterpret_cast<const f32x2*>(sc + 4 * k), *reinterpret_cast<const f32x2*>(sc + 4 * k + 2));
+                    const f32x2 t = z * -1.4426950408889634f;
+                    const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+                    const f32x2 o = z * (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                    pv[k] = pack_bf16x2(o.x, o.y);
                 }
                 *ptr = v;
             }
@@ -324,6 +350,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
                     issue_halo_buf(c0 + 64);                   // the halo tile is dead: refill it under the last MFMAs
 #pragma unroll
                     for (int i = 0; i < NPH; ++i) issue_b_piece(i, tap2, c02, buf);
+                } else if (res_mfma && p.dbg != 31) {
+                    issue_residual();                          // every stage is dead: the residual tile lands under the last MFMAs
                 }
                 mfma_step(1, I0{}, I0{});
             }
@@ -332,6 +360,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
 #pragma unroll 1
         for (int tap = 0; tap < 8; ++tap) tap_body(tap, std::false_type{});
         tap_body(8, std::true_type{});
+    }
+
+    if constexpr (NT == 4) {
+        if (res_mfma) {
+            if (nchunks == 0) issue_residual();
+            // identity fragments: row co = l31 of I holds a one at k = co, i.e. element e = l31 - 16 s - 8 half of k-step s
+            bf16x8 idf[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int e = l31 - 16 * s2 - 8 * half;
+                dvq_u32x4 w4;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) w4[d] = (e >> 1) == d ? ((e & 1) ? 0x3f800000u : 0x00003f80u) : 0u;     // (e < 0: e >> 1 < 0)
+                idf[s2] = __builtin_bit_cast(bf16x8, w4);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+            const char* rl = smem + (wave * 64 + l31) * 256;
+            if (p.dbg != 32)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 rf = *reinterpret_cast<const bf16x8*>(rl + mt * 32 * 256 + (((nt * 4 + s2 * 2 + half) ^ (l31 & 7)) << 4));
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idf[s2], rf, acc[mt][nt], 0, 0, 0);
+                    }
+        }
     }
 
     // ---- epilogue: stage the 256 px x CO_T tile as bf16 rows, then 16-byte stores -------------------------------------------
@@ -343,7 +399,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
     }
     if constexpr (TRACE) tr[1] = wall_clock64();
     const bool act = p.act_slope != 1.f;
-    const bool early_act = act && (p.R == nullptr || p.res_mask);     // no residual add between the accumulator and the activation
+    const bool resv = p.R != nullptr && !res_mfma;                    // residual / gate tile handled by the store loop
+    const bool early_act = act && (!resv || p.res_mask);              // no residual add between the accumulator and the activation
     // store loop roles: thread q = tid + 256 i handles 16-byte chunk ch = tid % CPRW of tile pixel lp = t + PPI * i, t = tid / CPRW
     constexpr int ITERS = CPRW, PPI = NTH / CPRW;            // (256 pixels x CPRW chunks) / 256 threads; pixels per iteration
     const int tq = tid / CPRW, ch = tid % CPRW;
@@ -362,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
     };
     // residual / gate tile: requested before the staging so that its latency hides behind it
     uint4 rpre[ITERS];
-    if (p.R != nullptr) {
+    if (resv) {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) rpre[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo_px, so_iter(i), 0));
     }
@@ -409,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
             uint4 v = *reinterpret_cast<const uint4*>(lane_ld + i * (PPI * ROWS));
-            if (p.R != nullptr) {
+            if (resv) {
                 const uint4 rv = rpre[i];
                 unsigned* pv = &v.x;
                 const unsigned* pr = &rv.x;

@@ -43,7 +43,7 @@ r = data["randn"]
 d = conv._desc(r)
 K.ensure_workspace(dev)
 stats = torch.zeros(B, 32, 2, dtype=torch.float64, device=dev)
-for name, x in data.items():
+for name, x in (data.items() if os.environ.get("PROBE_DATA", "1") != "0" else []):
     out = {"fwd": timeit(lambda: K.conv2d_fwd(d, x, w, bias, None)), "dgrad": timeit(lambda: K.conv2d_dgrad(d, x, wt))}
     print(f"{name:14s}", json.dumps(out), flush=True)
 x = data["swish(randn)"]
@@ -54,3 +54,9 @@ print("  fwd + residual   ", timeit(lambda: K.conv2d_fwd(d, x, w, bias, r)))
 print("  fwd + stats      ", timeit(lambda: K.conv2d_fwd(d, x, w, bias, None, out_stats=stats, out_groups=32)))
 print("  fwd + res + stats", timeit(lambda: K.conv2d_fwd(d, x, w, bias, r, out_stats=stats, out_groups=32)))
 print("  dgrad            ", timeit(lambda: K.conv2d_dgrad(d, x, wt)))
+gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+ss, _ = K.gn_scale_shift(r, gam, bet, 32)
+print("  fwd + gn prologue          ", timeit(lambda: K.conv2d_fwd(d, r, w, bias, None, gn_ss=ss)))
+print("  fwd + gn + stats           ", timeit(lambda: K.conv2d_fwd(d, r, w, bias, None, gn_ss=ss, out_stats=stats, out_groups=32)))
+print("  fwd + gn + res             ", timeit(lambda: K.conv2d_fwd(d, r, w, bias, r, gn_ss=ss)))
+print("  fwd + gn + res + stats     ", timeit(lambda: K.conv2d_fwd(d, r, w, bias, r, gn_ss=ss, out_stats=stats, out_groups=32)))
