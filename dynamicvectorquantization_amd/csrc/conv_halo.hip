@@ -15,7 +15,6 @@
 
 namespace {
 
-__device__ uint4 h_zero_page[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 
 constexpr int TH = 8, TW = 32;                 // pixel tile
 constexpr int HW_ = TW + 2;                    // halo width
@@ -739,6 +738,7 @@ struct WgParams {
     const float* gn_ss;  // optional fused GroupNorm+swish on x: {scale, shift} fp32 [N][Cin][2] (recomputed, never stored)
     float* ws;           // split-K partials: [nsplit][gi*gj][9][128][64] fp32 (+ bias partials behind), or null -> atomics
     float* ws_bias;      // [nsplit][gi*gj][128]
+    int dbg;             // profiling experiments only (DVQ_WGRAD_DBG): 1 = do not wait for the DMA, 2 = skip the MFMA loop, 3 = no DMA
 };
 
 // Cross-XCD fp32 atomics resolve at the memory side and cost far more than plain stores: with a workspace every
@@ -804,50 +804,85 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = THIN ? 0 : (wave & 3), nt = wave >> 2;
     const int st_lo = THIN ? 2 * (wave & 3) : 0, st_hi = THIN ? st_lo + 2 : 8;     // pixel steps (16 px each) of this wave
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(h_zero_page);
-
     int wi = xcd_remap(blockIdx.x, p.gi * p.gj * p.nsplit);
     const int split = wi / (p.gi * p.gj);           // the (co-tile, ci-chunk) blocks of one pixel range run together
     wi -= split * p.gi * p.gj;
     const int n0 = (wi % p.gi) * 128, j0 = (wi / p.gi) * 64;
     const int tbeg = split * p.tiles_per_split, tend = min(p.ntiles, tbeg + p.tiles_per_split);
 
-    auto issue = [&](int t, int buf) {
+    // ---- DMA of a tile (dy: 32 pieces of 4 pixel rows, x halo: 26 pieces of 8 pixel rows; piece pc belongs to wave pc % 8) ----------
+    // Everything that depends on the lane is computed ONCE: a 32-bit byte offset per piece relative to the tile's first (halo) pixel
+    // and the halo pieces' edge flags.  Per tile the scalar unit moves two buffer descriptors to the tile (the tile counters advance
+    // incrementally) and the vector unit spends 3 instructions per halo piece on the padding mask.  (Until round 3 every piece
+    // recomputed its pixel decode and a 64-bit address per tile: ~40 vector + ~60 scalar instructions x 8 pieces at the head of every
+    // tile, both waves of a SIMD at the same time -- the matrix pipe sat idle for a third of the kernel.)
+    typedef int wg_int32x4 __attribute__((ext_vector_type(4)));
+    const int SWd = p.W >> p.up, SHt = p.H >> p.up;
+    int vo_dy[4], vo_h[4], fl_h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pr = (wave + 8 * i) * 4 + (lane >> 4);                    // tile pixel of this lane's dy row
+        const int col = n0 + ((lane & 15) ^ ((pr & 3) << 2)) * 8;
+        vo_dy[i] = col < p.Cout ? (((pr >> 5) * p.W + (pr & 31)) * p.Cout + col) * 2 : VOFF_OOB;
+        const int hp = (wave + 8 * i) * 8 + (lane >> 3);                    // halo pixel of this lane's x row
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int cg = (lane & 7) ^ (((hp >> 1) & 1) << 2);
+        // source pixel relative to the pixel above-left of the tile origin (nearest x2 upsampling folded in: floor((h - 1) / 2) + 1)
+        const int sr = p.up ? ((hy - 1) >> 1) + 1 : hy, sc = p.up ? ((hx - 1) >> 1) + 1 : hx;
+        vo_h[i] = ((sr * SWd + sc) * p.Cin + j0 + cg * 8) * 2;
+        fl_h[i] = (hy == 0 ? 1 : 0) | (hy == WTH + 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == HW_ - 1 ? 8 : 0) | (hp >= WHROWS ? 16 : 0);
+    }
+    int it_n, it_ty, it_tx;                          // the next tile to be issued (tiles are issued in increasing order from tbeg)
+    {
         const int txy = p.tiles_x * p.tiles_y;
-        const int n = t / txy, rem = t - n * txy;
-        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int y0 = ty * WTH, x0 = tx * TW;
-        const int64_t img = (int64_t)n * p.H * p.W;
+        it_n = tbeg / txy;
+        const int rem = tbeg - it_n * txy;
+        it_ty = rem / p.tiles_x;
+        it_tx = rem - it_ty * p.tiles_x;
+    }
+    auto make_rsrc = [&](const bf16_t* base) {
+        const unsigned long long a = (unsigned long long)base;
+        wg_int32x4 r;
+        r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+        r.z = 0x7fff0000;                            // (below VOFF_OOB: masked lanes read zero)
+        r.w = 0x00020000;
+        return r;
+    };
+    auto issue = [&](int /*t*/, int buf) {
+        const int y0 = it_ty * WTH, x0 = it_tx * TW;
+        const wg_int32x4 rsD = make_rsrc(p.DY + (((int64_t)it_n * p.H + y0) * p.W + x0) * p.Cout);
+        // (for the first tile of the tensor this base lies one row and one pixel before it: only masked lanes would go there)
+        const wg_int32x4 rsX = make_rsrc(p.X + (((int64_t)it_n * SHt + (y0 >> p.up) - 1) * SWd + (x0 >> p.up) - 1) * p.Cin);
+        const int edge = (it_ty == 0 ? 1 : 0) | (it_ty == p.tiles_y - 1 ? 2 : 0) | (it_tx == 0 ? 4 : 0) | (it_tx == p.tiles_x - 1 ? 8 : 0) | 16;
         char* base = smem + buf * WSTAGE;
-#pragma unroll 1
-        for (int pc = wave; pc < WNPIECES; pc += 8) {
-            const bf16_t* src;
-            char* dst;
-            if (pc < 32) {                               // dy: 4 pixel rows of 256 B
-                const int pr = pc * 4 + (lane >> 4);
-                const int cg = (lane & 15) ^ ((pr & 3) << 2);
-                const int col = n0 + cg * 8;
-                src = col < p.Cout ? p.DY + (img + (int64_t)(y0 + (pr >> 5)) * p.W + x0 + (pr & 31)) * p.Cout + col : zero;
-                dst = base + pc * 4 * 256;
-            } else {                                     // x halo: 8 pixel rows of 128 B
-                const int hc = pc - 32;
-                const int hp = hc * 8 + (lane >> 3);
-                const int hy = hp / HW_, hx = hp - hy * HW_;
-                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                const int cg = (lane & 7) ^ (((hp >> 1) & 1) << 2);
-                const bool ok = hp < WHROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-                const int SWd = p.W >> p.up;
-                src = ok ? p.X + ((int64_t)n * (p.H >> p.up) * SWd + (int64_t)(gy >> p.up) * SWd + (gx >> p.up)) * p.Cin + j0 + cg * 8 : zero;
-                dst = base + WDYB + hc * 8 * ROWB;
+        // issued from inline assembly: the compiler orders every ds_read_b64_tr behind ALL LDS-DMA it knows to be pending
+        // (s_waitcnt vmcnt(0) before the first transpose read of the tile), which would serialise this prefetch of the next
+        // tile with the reads of the current one; the pieces are drained by hand before the barrier that publishes them
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(base + (wave + 8 * i) * 4 * 256));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(l), "v"(vo_dy[i]), "s"(rsD));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (wave + 8 * i < WHPIECES) {
+                const int vo = (fl_h[i] & edge) ? VOFF_OOB : vo_h[i];
+                const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(base + WDYB + (wave + 8 * i) * 8 * ROWB));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(l), "v"(vo), "s"(rsX));
             }
-            // issued from inline assembly: the compiler orders every ds_read_b64_tr behind ALL LDS-DMA it knows to be pending
-            // (s_waitcnt vmcnt(0) before the first transpose read of the tile), which would serialise this prefetch of the next
-            // tile with the reads of the current one; the pieces are drained by hand before the barrier that publishes them
-            const unsigned ldst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)dst);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(ldst), "v"(src));
+        }
+        if (++it_tx == p.tiles_x) {
+            it_tx = 0;
+            if (++it_ty == p.tiles_y) {
+                it_ty = 0;
+                ++it_n;
+            }
         }
     };
-    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); };
+    auto dma_wait = [&]() {
+        if (p.dbg != 1) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    };
 
     // fragment lane constants (transpose reads: lanes 4r..4r+3 of a 16-lane group address row r, 8 B each)
     const int g = lane >> 4, li = lane & 15;
@@ -855,6 +890,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
     const int chA = mt * 4 + 2 * (g & 1) + ((li & 3) >> 1);        // 16-B chunk of the dy row (co)
     const int chB = nt * 4 + 2 * (g & 1) + ((li & 3) >> 1);        // 16-B chunk of the halo row (ci)
     const int sub = (li & 1) * 8;
+    // lane bases of the pipelined loop: x fragment of tap column kw in halo row (even multiple of HW_) + kw + frow, swizzle bit =
+    // row parity ^ ((kw + frow) >> 1 & 1); dy fragment in tile row frow (its swizzle (row & 3) << 2 does not depend on the step)
+    int lbx[3][2];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+            lbx[kw][par] = (kw + frow) * ROWB + ((chB ^ (((((kw + frow) >> 1) & 1) ^ par) << 2)) << 4) + sub;
+    const int lba = frow * 256 + ((chA ^ ((frow & 3) << 2)) << 4) + sub;
 
     f32x16 acc[9];
 #pragma unroll
@@ -870,7 +914,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
         __syncthreads();
         for (int t = tbeg; t < tend; ++t) {
             const int buf = (t - tbeg) & 1;
-            if (p.gn_ss == nullptr && t + 1 < tend) issue(t + 1, buf ^ 1);
+            if (p.gn_ss == nullptr && t + 1 < tend && p.dbg != 3) issue(t + 1, buf ^ 1);
             const char* sdy = smem + buf * WSTAGE;
             const char* shl = sdy + WDYB;
             if (p.gn_ss != nullptr) {
@@ -901,46 +945,106 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
                 __syncthreads();
                 if (t + 1 < tend) issue(t + 1, buf ^ 1);     // prefetch after the barrier
             }
+            if (p.dbg == 2) {
+            } else if constexpr (!THIN) {
+                // Software pipeline over the tile's 8 x 9 (pixel step, tap) MFMAs: the transpose reads of x fragment q + 3 are issued
+                // before MFMA q (a ds_read_b64_tr round trip is ~100+ cycles under load; read -> wait -> MFMA one deep left each wave
+                // waiting on the LDS for most of every MFMA slot, both waves of a SIMD alike).  Fully unrolled: every fragment address is
+                // a lane constant (6 x bases by tap column and row parity -- the swizzle bit -- plus the dy base) + an immediate.
+                const char* lx[3][2];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int par = 0; par < 2; ++par) lx[kw][par] = shl + lbx[kw][par];
+                const char* la = sdy + lba;
+                constexpr int NS = 4, NQ = 72;
+                bf16x8 bq[NS], aq[2];
+                auto read_a = [&](int st) {
+                    const int o = ((st >> 1) * 32 + (st & 1) * 16) * 256;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(la + o));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(la + o + 4 * 256));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        aq[st & 1][j] = lo[j];
+                        aq[st & 1][4 + j] = hi[j];
+                    }
+                };
+                auto read_b = [&](int q) {
+                    const int st = q / 9, tap = q - st * 9, kh = tap / 3, kw = tap - kh * 3;
+                    const int rk = (st >> 1) + kh;
+                    const int o = (rk * HW_ + (st & 1) * 16) * ROWB;
+                    const char* b0 = lx[kw][rk & 1];
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(b0 + o));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(b0 + o + 4 * ROWB));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bq[q % NS][j] = lo[j];
+                        bq[q % NS][4 + j] = hi[j];
+                    }
+                };
+                read_a(0);
+#pragma unroll
+                for (int q = 0; q < NS - 1; ++q) read_b(q);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int st = q / 9, tap = q - st * 9;
+                    if (q + NS - 1 < NQ) read_b(q + NS - 1);
+                    if (tap == 4 && st + 1 < 8) read_a(st + 1);
+                    if (tap == 0 && do_bias) {
+                        const uint4 u = __builtin_bit_cast(uint4, aq[st & 1]);
+                        bsum += (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) +
+                                (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u)) +
+                                (__uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u)) +
+                                (__uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u));
+                    }
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[st & 1], bq[q % NS], acc[tap], 0, 0, 0);
+                    const bool rb = q + NS - 1 < NQ, ra = tap == 4 && st + 1 < 8;
+                    if (rb && ra) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    else if (rb || ra) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+            } else {
 #pragma unroll 2
-            for (int st = st_lo; st < st_hi; ++st) {       // 16 pixels per step: image row rr, half hs
-                const int rr = st >> 1, hs = st & 1;
-                bf16x8 a;
-                {
-                    const int r0 = rr * 32 + hs * 16 + frow;            // dy tile row of the first transpose read
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (lds_bf16x4_t*)(sdy + r0 * 256 + ((chA ^ ((r0 & 3) << 2)) << 4) + sub));
-                    const int r1 = r0 + 4;
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (lds_bf16x4_t*)(sdy + r1 * 256 + ((chA ^ ((r1 & 3) << 2)) << 4) + sub));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        a[j] = lo[j];
-                        a[4 + j] = hi[j];
+                for (int st = st_lo; st < st_hi; ++st) {       // 16 pixels per step: image row rr, half hs
+                    const int rr = st >> 1, hs = st & 1;
+                    bf16x8 a;
+                    {
+                        const int r0 = rr * 32 + hs * 16 + frow;            // dy tile row of the first transpose read
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (lds_bf16x4_t*)(sdy + r0 * 256 + ((chA ^ ((r0 & 3) << 2)) << 4) + sub));
+                        const int r1 = r0 + 4;
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (lds_bf16x4_t*)(sdy + r1 * 256 + ((chA ^ ((r1 & 3) << 2)) << 4) + sub));
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            a[j] = lo[j];
+                            a[4 + j] = hi[j];
+                        }
                     }
-                }
-                if (do_bias) {
-                    const uint4 u = __builtin_bit_cast(uint4, a);
-                    bsum += (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) +
-                            (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u)) +
-                            (__uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u)) +
-                            (__uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u));
-                }
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int kh = tap / 3, kw = tap - kh * 3;
-                    const int h0 = (rr + kh) * HW_ + hs * 16 + kw + frow;
-                    const int h1 = h0 + 4;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (lds_bf16x4_t*)(shl + h0 * ROWB + ((chB ^ (((h0 >> 1) & 1) << 2)) << 4) + sub));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (lds_bf16x4_t*)(shl + h1 * ROWB + ((chB ^ (((h1 >> 1) & 1) << 2)) << 4) + sub));
-                    bf16x8 b;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        b[j] = lo[j];
-                        b[4 + j] = hi[j];
+                    if (do_bias) {
+                        const uint4 u = __builtin_bit_cast(uint4, a);
+                        bsum += (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) +
+                                (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u)) +
+                                (__uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u)) +
+                                (__uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u));
                     }
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
+    #pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int kh = tap / 3, kw = tap - kh * 3;
+                        const int h0 = (rr + kh) * HW_ + hs * 16 + kw + frow;
+                        const int h1 = h0 + 4;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (lds_bf16x4_t*)(shl + h0 * ROWB + ((chB ^ (((h0 >> 1) & 1) << 2)) << 4) + sub));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (lds_bf16x4_t*)(shl + h1 * ROWB + ((chB ^ (((h1 >> 1) & 1) << 2)) << 4) + sub));
+                        bf16x8 b;
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            b[j] = lo[j];
+                            b[4 + j] = hi[j];
+                        }
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
+                    }
                 }
             }
             dma_wait();
@@ -1009,6 +1113,11 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
     p.c_oihw = c_oihw;
     p.up = up;
     p.gn_ss = gn_ss;
+    static const int wdbg_env = [] {
+        const char* e = getenv("DVQ_WGRAD_DBG");
+        return e != nullptr ? atoi(e) : 0;
+    }();
+    p.dbg = wdbg_env;
     const int64_t nblk = (int64_t)p.gi * p.gj * p.nsplit;
     int64_t ws_bytes = 0;
     char* wsp = (char*)dvq_workspace_stream(stream, &ws_bytes);

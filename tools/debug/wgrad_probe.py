@@ -20,7 +20,8 @@ def timeit(fn, reps=10):
     return s.elapsed_time(e) / reps
 
 
-for (n, h, cin, cout, per_step) in [(64, 256, 128, 128, 10), (64, 128, 128, 128, 9), (64, 64, 256, 256, 9), (64, 32, 256, 256, 20), (64, 128, 256, 128, 1), (64, 256, 128, 8, 3)]:
+SHAPES = [(64, 256, 128, 128, 10), (64, 128, 128, 128, 9), (64, 64, 256, 256, 9), (64, 32, 256, 256, 20), (64, 128, 256, 128, 1), (64, 256, 128, 8, 3)]
+for (n, h, cin, cout, per_step) in SHAPES[:int(os.environ.get('PROBE_NSHAPES', 6))]:
     conv = Conv2d(cin, cout, 3, 1, 1).to(dev)
     x = torch.randn(n, h, h, cin, device=dev).to(torch.bfloat16)
     cout_p = -(-cout // 8) * 8
