@@ -138,10 +138,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
         const int row = wave * (CO_T / NW) + i * 8 + lrow;
         // rows past Cout re-read the last real row: their output channels are never stored nor counted in the statistics
         boff[i] = min(n0 + row, p.Cout - 1) * 9 * p.Cin + (cpos ^ ((row >> 1) & 7)) * 8;
+        if (p.dbg >= 35 && p.dbg <= 38) boff[i] = VOFF_OOB / 2;        // experiment: no weight traffic (the DMA writes zeros)
     }
     // DMA through buffer descriptors (base in SGPRs, one 32-bit lane offset, tap / channel chunk as the scalar offset): no
     // per-piece 64-bit address arithmetic, and padding pixels are simply out of the descriptor's range (they read as zero)
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Wt), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Wt), 0, p.Cout * 9 * p.Cin * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Xn), 0, (p.H >> p.up) * SWd * p.Cin * 2, 0x00020000);
     // halo pieces of this wave (wave, wave + 4, ...): byte offset of this lane's 16 bytes at channel 0, once per TILE
     int hvo[NHP];
@@ -170,11 +171,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
             hvo[i] = ok ? (((gy >> p.up) * SWd + (gx >> p.up)) * p.Cin + (cpos ^ ((hp >> 1) & 7)) * 8) * 2 : VOFF_OOB;
         }
     }
+    if (p.dbg == 36 || p.dbg == 37) {                                  // experiment: no halo traffic either
+#pragma unroll
+        for (int i = 0; i < NHP; ++i) hvo[i] = VOFF_OOB;
+    }
     auto issue_b_piece = [&](int i, int tapx, int c0, int buf) {
         const int tb = p.flip ? 8 - tapx : tapx;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             rsW, (__attribute__((address_space(3))) void*)(bst + buf * BSTAGE + (wave * (CO_T / NW) + i * 8) * ROWB), 16, boff[i] * 2,
-            (tb * p.Cin + c0) * 2, 0, 0);
+            p.dbg == 39 || p.dbg == 40 ? 0 : (tb * p.Cin + c0) * 2, 0, 0);      // (39 / 40: every tap re-reads the same 16 KB: L1 hits)
     };
     auto issue_halo_buf = [&](int c0) {
 #pragma unroll
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
     // ---- epilogue: stage the 256 px x CO_T tile as bf16 rows, then 16-byte stores -------------------------------------------
     // (measured alternatives, all slower: 4-byte stores straight from the accumulators after a DPP lane-pair exchange; 8 waves x
     //  (1 x 4) tiles at 4 waves per SIMD -- 5 fragment reads per 4 MFMAs instead of 6 per 8 makes the loop LDS-bound.)
-    if (p.dbg == 1) {
+    if (p.dbg == 1 || p.dbg == 37 || p.dbg == 38 || p.dbg == 40) {
         if (acc[0][0][0] == 12345.678f) p.Y[0] = 0;       // keep the accumulators alive
         return;
     }

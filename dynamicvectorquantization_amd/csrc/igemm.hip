@@ -1576,6 +1576,205 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_tr_kernel(TnParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Convolution weight gradient on PATCHES (bf16): dW[co][tap][ci] += sum_px dy[px][co] x[gather(px, tap)][ci], 128 x 128 tile per
+// (tap, co tile, ci tile) like igemm_tn_tr_kernel, but a 64-row stage is an 8 x 8 PATCH of output pixels instead of 64 consecutive
+// pixels (the sum over pixels has no order).  Inside a patch the source address of a lane's 16 bytes is
+//     [patch origin: scalar, rebuilt per stage on the scalar unit]  +  [pixel of the lane inside the patch: one 32-bit constant],
+// for dy and for the gathered x rows alike (stride, padding, tap offset and the folded nearest x2 upsampling are part of the
+// constant), so a stage's DMA costs 3 vector instructions per x piece (the padding mask: per-lane edge flags & the patch's edge code)
+// and none per dy piece.  igemm_tn_tr_kernel decodes every row's pixel and builds two 64-bit addresses per piece and stage, ~40
+// vector instructions x 8 pieces per 16 MFMAs: it is bound by that arithmetic (0.12 of the MFMA peak on the step's shapes).
+// Fragment reads run one 16-row step ahead of their MFMAs.  Output rows / columns past DH / DW (31 x 31 PatchGAN maps) are
+// masked like padding.  Split over patch ranges, fp32 atomics.
+// -------------------------------------------------------------------------------------------------
+typedef int tn_int32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void conv_tn_patch_kernel(TnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using T = bf16_t;
+    constexpr int OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int per_split = p.itiles * p.jtiles * p.taps;
+    int bx = xcd_remap(blockIdx.x, per_split * p.nsplit);
+    const int split = bx / per_split;
+    bx -= split * per_split;
+    const int it = bx % p.itiles;
+    bx /= p.itiles;
+    const int jt = bx % p.jtiles;
+    const int tap = bx / p.jtiles;
+    const int i0 = it * TILE, j0 = jt * TILE;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const T* Ag = reinterpret_cast<const T*>(p.A);
+    const T* Bg = reinterpret_cast<const T*>(p.B);
+    const int PH = (p.DH + 7) >> 3, PW = (p.DW + 7) >> 3;            // patches per image column / row
+    const int npatch = (p.Mred / (p.DH * p.DW)) * PH * PW;
+    const int pbeg = split * p.m_per_split, pend = min(npatch, pbeg + p.m_per_split);      // (m_per_split counts patches here)
+
+    // ---- per-lane constants of this wave's 4 + 4 DMA pieces (stage rows (wave * 4 + i) * 4 + lr = patch pixel (r >> 3, r & 7)) ----
+    const int lr = lane >> 4, cpos = lane & 15;
+    const int cg = cpos ^ (lr << 2);
+    const int colA = i0 + cg * 8, colB = j0 + cg * 8;
+    // even bias of the lane-relative input coordinates (keeps them non-negative; even so that the >> up of the sum splits)
+    const int by = (p.pad_t + 1) & ~1, bxp = (p.pad_l + 1) & ~1;
+    int voA[4], voB[4], flA[4], flB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 4 + lr, ly = r >> 3, lx = r & 7;
+        voA[i] = colA < p.I ? (int)(((int64_t)(ly * p.DW + lx) * p.lda + colA) * 2) : OOB;
+        flA[i] = (ly >= p.DH - 8 * (PH - 1) ? 2 : 0) | (lx >= p.DW - 8 * (PW - 1) ? 8 : 0);
+        const int ry = ly * p.stride - p.pad_t + kh, rx = lx * p.stride - p.pad_l + kw;      // relative to the patch origin * stride
+        voB[i] = colB < p.J ? (int)(((int64_t)(((ry + by) >> p.up) * p.SW + ((rx + bxp) >> p.up)) * p.ldb + colB) * 2) : OOB;
+        flB[i] = (ry < 0 ? 1 : 0) | (8 * (PH - 1) * p.stride + ry >= p.LH ? 2 : 0) | (rx < 0 ? 4 : 0) | (8 * (PW - 1) * p.stride + rx >= p.LW ? 8 : 0);
+    }
+    int sn, spy, spx;                               // the next patch to be issued
+    {
+        const int ppi = PH * PW;
+        sn = pbeg / ppi;
+        const int rem = pbeg - sn * ppi;
+        spy = rem / PW;
+        spx = rem - spy * PW;
+    }
+    auto make_rsrc = [&](const T* base) {
+        const unsigned long long a = (unsigned long long)base;
+        tn_int32x4 r;
+        r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+        r.z = 0x7fff0000;
+        r.w = 0x00020000;
+        return r;
+    };
+    auto issue = [&](int buf) {
+        const int oy0 = spy * 8, ox0 = spx * 8;
+        const tn_int32x4 rsA = make_rsrc(Ag + (((int64_t)sn * p.DH + oy0) * p.DW + ox0) * p.lda);
+        // (for patches at the top / left edge this base lies before the image: only masked lanes would go there)
+        const tn_int32x4 rsB = make_rsrc(Bg + (((int64_t)sn * p.SH + ((oy0 * p.stride - by) >> p.up)) * p.SW + ((ox0 * p.stride - bxp) >> p.up)) * p.ldb);
+        const int edge = (spy == 0 ? 1 : 0) | (spy == PH - 1 ? 2 : 0) | (spx == 0 ? 4 : 0) | (spx == PW - 1 ? 8 : 0);
+        char* sa = smem + buf * TSTAGEB + wave * 16 * TROW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int va = (flA[i] & edge) ? OOB : voA[i];
+            const int vb = ((flB[i] | flA[i]) & edge) ? OOB : voB[i];
+            const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(sa + i * 4 * TROW));
+            // (inline assembly: see gemm_tn_wide_pipe_kernel -- the compiler would drain every LDS-DMA before the first transpose read)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(la), "v"(va), "s"(rsA));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(la + (unsigned)TOPB), "v"(vb), "s"(rsB));
+        }
+        if (++spx == PW) {
+            spx = 0;
+            if (++spy == PH) {
+                spy = 0;
+                ++sn;
+            }
+        }
+    };
+
+    // ---- fragment addressing (per lane constants, as igemm_tn_tr_kernel) ----
+    const int g = lane >> 4, li = lane & 15;
+    const int frow = 8 * (g >> 1) + (li >> 2);
+    const int fz = ((li >> 2) & 3) << 2;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int chA = wm * 8 + t * 4 + 2 * (g & 1) + ((li & 3) >> 1);
+        const int chB = wn * 8 + t * 4 + 2 * (g & 1) + ((li & 3) >> 1);
+        offA[t] = frow * TROW + ((chA ^ fz) << 4) + (li & 1) * 8;
+        offB[t] = frow * TROW + ((chB ^ fz) << 4) + (li & 1) * 8;
+    }
+    const bool do_bias = p.colsumA != nullptr && tap == 0 && jt == 0 && wn == 0;
+    float bsum[2] = {0.f, 0.f};
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    auto frag = [&](const char* base, int off, int ks) -> bf16x8 {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off + (ks * 16) * TROW));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off + (ks * 16 + 4) * TROW));
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = lo[j];
+            v[4 + j] = hi[j];
+        }
+        return v;
+    };
+
+    if (pbeg < pend) {
+        issue(0);
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        __syncthreads();
+        for (int j = pbeg; j < pend; ++j) {
+            const int buf = (j - pbeg) & 1;
+            if (j + 1 < pend) issue(buf ^ 1);
+            const char* sA = smem + buf * TSTAGEB;
+            const char* sB = sA + TOPB;
+            bf16x8 a[2][2], b[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[0][t] = frag(sA, offA[t], 0);
+                b[0][t] = frag(sB, offB[t], 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        a[(ks + 1) & 1][t] = frag(sA, offA[t], ks + 1);
+                        b[(ks + 1) & 1][t] = frag(sB, offB[t], ks + 1);
+                    }
+                }
+                if (do_bias) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const uint4 u = __builtin_bit_cast(uint4, a[ks & 1][t]);
+                        bsum[t] += (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) +
+                                   (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u)) +
+                                   (__uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u)) +
+                                   (__uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u));
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][mt], b[ks & 1][nt], acc[mt][nt], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ Cg = p.C;
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = j0 + wn * 64 + nt * 32 + l31;
+        if (col >= p.Jc) continue;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < p.I) atomicAdd(Cg + tn_c_offset(p, row, tap, col), acc[mt][nt][r]);
+            }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);
+            const int col = i0 + wm * 64 + t * 32 + l31;
+            if (half == 0 && col < p.I) atomicAdd(p.colsumA + col, v);
+        }
+    }
+#endif
+}
+
+// -------------------------------------------------------------------------------------------------
 // Wide TN GEMM (bf16 weight gradients of the Linear layers: C[i][j] += sum_m A[m][i] B[m][j]): 256 x 256 tile, 8 waves x (2 x 4)
 // MFMA tiles, 64 reduction rows per stage (2 x 32 KiB, rows of 512 B), operands in their natural [m][column] layout with the
 // K-contiguous fragments formed by ds_read_b64_tr_b16 (as igemm_tn_tr_kernel), split over m with fp32 atomics.  Main loop pipelined
@@ -2156,6 +2355,28 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
                 gemm_tn_wide_reduce_kernel<<<dim3((unsigned)(wtiles * 256)), dim3(256), 0, s>>>(p);
                 DVQ_CHECK_LAUNCH("gemm_tn_wide_reduce");
             }
+            return DVQ_OK;
+        }
+        static const int patch_env = [] {
+            const char* e = getenv("DVQ_CONV_TN_PATCH");
+            return e != nullptr ? atoi(e) : 1;
+        }();
+        if (sizeof(T) == 2 && p.conv && !p.thin && impl == 0 && patch_env != 0 && batch == 1 && p.I % 8 == 0 && p.J % 8 == 0 &&
+            p.pad_t <= 8 && p.pad_l <= 8 && p.Mred % (p.DH * p.DW) == 0 &&
+            (int64_t)(8 * p.stride + p.taps / p.KW + 10) * p.SW * p.ldb * 2 < (1ll << 30) && (int64_t)8 * p.DW * p.lda * 2 < (1ll << 30)) {
+            // 8 x 8 output-pixel patches as reduction stages (conv_tn_patch_kernel): split over patch ranges
+            const int64_t PH = cdiv64(p.DH, 8), PW = cdiv64(p.DW, 8);
+            const int64_t npatch = (p.Mred / ((int64_t)p.DH * p.DW)) * PH * PW;
+            const int64_t ptiles = (int64_t)p.itiles * p.jtiles * p.taps;
+            int64_t psplits = 1024 / ptiles;
+            if (psplits > npatch / 4) psplits = npatch / 4;
+            if (psplits < 1) psplits = 1;
+            const int64_t pps = cdiv64(npatch, psplits);
+            p.m_per_split = (int)pps;
+            p.nsplit = (int)cdiv64(npatch, pps);
+            dvq_ensure_dynamic_lds((const void*)conv_tn_patch_kernel, 2 * TSTAGEB);
+            conv_tn_patch_kernel<<<dim3((unsigned)(ptiles * p.nsplit)), dim3(256), 2 * TSTAGEB, s>>>(p);
+            DVQ_CHECK_LAUNCH("conv_tn_patch");
             return DVQ_OK;
         }
         if (sizeof(T) == 2 && impl != 3) {      // LDS-DMA + transpose-read kernel

@@ -155,6 +155,19 @@ def _halo_eligible(d: ConvDesc) -> bool:
             d.OH == d.H and d.OW == d.W and d.impl in (0, 4) and d.W % 32 == 0 and d.Cin % 64 == 0 and d.Cout % 8 == 0)
 
 
+def _tn_family(d: ConvDesc, cin_real: int) -> str:
+    """mirrors launch_tn() in csrc/igemm.hip: the kernel family a non-halo weight-gradient call lands on (timing labels)"""
+    if d.dtype != _lib.BF16:
+        return "igemm_tn_kernel"
+    if d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad_t == 0 and d.pad_l == 0 and not d.upsample and d.Cin >= 256 and d.Cout >= 256:
+        return "gemm_tn_wide_pipe_kernel"
+    if d.Cin == 8 and 1 < d.KH * d.KW <= 16:
+        return "igemm_tn_tr_kernel"          # thin: taps folded into the column tile
+    if d.impl == 0 and os.environ.get("DVQ_CONV_TN_PATCH", "1") != "0":
+        return "conv_tn_patch_kernel"
+    return "igemm_tn_tr_kernel"
+
+
 def _nt_family(d: ConvDesc, dgrad: bool) -> str:
     """mirrors launch_nt() in csrc/igemm.hip: the kernel family a non-halo forward / input-gradient call lands on (timing labels)"""
     cs, ncols = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
@@ -440,7 +453,7 @@ def conv2d_wgrad_oihw(d: ConvDesc, x, dy, cin_real, cout_real, grad_oihw, db=Non
             lib().dvq_conv2d_wgrad_oihw_ex(C.byref(d), _p(x), _p(dy), cin_real, cout_real, _praw(grad_oihw), _p(db),
                                            int(is_ohwi(grad_oihw)), _p(gn_ss), _s()), "dvq_conv2d_wgrad_oihw_ex"))
         return
-    _timed("conv3x3_halo_wgrad_kernel" if _halo_eligible(d) and d.H % 4 == 0 else "igemm_tn_tr_kernel", fl, nb, lambda: check(
+    _timed("conv3x3_halo_wgrad_kernel" if _halo_eligible(d) and d.H % 4 == 0 else _tn_family(d, cin_real), fl, nb, lambda: check(
         lib().dvq_conv2d_wgrad_oihw(C.byref(d), _p(x), _p(dy), cin_real, cout_real, _praw(grad_oihw), _p(db),
                                     int(is_ohwi(grad_oihw)), _s()), "dvq_conv2d_wgrad_oihw"))
 

@@ -409,6 +409,52 @@ def test_conv_pipelined_igemm_kernel(dev, case, epi):
     assert derr < 3e-2, f"input gradient: rel-to-max error {derr}"
 
 
+TN_PATCH_CASES = [
+    # cin, cout, k, kind, H, W, N      -- weight gradients on conv_tn_patch_kernel (8 x 8 output-pixel patches as reduction stages)
+    (256, 256, 3, "same", 16, 16, 2),      # 2 x 2 patches per image, padding on every side
+    (128, 128, 3, "down", 16, 12, 2),      # stride 2 + asymmetric pad, 8 x 6 outputs: a partial patch column
+    (64, 128, 4, "s2p1", 24, 16, 3),       # 4 x 4 stride 2, 12 x 8 outputs: a partial patch row
+    (256, 512, 4, "s1p1", 12, 13, 2),      # 4 x 4 stride 1, odd 11 x 12 outputs (PatchGAN tail), four column tiles
+    (512, 8, 4, "s1p1", 10, 9, 2),         # 8 gradient rows (PatchGAN logits)
+    (64, 64, 3, "up", 6, 6, 2),            # nearest x2 upsampling folded into the gather
+    (128, 64, 1, "same", 20, 24, 2),       # 1 x 1 below the 256-wide GEMM kernel's size
+    (64, 256, 3, "down", 40, 24, 1),       # more patches than splits
+]
+
+
+@pytest.mark.parametrize("case", TN_PATCH_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_conv_weight_gradient_patch_kernel(dev, case):
+    """conv_tn_patch_kernel (automatic choice for bf16 weight gradients off the halo kernel's shapes) against torch's fp32 convolution"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd.layers import Conv2d
+    cin, cout, k, kind, h, w_, n = case
+    rs = np.random.RandomState(11 * cin + cout + k + h)
+    x = bf16_round(rs.standard_normal((n, cin, h, w_)).astype(np.float32))
+    wt = bf16_round((rs.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32))
+    b = (0.1 * rs.standard_normal(cout)).astype(np.float32)
+    xr = torch.from_numpy(x)
+    wr, br = torch.from_numpy(wt).requires_grad_(True), torch.from_numpy(b).requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=1, padding=1) if kind == "s1p1" else _conv_ref(xr, wr, br, kind, k)
+    go = bf16_round(rs.standard_normal(tuple(yr.shape)).astype(np.float32))
+    (yr * torch.from_numpy(go)).sum().backward()
+    kw = dict(same=dict(stride=1, padding=(k - 1) // 2), down=dict(stride=2, padding=0, asym_pad=True),
+              up=dict(stride=1, padding=1, upsample=True), s2p1=dict(stride=2, padding=1), s1p1=dict(stride=1, padding=1))[kind]
+    mod = Conv2d(cin, cout, k, **kw).to(dev)
+    with torch.no_grad():
+        mod.weight.copy_(T(wt, dev))
+        mod.bias.copy_(T(b, dev))
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        d = mod._desc(T(x, dev).permute(0, 2, 3, 1).to(torch.bfloat16))
+        assert K._tn_family(d, cin) == "conv_tn_patch_kernel" or K._halo_eligible(d)
+        xt = T(x, dev).requires_grad_(True)
+        y = mod(xt)
+        (y.float() * T(go, dev)).sum().backward()
+    for name, got, ref in (("dw", mod.weight.grad.cpu().numpy(), wr.grad.numpy()), ("db", mod.bias.grad.cpu().numpy(), br.grad.numpy())):
+        err = float(np.abs(got - ref).max()) / max(1e-6, float(np.abs(ref).max()))
+        assert err < 1e-2, f"{name}: rel-to-max error {err}"
+
+
 HALO_CASES = [(64, 64, 8, 32, 2), (128, 128, 16, 32, 2), (64, 192, 8, 64, 1), (256, 128, 24, 32, 1), (128, 64, 8, 32, 1),
               (128, 8, 16, 32, 1), (64, 24, 8, 32, 2), (64, 40, 8, 64, 1)]      # thin outputs: 32- / 64-wide channel tiles
 
