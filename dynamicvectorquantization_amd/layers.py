@@ -429,6 +429,28 @@ class Conv2d(HipModule):
         return K.conv2d_dgrad(d, dy, wt, mask=mask, mask_act=mask_act)
 
 
+def conv1x1_bwd_accumulate(conv, dy, tape, acc):
+    """conv.bwd(dy, tape) + acc for a 1 x 1 / stride 1 convolution in ONE kernel: its input gradient is the forward 1 x 1 convolution
+    of dy with the transposed weight, whose epilogue adds a residual -- the separate dvq_add pass over the gradient (3 tensors of HBM
+    traffic: as long as the GEMM itself at 256 channels) disappears.  The weight gradient is issued as in Conv2d.bwd."""
+    x, d = tape.s["x"], tape.s["d"]
+    ok = (conv.kernel_size == 1 and conv.stride == 1 and conv.padding == 0 and not conv.upsample and not conv.asym_pad and
+          dy.dtype == torch.bfloat16 and rt.impl() == 0 and acc is not None and d.Cin == conv.in_channels and d.Cout == conv.out_channels)
+    if not ok:
+        dx = conv.bwd(dy, tape)
+        return dx if acc is None else K.add(dx, acc)
+    _, wt, _ = conv.packed(x.dtype)
+    dt_ = K.conv_desc(d.N, d.H, d.W, d.Cout, d.Cin, 1, 1, 1, 0, 0, d.H, d.W, False, dy.dtype, d.impl)
+    dx = K.conv2d_fwd(dt_, dy, wt, None, acc)
+    db = _grad_buf(conv.bias) if conv.bias is not None else None
+    gw = _grad_buf(conv.weight)
+    if rt.side_wgrad_enabled():
+        rt.run_on_side(lambda: K.conv2d_wgrad_oihw(d, x, dy, conv.in_channels, conv.out_channels, gw, db), x, dy)
+    else:
+        K.conv2d_wgrad_oihw(d, x, dy, conv.in_channels, conv.out_channels, gw, db)
+    return dx
+
+
 class _PackRegistry:
     """All Conv2d packed-weight buffers of the process; `repack` refreshes every one of them with ONE kernel
     launch (dvq_pack_weights_multi) after an optimizer step instead of one launch per layer."""
@@ -617,8 +639,8 @@ class AttnBlock(HipModule):
             dq, dk, dv = K.attn_full_bwd(q.view(b * n, c), k.view(b * n, c), v.view(b * n, c), st["o"], do.view(b * n, c), st["lse"],
                                          b, n, float(int(c) ** (-0.5)))
             dh = self.q.bwd(dq.view(b, h, w, c), tape.child("q"))
-            dh = K.add(dh, self.k.bwd(dk.view(b, h, w, c), tape.child("k")))
-            dh = K.add(dh, self.v.bwd(dv.view(b, h, w, c), tape.child("v")))
+            dh = conv1x1_bwd_accumulate(self.k, dk.view(b, h, w, c), tape.child("k"), dh)
+            dh = conv1x1_bwd_accumulate(self.v, dv.view(b, h, w, c), tape.child("v"), dh)
             return self.norm.bwd(dh, tape.child("norm"), addend=dy)
         dp = K.gemm_nt(do, v, n, n, c, c, c, n, batch=b, sa=n * c, sb=n * c, sc=n * n, impl=impl)      # dO v^T
         dv32 = K.gemm_tn(p, do, n, n, c, n, c, c, batch=b, sa=n * n, sb=n * c, sc=n * c, impl=impl)    # p^T dO
@@ -631,6 +653,6 @@ class AttnBlock(HipModule):
         dk = K.cast(dk32.view(b, h, w, c), dt_)
         dv = K.cast(dv32.view(b, h, w, c), dt_)
         dh = self.q.bwd(dq, tape.child("q"))
-        dh = K.add(dh, self.k.bwd(dk, tape.child("k")))
-        dh = K.add(dh, self.v.bwd(dv, tape.child("v")))
+        dh = conv1x1_bwd_accumulate(self.k, dk, tape.child("k"), dh)
+        dh = conv1x1_bwd_accumulate(self.v, dv, tape.child("v"), dh)
         return self.norm.bwd(dh, tape.child("norm"), addend=dy)
