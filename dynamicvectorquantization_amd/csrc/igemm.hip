@@ -2325,7 +2325,17 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
         // the weight gradient of a 1 x 1 / stride 1 / unpadded convolution IS a plain TN product (dy^T x)
         const bool conv1x1 = p.conv && p.taps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.up == 0 && p.LH == p.DH &&
                              p.LW == p.DW;
-        if (sizeof(T) == 2 && (impl == 0 || impl == 6) && (!p.conv || (conv1x1 && impl == 0)) && p.taps == 1 && p.I >= 256 && p.J >= 256 && p.Mred >= 1024 &&
+        // 1 x 1 weight gradients run on the patch kernel too (DVQ_TN_1X1_PATCH=0: the 256-wide plain-GEMM kernel): 65536 x 256 x 256
+        // 31 against 52 us, 16384 x 512 x 512 30 against 40 us -- a 256 x 256 tile leaves 64 workgroups for the whole chip
+        static const int x11_env = [] {
+            const char* e = getenv("DVQ_TN_1X1_PATCH");
+            return e != nullptr ? atoi(e) : 1;
+        }();
+        static const int pwgs_env = [] {         // workgroups the patch kernel aims at (sweep: 128 / 256 / 512 / 1024, profiles/)
+            const char* e = getenv("DVQ_TN_PATCH_WGS");
+            return e != nullptr ? atoi(e) : 512;
+        }();
+        if (sizeof(T) == 2 && (impl == 0 || impl == 6) && (!p.conv || (conv1x1 && impl == 0 && x11_env == 0)) && p.taps == 1 && p.I >= 256 && p.J >= 256 && p.Mred >= 1024 &&
             p.I % 8 == 0 && p.J % 8 == 0 && (int64_t)p.Mred * p.lda < (1ll << 30) && (int64_t)p.Mred * p.ldb < (1ll << 30) &&
             (p.sA * 2) % 4 == 0 && (p.sB * 2) % 4 == 0) {
             // large plain weight-gradient GEMMs: 256 x 256 tiles, pipelined main loop; ~one resident workgroup per CU
@@ -2368,8 +2378,8 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
             const int64_t PH = cdiv64(p.DH, 8), PW = cdiv64(p.DW, 8);
             const int64_t npatch = (p.Mred / ((int64_t)p.DH * p.DW)) * PH * PW;
             const int64_t ptiles = (int64_t)p.itiles * p.jtiles * p.taps;
-            int64_t psplits = 1024 / ptiles;
-            if (psplits > npatch / 4) psplits = npatch / 4;
+            int64_t psplits = pwgs_env / ptiles;
+            if (psplits > npatch / 16) psplits = npatch / 16;       // >= 16 stages per workgroup: the 64-KiB atomic flush amortised
             if (psplits < 1) psplits = 1;
             const int64_t pps = cdiv64(npatch, psplits);
             p.m_per_split = (int)pps;

@@ -159,7 +159,8 @@ def _tn_family(d: ConvDesc, cin_real: int) -> str:
     """mirrors launch_tn() in csrc/igemm.hip: the kernel family a non-halo weight-gradient call lands on (timing labels)"""
     if d.dtype != _lib.BF16:
         return "igemm_tn_kernel"
-    if d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad_t == 0 and d.pad_l == 0 and not d.upsample and d.Cin >= 256 and d.Cout >= 256:
+    if (d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad_t == 0 and d.pad_l == 0 and not d.upsample and d.Cin >= 256 and d.Cout >= 256 and
+            (d.impl != 0 or os.environ.get("DVQ_TN_1X1_PATCH", "1") == "0")):
         return "gemm_tn_wide_pipe_kernel"
     if d.Cin == 8 and 1 < d.KH * d.KW <= 16:
         return "igemm_tn_tr_kernel"          # thin: taps folded into the column tile
