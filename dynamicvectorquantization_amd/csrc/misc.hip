@@ -297,33 +297,46 @@ __device__ __forceinline__ float master_at(const float* m, int64_t co, int64_t c
     return ohwi ? m[(co * taps + tap) * Cin + ci] : m[(co * Cin + ci) * taps + tap];
 }
 
+// Four consecutive destination elements per thread (every entry's begin and both padded channel counts are multiples of 4, so a
+// quad never straddles a row, a tensor or an entry): one table search and one 32-bit index decode per quad instead of per element,
+// 8- / 16-byte stores.  (Per element with 64-bit divisions this launch took 0.45 ms per optimizer step -- 0.9 ms per train step.)
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackEntry* __restrict__ tab, int n, int64_t total) {
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < total; e += (int64_t)gridDim.x * 1024) {
         int lo = 0, hi = n - 1;            // last entry with begin <= e
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (tab[mid].begin <= e) lo = mid; else hi = mid - 1;
         }
         const PackEntry t = tab[lo];
-        const int64_t f0 = e - t.begin;
-        const int64_t nw = t.w ? t.Cout * t.taps * t.Cin_p : 0;
-        float v;
+        const unsigned f0 = (unsigned)(e - t.begin);                       // (a packed tensor pair has < 2^32 elements)
+        const unsigned taps = (unsigned)t.taps, Cin = (unsigned)t.Cin, Cout = (unsigned)t.Cout;
+        const unsigned nw = t.w ? Cout * taps * (unsigned)t.Cin_p : 0u;
+        const bool ohwi = (t.dtype >> 8) & 1;
+        float v[4];
         void* dst;
-        int64_t di;
+        unsigned di;
         if (f0 < nw) {
-            const int64_t ci = f0 % t.Cin_p, tap = (f0 / t.Cin_p) % t.taps, co = f0 / (t.Cin_p * t.taps);
-            v = ci < t.Cin ? master_at(t.master, co, ci, tap, t.Cin, t.taps, (t.dtype >> 8) & 1) : 0.f;
+            const unsigned cp = (unsigned)t.Cin_p, row = f0 / cp, ci = f0 - row * cp, co = row / taps, tap = row - co * taps;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ci + u < Cin ? master_at(t.master, co, ci + u, tap, Cin, taps, ohwi) : 0.f;
             dst = t.w;
             di = f0;
         } else {
-            const int64_t f = f0 - nw;
-            const int64_t co = f % t.Cout_p, tap = (f / t.Cout_p) % t.taps, ci = f / (t.Cout_p * t.taps);
-            v = co < t.Cout ? master_at(t.master, co, ci, tap, t.Cin, t.taps, (t.dtype >> 8) & 1) : 0.f;
+            const unsigned f = f0 - nw;
+            const unsigned cp = (unsigned)t.Cout_p, row = f / cp, co = f - row * cp, ci = row / taps, tap = row - ci * taps;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = co + u < Cout ? master_at(t.master, co + u, ci, tap, Cin, taps, ohwi) : 0.f;
             dst = t.wt;
             di = f;
         }
-        if ((t.dtype & 0xff) == DVQ_F32) reinterpret_cast<float*>(dst)[di] = v;
-        else reinterpret_cast<bf16_t*>(dst)[di] = f32_to_bf16(v);
+        if ((t.dtype & 0xff) == DVQ_F32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + di) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(dst) + di) = pk;
+        }
     }
 }
 
@@ -702,7 +715,7 @@ int dvq_pack_weight(const float* master, int64_t Cout, int64_t Cin, int64_t KH, 
 
 int dvq_pack_weights_multi(const void* table_dev, int64_t n_entries, int64_t total_work, dvq_stream_t stream) {
     DVQ_REQUIRE(table_dev && n_entries > 0 && n_entries < (1 << 30) && total_work > 0, DVQ_EINVAL, "dvq_pack_weights_multi: bad arguments");
-    pack_weights_multi_kernel<<<dim3(nblocks(total_work, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+    pack_weights_multi_kernel<<<dim3(nblocks(total_work, 1024)), dim3(256), 0, (hipStream_t)stream>>>(
         (const PackEntry*)table_dev, (int)n_entries, total_work);
     DVQ_CHECK_LAUNCH("pack_weights_multi");
     return DVQ_OK;

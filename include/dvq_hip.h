@@ -205,7 +205,9 @@ int dvq_conv2d_wgrad_oihw(const dvq_conv_desc* d, const void* x, const void* dy,
 
 /* Pack every conv weight of a model in ONE launch.  table_dev: device array of n_entries records
  * { const float* master; void* w; void* wt; int64 Cout, Cin, taps, Cin_p, Cout_p, begin, dtype } where `begin` is
- * the exclusive prefix sum of (Cout*taps*Cin_p [if w] + Cin*taps*Cout_p [if wt]) and total_work the full sum. */
+ * the exclusive prefix sum of (Cout*taps*Cin_p [if w] + Cin*taps*Cout_p [if wt]) and total_work the full sum.
+ * Cin_p and Cout_p must be multiples of 4 (the kernel moves four destination elements per thread); DVQ_EINVAL otherwise is NOT
+ * checked on the device table: the caller pads channels to the vector width of the dtype (4 fp32 / 8 bf16) anyway. */
 int dvq_pack_weights_multi(const void* table_dev, int64_t n_entries, int64_t total_work, dvq_stream_t stream);
 
 /* weight packing: master fp32 OIHW (the reference's nn.Conv2d parameter layout) -> `dtype`

@@ -409,6 +409,32 @@ def test_conv_pipelined_igemm_kernel(dev, case, epi):
     assert derr < 3e-2, f"input gradient: rel-to-max error {derr}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_multi_tensor_weight_pack_matches_single_pack(dev, dtype):
+    """dvq_pack_weights_multi (one launch refreshing every conv's packed copies after an optimizer step) against dvq_pack_weight per layer:
+    channel-padded image convs, 1x1 / 3x3 / 4x4, OIHW masters"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d
+    torch.manual_seed(3)
+    mods = [Conv2d(3, 128, 3, 1, 1), Conv2d(128, 128, 3, 1, 1), Conv2d(128, 3, 3, 1, 1), Conv2d(256, 256, 1), Conv2d(64, 128, 4, 2, 1),
+            Conv2d(40, 72, 3, 1, 1), Conv2d(512, 1, 4, 1, 1)]
+    mods = [m.to(dev) for m in mods]
+    with rt.compute_dtype_ctx(dtype):
+        for m in mods:
+            m.packed(dtype)                                   # first use: single-tensor pack, registers the buffers
+        with torch.no_grad():
+            for m in mods:
+                m.weight.add_(torch.randn_like(m.weight))     # version bump: the next packed() call repacks ALL of them in one launch
+        got = [tuple(t.clone() for t in m.packed(dtype)[:2]) for m in mods]
+    for m, (w, wt) in zip(mods, got):
+        cin_p, cout_p = m._padded(dtype)
+        rw, rwt = K.pack_weight(m.weight.detach(), cin_p, cout_p, dtype)
+        assert torch.equal(w[: m.out_channels], rw), f"w differs for {tuple(m.weight.shape)}"
+        assert torch.equal(wt, rwt), f"wt differs for {tuple(m.weight.shape)}"
+        assert float(w[m.out_channels:].abs().sum()) == 0.0
+
+
 TN_PATCH_CASES = [
     # cin, cout, k, kind, H, W, N      -- weight gradients on conv_tn_patch_kernel (8 x 8 output-pixel patches as reduction stages)
     (256, 256, 3, "same", 16, 16, 2),      # 2 x 2 patches per image, padding on every side
