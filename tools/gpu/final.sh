@@ -20,7 +20,7 @@ ff=$(find gpurun_out/pmcb_FETCH_SIZE -name "*counter_collection.csv" | head -1);
 DVQ_SIDE_WGRAD=0 TOP=120 timeout 300 python tools/debug/step_shapes.py 2>/dev/null | grep -v "Warn\|return get_obj" > gpurun_out/${TAG}_step_shapes.txt; echo "shapes exit $?"
 timeout 300 python tools/conv_bench.py --no-check 2>/dev/null | grep -v "Warn\|return get_obj" > gpurun_out/${TAG}_conv_bench.txt; echo "conv_bench exit $?"
 { echo "# 128->128 @256^2 B=64 halo conv (tools/debug/halo_data_probe.py): complete kernel / main loop only (DVQ_HALO_DBG=1) / epilogue only (=2)";
-  for d in 0 1 2; do echo "## DVQ_HALO_DBG=$d"; DVQ_HALO_DBG=$d timeout 200 python tools/debug/halo_data_probe.py 2>/dev/null | grep -A7 "epilogue options"; done;
+  for d in 0 1 2; do echo "## DVQ_HALO_DBG=$d"; DVQ_HALO_DBG=$d timeout 200 python tools/debug/halo_data_probe.py 2>/dev/null | grep -A11 "epilogue options"; done;
   echo "## per-workgroup trace (DVQ_HALO_DBG=6, tools/debug/halo_trace.py)"; for m in plain res+stats; do timeout 200 python tools/debug/halo_trace.py $m 2>/dev/null | grep "mode\|split\|overlapped"; done;
   echo "## VALU issue beside a busy MFMA wave (tools/debug/_valu_under_mfma)"; [ -x tools/debug/_valu_under_mfma ] && tools/debug/_valu_under_mfma; } > gpurun_out/${TAG}_halo_probes.txt 2>&1
 timeout 200 python tools/debug/gn_probe.py 2>/dev/null | grep "^N" > gpurun_out/${TAG}_gn_probe.txt
