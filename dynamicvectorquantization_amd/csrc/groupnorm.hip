@@ -67,11 +67,19 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
                 q[j] = fmaf(v[j], v[j], q[j]);
             }
         }
+        // the thread's 8 channels lie in 8 / cpg groups (1 for cpg >= 8): fold them in registers first -- 4096 fp64 LDS atomics per
+        // block on 64 addresses were most of this kernel's time on the small maps
+        double ds = 0.0, dq = 0.0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            ds += (double)s[j];
+            dq += (double)q[j];
             const int g = (col * 8 + j) / ge.cpg;
-            atomicAdd(&gs[2 * g], (double)s[j]);
-            atomicAdd(&gs[2 * g + 1], (double)q[j]);
+            if (j == 7 || (col * 8 + j + 1) / ge.cpg != g) {
+                atomicAdd(&gs[2 * g], ds);
+                atomicAdd(&gs[2 * g + 1], dq);
+                ds = dq = 0.0;
+            }
         }
     }
     __syncthreads();
