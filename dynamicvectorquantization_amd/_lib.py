@@ -19,6 +19,12 @@ class ConvDesc(C.Structure):
                 ("dtype", i32), ("impl", i32)]
 
 
+class DecodeLayer(C.Structure):
+    """dvq_decode_layer of include/dvq_hip.h"""
+    _fields_ = [(n, vp) for n in ("wq", "wk", "wv", "wo", "w1", "w2", "bq", "bk", "bv", "bo", "b1", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
+                                  "kcache", "vcache")]
+
+
 class PackEntry(C.Structure):
     _fields_ = [("master", vp), ("w", vp), ("wt", vp), ("Cout", i64), ("Cin", i64), ("taps", i64), ("Cin_p", i64),
                 ("Cout_p", i64), ("begin", i64), ("dtype", i64)]
@@ -110,6 +116,8 @@ SIGNATURES = {
     "dvq_attn_full_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i64, i32, f32, vp, vp, vp, vp, vp]),
     "dvq_attn_decode_dev": (i32, [vp, vp, vp, vp, vp, i32, i64, i64, i64, vp, i64, f32, vp, vp]),
     "dvq_rows_dev": (i32, [vp, vp, i32, i64, i64, i64, vp, i32, vp]),
+    "dvq_decode_stack_scratch_bytes": (sz, [i64, i64, i64]),
+    "dvq_decode_stack": (i32, [vp, i32, i64, i64, i32, i64, i64, vp, C.c_float, vp, vp, i32, vp]),
     "dvq_dropout": (i32, [vp, i32, i64, f32, C.c_uint64, vp, vp]),
     "dvq_fill_f32": (i32, [vp, f32, i64, vp]),
     "dvq_image_desc_bytes": (sz, []),

@@ -1,0 +1,431 @@
+// decode.hip -- one token step of a whole StackGPT transformer (all its blocks) as ONE persistent kernel.
+//
+// Replaces, for the K/V-cached sampler (reference: StackGPT.sample_* recompute the whole prefix per token,
+// models/stage2/stackgpt.py:234-339; Block / CausalSelfAttention :41-96), the per-token launch sequence
+//     ln1, key, query, value, attn_decode, proj, add, ln2, fc, gelu, proj2, add        (12 kernels x 24 blocks)
+// which the GPU's command processor runs at ~8.8 us per dependent kernel whatever its size (rocprofv3 of the recorded token
+// step: 3000 kernels, 9.1 us average duration, 0.5 us gaps -- 2.6 ms per token step at batch 8 for 618 MB of weights, i.e.
+// 0.23 TB/s).  Here every workgroup of a resident grid walks the blocks; the five phases of a block
+//     (1) LayerNorm + q / k / v projections (k, v straight into the caches)      (2) one-row attention per (sequence, head)
+//     (3) output projection + residual     (4) LayerNorm + fc + GELU     (5) second projection + residual
+// are separated by a device-wide barrier (one atomic counter; the last workgroup to finish resets it), and all matrix-vector
+// products stream their weight rows once with every load of a wave in flight at the same time.
+//
+// Coherence without cache flushes: what one phase hands to the next (q, the new k / v rows, the attention output, the residual
+// stream, the fc activations -- a few KB) is written and read with relaxed AGENT-SCOPE atomic 32- / 64-bit accesses, which go to
+// the memory side instead of the (per-XCD, non-coherent) L2; a workgroup arrives at the barrier when those stores are
+// acknowledged (s_waitcnt vmcnt(0)).  A first version used release / acquire fences instead: every barrier then wrote back and
+// invalidated whole L2s and cost as much as the kernel boundary it replaced (24 us per phase -- slower than 12 launches per block).
+//
+// Matrix-vector products: 16 output columns per work item, the 8 waves of a workgroup split K; v_mfma_f32_16x16x32_bf16 with the
+// WEIGHT rows as the A operand (lane: row l & 15, k 8 (l >> 4) ..) and the <= 16 activation rows as B; the waves' partial tiles
+// are added through LDS and thread (n, m) applies the epilogue.  LayerNorm rows are normalised once per workgroup into LDS.
+#include "dvq_common.h"
+
+namespace {
+
+struct DecLayer {                      // mirrors dvq_decode_layer (include/dvq_hip.h)
+    const bf16_t *wq, *wk, *wv, *wo, *w1, *w2;
+    const float *bq, *bk, *bv, *bo, *b1, *b2;
+    const float *ln1g, *ln1b, *ln2g, *ln2b;
+    bf16_t *kc, *vc;
+};
+
+struct DecParams {
+    const DecLayer* layers;
+    int nlayers, B, C, nh, F;
+    int64_t Tmax;
+    const int64_t* t_dev;
+    float eps, scale;
+    bf16_t *x, *q, *kn, *vn, *y, *m1;      // kn / vn: the new k / v rows [B][C] (also appended to the caches for later launches)
+    unsigned* sync;                    // [0] barrier arrivals, [1] finished workgroups, [2] error flag (barrier timeout)
+    unsigned long long* trace;         // optional: s_memrealtime stamps of workgroup 0 at the phase boundaries of the first blocks
+};
+
+constexpr int DTH = 512, DNW = 8;
+
+__device__ __forceinline__ float dec_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// device-wide barrier of a resident grid: arrivals are counted monotonically (target = barrier number x workgroups)
+// Call sequence at a phase boundary:  stores_done();  [issue the next phase's weight loads];  grid_barrier(..).
+// stores_done = every wave waits for the acknowledgement of its coherent stores; the barrier itself then synchronises the workgroup
+// WITHOUT draining vmcnt, so the weight loads issued in between stay in flight while the workgroup waits for the others.
+__device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+__device__ __forceinline__ void grid_barrier(unsigned* sync, unsigned target) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) {                // ~seconds: a workgroup is not resident -- give up loudly instead of hanging
+                sync[2] = 1u;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// coherent (memory-side) accesses to the buffers the phases exchange
+__device__ __forceinline__ uint2 cload8(const void* p) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((unsigned)v, (unsigned)(v >> 32));
+}
+__device__ __forceinline__ uint4 cload16(const void* p) {
+    const uint2 a = cload8(p), b = cload8(reinterpret_cast<const char*>(p) + 8);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ unsigned cload4(const void* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void cstore4(void* p, unsigned v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void unpack8(uint4 u, float (&v)[8]) {
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+// thread (n = tid >> 4, m) and its neighbour n + 1 (lane + 16) store their two bf16 values as one coherent dword (n even)
+__device__ __forceinline__ void cstore_pair(bf16_t* row, int col, float v, bool ok) {
+    const float hi = __shfl_down(v, 16, 64);
+    if (ok && ((threadIdx.x >> 4) & 1) == 0) cstore4(row + col, pack_bf16x2(v, hi));
+}
+
+// rows of x normalised into LDS (bf16 [B][C]); wave w takes rows w, w + 8; a row (C <= 2048) is read ONCE, coherently, into registers
+__device__ __forceinline__ void ln_rows_to_lds(const bf16_t* x, int B, int C, float eps, const float* g, const float* b, bf16_t* xn) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C8 = C >> 3;
+    for (int r = wave; r < B; r += DNW) {
+        uint4 buf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) buf[i] = lane + 64 * i < C8 ? cload16(x + (int64_t)r * C + (lane + 64 * i) * 8) : make_uint4(0, 0, 0, 0);
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[8];
+            unpack8(buf[i], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s += v[j];
+                q = fmaf(v[j], v[j], q);
+            }
+        }
+        s = wave_sum(s);
+        q = wave_sum(q);
+        const float mean = s / (float)C;
+        float var = q / (float)C - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        const float rstd = rsqrtf(var + eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c8 = lane + 64 * i;
+            if (c8 < C8) {
+                float v[8];
+                unpack8(buf[i], v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaf((v[j] - mean) * rstd, g[c8 * 8 + j], b[c8 * 8 + j]);
+                store8(xn + r * C + c8 * 8, v);
+            }
+        }
+    }
+}
+
+// Matrix-vector work item = 16 weight rows (n0 ..) x all K: this wave's share is k-steps wave, wave + 8, ... (<= 16 of them for
+// K <= 4096).  The WEIGHT loads do not depend on the previous phase: they are issued BEFORE the device-wide barrier (gemv_load_w)
+// and consumed after it (gemv_compute), so the HBM latency of the weights runs beside the barrier.
+struct WFrag {
+    uint4 w[16];
+};
+__device__ __forceinline__ void gemv_load_w(const bf16_t* __restrict__ W, int K, int n0, bool active, WFrag& f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nks = K >> 5;
+    const bf16_t* wrow = W + (int64_t)(n0 + (lane & 15)) * K + (lane >> 4) * 8;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int ks = wave + u * DNW;
+        f.w[u] = (active && ks < nks) ? *reinterpret_cast<const uint4*>(wrow + ks * 32) : make_uint4(0, 0, 0, 0);
+    }
+}
+template <bool A_LDS>
+__device__ __forceinline__ f32x4 gemv_compute(const WFrag& f, int K, const bf16_t* A, int lda, int B) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 15, kq = (lane >> 4) * 8;
+    const int nks = K >> 5;
+    const bf16_t* arow = A + (int64_t)row * lda + kq;
+    const bool aok = row < B;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    uint4 av[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int ks = wave + u * DNW;
+        av[u] = !(aok && ks < nks) ? z : A_LDS ? *reinterpret_cast<const uint4*>(arow + ks * 32) : cload16(arow + ks * 32);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.w[u]), __builtin_bit_cast(bf16x8, av[u]), acc, 0, 0, 0);
+    return acc;
+}
+
+// the 8 waves' partial tiles -> red[wave][n][m]; afterwards thread tid < 256 owns output (n = tid >> 4, m = tid & 15)
+__device__ __forceinline__ float gemv16_reduce(f32x4 acc, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                                          // red free (previous item consumed)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[r];
+    __syncthreads();
+    float v = 0.f;
+    if (threadIdx.x < 256) {
+#pragma unroll
+        for (int w = 0; w < DNW; ++w) v += red[w * 256 + threadIdx.x];
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);                      // [8][256]
+    bf16_t* xn = reinterpret_cast<bf16_t*>(smem + DNW * 256 * 4);     // [B][C] normalised rows | attention scratch
+    const int tid = threadIdx.x, nwg = gridDim.x, wg = blockIdx.x;
+    const int B = p.B, C = p.C, F = p.F, nh = p.nh, hs = C / nh;
+    const int64_t t = *p.t_dev;
+    if (t < 0 || t >= p.Tmax) return;                                 // (uniform over the grid: never write outside the caches)
+    const int Tlen = (int)t + 1;
+    const int n = tid >> 4, m = tid & 15;                             // epilogue role of threads 0 .. 255
+    const bool eok = tid < 256 && m < B;
+    unsigned bar = 0;
+    int ntr = 0;
+    auto stamp = [&]() {
+        if (p.trace != nullptr && wg == 0 && tid == 0 && ntr < 128) p.trace[ntr++] = __builtin_readcyclecounter();
+    };
+    stamp();
+    WFrag wf;
+    for (int l = 0; l < p.nlayers; ++l) {
+        const DecLayer L = p.layers[l];
+        // ---- (1) LayerNorm 1 + q / k / v ------------------------------------------------------------------------------------
+        const int cb = C >> 4;                                        // 16-column blocks per projection
+        const int fb = F >> 4;
+        if (l == 0) {                                                 // (later blocks: issued before the previous block's last barrier)
+            const int which = wg / cb;
+            gemv_load_w(which == 0 ? L.wq : which == 1 ? L.wk : L.wv, C, (wg - which * cb) * 16, wg < 3 * cb, wf);
+        }
+        if (wg < 3 * cb) ln_rows_to_lds(p.x, B, C, p.eps, L.ln1g, L.ln1b, xn);
+        __syncthreads();
+        stamp();
+        for (int blk = wg; blk < 3 * cb; blk += nwg) {
+            const int which = blk / cb, n0 = (blk - which * cb) * 16;
+            const bf16_t* W = which == 0 ? L.wq : which == 1 ? L.wk : L.wv;
+            const float* bias = which == 0 ? L.bq : which == 1 ? L.bk : L.bv;
+            if (blk != wg) gemv_load_w(W, C, n0, true, wf);
+            float v = gemv16_reduce(gemv_compute<true>(wf, C, xn, C, B), red);
+            if (tid < 256 && bias != nullptr) v += bias[n0 + n];
+            bf16_t* dst = which == 0 ? p.q : which == 1 ? p.kn : p.vn;
+            cstore_pair(dst + m * C, n0 + n, v, eok);
+            if (eok && which != 0) (which == 1 ? L.kc : L.vc)[((int64_t)m * p.Tmax + t) * C + n0 + n] = f32_to_bf16(v);
+        }
+        stores_done();
+        stamp();
+        grid_barrier(p.sync, ++bar * nwg);
+        stamp();
+        // ---- (2) attention of the new row over cache rows 0 .. t, one (sequence, head) per work item ------------------------------
+        {
+            float* sc = reinterpret_cast<float*>(xn);                 // [Tlen] scores -> probabilities
+            float* qs = sc + p.Tmax;                                  // [hs]
+            float* part = qs + hs;                                    // [ngrp][hs]
+            float* rd = part + (DTH / (hs >> 3)) * hs;                // [16]
+            const int lane = tid & 63, wave = tid >> 6;
+            const int nv = hs >> 3, ngrp = DTH / nv;
+            const int ch = tid % nv, grp = tid / nv;
+            for (int item = wg; item < B * nh; item += nwg) {
+                const int b = item / nh, h = item - b * nh;
+                const bf16_t* kb = L.kc + (int64_t)b * p.Tmax * C + h * hs;
+                const bf16_t* vb = L.vc + (int64_t)b * p.Tmax * C + h * hs;
+                const bf16_t* knr = p.kn + b * C + h * hs;            // row t itself: written during this launch, read coherently
+                const bf16_t* vnr = p.vn + b * C + h * hs;
+                __syncthreads();
+                for (int d2 = tid; d2 < (hs >> 1); d2 += DTH) {
+                    const unsigned u = cload4(p.q + b * C + h * hs + 2 * d2);
+                    qs[2 * d2] = __uint_as_float(u << 16);
+                    qs[2 * d2 + 1] = __uint_as_float(u & 0xffff0000u);
+                }
+                __syncthreads();
+                for (int r = tid; r < Tlen; r += DTH) {
+                    const bf16_t* kr = kb + (int64_t)r * C;
+                    float a = 0.f;
+                    for (int i = 0; i < nv; ++i) {
+                        float kv[8];
+                        if (r == Tlen - 1) unpack8(cload16(knr + i * 8), kv);
+                        else load8(kr + i * 8, kv);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a = fmaf(qs[i * 8 + j], kv[j], a);
+                    }
+                    sc[r] = a * p.scale;
+                }
+                __syncthreads();
+                float mx = -INFINITY;
+                for (int r = tid; r < Tlen; r += DTH) mx = fmaxf(mx, sc[r]);
+                mx = wave_max(mx);
+                if (lane == 0) rd[wave] = mx;
+                __syncthreads();
+                mx = rd[0];
+#pragma unroll
+                for (int w = 1; w < DNW; ++w) mx = fmaxf(mx, rd[w]);
+                float s = 0.f;
+                for (int r = tid; r < Tlen; r += DTH) {
+                    const float e = __expf(sc[r] - mx);
+                    sc[r] = e;
+                    s += e;
+                }
+                s = wave_sum(s);
+                if (lane == 0) rd[8 + wave] = s;
+                __syncthreads();
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < DNW; ++w) tot += rd[8 + w];
+                const float inv = 1.f / tot;
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int r = grp; r < Tlen; r += ngrp) {
+                    float vv[8];
+                    if (r == Tlen - 1) unpack8(cload16(vnr + ch * 8), vv);
+                    else load8(vb + (int64_t)r * C + ch * 8, vv);
+                    const float pt = sc[r];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(pt, vv[j], acc[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) part[grp * hs + ch * 8 + j] = acc[j];
+                __syncthreads();
+                for (int d2 = tid; d2 < (hs >> 1); d2 += DTH) {
+                    float v0 = 0.f, v1 = 0.f;
+                    for (int g = 0; g < ngrp; ++g) {
+                        v0 += part[g * hs + 2 * d2];
+                        v1 += part[g * hs + 2 * d2 + 1];
+                    }
+                    cstore4(p.y + b * C + h * hs + 2 * d2, pack_bf16x2(v0 * inv, v1 * inv));
+                }
+            }
+        }
+        stores_done();
+        stamp();
+        gemv_load_w(L.wo, C, wg * 16, wg < cb, wf);                    // weights of phase 3, in flight across the barrier
+        grid_barrier(p.sync, ++bar * nwg);
+        stamp();
+        // ---- (3) output projection + residual (in place: an element of x is read and written by the same thread pair) -------------
+        for (int blk = wg; blk < cb; blk += nwg) {
+            const int n0 = blk * 16;
+            if (blk != wg) gemv_load_w(L.wo, C, n0, true, wf);
+            float v = gemv16_reduce(gemv_compute<false>(wf, C, p.y, C, B), red);
+            if (tid < 256 && L.bo != nullptr) v += L.bo[n0 + n];
+            v = bf16_to_f32(f32_to_bf16(v));                          // (rounded like the separate kernels did)
+            if (eok) {
+                const unsigned xo = cload4(p.x + m * C + n0 + (n & ~1));
+                v += (n & 1) ? __uint_as_float(xo & 0xffff0000u) : __uint_as_float(xo << 16);
+            }
+            cstore_pair(p.x + m * C, n0 + n, v, eok);
+        }
+        stores_done();
+        stamp();
+        gemv_load_w(L.w1, C, wg * 16, wg < fb, wf);
+        grid_barrier(p.sync, ++bar * nwg);
+        stamp();
+        // ---- (4) LayerNorm 2 + fc + GELU -------------------------------------------------------------------------------------
+        if (wg < fb) ln_rows_to_lds(p.x, B, C, p.eps, L.ln2g, L.ln2b, xn);
+        __syncthreads();
+        stamp();
+        for (int blk = wg; blk < fb; blk += nwg) {
+            const int n0 = blk * 16;
+            if (blk != wg) gemv_load_w(L.w1, C, n0, true, wf);
+            float v = gemv16_reduce(gemv_compute<true>(wf, C, xn, C, B), red);
+            if (tid < 256 && L.b1 != nullptr) v += L.b1[n0 + n];
+            v = dec_gelu(bf16_to_f32(f32_to_bf16(v)));
+            cstore_pair(p.m1 + m * F, n0 + n, v, eok);
+        }
+        stores_done();
+        stamp();
+        gemv_load_w(L.w2, F, wg * 16, wg < cb, wf);
+        grid_barrier(p.sync, ++bar * nwg);
+        stamp();
+        // ---- (5) second projection + residual --------------------------------------------------------------------------------
+        for (int blk = wg; blk < cb; blk += nwg) {
+            const int n0 = blk * 16;
+            if (blk != wg) gemv_load_w(L.w2, F, n0, true, wf);
+            float v = gemv16_reduce(gemv_compute<false>(wf, F, p.m1, F, B), red);
+            if (tid < 256 && L.b2 != nullptr) v += L.b2[n0 + n];
+            v = bf16_to_f32(f32_to_bf16(v));
+            if (eok) {
+                const unsigned xo = cload4(p.x + m * C + n0 + (n & ~1));
+                v += (n & 1) ? __uint_as_float(xo & 0xffff0000u) : __uint_as_float(xo << 16);
+            }
+            cstore_pair(p.x + m * C, n0 + n, v, eok);
+        }
+        stores_done();
+        if (l + 1 < p.nlayers) {
+            const DecLayer& Ln = p.layers[l + 1];
+            const int which = wg / cb;
+            gemv_load_w(which == 0 ? Ln.wq : which == 1 ? Ln.wk : Ln.wv, C, (wg - which * cb) * 16, wg < 3 * cb, wf);
+        }
+        stamp();
+        grid_barrier(p.sync, ++bar * nwg);
+        stamp();
+    }
+    // the last workgroup to get here re-arms the counters for the next launch (every workgroup is past its last barrier)
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned done = __hip_atomic_fetch_add(&p.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (unsigned)nwg - 1u) {
+            __hip_atomic_store(&p.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&p.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dvq_decode_stack_scratch_bytes(int64_t B, int64_t C, int64_t F) {
+    return (size_t)((4 * B * C + B * F) * 2 + 64 + 1024);         // (+ 128 time stamps of workgroup 0, DVQ_DECODE_TRACE)
+}
+
+int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C, int n_head, int64_t F, int64_t Tmax, const int64_t* t_dev,
+                     float eps, void* x, void* scratch, int n_workgroups, dvq_stream_t stream) {
+    DVQ_REQUIRE(layers_dev && t_dev && x && scratch && n_layers > 0, DVQ_EINVAL, "dvq_decode_stack: null pointer");
+    DVQ_REQUIRE(B > 0 && B <= 16 && C > 0 && C % 32 == 0 && C <= 2048 && F > 0 && F % 32 == 0 && n_head > 0 && C % n_head == 0 &&
+                    (C / n_head) % 8 == 0 && C / n_head <= 256 && Tmax > 0 && Tmax <= 12000,
+                DVQ_ESHAPE, "dvq_decode_stack: needs B <= 16, C %% 32 == 0 (<= 2048), F %% 32 == 0, head size %% 8 == 0 (<= 256), Tmax <= 12000");
+    int dev = 0, cus = 0;
+    DVQ_REQUIRE(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0,
+                DVQ_EARCH, "dvq_decode_stack: no device");
+    // every workgroup must be resident at once (the barrier spins): at most one per CU
+    // default: half the CUs (128 on MI355X: one (sequence, head) item each at batch 8 x 16 heads; measured 3650 token-steps/s against
+    // 3400 with 256 -- fewer barrier participants -- and 2760 with 64)
+    int nwg = n_workgroups > 0 ? n_workgroups : (cus >= 128 ? (cus / 2 > 128 ? cus / 2 : 128) : cus);
+    if (nwg > cus) nwg = cus;
+    DecParams p{};
+    p.layers = (const DecLayer*)layers_dev; p.nlayers = n_layers;
+    p.B = (int)B; p.C = (int)C; p.nh = n_head; p.F = (int)F; p.Tmax = Tmax; p.t_dev = t_dev; p.eps = eps;
+    const int hs = (int)(C / n_head);
+    p.scale = 1.0f / sqrtf((float)hs);
+    p.x = (bf16_t*)x;
+    p.q = (bf16_t*)scratch;
+    p.kn = p.q + B * C;
+    p.vn = p.kn + B * C;
+    p.y = p.vn + B * C;
+    p.m1 = p.y + B * C;
+    p.sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + ((4 * B * C + B * F) * 2 + 15) / 16 * 16);
+    static const bool trace_env = getenv("DVQ_DECODE_TRACE") != nullptr;
+    p.trace = trace_env ? reinterpret_cast<unsigned long long*>(p.sync + 8) : nullptr;
+    const int64_t att = (Tmax + hs + (int64_t)(DTH / (hs >> 3)) * hs + 16) * 4;
+    const int64_t lnb = B * C * 2;
+    const int lds = (int)(DNW * 256 * 4 + (att > lnb ? att : lnb));
+    DVQ_REQUIRE(lds <= 160 * 1024, DVQ_ESHAPE, "dvq_decode_stack: LDS footprint %d", lds);
+    dvq_ensure_dynamic_lds((const void*)decode_stack_kernel, lds);
+    decode_stack_kernel<<<dim3((unsigned)nwg), dim3(DTH), lds, (hipStream_t)stream>>>(p);
+    DVQ_CHECK_LAUNCH("decode_stack");
+    return DVQ_OK;
+}
+
+}  // extern "C"

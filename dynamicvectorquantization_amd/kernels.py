@@ -861,6 +861,19 @@ def attn_full_bwd(q, k, v, out, dout, lse, b, t, scale):
     return dq, dk, dv
 
 
+def decode_stack_scratch(b, c, f, device):
+    """zeroed scratch of dvq_decode_stack (activations between its phases + the barrier counters it re-arms itself)"""
+    return torch.zeros(lib().dvq_decode_stack_scratch_bytes(b, c, f), dtype=torch.uint8, device=device)
+
+
+def decode_stack(table_dev, n_layers, x, n_head, f, tmax, t_dev, eps, scratch, n_workgroups=0):
+    """one token step of all blocks of a transformer in one persistent kernel; x [B, C] bf16 is updated in place"""
+    b, c = x.shape
+    check(lib().dvq_decode_stack(_p(table_dev), n_layers, b, c, n_head, f, tmax, _p(t_dev), float(eps), _p(x), _p(scratch),
+                                 int(n_workgroups), _s()), "dvq_decode_stack")
+    return x
+
+
 def attn_decode_dev(q, k_new, v_new, kcache, vcache, n_head, t_dev, scale):
     """device-indexed form (graph replay): append (k_new, v_new) at cache row t_dev[0], attend over rows [0, t]"""
     b, c = q.shape

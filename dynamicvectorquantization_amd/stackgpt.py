@@ -260,6 +260,7 @@ class DecodeState:
         self.t_con = torch.zeros(1, dtype=torch.long, device=dev)
         self.use_graph = os.environ.get("DVQ_DECODE_GRAPH", "1") != "0"
         self._steps = {}
+        self._stacks = {}
         self._sig = self._weights_signature()
 
     def _weights_signature(self):
@@ -275,11 +276,57 @@ class DecodeState:
         sig = self._weights_signature()
         if sig != self._sig:              # the captured graphs point at the previous compute-dtype weight copies
             self._steps.clear()
+            self._stacks.clear()
             self._sig = sig
 
     def reset_content(self):
         self.rows_con = 0
         self.t_con.zero_()
+
+    # ---- all blocks of a transformer in one persistent kernel (dvq_decode_stack) ---------------------------------------------------
+    def _stack(self, which):
+        """(device table of the blocks' weight / cache pointers, scratch, tensors kept alive) of the position ('pos') or content
+        ('con') transformer, or None when the fused kernel does not apply (fp32 runs, > 16 sequences, DVQ_DECODE_STACK=0)"""
+        g = self.gpt
+        blocks, caches = (g.position_transformer, self.pos_cache) if which == "pos" else (g.content_transformer, self.con_cache)
+        c, cd = g.config.n_embd, rt.compute_dtype()
+        nh = blocks[0].attn.n_head
+        if (os.environ.get("DVQ_DECODE_STACK", "1") == "0" or cd != torch.bfloat16 or self.b > 16 or c % 32 or c > 2048 or (c // nh) % 8 or
+                c // nh > 256 or self.max_rows > 12000):
+            return None
+        ent = self._stacks.get(which)
+        if ent is not None and ent["sig"] == self._sig:
+            return ent
+        import ctypes
+        from ._lib import DecodeLayer
+        arr = (DecodeLayer * len(blocks))()
+        keep = []
+        for i, (blk, cache) in enumerate(zip(blocks, caches)):
+            lins = [blk.attn.query, blk.attn.key, blk.attn.value, blk.attn.proj, blk.mlp[0], blk.mlp[2]]
+            if any(l.out_p != l.out_features for l in lins):
+                return None
+            wb = [l._w(cd) for l in lins]
+            keep.append(wb)
+            ptr = lambda t_: 0 if t_ is None else t_.data_ptr()
+            arr[i] = DecodeLayer(*[ptr(w) for w, _ in wb], *[ptr(b_) for _, b_ in wb], ptr(blk.ln1.weight), ptr(blk.ln1.bias),
+                                 ptr(blk.ln2.weight), ptr(blk.ln2.bias), cache[0].data_ptr(), cache[1].data_ptr())
+        dev = self.hidden.device
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        f = blocks[0].mlp[0].out_features
+        ent = {"sig": self._sig, "table": table, "n": len(blocks), "nh": nh, "f": f, "eps": blocks[0].ln1.eps,
+               "scratch": K.decode_stack_scratch(self.b, c, f, dev), "keep": keep}
+        self._stacks[which] = ent
+        return ent
+
+    def _run_blocks(self, which, x, t_dev):
+        ent = self._stack(which)
+        if ent is None:
+            blocks, caches = (self.gpt.position_transformer, self.pos_cache) if which == "pos" else (self.gpt.content_transformer, self.con_cache)
+            for blk, cache in zip(blocks, caches):
+                x = _block_append_dev(blk, x, cache, t_dev)
+            return x
+        return K.decode_stack(ent["table"], ent["n"], x.contiguous(), ent["nh"], ent["f"], self.max_rows, t_dev, ent["eps"], ent["scratch"],
+                              int(os.environ.get("DVQ_DECODE_WGS", "0")))
 
     def _step(self, key, body, inputs):
         """run `body(*static_inputs)`: eagerly the first time (creates weight caches, kernel attributes), then captured once and
@@ -310,8 +357,7 @@ class DecodeState:
             if seg_tok is not None:
                 pieces.append((g.seg_emb.weight, seg_tok, 0, None, False))
             x = g._embed(pieces, b, 1, None, "").view(b, -1)
-            for blk, cache in zip(g.position_transformer, self.pos_cache):
-                x = _block_append_dev(blk, x, cache, self.t_pos)
+            x = self._run_blocks("pos", x, self.t_pos)
             K.rows_dev(x, self.hidden, self.t_pos, True)
             logits = g._head(g.position_head, x, None, "ph")[:, : g.config.fine_position_size].float()
             self.t_pos.add_(1)
@@ -324,8 +370,7 @@ class DecodeState:
         def body(upd_tok):
             upd = g._embed([(upd_table, upd_tok, 0, None, False)], b, 1, None, "").view(b, -1)
             x = K.add(K.rows_dev(torch.empty_like(upd), self.hidden, self.t_con, False), upd)
-            for blk, cache in zip(g.content_transformer, self.con_cache):
-                x = _block_append_dev(blk, x, cache, self.t_con)
+            x = self._run_blocks("con", x, self.t_con)
             logits = g._head(g.content_head, x, None, "ch")[:, : g.config.vocab_size].float()
             self.t_con.add_(1)
             return logits

@@ -416,6 +416,27 @@ int dvq_attn_decode_dev(const void* q, const void* k_new, const void* v_new, voi
                         dvq_stream_t stream);
 int dvq_rows_dev(void* x, void* hidden, int dtype, int64_t B, int64_t C, int64_t Tmax, const int64_t* t_dev, int store,
                  dvq_stream_t stream);
+
+/* One token step of ALL blocks of a StackGPT transformer (stackgpt.py:41-96 Block / CausalSelfAttention, one new row per sequence
+ * against K/V caches) as ONE persistent kernel: per block LayerNorm + q / k / v (k, v appended to the caches at row t_dev[0]),
+ * single-row attention per (sequence, head), projection + residual, LayerNorm + fc + GELU, projection + residual -- the phases
+ * separated by a device-wide barrier.  Replaces 12 launches per block of the K/V-cached sampler (each costs ~9 us of command
+ * processing whatever its size).  bf16 weights [out][in] (row-major, as torch.nn.Linear), fp32 biases (may be NULL) and LayerNorm
+ * parameters; B <= 16 sequences, C %% 32 == 0 (<= 2048), F %% 32 == 0, head size %% 8 == 0; x [B][C] bf16 is updated in place.
+ * `layers_dev`: DEVICE array of n_layers dvq_decode_layer.  `scratch`: dvq_decode_stack_scratch_bytes(B, C, F) bytes, ZEROED once by
+ * the caller (the kernel re-arms its barrier counters itself).  n_workgroups <= 0: one workgroup per CU; the grid must be resident
+ * as a whole (nothing else may occupy the device's LDS / wave slots to the point of excluding a workgroup: a barrier that is not
+ * reached within seconds sets the error word -- the 4 bytes at scratch + 16-byte-aligned (4 B C + B F) 2 + 8 -- instead of hanging).
+ * The buffers the phases exchange are accessed with agent-scope atomics (memory side): the barrier needs no cache flush. */
+typedef struct dvq_decode_layer {
+    const void *wq, *wk, *wv, *wo, *w1, *w2;          /* bf16 [C][C] x 4, [F][C], [C][F] */
+    const float *bq, *bk, *bv, *bo, *b1, *b2;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    void *kcache, *vcache;                            /* bf16 [B][Tmax][C] */
+} dvq_decode_layer;
+size_t dvq_decode_stack_scratch_bytes(int64_t B, int64_t C, int64_t F);
+int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C, int n_head, int64_t F, int64_t Tmax, const int64_t* t_dev,
+                     float eps, void* x, void* scratch, int n_workgroups, dvq_stream_t stream);
 /* nn.Dropout(p) with a counter-based hash RNG: y = x * keep / (1-p); the same (seed) reproduces the mask for the backward */
 int dvq_dropout(const void* x, int dtype, int64_t n, float p, uint64_t seed, void* y, dvq_stream_t stream);
 

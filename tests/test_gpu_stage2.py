@@ -483,3 +483,55 @@ def test_fused_constrained_sampler_vs_op_by_op(dev):
     got = df._draw_rule(lg[:, :1027], 1.0, False, 10, None, rule).view(-1)
     ref = _torch_draw_probs(df, lg[:, :1027].float(), 1.0, 10, None, rule).argmax(dim=-1)
     assert torch.equal(got, ref)
+
+
+def test_decode_stack_kernel_vs_per_kernel_token_steps(dev, monkeypatch):
+    """dvq_decode_stack (all blocks of a transformer per token step in one persistent kernel with device-wide barriers) against the
+    per-kernel token steps it replaces: same logits within bf16 rounding over a run of single-row steps, same K/V cache rows, eager and
+    replayed from the captured graph; barrier error word stays clear"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    from dynamicvectorquantization_amd.stackgpt import DecodeState
+    from dynamicvectorquantization_amd import synth
+    cfg = dict(SAMPLER_GPT_CFG, n_embd=256, n_head=4, position_layer=2, content_layer=3)
+    b, steps = 5, 14
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        gpt = instantiate_from_config({"target": "modules.dynamic_modules.stackgpt.StackGPT", "params": cfg}).to(dev).eval()
+        with torch.no_grad():
+            for n, p in gpt.named_parameters():
+                v = synth.det_param("decstack." + n, tuple(p.shape))
+                p.copy_(torch.from_numpy(v * (0.3 if n == "pos_emb" else 1.0)).to(dev))
+        rs = np.random.RandomState(5)
+        tok_c = torch.from_numpy(rs.randint(0, 512, (b, steps))).to(dev)
+        tok_p = torch.from_numpy(rs.randint(0, 16, (b, steps))).to(dev)
+        tok_u = torch.from_numpy(rs.randint(0, 16, (b, steps))).to(dev)
+        seg = torch.zeros(b, steps, dtype=torch.long, device=dev)
+        table = gpt.content_coarse_pos_emb.weight
+
+        def run(flag, use_graph):
+            monkeypatch.setenv("DVQ_DECODE_STACK", flag)
+            st = DecodeState(gpt, b, 64)
+            st.use_graph = use_graph
+            outs = []
+            for i in range(steps):
+                pl = st.position_rows(tok_c[:, i:i + 1], tok_p[:, i:i + 1], table, None, seg[:, i:i + 1] if gpt.activate_segment else None)
+                cl = st.content_rows(tok_u[:, i:i + 1], table)
+                outs.append((pl.float().cpu().numpy(), cl.float().cpu().numpy()))
+            if flag == "1":
+                assert st._stacks, "the fused kernel was not used"
+                for ent in st._stacks.values():
+                    words = ent["scratch"][-64:].view(torch.int32).cpu().numpy()
+                    assert not words.any(), f"barrier counters / error word not clear: {words}"
+            caches = [c_[0][:, :steps].float().cpu().numpy() for c_ in st.con_cache] + [c_[1][:, :steps].float().cpu().numpy() for c_ in st.pos_cache]
+            return outs, caches
+
+        ref, ref_caches = run("0", False)
+        for use_graph in (False, True):
+            got, caches = run("1", use_graph)
+            for i, ((pr, cr), (pg, cg)) in enumerate(zip(ref, got)):
+                for name, a, g_ in (("position", pr, pg), ("content", cr, cg)):
+                    err = float(np.abs(a - g_).max()) / max(1e-6, float(np.abs(a).max()))
+                    assert err < 4e-2, f"step {i} {name} logits: rel-to-max error {err} (graph={use_graph})"
+            for a, g_ in zip(ref_caches, caches):
+                err = float(np.abs(a - g_).max()) / max(1e-6, float(np.abs(a).max()))
+                assert err < 4e-2, f"cache rows differ: {err}"
