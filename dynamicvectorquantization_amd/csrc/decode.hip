@@ -255,12 +255,21 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                 for (int r = tid; r < Tlen; r += DTH) {
                     const bf16_t* kr = kb + (int64_t)r * C;
                     float a = 0.f;
-                    for (int i = 0; i < nv; ++i) {
-                        float kv[8];
-                        if (r == Tlen - 1) unpack8(cload16(knr + i * 8), kv);
-                        else load8(kr + i * 8, kv);
+                    for (int i0 = 0; i0 < nv; i0 += 8) {              // 8 independent 16-byte loads in flight (a loop over nv serialised them)
+                        uint4 kk[8];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) a = fmaf(qs[i * 8 + j], kv[j], a);
+                        for (int u = 0; u < 8; ++u)
+                            kk[u] = i0 + u >= nv ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? cload16(knr + (i0 + u) * 8)
+                                                                                         : *reinterpret_cast<const uint4*>(kr + (i0 + u) * 8);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (i0 + u < nv) {
+                                float kv[8];
+                                unpack8(kk[u], kv);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) a = fmaf(qs[(i0 + u) * 8 + j], kv[j], a);
+                            }
+                        }
                     }
                     sc[r] = a * p.scale;
                 }
@@ -298,9 +307,21 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) part[grp * hs + ch * 8 + j] = acc[j];
                 __syncthreads();
+                // fold the ngrp row-group partials in two levels (32 threads walking all of them one by one took ~4 us)
+                const int nsl = DTH / hs;                             // slices of row groups, one per thread and output channel
+                const int gps = (ngrp + nsl - 1) / nsl;
+                {
+                    const int d = tid % hs, sl = tid / hs;
+                    float v = 0.f;
+                    if (sl < nsl)
+                        for (int g = sl * gps; g < min(ngrp, (sl + 1) * gps); ++g) v += part[g * hs + d];
+                    __syncthreads();
+                    if (sl < nsl) part[sl * hs + d] = v;
+                    __syncthreads();
+                }
                 for (int d2 = tid; d2 < (hs >> 1); d2 += DTH) {
                     float v0 = 0.f, v1 = 0.f;
-                    for (int g = 0; g < ngrp; ++g) {
+                    for (int g = 0; g < nsl; ++g) {
                         v0 += part[g * hs + 2 * d2];
                         v1 += part[g * hs + 2 * d2 + 1];
                     }
