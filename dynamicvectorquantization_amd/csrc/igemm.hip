@@ -2666,14 +2666,14 @@ int dvq_gemm_nt(const void* A, const void* B, void* C, int dtype, int64_t M, int
     return DVQ_EINVAL;
 }
 
-int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred, int64_t I, int64_t J, int64_t lda,
-                int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int impl,
-                dvq_stream_t stream) {
+static int gemm_tn_impl(const void* A, const void* B, float* C, float* colsum, int dtype, int64_t Mred, int64_t I, int64_t J, int64_t lda,
+                        int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int impl, dvq_stream_t stream) {
     DVQ_REQUIRE(A && B && C, DVQ_EINVAL, "dvq_gemm_tn: null pointer");
     DVQ_REQUIRE(Mred > 0 && I > 0 && J > 0 && batch > 0 && batch <= 65535 && Mred < (1ll << 31), DVQ_ESHAPE,
                 "dvq_gemm_tn: bad shape");
+    DVQ_REQUIRE(colsum == nullptr || batch == 1, DVQ_EINVAL, "dvq_gemm_tn_colsum: batch must be 1");
     TnParams p{};
-    p.A = A; p.B = B; p.C = C; p.colsumA = nullptr;
+    p.A = A; p.B = B; p.C = C; p.colsumA = colsum;
     p.conv = 0;
     p.Mred = (int)Mred; p.I = (int)I; p.J = (int)J;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -2684,6 +2684,18 @@ int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred,
     if (dtype == DVQ_BF16) return launch_tn<bf16_t>(p, batch, impl, (hipStream_t)stream);
     dvq_set_error("dvq_gemm_tn: bad dtype");
     return DVQ_EINVAL;
+}
+
+int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred, int64_t I, int64_t J, int64_t lda,
+                int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int impl,
+                dvq_stream_t stream) {
+    return gemm_tn_impl(A, B, C, nullptr, dtype, Mred, I, J, lda, ldb, ldc, batch, sA, sB, sC, impl, stream);
+}
+
+int dvq_gemm_tn_colsum(const void* A, const void* B, float* C, float* colsum, int dtype, int64_t Mred, int64_t I, int64_t J, int64_t lda,
+                       int64_t ldb, int64_t ldc, int impl, dvq_stream_t stream) {
+    DVQ_REQUIRE(colsum != nullptr, DVQ_EINVAL, "dvq_gemm_tn_colsum: null pointer");
+    return gemm_tn_impl(A, B, C, colsum, dtype, Mred, I, J, lda, ldb, ldc, 1, 0, 0, 0, impl, stream);
 }
 
 }  // extern "C"

@@ -528,13 +528,18 @@ def gemm_nt(a, b, m, n, k, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, alpha=1.0, 
     return out
 
 
-def gemm_tn(a, b, mred, i, j, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, out=None, impl=0):
-    """C[b][i][j] (fp32) += sum_m A[b][m][i] B[b][m][j]"""
+def gemm_tn(a, b, mred, i, j, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, out=None, impl=0, colsum=None):
+    """C[b][i][j] (fp32) += sum_m A[b][m][i] B[b][m][j]; colsum (fp32 [i], batch 1): += column sums of A from the same pass"""
     if out is None:
         out = torch.zeros(batch * (sc if sc else i * ldc), dtype=torch.float32, device=a.device)
     es = a.element_size()
     if a.is_cuda and es == 2 and mred >= 1024 and i >= 256 and j >= 256:
         ensure_workspace(a.device)        # split partials of the 256 x 256 kernel (fold kernel instead of fp32 atomics)
+    if colsum is not None:
+        assert batch == 1
+        _timed("gemm_tn", 2 * mred * i * j, es * mred * (i + j) + 4 * i * j, lambda: check(
+            lib().dvq_gemm_tn_colsum(_p(a), _p(b), _p(out), _p(colsum), dt(a), mred, i, j, lda, ldb, ldc, impl, _s()), "dvq_gemm_tn_colsum"))
+        return out
     _timed("gemm_tn", 2 * batch * mred * i * j, es * batch * mred * (i + j) + 4 * batch * i * j, lambda: check(
         lib().dvq_gemm_tn(_p(a), _p(b), _p(out), dt(a), mred, i, j, lda, ldb, ldc, batch, sa, sb, sc, impl, _s()),
         "dvq_gemm_tn"))

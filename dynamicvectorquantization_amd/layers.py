@@ -226,9 +226,12 @@ class Linear(nn.Module):
         x2d, w = tape.s["x"], tape.s["w"]
         m = x2d.shape[0]
         # dW[o][i] += sum_m dy[m][o] x[m][i]  straight into the fp32 gradient; db = column sums of dy
+        fused_db = self.bias is not None and self.out_p == self.out_features and os.environ.get("DVQ_LINEAR_DB", "fused") == "fused"
+        # bias gradient = column sums of dy: taken from the weight-gradient kernel's pass over dy (a separate 17-us reduction per layer
+        # otherwise: 2.5 ms of a stage-2 train step)
         K.gemm_tn(dy, x2d, m, self.out_features, self.in_features, self.out_p, self.in_features, self.in_features,
-                  out=_grad_buf(self.weight))
-        if self.bias is not None:
+                  out=_grad_buf(self.weight), colsum=_grad_buf(self.bias) if fused_db else None)
+        if self.bias is not None and not fused_db:
             if self.out_p == self.out_features:
                 K.sum_batch(dy, _grad_buf(self.bias))            # accumulates
             else:

@@ -234,6 +234,10 @@ int dvq_gemm_nt(const void* A, const void* B, void* C, int dtype, int64_t M, int
 int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred, int64_t I, int64_t J, int64_t lda,
                 int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int impl,
                 dvq_stream_t stream);
+/* the same product with colsum[i] += sum_m A[m][i] from the same pass over A (bias gradient of a Linear layer next to its weight
+ * gradient: torch.nn.Linear's autograd, stackgpt.py:44-96) */
+int dvq_gemm_tn_colsum(const void* A, const void* B, float* C, float* colsum, int dtype, int64_t Mred, int64_t I, int64_t J, int64_t lda,
+                       int64_t ldb, int64_t ldc, int impl, dvq_stream_t stream);
 
 /* Register a caller-owned device scratch buffer (one per process; the library cuts it into four slots, one per stream that
  * uses it, so the side-stream weight gradients and the main stream never share one).  With >= 76 MiB per slot the split-K
