@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void attn_bwd_dq_kernel(Att
 // registers next to 2 x 64 resident operand registers and the staged tiles do not fit one wave (measured: 1220 B/lane of
 // scratch); the score tile is then computed by both launches (1.25x the flops of this kernel).
 template <int HS, int MODE = 0>
-__global__ __launch_bounds__(256, HS == 64 ? 2 : 1) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (HS == 64 || (HS == 128 && MODE != 0)) ? 2 : 1) void attn_bwd_dkv_kernel(AttnParams p) {
     constexpr bool DO_DV = MODE != 2, DO_DK = MODE != 1;
     using G = Geo<HS>;
     constexpr int NS = HS / 16, NM = HS / 32, STAGE = 2 * G::RTILE + 2 * G::CTILE;
@@ -525,6 +525,14 @@ int launch_fwd(const AttnParams& p, dim3 grid, hipStream_t stream) {
     attn_fwd_kernel<HS><<<grid, dim3(256), lds, stream>>>(p);
     return 0;
 }
+static bool split128_env() {
+    static const bool v = [] {
+        const char* e = getenv("DVQ_ATTN_DKV_SPLIT");
+        return e == nullptr || atoi(e) != 0;
+    }();
+    return v;
+}
+
 template <int HS>
 int launch_bwd(const AttnParams& p, dim3 grid, int64_t rows, hipStream_t stream) {
     using G = Geo<HS>;
@@ -532,6 +540,13 @@ int launch_bwd(const AttnParams& p, dim3 grid, int64_t rows, hipStream_t stream)
     const int lds_kv = 2 * (2 * G::RTILE + 2 * G::CTILE), lds_q = 2 * (2 * G::RTILE + G::CTILE);
     dvq_ensure_dynamic_lds((const void*)attn_bwd_dq_kernel<HS>, lds_q);
     if constexpr (HS > 128) {
+        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 1>, lds_kv);
+        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 2>, lds_kv);
+        attn_bwd_dkv_kernel<HS, 1><<<grid, dim3(256), lds_kv, stream>>>(p);
+        attn_bwd_dkv_kernel<HS, 2><<<grid, dim3(256), lds_kv, stream>>>(p);
+    } else if (HS == 128 && split128_env()) {
+        // head size 128: dV and dK in two launches of half the accumulators (188 / 256 registers instead of 470: two waves per SIMD hide
+        // the operand loads; the score tile is computed twice).  Stage-2 train step 91.5 -> 90.3 ms; DVQ_ATTN_DKV_SPLIT=0: one launch
         dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 1>, lds_kv);
         dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 2>, lds_kv);
         attn_bwd_dkv_kernel<HS, 1><<<grid, dim3(256), lds_kv, stream>>>(p);
