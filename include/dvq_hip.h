@@ -40,8 +40,8 @@ enum { DVQ_F32 = 0, DVQ_BF16 = 1 };
 enum { DVQ_OK = 0, DVQ_EINVAL = -1, DVQ_ESHAPE = -2, DVQ_EARCH = -3, DVQ_ELAUNCH = -4, DVQ_EWORKSPACE = -5 };
 
 const char* dvq_last_error(void);
-int dvq_version(void);     /* 104: round 3 (fused constrained sampler, GroupNorm-backward partials argument, four workspace slots,
-                            * no vendor-library entry points) */
+int dvq_version(void);     /* 105: round 3 (fused constrained sampler, GroupNorm-backward partials argument, four workspace slots,
+                            * no vendor-library entry points; + dvq_decode_stack, dvq_gemm_tn_colsum) */
 /* 0 if the current HIP device is gfx950, DVQ_EARCH otherwise */
 int dvq_check_device(void);
 /* Diagnostics for the benchmark's roofline context (allocates, synchronises the stream; NOT for the hot path): TFLOP/s and shader
