@@ -45,10 +45,25 @@ def full_config(objective="full"):
                         loss="full" if objective == "full" else "ae", ndf=64)
 
 
-def _cpu_baseline_worker(threads, bs, objective="full"):
-    """child process: time train steps of the oracle on `threads` host threads; prints one JSON line"""
+def _cpu_baseline_worker(threads, bs, objective="full", budget_s=15.0):
+    """child process: time the oracle on `threads` host threads for ~budget_s seconds; prints one JSON line.
+    objective: "full" / "ae" = train steps of the DQ-VAE objective at 256x256; "vq" = the reference's VQ argmin formula
+    (fp32 addmm distances + argmin, quantize2_mask.py:29-55) at the BASELINE shape N=65536, D=256, K=1024."""
     torch.set_num_threads(threads)
     from dynamicvectorquantization_amd import synth
+    if objective == "vq":
+        from oracle import vq as ovq
+        x, cb = synth.vq_inputs(65536, 256, 1024, "normal", 0)
+        ovq.argmin_fp32_formula(x[:4096], cb)               # thread pool / allocator warm-up
+        t0 = time.time()
+        n = 0
+        while True:
+            ovq.argmin_fp32_formula(x, cb)
+            n += 1
+            if time.time() - t0 > budget_s or n >= 20:
+                break
+        print(json.dumps({"n": n, "sec": time.time() - t0}), flush=True)
+        return
     from dynamicvectorquantization_amd.config import instantiate_from_config
     from oracle import entropy as oent
     from oracle import train_step as ots
@@ -69,30 +84,54 @@ def _cpu_baseline_worker(threads, bs, objective="full"):
         else:
             ots.train_steps(sd, [x], thr, steps=1)
         n += 1
-        if time.time() - t0 > 15.0 or n >= 10:      # ~15 s of CPU work
+        if time.time() - t0 > budget_s or n >= 10:      # ~budget_s of CPU work
             break
     print(json.dumps({"n": n, "sec": time.time() - t0}), flush=True)
 
 
-def cpu_baseline(objective="full", timeout_s=150):
-    """oracle (a port of the reference's CPU path) timed on this host's cores: AE fwd+bwd+Adam at 256x256.
-    Bounded: a child process with a hard timeout, at most 16 threads (the torch-CPU conv path stops
-    scaling / collapses under oversubscription well before the box's full core count)."""
+def _cpu_leg(objective, threads, bs, budget_s, timeout_s):
+    """one bounded child process of the CPU oracle -> {"value", "unit", "cores", "sample"}"""
     import subprocess
-    threads = max(1, min(16, os.cpu_count() or 1))
-    bs = 1
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), str(bs), objective]
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), str(bs), objective, str(budget_s)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS=str(threads),
+               HIP_VISIBLE_DEVICES="")
+    what = {"full": f"train step(s) of the complete two-optimizer objective at bs={bs}, 256x256 fp32",
+            "ae": f"autoencoder-only train step(s) (L1 + codebook: forward + backward + Adam) at bs={bs}, 256x256 fp32",
+            "vq": "VQ argmin call(s) in the reference's fp32 addmm formula at N=65536, D=256, K=1024"}[objective]
+    unit = "GB/s (algorithmic bytes: rows + codebook + indices)" if objective == "vq" else "images/sec"
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
         rec = json.loads(r.stdout.strip().splitlines()[-1])
-        return {"value": round(rec["n"] * bs / rec["sec"], 4), "unit": "images/sec", "cores": threads, "kind": "port",
-                "sample": f"{rec['n']} train step(s) of the {'complete two-optimizer' if objective == 'full' else 'autoencoder-only'} "
-                          f"objective at bs={bs}, 256x256 fp32, "
-                          f"torch-CPU oracle, {threads} threads of {os.cpu_count()} host cores, {rec['sec']:.1f} s"}
+        if objective == "vq":
+            val = rec["n"] * (65536 * 256 * 4 + 1024 * 256 * 4 + 65536 * 8) / rec["sec"] / 1e9
+        else:
+            val = rec["n"] * bs / rec["sec"]
+        return {"workload": {"full": "complete_step", "ae": "ae_only_step", "vq": "vq_argmin"}[objective], "value": round(val, 4),
+                "unit": unit, "cores": threads, "kind": "port",
+                "sample": f"{rec['n']} {what}, torch-CPU / numpy oracle, {threads} thread(s) of {os.cpu_count()} host cores, {rec['sec']:.1f} s"}
     except Exception as e:      # timeout or failure: report, never stall the GPU measurement
-        return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port",
-                "sample": f"cpu baseline did not finish within {timeout_s}s ({type(e).__name__})"}
+        return {"workload": objective, "value": None, "unit": unit, "cores": threads, "kind": "port",
+                "sample": f"cpu baseline leg did not finish within {timeout_s}s ({type(e).__name__})"}
+
+
+def cpu_baseline(objective="full", timeout_s=150):
+    """oracle (a port of the reference's CPU path) timed on this host's cores.  Headline leg: the benchmark's own objective at
+    bs = 1 on at most 16 threads (the torch-CPU conv path stops scaling / collapses under oversubscription well before the box's
+    full core count).  `legs`: VQ argmin at the BASELINE shape on 16 threads and on ONE thread, the autoencoder-only
+    step at bs = 2 on 16 threads and at bs = 1 on one thread.  Every leg is a bounded child process (~8-15 s of CPU work)."""
+    threads = max(1, min(16, os.cpu_count() or 1))
+    t_end = time.time() + timeout_s
+    head = _cpu_leg(objective, threads, 1, 15.0, max(20.0, min(60.0, t_end - time.time())))
+    legs = []
+    for obj, th, bs, budget in (("vq", threads, 0, 6.0), ("vq", 1, 0, 6.0), ("ae", threads, 2, 8.0), ("ae", 1, 1, 10.0)):
+        left = t_end - time.time()
+        if left < 20.0:
+            legs.append({"workload": obj, "cores": th, "skipped": "time budget"})
+            continue
+        legs.append(_cpu_leg(obj, th, bs, budget, min(left, 60.0)))
+    out = {k: head[k] for k in ("value", "unit", "cores", "kind", "sample")}
+    out["legs"] = legs
+    return out
 
 
 OBJECTIVES = {
@@ -158,6 +197,42 @@ def vq_microbench(dev, reps=20, in_training=None):
                     "rerank_rows_full": int(flagged[0].item()), "rerank_rows_candidates": int(flagged[1].item()),
                     "alg_bytes": nbytes, "shape": [n, d, k]}
     return out
+
+
+def parity_bf16(model, x):
+    """bf16 is the benchmark's precision, fp32 the parity path ("bf16 is perf mode with a reported mismatch
+    rate").  The SAME weights (the ones the timed steps left behind), one bs-64 batch, eval forward through both instantiations of
+    the kernels: how many code indices / grain decisions differ and how far the reconstructions are apart
+    (reference bar for the indices: quantize2_mask.py:50-55)."""
+    from dynamicvectorquantization_amd import runtime as rt
+    was_training = model.training
+    model.eval()
+    res = {}
+    try:
+        with torch.no_grad():
+            for tag, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+                with rt.compute_dtype_ctx(dt):
+                    o = model.ae_fwd(x, None)
+                    res[tag] = (o["codes"].clone(), o["grain"].clone(), o["rec"].float().clone(), float(o["qloss"]))
+        torch.cuda.synchronize()
+    finally:
+        model.train(was_training)
+    cb, gb, rb, qb = res["bf16"]
+    cf, gf, rf, qf = res["fp32"]
+    # codes live on the fine grid; a coarse cell holds one code four times -- count CELLS (a coarse cell once)
+    rep = gf.repeat_interleave(cb.shape[1] // gf.shape[1], 1).repeat_interleave(cb.shape[2] // gf.shape[2], 2).bool()
+    diff = cb != cf
+    n_fine = int(rep.sum())
+    n_coarse = int((~rep).sum()) // 4
+    mism = int((diff & rep).sum()) + int((diff & ~rep).sum()) // 4
+    return {"batch": int(x.shape[0]), "cells": n_fine + n_coarse, "code_mismatches": mism,
+            "code_mismatch_rate": round(mism / max(1, n_fine + n_coarse), 6),
+            "grain_mismatches": int((gb != gf).sum()), "grain_cells": int(gf.numel()),
+            "recon_rel_err": round(float((rb - rf).norm() / rf.norm()), 6),
+            "qloss_bf16": round(qb, 6), "qloss_fp32": round(qf, 6),
+            "note": "eval forward (entropy gate, encoder, VQ argmin, decoder) of the bf16 benchmark path vs the fp32 instantiation "
+                    "of the same kernels on the weights the timed steps produced; indices are the exact argmin in both, they "
+                    "differ where bf16 rounding of the encoder activations moves a row across a Voronoi boundary"}
 
 
 def _spawn_ranks(n):
@@ -257,7 +332,8 @@ def extra_workloads(budget_s):
 
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
-        return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "full")
+        return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "full",
+                                    float(sys.argv[5]) if len(sys.argv) > 5 else 15.0)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -271,6 +347,7 @@ def main():
                          "(NOT the reference's schedule; reported in config.objective)")
     ap.add_argument("--no-ae-only", action="store_true", help="skip the secondary autoencoder-only measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-fp32 code-index mismatch block")
     ap.add_argument("--no-vq-microbench", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python (no hipGraph replay of the step)")
     ap.add_argument("--mode", default="auto", choices=["auto", "graph", "eager"],
@@ -447,6 +524,12 @@ def main():
     dt_, host_issue, prof, model = run(args.objective, args.steps, args.warmup, True)
     ratio = model._graph_info.pop("fine_ratio")
     graph_info, vq_seen = model._graph_info, getattr(model, "_vq_seen", None)
+    parity = None
+    if rank == 0 and not args.no_parity:
+        try:
+            parity = parity_bf16(model, torch.from_numpy(synth.half_flat_images(args.bs, 256, seed=4321)).to(dev))
+        except Exception as e:          # evidence block: never costs the headline line
+            parity = {"failed": f"{type(e).__name__}: {str(e)[:160]}"}
 
     ae_only = None
     if args.objective == "full" and not args.no_ae_only:
@@ -515,6 +598,7 @@ def main():
                                     "TFLOPs": round(v["TFLOPs"], 2)} for k, v in fam.items()},
         }
         out["ae_only"] = ae_only
+        out["parity_bf16"] = parity
         if not args.no_vq_microbench:
             out["vq_argmin"] = vq_microbench(dev, in_training=vq_seen)
         if world == 1 and not args.no_cpu_baseline:

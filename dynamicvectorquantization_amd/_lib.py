@@ -62,6 +62,7 @@ SIGNATURES = {
     "dvq_conv2d_fwd_act": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp]),
     "dvq_conv2d_dgrad_mask": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
     "dvq_set_workspace": (i32, [vp, i64]),
+    "dvq_workspace_release": (i32, [vp]),
     "dvq_halo_trace_read": (i32, [vp, i64]),
     "dvq_permute_dual": (i32, [vp, vp, i64, i32, i32, i32, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]),
     "dvq_permute_dual_back": (i32, [vp, vp, vp, vp, i64, i64, i64, i32, i32, i64, i64, vp, vp]),
@@ -118,6 +119,7 @@ SIGNATURES = {
     "dvq_attn_decode_dev": (i32, [vp, vp, vp, vp, vp, i32, i64, i64, i64, vp, i64, f32, vp, vp]),
     "dvq_rows_dev": (i32, [vp, vp, i32, i64, i64, i64, vp, i32, vp]),
     "dvq_decode_stack_scratch_bytes": (sz, [i64, i64, i64]),
+    "dvq_decode_stack_status": (i32, [vp, i64, i64, i64, i32, vp]),
     "dvq_decode_stack": (i32, [vp, i32, i64, i64, i32, i64, i64, vp, C.c_float, vp, vp, i32, vp]),
     "dvq_dropout": (i32, [vp, i32, i64, f32, C.c_uint64, vp, vp]),
     "dvq_fill_f32": (i32, [vp, f32, i64, vp]),

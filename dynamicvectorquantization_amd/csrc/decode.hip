@@ -51,20 +51,28 @@ __device__ __forceinline__ float dec_gelu(float x) { return 0.5f * x * (1.f + er
 // stores_done = every wave waits for the acknowledgement of its coherent stores; the barrier itself then synchronises the workgroup
 // WITHOUT draining vmcnt, so the weight loads issued in between stay in flight while the workgroup waits for the others.
 __device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
-__device__ __forceinline__ void grid_barrier(unsigned* sync, unsigned target) {
+// A workgroup that waits longer than ~seconds (some workgroup is not resident: the GPU is shared, or the grid was sized wrongly)
+// gives up LOUDLY: it raises the error word sync[2] and adds DEC_ABORT to the arrival counter, which releases every other
+// workgroup's wait at once; every workgroup sees the poisoned counter in the value that ended its own wait (no extra load) and
+// leaves the kernel.  The host reads sync[2] after the sampling run (dvq_decode_stack_status) and raises.
+constexpr unsigned DEC_ABORT = 0x40000000u;
+__device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, unsigned* lds_flag) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        unsigned spins = 0, seen;
+        while ((seen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 22)) {                // ~seconds: a workgroup is not resident -- give up loudly instead of hanging
-                sync[2] = 1u;
+            if (++spins > (1u << 22)) {
+                __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                seen = __hip_atomic_fetch_add(&sync[0], DEC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | DEC_ABORT;
                 break;
             }
         }
+        *lds_flag = seen >= DEC_ABORT ? 1u : 0u;
     }
     __syncthreads();
+    return *lds_flag == 0u;
 }
 
 // coherent (memory-side) accesses to the buffers the phases exchange
@@ -188,6 +196,8 @@ __device__ __forceinline__ float gemv16_reduce(f32x4 acc, float* red) {
 __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);                      // [8][256]
+    __shared__ unsigned bflag_s;
+    unsigned* bflag = &bflag_s;
     bf16_t* xn = reinterpret_cast<bf16_t*>(smem + DNW * 256 * 4);     // [B][C] normalised rows | attention scratch
     const int tid = threadIdx.x, nwg = gridDim.x, wg = blockIdx.x;
     const int B = p.B, C = p.C, F = p.F, nh = p.nh, hs = C / nh;
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
         }
         stores_done();
         stamp();
-        grid_barrier(p.sync, ++bar * nwg);
+        if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
         stamp();
         // ---- (2) attention of the new row over cache rows 0 .. t, one (sequence, head) per work item ------------------------------
         {
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                 for (int w = 0; w < DNW; ++w) tot += rd[8 + w];
                 const float inv = 1.f / tot;
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int r = grp; r < Tlen; r += ngrp) {
+                for (int r = grp < ngrp ? grp : Tlen; r < Tlen; r += ngrp) {
                     float vv[8];
                     if (r == Tlen - 1) unpack8(cload16(vnr + ch * 8), vv);
                     else load8(vb + (int64_t)r * C + ch * 8, vv);
@@ -304,8 +314,10 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[j] = fmaf(pt, vv[j], acc[j]);
                 }
+                if (grp < ngrp) {                                     // (DTH % nv != 0, e.g. head size 96: the last threads hold no group)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) part[grp * hs + ch * 8 + j] = acc[j];
+                    for (int j = 0; j < 8; ++j) part[grp * hs + ch * 8 + j] = acc[j];
+                }
                 __syncthreads();
                 // fold the ngrp row-group partials in two levels (32 threads walking all of them one by one took ~4 us)
                 const int nsl = DTH / hs;                             // slices of row groups, one per thread and output channel
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
         stores_done();
         stamp();
         gemv_load_w(L.wo, C, wg * 16, wg < cb, wf);                    // weights of phase 3, in flight across the barrier
-        grid_barrier(p.sync, ++bar * nwg);
+        if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
         stamp();
         // ---- (3) output projection + residual (in place: an element of x is read and written by the same thread pair) -------------
         for (int blk = wg; blk < cb; blk += nwg) {
@@ -350,7 +362,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
         stores_done();
         stamp();
         gemv_load_w(L.w1, C, wg * 16, wg < fb, wf);
-        grid_barrier(p.sync, ++bar * nwg);
+        if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
         stamp();
         // ---- (4) LayerNorm 2 + fc + GELU -------------------------------------------------------------------------------------
         if (wg < fb) ln_rows_to_lds(p.x, B, C, p.eps, L.ln2g, L.ln2b, xn);
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
         stores_done();
         stamp();
         gemv_load_w(L.w2, F, wg * 16, wg < cb, wf);
-        grid_barrier(p.sync, ++bar * nwg);
+        if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
         stamp();
         // ---- (5) second projection + residual --------------------------------------------------------------------------------
         for (int blk = wg; blk < cb; blk += nwg) {
@@ -389,7 +401,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
             gemv_load_w(which == 0 ? Ln.wq : which == 1 ? Ln.wk : Ln.wv, C, (wg - which * cb) * 16, wg < 3 * cb, wf);
         }
         stamp();
-        grid_barrier(p.sync, ++bar * nwg);
+        if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
         stamp();
     }
     // the last workgroup to get here re-arms the counters for the next launch (every workgroup is past its last barrier)
@@ -409,6 +421,20 @@ extern "C" {
 
 size_t dvq_decode_stack_scratch_bytes(int64_t B, int64_t C, int64_t F) {
     return (size_t)((4 * B * C + B * F) * 2 + 64 + 1024);         // (+ 128 time stamps of workgroup 0, DVQ_DECODE_TRACE)
+}
+
+int dvq_decode_stack_status(const void* scratch, int64_t B, int64_t C, int64_t F, int reset, dvq_stream_t stream) {
+    DVQ_REQUIRE(scratch && B > 0 && C > 0 && F > 0, DVQ_EINVAL, "dvq_decode_stack_status: bad arguments");
+    unsigned* sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(const_cast<void*>(scratch)) + ((4 * B * C + B * F) * 2 + 15) / 16 * 16);
+    unsigned host[4] = {0, 0, 0, 0};
+    DVQ_REQUIRE(hipMemcpyAsync(host, sync, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
+                    hipStreamSynchronize((hipStream_t)stream) == hipSuccess,
+                DVQ_ELAUNCH, "dvq_decode_stack_status: copy failed");
+    if (host[2] == 0u) return DVQ_OK;
+    if (reset) (void)hipMemsetAsync(sync, 0, sizeof(host), (hipStream_t)stream);
+    dvq_set_error("dvq_decode_stack: a device-wide barrier timed out (a workgroup of the persistent grid was not resident -- is the GPU "
+                  "shared?); the token steps since the last check are invalid");
+    return DVQ_ELAUNCH;
 }
 
 int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C, int n_head, int64_t F, int64_t Tmax, const int64_t* t_dev,

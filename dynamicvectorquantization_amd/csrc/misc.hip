@@ -561,34 +561,47 @@ void* dvq_workspace(int64_t* bytes) {
     return g_ws_ptr;
 }
 
-// The registered buffer is cut into DVQ_WS_SLOTS equal slots, one per STREAM that asks for scratch (least recently used slot
-// re-assigned when a new stream shows up): kernels that run concurrently on different streams -- weight gradients on the side
-// stream next to the main stream's split GEMMs -- never share partials.  Host-side bookkeeping only; calls come from one thread.
-static constexpr int DVQ_WS_SLOTS = 4;
+// The registered buffer is cut into DVQ_WS_SLOTS equal slots, one per STREAM that asks for scratch: kernels that run concurrently
+// on different streams -- weight gradients on the side stream next to the main stream's split GEMMs -- never share partials.
+//   * a stream that asks while it is CAPTURING pins its slot: the recorded graph bakes the address in, so the slot stays with
+//     that stream until dvq_workspace_release(stream) (runtime.StepGraph drops it with the recording) or dvq_set_workspace;
+//   * an unpinned slot may be handed to a new stream only when its owner is idle (hipStreamQuery == hipSuccess: nothing that
+//     could still write partials there), least recently used first;
+//   * otherwise the caller gets nullptr, which every user treats as "no workspace" (split kernels fall back to fp32 atomics).
+// The tables are guarded by a mutex (the autograd engine may call from its own thread).
+static constexpr int DVQ_WS_SLOTS = 8;
 static hipStream_t g_ws_stream[DVQ_WS_SLOTS] = {};
 static uint64_t g_ws_used[DVQ_WS_SLOTS] = {};
 static bool g_ws_taken[DVQ_WS_SLOTS] = {};
+static bool g_ws_pinned[DVQ_WS_SLOTS] = {};
 static uint64_t g_ws_tick = 0;
+static std::mutex g_ws_mutex;
 
 void* dvq_workspace_stream(hipStream_t stream, int64_t* bytes) {
-    if (g_ws_ptr == nullptr) {
-        if (bytes) *bytes = 0;
-        return nullptr;
-    }
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    if (bytes) *bytes = 0;
+    if (g_ws_ptr == nullptr) return nullptr;
     const int64_t slot_bytes = (g_ws_bytes / DVQ_WS_SLOTS) & ~(int64_t)255;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
     int slot = -1;
     for (int i = 0; i < DVQ_WS_SLOTS && slot < 0; ++i)
         if (g_ws_taken[i] && g_ws_stream[i] == stream) slot = i;
     for (int i = 0; i < DVQ_WS_SLOTS && slot < 0; ++i)
         if (!g_ws_taken[i]) slot = i;
     if (slot < 0) {
-        slot = 0;
-        for (int i = 1; i < DVQ_WS_SLOTS; ++i)
-            if (g_ws_used[i] < g_ws_used[slot]) slot = i;
+        for (int i = 0; i < DVQ_WS_SLOTS; ++i) {
+            if (g_ws_pinned[i] || (slot >= 0 && g_ws_used[i] >= g_ws_used[slot])) continue;
+            if (hipStreamQuery(g_ws_stream[i]) == hipSuccess) slot = i;       // idle owner: nothing in flight uses the slot
+        }
+        (void)hipGetLastError();                 // (hipErrorNotReady of a busy stream is not an error of ours)
+        if (slot < 0) return nullptr;
+        g_ws_pinned[slot] = false;
     }
     g_ws_taken[slot] = true;
     g_ws_stream[slot] = stream;
     g_ws_used[slot] = ++g_ws_tick;
+    if (capturing) g_ws_pinned[slot] = true;
     if (bytes) *bytes = slot_bytes;
     return (char*)g_ws_ptr + (int64_t)slot * slot_bytes;
 }
@@ -600,9 +613,17 @@ int dvq_version(void) { return 105; }
 
 int dvq_set_workspace(void* ptr, int64_t bytes) {
     DVQ_REQUIRE((ptr == nullptr) == (bytes == 0) && bytes >= 0, DVQ_EINVAL, "dvq_set_workspace: bad arguments");
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
     g_ws_ptr = ptr;
     g_ws_bytes = bytes;
-    for (int i = 0; i < DVQ_WS_SLOTS; ++i) g_ws_taken[i] = false;
+    for (int i = 0; i < DVQ_WS_SLOTS; ++i) g_ws_taken[i] = g_ws_pinned[i] = false;
+    return DVQ_OK;
+}
+
+int dvq_workspace_release(dvq_stream_t stream) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (int i = 0; i < DVQ_WS_SLOTS; ++i)
+        if (g_ws_taken[i] && g_ws_stream[i] == (hipStream_t)stream) g_ws_taken[i] = g_ws_pinned[i] = false;
     return DVQ_OK;
 }
 

@@ -429,9 +429,15 @@ def conv2d_wgrad(d: ConvDesc, x, dy, db=None):
 
 
 _workspace = {}
-# 4 per-stream slots (csrc/misc.hip: dvq_workspace_stream) of 80 MB: 256 workgroups x (9 x 128 x 64 + 128) fp32 partials of the
+# 8 per-stream slots (csrc/misc.hip: dvq_workspace_stream) of 80 MB: 256 workgroups x (9 x 128 x 64 + 128) fp32 partials of the
 # split-K weight-gradient kernels
-WORKSPACE_BYTES = 4 * (80 << 20)
+WORKSPACE_BYTES = 8 * (80 << 20)
+
+
+def workspace_release(stream):
+    """give back the scratch slot a (capture) stream holds -- called when its recording is dropped"""
+    if _workspace:
+        lib().dvq_workspace_release(C.c_void_p(int(stream.cuda_stream)))
 
 
 def ensure_workspace(device):
@@ -869,6 +875,12 @@ def attn_full_bwd(q, k, v, out, dout, lse, b, t, scale):
 def decode_stack_scratch(b, c, f, device):
     """zeroed scratch of dvq_decode_stack (activations between its phases + the barrier counters it re-arms itself)"""
     return torch.zeros(lib().dvq_decode_stack_scratch_bytes(b, c, f), dtype=torch.uint8, device=device)
+
+
+def decode_stack_status(scratch, b, c, f, reset=True):
+    """synchronising read-back of the kernel's error word: raises RuntimeError when a device-wide barrier timed out (and re-arms
+    the counters so that later launches are not poisoned)"""
+    check(lib().dvq_decode_stack_status(_p(scratch), b, c, f, int(reset), _s()), "dvq_decode_stack_status")
 
 
 def decode_stack(table_dev, n_layers, x, n_head, f, tmax, t_dev, eps, scratch, n_workgroups=0):

@@ -5,8 +5,8 @@ Same constructor kwargs, buffers (`cluster_size_ema`, `embed_ema`), parameter (`
 padding row, requires_grad False under EMA) and return signatures.  Differences that matter:
   * the [N,K] distance matrix and the [K,N] one-hot matrix are never formed;
   * the argmin is the mathematically exact one (oracle/vq.py), lowest index on ties;
-  * the two data-parallel all-reduces (:86-88) are ONE all-reduce of a fused [K, D+1] buffer, and the
-    restart broadcast (:99-100) is kept (rank 0's rows) -- see SURVEY.md section 5/8e;
+  * the two data-parallel all-reduces (:86-88) AND the restart broadcast (:99-100) are ONE all-reduce of a flat buffer
+    ([K, D+1] statistics | [K, D] restart rows: rank 0's candidates + zeros from the other ranks) -- SURVEY.md section 5/8e;
   * RNG: the restart candidate rows are k distinct rows drawn by dvq_sample_rows (keyed Feistel permutation, state in
     device memory) unless `restart_perm` is injected (tests): the reference's randperm stream cannot be reproduced.
 """
@@ -50,7 +50,7 @@ class VQEmbedding(nn.Embedding):
 
     def _prepared(self):
         ent = self._prep
-        ver = (self._cb_version, rt.weights_epoch())
+        ver = (self._cb_version, rt.weights_epoch(), rt.codebook_epoch())
         if ent is None or ent[0] != ver or ent[1].device != self.weight.device:
             ent = (ver, K.vq_prepare(self._codebook()))
             self._prep = ent
@@ -99,47 +99,63 @@ class VQEmbedding(nn.Embedding):
         k, d = self.n_embed, self.weight.shape[-1]
         vectors = vectors.reshape(-1, d)
         idxs = idxs.reshape(-1)
-        # the exchanged buffers are persistent (one pair per module): stable addresses for RCCL and for a recorded step
+        # the exchanged buffer is persistent (one per module): stable addresses for RCCL and for a recorded step.  ONE flat fp32
+        # buffer = [K, D+1] statistics (sums | count) followed by the [K, D] restart candidate rows, so that the data-parallel
+        # exchange is a single collective over it (see _exchange)
         xb = getattr(self, "_xchg", None)
         if xb is None or xb[0].device != vectors.device:
-            xb = (torch.empty(k, d + 1, dtype=torch.float32, device=vectors.device),
-                  torch.empty(k, d, dtype=torch.float32, device=vectors.device))
-            self._xchg = xb
-        stats = K.vq_ema_stats(vectors, idxs, k, out=xb[0])           # [K, D+1] = (sums | count)
+            xb = self._xchg = self._exchange_buffers(k, d, vectors.device)
+        stats = K.vq_ema_stats(vectors, idxs, k, out=xb[1])           # [K, D+1] = (sums | count)
         restart = None
+        dp = self._dp_active()
         if self.restart_unused_codes:
-            n = vectors.shape[0]
-            src = K.cast(vectors, torch.float32)
-            if n < k:
-                # _tile_with_noise (quantize2_mask.py:57-64): repeat rows and add U(0,1) * 0.01/sqrt(D);
-                # only reachable with tiny batches, host-side torch on a [K,D]-sized tensor
-                reps = (k + n - 1) // n
-                src = src.repeat(reps, 1)
-                src = src + torch.rand_like(src) * (0.01 / np.sqrt(d))
-                n = src.shape[0]
-            if self.restart_perm is not None:
-                perm = self.restart_perm.to(vectors.device)[:k]
+            if dp and dist.get_rank() != 0:
+                # only rank 0's candidate rows are used (quantize2_mask.py:99-100 broadcasts them): the others contribute
+                # exact zeros to the fused all-reduce and draw nothing
+                restart = xb[2].zero_()
             else:
-                perm = K.sample_rows(k, n, self._rng(vectors.device))     # = randperm(n)[:k]: k distinct rows
-            restart = K.vq_embed(src.contiguous(), perm, out=xb[1])
-        stats, restart = self._exchange(stats, restart)
+                n = vectors.shape[0]
+                src = K.cast(vectors, torch.float32)
+                if n < k:
+                    # _tile_with_noise (quantize2_mask.py:57-64): repeat rows and add U(0,1) * 0.01/sqrt(D);
+                    # only reachable with tiny batches, host-side torch on a [K,D]-sized tensor
+                    reps = (k + n - 1) // n
+                    src = src.repeat(reps, 1)
+                    src = src + torch.rand_like(src) * (0.01 / np.sqrt(d))
+                    n = src.shape[0]
+                if self.restart_perm is not None:
+                    perm = self.restart_perm.to(vectors.device)[:k]
+                else:
+                    perm = K.sample_rows(k, n, self._rng(vectors.device))     # = randperm(n)[:k]: k distinct rows
+                restart = K.vq_embed(src.contiguous(), perm, out=xb[2])
+        if dp:
+            self._exchange(xb[0] if restart is not None else stats)
         K.vq_ema_apply(stats, restart, self.decay, self.eps, self.cluster_size_ema, self.embed_ema, self.weight.data)
         self._cb_version += 1
 
     @staticmethod
-    def _exchange(stats, restart):
-        """Data-parallel step of the EMA update: ONE all-reduce(SUM) of the fused [K, D+1] statistics
-        (reference: two, quantize2_mask.py:86-88) and the rank-0 broadcast of the restart rows (:99-100).
-        Device-agnostic (tested on CPU tensors over gloo)."""
-        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_DP):
-            def exchange():          # eager even inside a captured training step (runtime.graph_break)
-                if os.environ.get("DVQ_DP_NOOP_COLLECTIVES", "0") == "1":
-                    return
-                dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-                if restart is not None:
-                    dist.broadcast(restart, 0)
-            rt.graph_break(exchange)
-        return stats, restart
+    def _exchange_buffers(k, d, device):
+        """(flat, statistics view [K, D+1], restart-rows view [K, D]) of one fp32 allocation"""
+        flat = torch.empty(k * (d + 1) + k * d, dtype=torch.float32, device=device)
+        return flat, flat[: k * (d + 1)].view(k, d + 1), flat[k * (d + 1):].view(k, d)
+
+    @staticmethod
+    def _dp_active():
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_DP)
+
+    @staticmethod
+    def _exchange(buf):
+        """Data-parallel step of the EMA update as ONE collective: all-reduce(SUM) of the flat buffer holding the [K, D+1]
+        statistics and, behind them, the restart candidate rows -- rank 0's rows plus exact zeros from every other rank, i.e. the
+        reference's `broadcast(_vectors_random, 0)` (quantize2_mask.py:99-100) folded into its two all-reduces (:86-88): one
+        launch and one latency per VQ forward instead of three.  (Sending only the rows of DEAD codes would need the dead set
+        on the host before the collective is sized -- a device-to-host sync in the middle of every training forward, which a
+        recorded step cannot have; the whole [K, D] block is 1 MB at K = 1024.)  Device-agnostic (tested on CPU tensors over gloo)."""
+        def exchange():          # eager even inside a captured training step (runtime.graph_break)
+            if os.environ.get("DVQ_DP_NOOP_COLLECTIVES", "0") == "1":
+                return
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        rt.graph_break(exchange)
 
     def forward(self, inputs):
         """inputs [B, N, D] -> (embeds, idx) with the reference's ordering (quantize2_mask.py:117-128):

@@ -63,6 +63,22 @@ def param_epoch(param):
     return (_weights_epoch, _group_epoch.get(g, 0))
 
 
+# Codebooks are rewritten in place by the EMA update of every training forward (quantize2_mask.py:117-128).  An eagerly
+# launched update bumps its own module's version; a REPLAYED training step rewrites the codebooks without running any
+# Python, so the Trainer bumps this process-wide epoch after every replay -- the search-side copies (vq_prepare planes)
+# of every VQEmbedding are then rebuilt by the next eager search.
+_codebook_epoch = 0
+
+
+def codebook_epoch() -> int:
+    return _codebook_epoch
+
+
+def bump_codebook_epoch():
+    global _codebook_epoch
+    _codebook_epoch += 1
+
+
 # GroupNorm+swish applied inside the consuming conv kernel (no materialised activation: saves HBM traffic and
 # ~1/3 of the saved-activation memory) -- measured SLOWER than the separate HBM-bound pass at B=64 (the in-LDS
 # transform steals VALU issue slots from MFMA-feeding waves), so it is off by default; the statistics epilogue of
@@ -245,6 +261,15 @@ class StepGraph:
 
     def n_segments(self):
         return sum(1 for k, _ in self.items if k == "graph")
+
+    def __del__(self):
+        # the recorded kernels hold the address of this stream's scratch slot (csrc/misc.hip: dvq_workspace_stream pins it while
+        # capturing): with the recording gone the slot may serve another stream
+        try:
+            from . import kernels as K
+            K.workspace_release(self.stream)
+        except Exception:
+            pass
 
 
 # ---------------------------------------------------------------------------------------------

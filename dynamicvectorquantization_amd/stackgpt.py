@@ -283,6 +283,20 @@ class DecodeState:
         self.rows_con = 0
         self.t_con.zero_()
 
+    def check(self):
+        """raise if a device-wide barrier of the persistent token-step kernel timed out since the last check (its workgroups were
+        not all resident, e.g. on a shared GPU): the rows written since are invalid.  One 16-byte read-back per transformer --
+        called once per sampling run, not per token.  After the error the fused kernel is switched off for this state (the next
+        runs use the per-kernel token steps)."""
+        for which, ent in list(self._stacks.items()):
+            try:
+                K.decode_stack_status(ent["scratch"], self.b, self.gpt.config.n_embd, ent["f"])
+            except RuntimeError:
+                self._stacks.clear()
+                self._steps.clear()
+                self._no_stack = True
+                raise
+
     # ---- all blocks of a transformer in one persistent kernel (dvq_decode_stack) ---------------------------------------------------
     def _stack(self, which):
         """(device table of the blocks' weight / cache pointers, scratch, tensors kept alive) of the position ('pos') or content
@@ -291,7 +305,7 @@ class DecodeState:
         blocks, caches = (g.position_transformer, self.pos_cache) if which == "pos" else (g.content_transformer, self.con_cache)
         c, cd = g.config.n_embd, rt.compute_dtype()
         nh = blocks[0].attn.n_head
-        if (os.environ.get("DVQ_DECODE_STACK", "1") == "0" or cd != torch.bfloat16 or self.b > 16 or c % 32 or c > 2048 or (c // nh) % 8 or
+        if (getattr(self, "_no_stack", False) or os.environ.get("DVQ_DECODE_STACK", "1") == "0" or cd != torch.bfloat16 or self.b > 16 or c % 32 or c > 2048 or (c // nh) % 8 or
                 c // nh > 256 or self.max_rows > 12000):
             return None
         ent = self._stacks.get(which)

@@ -391,10 +391,14 @@ class _SamplerMixin:
         kind, sampled, done = rule
         if logits2d.is_cuda and logits2d.shape[1] <= 2048 and logits2d.dtype in (torch.float32, torch.bfloat16) and \
                 os.environ.get("DVQ_SAMPLER", "fused") != "torch":
+            # {seed, counter} of the kernel's counter-based generator, keyed by torch's seed: a later torch.manual_seed() /
+            # seed_everything() restarts the stream (same seed -> same samples, like the op-by-op path's torch generator)
+            seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
             st = self.__dict__.get("_sampler_state")
-            if st is None or st.device != logits2d.device:
-                st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=logits2d.device)
+            if st is None or st.device != logits2d.device or self.__dict__.get("_sampler_seed") != seed:
+                st = torch.tensor([seed, 0], dtype=torch.int64, device=logits2d.device)
                 self.__dict__["_sampler_state"] = st
+                self.__dict__["_sampler_seed"] = seed
             kw = self._fused_rule(kind)
             if kind != "content":
                 kw["forbid_idx"] = sampled
@@ -514,6 +518,7 @@ class _SamplerMixin:
             x_f = torch.cat((x_f, ix), dim=1)
             if seg:
                 x_sf = torch.cat([x_sf, zeros1 + 1], dim=1)
+        st.check()                   # the persistent token-step kernel reports a barrier time-out here: never return garbage tokens
         x_c, x_pc = x_c[:, c_coarse.shape[1]:], x_pc[:, c_pos_coarse.shape[1]:]
         if self.activate_sos_for_fine_sequence:
             x_f, x_pf = x_f[:, c_fine.shape[1]:], x_pf[:, c_fine.shape[1]:]

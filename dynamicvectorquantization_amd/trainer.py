@@ -497,6 +497,10 @@ class Trainer:
             o._fstate["step"] += 1
             o._prepared = False
             sc["scheduler"].step()
+            # the replay rewrote this optimizer's parameters: whatever an EAGER forward (eval / encode / validation_step) packed
+            # or prepared from them before is stale -- same invalidation an eager opt.step() / EMA update does
+            rt.bump_group_epoch(id(o))
+        rt.bump_codebook_epoch()
         self.model.global_step += 1
         self.graph_replays += 1
         return g["losses"]

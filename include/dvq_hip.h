@@ -10,9 +10,10 @@
  *   - every pointer is a DEVICE pointer owned by the caller (incl. workspaces); the library allocates
  *     nothing, launches only on `stream`, never synchronises.  Process-wide state is limited to, and listed here:
  *     the scratch registration of dvq_set_workspace() (one caller-owned buffer per process, i.e. per rank / device, cut into
- *     four equal slots that are handed to the streams using them, least recently used first: set it once before the first call
- *     that uses it; calls that find a slot too small fall back to atomics) and caches of one-off hipFuncSetAttribute calls.
- *     dvq_probe_mfma_rate and dvq_halo_trace_read (diagnostics) are the entry points that allocate or synchronise;
+ *     eight equal slots that are handed to the streams using them; a slot requested during stream capture stays with its
+ *     stream until dvq_workspace_release(); set it once before the first call that uses it; calls that find no slot or a slot
+ *     too small fall back to atomics) and caches of one-off hipFuncSetAttribute calls.
+ *     dvq_probe_mfma_rate, dvq_halo_trace_read (diagnostics) and dvq_decode_stack_status are the entry points that allocate or synchronise;
  *     no vendor BLAS / DNN library is linked or loaded: every product is a kernel of this library;
  *   - every entry point issues KERNEL launches only (no memset / memcpy nodes), so a sequence of calls can be recorded by
  *     HIP stream capture after its first eager execution and replayed (the training step and the sampler do);
@@ -239,11 +240,15 @@ int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred,
 int dvq_gemm_tn_colsum(const void* A, const void* B, float* C, float* colsum, int dtype, int64_t Mred, int64_t I, int64_t J, int64_t lda,
                        int64_t ldb, int64_t ldc, int impl, dvq_stream_t stream);
 
-/* Register a caller-owned device scratch buffer (one per process; the library cuts it into four slots, one per stream that
+/* Register a caller-owned device scratch buffer (one per process; the library cuts it into eight slots, one per stream that
  * uses it, so the side-stream weight gradients and the main stream never share one).  With >= 76 MiB per slot the split-K
  * weight-gradient kernels store per-workgroup partial tiles with plain writes and fold them in a second kernel instead of
- * issuing cross-XCD fp32 atomics.  ptr = NULL, bytes = 0 unregisters. */
+ * issuing cross-XCD fp32 atomics.  ptr = NULL, bytes = 0 unregisters.
+ * Slot ownership: a stream keeps its slot; a slot handed out while the stream was CAPTURING is pinned (the recorded graph holds
+ * its address) until dvq_workspace_release(stream); an unpinned slot is re-assigned to a new stream only when its owner is idle,
+ * least recently used first; a stream that finds no slot gets none (atomics). */
 int dvq_set_workspace(void* ptr, int64_t bytes);
+int dvq_workspace_release(dvq_stream_t stream);
 /* diagnostics (DVQ_HALO_DBG=6): per workgroup of the LAST 3x3 halo-conv launch {CU key | (time before the final store drain) << 16,
  * start, end of the main loop, end, tile staged, tile stored} in 10-ns ticks; dst holds max_records x 6 uint64.  Synchronises. */
 int dvq_halo_trace_read(unsigned long long* dst, int64_t max_records);
@@ -430,7 +435,8 @@ int dvq_rows_dev(void* x, void* hidden, int dtype, int64_t B, int64_t C, int64_t
  * `layers_dev`: DEVICE array of n_layers dvq_decode_layer.  `scratch`: dvq_decode_stack_scratch_bytes(B, C, F) bytes, ZEROED once by
  * the caller (the kernel re-arms its barrier counters itself).  n_workgroups <= 0: one workgroup per CU; the grid must be resident
  * as a whole (nothing else may occupy the device's LDS / wave slots to the point of excluding a workgroup: a barrier that is not
- * reached within seconds sets the error word -- the 4 bytes at scratch + 16-byte-aligned (4 B C + B F) 2 + 8 -- instead of hanging).
+ * reached within seconds sets the error word and releases every workgroup, all of which leave the kernel -- read it with
+ * dvq_decode_stack_status -- instead of hanging or continuing on stale data).
  * The buffers the phases exchange are accessed with agent-scope atomics (memory side): the barrier needs no cache flush. */
 typedef struct dvq_decode_layer {
     const void *wq, *wk, *wv, *wo, *w1, *w2;          /* bf16 [C][C] x 4, [F][C], [C][F] */
@@ -439,6 +445,10 @@ typedef struct dvq_decode_layer {
     void *kcache, *vcache;                            /* bf16 [B][Tmax][C] */
 } dvq_decode_layer;
 size_t dvq_decode_stack_scratch_bytes(int64_t B, int64_t C, int64_t F);
+/* Synchronising read-back of the error word of dvq_decode_stack (call once per sampling run, not per token): DVQ_OK, or
+ * DVQ_ELAUNCH when a device-wide barrier timed out since the scratch was last zeroed -- every workgroup left the kernel at that
+ * barrier, so the rows produced since are invalid; reset != 0 re-arms the counters (on `stream`) so that later launches run. */
+int dvq_decode_stack_status(const void* scratch, int64_t B, int64_t C, int64_t F, int reset, dvq_stream_t stream);
 int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C, int n_head, int64_t F, int64_t Tmax, const int64_t* t_dev,
                      float eps, void* x, void* scratch, int n_workgroups, dvq_stream_t stream);
 /* nn.Dropout(p) with a counter-based hash RNG: y = x * keep / (1-p); the same (seed) reproduces the mask for the backward */

@@ -183,6 +183,7 @@ def test_entropy_gate_golden(dev):
     from oracle import entropy as oent
     g = load_golden("entropy")
     imgs = {"small": g["small_img"], "big": synth.half_flat_images(2, 256, seed=1234)}
+    n_band = n_flip = n_rows = 0
     for tag, img in imgs.items():
         for table in ("imagenet_train", "imagenet_val", "ffhq_train"):
             for r in (0.3, 0.5, 0.7, 0.55):
@@ -196,6 +197,17 @@ def test_entropy_gate_golden(dev):
                 gg = gate.cpu().numpy().astype(np.int8)
                 assert np.array_equal(gg[safe], g[f"{tag}_gate_{table}_{r}"][safe])
                 assert safe.mean() > 0.99
+                # EVERY row, in-band ones included: the device's gate must be the reference's compare (RouterDual.py:53-57,
+                # fp32 `entropy > threshold`) applied to the device's OWN entropies -- H agrees with the reference to 2e-5,
+                # so a row within that distance of the threshold may legitimately land on the other side, but the gate and
+                # the H the same launch reports may never disagree
+                assert np.array_equal(gg, oent.entropy_gate(ent, thr).astype(np.int8))
+                n_band += int((~safe).sum())
+                n_flip += int((gg[~safe] != g[f"{tag}_gate_{table}_{r}"][~safe]).any(-1).sum()) if (~safe).any() else 0
+                n_rows += int(safe.size)
+    from test_gpu_model import _report
+    _report("entropy_gate_golden", rows=n_rows, in_band_rows=n_band, in_band_rows_differing_from_reference_gate=n_flip)
+    assert n_flip <= n_band
     # all-underflow patch: H = 32 * eps * ln(1/eps) needs fp32 subnormals
     ent, _ = K.patch_entropy_gate(T(g["small_img"], dev), 16, None)
     assert abs(float(ent[2, 0, 0]) - 2.947293e-37) < 1e-40

@@ -30,6 +30,26 @@ def test_permuter_golden(dev, order, name, hw1):
     assert np.array_equal(back.cpu().numpy(), g[f"{tag}_{name}_back"])
 
 
+@pytest.mark.parametrize("order", ["region-first", "row-first"])
+def test_permuter_reference_known_answer_vector(dev, order):
+    """the reference's only in-repo known-answer vector (modules/dynamic_modules/permuter.py:181-285, `test_code == 2`: two 32x32
+    code maps + 16x16 grain maps with the reference's code / position constants): forward equals what the reference's permuter
+    emits for it, forward -> forward_back reproduces the code maps (the self-test prints True)"""
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    g = load_golden("permuter")
+    tag = order.split("-")[0]
+    perm = instantiate_from_config({"target": "modules.dynamic_modules.permuter.DualGrainSeperatePermuter", "params": dict(
+        coarse_hw=16, fine_hw=32, content_pad_code=1024, content_eos_code=1025, coarse_position_pad_code=256,
+        coarse_position_eos_code=257, fine_position_pad_code=1024, fine_position_eos_code=1025, fine_position_order=order)})
+    idx = torch.from_numpy(g["known_indices"]).to(dev)
+    out = perm(idx, torch.from_numpy(g["known_grain"]).to(dev))
+    for k in KEYS:
+        assert np.array_equal(out[k].cpu().numpy(), g[f"known_{tag}_{k}"]), k
+    back = perm.forward_back(out["coarse_content"], out["fine_content"], out["coarse_position"], out["fine_position"])
+    assert np.array_equal(back.cpu().numpy(), g[f"known_{tag}_back"])
+    assert bool(torch.all(back == idx))
+
+
 def test_permuter_malformed_sequences_golden(dev):
     """missing EOS, early EOS, duplicate positions: the reference's sequential semantics"""
     from dynamicvectorquantization_amd.stage2 import DualGrainSeperatePermuter

@@ -127,3 +127,59 @@ def test_step_graph_with_exchange_breaks_one_rank_nccl(dev):
     r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "dp_graph_check.py"), str(port), "both"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DP_GRAPH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_eager_forwards_after_replays_see_current_weights(dev):
+    """a replayed step rewrites codebook and parameters without running Python, so the search-side codebook
+    planes (vq_prepare) and the packed conv weights an EAGER forward cached between replays must be rebuilt.  Scenario: replays,
+    an eval encode + discriminator forward (fills the caches from the then-current weights), MORE replays, then the same eval
+    calls -- codes must be the exact argmin over the codebook as it is NOW (quantize2_mask.py:117-128 rewrites the weight every
+    training forward), PatchGAN logits must come from the current discriminator weights."""
+    from dynamicvectorquantization_amd import runtime as rt
+    from oracle import losses as olo
+    from oracle import vq as ovq
+    xs = [torch.from_numpy(synth.half_flat_images(2, 64, seed=40 + i)).to(dev) for i in range(3)]
+    xv = torch.from_numpy(synth.half_flat_images(2, 64, seed=77)).to(dev)
+    with rt.compute_dtype_ctx(torch.float32):
+        model, tr = _make(dev, True, "full")
+        def probe():
+            model.eval()
+            with torch.no_grad():
+                ent = model.entropy_calculation(xv)
+                hd = model.encoder(xv, ent)
+                h = model.quant_conv(hd[model.encoder.OUT_KEY])                   # [B,D,H,W]
+                _, _, info, grain, _, _ = model.encode(xv)
+                logits = model.loss.discriminator(xv.contiguous())
+            model.train()
+            torch.cuda.synchronize()
+            return h.float().cpu().numpy(), info[2].cpu().numpy(), grain.cpu().numpy(), logits.float().cpu()
+
+        def expect(h):
+            cb = model.quantize.codebook.weight.detach()[:-1].float().cpu().numpy()
+            b, d, hh, ww = h.shape
+            idx = ovq.argmin_exact(np.ascontiguousarray(h.transpose(0, 2, 3, 1)).reshape(-1, d), cb)
+            return idx.reshape(b, hh, ww), cb
+
+        step = 0
+        for _ in range(5):                                   # 2 eager + recording + 3 replays
+            tr.train_step({"image": xs[step % 3]}, step)
+            step += 1
+        assert tr.graph_replays >= 3
+        h0, codes0, _, logits0 = probe()                     # fills the eager-side caches
+        idx0, cb0 = expect(h0)
+        np.testing.assert_array_equal(codes0, idx0)
+        r0 = tr.graph_replays
+        for _ in range(3):                                   # replays only: no Python-side invalidation but the Trainer's
+            tr.train_step({"image": xs[step % 3]}, step)
+            step += 1
+        assert tr.graph_replays == r0 + 3
+        h1, codes1, _, logits1 = probe()
+        idx1, cb1 = expect(h1)
+        assert np.abs(cb1 - cb0).max() > 0                   # the codebook did move under the replays
+        np.testing.assert_array_equal(codes1, idx1)
+        # discriminator (eval mode: BatchNorm running statistics, which the replays advanced too) from the CURRENT state_dict
+        sd = {k[len("loss.discriminator."):]: v.detach().float().cpu() for k, v in model.state_dict().items()
+              if k.startswith("loss.discriminator.")}
+        want = olo.patchgan(sd, xv.float().cpu(), train=False)
+        assert float((logits1 - want).norm()) <= 2e-3 * float(want.norm()) + 1e-5
+        assert float((logits1 - logits0).norm()) > 1e-4 * float(logits0.norm())      # and they did change

@@ -153,10 +153,16 @@ def _dp_worker(rank, world, port, q):
     for w in gb.reduce():                              # ... the rest afterwards; every element averaged exactly once
         w.wait()
     ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params))
-    stats = torch.full((8, 5), float(rank + 1))
-    restart = torch.full((8, 4), float(rank + 10))
-    stats, restart = VQEmbedding._exchange(stats, restart)
-    ok = ok and torch.allclose(stats, torch.full((8, 5), 3.0)) and torch.allclose(restart, torch.full((8, 4), 10.0))
+    # VQ-EMA exchange (quantize2_mask.py:86-88 + 99-100) as ONE all-reduce of the flat [K, D+1 | K, D] buffer: statistics are
+    # summed, the restart rows every rank ends up with are rank 0's (the other ranks contribute exact zeros)
+    flat, stats, restart = VQEmbedding._exchange_buffers(8, 4, "cpu")
+    stats.fill_(float(rank + 1))
+    r0 = torch.arange(32, dtype=torch.float32).view(8, 4) * 0.37 - 3.0
+    restart.copy_(r0 if rank == 0 else torch.zeros(8, 4))
+    VQEmbedding._exchange(flat)
+    ok = ok and torch.equal(stats, torch.full((8, 5), 3.0)) and torch.equal(restart, r0)
+    VQEmbedding._exchange(stats)                        # restart_unused_codes=False: statistics only
+    ok = ok and torch.equal(stats, torch.full((8, 5), 6.0)) and torch.equal(restart, r0)
     gb.zero()
     ok = ok and all(float(p.grad.abs().sum()) == 0 for p in params)
     q.put((rank, bool(ok)))

@@ -675,6 +675,41 @@ def gen_permuter():
     back = perm.forward_back(t(cc), t(fc), t(cp), t(fp))
     check("permuter.malformed.back", back.numpy(), ope.forward_back(cc, fc, cp, fp, 4, 2))
     out.update(mal_cc=cc, mal_cp=cp, mal_fc=fc, mal_fp=fp, mal_back=back.numpy())
+    # The reference's ONLY in-repo known-answer vector: the `test_code == 2` pair of its self-test,
+    # permuter.py:181-285 -- two 32x32 code maps with their 16x16 grain maps, whose forward -> forward_back round trip the
+    # self-test prints as True.  The two literals are DATA: they are read out of the reference's file here (ast, nothing is
+    # executed or kept as text) and stored as arrays next to what the reference's permuter makes of them, both fine orders.
+    import ast
+    src = open(os.path.join(REF, "modules", "dynamic_modules", "permuter.py")).read()
+    lits = {}
+    for node in ast.walk(ast.parse(src)):
+        if (isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Name) and node.targets[0].id in ("original_indices", "grain_indices")
+                and isinstance(node.value, ast.Call) and getattr(node.value.func, "attr", "") == "tensor"):
+            arr = np.array(ast.literal_eval(node.value.args[0]), dtype=np.int64)
+            if arr.ndim == 3:
+                lits[node.targets[0].id] = arr
+    kidx, kgrain = lits["original_indices"], lits["grain_indices"]
+    assert kidx.shape == (2, 32, 32) and kgrain.shape == (2, 16, 16), (kidx.shape, kgrain.shape)
+    # the vector is self-consistent: a coarse region holds one code four times
+    rep = np.repeat(np.repeat(kgrain, 2, 1), 2, 2)
+    blocks = kidx.reshape(2, 16, 2, 16, 2).transpose(0, 1, 3, 2, 4).reshape(2, 16, 16, 4)
+    assert np.all((blocks == blocks[..., :1]).all(-1) | (kgrain == 1))
+    out["known_indices"], out["known_grain"] = kidx, kgrain
+    for order in ("region-first", "row-first"):
+        tag = order.split("-")[0]
+        perm = DualGrainSeperatePermuter(coarse_hw=16, fine_hw=32, content_pad_code=1024, content_eos_code=1025,
+                                         coarse_position_pad_code=256, coarse_position_eos_code=257, fine_position_pad_code=1024,
+                                         fine_position_eos_code=1025, fine_position_order=order)
+        ref = perm(t(kidx), t(kgrain))
+        ora = ope.forward(kidx, kgrain, 16, 2, order)
+        for k in ("coarse_content", "fine_content", "coarse_position", "fine_position", "coarse_segment", "fine_segment"):
+            check(f"permuter.known.{tag}.{k}", ref[k].numpy(), ora[k])
+            out[f"known_{tag}_{k}"] = ref[k].numpy()
+        back = perm.forward_back(ref["coarse_content"], ref["fine_content"], ref["coarse_position"], ref["fine_position"])
+        assert bool(torch.all(back == t(kidx))), "the reference's own self-test no longer prints True"
+        check(f"permuter.known.{tag}.back", back.numpy(), ope.forward_back(ora["coarse_content"], ora["fine_content"],
+                                                                            ora["coarse_position"], ora["fine_position"], 16, 2))
+        out[f"known_{tag}_back"] = back.numpy()
     np.savez_compressed(os.path.join(GOLD, "permuter.npz"), **out)
 
 
