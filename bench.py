@@ -195,6 +195,7 @@ def vq_microbench(dev, reps=20, in_training=None):
                     "TFLOPs_equiv": round(2 * n * k * d / ms / 1e9, 2),
                     "mfma_frac": round(passes * 2 * n * k * d / (ms * 1e-3) / PEAK_BF16, 4), "mfma_passes": passes,
                     "rerank_rows_full": int(flagged[0].item()), "rerank_rows_candidates": int(flagged[1].item()),
+                    "rerank_rows_wide": int(flagged[2].item()),
                     "alg_bytes": nbytes, "shape": [n, d, k]}
     return out
 

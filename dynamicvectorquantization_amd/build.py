@@ -17,6 +17,9 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdvq_hip.so")
 SOURCES = ["vq.hip", "entropy.hip", "groupnorm.hip", "igemm.hip", "conv_halo.hip", "misc.hip", "lossnet.hip", "router.hip", "permuter.hip", "transformer.hip", "attention.hip", "imgproc.hip", "decode.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+# per-file additions.  vq.hip: no SLP vectorisation -- it pairs the scalar fp32 bookkeeping between the MFMAs of the argmin main loop
+# into v_pk_fma_f32 / v_pk_add_f32, which issue more slowly beside a busy matrix pipe than the two instructions they replace
+EXTRA_FLAGS = {"vq.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -44,7 +47,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)

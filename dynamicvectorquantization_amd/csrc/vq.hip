@@ -86,10 +86,16 @@ __global__ void vq_prepare_kernel(const float* __restrict__ cb, int64_t K, int64
 constexpr int VQ_MAXC = 5;          // candidate codes kept per ambiguous row: an entry is {row, n, idx[5], class mask} = 32 B; a set
                                     // bit l of the mask = residue class l (codes k = l mod 32) holds MORE than one candidate, so
                                     // all K / 32 codes of that class are re-ranked too
+// The first 64 ints are counters.  They must be ZERO when dvq_vq_argmin starts: the caller zeroes a fresh workspace once, and
+// the re-rank kernel (the last launch of every call) re-arms them -- its last workgroup copies {count, ccount, nwide} to the
+// report slots and clears them -- so a call is two launches, not three.
 struct VqWs {
-    int count;      // rows to re-rank over ALL codes
-    int ccount;     // rows to re-rank over their candidate list
-    int pad[62];
+    int count;      // rows to re-rank over ALL codes (generic path only)
+    int ccount;     // rows to re-rank over their candidate list / flagged classes
+    int nwide;      // of those: rows with more than VQ_MAXC candidate classes (class scans only)
+    int done;       // workgroups of the re-rank kernel that have finished
+    int rep_count, rep_ccount, rep_nwide;     // the previous call's counters (what `flagged` reports)
+    int pad[57];
     int list[1];    // [N] full-rerank rows, then [N][8] candidate entries
 };
 __host__ __device__ inline int* vq_cand_entries(VqWs* ws, int64_t N) { return ws->list + N; }
@@ -98,9 +104,10 @@ __host__ __device__ inline const int* vq_cand_entries(const VqWs* ws, int64_t N)
 // ---- per row: global best over the 32 class winners, candidate set = classes within tau of it ---------------------------
 // (shared tail of the main kernels: b1 / b2 / i1 = best, second-best score and best index of this lane's residue class of codes
 //  for the 16 accumulator rows of the lane)
+// xnorm32: |x| (rounded up) of the 32 rows row0 .. row0 + 31 this call settles.
 template <int D>
-__device__ __forceinline__ void vq_select_rows(float (&b1)[16], float (&b2)[16], int (&i1)[16], const float* xnorm, const float emax,
-                                               const int wave, const int half, const int l31, const int64_t row0, const int64_t N,
+__device__ __forceinline__ void vq_select_rows(float (&b1)[16], float (&b2)[16], int (&i1)[16], const float* xnorm32, const float emax,
+                                               const int half, const int l31, const int64_t row0, const int64_t N,
                                                int64_t* __restrict__ idx_out, VqWs* ws) {
     {
         // error bound of one score: split residual 3*2^-18, accumulate D*2^-23 (relative to |x||e|),
@@ -122,7 +129,7 @@ __device__ __forceinline__ void vq_select_rows(float (&b1)[16], float (&b2)[16],
             }
             const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
             const int64_t row = row0 + rl;
-            const float xn = xnorm[wave * 32 + rl];
+            const float xn = xnorm32[rl];
             const float tau = coefA * xn * emax + coefB * (emax * emax + 2.0f * xn * emax + xn * xn) + 1e-37f;
             // a code whose exact score is minimal has an approximate score <= gb + tau: it is the winner of a class with
             // b1 <= gb + tau (is_c), unless that class holds two such codes (b2 <= gb + tau: over -> full re-rank)
@@ -135,9 +142,17 @@ __device__ __forceinline__ void vq_select_rows(float (&b1)[16], float (&b2)[16],
                 const int nc = __popc(mh);
                 if (l31 == 0) idx_out[row] = (int64_t)gi;
                 if (nc > VQ_MAXC) {
+                    // more candidate classes than an entry lists (exact many-way ties, pathological data): the exact argmin is a
+                    // code of one of the candidate classes, so the entry names no code and flags ALL of them for a class scan
+                    // (nc x K / 32 codes by one wave) -- until round 3 such a row was re-ranked over all K codes by a whole
+                    // 1024-thread block, and a single one of them cost a training step's search more than the main kernel
                     if (l31 == 0) {
-                        const int pos = atomicAdd(&ws->count, 1);
-                        ws->list[pos] = (int)row;
+                        const int pos = atomicAdd(&ws->ccount, 1);
+                        int* ent = cand + (int64_t)pos * 8;
+                        ent[0] = (int)row;
+                        ent[1] = 0;
+                        ent[7] = (int)(mh | oh);
+                        atomicAdd(&ws->nwide, 1);
                     }
                 } else if (nc >= 2 || oh != 0u) {
                     int pos = 0;
@@ -154,6 +169,103 @@ __device__ __forceinline__ void vq_select_rows(float (&b1)[16], float (&b2)[16],
             }
         }
     }
+}
+
+// ---- the same selection through LDS (round 4).  The shuffle version above costs 37 000 of the 130 000 cycles of the bf16 main
+// kernel (in-kernel time stamps): 16 rows x 5 butterfly steps x 2 values = 160 ds_bpermute per 32 rows plus ballots, all on the
+// critical path of a wave that has its SIMD to itself.  Here the wave TRANSPOSES its 32 rows x 32 classes of {b1, b2, i1} through
+// LDS (stride 33: conflict-free both ways) so that a lane owns a ROW: lane L takes row L & 31 and the 16 classes of half L >> 5,
+// finds the minimum and the candidate mask of its classes in registers, and one shuffle joins the two halves.  Entries are written
+// by one lane per row (coalesced idx_out stores).  Which code wins among EXACTLY tied scores is left to the re-rank (ties are
+// within tau of each other by definition, so such a row is always flagged).
+constexpr int VQ_SEL_WORDS = 3 * 32 * 33;          // LDS words per wave: b1, b2, i1 [32 rows][33]
+template <int D>
+__device__ __forceinline__ void vq_select_rows_lds(const float (&b1)[16], const float (&b2)[16], const int (&i1)[16], const float* xnorm32,
+                                                   const float emax, const int lane, const int64_t row0, const int64_t N,
+                                                   int64_t* __restrict__ idx_out, VqWs* ws, float* scr) {
+    const int half = lane >> 5, l31 = lane & 31;
+    float* s1 = scr;
+    float* s2 = scr + 32 * 33;
+    int* si = reinterpret_cast<int*>(scr + 2 * 32 * 33);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+        s1[rl * 33 + l31] = b1[r];
+        s2[rl * 33 + l31] = b2[r];
+        si[rl * 33 + l31] = i1[r];
+    }
+    __builtin_amdgcn_wave_barrier();               // (one wave: its LDS operations complete in order)
+    const int row = l31, c0 = 16 * half;           // this lane: row `row`, classes c0 .. c0 + 15
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = s1[row * 33 + c0 + j];
+    float mb = v[0], m2 = s2[row * 33 + c0];
+    int mj = 0;
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+        const bool lt = v[j] < mb;
+        mj = lt ? j : mj;
+        mb = lt ? v[j] : mb;
+        m2 = fminf(m2, s2[row * 33 + c0 + j]);
+    }
+    int gi = si[row * 33 + c0 + mj];
+    float gb = mb;
+    {
+        const float ob = __shfl_xor(gb, 32, 64);
+        const int oi = __shfl_xor(gi, 32, 64);
+        const bool take = (ob < gb) || (ob == gb && oi < gi);
+        gb = take ? ob : gb;
+        gi = take ? oi : gi;
+    }
+    m2 = fminf(m2, __shfl_xor(m2, 32, 64));         // smallest second-best of any class of the row
+    // error bound of one score: split residual 3*2^-18, accumulate D*2^-23 (relative to |x||e|),
+    // norm rounding + final fma 4*2^-24; two scores are compared -> factor 2, -2x.e -> factor 2.
+    const float coefA = 4.0f * (3.0f * 3.8147e-6f + (float)D * 1.1921e-7f);
+    const float coefB = 8.0f * 5.9605e-8f;
+    const float xn = xnorm32[row];
+    const float tau = coefA * xn * emax + coefB * (emax * emax + 2.0f * xn * emax + xn * xn) + 1e-37f;
+    // a code whose exact score is minimal has an approximate score <= gb + tau: it is the winner of a class with b1 <= gb + tau
+    // (mask mc), unless that class holds two such codes (b2 <= gb + tau: mask mo -> the whole class is re-ranked)
+    unsigned mc = 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) mc |= (v[j] - gb > tau) ? 0u : (1u << j);
+    unsigned mo = 0u;
+    if (!(m2 - gb > tau)) {                          // rare: some class of this row holds a second code within tau
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mo |= (s2[row * 33 + c0 + j] - gb > tau) ? 0u : (1u << j);
+    }
+    const unsigned mh = (mc << c0) | ((unsigned)__shfl_xor((int)mc, 32, 64) << (16 - c0));
+    const unsigned oh = (mo << c0) | ((unsigned)__shfl_xor((int)mo, 32, 64) << (16 - c0));
+    const int64_t grow = row0 + row;
+    if (half == 0 && grow < N) {
+        idx_out[grow] = (int64_t)gi;
+        const int nc = __popc(mh);
+        if (nc > VQ_MAXC || nc >= 2 || oh != 0u) {
+            int* cand = vq_cand_entries(ws, N);
+            const int pos = atomicAdd(&ws->ccount, 1);
+            int* ent = cand + (int64_t)pos * 8;
+            ent[0] = (int)grow;
+            if (nc > VQ_MAXC) {
+                // more candidate classes than an entry lists (exact many-way ties, pathological data): the exact argmin is a code of
+                // one of the candidate classes, so the entry names no code and flags ALL of them for a class scan (nc x K / 32 codes
+                // by one wave) -- never an all-codes row
+                ent[1] = 0;
+                ent[7] = (int)(mh | oh);
+                atomicAdd(&ws->nwide, 1);
+            } else {
+                ent[1] = nc;
+                ent[7] = (int)oh;
+                unsigned m = mh;
+                for (int k = 0; k < nc; ++k) {
+                    const int j = __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    ent[2 + k] = si[row * 33 + j];
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -285,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_kernel(const XT* __rest
 #undef VQ_G1
 #undef VQ_S1
 
-    vq_select_rows<D>(b1, b2, i1, xnorm, *pv.emax, wave, half, l31, row0, N, idx_out, ws);
+    vq_select_rows<D>(b1, b2, i1, xnorm + wave * 32, *pv.emax, half, l31, row0, N, idx_out, ws);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -316,7 +428,8 @@ __global__ __launch_bounds__(64 * NW, 1) void vq_argmin_mfma_pipe_kernel(const X
     constexpr int PPP = 32 / RPP;             // DMA pieces per plane: 4 / 8 / 16
     constexpr int RPK = 16 / KSTEPS;          // accumulator rows retired per k-step: 4 / 2 / 1
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xnorm = reinterpret_cast<float*>(smem + 2 * STAGE);   // [32 * NW]
+    constexpr int REGION = 2 * STAGE > NW * VQ_SEL_WORDS * 4 ? 2 * STAGE : NW * VQ_SEL_WORDS * 4;   // the two stages; later the selection scratch
+    float* xnorm = reinterpret_cast<float*>(smem + REGION);      // [32 * NW]
 
     VqPrepView pv = prep_view(const_cast<void*>(prep_c), K, D);
     const int tid = threadIdx.x;
@@ -481,7 +594,283 @@ __global__ __launch_bounds__(64 * NW, 1) void vq_argmin_mfma_pipe_kernel(const X
             }
         }
     }
-    vq_select_rows<D>(b1, b2, i1, xnorm, *pv.emax, wave, half, l31, row0, N, idx_out, ws);
+    const float emax = *pv.emax;
+    __syncthreads();                                    // every wave is done with the stages: they become the selection scratch
+    vq_select_rows_lds<D>(b1, b2, i1, xnorm + wave * 32, emax, lane, row0, N, idx_out, ws, reinterpret_cast<float*>(smem) + wave * VQ_SEL_WORDS);
+}
+
+// ---------------------------------------------------------------------------------------------
+// main kernel for bf16 rows (round 4; the training path): 4 waves x 64 rows per workgroup, ONE wave per SIMD.
+//
+// What bounded the 8-wave kernel above on bf16 rows (80 us at N = 65536, K = 1024, D = 256 against 38 us of MFMA issue at the
+// clock the chip sustains on random operands):
+//   * every wave reads the whole 32-code stage from LDS for its own 32 rows -- one ds_read_b128 per MFMA, half the LDS
+//     bandwidth of the CU;
+//   * the best / second-best bookkeeping of a stage (~100 vector instructions per wave) runs after the stage's MFMAs, on both
+//     waves of a SIMD at the same time (the stage barrier keeps them in phase): the matrix pipe idles through it, +40 %.
+// Here a wave owns TWO 32-row blocks (x fragments of 64 rows in 128 registers), so every code fragment read from LDS feeds two
+// MFMAs, and the results of stage c - 1 (copied out of the accumulators at its end) are retired row by row between the MFMAs of
+// stage c (one row of both row blocks per k-step: 10 vector instructions per 4 MFMAs).  The stage's DMA pieces are issued one
+// per two k-steps instead of all at the head, the first k-step of a stage multiplies onto an inline zero (no accumulator
+// clears).  ~350 registers: one wave per SIMD by construction.
+// ---------------------------------------------------------------------------------------------
+template <int KSTEPS, int dbg = 0>
+__global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const bf16_t* __restrict__ x, const void* prep_c, int64_t N, int64_t K,
+                                                                    int64_t* __restrict__ idx_out, VqWs* ws) {
+    constexpr int D = KSTEPS * 16;
+    constexpr int NW = 4;                     // waves per workgroup (64 rows each)
+    constexpr int ROWB = D * 2;               // LDS bytes per code row (unpadded, swizzled)
+    constexpr int CPR = ROWB / 16;            // 16-byte chunks per row: 8 / 16 / 32
+    constexpr int PIECE = 32 * ROWB;          // one bf16 plane of a 32-code stage
+    constexpr int STAGE = 2 * PIECE;
+    constexpr int RPP = 1024 / ROWB;          // code rows per 1-KiB DMA piece: 8 / 4 / 2
+    constexpr int PPP = 32 / RPP;             // DMA pieces per plane: 4 / 8 / 16
+    constexpr int NPW = 2 * PPP / NW;         // DMA pieces per wave and stage: 2 / 4 / 8  (= KSTEPS / 2)
+    constexpr int RPK = 16 / KSTEPS;          // accumulator rows retired per k-step: 4 / 2 / 1
+    static_assert(NPW * 2 == KSTEPS, "one DMA piece per two k-steps");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int REGION = 3 * STAGE > NW * VQ_SEL_WORDS * 4 ? 3 * STAGE : NW * VQ_SEL_WORDS * 4;   // the stage ring; later the selection scratch
+    float* xnorm = reinterpret_cast<float*>(smem + REGION);      // [64 * NW]
+
+    VqPrepView pv = prep_view(const_cast<void*>(prep_c), K, D);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * (64 * NW) + wave * 64;
+    // (dbg bit 5: shader-clock stamps of workgroup 7, wave 0 in ws->pad[8 ..]: start, rows loaded, first stage landed, loop done, end)
+    unsigned long long stamps[5];
+    auto stamp = [&](int i) {
+        if constexpr (dbg & 32) stamps[i] = __builtin_readcyclecounter();
+    };
+    stamp(0);
+
+    // ---- x fragments: the bf16 rows ARE the operand (x = x1 exactly).  The loads are issued here, the codebook DMA of the first two
+    // stages right behind them, and only then are the norms computed: the 33 MB of rows and the first stages travel together ---------
+    bf16x8 xa[2][KSTEPS];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        // (rows past N read row N - 1: branch-free loads; their results are never stored)
+        const int64_t r = min(row0 + rb * 32 + l31, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) xa[rb][ks] = *reinterpret_cast<const bf16x8*>(x + r * D + ks * 16 + half * 8);
+    }
+
+    // swizzle of the 16-B chunk index within a code row (conflict-free for the b128 lane groups of a 32-row fragment read)
+    auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : (row & 15); };
+    // ---- stage loader: this wave DMAs pieces wave, wave + NW, ... of the 2 * PPP pieces of a stage.  buffer_load ... lds through ONE
+    // descriptor over both planes (e2 follows e1 in the prep buffer): the lane's 16 bytes of piece i sit at a per-lane constant
+    // offset (row, swizzled chunk, plane), the stage is the scalar offset -- no address arithmetic in the loop -----------------------
+    const int prow = (lane * 16) / ROWB;           // row within a piece
+    const int pslot = (lane * 16 % ROWB) / 16;     // chunk position within that row
+    const int nstage = (int)(pv.Kp / 32);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(pv.e1, 0, (int)(2 * pv.Kp * D * 2), 0x00020000);
+    int pvo[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int pc = wave + NW * i;              // 0 .. 2 PPP - 1
+        const int plane = pc / PPP, pp = pc - plane * PPP;
+        const int row = pp * RPP + prow;           // code row within the stage (0..31)
+        const int chunk = pslot ^ swz(row);        // the chunk of the row that lives at this LDS position
+        pvo[i] = (int)(((int64_t)plane * pv.Kp * D + row * D + chunk * 8) * 2);
+    }
+    // (the lane offset is passed in: with pvo[i] indexed inside the lambda the HOST pass of clang 20 silently drops the kernel's stub)
+    auto issue_piece = [&](int c, int buf, int i, int vo) {
+        const int pc = wave + NW * i;
+        const int plane = pc / PPP, pp = pc - plane * PPP;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsE, (__attribute__((address_space(3))) void*)(smem + buf * STAGE + plane * PIECE + pp * 1024), 16,
+                                                 vo, c * (32 * D * 2), 0, 0);
+    };
+
+    // stages 0 and 1 up front (stage 1's pieces past the first NPOST are what stage 0's body issues)
+    constexpr int NPOST = NPW < 2 ? NPW : 2;  // pieces of stage c + 2 issued behind the barrier of stage c
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) issue_piece(0, 0, i, pvo[i]);
+#pragma unroll
+    for (int i = 0; i < NPOST; ++i) issue_piece(nstage > 1 ? 1 : 0, 1, i, pvo[i]);
+    // row norms (rounded up) for the error bound
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        float sq = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, xa[rb][ks][j]) << 16);
+                sq = fmaf(v, v, sq);
+            }
+        sq += __shfl_xor(sq, 32, 64);
+        if (half == 0) xnorm[wave * 64 + rb * 32 + l31] = sqrtf(sq) * 1.000001f;
+    }
+
+    float b1[2][16], b2[2][16];
+    int i1[2][16];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            b1[rb][r] = __builtin_inff();
+            b2[rb][r] = __builtin_inff();
+            i1[rb][r] = 0x7fffffff;
+        }
+    // ONE accumulator per row block takes both codebook planes (x.e1 and x.e2 are summed anyway; the two MFMAs of a block on one
+    // accumulator are separated by the other block's, so neither waits for the one before it).  Two accumulator sets alternate
+    // by stage: while stage c multiplies into one, the rows of stage c - 1 are read out of the other between the MFMAs.
+    f32x16 accA[2], accB[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accA[rb][r] = accB[rb][r] = 0.f;
+
+    const int fsw = swz(l31);
+    // best / second best of row r of the retired stage (codes kidx = 32 * stage + l31, norm en)
+    auto retire_row = [&](int rb, int r, float dot, float en, int kidx) {
+        const float sc = fmaf(-2.0f, dot, en);
+        const bool lt = sc < b1[rb][r];
+        b2[rb][r] = __builtin_amdgcn_fmed3f(b1[rb][r], b2[rb][r], sc);      // second best of {b1, b2, sc} once b1 takes the minimum
+        i1[rb][r] = lt ? kidx : i1[rb][r];
+        b1[rb][r] = lt ? sc : b1[rb][r];                                      // (a select on the same compare: fminf costs a canonicalising v_max)
+    };
+    constexpr int PF = KSTEPS < 2 ? KSTEPS : 2;      // fragment reads run PF k-steps (8 MFMAs) ahead of their use
+    // fragment addresses: chunk (2 ks + half) ^ swizzle -- the swizzle reaches the low 4 chunk bits only, so NJ per-lane byte offsets
+    // into the stage buffers (current buffer, toggled per stage) + an immediate for ks >= NJ replace a shift / xor / add per read
+    constexpr int NJ = KSTEPS < 8 ? KSTEPS : 8;
+    unsigned fo[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        fo[j] = (unsigned)(l31 * ROWB + (((j * 2 + half) ^ fsw) << 4));
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // ---- the stage loop.  LDS holds a ring of THREE stages: while stage c is multiplied, stage c + 1 has landed and stage c + 2 is in
+    // flight.  The stage barrier sits BEFORE the last two k-steps of a stage (as in the 3x3 halo convolution): behind it every wave
+    // reads the first two fragment pairs of stage c + 1 under its own last 8 MFMAs of stage c, so a stage starts with its operands in
+    // registers (the barrier at the very end of a stage left ~900 cycles of LDS latency per stage in the open: one wave per SIMD has
+    // nobody to cover it).  Buffer (c + 2) % 3 = (c - 1) % 3 is free once every wave has passed that barrier (it is inside stage c):
+    // the DMA pieces of stage c + 2 are issued from there on -- two in the last two k-steps of stage c, the rest in the first k-steps
+    // of stage c + 1 -- and have a whole stage to land before the next barrier waits for them.
+    // stage "-1" retires nothing real: zero accumulators and norm +inf (a score of +inf never wins and never ties)
+    float en_prev = __builtin_inff();
+    int c = 0;
+    constexpr int KB = KSTEPS - 2;            // the barrier precedes k-step KB; NPOST pieces follow it (k-steps KB, KB + 1)
+    bf16x8 g1[2], g2[2];                      // fragments of the first two k-steps of the NEXT stage
+    auto frag_at = [&](bf16x8& d1, bf16x8& d2, int ks, int rel) {      // rel: 0 = current stage's buffer, 1 = the next one's
+        const unsigned o = fo[ks % NJ] + (ks / NJ) * (NJ * 32);
+        const unsigned sh = rel == 0 ? 0u : ((c % 3) == 2 ? (unsigned)(-2 * STAGE) : (unsigned)STAGE);
+        const char* a = smem + (o + sh);
+        d1 = *reinterpret_cast<const bf16x8*>(a);
+        d2 = *reinterpret_cast<const bf16x8*>(a + PIECE);
+    };
+    auto stage_body = [&](f32x16 (&cur)[2], const f32x16 (&prev)[2]) {
+        const int kprev = (c - 1) * 32 + l31;
+        const float en_cur = pv.en[c * 32 + l31];       // requested BEFORE the DMAs below: waiting for it never waits for them (in-order vmcnt)
+        // DMA is issued unconditionally (a branch would cut the k-steps' scheduling regions): past the last stage the pieces re-fetch
+        // the last stage into a buffer nobody reads any more
+        const int c1 = c + 1 < nstage ? c + 1 : nstage - 1, c2 = c + 2 < nstage ? c + 2 : nstage - 1;
+        const int b1n = (c + 1) % 3, b2n = (c + 2) % 3;
+        bf16x8 f1[KSTEPS], f2[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) {
+            f1[ks] = g1[ks];
+            f2[ks] = g2[ks];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if (ks == KB) {
+                if constexpr (dbg & 16) {               // (dbg bit 4: no stage barrier -- racy)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    __syncthreads();                    // vmcnt(0): this wave's pieces of stage c + 1 have landed; all waves are inside stage c
+                }
+            }
+            if (ks + PF < KSTEPS) {
+                if constexpr (dbg & 8) {                // (dbg bit 3: no fragment reads past the first two k-steps)
+                    f1[ks + PF] = f1[ks];
+                    f2[ks + PF] = f2[ks];
+                } else {
+                    frag_at(f1[ks + PF], f2[ks + PF], ks + PF, 0);
+                }
+            } else {
+                frag_at(g1[ks + PF - KSTEPS], g2[ks + PF - KSTEPS], ks + PF - KSTEPS, 1);       // k-steps 0, 1 of stage c + 1 (behind the barrier)
+            }
+            if constexpr (!(dbg & 4)) {
+                if (ks >= KB && ks - KB < NPOST) issue_piece(c2, b2n, ks - KB, pvo[ks - KB]);
+                if (ks + NPOST < NPW) issue_piece(c1, b1n, ks + NPOST, pvo[ks + NPOST]);
+            }
+            if constexpr (!(dbg & 2)) {      // (dbg: timing experiments only -- bit 0 no bookkeeping, bit 1 no MFMA, bit 2 no DMA)
+                cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0][ks], f1[ks], ks == 0 ? zero : cur[0], 0, 0, 0);
+                cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1][ks], f1[ks], ks == 0 ? zero : cur[1], 0, 0, 0);
+                cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0][ks], f2[ks], cur[0], 0, 0, 0);
+                cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1][ks], f2[ks], cur[1], 0, 0, 0);
+            } else {
+                const float v = __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, f1[ks][0]) << 16) +
+                                __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, f2[ks][0]) << 16);
+                if (ks == 0) cur[0] = cur[1] = zero;
+                cur[0][ks & 15] += v;
+            }
+            if constexpr (!(dbg & 1)) {
+#pragma unroll
+                for (int j = 0; j < RPK; ++j) {
+                    retire_row(0, ks * RPK + j, prev[0][ks * RPK + j], en_prev, kprev);
+                    retire_row(1, ks * RPK + j, prev[1][ks * RPK + j], en_prev, kprev);
+                }
+            }
+            // issue order of the k-step: MFMA, the two fragment reads, MFMA, [DMA piece], bookkeeping spread over the rest
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4 * RPK, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4 * RPK, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4 * RPK, 0);
+            __builtin_amdgcn_sched_barrier(0);      // keep the k-steps (and their fillers) in this order
+        }
+        en_prev = en_cur;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fo[j] = (c % 3) == 2 ? fo[j] - 2 * STAGE : fo[j] + STAGE;      // the next buffer of the ring
+        ++c;
+    };
+
+    stamp(1);
+    __syncthreads();
+    stamp(2);
+#pragma unroll
+    for (int ks = 0; ks < PF; ++ks) {
+        const char* a = smem + fo[ks % NJ] + (ks / NJ) * (NJ * 32);
+        g1[ks] = *reinterpret_cast<const bf16x8*>(a);
+        g2[ks] = *reinterpret_cast<const bf16x8*>(a + PIECE);
+    }
+    for (; c + 1 < nstage;) {
+        stage_body(accA, accB);
+        stage_body(accB, accA);
+    }
+    bool lastA = false;                                 // which set holds the stage that is still to be retired
+    if (c < nstage) {
+        stage_body(accA, accB);
+        lastA = true;
+    }
+    if (nstage > 0) {
+        const int klast = (nstage - 1) * 32 + l31;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) retire_row(rb, r, lastA ? accA[rb][r] : accB[rb][r], en_prev, klast);
+    }
+    stamp(3);
+    const float emax = *pv.emax;
+    __syncthreads();                                    // every wave is done with the stage ring: it becomes the selection scratch
+    float* scr = reinterpret_cast<float*>(smem) + wave * VQ_SEL_WORDS;
+    vq_select_rows_lds<D>(b1[0], b2[0], i1[0], xnorm + wave * 64, emax, lane, row0, N, idx_out, ws, scr);
+    vq_select_rows_lds<D>(b1[1], b2[1], i1[1], xnorm + wave * 64 + 32, emax, lane, row0 + 32, N, idx_out, ws, scr);
+    stamp(4);
+    if constexpr (dbg & 32) {
+        if (blockIdx.x == 7 && tid == 0) {
+            unsigned long long* t = reinterpret_cast<unsigned long long*>(&ws->pad[9]);
+            for (int i = 0; i < 5; ++i) t[i] = stamps[i];
+        }
+    }
 }
 
 __global__ void vq_flag_all_kernel(VqWs* ws, int64_t N) {
@@ -505,6 +894,7 @@ __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __
     double* wbest = xs + 4 * D;                              // [4][16]
     int* widx = reinterpret_cast<int*>(wbest + 4 * 16);      // [4][16]
     const int cnt = ws->count;
+    const int ccnt = do_cand ? ws->ccount : 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 3, sub = lane & 7;
     constexpr int NW = RR_THREADS / 64;
@@ -639,7 +1029,6 @@ __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __
     // distances each, plus the K / 32 codes of every residue class that holds more than one candidate (same launch as the
     // all-codes rows above: one launch for both)
     if (do_cand) {
-        const int ccnt = ws->ccount;
         const int* cand = vq_cand_entries(ws, N);
         for (int e = blockIdx.x * NW + wave; e < ccnt; e += gridDim.x * NW) {
             const int* ent = cand + (int64_t)e * 8;
@@ -707,6 +1096,26 @@ __global__ __launch_bounds__(RR_THREADS) void vq_rerank_fp64_kernel(const XT* __
                 }
             }
             if (lane == 0) idx_out[row] = (int64_t)bi;
+        }
+    }
+    // re-arm the counters for the next call (no separate zero-fill launch): every workgroup has read them (above) before it gets
+    // here; the last one to arrive publishes them in the report slots and clears them.  Only the workgroups that HAD work take part
+    // (the others could not have read the counters any later than these): a light call is a fan-in of a few arrivals, not of 256.
+    const int nwork_a = (cnt + RB - 1) / RB, nwork_c = (ccnt + NW - 1) / NW;
+    int nwork = nwork_a > nwork_c ? nwork_a : nwork_c;
+    nwork = nwork < 1 ? 1 : (nwork > (int)gridDim.x ? (int)gridDim.x : nwork);
+    if ((int)blockIdx.x >= nwork) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        VqWs* w = const_cast<VqWs*>(ws);
+        if (atomicAdd(&w->done, 1) == nwork - 1) {
+            w->rep_count = cnt;
+            w->rep_ccount = ccnt;
+            w->rep_nwide = w->nwide;
+            w->count = 0;
+            w->ccount = 0;
+            w->nwide = 0;
+            w->done = 0;
         }
     }
 }
@@ -910,6 +1319,36 @@ __global__ __launch_bounds__(256) void vq_distances_kernel(const XT* __restrict_
 
 }  // namespace
 
+// bf16 rows: 4 waves x 64 rows.  DVQ_VQ_DBG = 1 / 2 / 4 (D = 256 only): timing experiments without bookkeeping / MFMAs / DMA (WRONG results)
+template <int KS, int DB>
+static void vq_launch_rb2_dbg(const bf16_t* x, const void* prep, int64_t N, int64_t K, int64_t* idx, VqWs* ws, hipStream_t s) {
+    constexpr int Dc = KS * 16;
+    const size_t ring = 3 * (2 * 32 * (Dc * 2)), sel = 4 * VQ_SEL_WORDS * 4;
+    const size_t lds = (ring > sel ? ring : sel) + 64 * 4 * 4;          // a ring of three 32-code stages (later: selection scratch) + the row norms
+    dvq_ensure_dynamic_lds((const void*)vq_argmin_mfma_rb2_kernel<KS, DB>, (int)lds);
+    vq_argmin_mfma_rb2_kernel<KS, DB><<<dim3((unsigned)cdiv64(N, 256)), dim3(256), lds, s>>>(x, prep, N, K, idx, ws);
+}
+template <int KS>
+static void vq_launch_rb2(const bf16_t* x, const void* prep, int64_t N, int64_t K, int64_t* idx, VqWs* ws, hipStream_t s) {
+    static const int vdbg = [] {
+        const char* e = getenv("DVQ_VQ_DBG");
+        return e != nullptr ? atoi(e) : 0;
+    }();
+    if constexpr (KS == 16) {
+        if (vdbg == 1) return vq_launch_rb2_dbg<KS, 1>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 2) return vq_launch_rb2_dbg<KS, 2>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 4) return vq_launch_rb2_dbg<KS, 4>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 8) return vq_launch_rb2_dbg<KS, 8>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 9) return vq_launch_rb2_dbg<KS, 9>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 16) return vq_launch_rb2_dbg<KS, 16>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 13) return vq_launch_rb2_dbg<KS, 13>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 29) return vq_launch_rb2_dbg<KS, 29>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 32) return vq_launch_rb2_dbg<KS, 32>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 61) return vq_launch_rb2_dbg<KS, 61>(x, prep, N, K, idx, ws, s);
+    }
+    vq_launch_rb2_dbg<KS, 0>(x, prep, N, K, idx, ws, s);
+}
+
 template <typename XT>
 static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_t N, int64_t K, int64_t D,
                           int64_t* idx, void* wsv, int impl, hipStream_t s) {
@@ -918,8 +1357,6 @@ static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_
     DVQ_REQUIRE(!(impl == 2 && !mfma_ok), DVQ_ESHAPE, "dvq_vq_argmin: MFMA path needs D in {64,128,256} and prep");
     const bool use_mfma = impl == 2 || (impl == 0 && mfma_ok);
     if (use_mfma) {
-        vq_zero(ws, 256, s);
-        DVQ_CHECK_LAUNCH("vq_zero");
         dim3 grid((unsigned)cdiv64(N, 128)), block(256);
         static const bool v1 = [] {
             const char* e = getenv("DVQ_VQ_V1");          // A/B switch: the register-staged kernel of round 1
@@ -942,14 +1379,20 @@ static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_
                 auto go = [&](auto pipe, auto nw) {
                     constexpr bool P = decltype(pipe)::value;
                     constexpr int W = decltype(nw)::value;
-                    const size_t lds = 2 * (2 * 32 * (Dc * 2)) + 32 * W * 4;
+                    const size_t stg = 2 * (2 * 32 * (Dc * 2)), sel = (size_t)W * VQ_SEL_WORDS * 4;
+                    const size_t lds = (stg > sel ? stg : sel) + 32 * W * 4;
                     dvq_ensure_dynamic_lds((const void*)vq_argmin_mfma_pipe_kernel<KS, XT, 0, P, W>, (int)lds);
                     vq_argmin_mfma_pipe_kernel<KS, XT, 0, P, W><<<dim3((unsigned)cdiv64(N, 32 * W)), dim3(64 * W), lds, s>>>(
                         x, prep, N, K, idx, ws);
                 };
                 if (variant == 1) go(std::true_type{}, std::integral_constant<int, 4>{});
                 else if (variant == 2) go(std::false_type{}, std::integral_constant<int, 4>{});
-                else go(std::false_type{}, std::integral_constant<int, 8>{});
+                else if (variant == 3 || !std::is_same<XT, bf16_t>::value) go(std::false_type{}, std::integral_constant<int, 8>{});
+                else {
+                    // bf16 rows (default): 4 waves x 64 rows, one wave per SIMD, bookkeeping pipelined under the MFMAs.
+                    // DVQ_VQ_VARIANT=3 keeps the 8-wave x 32-row kernel (A/B); DVQ_VQ_DBG = 1 / 2 / 4 timing experiments (WRONG results)
+                    if constexpr (std::is_same<XT, bf16_t>::value) vq_launch_rb2<KS>(x, prep, N, K, idx, ws, s);
+                }
             }
         };
         if (D == 64) launch(std::integral_constant<int, 4>{});

@@ -201,21 +201,48 @@ def vq_prepare(codebook: torch.Tensor) -> torch.Tensor:
     return prep
 
 
+_vq_ws = {}
+
+
+def _vq_workspace(n, device):
+    """scratch of dvq_vq_argmin: its counters must be zero when a call starts and every call leaves them zero (the re-rank kernel
+    re-arms them), so ONE zero-filled buffer per (device, stream, N) serves all calls on that stream -- no zero-fill launch per
+    search.  Inside a stream capture a fresh zeroed buffer is used instead (it lives in the capture's pool; the fill is recorded
+    with it)."""
+    nbytes = lib().dvq_vq_argmin_workspace_bytes(n)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, n)
+    ws = _vq_ws.get(key)
+    if ws is None:
+        if len(_vq_ws) >= 16:
+            _vq_ws.clear()
+        ws = _vq_ws[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
 def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, prep: torch.Tensor | None = None, impl: int = 0,
               return_flagged: bool = False):
-    """x [N,D] (fp32/bf16), codebook [K,D] fp32 -> idx int64 [N] (exact argmin, lowest index on ties)."""
+    """x [N,D] (fp32/bf16), codebook [K,D] fp32 -> idx int64 [N] (exact argmin, lowest index on ties).
+    return_flagged: also a device int32 [3] = rows of THIS call settled in fp64 {over all K codes (generic kernel only), over their
+    candidate list / flagged residue classes, of those: rows with more candidate classes than an entry lists}; it is a view of the
+    shared scratch, valid until the next search on this stream."""
     n, d = x.shape
     k = codebook.shape[0]
     assert codebook.dtype == torch.float32 and codebook.shape[1] == d
     if prep is None and impl != 1 and d in (64, 128, 256):
         prep = vq_prepare(codebook)
     idx = torch.empty(n, dtype=torch.int64, device=x.device)
-    ws = torch.empty(lib().dvq_vq_argmin_workspace_bytes(n), dtype=torch.uint8, device=x.device)
+    ws = _vq_workspace(n, x.device)
     nbytes = n * d * x.element_size() + k * d * 4 + n * 8
-    _timed("vq_argmin", 2 * n * k * d, nbytes, lambda: check(
-        lib().dvq_vq_argmin(_p(x), dt(x), _p(codebook), _p(prep), n, k, d, _p(idx), _p(ws), impl, _s()), "dvq_vq_argmin"))
+    try:
+        _timed("vq_argmin", 2 * n * k * d, nbytes, lambda: check(
+            lib().dvq_vq_argmin(_p(x), dt(x), _p(codebook), _p(prep), n, k, d, _p(idx), _p(ws), impl, _s()), "dvq_vq_argmin"))
+    except Exception:
+        _vq_ws.clear()            # a failed call may leave the counters armed
+        raise
     if return_flagged:
-        return idx, ws[:8].view(torch.int32)      # rows re-ranked in fp64: [over all K codes, over their candidate list]
+        return idx, ws[16:28].view(torch.int32)
     return idx
 
 

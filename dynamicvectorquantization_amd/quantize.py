@@ -42,7 +42,7 @@ class VQEmbedding(nn.Embedding):
         self._prep = None          # (version, prep buffer)
         self._cb_version = 0       # bumped by every in-place codebook rewrite (EMA); conv packs are unaffected
         self.restart_perm = None   # optional injected permutation (tests)
-        self.last_flagged = None   # device int32 [2]: rows re-ranked in fp64 by the last search (all codes, candidate list)
+        self.last_flagged = None   # device int32 [3]: rows settled in fp64 by the last search (all codes, candidate list, of those: class scans only)
 
     # -- search -------------------------------------------------------------------------------------
     def _codebook(self):

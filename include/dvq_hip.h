@@ -62,9 +62,12 @@ size_t dvq_vq_prep_bytes(int64_t K, int64_t D);
 int dvq_vq_prepare(const float* codebook, int64_t K, int64_t D, void* prep, dvq_stream_t stream);
 
 /* idx[n] = argmin_k |x[n,:] - codebook[k,:]|^2.  x is [N,D] (row stride D) of `x_dtype`.
- * ws: dvq_vq_argmin_workspace_bytes(N) bytes; after the call its first two int32 hold the number of rows that were
- * re-ranked in fp64 over all K codes and over their short candidate list.  impl: 0 = auto, 1 = force generic VALU
- * kernel, 2 = force MFMA kernel (DVQ_ESHAPE if unsupported). */
+ * ws: dvq_vq_argmin_workspace_bytes(N) bytes whose first 256 bytes are ZERO when the call starts: zero a new buffer once; every
+ * call leaves them zero again (the re-rank kernel, its last launch, re-arms the counters), so a buffer serves any number of
+ * stream-ordered calls without a zero-fill launch.  After the call int32 slots [4], [5], [6] hold the number of rows settled in
+ * fp64 over all K codes (generic kernel only), over their candidate list / flagged residue classes, and -- of the latter -- with
+ * more candidate classes than an entry lists.  impl: 0 = auto, 1 = force generic VALU kernel, 2 = force MFMA kernel
+ * (DVQ_ESHAPE if unsupported). */
 size_t dvq_vq_argmin_workspace_bytes(int64_t N);
 /* Analysis entry point (VQEmbedding.compute_distances, quantize2_mask.py:29-48): out[n][k] = (|x_n|^2 + |e_k|^2) - 2 x_n.e_k
  * (fp32 FMA arithmetic, the reference's addmm formula), out fp32 [N][K] caller-owned; at most 2^20 rows per call. */

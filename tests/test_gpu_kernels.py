@@ -47,7 +47,7 @@ def test_vq_argmin_golden(dev, ci, impl):
     scale = (x[bad].astype(np.float64) ** 2).sum(axis=1) + 1.0
     assert np.all(g[f"case{ci}_gap"][bad] < 4e-7 * scale), (g[f"case{ci}_gap"][bad], scale)
     if impl == 0 and d in (64, 128, 256):
-        frac = int(flagged.sum().item()) / n
+        frac = int(flagged[:2].sum().item()) / n
         assert frac < 0.2, f"fp64 re-rank fraction {frac} unexpectedly high"
 
 
@@ -76,7 +76,7 @@ def test_vq_argmin_ties(dev):
     idx = idx.cpu().numpy()
     assert np.array_equal(idx, exact)
     assert np.all(idx[:10] == 3)
-    assert int(flagged.sum()) >= 20         # the rows nearest to the duplicated codes were re-ranked (same-class duplicates: whole class)
+    assert int(flagged[:2].sum()) >= 20         # the rows nearest to the duplicated codes were re-ranked (same-class duplicates: whole class)
 
 
 @pytest.mark.parametrize("k", [1024, 8192])
@@ -92,10 +92,10 @@ def test_vq_argmin_full_size_properties(dev, k):
         idx = idx.cpu().numpy()
         sample = np.random.RandomState(1).choice(n, 2048, replace=False)
         assert np.array_equal(idx[sample], ovq.argmin_exact(x[sample], cb))
-        assert int(flagged.sum().item()) < 0.1 * n
+        assert int(flagged[:2].sum().item()) < 0.1 * n
         # ambiguous rows are settled among their few candidate codes (+ whole residue classes); the all-codes re-rank (more
         # than VQ_MAXC candidate classes) is the rare exception
-        assert int(flagged[0]) <= 0.05 * int(flagged.sum()) + 4, flagged.cpu().numpy()
+        assert int(flagged[0]) == 0 and int(flagged[2]) <= 0.05 * int(flagged[1]) + 4, flagged.cpu().numpy()
         # idempotence: quantising code vectors returns their own index
         self_idx = K.vq_argmin(cbt, cbt, impl=2).cpu().numpy()
         assert np.array_equal(self_idx, np.arange(k))
@@ -103,6 +103,48 @@ def test_vq_argmin_full_size_properties(dev, k):
         xb = xt[:4096].to(torch.bfloat16)
         idxb = K.vq_argmin(xb, cbt, impl=2).cpu().numpy()
         assert np.array_equal(idxb, ovq.argmin_exact(xb.float().cpu().numpy(), cb))
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_vq_argmin_bf16_rows_kernel(dev, d):
+    """bf16 rows (the training path) run on their own main kernel (4 waves x 64 rows, bookkeeping pipelined under the MFMAs):
+    exact argmin w.r.t. the bf16-rounded rows for every supported D, ragged row counts (tile tails, fewer rows than a tile),
+    K not a multiple of 32, both benchmark distributions, exact many-way ties (more candidate classes than an entry lists ->
+    class scans, no all-codes row) -- and repeated calls on the shared scratch, whose counters the re-rank kernel re-arms."""
+    from dynamicvectorquantization_amd import kernels as K
+    from oracle import vq as ovq
+    for n, k, dist_, seed in ((4096, 1024, "normal", 1), (4096 + 77, 1000, "encoder", 2), (130, 96, "normal", 3), (7, 33, "normal", 4)):
+        x, cb = synth.vq_inputs(n, d, k, dist_, seed)
+        xb = T(x, dev).to(torch.bfloat16)
+        cbt = T(cb, dev)
+        want = ovq.argmin_exact(xb.float().cpu().numpy(), cb)
+        for rep in range(3):                               # same scratch three times: counters re-armed, reports per call
+            idx, flagged = K.vq_argmin(xb, cbt, impl=2, return_flagged=True)
+            assert np.array_equal(idx.cpu().numpy(), want), (n, k, dist_, rep)
+            f = flagged.cpu().numpy()
+            assert f[0] == 0 and 0 <= f[2] <= f[1] <= n, f
+            if rep:
+                assert np.array_equal(f, f_prev)           # deterministic candidate sets
+            f_prev = f
+    # many-way exact ties: 40 copies of one code spread over > 5 residue classes; rows next to it see > VQ_MAXC candidate classes
+    rs = np.random.RandomState(11)
+    k = 256
+    cb = rs.standard_normal((k, d)).astype(np.float32)
+    dup = rs.choice(np.arange(1, k), 40, replace=False)
+    cb[dup] = cb[0]
+    x = rs.standard_normal((500, d)).astype(np.float32)
+    x[:64] = cb[0] + 1e-3 * rs.standard_normal((64, d)).astype(np.float32)
+    xb = T(x, dev).to(torch.bfloat16)
+    want = ovq.argmin_exact(xb.float().cpu().numpy(), cb)
+    idx, flagged = K.vq_argmin(xb, T(cb, dev), impl=2, return_flagged=True)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert np.all(idx.cpu().numpy()[:64] == 0)             # lowest index among the exact ties
+    f = flagged.cpu().numpy()
+    assert f[0] == 0 and f[2] >= 64 and f[1] >= f[2], f    # the tied rows took the wide (class-scan) form, none an all-codes row
+    # fp32 rows through the same call sequence (8-wave kernel): the wide form as well
+    idx32, flagged32 = K.vq_argmin(T(x, dev), T(cb, dev), impl=2, return_flagged=True)
+    assert np.array_equal(idx32.cpu().numpy(), ovq.argmin_exact(x, cb))
+    assert int(flagged32[0]) == 0 and int(flagged32[2]) >= 64
 
 
 def test_vq_distances_and_soft_codes_golden(dev):
