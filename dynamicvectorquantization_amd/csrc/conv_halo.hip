@@ -635,6 +635,10 @@ __global__ __launch_bounds__(64) void halo_stats_finalize_kernel(const float* __
 
 }  // namespace
 
+int dvq_conv3x3_halo2_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N, int64_t H, int64_t W,
+                          int64_t Cin, int64_t Cout, int flip, int up, const float* gn_ss, double* out_stats, int out_groups,
+                          float act_slope, int res_mask, float mask_slope, hipStream_t stream);
+
 extern "C" int dvq_halo_trace_read(unsigned long long* dst, int64_t max_records) {
     DVQ_REQUIRE(dst != nullptr && max_records > 0, DVQ_EINVAL, "dvq_halo_trace_read: bad arguments");
     const int64_t n = max_records < HALO_TRACE_MAX ? max_records : HALO_TRACE_MAX;
@@ -652,6 +656,11 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
                          double* out_stats, int out_groups, float act_slope, int res_mask, float mask_slope,
                          hipStream_t stream) {
     if (H % TH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
+    {   // the persistent kernel (conv_halo2.hip) takes the launches it is built for: 128-channel output blocks, >= 2 tiles per CU
+        const int rc2 = dvq_conv3x3_halo2_try(x, w, bias, residual, y, N, H, W, Cin, Cout, flip, up, gn_ss, out_stats, out_groups, act_slope,
+                                              res_mask, mask_slope, stream);
+        if (rc2 != 0) return rc2;
+    }
     const int cot = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;          // output-channel tile of the kernel instance
     if (out_stats != nullptr && (out_groups <= 0 || Cout % out_groups != 0 || cot % (Cout / out_groups) != 0)) return 0;
     if (out_stats != nullptr) {
