@@ -20,6 +20,7 @@
 // Matrix-vector products: 16 output columns per work item, the 8 waves of a workgroup split K; v_mfma_f32_16x16x32_bf16 with the
 // WEIGHT rows as the A operand (lane: row l & 15, k 8 (l >> 4) ..) and the <= 16 activation rows as B; the waves' partial tiles
 // are added through LDS and thread (n, m) applies the epilogue.  LayerNorm rows are normalised once per workgroup into LDS.
+// Round 4: up to 64 sequences (row tiles of 16, one tile per workgroup; attention with one wave per item when there are many).
 #include "dvq_common.h"
 
 namespace {
@@ -40,6 +41,7 @@ struct DecParams {
     bf16_t *x, *q, *kn, *vn, *y, *m1;      // kn / vn: the new k / v rows [B][C] (also appended to the caches for later launches)
     unsigned* sync;                    // [0] barrier arrivals, [1] finished workgroups, [2] error flag (barrier timeout)
     unsigned long long* trace;         // optional: s_memrealtime stamps of workgroup 0 at the phase boundaries of the first blocks
+    int wave_attn;                     // 1: attention with one wave per (sequence, head) item (many items), 0: one workgroup per item
 };
 
 constexpr int DTH = 512, DNW = 8;
@@ -205,7 +207,15 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
     if (t < 0 || t >= p.Tmax) return;                                 // (uniform over the grid: never write outside the caches)
     const int Tlen = (int)t + 1;
     const int n = tid >> 4, m = tid & 15;                             // epilogue role of threads 0 .. 255
-    const bool eok = tid < 256 && m < B;
+    // More than 16 sequences (the reference samples 50 at a time, scripts/sample_val/sample_dynamic_uncond.py:29): the rows are cut
+    // into tiles of 16 and a workgroup serves ONE tile -- workgroup wg: tile wg % MB, and among the nwq workgroups of that tile the
+    // wq-th; a matrix-vector item is (16 output columns) x (the 16 rows of the tile), exactly the item of the <= 16-row case, and
+    // the LayerNorm of a phase normalises the workgroup's own 16 rows only.  Weights are then read once per row tile (from L2).
+    const int MB = (B + 15) >> 4;
+    const int mbt = wg % MB, wq = wg / MB, nwq = nwg / MB;
+    const int row0 = 16 * mbt, nrows = min(16, B - row0);
+    const bool eok = tid < 256 && m < nrows;
+    const int mg = row0 + m;                                          // the global row of this thread's epilogue role
     unsigned bar = 0;
     int ntr = 0;
     auto stamp = [&]() {
@@ -219,29 +229,165 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
         const int cb = C >> 4;                                        // 16-column blocks per projection
         const int fb = F >> 4;
         if (l == 0) {                                                 // (later blocks: issued before the previous block's last barrier)
-            const int which = wg / cb;
-            gemv_load_w(which == 0 ? L.wq : which == 1 ? L.wk : L.wv, C, (wg - which * cb) * 16, wg < 3 * cb, wf);
+            const int which = wq / cb;
+            gemv_load_w(which == 0 ? L.wq : which == 1 ? L.wk : L.wv, C, (wq - which * cb) * 16, wq < 3 * cb, wf);
         }
-        if (wg < 3 * cb) ln_rows_to_lds(p.x, B, C, p.eps, L.ln1g, L.ln1b, xn);
+        if (wq < 3 * cb) ln_rows_to_lds(p.x + (int64_t)row0 * C, nrows, C, p.eps, L.ln1g, L.ln1b, xn);
         __syncthreads();
         stamp();
-        for (int blk = wg; blk < 3 * cb; blk += nwg) {
+        for (int blk = wq; blk < 3 * cb; blk += nwq) {
             const int which = blk / cb, n0 = (blk - which * cb) * 16;
             const bf16_t* W = which == 0 ? L.wq : which == 1 ? L.wk : L.wv;
             const float* bias = which == 0 ? L.bq : which == 1 ? L.bk : L.bv;
-            if (blk != wg) gemv_load_w(W, C, n0, true, wf);
-            float v = gemv16_reduce(gemv_compute<true>(wf, C, xn, C, B), red);
+            if (blk != wq) gemv_load_w(W, C, n0, true, wf);
+            float v = gemv16_reduce(gemv_compute<true>(wf, C, xn, C, nrows), red);
             if (tid < 256 && bias != nullptr) v += bias[n0 + n];
             bf16_t* dst = which == 0 ? p.q : which == 1 ? p.kn : p.vn;
-            cstore_pair(dst + m * C, n0 + n, v, eok);
-            if (eok && which != 0) (which == 1 ? L.kc : L.vc)[((int64_t)m * p.Tmax + t) * C + n0 + n] = f32_to_bf16(v);
+            cstore_pair(dst + mg * C, n0 + n, v, eok);
+            if (eok && which != 0) (which == 1 ? L.kc : L.vc)[((int64_t)mg * p.Tmax + t) * C + n0 + n] = f32_to_bf16(v);
         }
         stores_done();
         stamp();
         if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
         stamp();
         // ---- (2) attention of the new row over cache rows 0 .. t, one (sequence, head) per work item ------------------------------
-        {
+        if (p.wave_attn) {
+            // many items (B x heads beyond a few per workgroup): one WAVE -- or, while there are waves to spare, a PAIR of waves that
+            // split the cache rows in halves (wave_attn == 2) -- per item, eight waves of a workgroup at a time.  Scores of a wave
+            // live in its own LDS strip; a pair folds its two partial (max, sum, accumulator) triples through LDS (flash-decoding
+            // style), which is the only workgroup barrier of an item.  Lane roles: scores: row r = lane, lane + 64, ..;
+            // probabilities x values: lane group g = lane / nv takes rows g, g + ngrp, .., lane % nv its eight channels.
+            const int lane = tid & 63, wave = tid >> 6;
+            const int nv = hs >> 3, ngrp = 64 / nv;
+            const int ch = lane % nv, grp = lane / nv;
+            const int NS = p.wave_attn, WPI = DNW / NS;               // row splits per item; items of a workgroup in flight
+            const int pw = wave % WPI, part = wave / WPI;
+            const int strip = p.Tmax + 2 * hs + 8;
+            float* sc = reinterpret_cast<float*>(xn) + wave * strip;  // [Tmax] scores -> probabilities | [hs] q | [hs + 2] partial result
+            float* qs = sc + p.Tmax;
+            float* mrg = qs + hs;
+            const int nitem = B * nh, niter = (nitem + nwg * WPI - 1) / (nwg * WPI);
+            const int tsplit = NS == 1 ? Tlen : (((Tlen + 1) / 2 + 63) & ~63);
+            const int lo = part * tsplit, hi = min(Tlen, lo + tsplit);
+            for (int it = 0; it < niter; ++it) {
+                const int item = (it * WPI + pw) * nwg + wg;          // (workgroup-major: every CU pulls rows)
+                const bool live = item < nitem;
+                float mx = -INFINITY, ssum = 0.f;
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                int b = 0, h = 0;
+                if (live) {
+                    b = item / nh;
+                    h = item - b * nh;
+                    const bf16_t* kb = L.kc + (int64_t)b * p.Tmax * C + h * hs;
+                    const bf16_t* vb = L.vc + (int64_t)b * p.Tmax * C + h * hs;
+                    const bf16_t* knr = p.kn + b * C + h * hs;        // row t itself: written during this launch, read coherently
+                    const bf16_t* vnr = p.vn + b * C + h * hs;
+                    __builtin_amdgcn_wave_barrier();
+                    for (int d2 = lane; d2 < (hs >> 1); d2 += 64) {
+                        const unsigned u = cload4(p.q + b * C + h * hs + 2 * d2);
+                        qs[2 * d2] = __uint_as_float(u << 16);
+                        qs[2 * d2 + 1] = __uint_as_float(u & 0xffff0000u);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    for (int r0 = lo + lane; r0 < hi; r0 += 128) {    // two rows per lane and pass: 16 independent 16-byte loads in flight
+                        float a2[2] = {0.f, 0.f};
+                        for (int i0 = 0; i0 < nv; i0 += 8) {
+                            uint4 kk[2][8];
+#pragma unroll
+                            for (int w2 = 0; w2 < 2; ++w2) {
+                                const int r = r0 + 64 * w2;
+                                const bf16_t* kr = kb + (int64_t)r * C;
+#pragma unroll
+                                for (int u = 0; u < 8; ++u)
+                                    kk[w2][u] = (i0 + u >= nv || r >= hi) ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? cload16(knr + (i0 + u) * 8)
+                                                                                                                 : *reinterpret_cast<const uint4*>(kr + (i0 + u) * 8);
+                            }
+#pragma unroll
+                            for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    if (i0 + u < nv) {
+                                        float kv[8];
+                                        unpack8(kk[w2][u], kv);
+#pragma unroll
+                                        for (int j = 0; j < 8; ++j) a2[w2] = fmaf(qs[(i0 + u) * 8 + j], kv[j], a2[w2]);
+                                    }
+                                }
+                        }
+#pragma unroll
+                        for (int w2 = 0; w2 < 2; ++w2) {
+                            const int r = r0 + 64 * w2;
+                            if (r < hi) {
+                                const float a = a2[w2] * p.scale;
+                                sc[r - lo] = a;
+                                mx = fmaxf(mx, a);
+                            }
+                        }
+                    }
+                    mx = wave_max(mx);
+                    for (int r = lo + lane; r < hi; r += 64) {
+                        const float e = __expf(sc[r - lo] - mx);
+                        sc[r - lo] = e;
+                        ssum += e;
+                    }
+                    ssum = wave_sum(ssum);
+                    __builtin_amdgcn_wave_barrier();                  // (one wave: its LDS operations complete in order)
+                    for (int r0 = lo + grp; r0 < hi; r0 += 8 * ngrp) {       // eight rows (independent 16-byte loads) in flight per lane
+                        uint4 vq[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int r = r0 + u * ngrp;
+                            vq[u] = r >= hi ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? cload16(vnr + ch * 8)
+                                                                                   : *reinterpret_cast<const uint4*>(vb + (int64_t)r * C + ch * 8);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int r = r0 + u * ngrp;
+                            const float pt = r < hi ? sc[r - lo] : 0.f;
+                            float vv[8];
+                            unpack8(vq[u], vv);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[j] = fmaf(pt, vv[j], acc[j]);
+                        }
+                    }
+                    for (int o = nv; o < 64; o <<= 1) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+                    }
+                }
+                if (NS == 2) {                                        // fold the pair: the second half parks its triple, the first combines
+                    if (part == 1 && live) {
+                        if (grp == 0) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) mrg[ch * 8 + j] = acc[j];
+                        }
+                        if (lane == 0) {
+                            mrg[hs] = mx;
+                            mrg[hs + 1] = ssum;
+                        }
+                    }
+                    __syncthreads();
+                    if (part == 0 && live) {
+                        const float* om = mrg + WPI * strip;          // the strip of wave + WPI
+                        const float m1 = om[hs], s1 = om[hs + 1];
+                        const float m = fmaxf(mx, m1);
+                        const float f0 = __expf(mx - m), f1 = m1 == -INFINITY ? 0.f : __expf(m1 - m);
+                        ssum = ssum * f0 + s1 * f1;
+                        if (grp == 0) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[j] = acc[j] * f0 + om[ch * 8 + j] * f1;
+                        }
+                    }
+                    __syncthreads();                                  // the strips may be rewritten by the next item
+                }
+                if (live && part == 0 && grp == 0) {
+                    const float inv = 1.f / ssum;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        cstore4(p.y + b * C + h * hs + ch * 8 + 2 * j, pack_bf16x2(acc[2 * j] * inv, acc[2 * j + 1] * inv));
+                }
+            }
+        } else {
             float* sc = reinterpret_cast<float*>(xn);                 // [Tlen] scores -> probabilities
             float* qs = sc + p.Tmax;                                  // [hs]
             float* part = qs + hs;                                    // [ngrp][hs]
@@ -306,13 +452,23 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                 for (int w = 0; w < DNW; ++w) tot += rd[8 + w];
                 const float inv = 1.f / tot;
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int r = grp < ngrp ? grp : Tlen; r < Tlen; r += ngrp) {
-                    float vv[8];
-                    if (r == Tlen - 1) unpack8(cload16(vnr + ch * 8), vv);
-                    else load8(vb + (int64_t)r * C + ch * 8, vv);
-                    const float pt = sc[r];
+                for (int r0 = grp < ngrp ? grp : Tlen; r0 < Tlen; r0 += 4 * ngrp) {     // four rows (independent loads) in flight per lane
+                    uint4 vq[4];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(pt, vv[j], acc[j]);
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = r0 + u * ngrp;
+                        vq[u] = r >= Tlen ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? cload16(vnr + ch * 8)
+                                                                                   : *reinterpret_cast<const uint4*>(vb + (int64_t)r * C + ch * 8);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = r0 + u * ngrp;
+                        const float pt = r < Tlen ? sc[r] : 0.f;
+                        float vv[8];
+                        unpack8(vq[u], vv);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(pt, vv[j], acc[j]);
+                    }
                 }
                 if (grp < ngrp) {                                     // (DTH % nv != 0, e.g. head size 96: the last threads hold no group)
 #pragma unroll
@@ -343,62 +499,62 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
         }
         stores_done();
         stamp();
-        gemv_load_w(L.wo, C, wg * 16, wg < cb, wf);                    // weights of phase 3, in flight across the barrier
+        gemv_load_w(L.wo, C, wq * 16, wq < cb, wf);                    // weights of phase 3, in flight across the barrier
         if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
         stamp();
         // ---- (3) output projection + residual (in place: an element of x is read and written by the same thread pair) -------------
-        for (int blk = wg; blk < cb; blk += nwg) {
+        for (int blk = wq; blk < cb; blk += nwq) {
             const int n0 = blk * 16;
-            if (blk != wg) gemv_load_w(L.wo, C, n0, true, wf);
-            float v = gemv16_reduce(gemv_compute<false>(wf, C, p.y, C, B), red);
+            if (blk != wq) gemv_load_w(L.wo, C, n0, true, wf);
+            float v = gemv16_reduce(gemv_compute<false>(wf, C, p.y + (int64_t)row0 * C, C, nrows), red);
             if (tid < 256 && L.bo != nullptr) v += L.bo[n0 + n];
             v = bf16_to_f32(f32_to_bf16(v));                          // (rounded like the separate kernels did)
             if (eok) {
-                const unsigned xo = cload4(p.x + m * C + n0 + (n & ~1));
+                const unsigned xo = cload4(p.x + mg * C + n0 + (n & ~1));
                 v += (n & 1) ? __uint_as_float(xo & 0xffff0000u) : __uint_as_float(xo << 16);
             }
-            cstore_pair(p.x + m * C, n0 + n, v, eok);
+            cstore_pair(p.x + mg * C, n0 + n, v, eok);
         }
         stores_done();
         stamp();
-        gemv_load_w(L.w1, C, wg * 16, wg < fb, wf);
+        gemv_load_w(L.w1, C, wq * 16, wq < fb, wf);
         if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
         stamp();
         // ---- (4) LayerNorm 2 + fc + GELU -------------------------------------------------------------------------------------
-        if (wg < fb) ln_rows_to_lds(p.x, B, C, p.eps, L.ln2g, L.ln2b, xn);
+        if (wq < fb) ln_rows_to_lds(p.x + (int64_t)row0 * C, nrows, C, p.eps, L.ln2g, L.ln2b, xn);
         __syncthreads();
         stamp();
-        for (int blk = wg; blk < fb; blk += nwg) {
+        for (int blk = wq; blk < fb; blk += nwq) {
             const int n0 = blk * 16;
-            if (blk != wg) gemv_load_w(L.w1, C, n0, true, wf);
-            float v = gemv16_reduce(gemv_compute<true>(wf, C, xn, C, B), red);
+            if (blk != wq) gemv_load_w(L.w1, C, n0, true, wf);
+            float v = gemv16_reduce(gemv_compute<true>(wf, C, xn, C, nrows), red);
             if (tid < 256 && L.b1 != nullptr) v += L.b1[n0 + n];
             v = dec_gelu(bf16_to_f32(f32_to_bf16(v)));
-            cstore_pair(p.m1 + m * F, n0 + n, v, eok);
+            cstore_pair(p.m1 + (int64_t)mg * F, n0 + n, v, eok);
         }
         stores_done();
         stamp();
-        gemv_load_w(L.w2, F, wg * 16, wg < cb, wf);
+        gemv_load_w(L.w2, F, wq * 16, wq < cb, wf);
         if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
         stamp();
         // ---- (5) second projection + residual --------------------------------------------------------------------------------
-        for (int blk = wg; blk < cb; blk += nwg) {
+        for (int blk = wq; blk < cb; blk += nwq) {
             const int n0 = blk * 16;
-            if (blk != wg) gemv_load_w(L.w2, F, n0, true, wf);
-            float v = gemv16_reduce(gemv_compute<false>(wf, F, p.m1, F, B), red);
+            if (blk != wq) gemv_load_w(L.w2, F, n0, true, wf);
+            float v = gemv16_reduce(gemv_compute<false>(wf, F, p.m1 + (int64_t)row0 * F, F, nrows), red);
             if (tid < 256 && L.b2 != nullptr) v += L.b2[n0 + n];
             v = bf16_to_f32(f32_to_bf16(v));
             if (eok) {
-                const unsigned xo = cload4(p.x + m * C + n0 + (n & ~1));
+                const unsigned xo = cload4(p.x + mg * C + n0 + (n & ~1));
                 v += (n & 1) ? __uint_as_float(xo & 0xffff0000u) : __uint_as_float(xo << 16);
             }
-            cstore_pair(p.x + m * C, n0 + n, v, eok);
+            cstore_pair(p.x + mg * C, n0 + n, v, eok);
         }
         stores_done();
         if (l + 1 < p.nlayers) {
             const DecLayer& Ln = p.layers[l + 1];
-            const int which = wg / cb;
-            gemv_load_w(which == 0 ? Ln.wq : which == 1 ? Ln.wk : Ln.wv, C, (wg - which * cb) * 16, wg < 3 * cb, wf);
+            const int which = wq / cb;
+            gemv_load_w(which == 0 ? Ln.wq : which == 1 ? Ln.wk : Ln.wv, C, (wq - which * cb) * 16, wq < 3 * cb, wf);
         }
         stamp();
         if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
@@ -440,17 +596,22 @@ int dvq_decode_stack_status(const void* scratch, int64_t B, int64_t C, int64_t F
 int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C, int n_head, int64_t F, int64_t Tmax, const int64_t* t_dev,
                      float eps, void* x, void* scratch, int n_workgroups, dvq_stream_t stream) {
     DVQ_REQUIRE(layers_dev && t_dev && x && scratch && n_layers > 0, DVQ_EINVAL, "dvq_decode_stack: null pointer");
-    DVQ_REQUIRE(B > 0 && B <= 16 && C > 0 && C % 32 == 0 && C <= 2048 && F > 0 && F % 32 == 0 && n_head > 0 && C % n_head == 0 &&
+    DVQ_REQUIRE(B > 0 && B <= 64 && C > 0 && C % 32 == 0 && C <= 2048 && F > 0 && F % 32 == 0 && n_head > 0 && C % n_head == 0 &&
                     (C / n_head) % 8 == 0 && C / n_head <= 256 && Tmax > 0 && Tmax <= 12000,
-                DVQ_ESHAPE, "dvq_decode_stack: needs B <= 16, C %% 32 == 0 (<= 2048), F %% 32 == 0, head size %% 8 == 0 (<= 256), Tmax <= 12000");
+                DVQ_ESHAPE, "dvq_decode_stack: needs B <= 64, C %% 32 == 0 (<= 2048), F %% 32 == 0, head size %% 8 == 0 (<= 256), Tmax <= 12000");
     int dev = 0, cus = 0;
     DVQ_REQUIRE(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0,
                 DVQ_EARCH, "dvq_decode_stack: no device");
     // every workgroup must be resident at once (the barrier spins): at most one per CU
     // default: half the CUs (128 on MI355X: one (sequence, head) item each at batch 8 x 16 heads; measured 3650 token-steps/s against
     // 3400 with 256 -- fewer barrier participants -- and 2760 with 64)
-    int nwg = n_workgroups > 0 ? n_workgroups : (cus >= 128 ? (cus / 2 > 128 ? cus / 2 : 128) : cus);
+    // more than 16 sequences: every CU (the K / V rows of B x heads items are the traffic that counts then), a multiple of the
+    // number of 16-row tiles (a workgroup serves one tile)
+    const int MB = (int)((B + 15) / 16);
+    int nwg = n_workgroups > 0 ? n_workgroups : (B > 16 ? cus : (cus >= 128 ? (cus / 2 > 128 ? cus / 2 : 128) : cus));
     if (nwg > cus) nwg = cus;
+    nwg = nwg / MB * MB;
+    DVQ_REQUIRE(nwg >= MB, DVQ_ESHAPE, "dvq_decode_stack: fewer workgroups than row tiles");
     DecParams p{};
     p.layers = (const DecLayer*)layers_dev; p.nlayers = n_layers;
     p.B = (int)B; p.C = (int)C; p.nh = n_head; p.F = (int)F; p.Tmax = Tmax; p.t_dev = t_dev; p.eps = eps;
@@ -465,8 +626,27 @@ int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C,
     p.sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + ((4 * B * C + B * F) * 2 + 15) / 16 * 16);
     static const bool trace_env = getenv("DVQ_DECODE_TRACE") != nullptr;
     p.trace = trace_env ? reinterpret_cast<unsigned long long*>(p.sync + 8) : nullptr;
-    const int64_t att = (Tmax + hs + (int64_t)(DTH / (hs >> 3)) * hs + 16) * 4;
-    const int64_t lnb = B * C * 2;
+    const int nvh = hs >> 3;
+    const int64_t att_wg = (Tmax + hs + (int64_t)(DTH / nvh) * hs + 16) * 4;
+    const int64_t att_wave = (int64_t)DNW * (Tmax + 2 * hs + 8) * 4;
+    // Attention per item: the workgroup path (8 cooperating waves, ~12 - 15 us per item whatever the batch: latency-bound) serves a
+    // workgroup's items one after the other; beyond ~2 items per workgroup the wave path takes over: one wave per item, or -- while
+    // twice the items still fit the resident waves -- a pair of waves per item that splits the cache rows (a single wave streams its
+    // item's 154 KB of K / V rows at cache row 600 in ~50 us; tools/debug/decode_trace.py).  DVQ_DECODE_WAVE_ATTN=0 / 1 / 2 forces
+    // the workgroup path / one wave / a pair.
+    static const int wa_env = [] {
+        const char* e = getenv("DVQ_DECODE_WAVE_ATTN");
+        return e != nullptr ? atoi(e) : -1;
+    }();
+    const bool wa_ok = 64 % nvh == 0 && DNW * 256 * 4 + att_wave <= 150 * 1024;
+    const int64_t nitems = B * n_head;
+    p.wave_attn = 0;
+    if (wa_ok) {
+        if (wa_env >= 0) p.wave_attn = wa_env > 2 ? 2 : wa_env;
+        else if (nitems > 2 * nwg) p.wave_attn = 2 * nitems <= (int64_t)nwg * DNW ? 2 : 1;
+    }
+    const int64_t att = p.wave_attn ? att_wave : att_wg;
+    const int64_t lnb = 16 * C * 2;                                   // the workgroup's own 16 rows
     const int lds = (int)(DNW * 256 * 4 + (att > lnb ? att : lnb));
     DVQ_REQUIRE(lds <= 160 * 1024, DVQ_ESHAPE, "dvq_decode_stack: LDS footprint %d", lds);
     dvq_ensure_dynamic_lds((const void*)decode_stack_kernel, lds);

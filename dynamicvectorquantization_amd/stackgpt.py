@@ -300,12 +300,12 @@ class DecodeState:
     # ---- all blocks of a transformer in one persistent kernel (dvq_decode_stack) ---------------------------------------------------
     def _stack(self, which):
         """(device table of the blocks' weight / cache pointers, scratch, tensors kept alive) of the position ('pos') or content
-        ('con') transformer, or None when the fused kernel does not apply (fp32 runs, > 16 sequences, DVQ_DECODE_STACK=0)"""
+        ('con') transformer, or None when the fused kernel does not apply (fp32 runs, > 64 sequences, DVQ_DECODE_STACK=0)"""
         g = self.gpt
         blocks, caches = (g.position_transformer, self.pos_cache) if which == "pos" else (g.content_transformer, self.con_cache)
         c, cd = g.config.n_embd, rt.compute_dtype()
         nh = blocks[0].attn.n_head
-        if (getattr(self, "_no_stack", False) or os.environ.get("DVQ_DECODE_STACK", "1") == "0" or cd != torch.bfloat16 or self.b > 16 or c % 32 or c > 2048 or (c // nh) % 8 or
+        if (getattr(self, "_no_stack", False) or os.environ.get("DVQ_DECODE_STACK", "1") == "0" or cd != torch.bfloat16 or self.b > 64 or c % 32 or c > 2048 or (c // nh) % 8 or
                 c // nh > 256 or self.max_rows > 12000):
             return None
         ent = self._stacks.get(which)

@@ -434,7 +434,7 @@ int dvq_rows_dev(void* x, void* hidden, int dtype, int64_t B, int64_t C, int64_t
  * single-row attention per (sequence, head), projection + residual, LayerNorm + fc + GELU, projection + residual -- the phases
  * separated by a device-wide barrier.  Replaces 12 launches per block of the K/V-cached sampler (each costs ~9 us of command
  * processing whatever its size).  bf16 weights [out][in] (row-major, as torch.nn.Linear), fp32 biases (may be NULL) and LayerNorm
- * parameters; B <= 16 sequences, C %% 32 == 0 (<= 2048), F %% 32 == 0, head size %% 8 == 0; x [B][C] bf16 is updated in place.
+ * parameters; B <= 64 sequences, C %% 32 == 0 (<= 2048), F %% 32 == 0, head size %% 8 == 0; x [B][C] bf16 is updated in place.
  * `layers_dev`: DEVICE array of n_layers dvq_decode_layer.  `scratch`: dvq_decode_stack_scratch_bytes(B, C, F) bytes, ZEROED once by
  * the caller (the kernel re-arms its barrier counters itself).  n_workgroups <= 0: one workgroup per CU; the grid must be resident
  * as a whole (nothing else may occupy the device's LDS / wave slots to the point of excluding a workgroup: a barrier that is not

@@ -505,16 +505,21 @@ def test_fused_constrained_sampler_vs_op_by_op(dev):
     assert torch.equal(got, ref)
 
 
-def test_decode_stack_kernel_vs_per_kernel_token_steps(dev, monkeypatch):
+@pytest.mark.parametrize("b,wgs,wattn", [(5, 0, 0), (16, 0, 0), (50, 0, 0), (50, 32, 1), (37, 30, 2), (64, 64, 1), (50, 128, 2), (7, 16, 2)])
+def test_decode_stack_kernel_vs_per_kernel_token_steps(dev, monkeypatch, b, wgs, wattn):
     """dvq_decode_stack (all blocks of a transformer per token step in one persistent kernel with device-wide barriers) against the
     per-kernel token steps it replaces: same logits within bf16 rounding over a run of single-row steps, same K/V cache rows, eager and
-    replayed from the captured graph; barrier error word stays clear"""
+    replayed from the captured graph; barrier error word stays clear.  b = 50 is the reference's sampling batch
+    (scripts/sample_val/sample_dynamic_uncond.py:29): row tiles of 16, and -- with few workgroups (`wgs`) -- the one-wave-per-item
+    attention paths (one wave / a pair of waves splitting the cache rows per item); b = 37: a ragged last tile, three tiles."""
     from dynamicvectorquantization_amd import runtime as rt
     from dynamicvectorquantization_amd.config import instantiate_from_config
     from dynamicvectorquantization_amd.stackgpt import DecodeState
     from dynamicvectorquantization_amd import synth
     cfg = dict(SAMPLER_GPT_CFG, n_embd=256, n_head=4, position_layer=2, content_layer=3)
-    b, steps = 5, 14
+    steps = 14
+    monkeypatch.setenv("DVQ_DECODE_WGS", str(wgs))
+    monkeypatch.setenv("DVQ_DECODE_WAVE_ATTN", str(wattn))      # attention by the whole workgroup / one wave / a pair of waves per item
     with rt.compute_dtype_ctx(torch.bfloat16):
         gpt = instantiate_from_config({"target": "modules.dynamic_modules.stackgpt.StackGPT", "params": cfg}).to(dev).eval()
         with torch.no_grad():
@@ -539,9 +544,7 @@ def test_decode_stack_kernel_vs_per_kernel_token_steps(dev, monkeypatch):
                 outs.append((pl.float().cpu().numpy(), cl.float().cpu().numpy()))
             if flag == "1":
                 assert st._stacks, "the fused kernel was not used"
-                for ent in st._stacks.values():
-                    words = ent["scratch"][-64:].view(torch.int32).cpu().numpy()
-                    assert not words.any(), f"barrier counters / error word not clear: {words}"
+                st.check()                                       # raises if a device-wide barrier timed out
             caches = [c_[0][:, :steps].float().cpu().numpy() for c_ in st.con_cache] + [c_[1][:, :steps].float().cpu().numpy() for c_ in st.pos_cache]
             return outs, caches
 

@@ -7,7 +7,7 @@ import torch, ctypes
 from dynamicvectorquantization_amd import kernels as K, _lib
 from dynamicvectorquantization_amd._lib import DecodeLayer
 dev = torch.device("cuda:0")
-B, C, NH, F, TMAX, NL = 8, 1024, 16, 4096, 1300, int(os.environ.get("NL", 18))
+B, C, NH, F, TMAX, NL = int(os.environ.get("B", 8)), 1024, 16, 4096, 1300, int(os.environ.get("NL", 18))
 bf = lambda *s: (torch.randn(*s, device=dev) * 0.02).to(torch.bfloat16)
 keep, arr = [], (DecodeLayer * NL)()
 for i in range(NL):
