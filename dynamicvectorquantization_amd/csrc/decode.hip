@@ -86,6 +86,8 @@ __device__ __forceinline__ uint4 cload16(const void* p) {
     const uint2 a = cload8(p), b = cload8(reinterpret_cast<const char*>(p) + 8);
     return make_uint4(a.x, a.y, b.x, b.y);
 }
+// (a 16-byte `global_load_dwordx4 ... sc1` from inline assembly in place of the two 8-byte atomic loads was tried in round 4: 2 - 5 x
+//  SLOWER per phase and stale rows under the multi-step test -- the agent-scope atomic load is what goes to the memory side.)
 __device__ __forceinline__ unsigned cload4(const void* p) {
     return __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -149,10 +151,11 @@ __device__ __forceinline__ void ln_rows_to_lds(const bf16_t* x, int B, int C, fl
 struct WFrag {
     uint4 w[16];
 };
-__device__ __forceinline__ void gemv_load_w(const bf16_t* __restrict__ W, int K, int n0, bool active, WFrag& f) {
+// (cw = 8: an item of 8 weight rows -- lanes 8 .. 15 of a 16-lane group repeat rows 0 .. 7, their results are ignored)
+__device__ __forceinline__ void gemv_load_w(const bf16_t* __restrict__ W, int K, int n0, bool active, WFrag& f, int cw = 16) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nks = K >> 5;
-    const bf16_t* wrow = W + (int64_t)(n0 + (lane & 15)) * K + (lane >> 4) * 8;
+    const bf16_t* wrow = W + (int64_t)(n0 + ((lane & 15) & (cw - 1))) * K + (lane >> 4) * 8;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int ks = wave + u * DNW;
@@ -499,21 +502,25 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
         }
         stores_done();
         stamp();
-        gemv_load_w(L.wo, C, wq * 16, wq < cb, wf);                    // weights of phase 3, in flight across the barrier
+        // the two C-column projections have C / 16 items: fewer than workgroups at the p6c18 width -- items of 8 columns then, so
+        // that every workgroup streams weights (proj2 at batch 8: 10.0 -> ~6 us per block)
+        const int cw = cb < nwq ? 8 : 16, cbw = C / cw;
+        gemv_load_w(L.wo, C, wq * cw, wq < cbw, wf, cw);               // weights of phase 3, in flight across the barrier
         if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
         stamp();
         // ---- (3) output projection + residual (in place: an element of x is read and written by the same thread pair) -------------
-        for (int blk = wq; blk < cb; blk += nwq) {
-            const int n0 = blk * 16;
-            if (blk != wq) gemv_load_w(L.wo, C, n0, true, wf);
+        const bool eokw = eok && n < cw;
+        for (int blk = wq; blk < cbw; blk += nwq) {
+            const int n0 = blk * cw;
+            if (blk != wq) gemv_load_w(L.wo, C, n0, true, wf, cw);
             float v = gemv16_reduce(gemv_compute<false>(wf, C, p.y + (int64_t)row0 * C, C, nrows), red);
-            if (tid < 256 && L.bo != nullptr) v += L.bo[n0 + n];
+            if (tid < 256 && n < cw && L.bo != nullptr) v += L.bo[n0 + n];
             v = bf16_to_f32(f32_to_bf16(v));                          // (rounded like the separate kernels did)
-            if (eok) {
+            if (eokw) {
                 const unsigned xo = cload4(p.x + mg * C + n0 + (n & ~1));
                 v += (n & 1) ? __uint_as_float(xo & 0xffff0000u) : __uint_as_float(xo << 16);
             }
-            cstore_pair(p.x + mg * C, n0 + n, v, eok);
+            cstore_pair(p.x + mg * C, n0 + n, v, eokw);
         }
         stores_done();
         stamp();
@@ -534,21 +541,21 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
         }
         stores_done();
         stamp();
-        gemv_load_w(L.w2, F, wq * 16, wq < cb, wf);
+        gemv_load_w(L.w2, F, wq * cw, wq < cbw, wf, cw);
         if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
         stamp();
         // ---- (5) second projection + residual --------------------------------------------------------------------------------
-        for (int blk = wq; blk < cb; blk += nwq) {
-            const int n0 = blk * 16;
-            if (blk != wq) gemv_load_w(L.w2, F, n0, true, wf);
+        for (int blk = wq; blk < cbw; blk += nwq) {
+            const int n0 = blk * cw;
+            if (blk != wq) gemv_load_w(L.w2, F, n0, true, wf, cw);
             float v = gemv16_reduce(gemv_compute<false>(wf, F, p.m1 + (int64_t)row0 * F, F, nrows), red);
-            if (tid < 256 && L.b2 != nullptr) v += L.b2[n0 + n];
+            if (tid < 256 && n < cw && L.b2 != nullptr) v += L.b2[n0 + n];
             v = bf16_to_f32(f32_to_bf16(v));
-            if (eok) {
+            if (eokw) {
                 const unsigned xo = cload4(p.x + mg * C + n0 + (n & ~1));
                 v += (n & 1) ? __uint_as_float(xo & 0xffff0000u) : __uint_as_float(xo << 16);
             }
-            cstore_pair(p.x + mg * C, n0 + n, v, eok);
+            cstore_pair(p.x + mg * C, n0 + n, v, eokw);
         }
         stores_done();
         if (l + 1 < p.nlayers) {
