@@ -103,6 +103,7 @@ SIGNATURES = {
     "dvq_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "dvq_layernorm_fwd": (i32, [vp, i32, i64, i64, f32, vp, vp, vp, vp, vp]),
     "dvq_layernorm_bwd": (i32, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, vp]),
+    "dvq_layernorm_bwd_res": (i32, [vp, vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, vp]),
     "dvq_gelu": (i32, [vp, i32, i64, vp, vp]),
     "dvq_gelu_bwd": (i32, [vp, vp, i32, i64, vp, vp]),
     "dvq_softmax_causal": (i32, [vp, i32, i64, i64, i64, i64, f32, vp, vp]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "dvq_decode_stack_status": (i32, [vp, i64, i64, i64, i32, vp]),
     "dvq_decode_stack": (i32, [vp, i32, i64, i64, i32, i64, i64, vp, C.c_float, vp, vp, i32, vp]),
     "dvq_dropout": (i32, [vp, i32, i64, f32, C.c_uint64, vp, vp]),
+    "dvq_dropout_add": (i32, [vp, vp, i32, i64, f32, C.c_uint64, vp, vp]),
     "dvq_fill_f32": (i32, [vp, f32, i64, vp]),
     "dvq_image_desc_bytes": (sz, []),
     "dvq_image_batch_transform": (i32, [vp, vp, vp, vp, i64, i32, i32, vp, vp]),

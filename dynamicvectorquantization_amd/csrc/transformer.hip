@@ -7,6 +7,7 @@
 //   dropout (counter-based hash RNG)        nn.Dropout                      stackgpt.py:31-32,82,146
 // The GEMMs (q/k/v/proj/MLP/heads, QK^T, PV and their backward) run on igemm.hip's kernels.
 #include "dvq_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -55,83 +56,151 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += sum dy * xhat, dbeta += sum dy.
 // Each wave walks a contiguous block of rows and keeps its dgamma / dbeta partials in registers (C <= 4096).
-template <typename T>
+// Round 4: NV = vectors per lane is a template parameter (C = 1024: 2 instead of a fixed 8 -- the accumulators alone were 128
+// registers), a row is read ONCE (x and dy stay in registers between the reduction and the dx pass) and the NEXT row's loads are
+// issued before the current row's reduction: the kernel walked its ~20 rows one dependent round trip after the other (73 us per
+// launch at [20736, 1024] against ~25 us of traffic).
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t rows, int C8,
                                                      const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows_per_wave) {
+                                                     float* __restrict__ dbeta, int rows_per_wave, const T* __restrict__ res,
+                                                     float* __restrict__ part) {
     const int lane = threadIdx.x & 63;
     const int64_t C = (int64_t)C8 * 8;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t r0 = wave * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
-    constexpr int MAXV = 8;                      // up to 8 vectors per lane: C <= 4096
-    float ag[MAXV][8], ab[MAXV][8];
+    float ag[NV][8], ab[NV][8], gam[NV][8];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
+    for (int i = 0; i < NV; ++i) {
+        const int c8 = lane + 64 * i;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ag[i][j] = ab[i][j] = 0.f;
+        for (int j = 0; j < 8; ++j) {
+            ag[i][j] = ab[i][j] = 0.f;
+            gam[i][j] = c8 < C8 ? gamma[c8 * 8 + j] : 0.f;
+        }
+    }
+    typedef typename std::conditional<sizeof(T) == 2, uint4, float4>::type vec_t;      // 8 bf16 / 4 fp32 per 16-byte load
+    constexpr int LPV = sizeof(T) == 2 ? 1 : 2;                                        // 16-byte loads per 8-element vector
+    vec_t xr[NV][LPV], gr[NV][LPV], xn[NV][LPV], gn[NV][LPV];
+    auto fetch = [&](int64_t r, vec_t (&xv)[NV][LPV], vec_t (&gv)[NV][LPV]) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c8 = min(lane + 64 * i, C8 - 1);            // (lanes past the row repeat its last vector: branch-free)
+#pragma unroll
+            for (int l = 0; l < LPV; ++l) {
+                xv[i][l] = *reinterpret_cast<const vec_t*>(x + r * C + c8 * 8 + l * (8 / LPV));
+                gv[i][l] = *reinterpret_cast<const vec_t*>(dy + r * C + c8 * 8 + l * (8 / LPV));
+            }
+        }
+    };
+    auto unpack = [&](const vec_t (&v)[LPV], float (&o)[8]) {
+        if constexpr (sizeof(T) == 2) {
+            const unsigned w[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[2 * j] = __uint_as_float(w[j] << 16);
+                o[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+            }
+        } else {
+            o[0] = v[0].x; o[1] = v[0].y; o[2] = v[0].z; o[3] = v[0].w;
+            o[4] = v[LPV - 1].x; o[5] = v[LPV - 1].y; o[6] = v[LPV - 1].z; o[7] = v[LPV - 1].w;
+        }
+    };
+    if (r0 < r1) fetch(r0, xn, gn);
     for (int64_t r = r0; r < r1; ++r) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int l = 0; l < LPV; ++l) {
+                xr[i][l] = xn[i][l];
+                gr[i][l] = gn[i][l];
+            }
+        if (r + 1 < r1) fetch(r + 1, xn, gn);                      // in flight during this row's arithmetic
         const float mean = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
         float s1 = 0.f, s2 = 0.f;
+        float xh[NV][8], gg[NV][8];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c8 = lane + 64 * i;
-            if (c8 < C8) {
-                float v[8], g[8];
-                load8(x + r * C + c8 * 8, v);
-                load8(dy + r * C + c8 * 8, g);
+        for (int i = 0; i < NV; ++i) {
+            const bool ok = lane + 64 * i < C8;
+            float v[8], g[8];
+            unpack(xr[i], v);
+            unpack(gr[i], g);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xh = (v[j] - mean) * rstd;
-                    const float gg = g[j] * gamma[c8 * 8 + j];
-                    s1 += gg;
-                    s2 = fmaf(gg, xh, s2);
-                    ag[i][j] = fmaf(g[j], xh, ag[i][j]);
-                    ab[i][j] += g[j];
-                }
+            for (int j = 0; j < 8; ++j) {
+                xh[i][j] = (v[j] - mean) * rstd;
+                const float gj = ok ? g[j] : 0.f;
+                gg[i][j] = gj * gam[i][j];
+                s1 += gg[i][j];
+                s2 = fmaf(gg[i][j], xh[i][j], s2);
+                ag[i][j] = fmaf(gj, xh[i][j], ag[i][j]);
+                ab[i][j] += gj;
             }
         }
         s1 = wave_sum(s1) / (float)C;
         s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c8 = lane + 64 * i;
             if (c8 < C8) {
-                float v[8], g[8];
-                load8(x + r * C + c8 * 8, v);
-                load8(dy + r * C + c8 * 8, g);
+                float o[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xh = (v[j] - mean) * rstd;
-                    g[j] = rstd * (g[j] * gamma[c8 * 8 + j] - s1 - xh * s2);
+                for (int j = 0; j < 8; ++j) o[j] = rstd * (gg[i][j] - s1 - xh[i][j] * s2);
+                if (res != nullptr) {                             // the gradient that by-passed the normalisation (residual stream)
+                    float rr[8];
+                    load8(res + r * C + c8 * 8, rr);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += rr[j];
                 }
-                store8(dx + r * C + c8 * 8, g);
+                store8(dx + r * C + c8 * 8, o);
             }
         }
     }
-    // combine the four waves of the workgroup in LDS first: one global atomic per channel and WORKGROUP (cross-XCD fp32
-    // atomics are slow; 2 x C of them per wave dominated this kernel)
+    // combine the four waves of the workgroup through LDS: every wave parks its partials as a row [2 C] (16-byte stores -- the
+    // first version used LDS atomics: 128 conflicting ds_add_f32 per workgroup, ~6 us each time), a thread then adds the four rows
     extern __shared__ __attribute__((aligned(16))) char ln_smem[];
-    float* sg = reinterpret_cast<float*>(ln_smem);          // [C] dgamma partial
-    float* sb = sg + C;                                      // [C] dbeta partial
-    for (int c = threadIdx.x; c < 2 * C; c += 256) sg[c] = 0.f;
-    __syncthreads();
-    if (r0 < r1) {
+    float* sw = reinterpret_cast<float*>(ln_smem) + (threadIdx.x >> 6) * 2 * C;      // [4][2 C]
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c8 = lane + 64 * i;
-            if (c8 < C8)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    atomicAdd(&sg[c8 * 8 + j], ag[i][j]);
-                    atomicAdd(&sb[c8 * 8 + j], ab[i][j]);
-                }
+    for (int i = 0; i < NV; ++i) {
+        const int c8 = lane + 64 * i;
+        if (c8 < C8) {
+            const bool live = r0 < r1;
+            *reinterpret_cast<float4*>(sw + c8 * 8) = live ? make_float4(ag[i][0], ag[i][1], ag[i][2], ag[i][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(sw + c8 * 8 + 4) = live ? make_float4(ag[i][4], ag[i][5], ag[i][6], ag[i][7]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(sw + C + c8 * 8) = live ? make_float4(ab[i][0], ab[i][1], ab[i][2], ab[i][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(sw + C + c8 * 8 + 4) = live ? make_float4(ab[i][4], ab[i][5], ab[i][6], ab[i][7]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        atomicAdd(&dgamma[c], sg[c]);
-        atomicAdd(&dbeta[c], sb[c]);
+    const float* s0 = reinterpret_cast<const float*>(ln_smem);
+    if (part != nullptr) {
+        // per-workgroup partial rows [workgroup][2 C] (plain coalesced stores) for ln_bwd_fold_kernel
+        float* dst = part + (int64_t)blockIdx.x * 2 * C;
+        for (int c = threadIdx.x; c < 2 * C; c += 256) dst[c] = (s0[c] + s0[2 * C + c]) + (s0[4 * C + c] + s0[6 * C + c]);
+    } else {
+        for (int c = threadIdx.x; c < 2 * C; c += 256)
+            atomicAdd(c < C ? &dgamma[c] : &dbeta[c - C], (s0[c] + s0[2 * C + c]) + (s0[4 * C + c] + s0[6 * C + c]));
+    }
+}
+
+// dgamma[c] += sum over workgroups of part[w][c], dbeta[c] += ... part[w][C + c].  Grid (column blocks of 64) x (row blocks of 64):
+// a thread sums 16 partial rows of its column (256-byte coalesced row segments), the four row groups of a block meet in LDS, one
+// atomic per column and block -- nwg / 64 per address instead of nwg.
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* __restrict__ part, int nwg, int C, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int w0 = blockIdx.y * 64 + rg * 16;
+    float a = 0.f;
+    if (col < 2 * C) {
+#pragma unroll 4
+        for (int w = w0; w < min(nwg, w0 + 16); ++w) a += part[(int64_t)w * 2 * C + col];
+    }
+    red[rg][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rg == 0 && col < 2 * C) {
+        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(col < C ? &dgamma[col] : &dbeta[col - C], t);
     }
 }
 
@@ -275,6 +344,25 @@ __global__ __launch_bounds__(256) void embed_scatter_rows_kernel(const int64_t* 
 // ---- cross entropy over V columns of rows with stride ldl; one wave per row --------------------------------------
 // loss_sum += sum over non-ignored rows of (logsumexp - logit[target]); cnt += number of them;
 // dlogits (optional) = (softmax - onehot) * gscale[0]  (0 for ignored rows and for the padding columns >= V)
+// one pair of atomics per WORKGROUP: 2 x 20736 same-address fp32 atomics (one per row) were what a call cost -- 0.35 ms at
+// [20736, 1027] whatever the loads did (rocprofv3 of the stage-2 step, round 4)
+__device__ __forceinline__ void ce_fold(float lsum, float lcnt, float* loss_sum, float* cnt) {
+    __shared__ float part[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        part[wave] = lsum;
+        part[4 + wave] = lcnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float c = part[4] + part[5] + part[6] + part[7];
+        if (c > 0.f) {
+            atomicAdd(loss_sum, part[0] + part[1] + part[2] + part[3]);
+            atomicAdd(cnt, c);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const T* __restrict__ logits, int64_t rows, int V, int ldl,
                                                             const int64_t* __restrict__ target, int64_t ignore_index,
@@ -307,10 +395,73 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const T* __restrict_
             }
         }
     }
-    if (lane == 0 && lcnt > 0.f) {
-        atomicAdd(loss_sum, lsum);
-        atomicAdd(cnt, lcnt);
+    ce_fold(lsum, lcnt, loss_sum, cnt);
+}
+
+// The same with the row held in registers (ldl % 8 == 0, ldl <= 64 * 8 * NV): ONE pass of 16-byte loads per row instead of three
+// passes of 2-byte loads -- 0.36 ms per call at [20736, 1027] against ~17 us of traffic (rocprofv3 of the stage-2 step, round 4).
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void cross_entropy_vec_kernel(const T* __restrict__ logits, int64_t rows, int V, int ldl,
+                                                                const int64_t* __restrict__ target, int64_t ignore_index,
+                                                                float* __restrict__ loss_sum, float* __restrict__ cnt,
+                                                                const float* __restrict__ gscale, T* __restrict__ dlogits) {
+    const int lane = threadIdx.x & 63;
+    const int L8 = ldl >> 3;
+    float lsum = 0.f, lcnt = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const int64_t tg = target[r];
+        const T* row = logits + r * ldl;
+        const bool ign = tg == ignore_index;
+        if (ign && dlogits == nullptr) continue;
+        float v[NV][8];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c8 = lane + 64 * i;
+            if (c8 < L8) load8(row + c8 * 8, v[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (c8 >= L8 || c8 * 8 + j >= V) v[i][j] = -INFINITY;
+                m = fmaxf(m, v[i][j]);
+            }
+        }
+        m = wave_max(m);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[i][j] = __expf(v[i][j] - m);                      // (columns >= V: exp(-inf) = 0)
+                s += v[i][j];
+            }
+        s = wave_sum(s);
+        if (!ign && lane == 0) {
+            lsum += (m + __logf(s)) - ElemIO<T>::load(row + tg);
+            lcnt += 1.f;
+        }
+        if (dlogits != nullptr) {
+            const float g = ign ? 0.f : gscale[0];
+            const float inv = g / s;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c8 = lane + 64 * i;
+                if (c8 < L8) {
+                    float d[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d[j] = v[i][j] * inv - ((int64_t)(c8 * 8 + j) == tg ? g : 0.f);
+                    store8(dlogits + r * ldl + c8 * 8, d);
+                }
+            }
+        }
     }
+    ce_fold(lsum, lcnt, loss_sum, cnt);
+}
+
+// (the unfused sequence stores dropout(a) in the compute dtype before adding: same rounding here)
+template <typename T>
+__device__ __forceinline__ float bf16_round_like(float v) {
+    if constexpr (sizeof(T) == 2) return bf16_to_f32(f32_to_bf16(v));
+    else return v;
 }
 
 // ---- dropout: y = x * keep / (1 - p), keep decided by dvq_hash32 of (seed, element index) (dvq_common.h).  The same call
@@ -331,6 +482,28 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, i
     }
 }
 
+// y = x + dropout(a) (same decisions as dropout_kernel for the same seed and element index); p == 0: a plain add
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_add_kernel(const T* __restrict__ x, const T* __restrict__ a, int64_t n8, float p, unsigned rm,
+                                                          unsigned ra, T* __restrict__ y) {
+    const float scale = 1.f / (1.f - p);
+    const unsigned thr = (unsigned)((double)p * 4294967296.0);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
+        float v[8], w[8];
+        load8(x + e * 8, v);
+        load8(a + e * 8, w);
+        const unsigned long long i0 = (unsigned long long)e * 8;
+        const unsigned base = ra + (unsigned)(i0 >> 32) * 0x9E3779B1u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = w[j];
+            if (thr != 0u) t = dvq_hash32(((unsigned)i0 + j) * rm + base) >= thr ? bf16_round_like<T>(t * scale) : 0.f;
+            v[j] += t;
+        }
+        store8(y + e * 8, v);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -346,13 +519,38 @@ int dvq_layernorm_fwd(const void* x, int dtype, int64_t rows, int64_t C, float e
 
 int dvq_layernorm_bwd(const void* x, const void* dy, int dtype, int64_t rows, int64_t C, const float* mean_rstd, const float* gamma,
                       void* dx, float* dgamma, float* dbeta, dvq_stream_t stream) {
+    return dvq_layernorm_bwd_res(x, dy, nullptr, dtype, rows, C, mean_rstd, gamma, dx, dgamma, dbeta, stream);
+}
+
+int dvq_layernorm_bwd_res(const void* x, const void* dy, const void* dres, int dtype, int64_t rows, int64_t C, const float* mean_rstd,
+                          const float* gamma, void* dx, float* dgamma, float* dbeta, dvq_stream_t stream) {
     DVQ_REQUIRE(x && dy && mean_rstd && gamma && dx && dgamma && dbeta && rows > 0 && C > 0 && C % 8 == 0 && C <= 4096, DVQ_EINVAL,
                 "dvq_layernorm_bwd: bad arguments (C %% 8 == 0, C <= 4096)");
-    int rpw = (int)cdiv64(rows, 1024);                // ~1024 waves (256 workgroups): long runs keep the dgamma/dbeta atomics rare
+    static const int ln_waves = [] {
+        const char* e = getenv("DVQ_LN_BWD_WAVES");
+        return e != nullptr ? atoi(e) : 2048;
+    }();
+    int rpw = (int)cdiv64(rows, ln_waves);            // ~2048 waves (512 workgroups, two per CU): long runs keep the dgamma/dbeta partials few
     if (rpw < 1) rpw = 1;
     const int64_t waves = cdiv64(rows, rpw);
-    DVQ_DISPATCH_DTYPE(dtype, T, ln_bwd_kernel<T><<<dim3((unsigned)cdiv64(waves, 4)), dim3(256), (size_t)(2 * C * sizeof(float)), (hipStream_t)stream>>>(
-                                     (const T*)x, (const T*)dy, rows, (int)(C / 8), mean_rstd, gamma, (T*)dx, dgamma, dbeta, rpw););
+    const int c8 = (int)(C / 8);
+    const dim3 grid((unsigned)cdiv64(waves, 4));
+    const size_t lds = (size_t)(4 * 2 * C * sizeof(float));           // one [2 C] row per wave
+    float* part = nullptr;
+    {
+        int64_t ws_bytes = 0;
+        void* ws = dvq_workspace_stream((hipStream_t)stream, &ws_bytes);
+        if (ws != nullptr && ws_bytes >= (int64_t)grid.x * 2 * C * (int64_t)sizeof(float) && grid.x > 8) part = (float*)ws;
+    }
+#define DVQ_LN_BWD(NVV) \
+    DVQ_DISPATCH_DTYPE(dtype, T, if (lds > 48 * 1024) dvq_ensure_dynamic_lds((const void*)ln_bwd_kernel<T, NVV>, (int)lds); \
+                                 ln_bwd_kernel<T, NVV><<<grid, dim3(256), lds, (hipStream_t)stream>>>( \
+                                     (const T*)x, (const T*)dy, rows, c8, mean_rstd, gamma, (T*)dx, dgamma, dbeta, rpw, (const T*)dres, part);)
+    if (c8 <= 64) { DVQ_LN_BWD(1); } else if (c8 <= 128) { DVQ_LN_BWD(2); } else if (c8 <= 256) { DVQ_LN_BWD(4); } else { DVQ_LN_BWD(8); }
+#undef DVQ_LN_BWD
+    if (part != nullptr)
+        ln_bwd_fold_kernel<<<dim3((unsigned)cdiv64(2 * C, 64), (unsigned)cdiv64(grid.x, 64)), dim3(256), 0, (hipStream_t)stream>>>(
+            part, (int)grid.x, (int)C, dgamma, dbeta);
     DVQ_CHECK_LAUNCH("layernorm_bwd");
     return DVQ_OK;
 }
@@ -417,10 +615,32 @@ int dvq_cross_entropy(const void* logits, int dtype, int64_t rows, int64_t V, in
                       float* loss_sum, float* count, const float* gscale_dev, void* dlogits, dvq_stream_t stream) {
     DVQ_REQUIRE(logits && target && loss_sum && count && rows > 0 && V > 0 && ldl >= V && (dlogits == nullptr || gscale_dev != nullptr),
                 DVQ_EINVAL, "dvq_cross_entropy: bad arguments");
-    DVQ_DISPATCH_DTYPE(dtype, T, cross_entropy_kernel<T><<<dim3(nblk(rows, 4, 1 << 14)), dim3(256), 0, (hipStream_t)stream>>>(
-                                     (const T*)logits, rows, (int)V, (int)ldl, target, ignore_index, loss_sum, count, gscale_dev,
-                                     (T*)dlogits););
+    if (ldl % 8 == 0 && ldl <= 64 * 8 * 4) {
+        if (ldl <= 64 * 8 * 2) {
+            DVQ_DISPATCH_DTYPE(dtype, T, cross_entropy_vec_kernel<T, 2><<<dim3(nblk(rows, 4, 1024)), dim3(256), 0, (hipStream_t)stream>>>(
+                                             (const T*)logits, rows, (int)V, (int)ldl, target, ignore_index, loss_sum, count, gscale_dev,
+                                             (T*)dlogits););
+        } else {
+            DVQ_DISPATCH_DTYPE(dtype, T, cross_entropy_vec_kernel<T, 4><<<dim3(nblk(rows, 4, 1024)), dim3(256), 0, (hipStream_t)stream>>>(
+                                             (const T*)logits, rows, (int)V, (int)ldl, target, ignore_index, loss_sum, count, gscale_dev,
+                                             (T*)dlogits););
+        }
+    } else {
+        DVQ_DISPATCH_DTYPE(dtype, T, cross_entropy_kernel<T><<<dim3(nblk(rows, 4, 1024)), dim3(256), 0, (hipStream_t)stream>>>(
+                                         (const T*)logits, rows, (int)V, (int)ldl, target, ignore_index, loss_sum, count, gscale_dev,
+                                         (T*)dlogits););
+    }
     DVQ_CHECK_LAUNCH("cross_entropy");
+    return DVQ_OK;
+}
+
+int dvq_dropout_add(const void* x, const void* a, int dtype, int64_t n, float p, uint64_t seed, void* y, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && a && y && n > 0 && n % 8 == 0 && p >= 0.f && p < 1.f, DVQ_EINVAL, "dvq_dropout_add: bad arguments");
+    unsigned rm, ra;
+    dvq_dropout_seed(seed, &rm, &ra);
+    DVQ_DISPATCH_DTYPE(dtype, T, dropout_add_kernel<T><<<dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)x, (const T*)a, n / 8, p, rm, ra, (T*)y););
+    DVQ_CHECK_LAUNCH("dropout_add");
     return DVQ_OK;
 }
 

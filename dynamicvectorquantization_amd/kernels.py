@@ -779,11 +779,13 @@ def layernorm_fwd(x2d, gamma, beta, eps=1e-5, want_stats=True):
     return y, mr
 
 
-def layernorm_bwd(x2d, dy, mr, gamma, dgamma, dbeta):
+def layernorm_bwd(x2d, dy, mr, gamma, dgamma, dbeta, dres=None):
+    """dx (+ dres: the gradient of the residual stream that by-passes the normalisation, added in the same pass)"""
     rows, c = x2d.shape
     dx = torch.empty_like(x2d)
-    check(lib().dvq_layernorm_bwd(_p(x2d), _p(dy), dt(x2d), rows, c, _p(mr), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _s()),
-          "dvq_layernorm_bwd")
+    ensure_workspace(x2d.device)          # per-workgroup dgamma / dbeta partials + fold kernel instead of a million atomics
+    check(lib().dvq_layernorm_bwd_res(_p(x2d), _p(dy), _p(dres), dt(x2d), rows, c, _p(mr), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _s()),
+          "dvq_layernorm_bwd_res")
     return dx
 
 
@@ -828,6 +830,13 @@ def cross_entropy(logits2d, v, target, ignore_index, loss_sum, count, gscale=Non
     check(lib().dvq_cross_entropy(_p(logits2d), dt(logits2d), rows, v, ldl, _p(target), ignore_index, _p(loss_sum), _p(count),
                                   _p(gscale), _p(dl), _s()), "dvq_cross_entropy")
     return dl
+
+
+def dropout_add(x, a, p, seed):
+    """x + dropout(a) in one pass (p = 0: x + a); same decisions as dropout(a, p, seed)"""
+    y = torch.empty_like(x)
+    check(lib().dvq_dropout_add(_p(x), _p(a), dt(x), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(y), _s()), "dvq_dropout_add")
+    return y
 
 
 def dropout(x, p, seed):

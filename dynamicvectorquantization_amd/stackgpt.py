@@ -50,6 +50,16 @@ def _drop(x, p, training, tape, key):
     return K.dropout(x, p, seed)
 
 
+def _drop_add(x, a, p, training, tape, key):
+    """x + dropout(a) in one pass (the residual add + resid_drop of a block, stackgpt.py:66-69,91-96 of the reference)"""
+    if not training or p <= 0.0:
+        return K.add(x, a)
+    seed = _next_seed()
+    if tape is not None:
+        tape.s[key] = (p, seed)
+    return K.dropout_add(x, a, p, seed)
+
+
 def _drop_bwd(g, tape, key):
     ps = tape.s.get(key)
     return g if ps is None else K.dropout(g, ps[0], ps[1])
@@ -68,8 +78,9 @@ class LayerNorm(nn.Module):
             tape.s.update(x=x2d, mr=mr)
         return y
 
-    def bwd(self, dy, tape):
-        return K.layernorm_bwd(tape.s["x"], dy, tape.s["mr"], self.weight, _grad_buf(self.weight), _grad_buf(self.bias))
+    def bwd(self, dy, tape, dres=None):
+        """dres: gradient of the residual stream around this normalisation, added to the result in the same pass"""
+        return K.layernorm_bwd(tape.s["x"], dy, tape.s["mr"], self.weight, _grad_buf(self.weight), _grad_buf(self.bias), dres)
 
 
 class CausalSelfAttention(nn.Module):
@@ -89,7 +100,7 @@ class CausalSelfAttention(nn.Module):
         self.n_head = config.n_head
         self._n_unmasked = int(getattr(config, "n_unmasked", 0) or 0)
 
-    def fwd(self, x2d, b, t, tape):
+    def fwd(self, x2d, b, t, tape, resid=None):
         c = x2d.shape[1]
         nh, hs = self.n_head, c // self.n_head
         k = self.key.fwd(x2d, _child(tape, "k"))
@@ -117,10 +128,11 @@ class CausalSelfAttention(nn.Module):
             for h in range(nh):
                 K.gemm_nt(pd[h * t * t:], vt[h * hs * t:], t, hs, t, t, t, c, batch=b, sa=nh * t * t, sb=c * t, sc=t * c, out=yf[h * hs:])
         out = self.proj.fwd(y, _child(tape, "proj"))
-        out = _drop(out, self.resid_drop.p, self.training, tape, "rdrop")
         if tape is not None:
             tape.s.update(q=q, k=k, v=v, p=p, pd=pd, b=b, t=t)
-        return out
+        if resid is not None:            # the block's residual stream: x + resid_drop(proj(..)) in one pass
+            return _drop_add(resid, out, self.resid_drop.p, self.training, tape, "rdrop")
+        return _drop(out, self.resid_drop.p, self.training, tape, "rdrop")
 
     def bwd(self, dout, tape):
         s_ = tape.s
@@ -166,22 +178,21 @@ class Block(nn.Module):
                                  nn.Dropout(config.resid_pdrop))
 
     def fwd(self, x, b, t, tape):
-        a = self.attn.fwd(self.ln1.fwd(x, _child(tape, "ln1")), b, t, _child(tape, "attn"))
-        x1 = K.add(x, a)
+        # (residual adds and resid_drop ride in one kernel each; the backward's residual adds ride in the LayerNorm backward)
+        x1 = self.attn.fwd(self.ln1.fwd(x, _child(tape, "ln1")), b, t, _child(tape, "attn"), resid=x)
         hid = self.mlp[0].fwd(self.ln2.fwd(x1, _child(tape, "ln2")), _child(tape, "fc1"))
         m = self.mlp[2].fwd(K.gelu(hid), _child(tape, "fc2"))
-        m = _drop(m, self.mlp[3].p, self.training, tape, "mdrop")
         if tape is not None:
             tape.s["hid"] = hid
-        return K.add(x1, m)
+        return _drop_add(x1, m, self.mlp[3].p, self.training, tape, "mdrop")
 
     def bwd(self, d, tape):
         dm = _drop_bwd(d, tape, "mdrop")
         dact = self.mlp[2].bwd(dm, tape.child("fc2"))
         dh2 = self.mlp[0].bwd(K.gelu_bwd(tape.s["hid"], dact), tape.child("fc1"))
-        dx1 = K.add(d, self.ln2.bwd(dh2, tape.child("ln2")))
+        dx1 = self.ln2.bwd(dh2, tape.child("ln2"), dres=d)
         dh1 = self.attn.bwd(dx1, tape.child("attn"))
-        return K.add(dx1, self.ln1.bwd(dh1, tape.child("ln1")))
+        return self.ln1.bwd(dh1, tape.child("ln1"), dres=dx1)
 
 
 def _attn_append(attn, x2d, b, n, cache, t0):

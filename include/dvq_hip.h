@@ -361,6 +361,10 @@ int dvq_layernorm_fwd(const void* x, int dtype, int64_t rows, int64_t C, float e
 /* dx written; dgamma / dbeta (fp32 [C]) accumulated into */
 int dvq_layernorm_bwd(const void* x, const void* dy, int dtype, int64_t rows, int64_t C, const float* mean_rstd, const float* gamma,
                       void* dx, float* dgamma, float* dbeta, dvq_stream_t stream);
+/* the same with the gradient that by-passes the normalisation added in: dx = layernorm_bwd(..) + dres (dres may be NULL) -- the
+ * residual stream of a transformer block (stackgpt.py:80-96) without a separate add pass */
+int dvq_layernorm_bwd_res(const void* x, const void* dy, const void* dres, int dtype, int64_t rows, int64_t C, const float* mean_rstd,
+                          const float* gamma, void* dx, float* dgamma, float* dbeta, dvq_stream_t stream);
 /* nn.GELU() (exact erf form) and its backward (x = pre-activation) */
 int dvq_gelu(const void* x, int dtype, int64_t n, void* y, dvq_stream_t stream);
 int dvq_gelu_bwd(const void* x, const void* dy, int dtype, int64_t n, void* dx, dvq_stream_t stream);
@@ -456,6 +460,8 @@ int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C,
                      float eps, void* x, void* scratch, int n_workgroups, dvq_stream_t stream);
 /* nn.Dropout(p) with a counter-based hash RNG: y = x * keep / (1-p); the same (seed) reproduces the mask for the backward */
 int dvq_dropout(const void* x, int dtype, int64_t n, float p, uint64_t seed, void* y, dvq_stream_t stream);
+/* y = x + dropout(a), the decisions of dvq_dropout for the same seed (p = 0: y = x + a): residual add + resid_drop of a block in one pass */
+int dvq_dropout_add(const void* x, const void* a, int dtype, int64_t n, float p, uint64_t seed, void* y, dvq_stream_t stream);
 
 /* AdamW step whose hyper-parameters are read from DEVICE memory (so that a step captured as a hipGraph follows the LR schedule):
  * hyper[8] = {lr / (1 - beta1^t), beta1, beta2, eps, 1 / sqrt(1 - beta2^t), 1 - lr * weight_decay, unused, unused}.
