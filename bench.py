@@ -408,6 +408,7 @@ def main():
         model = instantiate_from_config(full_config(objective)).to(dev)
         model.reuse_generator_forward = bool(args.reuse_forward)
         from dynamicvectorquantization_amd.trainer import reference_learning_rate
+        from dynamicvectorquantization_amd import runtime as rt
         model.learning_rate = reference_learning_rate({"base_learning_rate": 4.5e-6}, world, args.bs)     # train.py:248-257
         model.training_steps, model.steps_per_epoch = 100000, 1000
         model.train()
@@ -469,6 +470,11 @@ def main():
         host = sum(fast) / len(fast) * steps
         barrier()
         dt = time.perf_counter() - t0
+        # host cost of handing ONE step to an idle device (no waiting for queue space): outside the timed region
+        t_idle = time.perf_counter()
+        trainer.train_step(batches[0], SETUP + warmup + steps)
+        host_idle = time.perf_counter() - t_idle
+        torch.cuda.synchronize()
         prof = {}
         if profile:
             # per-kernel HIP-event timing: ONE extra step right after the timed region, launched eagerly (events cannot be
@@ -512,6 +518,9 @@ def main():
                       "allreduce_exposed_ms": exposed,
                       "host_enqueue_all_ms_per_step": round(enqueue_all / steps * 1e3, 2),
                       "segments": trainer._graph["sg"].n_segments() if trainer._graph is not None else 0,
+                      "replay": rt.step_replay_mode() if trainer._graph is not None else None,
+                      "host_ms_one_step_idle_queue": round(host_idle * 1e3, 2),
+                      "launches_main_side_waits": trainer._graph["sg"].launch_counts() if trainer._graph is not None else None,
                       "fine_ratio": float(model._logged.get("train_fine_ratio", torch.tensor(float("nan"))))}
         model._logged = {}
         if world > 1:

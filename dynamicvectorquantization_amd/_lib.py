@@ -63,6 +63,10 @@ SIGNATURES = {
     "dvq_conv2d_dgrad_mask": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
     "dvq_set_workspace": (i32, [vp, i64]),
     "dvq_workspace_release": (i32, [vp]),
+    "dvq_cmdlist_create": (i32, [vp, C.POINTER(vp)]),
+    "dvq_cmdlist_replay": (i32, [vp, vp, vp]),
+    "dvq_cmdlist_info": (i32, [vp, vp]),
+    "dvq_cmdlist_destroy": (i32, [vp]),
     "dvq_halo_trace_read": (i32, [vp, i64]),
     "dvq_permute_dual": (i32, [vp, vp, i64, i32, i32, i32, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]),
     "dvq_permute_dual_back": (i32, [vp, vp, vp, vp, i64, i64, i64, i32, i32, i64, i64, vp, vp]),
@@ -130,6 +134,7 @@ SIGNATURES = {
     "dvq_adamw_dev": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "dvq_set_f32x8": (i32, [vp, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
     "dvq_sample_rows": (i32, [vp, i64, i64, vp, vp]),
+    "dvq_add_uniform": (i32, [vp, i64, f32, vp, vp]),
     "dvq_sample_constrained": (i32, [vp, i32, i64, i64, i64, f32, vp, i64, i64, i64, vp, i64, i64, i64, vp, i32, f32, i32, vp, vp, vp]),
 }
 

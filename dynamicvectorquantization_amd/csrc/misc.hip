@@ -516,6 +516,16 @@ __global__ __launch_bounds__(256) void sample_rows_kernel(int64_t* __restrict__ 
     }
 }
 
+// x[i] += scale * U[0,1) from the same device-resident {seed, counter} state (24-bit uniforms, one hash chain per element)
+__global__ __launch_bounds__(256) void add_uniform_kernel(float* __restrict__ x, int64_t n, float scale, const uint64_t* __restrict__ state) {
+    const uint64_t key = state[0] * 0x9E3779B97F4A7C15ull + state[1] * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
+    const unsigned k0 = (unsigned)key, k1 = (unsigned)(key >> 32);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned h = dvq_hash32(dvq_hash32((unsigned)i ^ k0) + (unsigned)(i >> 32) * 0x9E3779B1u + k1);
+        x[i] += scale * (float)(h >> 8) * (1.f / 16777216.f);
+    }
+}
+
 __global__ void bump_state_kernel(uint64_t* state) {
     if (threadIdx.x == 0) state[1] += 1;
 }
@@ -881,6 +891,15 @@ int dvq_sample_rows(int64_t* out, int64_t k, int64_t n, uint64_t* state, dvq_str
     DVQ_CHECK_LAUNCH("sample_rows");
     bump_state_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(state);
     DVQ_CHECK_LAUNCH("sample_rows_bump");
+    return DVQ_OK;
+}
+
+int dvq_add_uniform(float* x, int64_t n, float scale, uint64_t* state, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && state && n > 0, DVQ_EINVAL, "dvq_add_uniform: bad arguments");
+    add_uniform_kernel<<<dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream>>>(x, n, scale, state);
+    DVQ_CHECK_LAUNCH("add_uniform");
+    bump_state_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(state);
+    DVQ_CHECK_LAUNCH("add_uniform_bump");
     return DVQ_OK;
 }
 

@@ -467,6 +467,40 @@ def workspace_release(stream):
         lib().dvq_workspace_release(C.c_void_p(int(stream.cuda_stream)))
 
 
+def copy_kernel_(dst, src):
+    """dst <- src through an elementwise KERNEL.  torch's copy_ between contiguous same-dtype tensors is a hipMemcpyAsync, which a
+    recorded step keeps as a 1-D memcpy node -- the one node kind a launch list (csrc/cmdlist.hip) cannot re-issue.  x * 1 is exact."""
+    return torch.mul(src, 1, out=dst)
+
+
+class CmdList:
+    """launch list of one captured segment (csrc/cmdlist.hip); `graph` is the torch.cuda.CUDAGraph(keep_graph=True) whose nodes
+    own the argument blocks -- kept alive here, released after the list"""
+
+    def __init__(self, graph):
+        self.graph = graph
+        h = C.c_void_p()
+        check(lib().dvq_cmdlist_create(C.c_void_p(int(graph.raw_cuda_graph())), C.byref(h)), "dvq_cmdlist_create")
+        self.handle = h
+        info = (C.c_int64 * 4)()
+        check(lib().dvq_cmdlist_info(h, info), "dvq_cmdlist_info")
+        self.kernels, self.side_kernels, self.waits = int(info[0]), int(info[1]), int(info[2])
+        self.other, self.side_open = int(info[3]) & 0xffffffff, bool(int(info[3]) >> 32)
+
+    def replay(self, main, side):
+        check(lib().dvq_cmdlist_replay(self.handle, C.c_void_p(int(main.cuda_stream)), C.c_void_p(int(side.cuda_stream))),
+              "dvq_cmdlist_replay")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().dvq_cmdlist_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+        self.graph = None
+
+
 def ensure_workspace(device):
     """register the process-wide scratch buffer of libdvq_hip (kept alive here)"""
     device = torch.device(device)
@@ -963,6 +997,13 @@ def sample_rows(k, n, state):
     out = torch.empty(k, dtype=torch.int64, device=state.device)
     check(lib().dvq_sample_rows(_p(out), k, n, _p(state), _s()), "dvq_sample_rows")
     return out
+
+
+def add_uniform_(x, scale, state):
+    """x (fp32, contiguous) += scale * U[0,1) drawn from the device-resident generator state (replay-safe)"""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    check(lib().dvq_add_uniform(_p(x), x.numel(), float(scale), _p(state), _s()), "dvq_add_uniform")
+    return x
 
 
 def attn_decode(q, kcache, vcache, n_head, t, scale):

@@ -204,11 +204,11 @@ class Linear(nn.Module):
         b = self.bias.detach() if self.bias is not None else None
         if self.out_p != self.out_features:
             wp = torch.zeros(self.out_p, self.in_features, dtype=dtype, device=w.device)
-            wp[: self.out_features].copy_(w)
+            K.copy_kernel_(wp[: self.out_features], w)
             w = wp
             if b is not None:
                 bp = torch.zeros(self.out_p, dtype=torch.float32, device=w.device)
-                bp[: self.out_features].copy_(b)
+                K.copy_kernel_(bp[: self.out_features], b)
                 b = bp
         return w, b
 
@@ -360,7 +360,7 @@ class Conv2d(HipModule):
         if ent["bias"] is not None and ent.get("bias_epoch") != ep:
             # zero-padded bias copy (Cout not a multiple of the vector width): tracked on its own -- the multi-tensor
             # re-pack triggered by ANOTHER conv refreshes this module's weights but not this small copy
-            ent["bias"][: self.out_channels] = self.bias.detach()
+            K.copy_kernel_(ent["bias"][: self.out_channels], self.bias.detach())
             ent["bias_epoch"] = ep
         bias = ent["bias"] if ent["bias"] is not None else (self.bias.detach() if self.bias is not None else None)
         return ent["w"], ent["wt"], bias

@@ -490,7 +490,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
                 budget_loss = self.budget_loss(gate=gate)
                 loss = loss + budget_loss
                 log["{}_budget_loss".format(split)] = budget_loss.detach().mean()
-            log.update({"{}_total_loss".format(split): loss.clone().detach().mean(),
+            log.update({"{}_total_loss".format(split): loss.detach().mean(),
                         "{}_quant_loss".format(split): codebook_loss.detach().mean(),
                         "{}_nll_loss".format(split): parts["nll"],
                         "{}_rec_loss".format(split): parts["nll"],
@@ -504,7 +504,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
             want_grad = torch.is_grad_enabled() and len(params) > 0
             d_loss, m_real, m_fake = _DiscLossFn.apply(self, want_grad, x, reconstructions.detach().contiguous().float(),
                                                        disc_factor, *params)
-            log = {"{}_disc_loss".format(split): d_loss.clone().detach().mean(),
+            log = {"{}_disc_loss".format(split): d_loss.detach().mean(),
                    "{}_logits_real".format(split): m_real,
                    "{}_logits_fake".format(split): m_fake}
             return d_loss, log

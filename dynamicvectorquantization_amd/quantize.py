@@ -118,10 +118,9 @@ class VQEmbedding(nn.Embedding):
                 src = K.cast(vectors, torch.float32)
                 if n < k:
                     # _tile_with_noise (quantize2_mask.py:57-64): repeat rows and add U(0,1) * 0.01/sqrt(D);
-                    # only reachable with tiny batches, host-side torch on a [K,D]-sized tensor
+                    # only reachable with tiny batches; the noise comes from the module's device generator (replay-safe)
                     reps = (k + n - 1) // n
-                    src = src.repeat(reps, 1)
-                    src = src + torch.rand_like(src) * (0.01 / np.sqrt(d))
+                    src = K.add_uniform_(src.repeat(reps, 1), 0.01 / np.sqrt(d), self._rng(vectors.device))
                     n = src.shape[0]
                 if self.restart_perm is not None:
                     perm = self.restart_perm.to(vectors.device)[:k]
@@ -198,7 +197,9 @@ class VectorQuantize2(nn.Module):
         xq, loss_sum = K.vq_gather_loss(flat, cbk._codebook(), idx, mflat)
         if cbk.training and cbk.ema:
             if tape is not None:
-                tape.s["cb_old"] = cbk._codebook().clone()
+                # a kernel copy: torch's clone() of a contiguous tensor is a hipMemcpy node in a recorded step, and launch lists
+                # (csrc/cmdlist.hip) re-issue kernel nodes only.  x * 1 is exact for every value
+                tape.s["cb_old"] = cbk._codebook().mul(1)
             cbk._update_buffers(flat, idx)
         n_el = flat.numel()
         loss = (loss_sum * ((1.0 + self.beta) / n_el)).to(torch.float32).reshape(())

@@ -147,6 +147,12 @@ def graph_break(fn):
     return _capture.brk(fn)
 
 
+def step_replay_mode() -> str:
+    """how a recorded segment is replayed: "list" = csrc/cmdlist.hip re-issues the captured launches on the current + side stream
+    (default: the device sees an eager step's queues); "graph" = hipGraphLaunch of the instantiated capture (DVQ_STEP_REPLAY)"""
+    return os.environ.get("DVQ_STEP_REPLAY", "list")
+
+
 class StepGraph:
     """A recorded training step: hipGraph segments interleaved with eager callables, sharing one private memory pool
     (segments are replayed in capture order, never concurrently, so blocks freed in one segment may be reused by the next)."""
@@ -176,7 +182,8 @@ class StepGraph:
     def _begin(self):
         self._dbg("begin segment", len(self.items))
         self._names = []
-        g = torch.cuda.CUDAGraph()
+        # launch-list replay (default) reads the captured nodes itself and never instantiates an executable graph
+        g = torch.cuda.CUDAGraph(keep_graph=True) if step_replay_mode() == "list" else torch.cuda.CUDAGraph()
         if _SEPARATE_POOLS:
             self.pool = torch.cuda.graph_pool_handle()
         g.capture_begin(pool=self.pool, capture_error_mode=self._mode)
@@ -187,7 +194,18 @@ class StepGraph:
         self._g.capture_end()
         if _GRAPH_DEBUG:
             self._dbg("segment", len(self.items), "calls:", " ".join(getattr(self, "_names", [])))
-        self.items.append(("graph", self._g))
+        if step_replay_mode() == "list":
+            from . import kernels as K
+            from ._lib import DvqError
+            try:
+                self.items.append(("list", K.CmdList(self._g)))
+            except DvqError as e:
+                # a segment with nodes the list cannot re-issue (a torch memcpy): this segment replays through hipGraphLaunch
+                import warnings
+                warnings.warn(f"StepGraph: segment {len(self.items)} replays as a hipGraph ({e})")
+                self.items.append(("graph", self._g))
+        else:
+            self.items.append(("graph", self._g))
         self._g = None
 
     def brk(self, fn):
@@ -253,6 +271,8 @@ class StepGraph:
         for i, (kind, it) in enumerate(self.items):
             if kind == "graph":
                 it.replay()
+            elif kind == "list":
+                it.replay(torch.cuda.current_stream(self.device), side_stream(self.device)["stream"])
             else:
                 it()
             if _GRAPH_DEBUG:                     # localise a faulting segment: finish every item before the next one
@@ -260,7 +280,12 @@ class StepGraph:
                 self._dbg("replayed item", i, kind)
 
     def n_segments(self):
-        return sum(1 for k, _ in self.items if k == "graph")
+        return sum(1 for k, _ in self.items if k != "eager")
+
+    def launch_counts(self):
+        """(kernel launches, of those on the side stream, cross-stream waits) of one replay; None for hipGraph segments"""
+        ls = [it for k, it in self.items if k == "list"]
+        return (sum(l.kernels for l in ls), sum(l.side_kernels for l in ls), sum(l.waits for l in ls)) if ls else None
 
     def __del__(self):
         # the recorded kernels hold the address of this stream's scratch slot (csrc/misc.hip: dvq_workspace_stream pins it while
@@ -298,9 +323,10 @@ class side_wgrad:
         self.prev = _side_on
         # eagerly launched steps only: a hipGraph replay of the two-stream capture ran no faster than the single-stream one on
         # ROCm 7.2 (179.9 vs 179.1 ms, with 39 ms of host time per launch; DEBUG_HIP_FORCE_GRAPH_QUEUES / packet capture made no
-        # difference), while eager steps gain 2.5 % (174.8 vs 179.3 ms); DVQ_SIDE_WGRAD=graph forces it inside captures too
+        # difference), while eager steps gain 2.5 % (174.8 vs 179.3 ms); DVQ_SIDE_WGRAD=graph forces it inside captures too.
+        # A capture that is replayed as a launch list keeps the fork: the list issues the side chain on the side stream.
         mode = os.environ.get("DVQ_SIDE_WGRAD", "1")
-        _side_on = mode == "graph" or (mode == "1" and not capturing())
+        _side_on = mode == "graph" or (mode == "1" and (not capturing() or step_replay_mode() == "list"))
         return self
 
     def __exit__(self, *exc):

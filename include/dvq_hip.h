@@ -36,6 +36,7 @@ extern "C" {
 #endif
 
 typedef void* dvq_stream_t; /* hipStream_t */
+typedef void* dvq_cmdlist_t; /* launch list built from a captured hipGraph_t (dvq_cmdlist_create) */
 
 enum { DVQ_F32 = 0, DVQ_BF16 = 1 };
 enum { DVQ_OK = 0, DVQ_EINVAL = -1, DVQ_ESHAPE = -2, DVQ_EARCH = -3, DVQ_ELAUNCH = -4, DVQ_EWORKSPACE = -5 };
@@ -252,6 +253,20 @@ int dvq_gemm_tn_colsum(const void* A, const void* B, float* C, float* colsum, in
  * least recently used first; a stream that finds no slot gets none (atomics). */
 int dvq_set_workspace(void* ptr, int64_t bytes);
 int dvq_workspace_release(dvq_stream_t stream);
+
+/* ---- launch lists: a recorded step re-issued as plain stream launches -----------------------------------------------
+ * The training step of the reference is driven by pytorch-lightning, one Python call per operator per step (train.py:233-262,
+ * models/stage1_dynamic/dqvae_dual_entropy.py:123-150); here the step's launch sequence is static, is recorded once by HIP stream
+ * capture, and is replayed from C.  dvq_cmdlist_create walks a captured hipGraph_t (kernel / memset / memcpy / empty nodes) into
+ * a flat operation array: nodes keep their capture order, the fork / join structure of a two-stream capture is mapped onto two
+ * streams with event pairs at the cross-stream edges.  dvq_cmdlist_replay issues the array with hipLaunchKernel on (main, side):
+ * the device sees what an eagerly launched step puts in its queues (hipGraphLaunch adds ~7 % on a 2400-kernel step on ROCm 7.2).
+ * The list borrows the argument blocks held by the graph's nodes: destroy the list before the graph.
+ * dvq_cmdlist_info: {kernel launches, of those on the side stream, event waits, memset + memcpy operations | side_open << 32}. */
+int dvq_cmdlist_create(void* hip_graph, dvq_cmdlist_t* out);
+int dvq_cmdlist_replay(dvq_cmdlist_t list, dvq_stream_t main_stream, dvq_stream_t side_stream);
+int dvq_cmdlist_info(dvq_cmdlist_t list, int64_t* info4);
+int dvq_cmdlist_destroy(dvq_cmdlist_t list);
 /* diagnostics (DVQ_HALO_DBG=6): per workgroup of the LAST 3x3 halo-conv launch {CU key | (time before the final store drain) << 16,
  * start, end of the main loop, end, tile staged, tile stored} in 10-ns ticks; dst holds max_records x 6 uint64.  Synchronises. */
 int dvq_halo_trace_read(unsigned long long* dst, int64_t max_records);
@@ -473,6 +488,9 @@ int dvq_set_f32x8(float* dst, float v0, float v1, float v2, float v3, float v4, 
 /* k distinct pseudo-random indices in [0, n) = prefix of a keyed Feistel permutation (replaces torch.randperm(n)[:k] of
  * quantize2_mask.py:93-98); state = uint64[2] {seed, counter} in device memory, the counter is advanced on the stream. */
 int dvq_sample_rows(int64_t* out, int64_t k, int64_t n, uint64_t* state, dvq_stream_t stream);
+/* x[i] += scale * U[0,1), fp32, same state convention (the noise of _tile_with_noise, quantize2_mask.py:57-64: torch.rand_like
+ * under stream capture depends on torch's graph executor rewriting the Philox offset, which a launch-list replay does not run) */
+int dvq_add_uniform(float* x, int64_t n, float scale, uint64_t* state, dvq_stream_t stream);
 
 int dvq_fill_f32(float* p, float v, int64_t n, dvq_stream_t stream);
 
