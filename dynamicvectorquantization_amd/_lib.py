@@ -116,8 +116,9 @@ SIGNATURES = {
     "dvq_cross_entropy": (i32, [vp, i32, i64, i64, i64, vp, i64, vp, vp, vp, vp, vp]),
     "dvq_attn_decode": (i32, [vp, vp, vp, i32, i64, i64, i64, i64, i64, f32, vp, vp]),
     "dvq_attn_causal_scratch_bytes": (i64, [i64, i64, i32, i32, i32]),
-    "dvq_attn_causal_fwd": (i32, [vp, vp, vp, i32, i64, i64, i32, i32, f32, f32, C.c_uint64, vp, vp, vp, vp]),
-    "dvq_attn_causal_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i64, i32, i32, f32, f32, C.c_uint64, vp, vp, vp, vp, vp]),
+    "dvq_attn_causal_mask_bytes": (i64, [i64, i64, i32]),
+    "dvq_attn_causal_fwd": (i32, [vp, vp, vp, i32, i64, i64, i32, i32, f32, f32, C.c_uint64, vp, vp, vp, vp, vp]),
+    "dvq_attn_causal_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i64, i32, i32, f32, f32, C.c_uint64, vp, vp, vp, vp, vp, vp]),
     "dvq_attn_full_scratch_bytes": (i64, [i64, i64, i32, i32]),
     "dvq_attn_full_fwd": (i32, [vp, vp, vp, i32, i64, i64, i32, f32, vp, vp, vp, vp]),
     "dvq_attn_full_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i64, i32, f32, vp, vp, vp, vp, vp]),

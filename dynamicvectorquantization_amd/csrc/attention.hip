@@ -21,6 +21,8 @@
 // other sequence axis together: each 32-row operand tile is fetched from global memory ONCE per workgroup into registers
 // (issued one tile ahead), published through double-buffered LDS (one barrier per tile) and read by all four waves as MFMA
 // fragments (padded rows: conflict-free ds_read_b128 / ds_read_b64).  Waves beyond their causal range idle for <= 3 tiles.
+#include <type_traits>
+
 #include "dvq_common.h"
 
 namespace {
@@ -39,7 +41,22 @@ struct AttnParams {
     float scale;                             // 1 / sqrt(hs)
     float inv_keep;                          // 1 / (1 - p)
     unsigned thr, rm, ra;                    // dropout: keep iff dvq_hash32(idx * rm + ra) >= thr (thr == 0: no dropout)
+    int dbg;                                 // DVQ_ATTN_DBG (timing experiments on the dQ kernel, results wrong): 1 no tile refills,
+                                             //    2 no element-wise pass, 4 no second GEMM, 8 no first GEMMs
+    unsigned long long* mask;                // optional keep-decision words, [B * nh][nqt][nkt][16] (see drop_tile): written by the
+                                             //    forward, read by the backward kernels instead of hashing every element again
 };
+
+// Dropout decisions of one 32 x 32 score tile as 16 lane masks.  The forward (and dQ) kernels hold the tile as lane = (query l31,
+// half), register r = key (r & 3) + 8 (r >> 2) + 4 half; word r of a tile is the wave-wide ballot of "keep" for register r, i.e.
+// bit (l31 + 32 half) of word r = keep(query l31, key crow(r, half)).  dQ has the same lane / register layout: word r, read with
+// scalar loads, IS its select mask for register r (v_cndmask with an SGPR pair: no VALU work per element besides the select).
+// dK / dV hold the tile transposed (lane = key, registers = queries): lane (key kl, half h') needs keep(query crow(r', h'), kl)
+// = bit crow(r', h') of the 32-bit half-word (kl >> 2 & 1) of word (kl & 3) + 4 (kl >> 3): ONE 4-byte load per lane and tile, then
+// constant bit positions after a shift by 4 h'.  The hash costs 3 quarter-rate integer multiplies + 7 ALU operations per element
+// (~19 issue slots against 4 for the exponential): taken once per element in the forward instead of four times per step, the three
+// backward kernels drop from ~31 to ~13 VALU slots per score element (they were VALU-bound 2.5 : 1 against their MFMAs).
+__device__ __forceinline__ int64_t drop_tile(int bh, int nt, int qt, int kt) { return (((int64_t)bh * nt + qt) * nt + kt) * 16; }
 
 union Frag {
     uint4 u;
@@ -238,11 +255,20 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void attn_fwd_kernel(AttnPa
                     for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
             }
             if (p.thr != 0) {
+                unsigned mlo = 0, mhi = 0;                       // lane r collects the ballot of register r (v_writelane from the SGPR pair)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned idx = idx_row + (unsigned)(k0 + crow(r, half));
-                    s[r] = dvq_hash32(idx * p.rm + p.ra) >= p.thr ? s[r] * p.inv_keep : 0.f;
+                    const bool keep = dvq_hash32(idx * p.rm + p.ra) >= p.thr;
+                    if (p.mask != nullptr) {
+                        const unsigned long long m = __ballot(keep);
+                        mlo = __builtin_amdgcn_writelane((unsigned)m, r, mlo);
+                        mhi = __builtin_amdgcn_writelane((unsigned)(m >> 32), r, mhi);
+                    }
+                    s[r] = keep ? s[r] * p.inv_keep : 0.f;
                 }
+                if (p.mask != nullptr && lane < 16)
+                    *reinterpret_cast<uint2*>(p.mask + drop_tile(bh, nqt, qt, kt) + lane) = make_uint2(mlo, mhi);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -289,7 +315,7 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(AttnParams p, int64_t 
 // ------------------------------------------------------------------------------------------------------------------
 // backward, dQ: one wave per 32 queries (same walk as the forward); LDS stage = K, V (row-major) and K^T tiles
 // ------------------------------------------------------------------------------------------------------------------
-template <int HS>
+template <int HS, bool MASKED = false>
 __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void attn_bwd_dq_kernel(AttnParams p) {
     using G = Geo<HS>;
     constexpr int NS = HS / 16, NM = HS / 32, STAGE = 2 * G::RTILE + G::CTILE;
@@ -338,7 +364,7 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void attn_bwd_dq_kernel(Att
         const char* kl = smem + (kt & 1) * STAGE;
         const char* vl = kl + G::RTILE;
         const char* tl = kl + 2 * G::RTILE;
-        const bool more = kt < kt_last;
+        const bool more = kt < kt_last && !(p.dbg & 1);
         if (more) {
             gload_rows<HS>(kbase, rowbase, 32 * (kt + 1), T, C, tid, rk);
             gload_rows<HS>(vbase, rowbase, 32 * (kt + 1), T, C, tid, rv);
@@ -346,27 +372,56 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void attn_bwd_dq_kernel(Att
         }
         if (active && (!p.causal || kt <= qt)) {
             const int k0 = kt * 32;
-            f32x16 s = zero16(), dp = zero16();
+            unsigned long long mk[16];                           // the tile's 16 select masks: scalar loads, issued ahead of the first GEMMs
+            if constexpr (MASKED) {
+                const unsigned long long* mw = p.mask + drop_tile(bh, nqt, __builtin_amdgcn_readfirstlane(qt), kt);
 #pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                s = MFMA(frag_r<HS>(kl, l31, half, st), qf[st], s);
-                dp = MFMA(frag_r<HS>(vl, l31, half, st), dof[st], dp);
+                for (int r = 0; r < 16; ++r) mk[r] = mw[r];
+            }
+            f32x16 s = zero16(), dp = zero16();
+            if (!(p.dbg & 8)) {
+#pragma unroll
+                for (int st = 0; st < NS; ++st) {
+                    s = MFMA(frag_r<HS>(kl, l31, half, st), qf[st], s);
+                    dp = MFMA(frag_r<HS>(vl, l31, half, st), dof[st], dp);
+                }
             }
             const bool diag = p.causal && kt == qt;
+            auto elementwise = [&](auto diag_c) {
+                constexpr bool DIAG = decltype(diag_c)::value, MASK = MASKED;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + crow(r, half);
-                const bool valid = !diag || (key <= qrow && key < T);
-                const float pr = valid ? __builtin_amdgcn_exp2f(s[r] * c2 - lq) : 0.f;
-                float g = dp[r];
-                if (p.thr != 0) g = dvq_hash32((idx_row + (unsigned)key) * p.rm + p.ra) >= p.thr ? g * p.inv_keep : 0.f;
-                s[r] = pr * (g - dq_);                            // d loss / d (scaled score)
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + crow(r, half);
+                    float pr = __builtin_amdgcn_exp2f(s[r] * c2 - lq);
+                    if constexpr (DIAG) pr = (key <= qrow && key < T) ? pr : 0.f;
+                    float g = dp[r];
+                    if constexpr (MASK) {
+                        g = __builtin_amdgcn_inverse_ballot_w64(mk[r]) ? g * p.inv_keep : 0.f;
+                    } else {
+                        if (p.thr != 0) g = dvq_hash32((idx_row + (unsigned)key) * p.rm + p.ra) >= p.thr ? g * p.inv_keep : 0.f;
+                    }
+                    s[r] = pr * (g - dq_);                        // d loss / d (scaled score)
+                }
+            };
+            if (p.dbg & 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] += dp[r];
+            } else if constexpr (HS > 128) {
+                elementwise(std::false_type{});                  // full attention only (T % 32 == 0): no diagonal tiles
+            } else {
+                if (diag) elementwise(std::true_type{});
+                else elementwise(std::false_type{});
             }
+            if (p.dbg & 4) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 df = pack8(s, s2);
+                for (int r = 0; r < 16; ++r) acc[0][r] += s[r];
+            } else {
 #pragma unroll
-                for (int mt = 0; mt < NM; ++mt) acc[mt] = MFMA(frag_c<HS>(tl, l31, half, mt, s2), df, acc[mt]);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 df = pack8(s, s2);
+#pragma unroll
+                    for (int mt = 0; mt < NM; ++mt) acc[mt] = MFMA(frag_c<HS>(tl, l31, half, mt, s2), df, acc[mt]);
+                }
             }
         }
         if (more) {
@@ -388,7 +443,7 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void attn_bwd_dq_kernel(Att
 // MODE 0: dK and dV together; 1: dV only; 2: dK only.  Head size 256 runs as two launches (1, then 2): 2 x 128 accumulator
 // registers next to 2 x 64 resident operand registers and the staged tiles do not fit one wave (measured: 1220 B/lane of
 // scratch); the score tile is then computed by both launches (1.25x the flops of this kernel).
-template <int HS, int MODE = 0>
+template <int HS, int MODE = 0, bool MASKED = false>
 __global__ __launch_bounds__(256, (HS == 64 || (HS == 128 && MODE != 0)) ? 2 : 1) void attn_bwd_dkv_kernel(AttnParams p) {
     constexpr bool DO_DV = MODE != 2, DO_DK = MODE != 1;
     using G = Geo<HS>;
@@ -436,7 +491,14 @@ __global__ __launch_bounds__(256, (HS == 64 || (HS == 128 && MODE != 0)) ? 2 : 1
     if constexpr (DO_DK) swrite_cols<HS>(smem + 2 * G::RTILE, tid, rqt);
     if constexpr (DO_DV) swrite_cols<HS>(smem + 2 * G::RTILE + G::CTILE, tid, rdt);
     __syncthreads();
+    constexpr bool masked = MASKED;
+    // keep bits of this lane's key over a tile's 32 queries (see drop_tile): one 4-byte load per tile, fetched one tile ahead
+    const unsigned* mlane = reinterpret_cast<const unsigned*>(p.mask) + 2 * ((l31 & 3) + 4 * (l31 >> 3)) + ((l31 >> 2) & 1);
+    auto mask_word = [&](int qt_) { return masked && active && (!p.causal || qt_ >= kt) ? mlane[2 * drop_tile(bh, nt, qt_, kt)] : 0u; };
+    unsigned mnext = mask_word(qt_first);
     for (int qt = qt_first; qt < nt; ++qt) {
+        const unsigned mword = mnext >> (4 * half);              // query 8 g + 4 half + i of the tile is bit 8 g + i
+        if (qt + 1 < nt) mnext = mask_word(qt + 1);
         const char* ql = smem + ((qt - qt_first) & 1) * STAGE;
         const char* dl = ql + G::RTILE;
         const char* qtl = ql + 2 * G::RTILE;
@@ -459,47 +521,63 @@ __global__ __launch_bounds__(256, (HS == 64 || (HS == 128 && MODE != 0)) ? 2 : 1
             // element-wise pass and second GEMMs in two halves (registers 8 s2 .. 8 s2 + 7 = two groups of 4 consecutive
             // queries each): only 8 probabilities / 8 score gradients and 8 per-query statistics are live at a time
             const bool diag = p.causal && qt == kt;
+            const bool edge = diag || q0 + 32 > T;               // tiles that need per-element validity tests
+            auto second = [&](auto edge_c) {
+                constexpr bool EDGE = decltype(edge_c)::value, MASK = MASKED;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                Frag pf, df;
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    Frag pf, df;
 #pragma unroll
-                for (int gg = 0; gg < 2; ++gg) {
-                    const int g = 2 * s2 + gg;
-                    const int qq = q0 + 8 * g + 4 * half;
-                    const bool ok = qq < T;                       // T % 4 == 0: a group is entirely in or out
-                    const float4 l4 = ok ? *reinterpret_cast<const float4*>(lsep + qq) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float4 d4 = ok ? *reinterpret_cast<const float4*>(dsp + qq) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq_[4] = {d4.x, d4.y, d4.z, d4.w};
-                    float pk[4], ds[4];
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int g = 2 * s2 + gg;
+                        const int qq = q0 + 8 * g + 4 * half;
+                        const bool ok = !EDGE || qq < T;              // T % 4 == 0: a group is entirely in or out
+                        const float4 l4 = ok ? *reinterpret_cast<const float4*>(lsep + qq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 d4 = ok ? *reinterpret_cast<const float4*>(dsp + qq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq_[4] = {d4.x, d4.y, d4.z, d4.w};
+                        float pk[4], ds[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 4 * g + i;
-                        const int query = qq + i;
-                        const bool valid = ok && (!diag || krow <= query);
-                        const float pr = valid ? __builtin_amdgcn_exp2f(s[r] * c2 - lq[i] * LOG2E) : 0.f;
-                        float gr = dp[r];
-                        pk[i] = pr;
-                        if (p.thr != 0) {
-                            const unsigned idx = (unsigned)(((int64_t)bh * T + query) * T) + (unsigned)krow;
-                            const bool keep = dvq_hash32(idx * p.rm + p.ra) >= p.thr;
-                            gr = keep ? gr * p.inv_keep : 0.f;
-                            pk[i] = keep ? pr * p.inv_keep : 0.f;
+                        for (int i = 0; i < 4; ++i) {
+                            const int r = 4 * g + i;
+                            const int query = qq + i;
+                            float pr = __builtin_amdgcn_exp2f(s[r] * c2 - lq[i] * LOG2E);
+                            if constexpr (EDGE) pr = (ok && (!diag || krow <= query)) ? pr : 0.f;
+                            float gr = dp[r];
+                            pk[i] = pr;
+                            if constexpr (MASK) {
+                                const bool keep = (mword >> (8 * g + i)) & 1u;
+                                gr = keep ? gr * p.inv_keep : 0.f;
+                                pk[i] = keep ? pr * p.inv_keep : 0.f;
+                            } else {
+                                if (p.thr != 0) {
+                                    const unsigned idx = (unsigned)(((int64_t)bh * T + query) * T) + (unsigned)krow;
+                                    const bool keep = dvq_hash32(idx * p.rm + p.ra) >= p.thr;
+                                    gr = keep ? gr * p.inv_keep : 0.f;
+                                    pk[i] = keep ? pr * p.inv_keep : 0.f;
+                                }
+                            }
+                            ds[i] = pr * (gr - dq_[i]);           // d loss / d (scaled score): dK;  pk: dropped-out probabilities: dV
                         }
-                        ds[i] = pr * (gr - dq_[i]);               // d loss / d (scaled score): dK;  pk: dropped-out probabilities: dV
+                        const unsigned p0 = pack_bf16x2(pk[0], pk[1]), p1 = pack_bf16x2(pk[2], pk[3]);
+                        const unsigned d0 = pack_bf16x2(ds[0], ds[1]), d1 = pack_bf16x2(ds[2], ds[3]);
+                        if (gg == 0) {
+                            pf.u.x = p0; pf.u.y = p1; df.u.x = d0; df.u.y = d1;
+                        } else {
+                            pf.u.z = p0; pf.u.w = p1; df.u.z = d0; df.u.w = d1;
+                        }
                     }
-                    const unsigned p0 = pack_bf16x2(pk[0], pk[1]), p1 = pack_bf16x2(pk[2], pk[3]);
-                    const unsigned d0 = pack_bf16x2(ds[0], ds[1]), d1 = pack_bf16x2(ds[2], ds[3]);
-                    if (gg == 0) {
-                        pf.u.x = p0; pf.u.y = p1; df.u.x = d0; df.u.y = d1;
-                    } else {
-                        pf.u.z = p0; pf.u.w = p1; df.u.z = d0; df.u.w = d1;
-                    }
-                }
 #pragma unroll
-                for (int mt = 0; mt < NM; ++mt) {
-                    if constexpr (DO_DV) dv[mt] = MFMA(frag_c<HS>(dtl, l31, half, mt, s2), pf.v, dv[mt]);
-                    if constexpr (DO_DK) dk[mt] = MFMA(frag_c<HS>(qtl, l31, half, mt, s2), df.v, dk[mt]);
+                    for (int mt = 0; mt < NM; ++mt) {
+                        if constexpr (DO_DV) dv[mt] = MFMA(frag_c<HS>(dtl, l31, half, mt, s2), pf.v, dv[mt]);
+                        if constexpr (DO_DK) dk[mt] = MFMA(frag_c<HS>(qtl, l31, half, mt, s2), df.v, dk[mt]);
+                    }
                 }
+            };
+            if constexpr (HS > 128) {
+                second(std::false_type{});                       // full attention only (T % 32 == 0): no diagonal / ragged tiles
+            } else {
+                if (edge) second(std::true_type{});
+                else second(std::false_type{});
             }
         }
         if (more) {
@@ -533,30 +611,37 @@ static bool split128_env() {
     return v;
 }
 
-template <int HS>
-int launch_bwd(const AttnParams& p, dim3 grid, int64_t rows, hipStream_t stream) {
+template <int HS, bool MASKED>
+int launch_bwd_m(const AttnParams& p, dim3 grid, int64_t rows, hipStream_t stream) {
     using G = Geo<HS>;
     attn_rowdot_kernel<HS><<<dim3((unsigned)cdiv64(rows * p.nh, 256)), dim3(256), 0, stream>>>(p, rows);
     const int lds_kv = 2 * (2 * G::RTILE + 2 * G::CTILE), lds_q = 2 * (2 * G::RTILE + G::CTILE);
-    dvq_ensure_dynamic_lds((const void*)attn_bwd_dq_kernel<HS>, lds_q);
+    dvq_ensure_dynamic_lds((const void*)attn_bwd_dq_kernel<HS, MASKED>, lds_q);
     if constexpr (HS > 128) {
-        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 1>, lds_kv);
-        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 2>, lds_kv);
-        attn_bwd_dkv_kernel<HS, 1><<<grid, dim3(256), lds_kv, stream>>>(p);
-        attn_bwd_dkv_kernel<HS, 2><<<grid, dim3(256), lds_kv, stream>>>(p);
+        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 1, MASKED>, lds_kv);
+        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 2, MASKED>, lds_kv);
+        attn_bwd_dkv_kernel<HS, 1, MASKED><<<grid, dim3(256), lds_kv, stream>>>(p);
+        attn_bwd_dkv_kernel<HS, 2, MASKED><<<grid, dim3(256), lds_kv, stream>>>(p);
     } else if (HS == 128 && split128_env()) {
         // head size 128: dV and dK in two launches of half the accumulators (188 / 256 registers instead of 470: two waves per SIMD hide
         // the operand loads; the score tile is computed twice).  Stage-2 train step 91.5 -> 90.3 ms; DVQ_ATTN_DKV_SPLIT=0: one launch
-        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 1>, lds_kv);
-        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 2>, lds_kv);
-        attn_bwd_dkv_kernel<HS, 1><<<grid, dim3(256), lds_kv, stream>>>(p);
-        attn_bwd_dkv_kernel<HS, 2><<<grid, dim3(256), lds_kv, stream>>>(p);
+        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 1, MASKED>, lds_kv);
+        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 2, MASKED>, lds_kv);
+        attn_bwd_dkv_kernel<HS, 1, MASKED><<<grid, dim3(256), lds_kv, stream>>>(p);
+        attn_bwd_dkv_kernel<HS, 2, MASKED><<<grid, dim3(256), lds_kv, stream>>>(p);
     } else {
-        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS>, lds_kv);
-        attn_bwd_dkv_kernel<HS><<<grid, dim3(256), lds_kv, stream>>>(p);
+        dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 0, MASKED>, lds_kv);
+        attn_bwd_dkv_kernel<HS, 0, MASKED><<<grid, dim3(256), lds_kv, stream>>>(p);
     }
-    attn_bwd_dq_kernel<HS><<<grid, dim3(256), lds_q, stream>>>(p);
+    attn_bwd_dq_kernel<HS, MASKED><<<grid, dim3(256), lds_q, stream>>>(p);
     return 0;
+}
+template <int HS>
+int launch_bwd(const AttnParams& p, dim3 grid, int64_t rows, hipStream_t stream) {
+    if constexpr (HS <= 128) {
+        if (p.thr != 0 && p.mask != nullptr) return launch_bwd_m<HS, true>(p, grid, rows, stream);
+    }
+    return launch_bwd_m<HS, false>(p, grid, rows, stream);
 }
 
 int fill_params(AttnParams& p, const char* who, int dtype, int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop,
@@ -574,6 +659,11 @@ int fill_params(AttnParams& p, const char* who, int dtype, int64_t B, int64_t T,
     p.inv_keep = 1.f / (1.f - p_drop);
     p.thr = (unsigned)((double)p_drop * 4294967296.0);
     dvq_dropout_seed(seed, &p.rm, &p.ra);
+    static const int dbg = [] {
+        const char* e = getenv("DVQ_ATTN_DBG");
+        return e != nullptr ? atoi(e) : 0;
+    }();
+    p.dbg = dbg;
     return DVQ_OK;
 }
 
@@ -587,8 +677,14 @@ int64_t dvq_attn_causal_scratch_bytes(int64_t B, int64_t T, int n_head, int head
     return 3 * elems * 2 + ((B * n_head * T * 4 + 255) / 256) * 256;
 }
 
+int64_t dvq_attn_causal_mask_bytes(int64_t B, int64_t T, int n_head) {
+    const int64_t nt = (T + 31) / 32;
+    return B * n_head * nt * nt * 16 * 8;
+}
+
 int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, int64_t B, int64_t T, int n_head, int head_dim,
-                        float scale, float p_drop, uint64_t seed, void* out, float* lse, void* scratch, dvq_stream_t stream) {
+                        float scale, float p_drop, uint64_t seed, void* out, float* lse, void* scratch, void* drop_mask,
+                        dvq_stream_t stream) {
     DVQ_REQUIRE(q && k && v && out && lse && scratch, DVQ_EINVAL, "dvq_attn_causal_fwd: null pointer");
     AttnParams p{};
     int rc = fill_params(p, "dvq_attn_causal_fwd", dtype, B, T, n_head, head_dim, scale, p_drop, seed);
@@ -597,6 +693,7 @@ int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, 
     if (rc != DVQ_OK) return rc;
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.vt = (const bf16_t*)scratch;
     p.out = (bf16_t*)out; p.lse = lse;
+    p.mask = (unsigned long long*)drop_mask;
     const int nqt = (int)((T + 31) / 32);
     const dim3 grid((unsigned)((nqt + 3) / 4), (unsigned)(B * n_head));
     if (head_dim == 64) launch_fwd<64>(p, grid, (hipStream_t)stream);
@@ -607,7 +704,7 @@ int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, 
 
 int dvq_attn_causal_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse, int dtype,
                         int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop, uint64_t seed, void* dq, void* dk,
-                        void* dv, void* scratch, dvq_stream_t stream) {
+                        void* dv, void* scratch, const void* drop_mask, dvq_stream_t stream) {
     DVQ_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && scratch, DVQ_EINVAL, "dvq_attn_causal_bwd: null pointer");
     AttnParams p{};
     int rc = fill_params(p, "dvq_attn_causal_bwd", dtype, B, T, n_head, head_dim, scale, p_drop, seed);
@@ -624,6 +721,7 @@ int dvq_attn_causal_bwd(const void* q, const void* k, const void* v, const void*
     p.qt = qt; p.kt = kt; p.dot = dot;
     p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
     p.lse = const_cast<float*>(lse); p.dsum = dsum;
+    p.mask = (unsigned long long*)const_cast<void*>(drop_mask);
     const int nt = (int)((T + 31) / 32);
     const dim3 grid((unsigned)((nt + 3) / 4), (unsigned)(B * n_head));
     if (head_dim == 64) launch_bwd<64>(p, grid, B * T, (hipStream_t)stream);

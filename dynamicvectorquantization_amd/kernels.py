@@ -891,25 +891,32 @@ def _attn_scratch(q, b, t, n_head, backward):
     return torch.empty(nbytes, dtype=torch.uint8, device=q.device)
 
 
-def attn_causal_fwd(q, k, v, b, t, n_head, scale, p_drop=0.0, seed=0):
-    """q, k, v [B*T, C] -> (out [B*T, C], lse fp32 [B, n_head, T])"""
+def attn_causal_drop_mask(q, b, t, n_head):
+    """buffer for the forward's dropout keep decisions (1 bit per score of the causal tiles; csrc/attention.hip: drop_tile)"""
+    return torch.empty(lib().dvq_attn_causal_mask_bytes(b, t, n_head) // 8, dtype=torch.int64, device=q.device)
+
+
+def attn_causal_fwd(q, k, v, b, t, n_head, scale, p_drop=0.0, seed=0, drop_mask=None):
+    """q, k, v [B*T, C] -> (out [B*T, C], lse fp32 [B, n_head, T]); drop_mask (attn_causal_drop_mask): receives the keep decisions"""
     out = torch.empty_like(q)
     lse = torch.empty(b, n_head, t, dtype=torch.float32, device=q.device)
     scratch = _attn_scratch(q, b, t, n_head, False)
     c = q.shape[-1]
     _timed("attn_causal_fwd", 2 * b * t * t * c, 4 * q.numel() * q.element_size(), lambda: check(
         lib().dvq_attn_causal_fwd(_p(q), _p(k), _p(v), dt(q), b, t, n_head, c // n_head, float(scale), float(p_drop),
-                                  int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out), _p(lse), _p(scratch), _s()), "dvq_attn_causal_fwd"))
+                                  int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out), _p(lse), _p(scratch), _p(drop_mask), _s()),
+        "dvq_attn_causal_fwd"))
     return out, lse
 
 
-def attn_causal_bwd(q, k, v, out, dout, lse, b, t, n_head, scale, p_drop=0.0, seed=0):
+def attn_causal_bwd(q, k, v, out, dout, lse, b, t, n_head, scale, p_drop=0.0, seed=0, drop_mask=None):
+    """drop_mask: the buffer the forward filled with the same (p_drop, seed); None: the decisions are hashed again"""
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     scratch = _attn_scratch(q, b, t, n_head, True)
     c = q.shape[-1]
     _timed("attn_causal_bwd", 5 * b * t * t * c, 8 * q.numel() * q.element_size(), lambda: check(
         lib().dvq_attn_causal_bwd(_p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), dt(q), b, t, n_head, c // n_head, float(scale),
-                                  float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(dq), _p(dk), _p(dv), _p(scratch), _s()),
+                                  float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(dq), _p(dk), _p(dv), _p(scratch), _p(drop_mask), _s()),
         "dvq_attn_causal_bwd"))
     return dq, dk, dv
 

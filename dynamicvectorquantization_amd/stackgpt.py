@@ -111,9 +111,15 @@ class CausalSelfAttention(nn.Module):
             # one kernel per direction, scores stay in registers (csrc/attention.hip)
             p_drop = self.attn_drop.p if self.training else 0.0
             seed = _next_seed() if p_drop > 0.0 else 0
-            y, lse = K.attn_causal_fwd(q, k, v, b, t, nh, 1.0 / math.sqrt(hs), p_drop, seed)
+            # DVQ_ATTN_DROP_MASK=1: the forward leaves its keep decisions (1 bit per score) for the three backward kernels instead of
+            # each hashing every element again.  Measured on the p6c18 step: 84.14 vs 84.06 ms -- the backward kernels wait on
+            # LDS refills and barriers, not on VALU issue (profiles/r04_attn_bwd_probe.txt) -- so the 20 MB per layer stay unspent
+            dm = None
+            if tape is not None and p_drop > 0.0 and os.environ.get("DVQ_ATTN_DROP_MASK", "0") == "1":
+                dm = K.attn_causal_drop_mask(q, b, t, nh)
+            y, lse = K.attn_causal_fwd(q, k, v, b, t, nh, 1.0 / math.sqrt(hs), p_drop, seed, drop_mask=dm)
             if tape is not None:
-                tape.s.update(fused=(p_drop, seed), y=y, lse=lse)
+                tape.s.update(fused=(p_drop, seed), y=y, lse=lse, drop_mask=dm)
             p = pd = None
         else:
             s = torch.empty(b * nh * t * t, dtype=x2d.dtype, device=x2d.device)
@@ -143,7 +149,8 @@ class CausalSelfAttention(nn.Module):
         dy = self.proj.bwd(dout, tape.child("proj"))
         if "fused" in s_:
             p_drop, seed = s_["fused"]
-            dq, dk, dv = K.attn_causal_bwd(q, k, v, s_["y"], dy, s_["lse"], b, t, nh, 1.0 / math.sqrt(hs), p_drop, seed)
+            dq, dk, dv = K.attn_causal_bwd(q, k, v, s_["y"], dy, s_["lse"], b, t, nh, 1.0 / math.sqrt(hs), p_drop, seed,
+                                           drop_mask=s_.get("drop_mask"))
             dx = self.query.bwd(dq, tape.child("q"))
             dx = K.add(dx, self.key.bwd(dk, tape.child("k")))
             return K.add(dx, self.value.bwd(dv, tape.child("v")))

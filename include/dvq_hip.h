@@ -418,13 +418,18 @@ int dvq_sample_constrained(const void* logits, int dtype, int64_t B, int64_t V, 
  * lse: fp32 [B][n_head][T] (forward output, backward input); p_drop / seed: attention dropout (element index of the
  * [B][n_head][T][T] probability tensor, same generator as dvq_dropout; p_drop == 0: none).
  * scratch: dvq_attn_causal_scratch_bytes(B, T, n_head, head_dim, backward) bytes of device memory (channel-major operand copies).
+ * drop_mask (may be NULL): dvq_attn_causal_mask_bytes(B, T, n_head) bytes; the forward stores its keep decisions there, one bit per
+ * (query, key) of every causal 32 x 32 tile, and a backward given the same buffer reads them instead of hashing every element again
+ * in each of its three kernels (identical results: test_fused_attention_drop_mask_equals_rehash).  NULL: decisions recomputed.
  * DVQ_ESHAPE when dtype / head_dim are not bf16 / 64 or 128: callers use the per-head GEMM path then. */
 int64_t dvq_attn_causal_scratch_bytes(int64_t B, int64_t T, int n_head, int head_dim, int backward);
+int64_t dvq_attn_causal_mask_bytes(int64_t B, int64_t T, int n_head);
 int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, int64_t B, int64_t T, int n_head, int head_dim,
-                        float scale, float p_drop, uint64_t seed, void* out, float* lse, void* scratch, dvq_stream_t stream);
+                        float scale, float p_drop, uint64_t seed, void* out, float* lse, void* scratch, void* drop_mask,
+                        dvq_stream_t stream);
 int dvq_attn_causal_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse, int dtype,
                         int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop, uint64_t seed, void* dq, void* dk,
-                        void* dv, void* scratch, dvq_stream_t stream);
+                        void* dv, void* scratch, const void* drop_mask, dvq_stream_t stream);
 /* Single-head FULL (non-causal) self-attention of the DQ-VAE's AttnBlock (modules/diffusionmodules/model.py:168-192:
  * w = softmax_j(q^T k * C^-1/2), h = v w^T) for C = 256 (bf16, T %% 32 == 0): the same flash kernels as above with one head of
  * size C, no mask, no dropout; q, k, v, out [B*T][C]; lse fp32 [B][T].  The [B,T,T] score tensor never reaches HBM.  Other

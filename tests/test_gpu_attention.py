@@ -66,6 +66,41 @@ def test_fused_attention_vs_fp64_reference(dev, shape, p_drop, hs):
         assert _rel(got.float().cpu().numpy(), ref) < 2e-2, name
 
 
+@pytest.mark.parametrize("shape", [(2, 72, 2), (3, 200, 4), (2, 776, 3)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("hs", [64, 128])
+def test_fused_attention_drop_mask_equals_rehash(dev, shape, hs):
+    """the keep decisions the forward leaves in the drop-mask buffer (1 bit per score, csrc/attention.hip: drop_tile) give the
+    backward kernels exactly the dropout they would hash themselves: outputs and all three gradients are bit-identical"""
+    from dynamicvectorquantization_amd import kernels as K
+    b, t, nh = shape
+    c, scale, p_drop, seed = nh * hs, 1.0 / math.sqrt(hs), 0.1, 0xABCDEF12345 + t
+    g = torch.Generator(device="cpu").manual_seed(t + hs)
+    q, k, v, do = (torch.randn(b * t, c, generator=g).to(dev, torch.bfloat16) for _ in range(4))
+    y0, lse0 = K.attn_causal_fwd(q, k, v, b, t, nh, scale, p_drop, seed)
+    ref = K.attn_causal_bwd(q, k, v, y0, do, lse0, b, t, nh, scale, p_drop, seed)
+    dm = K.attn_causal_drop_mask(q, b, t, nh)
+    dm.fill_(-1)                                             # stale contents must not matter: every causal tile is rewritten
+    y1, lse1 = K.attn_causal_fwd(q, k, v, b, t, nh, scale, p_drop, seed, drop_mask=dm)
+    got = K.attn_causal_bwd(q, k, v, y1, do, lse1, b, t, nh, scale, p_drop, seed, drop_mask=dm)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(lse0, lse1)
+    # same decisions -> same gradients; the two kernel variants are separate compilations of the element-wise code (fp contraction
+    # may differ), so "same" is: a vanishing fraction of elements off by at most one bf16 rounding step
+    for name, a, r in zip(("dq", "dk", "dv"), got, ref):
+        d = (a.float() - r.float()).abs()
+        n_off, worst = int((d > 0).sum()), float(d.max() / r.float().abs().max())
+        print(f"drop-mask vs rehash {name}: {n_off} of {d.numel()} elements differ, worst {worst:.2e} of max|ref|")
+        assert n_off <= 1e-3 * d.numel() and worst < 4e-3, (name, n_off, worst)
+    # the buffer really carries the decisions: the kept fraction of the causal tiles' bits is 1 - p
+    nt = (t + 31) // 32
+    w = dm.view(b * nh, nt, nt, 16)
+    tri = torch.tril(torch.ones(nt, nt, dtype=torch.bool, device=dev), diagonal=-1)          # strictly-below-diagonal tiles: all valid
+    if int(tri.sum()) > 0 and t % 32 == 0:
+        bits = w[:, tri].cpu().numpy().view(np.uint64)
+        frac = float(np.unpackbits(bits.view(np.uint8)).mean())
+        assert abs(frac - (1 - p_drop)) < 0.02, frac
+
+
 def test_fused_attention_rejects_unsupported_geometry(dev):
     from dynamicvectorquantization_amd import kernels as K
     from dynamicvectorquantization_amd._lib import DvqError

@@ -23,9 +23,10 @@ def timeit(fn):
     return s.elapsed_time(e) / reps
 
 
-out, lse = K.attn_causal_fwd(q, k, v, b, t, nh, scale, p_drop, 7)
+dm = K.attn_causal_drop_mask(q, b, t, nh) if p_drop > 0 and os.environ.get("MASK", "1") == "1" else None
+out, lse = K.attn_causal_fwd(q, k, v, b, t, nh, scale, p_drop, 7, drop_mask=dm)
 fl = 2.0 * b * t * t * c            # 4 B nh T^2/2 hs
-ms = timeit(lambda: K.attn_causal_fwd(q, k, v, b, t, nh, scale, p_drop, 7))
+ms = timeit(lambda: K.attn_causal_fwd(q, k, v, b, t, nh, scale, p_drop, 7, drop_mask=dm))
 print(f"fwd  {ms:7.3f} ms {fl / ms / 1e9:6.0f} TF/s")
-ms = timeit(lambda: K.attn_causal_bwd(q, k, v, out, do, lse, b, t, nh, scale, p_drop, 7))
+ms = timeit(lambda: K.attn_causal_bwd(q, k, v, out, do, lse, b, t, nh, scale, p_drop, 7, drop_mask=dm))
 print(f"bwd  {ms:7.3f} ms {2.5 * fl / ms / 1e9:6.0f} TF/s   (x24 layers = {ms * 24:6.2f} ms/step)")
