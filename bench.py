@@ -326,6 +326,8 @@ def extra_workloads(budget_s):
                          "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")} if roof else None}
             if "detail" in e:
                 res[name]["detail"] = e["detail"]
+            if "by_batch" in e:
+                res[name]["by_batch"] = e["by_batch"]
         except Exception as ex:                     # the headline line must not depend on a secondary workload
             res[name] = {"failed": f"{type(ex).__name__}: {str(ex)[:120]}"}
     return res

@@ -176,16 +176,44 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = stage2_cpu_baseline(int(z["coarse_content"].shape[1]), int(z["fine_content"].shape[1]))
         else:
-            bs = args.bs or 8
             model.eval()
+            tr_ = model.transformer
+            n_par = sum(p.numel() for p in tr_.parameters())
+            n_layer_all = len(tr_.position_transformer) + len(tr_.content_transformer)
+            n_embd = int(tr_.config.n_embd)
+
+            def kv_run(bs):
+                """end-to-end constrained sampling with K/V caches (fixed fine positions), random-init weights -> dict"""
+                x = torch.from_numpy(synth.half_flat_images(bs, 256, seed=277)).to(dev)
+                with torch.no_grad():
+                    cnd = model.encode_to_c(x)
+                    model.sample_from_scratch(*cnd, sample=True, top_k=300, top_k_pos=100, process=False, fix_fine_position=True)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    r = model.sample_from_scratch(*cnd, sample=True, top_k=300, top_k_pos=100, process=False, fix_fine_position=True)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                ntok = int(r[0].shape[1] + r[1].shape[1])
+                # HBM roofline of one token step: every transformer weight (bf16) is streamed once for the whole batch, plus the K and V
+                # rows of the prefix (average prefix = half the sequence) of every block for every sequence
+                w_bytes = 2.0 * n_par
+                kv_bytes = bs * n_layer_all * 2 * (ntok / 2.0) * n_embd * 2.0
+                steps_per_s = ntok / dt
+                achieved = (w_bytes + kv_bytes) * steps_per_s
+                return {"bs": bs, "tokens_per_sequence": ntok, "seconds": round(dt, 3), "token_steps_per_sec": round(bs * ntok / dt, 1),
+                        "ms_per_token_step": round(dt / ntok * 1e3, 3),
+                        "roofline": {"bound": "hbm", "weight_bytes_per_step": int(w_bytes), "kv_bytes_per_step_avg": int(kv_bytes),
+                                     "achieved": round(achieved / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8e12, 4)}}
+
+            sizes = [args.bs] if args.bs else [8, 50]             # 50 = the reference sampler's default (scripts/sample_val/sample_dynamic_uncond.py:29)
+            res = {}
+            bs = sizes[0]
             x = torch.from_numpy(synth.half_flat_images(bs, 256, seed=277)).to(dev)
             with torch.no_grad():
                 _, z = model.encode_to_z(x)
                 tf = model.teacher_forcing_inputs(z, model.encode_to_c(x))
                 cc, fc, cp, fp, cs, fs = (tf[k] for k in ("coarse_content", "fine_content", "coarse_position", "fine_position",
                                                          "coarse_seg", "fine_seg"))
-                tr_ = model.transformer
-                res = {}
                 # one sampling step of the fine stream at (a) half and (b) the full prefix: position pass + content pass,
                 # recomputed over the whole prefix exactly like the reference's sampler (no KV cache)
                 for tag, lf in (("half_prefix", fc.shape[1] // 2), ("full_prefix", fc.shape[1] - 1)):
@@ -201,24 +229,19 @@ def main():
                         step()
                     torch.cuda.synchronize()
                     dt = (time.perf_counter() - t0) / n
-                    res[tag] = {"prefix_len": int(cc.shape[1] + lf), "ms_per_token_step": round(dt * 1e3, 2),
+                    res[tag] = {"bs": bs, "prefix_len": int(cc.shape[1] + lf), "ms_per_token_step": round(dt * 1e3, 2),
                                 "tokens_per_sec": round(bs / dt, 1)}
-                # end-to-end constrained sampling with K/V caches (fixed fine positions), random-init weights
-                c = model.encode_to_c(x)
-                for _ in range(1):
-                    model.sample_from_scratch(*c, sample=True, top_k=300, top_k_pos=100, process=False, fix_fine_position=True)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                r = model.sample_from_scratch(*c, sample=True, top_k=300, top_k_pos=100, process=False, fix_fine_position=True)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-                ntok = int(r[0].shape[1] + r[1].shape[1])
-                res["kv_cached_end_to_end"] = {"tokens_per_sequence": ntok, "seconds": round(dt, 3),
-                                               "token_steps_per_sec": round(bs * ntok / dt, 1)}
+            runs = [kv_run(b_) for b_ in sizes]
+            res["kv_cached_end_to_end"] = runs[0]
+            for r_ in runs[1:]:
+                res[f"kv_cached_end_to_end_bs{r_['bs']}"] = r_
             out = {"workload": "sampling", "metric": "AR sampling token-steps/sec (one position + one content token per step): end-to-end "
                                                      "with K/V caches; `*_prefix` = the reference's schedule (whole prefix recomputed)",
-                   "value": res["kv_cached_end_to_end"]["token_steps_per_sec"], "unit": "token-steps/sec", "detail": res,
-                   "config": {"yaml": "configs/stage2/uncond_imagenet_p6c18.yml", "bs": bs}, "dtype": "bf16", "data": "synthetic"}
+                   "value": runs[0]["token_steps_per_sec"], "unit": "token-steps/sec", "detail": res,
+                   "by_batch": {str(r_["bs"]): {"token_steps_per_sec": r_["token_steps_per_sec"], "roofline": r_["roofline"]} for r_ in runs},
+                   "roofline": runs[0]["roofline"],
+                   "config": {"yaml": "configs/stage2/uncond_imagenet_p6c18.yml", "bs": bs, "batch_sizes": sizes,
+                              "transformer_params": n_par}, "dtype": "bf16", "data": "synthetic"}
     print(json.dumps(out), flush=True)
 
 
