@@ -619,7 +619,7 @@ void* dvq_workspace_stream(hipStream_t stream, int64_t* bytes) {
 extern "C" {
 
 const char* dvq_last_error(void) { return g_err; }
-int dvq_version(void) { return 105; }
+int dvq_version(void) { return 106; }
 
 int dvq_set_workspace(void* ptr, int64_t bytes) {
     DVQ_REQUIRE((ptr == nullptr) == (bytes == 0) && bytes >= 0, DVQ_EINVAL, "dvq_set_workspace: bad arguments");

@@ -42,7 +42,10 @@ enum { DVQ_F32 = 0, DVQ_BF16 = 1 };
 enum { DVQ_OK = 0, DVQ_EINVAL = -1, DVQ_ESHAPE = -2, DVQ_EARCH = -3, DVQ_ELAUNCH = -4, DVQ_EWORKSPACE = -5 };
 
 const char* dvq_last_error(void);
-int dvq_version(void);     /* 105: round 3 (fused constrained sampler, GroupNorm-backward partials argument, four workspace slots,
+int dvq_version(void);     /* 106: round 4 (launch lists dvq_cmdlist_*, dvq_add_uniform, dvq_decode_stack_status + 64 sequences, drop_mask argument
+                            * of dvq_attn_causal_fwd / bwd + dvq_attn_causal_mask_bytes, dvq_layernorm_bwd_res, dvq_dropout_add, eight
+                            * workspace slots + dvq_workspace_release, vq_argmin workspace report slots);
+                            * 105: round 3 (fused constrained sampler, GroupNorm-backward partials argument,
                             * no vendor-library entry points; + dvq_decode_stack, dvq_gemm_tn_colsum) */
 /* 0 if the current HIP device is gfx950, DVQ_EARCH otherwise */
 int dvq_check_device(void);
