@@ -255,20 +255,18 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void attn_fwd_kernel(AttnPa
                     for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
             }
             if (p.thr != 0) {
-                unsigned mlo = 0, mhi = 0;                       // lane r collects the ballot of register r (v_writelane from the SGPR pair)
+                unsigned long long mine = 0;                     // lane r keeps the ballot of register r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned idx = idx_row + (unsigned)(k0 + crow(r, half));
                     const bool keep = dvq_hash32(idx * p.rm + p.ra) >= p.thr;
                     if (p.mask != nullptr) {
                         const unsigned long long m = __ballot(keep);
-                        mlo = __builtin_amdgcn_writelane((unsigned)m, r, mlo);
-                        mhi = __builtin_amdgcn_writelane((unsigned)(m >> 32), r, mhi);
+                        mine = lane == r ? m : mine;
                     }
                     s[r] = keep ? s[r] * p.inv_keep : 0.f;
                 }
-                if (p.mask != nullptr && lane < 16)
-                    *reinterpret_cast<uint2*>(p.mask + drop_tile(bh, nqt, qt, kt) + lane) = make_uint2(mlo, mhi);
+                if (p.mask != nullptr && lane < 16) p.mask[drop_tile(bh, nqt, qt, kt) + lane] = mine;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
