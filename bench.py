@@ -522,6 +522,7 @@ def main():
                       "segments": trainer._graph["sg"].n_segments() if trainer._graph is not None else 0,
                       "replay": rt.step_replay_mode() if trainer._graph is not None else None,
                       "host_ms_one_step_idle_queue": round(host_idle * 1e3, 2),
+                      "host_call_ms_fast_half": round(host / steps * 1e3, 2),
                       "launches_main_side_waits": trainer._graph["sg"].launch_counts() if trainer._graph is not None else None,
                       "fine_ratio": float(model._logged.get("train_fine_ratio", torch.tensor(float("nan"))))}
         model._logged = {}
@@ -572,7 +573,8 @@ def main():
                         "alg_bytes_per_launch": v["bytes"] / max(1, v["launches"]),
                         "timed": "HIP events around every launch of this kernel during one eagerly launched single-stream step right "
                                  "after the timed region; the timed steps themselves are " +
-                                 ("hipGraph replays of the same launch sequence" if graph_info["timed_steps"] == "graph" else
+                                 (("launch-list replays of the recorded sequence (csrc/cmdlist.hip: main + side stream)" if graph_info.get("replay") == "list"
+                                   else "hipGraph replays of the same launch sequence") if graph_info["timed_steps"] == "graph" else
                                   "eager launches of the same sequence with the conv weight gradients on a second stream")}
             # HBM traffic per launch: PMC counters cannot be collected from inside this process; the figure comes from the
             # committed rocprofv3 --pmc passes over this same command (tools/gpu_pmc_bench.sh -> tools/pmc_summarise.py)
@@ -602,7 +604,9 @@ def main():
                        "step_graph": graph_info},
             "step_mfma_frac": round(ips / world * STEP_FLOP_PER_IMG[args.objective] / PEAK_BF16, 4),
             "step_flop_per_img": STEP_FLOP_PER_IMG[args.objective],
-            "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 2),
+            # host WORK to hand one step to an idle device; the mean of the faster half of the timed calls (which still contains waits
+            # for queue space: two steps of 2200 packets do not fit the queues) is config.step_graph.host_call_ms_fast_half
+            "host_issue_ms_per_step": graph_info.get("host_ms_one_step_idle_queue"),
             "rccl_ranks": dist.get_world_size() if dist.is_available() and dist.is_initialized() else 0,
             "allreduce_exposed_ms": graph_info.get("allreduce_exposed_ms"),
             "roofline": roofline,

@@ -1,8 +1,8 @@
 #!/bin/bash
-# measurement set of a round (TAG=r03_v1 bash tools/gpu/final.sh): parity suite, smoke, headline bench (with the secondary-workload
+# measurement set of a round (TAG=r04_v1 bash tools/gpu/final.sh): parity suite, smoke, headline bench (with the secondary-workload
 # blocks), rocprofv3 kernel stats of the recorded single-stream step, FETCH / WRITE PMC passes, per-shape conv table, halo-conv probes
 set -u
-cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp; R="$PWD"; TAG=${TAG:-r03_v1}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp; R="$PWD"; TAG=${TAG:-r04_v1}
 rm -f gpurun_out/test_reports.jsonl
 timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --tb=short -rf --timeout 900 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -n 3 gpurun_out/pytest_gpu.log | cut -c1-200
 cp gpurun_out/test_reports.jsonl gpurun_out/${TAG}_test_reports.jsonl 2>/dev/null
@@ -24,9 +24,10 @@ timeout 300 python tools/conv_bench.py --no-check 2>/dev/null | grep -v "Warn\|r
   echo "## per-workgroup trace (DVQ_HALO_DBG=6, tools/debug/halo_trace.py)"; for m in plain res+stats; do timeout 200 python tools/debug/halo_trace.py $m 2>/dev/null | grep "mode\|split\|overlapped"; done;
   echo "## VALU issue beside a busy MFMA wave (tools/debug/_valu_under_mfma)"; [ -x tools/debug/_valu_under_mfma ] && tools/debug/_valu_under_mfma; } > gpurun_out/${TAG}_halo_probes.txt 2>&1
 timeout 200 python tools/debug/gn_probe.py 2>/dev/null | grep "^N" > gpurun_out/${TAG}_gn_probe.txt
+TOP=40 bash tools/gpu/r4_s2prof.sh > gpurun_out/${TAG}_stage2_step_table.txt 2>&1; cp gpurun_out/r04_stage2_kernel_stats.csv gpurun_out/${TAG}_stage2_kernel_stats.csv 2>/dev/null; echo "stage2 prof exit $?"
 python - <<'P'
 import json,os
-tag=os.environ.get("TAG","r03_v1")
+tag=os.environ.get("TAG","r04_v1")
 for l in open(f"gpurun_out/{tag}_bench.json"):
     if l.startswith('{"metric"'):
         d=json.loads(l)
