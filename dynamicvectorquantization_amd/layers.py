@@ -212,12 +212,13 @@ class Linear(nn.Module):
                 b = bp
         return w, b
 
-    def fwd(self, x2d, tape):
-        """x2d [M, in] (compute dtype) -> [M, out_p]"""
+    def fwd(self, x2d, tape, out=None):
+        """x2d [M, in] (compute dtype) -> [M, out_p]; `out`: flat destination allocated by the caller (side-stream launches: the
+        result must come from the consumer stream's pool)"""
         m = x2d.shape[0]
         w, b = self._w(x2d.dtype)
         y = K.gemm_nt(x2d, w, m, self.out_p, self.in_features, self.in_features, self.in_features, self.out_p,
-                      bias=b, bias_mode=1 if b is not None else 0)
+                      bias=b, bias_mode=1 if b is not None else 0, out=out)
         if tape is not None:
             tape.s.update(x=x2d, w=w)
         return y.view(m, self.out_p)
@@ -229,15 +230,26 @@ class Linear(nn.Module):
         fused_db = self.bias is not None and self.out_p == self.out_features and os.environ.get("DVQ_LINEAR_DB", "fused") == "fused"
         # bias gradient = column sums of dy: taken from the weight-gradient kernel's pass over dy (a separate 17-us reduction per layer
         # otherwise: 2.5 ms of a stage-2 train step)
-        K.gemm_tn(dy, x2d, m, self.out_features, self.in_features, self.out_p, self.in_features, self.in_features,
-                  out=_grad_buf(self.weight), colsum=_grad_buf(self.bias) if fused_db else None)
-        if self.bias is not None and not fused_db:
-            if self.out_p == self.out_features:
-                K.sum_batch(dy, _grad_buf(self.bias))            # accumulates
-            else:
-                db = torch.zeros(self.out_p, dtype=torch.float32, device=dy.device)
-                K.sum_batch(dy, db)
-                _grad_buf(self.bias).add_(db[: self.out_features])
+        def wgrad():
+            K.gemm_tn(dy, x2d, m, self.out_features, self.in_features, self.out_p, self.in_features, self.in_features,
+                      out=_grad_buf(self.weight), colsum=_grad_buf(self.bias) if fused_db else None)
+            if self.bias is not None and not fused_db:
+                if self.out_p == self.out_features:
+                    K.sum_batch(dy, _grad_buf(self.bias))            # accumulates
+                else:
+                    db = torch.zeros(self.out_p, dtype=torch.float32, device=dy.device)
+                    K.sum_batch(dy, db)
+                    _grad_buf(self.bias).add_(db[: self.out_features])
+
+        # the weight gradient has no consumer before the optimizer step / gradient exchange: on the side stream (runtime.side_wgrad)
+        # its workgroups fill the partially occupied last round of the input-gradient GEMM that runs beside it (20576-row operands
+        # give 324 / 432 tiles for 256 CUs) and its HBM-bound partial fold overlaps MFMA-bound kernels.  DVQ_LINEAR_SIDE=0: main stream
+        if need_dx and m >= 1024 and rt.side_wgrad_enabled() and os.environ.get("DVQ_LINEAR_SIDE", "1") != "0":
+            wt = self._wt(w)                                                 # made on the main stream, before the fork
+            dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self.out_p, self.in_features)
+            rt.run_on_side(wgrad, dy, x2d)      # after the input gradient (forking before it measured the same: 82.3 vs 82.0 ms)
+            return dx.view(m, self.in_features)
+        wgrad()
         if not need_dx:
             return None
         wt = self._wt(w)                                                     # [in, out_p]
