@@ -838,27 +838,28 @@ __device__ __forceinline__ bool sample_before(float va, int ia, float vb, int ib
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void sample_constrained_kernel(SampleParams p) {
+__global__ __launch_bounds__(1024) void sample_constrained_kernel(SampleParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sv = reinterpret_cast<float*>(smem);             // [N] values, then probabilities
     int* si = reinterpret_cast<int*>(sv + p.N);             // [N] column indices
     float* scan = reinterpret_cast<float*>(si + p.N);       // [N] inclusive scans
     unsigned char* flag = reinterpret_cast<unsigned char*>(scan + p.N);     // [N] forbid flags
-    __shared__ float red[8];
-    __shared__ int redi[8];
-    const int tid = threadIdx.x, row = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float red[16];
+    __shared__ int redi[16];
+    // N / 2 threads (256 .. 1024): one compare-exchange per thread and sort step
+    const int tid = threadIdx.x, row = blockIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x, nw = nth >> 6;
     const int V = p.V, N = p.N;
     const bool fin = p.finished != nullptr && p.finished[row] != 0.f;
-    for (int c = tid; c < N; c += 256) flag[c] = 0;
+    for (int c = tid; c < N; c += nth) flag[c] = 0;
     __syncthreads();
     if (!fin && p.forbid_idx != nullptr)
-        for (int j = tid; j < p.n_forbid; j += 256) {
+        for (int j = tid; j < p.n_forbid; j += nth) {
             const int64_t c = p.forbid_idx[(int64_t)row * p.forbid_ld + j];
             if (c >= 0 && c < V) flag[c] = 1;
         }
     __syncthreads();
     const T* lg = reinterpret_cast<const T*>(p.logits) + (int64_t)row * p.ldl;
-    for (int c = tid; c < N; c += 256) {
+    for (int c = tid; c < N; c += nth) {
         float v = -INFINITY;
         if (c < V) {
             const float x = ElemIO<T>::load(lg + c) * p.inv_temperature;
@@ -876,10 +877,12 @@ __global__ __launch_bounds__(256) void sample_constrained_kernel(SampleParams p)
         si[c] = c;
     }
     __syncthreads();
-    // bitonic sort, N / 2 compare-exchanges per step
+    // bitonic sort, N / 2 compare-exchanges per step.  With N / 2 threads a wave's 64 exchanges of a step with j <= 64 stay inside
+    // one 128-element block that no other wave touches before the next step with j >= 128: those steps (56 of the 66 at N = 2048) need
+    // no workgroup barrier -- a wave's LDS operations complete in order.  (256 threads with a barrier per step: 68 us per call.)
     for (int k2 = 2; k2 <= N; k2 <<= 1)
         for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (N >> 1); t += 256) {
+            for (int t = tid; t < (N >> 1); t += nth) {
                 const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
                 const bool up = (lo & k2) == 0;                       // this run is ordered "best first"
                 const float va = sv[lo], vb = sv[hi];
@@ -890,7 +893,10 @@ __global__ __launch_bounds__(256) void sample_constrained_kernel(SampleParams p)
                     si[lo] = ib; si[hi] = ia;
                 }
             }
-            __syncthreads();
+            // the next step's partner distance decides who reads what this step wrote
+            const int jn = j > 1 ? (j >> 1) : k2;                     // (after j == 1 comes the next k2's first step, j = k2)
+            if (2 * nth != N || j > 64 || jn > 64) __syncthreads();
+            else __builtin_amdgcn_wave_barrier();
         }
     // top-k threshold and softmax over the kept entries
     const float vmax = sv[0];
@@ -900,17 +906,19 @@ __global__ __launch_bounds__(256) void sample_constrained_kernel(SampleParams p)
         __syncthreads();
         if (lane == 0) red[wave] = x;
         __syncthreads();
-        return (red[0] + red[1]) + (red[2] + red[3]);
+        float tsum = 0.f;
+        for (int w = 0; w < nw; ++w) tsum += red[w];
+        return tsum;
     };
-    // inclusive scan of scan[] over positions 0 .. N-1 (each thread owns N / 256 consecutive positions; N >= 256)
-    const int per = N >> 8;
+    // inclusive scan of scan[] over positions 0 .. N-1 (each thread owns N / nth consecutive positions; N >= nth)
+    const int per = N / nth;
     auto block_scan = [&]() {
         float run = 0.f;
         for (int i = 0; i < per; ++i) {
             run += scan[tid * per + i];
             scan[tid * per + i] = run;
         }
-        // scan of the 256 thread totals: wave-level inclusive scan, then wave offsets
+        // scan of the thread totals: wave-level inclusive scan, then wave offsets
         float x = run;
         for (int off = 1; off < 64; off <<= 1) {
             const float y = __shfl_up(x, off, 64);
@@ -925,14 +933,14 @@ __global__ __launch_bounds__(256) void sample_constrained_kernel(SampleParams p)
         __syncthreads();
     };
     float part = 0.f;
-    for (int c = tid; c < N; c += 256) {
+    for (int c = tid; c < N; c += nth) {
         const float v = sv[c];
         const float e = (v >= thr && v > -INFINITY) ? __expf(v - vmax) : 0.f;
         sv[c] = e;
         part += e;
     }
     const float z = block_sum(part);
-    for (int c = tid; c < N; c += 256) {
+    for (int c = tid; c < N; c += nth) {
         sv[c] = sv[c] / z;
         scan[c] = sv[c];
     }
@@ -941,14 +949,14 @@ __global__ __launch_bounds__(256) void sample_constrained_kernel(SampleParams p)
     if (p.top_p > 0.f && p.top_p < 1.f) {
         block_scan();
         part = 0.f;
-        for (int c = tid; c < N; c += 256) {
+        for (int c = tid; c < N; c += nth) {
             const bool remove = c > 0 && scan[c - 1] >= p.top_p;
             const float pr = remove ? 0.f : sv[c];
             part += pr;
             flag[c] = remove ? 1 : 0;                                  // (re-used: the forbid flags are no longer needed)
         }
         __syncthreads();
-        for (int c = tid; c < N; c += 256) {
+        for (int c = tid; c < N; c += nth) {
             if (flag[c]) sv[c] = 0.f;
             scan[c] = sv[c];
         }
@@ -963,7 +971,7 @@ __global__ __launch_bounds__(256) void sample_constrained_kernel(SampleParams p)
         const float u = (float)(s >> 40) * (1.0f / 16777216.0f) * mass;
         // first position whose inclusive cumulative mass exceeds u (positions with zero probability are never picked)
         int best = N;
-        for (int c = tid; c < N; c += 256)
+        for (int c = tid; c < N; c += nth)
             if (sv[c] > 0.f && scan[c] > u) {
                 best = c;
                 break;                                                  // (positions of a thread ascend)
@@ -972,16 +980,18 @@ __global__ __launch_bounds__(256) void sample_constrained_kernel(SampleParams p)
         __syncthreads();
         if (lane == 0) redi[wave] = best;
         __syncthreads();
-        best = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+        best = redi[0];
+        for (int w = 1; w < nw; ++w) best = min(best, redi[w]);
         if (best >= N) {                                                // rounding left u at the very top: the last kept entry
             int last = -1;
-            for (int c = tid; c < N; c += 256)
+            for (int c = tid; c < N; c += nth)
                 if (sv[c] > 0.f) last = c;
             for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
             __syncthreads();
             if (lane == 0) redi[wave] = last;
             __syncthreads();
-            best = max(max(redi[0], redi[1]), max(redi[2], redi[3]));
+            best = redi[0];
+            for (int w = 1; w < nw; ++w) best = max(best, redi[w]);
         }
         pick = max(best, 0);
     }
@@ -1014,7 +1024,8 @@ extern "C" int dvq_sample_constrained(const void* logits, int dtype, int64_t B, 
     p.keep_code = (int)keep_code; p.late_forbid_code = (int)late_forbid_code; p.pad_code = (int)pad_code;
     p.finished = finished; p.top_k = top_k; p.top_p = top_p; p.sample = sample; p.state = state; p.out = out;
     const int lds = n * (4 + 4 + 4 + 1);
-    DVQ_DISPATCH_DTYPE(dtype, TT, sample_constrained_kernel<TT><<<dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream>>>(p););
+    const unsigned nthreads = (unsigned)(n / 2 < 256 ? 256 : n / 2 > 1024 ? 1024 : n / 2);
+    DVQ_DISPATCH_DTYPE(dtype, TT, sample_constrained_kernel<TT><<<dim3((unsigned)B), dim3(nthreads), lds, (hipStream_t)stream>>>(p););
     DVQ_CHECK_LAUNCH("sample_constrained");
     if (sample) {
         sample_bump_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(state);
