@@ -74,6 +74,10 @@ SIGNATURES = {
     "dvq_avgpool_slice_bwd": (i32, [vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp]),
     "dvq_silu": (i32, [vp, i32, i64, vp, vp]),
     "dvq_silu_bwd": (i32, [vp, vp, i32, i64, vp, vp]),
+    "dvq_relu": (i32, [vp, i32, i64, vp, vp]),
+    "dvq_relu_bwd": (i32, [vp, vp, i32, i64, vp, vp]),
+    "dvq_upsample_nearest2x": (i32, [vp, i32, i64, i64, i64, i64, vp, vp]),
+    "dvq_upsample_nearest2x_bwd": (i32, [vp, i32, i64, i64, i64, i64, vp, vp]),
     "dvq_grain_merge": (i32, [vp, i32, vp, vp, i32, i64, i64, i64, i64, vp, vp, vp]),
     "dvq_grain_merge_bwd": (i32, [vp, vp, i32, vp, vp, i32, i64, i64, i64, i64, vp, vp, vp]),
     "dvq_affine_channels": (i32, [vp, i32, i64, i64, vp, vp, vp, vp]),

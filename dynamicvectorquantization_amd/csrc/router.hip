@@ -90,6 +90,62 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const T* __restrict__ x, 
     }
 }
 
+// nn.ReLU of the 2layer-fc-ReLu router gate (RouterTriple.py:23-28) and its backward (x = pre-activation)
+template <typename T>
+__global__ __launch_bounds__(256) void relu_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t n8, T* __restrict__ y) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
+        float v[8], g[8];
+        load8(x + e * 8, v);
+        if (dy != nullptr) {
+            load8(dy + e * 8, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? g[j] : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+        }
+        store8(y + e * 8, v);
+    }
+}
+
+// F.interpolate(scale_factor=2, mode="nearest") of Upsample(with_conv=False) (model.py:49-53), NHWC: every 8-channel chunk of an input
+// pixel is written to its 2 x 2 output pixels; backward: the four output gradients are added
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void nearest2x_kernel(const T* __restrict__ src, int64_t N, int h, int w, int C8, T* __restrict__ dst) {
+    const int64_t total = N * h * w * C8;                     // one thread per (input pixel, chunk)
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c8 = (int)(e % C8);
+        int64_t px = e / C8;
+        const int j = (int)(px % w);
+        px /= w;
+        const int i = (int)(px % h);
+        const int64_t n = px / h;
+        const int64_t big = ((n * 2 * h + 2 * i) * 2 * w + 2 * j) * C8 + c8;       // top-left output pixel, in chunks
+        const int64_t rowc = (int64_t)2 * w * C8;
+        if (BWD) {
+            float a[8], b[8];
+            load8(src + big * 8, a);
+            load8(src + (big + C8) * 8, b);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] += b[q];
+            load8(src + (big + rowc) * 8, b);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] += b[q];
+            load8(src + (big + rowc + C8) * 8, b);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] += b[q];
+            store8(dst + e * 8, a);
+        } else {
+            float a[8];
+            load8(src + e * 8, a);
+            store8(dst + big * 8, a);
+            store8(dst + (big + C8) * 8, a);
+            store8(dst + (big + rowc) * 8, a);
+            store8(dst + (big + rowc + C8) * 8, a);
+        }
+    }
+}
+
 struct MergeParams {
     const void* h[3];     // heads, level 0 = coarsest [N,hc,wc,C] ... level S-1 = finest [N,hc<<(S-1),wc<<(S-1),C]
     void* dh[3];          // backward: per-head gradients (same shapes)
@@ -223,6 +279,38 @@ int dvq_silu_bwd(const void* x, const void* dy, int dtype, int64_t n, void* dx, 
     DVQ_DISPATCH_DTYPE(dtype, T, silu_bwd_kernel<T><<<dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream>>>(
                                      (const T*)x, (const T*)dy, n / 8, (T*)dx););
     DVQ_CHECK_LAUNCH("silu_bwd");
+    return DVQ_OK;
+}
+
+int dvq_relu(const void* x, int dtype, int64_t n, void* y, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && y && n > 0 && n % 8 == 0, DVQ_EINVAL, "dvq_relu: bad arguments (n %% 8 == 0)");
+    DVQ_DISPATCH_DTYPE(dtype, T, relu_kernel<T><<<dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream>>>((const T*)x, (const T*)nullptr, n / 8, (T*)y););
+    DVQ_CHECK_LAUNCH("relu");
+    return DVQ_OK;
+}
+
+int dvq_relu_bwd(const void* x, const void* dy, int dtype, int64_t n, void* dx, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && dy && dx && n > 0 && n % 8 == 0, DVQ_EINVAL, "dvq_relu_bwd: bad arguments (n %% 8 == 0)");
+    DVQ_DISPATCH_DTYPE(dtype, T, relu_kernel<T><<<dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream>>>((const T*)x, (const T*)dy, n / 8, (T*)dx););
+    DVQ_CHECK_LAUNCH("relu_bwd");
+    return DVQ_OK;
+}
+
+int dvq_upsample_nearest2x(const void* x, int dtype, int64_t N, int64_t h, int64_t w, int64_t C, void* y, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && y && N > 0 && h > 0 && w > 0 && C > 0 && C % 8 == 0 && h < (1 << 30) && w < (1 << 30), DVQ_EINVAL,
+                "dvq_upsample_nearest2x: bad arguments (C %% 8 == 0)");
+    DVQ_DISPATCH_DTYPE(dtype, T, nearest2x_kernel<T, false><<<dim3(nblk(N * h * w * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)x, N, (int)h, (int)w, (int)(C / 8), (T*)y););
+    DVQ_CHECK_LAUNCH("upsample_nearest2x");
+    return DVQ_OK;
+}
+
+int dvq_upsample_nearest2x_bwd(const void* dy, int dtype, int64_t N, int64_t h, int64_t w, int64_t C, void* dx, dvq_stream_t stream) {
+    DVQ_REQUIRE(dy && dx && N > 0 && h > 0 && w > 0 && C > 0 && C % 8 == 0 && h < (1 << 30) && w < (1 << 30), DVQ_EINVAL,
+                "dvq_upsample_nearest2x_bwd: bad arguments (C %% 8 == 0)");
+    DVQ_DISPATCH_DTYPE(dtype, T, nearest2x_kernel<T, true><<<dim3(nblk(N * h * w * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream>>>(
+                                     (const T*)dy, N, (int)h, (int)w, (int)(C / 8), (T*)dx););
+    DVQ_CHECK_LAUNCH("upsample_nearest2x_bwd");
     return DVQ_OK;
 }
 

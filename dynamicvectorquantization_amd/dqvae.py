@@ -710,6 +710,8 @@ class DualGrainVQModel(nn.Module):
         cb = getattr(self.quantize, "codebook", None)
         if getattr(cb, "restart_perm", None) is not None or getattr(self.encoder, "gumbel_exponential", None) is not None:
             return None                      # injected test noise lives on the host
+        if any(isinstance(m, ResnetBlock) and m.dropout.p > 0.0 for m in self.modules()):
+            return None                      # dropout seeds are drawn on the host per call (a replay would repeat the masks)
         step = self.current_epoch if self.loss_with_epoch else self.global_step
         disc_on = None
         if hasattr(self.loss, "discriminator_iter_start"):

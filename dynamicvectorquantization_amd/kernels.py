@@ -773,6 +773,33 @@ def silu_bwd(x, dy):
     return dx
 
 
+def relu(x):
+    y = torch.empty_like(x)
+    check(lib().dvq_relu(_p(x), dt(x), x.numel(), _p(y), _s()), "dvq_relu")
+    return y
+
+
+def relu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    check(lib().dvq_relu_bwd(_p(x), _p(dy), dt(x), x.numel(), _p(dx), _s()), "dvq_relu_bwd")
+    return dx
+
+
+def upsample_nearest2x(x):
+    """NHWC [N,h,w,C] -> [N,2h,2w,C] (F.interpolate(scale_factor=2, mode="nearest"))"""
+    n, h, w, c = x.shape
+    y = torch.empty(n, 2 * h, 2 * w, c, dtype=x.dtype, device=x.device)
+    check(lib().dvq_upsample_nearest2x(_p(x), dt(x), n, h, w, c, _p(y), _s()), "dvq_upsample_nearest2x")
+    return y
+
+
+def upsample_nearest2x_bwd(dy):
+    n, h2, w2, c = dy.shape
+    dx = torch.empty(n, h2 // 2, w2 // 2, c, dtype=dy.dtype, device=dy.device)
+    check(lib().dvq_upsample_nearest2x_bwd(_p(dy), dt(dy), n, h2 // 2, w2 // 2, c, _p(dx), _s()), "dvq_upsample_nearest2x_bwd")
+    return dx
+
+
 def _ptr_array(tensors):
     arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     for t in tensors:

@@ -514,36 +514,51 @@ PACKS = _PackRegistry()
 
 
 class Upsample(HipModule):
-    """nearest x2 + 3x3 conv (model.py:38-53); the upsampled tensor is never materialised."""
+    """nearest x2 (+ 3x3 conv: the upsampled tensor is then never materialised) (model.py:38-53)"""
 
     def __init__(self, in_channels, with_conv):
         super().__init__()
-        if not with_conv:
-            raise NotImplementedError("Upsample(with_conv=False) is not on the shipped configs' path")
         self.with_conv = with_conv
-        self.conv = Conv2d(in_channels, in_channels, 3, stride=1, padding=1, upsample=True)
+        if with_conv:
+            self.conv = Conv2d(in_channels, in_channels, 3, stride=1, padding=1, upsample=True)
 
     def fwd(self, x, tape):
+        if not self.with_conv:
+            return K.upsample_nearest2x(x)
         return self.conv.fwd(x, _child(tape, "conv"), want_stats=True)
 
     def bwd(self, dy, tape):
+        if not self.with_conv:
+            return K.upsample_nearest2x_bwd(dy)
         return self.conv.bwd(dy, tape.child("conv"))
 
 
 class Downsample(HipModule):
-    """pad (0,1,0,1) + 3x3 stride-2 conv (model.py:56-75); the padding is folded into the gather."""
+    """pad (0,1,0,1) + 3x3 stride-2 conv (the padding is folded into the gather), or avg_pool2d(2, 2) (model.py:56-75)"""
 
     def __init__(self, in_channels, with_conv):
         super().__init__()
-        if not with_conv:
-            raise NotImplementedError("Downsample(with_conv=False) is not on the shipped configs' path")
         self.with_conv = with_conv
-        self.conv = Conv2d(in_channels, in_channels, 3, stride=2, padding=0, asym_pad=True)
+        if with_conv:
+            self.conv = Conv2d(in_channels, in_channels, 3, stride=2, padding=0, asym_pad=True)
 
     def fwd(self, x, tape):
+        if not self.with_conv:
+            n, h, w, c = x.shape
+            y = torch.empty(n, h // 2, w // 2, c, dtype=x.dtype, device=x.device)
+            K.avgpool_slice(x[:, : 2 * (h // 2), : 2 * (w // 2)].contiguous() if (h | w) & 1 else x, 2, y, 0)
+            if tape is not None:
+                tape.s["in_hw"] = (h, w)
+            return y
         return self.conv.fwd(x, _child(tape, "conv"))
 
     def bwd(self, dy, tape):
+        if not self.with_conv:
+            dx = K.avgpool_slice_bwd(dy, 0, dy.shape[-1], 2)
+            h, w = tape.s["in_hw"]
+            if (h | w) & 1:                           # odd sizes: avg_pool2d drops the last row / column
+                dx = torch.nn.functional.pad(dx, (0, 0, 0, w - dx.shape[2], 0, h - dx.shape[1]))
+            return dx
         return self.conv.bwd(dy, tape.child("conv"))
 
 
@@ -571,8 +586,7 @@ class ResnetBlock(HipModule):
             raise NotImplementedError("conv_shortcut=True is unused by the shipped configs")
         if temb_channels > 0:
             raise NotImplementedError("temb_channels > 0 is unused by the DQ-VAE (temb is None)")
-        if dropout != 0.0:
-            raise NotImplementedError("dropout != 0 is unused by the shipped configs")
+        self.dropout = nn.Dropout(dropout)        # (model.py:97; applied between norm2 + swish and conv2, :127)
         self.in_channels, self.out_channels = in_channels, out_channels
         self.use_conv_shortcut = conv_shortcut
         self.norm1 = Normalize(in_channels)
@@ -589,10 +603,21 @@ class ResnetBlock(HipModule):
     def fwd(self, x, tape, temb=None):
         h1 = norm_swish_conv(self.norm1, self.conv1, x, tape, "norm1", "conv1")
         sc = self.nin_shortcut.fwd(x, _child(tape, "nin")) if self.in_channels != self.out_channels else x
+        if self.training and self.dropout.p > 0.0:
+            # dropout between the activation and conv2: the activation is materialised (no prologue fusion); the keep decisions are
+            # a hash of (seed, element index) -- the backward re-derives them from the seed (csrc/dvq_common.h: dvq_hash32)
+            a = self.norm2.fwd(h1, _child(tape, "norm2"), silu=True)
+            seed = rt.next_dropout_seed()             # host-side: a model with dropout > 0 is not step-recorded (dqvae.graph_signature)
+            if tape is not None:
+                tape.s["drop"] = (float(self.dropout.p), seed)
+            a = K.dropout(a, float(self.dropout.p), seed)
+            return self.conv2.fwd(a, _child(tape, "conv2"), residual=sc, want_stats=True)
         return norm_swish_conv(self.norm2, self.conv2, h1, tape, "norm2", "conv2", residual=sc)
 
     def bwd(self, dy, tape):
         d = self.conv2.bwd(dy, tape.child("conv2"))
+        if "drop" in tape.s:
+            d = K.dropout(d, *tape.s["drop"])
         d = self.norm2.bwd(d, tape.child("norm2"))
         d = self.conv1.bwd(d, tape.child("conv1"))
         sc = self.nin_shortcut.bwd(dy, tape.child("nin")) if self.in_channels != self.out_channels else dy

@@ -33,8 +33,8 @@ class _FeatureRouter(nn.Module):
             self.gate = Linear(num_channels * s, s)
         elif gate_type == "2layer-fc-SiLu":
             self.gate = nn.Sequential(Linear(num_channels * s, num_channels * s), nn.SiLU(inplace=True), Linear(num_channels * s, s))
-        elif gate_type == "2layer-fc-ReLu" and relu_ok:
-            raise NotImplementedError("gate_type 2layer-fc-ReLu is unused by the shipped configs")
+        elif gate_type == "2layer-fc-ReLu" and relu_ok:          # RouterTriple.py:23-28 (the dual router has no such branch)
+            self.gate = nn.Sequential(Linear(num_channels * s, num_channels * s), nn.ReLU(inplace=True), Linear(num_channels * s, s))
         else:
             raise NotImplementedError()
         self.normalization_type = normalization_type
@@ -63,7 +63,7 @@ class _FeatureRouter(nn.Module):
             y = self.gate.fwd(x, _child(tape, "g0"))
         else:
             hid = self.gate[0].fwd(x, _child(tape, "g0"))
-            act = K.silu(hid)
+            act = K.relu(hid) if isinstance(self.gate[1], nn.ReLU) else K.silu(hid)
             if tape is not None:
                 tape.s["hid"] = hid
             y = self.gate[2].fwd(act, _child(tape, "g2"))
@@ -83,7 +83,7 @@ class _FeatureRouter(nn.Module):
             dfeat = self.gate.bwd(dy, tape.child("g0"))
         else:
             dact = self.gate[2].bwd(dy, tape.child("g2"))
-            dhid = K.silu_bwd(tape.s["hid"], dact)
+            dhid = K.relu_bwd(tape.s["hid"], dact) if isinstance(self.gate[1], nn.ReLU) else K.silu_bwd(tape.s["hid"], dact)
             dfeat = self.gate[0].bwd(dhid, tape.child("g0"))
         dfeat = dfeat.view(b, hc, wc, s * c)
         out = []

@@ -147,6 +147,16 @@ def graph_break(fn):
     return _capture.brk(fn)
 
 
+# host-side dropout seeds (a hash of (seed, element index) decides every keep bit on the device: csrc/dvq_common.h): derived from torch's
+# seed + a process-wide counter, so runs are reproducible under torch.manual_seed and no launch reads device RNG state
+_seed_counter = [0]
+
+
+def next_dropout_seed() -> int:
+    _seed_counter[0] += 1
+    return (torch.initial_seed() * 1000003 + _seed_counter[0]) & 0x7FFFFFFFFFFFFFFF
+
+
 def step_replay_mode() -> str:
     """how a recorded segment is replayed: "list" = csrc/cmdlist.hip re-issues the captured launches on the current + side stream
     (default: the device sees an eager step's queues); "graph" = hipGraphLaunch of the instantiated capture (DVQ_STEP_REPLAY)"""

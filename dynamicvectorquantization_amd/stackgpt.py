@@ -33,12 +33,7 @@ class StackGPTConfig:
             setattr(self, k, v)
 
 
-_seed_counter = [0]
-
-
-def _next_seed():
-    _seed_counter[0] += 1
-    return (torch.initial_seed() * 1000003 + _seed_counter[0]) & 0x7FFFFFFFFFFFFFFF
+_next_seed = rt.next_dropout_seed
 
 
 def _drop(x, p, training, tape, key):

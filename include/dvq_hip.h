@@ -304,6 +304,14 @@ int dvq_avgpool_slice_bwd(const void* dy, int dtype, int64_t ldy, int64_t coff, 
 /* nn.SiLU of the router MLP and its backward (x = pre-activation); n % 8 == 0 */
 int dvq_silu(const void* x, int dtype, int64_t n, void* y, dvq_stream_t stream);
 int dvq_silu_bwd(const void* x, const void* dy, int dtype, int64_t n, void* dx, dvq_stream_t stream);
+/* nn.ReLU of the gate_type="2layer-fc-ReLu" router MLP (RouterTriple.py:23-28) and its backward (x = pre-activation); n % 8 == 0 */
+int dvq_relu(const void* x, int dtype, int64_t n, void* y, dvq_stream_t stream);
+int dvq_relu_bwd(const void* x, const void* dy, int dtype, int64_t n, void* dx, dvq_stream_t stream);
+/* Upsample(with_conv=False) (modules/diffusionmodules/model.py:49-53): F.interpolate(scale_factor=2, mode="nearest"), NHWC
+ * x [N,h,w,C] -> y [N,2h,2w,C]; backward dx[n,i,j] = sum of dy over the 2 x 2 footprint.  C % 8 == 0.
+ * (Downsample(with_conv=False) = avg_pool2d(2, 2), model.py:73-74, is dvq_avgpool_slice / _bwd with k = 2.) */
+int dvq_upsample_nearest2x(const void* x, int dtype, int64_t N, int64_t h, int64_t w, int64_t C, void* y, dvq_stream_t stream);
+int dvq_upsample_nearest2x_bwd(const void* dy, int dtype, int64_t N, int64_t h, int64_t w, int64_t C, void* dx, dvq_stream_t stream);
 /* S-grain merge (S = 2, 3).  heads[l]: [N, hc<<l, wc<<l, C] (l = 0 coarsest); idx int64 [N,hc,wc] = selected level of each
  * coarsest cell; out [N, hc<<(S-1), wc<<(S-1), C] = nearest-upsampled selected head (* scale[cell] if scale != NULL, the
  * straight-through gate_grad); mask (optional) fp32 [N,hf,wf] = 4^-(S-1-level) (codebook mask).

@@ -34,11 +34,15 @@ def conv(sd, prefix, x, stride=1, padding=0):
     return F.conv2d(x, sd[prefix + ".weight"], sd.get(prefix + ".bias"), stride=stride, padding=padding)
 
 
-def resnet_block(sd, prefix, x):
+def resnet_block(sd, prefix, x, drop_mask=None):
+    """drop_mask (tests of dropout > 0, model.py:127): multiplier [B,C,H,W] (0 or 1 / (1 - p)) applied to the second activation"""
     cin = sd[prefix + ".conv1.weight"].shape[1]
     cout = sd[prefix + ".conv1.weight"].shape[0]
     h = conv(sd, prefix + ".conv1", swish(group_norm(sd, prefix + ".norm1", x)), padding=1)
-    h = conv(sd, prefix + ".conv2", swish(group_norm(sd, prefix + ".norm2", h)), padding=1)
+    a = swish(group_norm(sd, prefix + ".norm2", h))
+    if drop_mask is not None:
+        a = a * drop_mask
+    h = conv(sd, prefix + ".conv2", a, padding=1)
     if cin != cout:
         x = conv(sd, prefix + ".nin_shortcut", x)
     return x + h
@@ -58,11 +62,15 @@ def attn_block(sd, prefix, x):
 
 
 def downsample(sd, prefix, x):
+    if prefix + ".conv.weight" not in sd:            # with_conv=False (model.py:73-74): 2 x 2 average pooling
+        return F.avg_pool2d(x, kernel_size=2, stride=2)
     return conv(sd, prefix + ".conv", F.pad(x, (0, 1, 0, 1)), stride=2)
 
 
 def upsample(sd, prefix, x):
     x = x.repeat_interleave(2, dim=-1).repeat_interleave(2, dim=-2)
+    if prefix + ".conv.weight" not in sd:            # with_conv=False (model.py:49-53): nearest x2 only
+        return x
     return conv(sd, prefix + ".conv", x, padding=1)
 
 

@@ -35,7 +35,8 @@ def feature_router(sd, prefix, heads):
     x = torch.cat(feats, dim=1).permute(0, 2, 3, 1)
     if f"{prefix}.gate.weight" in sd:
         return F.linear(x, sd[f"{prefix}.gate.weight"], sd[f"{prefix}.gate.bias"])
-    x = F.silu(F.linear(x, sd[f"{prefix}.gate.0.weight"], sd[f"{prefix}.gate.0.bias"]))
+    act = F.relu if sd.get(f"{prefix}.gate_type") == "2layer-fc-ReLu" else F.silu      # (the activation has no parameters: the caller says)
+    x = act(F.linear(x, sd[f"{prefix}.gate.0.weight"], sd[f"{prefix}.gate.0.bias"]))
     return F.linear(x, sd[f"{prefix}.gate.2.weight"], sd[f"{prefix}.gate.2.bias"])
 
 

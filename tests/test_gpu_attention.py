@@ -133,7 +133,7 @@ def test_attention_module_fused_equals_unfused_full_size(dev, train, n_head):
         for fused in (True, False):
             os.environ["DVQ_NO_FUSED_ATTN"] = "0" if fused else "1"
             try:
-                sg._seed_counter[0] = 77
+                rt._seed_counter[0] = 77
                 for p_ in attn.parameters():
                     p_.grad = None
                 tape = Tape()

@@ -1,0 +1,114 @@
+"""Constructor options of the reference that no shipped YAML uses but the classes implement: Upsample / Downsample(with_conv=False)
+(modules/diffusionmodules/model.py:38-75), TripleGrainFeatureRouter(gate_type="2layer-fc-ReLu") (RouterTriple.py:23-28), ResnetBlock
+with dropout > 0 (model.py:97,127).  Goldens: tests/golden/options.npz (tools/gen_golden.py --only options, from the reference).
+`pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from dynamicvectorquantization_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("name", ["down_64_pool", "up_64_nn"])
+def test_resample_without_conv_golden(dev, name, dtype, tol):
+    from dynamicvectorquantization_amd import layers as L
+    from dynamicvectorquantization_amd import runtime as rt
+    g = load_golden("options")
+    mod = (L.Downsample(64, False) if name.startswith("down") else L.Upsample(64, False)).to(dev)
+    assert len(list(mod.parameters())) == 0                      # with_conv=False: no conv module, no state_dict keys (reference layout)
+    xshape = (2, 64, 8, 8) if name.startswith("down") else (2, 64, 6, 6)
+    x = T(synth.det_param(name + ".x", xshape) * 8.0, dev).requires_grad_(True)
+    with rt.compute_dtype_ctx(dtype):
+        y = mod(x)
+        gout = T(synth.det_param(name + ".gout", tuple(y.shape)), dev)
+        (y * gout).sum().backward()
+    s = float(np.abs(g[name + "_y"]).max())
+    assert float(np.abs(y.detach().float().cpu().numpy() - g[name + "_y"]).max()) <= tol * s
+    sg = float(np.abs(g[name + "_dx"]).max())
+    assert float(np.abs(x.grad.float().cpu().numpy() - g[name + "_dx"]).max()) <= tol * sg
+
+
+def test_triple_router_relu_gate_golden(dev):
+    from dynamicvectorquantization_amd import routing as R
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Tape
+    g = load_golden("options")
+    name = "router3_relu"
+    mod = R.TripleGrainFeatureRouter(num_channels=64, normalization_type="group-32", gate_type="2layer-fc-ReLu").to(dev)
+    assert isinstance(mod.gate[1], torch.nn.ReLU)
+    with torch.no_grad():
+        for k, p in mod.named_parameters():
+            p.copy_(T(synth.det_param(name + "." + k, p.shape), dev))
+    heads = [T(synth.det_param(f"{name}.h{lvl}", (2, 64, 2 << lvl, 2 << lvl)) * 3.0, dev).permute(0, 2, 3, 1).contiguous() for lvl in range(3)]
+    with rt.compute_dtype_ctx(torch.float32):
+        tape = Tape()
+        y = mod.fwd(heads, tape)                                   # [B,hc,wc,3] fp32
+        np.testing.assert_allclose(y.cpu().numpy(), g[name + "_y"], rtol=1e-3, atol=1e-4)
+        gout = T(synth.det_param(name + ".gout", tuple(y.shape)), dev)
+        dh = mod.bwd(gout, tape)
+    for lvl in range(3):
+        ref = g[f"{name}_dh{lvl}"]
+        got = dh[lvl].permute(0, 3, 1, 2).float().cpu().numpy()
+        assert float(np.abs(got - ref).max()) <= 2e-3 * float(np.abs(ref).max()), lvl
+    for k, p in mod.named_parameters():
+        ref = g[f"{name}_d.{k}"]
+        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) <= 2e-3 * max(1e-6, float(np.abs(ref).max())), k
+    with pytest.raises(NotImplementedError):                        # the reference's dual router has no ReLU branch either
+        R.DualGrainFeatureRouter(num_channels=64, gate_type="2layer-fc-ReLu")
+
+
+def test_resnet_block_dropout(dev):
+    """dropout sits between swish(norm2(h)) and conv2 (model.py:127).  Eval mode: identical to the block without dropout.  Train mode:
+    equal to the oracle block with the device's keep mask injected (the mask is DEFINED as dvq_dropout's over the flat NHWC
+    activation with the seed the block drew), gradients included."""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import layers as L
+    from dynamicvectorquantization_amd import runtime as rt
+    from oracle import dqvae as odq
+    p_drop, n, c, hw = 0.3, 2, 64, 12
+    mod = L.ResnetBlock(in_channels=c, out_channels=c, temb_channels=0, dropout=p_drop).to(dev)
+    ref0 = L.ResnetBlock(in_channels=c, out_channels=c, temb_channels=0, dropout=0.0).to(dev)
+    assert sorted(k for k, _ in mod.named_parameters()) == sorted(k for k, _ in ref0.named_parameters())
+    with torch.no_grad():
+        for (k, a), (_, b) in zip(mod.named_parameters(), ref0.named_parameters()):
+            a.copy_(T(synth.det_param("drop." + k, a.shape), dev))
+            b.copy_(a)
+    xin = synth.det_param("drop.x", (n, c, hw, hw)) * 4.0
+    gout = synth.det_param("drop.gout", (n, c, hw, hw))
+    with rt.compute_dtype_ctx(torch.float32):
+        mod.eval()
+        ref0.eval()
+        with torch.no_grad():
+            assert torch.equal(mod(T(xin, dev), None), ref0(T(xin, dev), None))
+        mod.train()
+        torch.manual_seed(123)
+        rt._seed_counter[0] = 1000
+        seed = (torch.initial_seed() * 1000003 + 1001) & 0x7FFFFFFFFFFFFFFF        # what the block's next draw will be
+        x = T(xin, dev).requires_grad_(True)
+        y = mod(x, None)
+        (y * T(gout, dev)).sum().backward()
+        ones = torch.ones(n * hw * hw * c, dtype=torch.float32, device=dev)
+        mask_nhwc = K.dropout(ones, p_drop, seed).view(n, hw, hw, c)
+    mask = mask_nhwc.permute(0, 3, 1, 2).contiguous().cpu()
+    keep = float((mask > 0).float().mean())
+    assert abs(keep - (1 - p_drop)) < 0.02 and abs(float(mask.max()) - 1 / (1 - p_drop)) < 1e-6, keep
+    sd = {"b." + k: v.detach().float().cpu().requires_grad_(True) for k, v in mod.state_dict().items()}
+    xr = torch.from_numpy(xin).requires_grad_(True)
+    yr = odq.resnet_block(sd, "b", xr, drop_mask=mask)
+    (yr * torch.from_numpy(gout)).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=2e-3, atol=2e-3)
+    assert float((x.grad.cpu() - xr.grad).abs().max()) <= 2e-3 * float(xr.grad.abs().max())
+    for k, p in mod.named_parameters():
+        ref = sd["b." + k].grad
+        assert float((p.grad.cpu() - ref).abs().max()) <= 3e-3 * max(1e-5, float(ref.abs().max())), k
+    # and the masks differ from call to call
+    y2 = mod(T(xin, dev), None)
+    assert not torch.equal(y2, y.detach())

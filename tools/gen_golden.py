@@ -288,6 +288,42 @@ def gen_blocks():
     np.savez_compressed(os.path.join(GOLD, "blocks.npz"), **out)
 
 
+def gen_options():
+    """constructor options of the reference that no shipped YAML uses: Upsample / Downsample(with_conv=False) (model.py:38-75) and the
+    triple router's gate_type="2layer-fc-ReLu" (RouterTriple.py:23-28).  -> tests/golden/options.npz"""
+    from modules.diffusionmodules.model import Downsample, Upsample
+    from modules.dynamic_modules.RouterTriple import TripleGrainFeatureRouter
+    from oracle import routing as oro
+    out = {}
+    for name, ctor, shape, ofn in (("down_64_pool", lambda: Downsample(64, False), (2, 64, 8, 8), odq.downsample),
+                                   ("up_64_nn", lambda: Upsample(64, False), (2, 64, 6, 6), odq.upsample)):
+        mod = ctor()
+        x = synth.det_param(name + ".x", shape) * 8.0
+        y, dx, _ = run_block(mod, x, name + ".gout")
+        with torch.no_grad():
+            oy = ofn({}, name, t(x)).numpy()
+        check(f"options.{name}.y", y, oy, rtol=1e-6, atol=1e-6)
+        out[name + "_y"], out[name + "_dx"] = y, dx
+    name = "router3_relu"
+    mod = TripleGrainFeatureRouter(num_channels=64, normalization_type="group-32", gate_type="2layer-fc-ReLu")
+    load_det(mod, prefix=name + ".")
+    hs = [t(synth.det_param(f"{name}.h{lvl}", (2, 64, 2 << lvl, 2 << lvl)) * 3.0).requires_grad_(True) for lvl in range(3)]   # coarse, median, fine
+    y = mod(hs[2], hs[1], hs[0])
+    g = synth.det_param(name + ".gout", y.shape)
+    (y * t(g)).sum().backward()
+    sd = {name + "." + k: v.detach() for k, v in mod.state_dict().items()}
+    sd[name + ".gate_type"] = "2layer-fc-ReLu"
+    with torch.no_grad():
+        oy = oro.feature_router(sd, name, [h.detach() for h in hs]).numpy()
+    check("options.router3_relu.y", y.detach().numpy(), oy, rtol=1e-5, atol=1e-5)
+    out[name + "_y"] = y.detach().numpy()
+    for lvl in range(3):
+        out[f"{name}_dh{lvl}"] = hs[lvl].grad.numpy().copy()
+    for n_, p_ in mod.named_parameters():
+        out[f"{name}_d.{n_}"] = p_.grad.numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "options.npz"), **out)
+
+
 # ------------------------------------------------------------------------------------------
 def build_dqvae(ch, resolution, latent, zc, k, attn_enc, attn_dec, ratio=0.5):
     from models.stage1_dynamic.dqvae_dual_entropy import DualGrainVQModel
@@ -934,7 +970,7 @@ def gen_ckpt_layout():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter,stackgpt,sampler,dualformer,ckpt_layout,vq_distances")
+    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter,stackgpt,sampler,dualformer,ckpt_layout,vq_distances,options")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -942,7 +978,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for name in args.only.split(","):
         print(f"[gen] {name}")
-        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter, "stackgpt": gen_stackgpt, "sampler": gen_sampler, "dualformer": gen_dualformer, "ckpt_layout": gen_ckpt_layout, "vq_distances": gen_vq_distances}[name]()
+        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter, "stackgpt": gen_stackgpt, "sampler": gen_sampler, "dualformer": gen_dualformer, "ckpt_layout": gen_ckpt_layout, "vq_distances": gen_vq_distances, "options": gen_options}[name]()
     print("done ->", GOLD)
 
 
