@@ -352,8 +352,6 @@ class Decoder(HipModule):
         self.num_resolutions = len(ch_mult)
         self.num_res_blocks, self.resolution, self.in_ch, self.ch = num_res_blocks, resolution, in_ch, ch
         self.temb_ch, self.give_pre_end, self.out_ch = 0, give_pre_end, out_ch
-        if give_pre_end:
-            raise NotImplementedError("give_pre_end=True is unused by the shipped configs")
         block_in = ch * ch_mult[self.num_resolutions - 1]
         curr_res = resolution // 2 ** (self.num_resolutions - 1)
         self.z_shape = (1, in_ch, curr_res, curr_res)
@@ -380,8 +378,13 @@ class Decoder(HipModule):
         self.norm_out = Normalize(block_in)
         self.conv_out = Conv2d(block_in, out_ch, 3, 1, 1)
         self.position_type = position_type
+        # "learned" and "learned-relative": the reference registers the parameter and its forward has no branch that uses it
+        # (DecoderPositional.py:94-99 against :112-123) -- the same here: present in the state_dict, nothing added, no gradient
         if position_type == "learned":
             self.position_bias = PositionEmbedding2DLearned(n_row=latent_size, feats_dim=in_ch)
+        elif position_type == "learned-relative":
+            self.position_bias = PositionEmbedding2DLearned(n_row=window_size, feats_dim=in_ch)
+            self.window_size, self.window_num = window_size, latent_size // window_size
         elif position_type == "fourier":
             self.position_bias = FourierPositionEmbedding(coord_size=latent_size, hidden_size=in_ch)
         elif position_type == "fourier+learned":
@@ -397,9 +400,10 @@ class Decoder(HipModule):
             mod = self.position_bias if self.position_type == "fourier" else self.position_bias_fourier
             four, pre, coord = mod.bias_hwc(device)
             ctx.update(pre=pre, coord=coord)
-        if self.position_type in ("learned", "fourier+learned"):
-            mod = self.position_bias if self.position_type == "learned" else self.position_bias_learned
-            learned = mod.bias_hwc(h, w)
+        if self.position_type == "fourier+learned":
+            learned = self.position_bias_learned.bias_hwc(h, w)
+        if four is None and learned is None:
+            return None, ctx
         bias = four if learned is None else (learned if four is None else four + learned)
         return bias.contiguous().float(), ctx
 
@@ -407,7 +411,7 @@ class Decoder(HipModule):
         """z NHWC [B,h,w,in_ch] -> rec NHWC [B,H,W,out_ch padded]"""
         b, hh, ww, _ = z.shape
         bias, pctx = self._position_bias(hh, ww, z.device)
-        h = K.add_bias_bcast(z, bias)
+        h = K.add_bias_bcast(z, bias) if bias is not None else z
         h = self.conv_in.fwd(h, _child(tape, "conv_in"))
         h = self.mid.block_1.fwd(h, _child(tape, "m1"))
         h = self.mid.attn_1.fwd(h, _child(tape, "ma"))
@@ -420,14 +424,16 @@ class Decoder(HipModule):
                     h = lvl.attn[i_block].fwd(h, _child(tape, f"u{i_level}a{i_block}"))
             if i_level != 0:
                 h = lvl.upsample.fwd(h, _child(tape, f"u{i_level}us"))
-        h = norm_swish_conv(self.norm_out, self.conv_out, h, tape, "no", "co")
         if tape is not None:
             tape.s["pctx"] = pctx
-        return h
+        if self.give_pre_end:                         # DecoderPositional.py:139-140: the features before norm_out / conv_out
+            return h
+        return norm_swish_conv(self.norm_out, self.conv_out, h, tape, "no", "co")
 
     def bwd(self, g, tape):
-        g = self.conv_out.bwd(g, tape.child("co"))
-        g = self.norm_out.bwd(g, tape.child("no"))
+        if not self.give_pre_end:
+            g = self.conv_out.bwd(g, tape.child("co"))
+            g = self.norm_out.bwd(g, tape.child("no"))
         for i_level in range(self.num_resolutions):
             lvl = self.up[i_level]
             if i_level != 0:
@@ -441,24 +447,24 @@ class Decoder(HipModule):
         g = self.mid.block_1.bwd(g, tape.child("m1"))
         g = self.conv_in.bwd(g, tape.child("conv_in"))
         # position-bias gradients: batch reduction on the GPU, tiny parameter maps on the host side
-        b, hh, ww, c = g.shape
-        gsum = K.sum_batch(g, torch.zeros(hh, ww, c, dtype=torch.float32, device=g.device))
-        pctx = tape.s["pctx"]
         if self.position_type in ("fourier", "fourier+learned"):
+            b, hh, ww, c = g.shape
+            gsum = K.sum_batch(g, torch.zeros(hh, ww, c, dtype=torch.float32, device=g.device))
+            pctx = tape.s["pctx"]
             mod = self.position_bias if self.position_type == "fourier" else self.position_bias_fourier
             mod.accumulate_grad(gsum, pctx["pre"], pctx["coord"])
-        if self.position_type in ("learned", "fourier+learned"):
-            mod = self.position_bias if self.position_type == "learned" else self.position_bias_learned
-            mod.accumulate_grad(gsum)
+            if self.position_type == "fourier+learned":
+                self.position_bias_learned.accumulate_grad(gsum)
         return g
 
     def _fwd_nchw(self, x, tape):
         y = self.fwd(to_nhwc(x, rt.compute_dtype()), tape)
-        return K.nhwc_pad_to_nchw(y, self.out_ch)
+        return K.nhwc_pad_to_nchw(y, y.shape[-1] if self.give_pre_end else self.out_ch)
 
     def _bwd_nchw(self, dy, tape, in_dtype):
         cd = rt.compute_dtype()
-        g = K.nchw_to_nhwc_pad(dy.contiguous().float(), K.vec(cd) * -(-self.out_ch // K.vec(cd)), cd)
+        n_out = dy.shape[1] if self.give_pre_end else self.out_ch
+        g = K.nchw_to_nhwc_pad(dy.contiguous().float(), K.vec(cd) * -(-n_out // K.vec(cd)), cd)
         dx = self.bwd(g, tape)
         return to_nchw(K.cast(dx, in_dtype))
 

@@ -582,8 +582,6 @@ class ResnetBlock(HipModule):
     def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=512):
         super().__init__()
         out_channels = in_channels if out_channels is None else out_channels
-        if conv_shortcut:
-            raise NotImplementedError("conv_shortcut=True is unused by the shipped configs")
         if temb_channels > 0:
             raise NotImplementedError("temb_channels > 0 is unused by the DQ-VAE (temb is None)")
         self.dropout = nn.Dropout(dropout)        # (model.py:97; applied between norm2 + swish and conv2, :127)
@@ -594,7 +592,13 @@ class ResnetBlock(HipModule):
         self.norm2 = Normalize(out_channels)
         self.conv2 = Conv2d(out_channels, out_channels, 3, 1, 1)
         if in_channels != out_channels:
-            self.nin_shortcut = Conv2d(in_channels, out_channels, 1, 1, 0)
+            if conv_shortcut:                         # model.py:103-108: a 3x3 shortcut under the reference's parameter name
+                self.conv_shortcut = Conv2d(in_channels, out_channels, 3, 1, 1)
+            else:
+                self.nin_shortcut = Conv2d(in_channels, out_channels, 1, 1, 0)
+
+    def _shortcut(self):
+        return self.conv_shortcut if self.use_conv_shortcut else self.nin_shortcut
 
     def forward(self, x, temb=None, **kw):
         assert temb is None
@@ -602,7 +606,7 @@ class ResnetBlock(HipModule):
 
     def fwd(self, x, tape, temb=None):
         h1 = norm_swish_conv(self.norm1, self.conv1, x, tape, "norm1", "conv1")
-        sc = self.nin_shortcut.fwd(x, _child(tape, "nin")) if self.in_channels != self.out_channels else x
+        sc = self._shortcut().fwd(x, _child(tape, "nin")) if self.in_channels != self.out_channels else x
         if self.training and self.dropout.p > 0.0:
             # dropout between the activation and conv2: the activation is materialised (no prologue fusion); the keep decisions are
             # a hash of (seed, element index) -- the backward re-derives them from the seed (csrc/dvq_common.h: dvq_hash32)
@@ -620,7 +624,7 @@ class ResnetBlock(HipModule):
             d = K.dropout(d, *tape.s["drop"])
         d = self.norm2.bwd(d, tape.child("norm2"))
         d = self.conv1.bwd(d, tape.child("conv1"))
-        sc = self.nin_shortcut.bwd(dy, tape.child("nin")) if self.in_channels != self.out_channels else dy
+        sc = self._shortcut().bwd(dy, tape.child("nin")) if self.in_channels != self.out_channels else dy
         return self.norm1.bwd(d, tape.child("norm1"), addend=sc)      # skip-path gradient added in the same pass
 
 

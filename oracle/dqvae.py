@@ -44,7 +44,10 @@ def resnet_block(sd, prefix, x, drop_mask=None):
         a = a * drop_mask
     h = conv(sd, prefix + ".conv2", a, padding=1)
     if cin != cout:
-        x = conv(sd, prefix + ".nin_shortcut", x)
+        if prefix + ".conv_shortcut.weight" in sd:       # conv_shortcut=True (model.py:103-108,131-135): a 3x3 instead of the 1x1
+            x = conv(sd, prefix + ".conv_shortcut", x, padding=1)
+        else:
+            x = conv(sd, prefix + ".nin_shortcut", x)
     return x + h
 
 
@@ -133,10 +136,20 @@ def position_bias(sd, latent, prefix="decoder"):
     return four, learned
 
 
-def decoder(sd, z, prefix="decoder"):
+def decoder(sd, z, prefix="decoder", give_pre_end=False):
+    """position_type is read off the state_dict keys: `position_bias_fourier` + `position_bias_learned` = "fourier+learned" (the shipped
+    configs); a lone `position_bias.lff...` = "fourier"; a lone `position_bias.row_embed` = "learned" / "learned-relative", for which the
+    reference's forward (DecoderPositional.py:112-123) has no branch: the parameter exists and NOTHING is added."""
     p = prefix
-    four, learned = position_bias(sd, z.shape[-1], p)
-    h = (z + four) + learned
+    if p + ".position_bias_fourier.lff.ffm.conv.weight" in sd:
+        four, learned = position_bias(sd, z.shape[-1], p)
+        h = (z + four) + learned
+    elif p + ".position_bias.lff.ffm.conv.weight" in sd:
+        lin = torch.linspace(-1, 1, z.shape[-1])
+        coord = torch.cat([lin.view(1, 1, 1, -1).repeat(1, 1, z.shape[-1], 1), lin.view(1, 1, -1, 1).repeat(1, 1, 1, z.shape[-1])], dim=1)
+        h = z + torch.sin(conv(sd, p + ".position_bias.lff.ffm.conv", coord))
+    else:
+        h = z
     h = conv(sd, p + ".conv_in", h, padding=1)
     h = resnet_block(sd, p + ".mid.block_1", h)
     h = attn_block(sd, p + ".mid.attn_1", h)
@@ -151,6 +164,8 @@ def decoder(sd, z, prefix="decoder"):
                 h = attn_block(sd, p + f".up.{lvl}.attn.{blk}", h)
         if lvl != 0:
             h = upsample(sd, p + f".up.{lvl}.upsample", h)
+    if give_pre_end:                                       # DecoderPositional.py:139-140
+        return h
     return conv(sd, p + ".conv_out", swish(group_norm(sd, p + ".norm_out", h)), padding=1)
 
 

@@ -112,3 +112,63 @@ def test_resnet_block_dropout(dev):
     # and the masks differ from call to call
     y2 = mod(T(xin, dev), None)
     assert not torch.equal(y2, y.detach())
+
+
+def test_resnet_block_conv_shortcut_golden(dev):
+    """conv_shortcut=True (model.py:103-108): a 3x3 shortcut registered as `conv_shortcut` instead of the 1x1 `nin_shortcut`"""
+    from dynamicvectorquantization_amd import layers as L
+    from dynamicvectorquantization_amd import runtime as rt
+    g = load_golden("options")
+    name = "res_32_64_cs"
+    mod = L.ResnetBlock(in_channels=32, out_channels=64, conv_shortcut=True, temb_channels=0, dropout=0.0).to(dev)
+    names = sorted(k for k, _ in mod.named_parameters())
+    assert "conv_shortcut.weight" in names and "nin_shortcut.weight" not in names
+    assert names == sorted(k[len(name) + 3:] for k in g.files if k.startswith(name + "_d."))
+    with torch.no_grad():
+        for k, p in mod.named_parameters():
+            p.copy_(T(synth.det_param(name + "." + k, p.shape), dev))
+    x = T(synth.det_param(name + ".x", (2, 32, 8, 8)) * 8.0, dev).requires_grad_(True)
+    with rt.compute_dtype_ctx(torch.float32):
+        y = mod(x, None)
+        (y * T(synth.det_param(name + ".gout", tuple(y.shape)), dev)).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[name + "_y"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[name + "_dx"], rtol=1e-3, atol=1e-3)
+    for k, p in mod.named_parameters():
+        ref = g[f"{name}_d.{k}"]
+        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) <= 2e-3 * max(1e-5, float(np.abs(ref).max())), k
+
+
+@pytest.mark.parametrize("name,ptype,pre", [("dec_learned_pre", "learned", True), ("dec_learnedrel", "learned-relative", False)])
+def test_decoder_options_golden(dev, name, ptype, pre):
+    """give_pre_end=True returns the features before norm_out / conv_out (DecoderPositional.py:139-140); position_type "learned" and
+    "learned-relative" register their embedding and -- like the reference, whose forward has no branch for them -- add nothing: same
+    state_dict keys, the embedding receives no gradient"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.dqvae import Decoder
+    g = load_golden("options")
+    mod = Decoder(ch=32, in_ch=64, out_ch=3, ch_mult=[1, 2], num_res_blocks=1, resolution=16, attn_resolutions=[8], latent_size=8,
+                  window_size=2, position_type=ptype, give_pre_end=pre).to(dev)
+    assert sorted(mod.state_dict().keys()) == list(g[name + "_keys"])
+    with torch.no_grad():
+        for k, p in mod.named_parameters():
+            p.copy_(T(synth.det_param(name + "." + k, p.shape), dev))
+    x = T(synth.det_param(name + ".x", (2, 64, 8, 8)) * 2.0, dev).requires_grad_(True)
+    with rt.compute_dtype_ctx(torch.float32):
+        y = mod(x, None)
+        assert tuple(y.shape) == tuple(g[name + "_y"].shape)
+        (y * T(synth.det_param(name + ".gout", tuple(y.shape)), dev)).sum().backward()
+    s = float(np.abs(g[name + "_y"]).max())
+    assert float(np.abs(y.detach().cpu().numpy() - g[name + "_y"]).max()) <= 1e-3 * s
+    assert float(np.abs(x.grad.cpu().numpy() - g[name + "_dx"]).max()) <= 2e-3 * float(np.abs(g[name + "_dx"]).max())
+    params = dict(mod.named_parameters())
+    for k in ("conv_in.weight", "mid.attn_1.q.weight", "up.1.upsample.conv.weight", "up.0.block.0.conv1.bias"):
+        ref = g[f"{name}_d.{k}"]
+        # (a conv bias in front of a GroupNorm has an analytically zero gradient: both sides hold rounding noise ~1e-7 there)
+        assert float(np.abs(params[k].grad.cpu().numpy() - ref).max()) <= 2e-3 * float(np.abs(ref).max()) + 1e-6, k
+    for k in g[name + "_unused"]:                                 # parameters the reference's forward never touches
+        pg = params[str(k)].grad
+        assert pg is None or float(pg.abs().max()) == 0.0, k
+    assert any("position_bias" in str(k) for k in g[name + "_unused"])
+    with pytest.raises(NotImplementedError):                        # the reference's constructor rejects its own default too
+        Decoder(ch=32, in_ch=64, out_ch=3, ch_mult=[1, 2], num_res_blocks=1, resolution=16, attn_resolutions=[8], latent_size=8,
+                position_type="relative")

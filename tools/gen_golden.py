@@ -248,7 +248,7 @@ def run_block(mod, x, gname, fwd=None):
     y = fwd(mod, xt) if fwd else mod(xt)
     g = synth.det_param(gname, y.shape)
     (y * t(g)).sum().backward()
-    grads = {n: p.grad.numpy().copy() for n, p in mod.named_parameters()}
+    grads = {n: p.grad.numpy().copy() for n, p in mod.named_parameters() if p.grad is not None}
     return y.detach().numpy(), xt.grad.numpy().copy(), grads
 
 
@@ -321,6 +321,35 @@ def gen_options():
         out[f"{name}_dh{lvl}"] = hs[lvl].grad.numpy().copy()
     for n_, p_ in mod.named_parameters():
         out[f"{name}_d.{n_}"] = p_.grad.numpy().copy()
+    # ResnetBlock(conv_shortcut=True) (model.py:103-108) and Decoder options (DecoderPositional.py:94-99,139-140)
+    from modules.diffusionmodules.model import ResnetBlock
+    from modules.dynamic_modules.DecoderPositional import Decoder
+    name = "res_32_64_cs"
+    mod = ResnetBlock(in_channels=32, out_channels=64, conv_shortcut=True, temb_channels=0, dropout=0.0)
+    load_det(mod, prefix=name + ".")
+    x = synth.det_param(name + ".x", (2, 32, 8, 8)) * 8.0
+    y, dx, grads = run_block(mod, x, name + ".gout", lambda m, xx: m(xx, None))
+    sd = {name + "." + k: v.detach() for k, v in mod.state_dict().items()}
+    with torch.no_grad():
+        check(f"options.{name}.y", y, odq.resnet_block(sd, name, t(x)).numpy(), rtol=1e-5, atol=1e-5)
+    out[name + "_y"], out[name + "_dx"] = y, dx
+    for k, v in grads.items():
+        out[name + "_d." + k] = v
+    for name, ptype, pre in (("dec_learned_pre", "learned", True), ("dec_learnedrel", "learned-relative", False)):
+        mod = Decoder(ch=32, in_ch=64, out_ch=3, ch_mult=[1, 2], num_res_blocks=1, resolution=16, attn_resolutions=[8], latent_size=8,
+                      window_size=2, position_type=ptype, give_pre_end=pre)
+        load_det(mod, prefix=name + ".")
+        x = synth.det_param(name + ".x", (2, 64, 8, 8)) * 2.0
+        y, dx, grads = run_block(mod, x, name + ".gout", lambda m, xx: m(xx, None))
+        sd = {name + "." + k: v.detach() for k, v in mod.state_dict().items()}
+        with torch.no_grad():
+            check(f"options.{name}.y", y, odq.decoder(sd, t(x), prefix=name, give_pre_end=pre).numpy(), rtol=1e-4, atol=1e-5)
+        out[name + "_y"], out[name + "_dx"] = y, dx
+        unused = [k for k, p_ in mod.named_parameters() if p_.grad is None]
+        out[name + "_unused"] = np.array(sorted(unused))
+        for k in ("conv_in.weight", "mid.attn_1.q.weight", "up.1.upsample.conv.weight", "up.0.block.0.conv1.bias"):
+            out[name + "_d." + k] = grads[k]
+        out[name + "_keys"] = np.array(sorted(mod.state_dict().keys()))
     np.savez_compressed(os.path.join(GOLD, "options.npz"), **out)
 
 
