@@ -359,8 +359,9 @@ def gn_scale_shift(x, gamma, beta, groups=32, eps=1e-6, stats=None):
 _GN_PARTIALS = os.environ.get("DVQ_GN_PARTIALS", "1") != "0"
 
 
-def gn_backward(x, dy, mean_rstd, gamma, beta, dgamma, dbeta, groups=32, silu=True, addend=None):
-    """dgamma/dbeta (fp32 [C]) are accumulated into; returns dx"""
+def gn_backward(x, dy, mean_rstd, gamma, beta, dgamma, dbeta, groups=32, silu=True, addend=None, fixed_stats=False):
+    """dgamma/dbeta (fp32 [C]) are accumulated into; returns dx.  fixed_stats: mean / rstd are constants, not functions of x (ActNorm:
+    a per-channel affine): the statistic terms of dx are dropped by zeroing the reduced sums, dx = rstd * gamma * dz"""
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
     red = zeros_small((n, groups, 2), torch.float64, x.device)
@@ -369,6 +370,8 @@ def gn_backward(x, dy, mean_rstd, gamma, beta, dgamma, dbeta, groups=32, silu=Tr
         part = torch.empty(lib().dvq_gn_bwd_partial_bytes(n, hw, c), dtype=torch.uint8, device=x.device)
     check(lib().dvq_gn_bwd_reduce(_p(x), _p(dy), dt(x), n, hw, c, groups, _p(mean_rstd), _p(gamma), _p(beta), int(silu),
                                   _p(red), _p(dgamma), _p(dbeta), _p(part), _s()), "dvq_gn_bwd_reduce")
+    if fixed_stats:
+        red.zero_()
     dx = torch.empty_like(x)
     check(lib().dvq_gn_bwd_dx(_p(x), _p(dy), dt(x), n, hw, c, groups, _p(mean_rstd), _p(gamma), _p(beta), int(silu),
                               _p(red), _p(addend), _p(dx), _s()), "dvq_gn_bwd_dx")

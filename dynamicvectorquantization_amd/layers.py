@@ -308,6 +308,59 @@ class BatchNorm2d(HipModule):
         return dx.view(s["shape"])
 
 
+class ActNorm(HipModule):
+    """utils/utils.py:58-140 (the forward direction the PatchGAN uses with use_actnorm=True, modules/discriminator/model.py:30-33):
+    h = scale * (x + loc) per channel, loc / scale initialised from the first training batch (loc = -mean, scale = 1 / (std + 1e-6),
+    unbiased std) and trained afterwards; the LeakyReLU that follows is fused in.  Runs on the normalisation kernels with CONSTANT
+    statistics (mean = -loc, rstd = 1, gamma = scale): forward = dvq_gn_apply, backward = the reduction (d scale = sum dz (x + loc),
+    d loc = scale * sum dz) + dx = scale * dz."""
+
+    EPS = 1e-5
+
+    def __init__(self, num_features, logdet=False, affine=True, allow_reverse_init=False):
+        assert affine
+        super().__init__()
+        if logdet:
+            raise NotImplementedError("ActNorm(logdet=True) belongs to the flow models, not to this repository's path")
+        self.logdet, self.allow_reverse_init, self.num_features = logdet, allow_reverse_init, num_features
+        self.loc = nn.Parameter(torch.zeros(1, num_features, 1, 1))
+        self.scale = nn.Parameter(torch.ones(1, num_features, 1, 1))
+        self.register_buffer("initialized", torch.tensor(0, dtype=torch.uint8))
+        self.act = K.ACT_NONE
+
+    def fwd(self, x, tape, act=None, update_running=True):
+        act = self.act if act is None else act
+        n, h, w, c = x.shape
+        flat = x.view(1, n * h * w, c)
+        if self.training and int(self.initialized.item()) == 0:         # data-dependent initialisation (one host sync, once)
+            with torch.no_grad():
+                f = x.float().reshape(-1, c)
+                self.loc.data.copy_((-f.mean(0)).view(1, c, 1, 1))
+                self.scale.data.copy_((1.0 / (f.std(0) + 1e-6)).view(1, c, 1, 1))
+                self.initialized.fill_(1)
+        cnt = float(n * h * w)
+        mean = -self.loc.detach().view(c).double()
+        stats = (torch.stack([mean, (1.0 - self.EPS) + mean * mean], dim=1) * cnt).view(1, c, 2).contiguous()
+        zero = torch.zeros(c, dtype=torch.float32, device=x.device)
+        y, mr = K.gn_forward(flat, self.scale.detach().view(c), zero, c, self.EPS, act, stats=stats)
+        if tape is not None:
+            tape.s.update(x=flat, mr=mr, act=act, shape=x.shape)
+        return y.view(n, h, w, c)
+
+    def bwd(self, dy, tape, need_dw=True):
+        s = tape.s
+        c = self.num_features
+        dscale = torch.zeros(c, dtype=torch.float32, device=dy.device)
+        dsum = torch.zeros(c, dtype=torch.float32, device=dy.device)
+        zero = torch.zeros(c, dtype=torch.float32, device=dy.device)
+        dx = K.gn_backward(s["x"], dy.view(s["x"].shape), s["mr"], self.scale.detach().view(c), zero, dscale, dsum, c, s["act"],
+                           fixed_stats=True)
+        if need_dw:
+            _grad_buf(self.scale).view(c).add_(dscale)
+            _grad_buf(self.loc).view(c).add_(dsum * self.scale.detach().view(c))
+        return dx.view(s["shape"])
+
+
 _SIDE_AFTER_DGRAD = os.environ.get("DVQ_SIDE_AFTER_DGRAD", "1") != "0"
 
 

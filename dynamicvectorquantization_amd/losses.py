@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import kernels as K
 from . import runtime as rt
 from .config import instantiate_from_config
-from .layers import BatchNorm2d, Conv2d, HipModule, Tape, _child
+from .layers import ActNorm, BatchNorm2d, Conv2d, HipModule, Tape, _child
 
 
 class DummyLoss(nn.Module):
@@ -74,17 +74,17 @@ class NLayerDiscriminator(HipModule):
 
     def __init__(self, input_nc=3, ndf=64, n_layers=3, use_actnorm=False):
         super().__init__()
-        if use_actnorm:
-            raise NotImplementedError("use_actnorm=True is unused by the shipped configs")
+        norm_layer = ActNorm if use_actnorm else BatchNorm2d          # model.py:30-37: ActNorm layers follow convs WITH a bias
+        use_bias = use_actnorm
         kw, padw = 4, 1
         seq = [Conv2d(input_nc, ndf, kw, 2, padw), nn.LeakyReLU(0.2, True)]
         nf_mult = 1
         for n in range(1, n_layers):
             nf_prev, nf_mult = nf_mult, min(2 ** n, 8)
-            seq += [Conv2d(ndf * nf_prev, ndf * nf_mult, kw, 2, padw, bias=False), BatchNorm2d(ndf * nf_mult),
+            seq += [Conv2d(ndf * nf_prev, ndf * nf_mult, kw, 2, padw, bias=use_bias), norm_layer(ndf * nf_mult),
                     nn.LeakyReLU(0.2, True)]
         nf_prev, nf_mult = nf_mult, min(2 ** n_layers, 8)
-        seq += [Conv2d(ndf * nf_prev, ndf * nf_mult, kw, 1, padw, bias=False), BatchNorm2d(ndf * nf_mult),
+        seq += [Conv2d(ndf * nf_prev, ndf * nf_mult, kw, 1, padw, bias=use_bias), norm_layer(ndf * nf_mult),
                 nn.LeakyReLU(0.2, True)]
         seq += [Conv2d(ndf * nf_mult, 1, kw, 1, padw)]
         self.main = nn.Sequential(*seq)
@@ -100,7 +100,7 @@ class NLayerDiscriminator(HipModule):
             elif isinstance(m, Conv2d):
                 plan.append(("conv", i, K.ACT_NONE))
                 i += 1
-            elif isinstance(m, BatchNorm2d):
+            elif isinstance(m, (BatchNorm2d, ActNorm)):
                 assert isinstance(nxt, nn.LeakyReLU)
                 plan.append(("bn", i, K.ACT_LRELU))
                 i += 2
@@ -408,7 +408,9 @@ class VQLPIPSWithDiscriminator(nn.Module):
         self.disc_factor, self.discriminator_weight = disc_factor, disc_weight
         self.disc_conditional, self.disc_adaptive_loss, self.disc_weight_max = disc_conditional, disc_adaptive_loss, disc_weight_max
         if disc_conditional:
-            raise NotImplementedError("disc_conditional=True is unused by the shipped configs")
+            # the reference asserts `not self.disc_conditional` whenever cond is None (vqperceptual_multidisc.py:121-129), and none of its
+            # models passes a cond: the option cannot run there either
+            raise NotImplementedError("disc_conditional=True needs a `cond` input that no model of the reference provides")
         self.budget_loss_config = budget_loss_config
         if budget_loss_config is not None:
             self.budget_loss = instantiate_from_config(budget_loss_config)

@@ -33,8 +33,12 @@ def patchgan(sd, x, n_layers=3, train=True, prefix="main.", running=None):
     idx = 2
     for n in range(1, n_layers + 1):
         stride = 2 if n < n_layers else 1
-        h = F.conv2d(h, sd[f"{prefix}{idx}.weight"], None, stride=stride, padding=1)
+        h = F.conv2d(h, sd[f"{prefix}{idx}.weight"], sd.get(f"{prefix}{idx}.bias"), stride=stride, padding=1)
         bn = f"{prefix}{idx + 1}"
+        if bn + ".loc" in sd:                           # use_actnorm=True (utils/utils.py:58-110): h = scale * (x + loc), already initialised
+            h = F.leaky_relu(sd[bn + ".scale"] * (h + sd[bn + ".loc"]), 0.2)
+            idx += 3
+            continue
         if train:
             mean = h.mean(dim=(0, 2, 3))
             var = h.var(dim=(0, 2, 3), unbiased=False)

@@ -172,3 +172,43 @@ def test_decoder_options_golden(dev, name, ptype, pre):
     with pytest.raises(NotImplementedError):                        # the reference's constructor rejects its own default too
         Decoder(ch=32, in_ch=64, out_ch=3, ch_mult=[1, 2], num_res_blocks=1, resolution=16, attn_resolutions=[8], latent_size=8,
                 position_type="relative")
+
+
+def test_patchgan_actnorm_golden(dev):
+    """NLayerDiscriminator(use_actnorm=True): convs with a bias, ActNorm instead of BatchNorm (same Sequential indices: main.3.loc / .scale /
+    .initialized).  First training batch initialises loc / scale from its statistics; a second batch runs forward + backward through
+    the trained-affine form."""
+    from dynamicvectorquantization_amd import losses as LO
+    from dynamicvectorquantization_amd import runtime as rt
+    g = load_golden("options")
+    name = "disc_actnorm"
+    mod = LO.NLayerDiscriminator(input_nc=3, ndf=16, n_layers=3, use_actnorm=True).to(dev).train()
+    assert sorted(mod.state_dict().keys()) == list(g[name + "_keys"])
+    with torch.no_grad():
+        for k, p in mod.named_parameters():
+            p.copy_(T(synth.det_param(name + "." + k, p.shape), dev))
+    x1 = T(synth.det_param(name + ".x1", (4, 3, 64, 64)) * 2.0, dev)
+    x2 = T(synth.det_param(name + ".x2", (4, 3, 64, 64)) * 2.0 + 0.1, dev).requires_grad_(True)
+    with rt.compute_dtype_ctx(torch.float32):
+        with torch.no_grad():
+            y1 = mod(x1)
+        np.testing.assert_allclose(y1.cpu().numpy(), g[name + "_y1"], rtol=2e-3, atol=2e-4)
+        sd = mod.state_dict()
+        assert int(sd["main.3.initialized"]) == 1
+        for k in g.files:
+            if k.startswith(name + "_init."):
+                kk = k[len(name) + 6:]
+                np.testing.assert_allclose(sd[kk].cpu().numpy(), g[k], rtol=2e-3, atol=2e-5, err_msg=kk)
+                with torch.no_grad():                                  # continue from the reference's initialisation exactly
+                    sd[kk].copy_(T(g[k], dev))
+        y2 = mod(x2)
+        (y2 * T(synth.det_param(name + ".gout", tuple(y2.shape)), dev)).sum().backward()
+    np.testing.assert_allclose(y2.detach().cpu().numpy(), g[name + "_y2"], rtol=2e-3, atol=2e-4)
+    assert float(np.abs(x2.grad.cpu().numpy() - g[name + "_dx2"]).max()) <= 3e-3 * float(np.abs(g[name + "_dx2"]).max())
+    for k, p in mod.named_parameters():
+        ref = g[f"{name}_d.{k}"]
+        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) <= 3e-3 * float(np.abs(ref).max()) + 1e-6, k
+    # eval mode: the same affine (no batch statistics anywhere)
+    mod.eval()
+    with rt.compute_dtype_ctx(torch.float32), torch.no_grad():
+        np.testing.assert_allclose(mod(x2.detach()).cpu().numpy(), g[name + "_y2"], rtol=2e-3, atol=2e-4)

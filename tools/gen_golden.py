@@ -350,6 +350,29 @@ def gen_options():
         for k in ("conv_in.weight", "mid.attn_1.q.weight", "up.1.upsample.conv.weight", "up.0.block.0.conv1.bias"):
             out[name + "_d." + k] = grads[k]
         out[name + "_keys"] = np.array(sorted(mod.state_dict().keys()))
+    # PatchGAN with use_actnorm=True (modules/discriminator/model.py:30-37, utils/utils.py:58-110): data-dependent initialisation on the
+    # first training batch, then a second batch forward + backward through the initialised layers
+    from modules.discriminator.model import NLayerDiscriminator
+    from oracle import losses as olo
+    name = "disc_actnorm"
+    mod = NLayerDiscriminator(input_nc=3, ndf=16, n_layers=3, use_actnorm=True).train()
+    load_det(mod, prefix=name + ".")
+    x1 = synth.det_param(name + ".x1", (4, 3, 64, 64)) * 2.0
+    x2 = synth.det_param(name + ".x2", (4, 3, 64, 64)) * 2.0 + 0.1
+    with torch.no_grad():
+        out[name + "_y1"] = mod(t(x1)).numpy()
+    assert int(mod.main[3].initialized) == 1
+    for k, v in mod.state_dict().items():
+        if k.endswith(".loc") or k.endswith(".scale"):
+            out[f"{name}_init.{k}"] = v.numpy().copy()
+    y, dx, grads = run_block(mod, x2, name + ".gout")
+    sd = {k: v.detach() for k, v in mod.state_dict().items()}
+    with torch.no_grad():
+        check(f"options.{name}.y2", y, olo.patchgan(sd, t(x2)).numpy(), rtol=1e-4, atol=1e-5)
+    out[name + "_y2"], out[name + "_dx2"] = y, dx
+    for k, v in grads.items():
+        out[f"{name}_d.{k}"] = v
+    out[name + "_keys"] = np.array(sorted(mod.state_dict().keys()))
     np.savez_compressed(os.path.join(GOLD, "options.npz"), **out)
 
 
