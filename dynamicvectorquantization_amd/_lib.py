@@ -130,7 +130,7 @@ SIGNATURES = {
     "dvq_rows_dev": (i32, [vp, vp, i32, i64, i64, i64, vp, i32, vp]),
     "dvq_decode_stack_scratch_bytes": (sz, [i64, i64, i64]),
     "dvq_decode_stack_status": (i32, [vp, i64, i64, i64, i32, vp]),
-    "dvq_decode_stack": (i32, [vp, i32, i64, i64, i32, i64, i64, vp, C.c_float, vp, vp, i32, vp]),
+    "dvq_decode_stack": (i32, [vp, i32, i64, i64, i32, i64, i64, vp, C.c_float, vp, vp, i32, vp, vp]),
     "dvq_dropout": (i32, [vp, i32, i64, f32, C.c_uint64, vp, vp]),
     "dvq_dropout_add": (i32, [vp, vp, i32, i64, f32, C.c_uint64, vp, vp]),
     "dvq_fill_f32": (i32, [vp, f32, i64, vp]),

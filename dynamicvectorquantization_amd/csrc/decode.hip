@@ -41,6 +41,9 @@ struct DecParams {
     bf16_t *x, *q, *kn, *vn, *y, *m1;      // kn / vn: the new k / v rows [B][C] (also appended to the caches for later launches)
     unsigned* sync;                    // [0] barrier arrivals, [1] finished workgroups, [2] error flag (barrier timeout)
     unsigned long long* trace;         // optional: s_memrealtime stamps of workgroup 0 at the phase boundaries of the first blocks
+    int layer0;                        // phase kernels (ONLY != 0): the block this launch works on
+    int have_l0;                       //   ... and its pointer record by value (host copy of the table given): no dependent load of the
+    DecLayer l0;                       //   device table at the head of every launch
     int wave_attn;                     // 1: attention with one wave per (sequence, head) item (many items), 0: one workgroup per item
 };
 
@@ -94,6 +97,23 @@ __device__ __forceinline__ unsigned cload4(const void* p) {
 __device__ __forceinline__ void cstore4(void* p, unsigned v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// COH = true: the persistent kernel (exchange through the memory side); false: the phase kernels (a kernel boundary lies between a
+// buffer's producer and its consumers: ordinary cached accesses)
+template <bool COH>
+struct Mem {
+    static __device__ __forceinline__ uint4 ld16(const void* p) {
+        if constexpr (COH) return cload16(p);
+        else return *reinterpret_cast<const uint4*>(p);
+    }
+    static __device__ __forceinline__ unsigned ld4(const void* p) {
+        if constexpr (COH) return cload4(p);
+        else return *reinterpret_cast<const unsigned*>(p);
+    }
+    static __device__ __forceinline__ void st4(void* p, unsigned v) {
+        if constexpr (COH) cstore4(p, v);
+        else *reinterpret_cast<unsigned*>(p) = v;
+    }
+};
 __device__ __forceinline__ void unpack8(uint4 u, float (&v)[8]) {
     v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
     v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
@@ -101,19 +121,21 @@ __device__ __forceinline__ void unpack8(uint4 u, float (&v)[8]) {
     v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
 }
 // thread (n = tid >> 4, m) and its neighbour n + 1 (lane + 16) store their two bf16 values as one coherent dword (n even)
+template <bool COH>
 __device__ __forceinline__ void cstore_pair(bf16_t* row, int col, float v, bool ok) {
     const float hi = __shfl_down(v, 16, 64);
-    if (ok && ((threadIdx.x >> 4) & 1) == 0) cstore4(row + col, pack_bf16x2(v, hi));
+    if (ok && ((threadIdx.x >> 4) & 1) == 0) Mem<COH>::st4(row + col, pack_bf16x2(v, hi));
 }
 
 // rows of x normalised into LDS (bf16 [B][C]); wave w takes rows w, w + 8; a row (C <= 2048) is read ONCE, coherently, into registers
+template <bool COH>
 __device__ __forceinline__ void ln_rows_to_lds(const bf16_t* x, int B, int C, float eps, const float* g, const float* b, bf16_t* xn) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C8 = C >> 3;
     for (int r = wave; r < B; r += DNW) {
         uint4 buf[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) buf[i] = lane + 64 * i < C8 ? cload16(x + (int64_t)r * C + (lane + 64 * i) * 8) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) buf[i] = lane + 64 * i < C8 ? Mem<COH>::ld16(x + (int64_t)r * C + (lane + 64 * i) * 8) : make_uint4(0, 0, 0, 0);
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -162,7 +184,7 @@ __device__ __forceinline__ void gemv_load_w(const bf16_t* __restrict__ W, int K,
         f.w[u] = (active && ks < nks) ? *reinterpret_cast<const uint4*>(wrow + ks * 32) : make_uint4(0, 0, 0, 0);
     }
 }
-template <bool A_LDS>
+template <bool A_LDS, bool COH>
 __device__ __forceinline__ f32x4 gemv_compute(const WFrag& f, int K, const bf16_t* A, int lda, int B) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane & 15, kq = (lane >> 4) * 8;
@@ -174,7 +196,7 @@ __device__ __forceinline__ f32x4 gemv_compute(const WFrag& f, int K, const bf16_
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int ks = wave + u * DNW;
-        av[u] = !(aok && ks < nks) ? z : A_LDS ? *reinterpret_cast<const uint4*>(arow + ks * 32) : cload16(arow + ks * 32);
+        av[u] = !(aok && ks < nks) ? z : A_LDS ? *reinterpret_cast<const uint4*>(arow + ks * 32) : Mem<COH>::ld16(arow + ks * 32);
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -198,7 +220,13 @@ __device__ __forceinline__ float gemv16_reduce(f32x4 acc, float* red) {
     return v;
 }
 
+// ONLY == 0: the persistent form -- all blocks, five phases per block separated by device-wide barriers, exchanged activations
+//            through agent-scope atomics.
+// ONLY == 1 .. 5: ONE phase of ONE block (p.layer0) per launch: the kernel boundary is the barrier and the coherence point (round 4:
+//            a dependent boundary costs 1.2 - 1.9 us on this chip, a 128-workgroup barrier + memory-side exchange 6 - 9 us).
+template <int ONLY>
 __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
+    constexpr bool COH = ONLY == 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);                      // [8][256]
     __shared__ unsigned bflag_s;
@@ -206,7 +234,8 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
     bf16_t* xn = reinterpret_cast<bf16_t*>(smem + DNW * 256 * 4);     // [B][C] normalised rows | attention scratch
     const int tid = threadIdx.x, nwg = gridDim.x, wg = blockIdx.x;
     const int B = p.B, C = p.C, F = p.F, nh = p.nh, hs = C / nh;
-    const int64_t t = *p.t_dev;
+    // the cache row: phases 3 - 5 never need it; phase 1 only for the addresses of its cache stores (read after the weight loads are out)
+    const int64_t t = (ONLY >= 3) ? 0 : *p.t_dev;
     if (t < 0 || t >= p.Tmax) return;                                 // (uniform over the grid: never write outside the caches)
     const int Tlen = (int)t + 1;
     const int n = tid >> 4, m = tid & 15;                             // epilogue role of threads 0 .. 255
@@ -226,16 +255,17 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
     };
     stamp();
     WFrag wf;
-    for (int l = 0; l < p.nlayers; ++l) {
-        const DecLayer L = p.layers[l];
+    for (int l = ONLY ? p.layer0 : 0; l < (ONLY ? p.layer0 + 1 : p.nlayers); ++l) {
+        const DecLayer L = (ONLY != 0 && p.have_l0) ? p.l0 : p.layers[l];
         // ---- (1) LayerNorm 1 + q / k / v ------------------------------------------------------------------------------------
         const int cb = C >> 4;                                        // 16-column blocks per projection
         const int fb = F >> 4;
-        if (l == 0) {                                                 // (later blocks: issued before the previous block's last barrier)
+        if (ONLY == 0 || ONLY == 1) {
+        if (ONLY == 1 || l == 0) {                                    // (later blocks: issued before the previous block's last barrier)
             const int which = wq / cb;
             gemv_load_w(which == 0 ? L.wq : which == 1 ? L.wk : L.wv, C, (wq - which * cb) * 16, wq < 3 * cb, wf);
         }
-        if (wq < 3 * cb) ln_rows_to_lds(p.x + (int64_t)row0 * C, nrows, C, p.eps, L.ln1g, L.ln1b, xn);
+        if (wq < 3 * cb) ln_rows_to_lds<COH>(p.x + (int64_t)row0 * C, nrows, C, p.eps, L.ln1g, L.ln1b, xn);
         __syncthreads();
         stamp();
         for (int blk = wq; blk < 3 * cb; blk += nwq) {
@@ -243,16 +273,20 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
             const bf16_t* W = which == 0 ? L.wq : which == 1 ? L.wk : L.wv;
             const float* bias = which == 0 ? L.bq : which == 1 ? L.bk : L.bv;
             if (blk != wq) gemv_load_w(W, C, n0, true, wf);
-            float v = gemv16_reduce(gemv_compute<true>(wf, C, xn, C, nrows), red);
+            float v = gemv16_reduce(gemv_compute<true, COH>(wf, C, xn, C, nrows), red);
             if (tid < 256 && bias != nullptr) v += bias[n0 + n];
             bf16_t* dst = which == 0 ? p.q : which == 1 ? p.kn : p.vn;
-            cstore_pair(dst + mg * C, n0 + n, v, eok);
+            cstore_pair<COH>(dst + mg * C, n0 + n, v, eok);
             if (eok && which != 0) (which == 1 ? L.kc : L.vc)[((int64_t)mg * p.Tmax + t) * C + n0 + n] = f32_to_bf16(v);
         }
-        stores_done();
-        stamp();
-        if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
-        stamp();
+        }
+        if (ONLY == 0) {
+            stores_done();
+            stamp();
+            if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
+            stamp();
+        }
+        if (ONLY == 0 || ONLY == 2) {
         // ---- (2) attention of the new row over cache rows 0 .. t, one (sequence, head) per work item ------------------------------
         if (p.wave_attn) {
             // many items (B x heads beyond a few per workgroup): one WAVE -- or, while there are waves to spare, a PAIR of waves that
@@ -287,7 +321,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                     const bf16_t* vnr = p.vn + b * C + h * hs;
                     __builtin_amdgcn_wave_barrier();
                     for (int d2 = lane; d2 < (hs >> 1); d2 += 64) {
-                        const unsigned u = cload4(p.q + b * C + h * hs + 2 * d2);
+                        const unsigned u = Mem<COH>::ld4(p.q + b * C + h * hs + 2 * d2);
                         qs[2 * d2] = __uint_as_float(u << 16);
                         qs[2 * d2 + 1] = __uint_as_float(u & 0xffff0000u);
                     }
@@ -302,7 +336,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                                 const bf16_t* kr = kb + (int64_t)r * C;
 #pragma unroll
                                 for (int u = 0; u < 8; ++u)
-                                    kk[w2][u] = (i0 + u >= nv || r >= hi) ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? cload16(knr + (i0 + u) * 8)
+                                    kk[w2][u] = (i0 + u >= nv || r >= hi) ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? Mem<COH>::ld16(knr + (i0 + u) * 8)
                                                                                                                  : *reinterpret_cast<const uint4*>(kr + (i0 + u) * 8);
                             }
 #pragma unroll
@@ -340,7 +374,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const int r = r0 + u * ngrp;
-                            vq[u] = r >= hi ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? cload16(vnr + ch * 8)
+                            vq[u] = r >= hi ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? Mem<COH>::ld16(vnr + ch * 8)
                                                                                    : *reinterpret_cast<const uint4*>(vb + (int64_t)r * C + ch * 8);
                         }
 #pragma unroll
@@ -387,7 +421,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                     const float inv = 1.f / ssum;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        cstore4(p.y + b * C + h * hs + ch * 8 + 2 * j, pack_bf16x2(acc[2 * j] * inv, acc[2 * j + 1] * inv));
+                        Mem<COH>::st4(p.y + b * C + h * hs + ch * 8 + 2 * j, pack_bf16x2(acc[2 * j] * inv, acc[2 * j + 1] * inv));
                 }
             }
         } else {
@@ -406,7 +440,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                 const bf16_t* vnr = p.vn + b * C + h * hs;
                 __syncthreads();
                 for (int d2 = tid; d2 < (hs >> 1); d2 += DTH) {
-                    const unsigned u = cload4(p.q + b * C + h * hs + 2 * d2);
+                    const unsigned u = Mem<COH>::ld4(p.q + b * C + h * hs + 2 * d2);
                     qs[2 * d2] = __uint_as_float(u << 16);
                     qs[2 * d2 + 1] = __uint_as_float(u & 0xffff0000u);
                 }
@@ -418,7 +452,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                         uint4 kk[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u)
-                            kk[u] = i0 + u >= nv ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? cload16(knr + (i0 + u) * 8)
+                            kk[u] = i0 + u >= nv ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? Mem<COH>::ld16(knr + (i0 + u) * 8)
                                                                                          : *reinterpret_cast<const uint4*>(kr + (i0 + u) * 8);
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
@@ -460,7 +494,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int r = r0 + u * ngrp;
-                        vq[u] = r >= Tlen ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? cload16(vnr + ch * 8)
+                        vq[u] = r >= Tlen ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? Mem<COH>::ld16(vnr + ch * 8)
                                                                                    : *reinterpret_cast<const uint4*>(vb + (int64_t)r * C + ch * 8);
                     }
 #pragma unroll
@@ -496,77 +530,99 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                         v0 += part[g * hs + 2 * d2];
                         v1 += part[g * hs + 2 * d2 + 1];
                     }
-                    cstore4(p.y + b * C + h * hs + 2 * d2, pack_bf16x2(v0 * inv, v1 * inv));
+                    Mem<COH>::st4(p.y + b * C + h * hs + 2 * d2, pack_bf16x2(v0 * inv, v1 * inv));
                 }
             }
         }
-        stores_done();
-        stamp();
+        }
+        if (ONLY == 0) {
+            stores_done();
+            stamp();
+        }
         // the two C-column projections have C / 16 items: fewer than workgroups at the p6c18 width -- items of 8 columns then, so
         // that every workgroup streams weights (proj2 at batch 8: 10.0 -> ~6 us per block)
         const int cw = cb < nwq ? 8 : 16, cbw = C / cw;
-        gemv_load_w(L.wo, C, wq * cw, wq < cbw, wf, cw);               // weights of phase 3, in flight across the barrier
-        if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
-        stamp();
+        if (ONLY == 0 || ONLY == 3) gemv_load_w(L.wo, C, wq * cw, wq < cbw, wf, cw);   // weights of phase 3, in flight across the barrier
+        if (ONLY == 0) {
+            if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
+            stamp();
+        }
         // ---- (3) output projection + residual (in place: an element of x is read and written by the same thread pair) -------------
         const bool eokw = eok && n < cw;
+        if (ONLY == 0 || ONLY == 3) {
         for (int blk = wq; blk < cbw; blk += nwq) {
             const int n0 = blk * cw;
             if (blk != wq) gemv_load_w(L.wo, C, n0, true, wf, cw);
-            float v = gemv16_reduce(gemv_compute<false>(wf, C, p.y + (int64_t)row0 * C, C, nrows), red);
+            float v = gemv16_reduce(gemv_compute<false, COH>(wf, C, p.y + (int64_t)row0 * C, C, nrows), red);
             if (tid < 256 && n < cw && L.bo != nullptr) v += L.bo[n0 + n];
             v = bf16_to_f32(f32_to_bf16(v));                          // (rounded like the separate kernels did)
             if (eokw) {
-                const unsigned xo = cload4(p.x + mg * C + n0 + (n & ~1));
+                const unsigned xo = Mem<COH>::ld4(p.x + mg * C + n0 + (n & ~1));
                 v += (n & 1) ? __uint_as_float(xo & 0xffff0000u) : __uint_as_float(xo << 16);
             }
-            cstore_pair(p.x + mg * C, n0 + n, v, eokw);
+            cstore_pair<COH>(p.x + mg * C, n0 + n, v, eokw);
         }
-        stores_done();
-        stamp();
-        gemv_load_w(L.w1, C, wq * 16, wq < fb, wf);
-        if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
-        stamp();
+        }
+        if (ONLY == 0) {
+            stores_done();
+            stamp();
+        }
+        if (ONLY == 0 || ONLY == 4) gemv_load_w(L.w1, C, wq * 16, wq < fb, wf);
+        if (ONLY == 0) {
+            if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
+            stamp();
+        }
         // ---- (4) LayerNorm 2 + fc + GELU -------------------------------------------------------------------------------------
-        if (wq < fb) ln_rows_to_lds(p.x + (int64_t)row0 * C, nrows, C, p.eps, L.ln2g, L.ln2b, xn);
+        if (ONLY == 0 || ONLY == 4) {
+        if (wq < fb) ln_rows_to_lds<COH>(p.x + (int64_t)row0 * C, nrows, C, p.eps, L.ln2g, L.ln2b, xn);
         __syncthreads();
         stamp();
         for (int blk = wq; blk < fb; blk += nwq) {
             const int n0 = blk * 16;
             if (blk != wq) gemv_load_w(L.w1, C, n0, true, wf);
-            float v = gemv16_reduce(gemv_compute<true>(wf, C, xn, C, nrows), red);
+            float v = gemv16_reduce(gemv_compute<true, COH>(wf, C, xn, C, nrows), red);
             if (tid < 256 && L.b1 != nullptr) v += L.b1[n0 + n];
             v = dec_gelu(bf16_to_f32(f32_to_bf16(v)));
-            cstore_pair(p.m1 + (int64_t)mg * F, n0 + n, v, eok);
+            cstore_pair<COH>(p.m1 + (int64_t)mg * F, n0 + n, v, eok);
         }
-        stores_done();
-        stamp();
-        gemv_load_w(L.w2, F, wq * cw, wq < cbw, wf, cw);
-        if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
-        stamp();
+        }
+        if (ONLY == 0) {
+            stores_done();
+            stamp();
+        }
+        if (ONLY == 0 || ONLY == 5) gemv_load_w(L.w2, F, wq * cw, wq < cbw, wf, cw);
+        if (ONLY == 0) {
+            if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
+            stamp();
+        }
         // ---- (5) second projection + residual --------------------------------------------------------------------------------
+        if (ONLY == 0 || ONLY == 5) {
         for (int blk = wq; blk < cbw; blk += nwq) {
             const int n0 = blk * cw;
             if (blk != wq) gemv_load_w(L.w2, F, n0, true, wf, cw);
-            float v = gemv16_reduce(gemv_compute<false>(wf, F, p.m1 + (int64_t)row0 * F, F, nrows), red);
+            float v = gemv16_reduce(gemv_compute<false, COH>(wf, F, p.m1 + (int64_t)row0 * F, F, nrows), red);
             if (tid < 256 && n < cw && L.b2 != nullptr) v += L.b2[n0 + n];
             v = bf16_to_f32(f32_to_bf16(v));
             if (eokw) {
-                const unsigned xo = cload4(p.x + mg * C + n0 + (n & ~1));
+                const unsigned xo = Mem<COH>::ld4(p.x + mg * C + n0 + (n & ~1));
                 v += (n & 1) ? __uint_as_float(xo & 0xffff0000u) : __uint_as_float(xo << 16);
             }
-            cstore_pair(p.x + mg * C, n0 + n, v, eokw);
+            cstore_pair<COH>(p.x + mg * C, n0 + n, v, eokw);
         }
-        stores_done();
-        if (l + 1 < p.nlayers) {
-            const DecLayer& Ln = p.layers[l + 1];
-            const int which = wq / cb;
-            gemv_load_w(which == 0 ? Ln.wq : which == 1 ? Ln.wk : Ln.wv, C, (wq - which * cb) * 16, wq < 3 * cb, wf);
         }
-        stamp();
-        if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
-        stamp();
+        if (ONLY == 0) {
+            stores_done();
+            if (l + 1 < p.nlayers) {
+                const DecLayer& Ln = p.layers[l + 1];
+                const int which = wq / cb;
+                gemv_load_w(which == 0 ? Ln.wq : which == 1 ? Ln.wk : Ln.wv, C, (wq - which * cb) * 16, wq < 3 * cb, wf);
+            }
+            stamp();
+            if (!grid_barrier(p.sync, ++bar * nwg, bflag)) return;
+            stamp();
+        }
     }
+    if (ONLY != 0) return;
     // the last workgroup to get here re-arms the counters for the next launch (every workgroup is past its last barrier)
     __syncthreads();
     if (tid == 0) {
@@ -601,7 +657,7 @@ int dvq_decode_stack_status(const void* scratch, int64_t B, int64_t C, int64_t F
 }
 
 int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C, int n_head, int64_t F, int64_t Tmax, const int64_t* t_dev,
-                     float eps, void* x, void* scratch, int n_workgroups, dvq_stream_t stream) {
+                     float eps, void* x, void* scratch, int n_workgroups, const void* layers_host, dvq_stream_t stream) {
     DVQ_REQUIRE(layers_dev && t_dev && x && scratch && n_layers > 0, DVQ_EINVAL, "dvq_decode_stack: null pointer");
     DVQ_REQUIRE(B > 0 && B <= 64 && C > 0 && C % 32 == 0 && C <= 2048 && F > 0 && F % 32 == 0 && n_head > 0 && C % n_head == 0 &&
                     (C / n_head) % 8 == 0 && C / n_head <= 256 && Tmax > 0 && Tmax <= 12000,
@@ -641,7 +697,7 @@ int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C,
     // twice the items still fit the resident waves -- a pair of waves per item that splits the cache rows (a single wave streams its
     // item's 154 KB of K / V rows at cache row 600 in ~50 us; tools/debug/decode_trace.py).  DVQ_DECODE_WAVE_ATTN=0 / 1 / 2 forces
     // the workgroup path / one wave / a pair.
-    static const int wa_env = [] {
+    const int wa_env = [] {                 // (read per call: tests switch it inside one process)
         const char* e = getenv("DVQ_DECODE_WAVE_ATTN");
         return e != nullptr ? atoi(e) : -1;
     }();
@@ -656,8 +712,40 @@ int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C,
     const int64_t lnb = 16 * C * 2;                                   // the workgroup's own 16 rows
     const int lds = (int)(DNW * 256 * 4 + (att > lnb ? att : lnb));
     DVQ_REQUIRE(lds <= 160 * 1024, DVQ_ESHAPE, "dvq_decode_stack: LDS footprint %d", lds);
-    dvq_ensure_dynamic_lds((const void*)decode_stack_kernel, lds);
-    decode_stack_kernel<<<dim3((unsigned)nwg), dim3(DTH), lds, (hipStream_t)stream>>>(p);
+    // Five launches per block (default) instead of the persistent kernel: the kernel boundary replaces barrier + memory-side exchange
+    // (measured at cache row 600: batch 8 45.6 vs 72.1 us per block, batch 50 90.5 vs 135.6).  DVQ_DECODE_MODE=persistent: one launch
+    const int mode_env = [] {
+        const char* e = getenv("DVQ_DECODE_MODE");
+        return e != nullptr && strcmp(e, "phases") == 0 ? 1 : e != nullptr && strcmp(e, "persistent") == 0 ? 0 : -1;
+    }();
+    const bool phases = mode_env != 0;
+    if (phases) {
+        dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<1>, lds);
+        dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<2>, lds);
+        dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<3>, lds);
+        dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<4>, lds);
+        dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<5>, lds);
+        p.trace = nullptr;
+        // grids: the matrix-vector phases on every CU (each workgroup streams its slice of the weights; no barrier whose cost grows
+        // with the grid), attention on as many workgroups as it has items (workgroup path) or on every CU (wave path)
+        const int gv = cus / MB * MB;
+        const int ga = p.wave_attn ? gv : (int)((nitems < gv ? (nitems + MB - 1) / MB * MB : gv));
+        const DecLayer* host = reinterpret_cast<const DecLayer*>(layers_host);
+        p.have_l0 = host != nullptr;
+        for (int l = 0; l < n_layers; ++l) {
+            p.layer0 = l;
+            if (host != nullptr) p.l0 = host[l];
+            decode_stack_kernel<1><<<dim3((unsigned)gv), dim3(DTH), lds, (hipStream_t)stream>>>(p);
+            decode_stack_kernel<2><<<dim3((unsigned)(ga > 0 ? ga : MB)), dim3(DTH), lds, (hipStream_t)stream>>>(p);
+            decode_stack_kernel<3><<<dim3((unsigned)gv), dim3(DTH), lds, (hipStream_t)stream>>>(p);
+            decode_stack_kernel<4><<<dim3((unsigned)gv), dim3(DTH), lds, (hipStream_t)stream>>>(p);
+            decode_stack_kernel<5><<<dim3((unsigned)gv), dim3(DTH), lds, (hipStream_t)stream>>>(p);
+        }
+        DVQ_CHECK_LAUNCH("decode_stack (phase kernels)");
+        return DVQ_OK;
+    }
+    dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<0>, lds);
+    decode_stack_kernel<0><<<dim3((unsigned)nwg), dim3(DTH), lds, (hipStream_t)stream>>>(p);
     DVQ_CHECK_LAUNCH("decode_stack");
     return DVQ_OK;
 }

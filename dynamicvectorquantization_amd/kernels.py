@@ -990,11 +990,13 @@ def decode_stack_status(scratch, b, c, f, reset=True):
     check(lib().dvq_decode_stack_status(_p(scratch), b, c, f, int(reset), _s()), "dvq_decode_stack_status")
 
 
-def decode_stack(table_dev, n_layers, x, n_head, f, tmax, t_dev, eps, scratch, n_workgroups=0):
-    """one token step of all blocks of a transformer in one persistent kernel; x [B, C] bf16 is updated in place"""
+def decode_stack(table_dev, n_layers, x, n_head, f, tmax, t_dev, eps, scratch, n_workgroups=0, table_host=None):
+    """one token step of all blocks of a transformer (one persistent kernel, or five launches per block); x [B, C] bf16 is updated in
+    place.  table_host: the ctypes array the device table was made from (kept alive by the caller)"""
     b, c = x.shape
+    host = None if table_host is None else C.cast(table_host, C.c_void_p)
     check(lib().dvq_decode_stack(_p(table_dev), n_layers, b, c, n_head, f, tmax, _p(t_dev), float(eps), _p(x), _p(scratch),
-                                 int(n_workgroups), _s()), "dvq_decode_stack")
+                                 int(n_workgroups), host, _s()), "dvq_decode_stack")
     return x
 
 

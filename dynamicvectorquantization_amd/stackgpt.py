@@ -343,7 +343,7 @@ class DecodeState:
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         f = blocks[0].mlp[0].out_features
         ent = {"sig": self._sig, "table": table, "n": len(blocks), "nh": nh, "f": f, "eps": blocks[0].ln1.eps,
-               "scratch": K.decode_stack_scratch(self.b, c, f, dev), "keep": keep}
+               "scratch": K.decode_stack_scratch(self.b, c, f, dev), "keep": keep, "host": arr}
         self._stacks[which] = ent
         return ent
 
@@ -355,7 +355,7 @@ class DecodeState:
                 x = _block_append_dev(blk, x, cache, t_dev)
             return x
         return K.decode_stack(ent["table"], ent["n"], x.contiguous(), ent["nh"], ent["f"], self.max_rows, t_dev, ent["eps"], ent["scratch"],
-                              int(os.environ.get("DVQ_DECODE_WGS", "0")))
+                              int(os.environ.get("DVQ_DECODE_WGS", "0")), table_host=ent["host"])
 
     def _step(self, key, body, inputs):
         """run `body(*static_inputs)`: eagerly the first time (creates weight caches, kernel attributes), then captured once and

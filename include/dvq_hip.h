@@ -475,7 +475,11 @@ int dvq_rows_dev(void* x, void* hidden, int dtype, int64_t B, int64_t C, int64_t
  * as a whole (nothing else may occupy the device's LDS / wave slots to the point of excluding a workgroup: a barrier that is not
  * reached within seconds sets the error word and releases every workgroup, all of which leave the kernel -- read it with
  * dvq_decode_stack_status -- instead of hanging or continuing on stale data).
- * The buffers the phases exchange are accessed with agent-scope atomics (memory side): the barrier needs no cache flush. */
+ * The buffers the phases exchange are accessed with agent-scope atomics (memory side): the barrier needs no cache flush.
+ * Round 4, the default for B <= 16: the same five phases as FIVE LAUNCHES per block (DVQ_DECODE_MODE=phases / persistent): a dependent
+ * kernel boundary costs 1.2 - 1.9 us on this chip, a 128-workgroup barrier plus the memory-side exchange 6 - 9 us per phase.
+ * `layers_host` (may be NULL): a HOST copy of the same array; the phase launches then carry each block's pointers by value instead
+ * of starting with a dependent load of the device table. */
 typedef struct dvq_decode_layer {
     const void *wq, *wk, *wv, *wo, *w1, *w2;          /* bf16 [C][C] x 4, [F][C], [C][F] */
     const float *bq, *bk, *bv, *bo, *b1, *b2;
@@ -488,7 +492,7 @@ size_t dvq_decode_stack_scratch_bytes(int64_t B, int64_t C, int64_t F);
  * barrier, so the rows produced since are invalid; reset != 0 re-arms the counters (on `stream`) so that later launches run. */
 int dvq_decode_stack_status(const void* scratch, int64_t B, int64_t C, int64_t F, int reset, dvq_stream_t stream);
 int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C, int n_head, int64_t F, int64_t Tmax, const int64_t* t_dev,
-                     float eps, void* x, void* scratch, int n_workgroups, dvq_stream_t stream);
+                     float eps, void* x, void* scratch, int n_workgroups, const void* layers_host, dvq_stream_t stream);
 /* nn.Dropout(p) with a counter-based hash RNG: y = x * keep / (1-p); the same (seed) reproduces the mask for the backward */
 int dvq_dropout(const void* x, int dtype, int64_t n, float p, uint64_t seed, void* y, dvq_stream_t stream);
 /* y = x + dropout(a), the decisions of dvq_dropout for the same seed (p = 0: y = x + a): residual add + resid_drop of a block in one pass */

@@ -505,10 +505,11 @@ def test_fused_constrained_sampler_vs_op_by_op(dev):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("mode", ["phases", "persistent"])
 @pytest.mark.parametrize("b,wgs,wattn", [(5, 0, 0), (16, 0, 0), (50, 0, 0), (50, 32, 1), (37, 30, 2), (64, 64, 1), (50, 128, 2), (7, 16, 2)])
-def test_decode_stack_kernel_vs_per_kernel_token_steps(dev, monkeypatch, b, wgs, wattn):
-    """dvq_decode_stack (all blocks of a transformer per token step in one persistent kernel with device-wide barriers) against the
-    per-kernel token steps it replaces: same logits within bf16 rounding over a run of single-row steps, same K/V cache rows, eager and
+def test_decode_stack_kernel_vs_per_kernel_token_steps(dev, monkeypatch, b, wgs, wattn, mode):
+    """dvq_decode_stack (all blocks of a transformer per token step: five fused launches per block -- `phases`, the default -- or ONE
+    persistent kernel with device-wide barriers -- `persistent`) against the per-kernel token steps it replaces: same logits within bf16 rounding over a run of single-row steps, same K/V cache rows, eager and
     replayed from the captured graph; barrier error word stays clear.  b = 50 is the reference's sampling batch
     (scripts/sample_val/sample_dynamic_uncond.py:29): row tiles of 16, and -- with few workgroups (`wgs`) -- the one-wave-per-item
     attention paths (one wave / a pair of waves splitting the cache rows per item); b = 37: a ragged last tile, three tiles."""
@@ -518,6 +519,7 @@ def test_decode_stack_kernel_vs_per_kernel_token_steps(dev, monkeypatch, b, wgs,
     from dynamicvectorquantization_amd import synth
     cfg = dict(SAMPLER_GPT_CFG, n_embd=256, n_head=4, position_layer=2, content_layer=3)
     steps = 14
+    monkeypatch.setenv("DVQ_DECODE_MODE", mode)
     monkeypatch.setenv("DVQ_DECODE_WGS", str(wgs))
     monkeypatch.setenv("DVQ_DECODE_WAVE_ATTN", str(wattn))      # attention by the whole workgroup / one wave / a pair of waves per item
     with rt.compute_dtype_ctx(torch.bfloat16):

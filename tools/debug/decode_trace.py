@@ -23,12 +23,12 @@ t_dev = torch.full((1,), int(os.environ.get("ROW", 600)), dtype=torch.long, devi
 x = bf(B, C)
 nwg = int(os.environ.get("DVQ_DECODE_WGS", "0"))
 for _ in range(3):
-    K.decode_stack(table, NL, x, NH, F, TMAX, t_dev, 1e-5, scratch, nwg)
+    K.decode_stack(table, NL, x, NH, F, TMAX, t_dev, 1e-5, scratch, nwg, table_host=arr)
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 for _ in range(20):
-    K.decode_stack(table, NL, x, NH, F, TMAX, t_dev, 1e-5, scratch, nwg)
+    K.decode_stack(table, NL, x, NH, F, TMAX, t_dev, 1e-5, scratch, nwg, table_host=arr)
 e.record(); torch.cuda.synchronize()
 print(f"{NL} blocks: {s.elapsed_time(e) / 20 * 1e3:.1f} us per launch = {s.elapsed_time(e) / 20 / NL * 1e3:.1f} us per block")
 off = ((4 * B * C + B * F) * 2 + 15) // 16 * 16
