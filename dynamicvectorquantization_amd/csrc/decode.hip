@@ -224,7 +224,9 @@ __device__ __forceinline__ float gemv16_reduce(f32x4 acc, float* red) {
 //            through agent-scope atomics.
 // ONLY == 1 .. 5: ONE phase of ONE block (p.layer0) per launch: the kernel boundary is the barrier and the coherence point (round 4:
 //            a dependent boundary costs 1.2 - 1.9 us on this chip, a 128-workgroup barrier + memory-side exchange 6 - 9 us).
-template <int ONLY>
+// WATT (attention phase launches): 0 = workgroup-per-item path only, 1 = wave paths only (separate register allocations);
+//            -1 = both, chosen at run time
+template <int ONLY, int WATT = -1>
 __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
     constexpr bool COH = ONLY == 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
         }
         if (ONLY == 0 || ONLY == 2) {
         // ---- (2) attention of the new row over cache rows 0 .. t, one (sequence, head) per work item ------------------------------
-        if (p.wave_attn) {
+        if (WATT < 0 ? p.wave_attn != 0 : WATT != 0) {
             // many items (B x heads beyond a few per workgroup): one WAVE -- or, while there are waves to spare, a PAIR of waves that
             // split the cache rows in halves (wave_attn == 2) -- per item, eight waves of a workgroup at a time.  Scores of a wave
             // live in its own LDS strip; a pair folds its two partial (max, sum, accumulator) triples through LDS (flash-decoding
@@ -541,6 +543,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
         }
         // the two C-column projections have C / 16 items: fewer than workgroups at the p6c18 width -- items of 8 columns then, so
         // that every workgroup streams weights (proj2 at batch 8: 10.0 -> ~6 us per block)
+        // (items of 4 columns -- 256 of them on the 256 workgroups of a phase launch -- measured the same: 9.3 us for proj2)
         const int cw = cb < nwq ? 8 : 16, cbw = C / cw;
         if (ONLY == 0 || ONLY == 3) gemv_load_w(L.wo, C, wq * cw, wq < cbw, wf, cw);   // weights of phase 3, in flight across the barrier
         if (ONLY == 0) {
@@ -721,7 +724,8 @@ int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C,
     const bool phases = mode_env != 0;
     if (phases) {
         dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<1>, lds);
-        dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<2>, lds);
+        dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<2, 0>, lds);
+        dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<2, 1>, lds);
         dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<3>, lds);
         dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<4>, lds);
         dvq_ensure_dynamic_lds((const void*)decode_stack_kernel<5>, lds);
@@ -736,7 +740,8 @@ int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C,
             p.layer0 = l;
             if (host != nullptr) p.l0 = host[l];
             decode_stack_kernel<1><<<dim3((unsigned)gv), dim3(DTH), lds, (hipStream_t)stream>>>(p);
-            decode_stack_kernel<2><<<dim3((unsigned)(ga > 0 ? ga : MB)), dim3(DTH), lds, (hipStream_t)stream>>>(p);
+            if (p.wave_attn) decode_stack_kernel<2, 1><<<dim3((unsigned)(ga > 0 ? ga : MB)), dim3(DTH), lds, (hipStream_t)stream>>>(p);
+            else decode_stack_kernel<2, 0><<<dim3((unsigned)(ga > 0 ? ga : MB)), dim3(DTH), lds, (hipStream_t)stream>>>(p);
             decode_stack_kernel<3><<<dim3((unsigned)gv), dim3(DTH), lds, (hipStream_t)stream>>>(p);
             decode_stack_kernel<4><<<dim3((unsigned)gv), dim3(DTH), lds, (hipStream_t)stream>>>(p);
             decode_stack_kernel<5><<<dim3((unsigned)gv), dim3(DTH), lds, (hipStream_t)stream>>>(p);
