@@ -1,10 +1,10 @@
 #!/bin/bash
 # rocprofv3 kernel stats of the K/V-cached sampler at bs 8: kernel time per token step by kernel
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; R="$PWD"; cd /tmp; export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof_smp
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_smp -o s -- python $R/tools/debug/sampling_profile.py > $R/gpurun_out/prof_smp.log 2>&1
+rm -rf $R/gpurun_out/prof_smp /tmp/prof_smp
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_smp -o s -- python $R/tools/debug/sampling_profile.py > $R/gpurun_out/prof_smp.log 2>&1
 cd $R; grep "token steps" gpurun_out/prof_smp.log
-f=$(find gpurun_out/prof_smp -name "*kernel_stats.csv" | head -1)
+f=$(find /tmp/prof_smp -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'P'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
