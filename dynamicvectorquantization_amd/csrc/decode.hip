@@ -41,6 +41,9 @@ struct DecParams {
     bf16_t *x, *q, *kn, *vn, *y, *m1;      // kn / vn: the new k / v rows [B][C] (also appended to the caches for later launches)
     unsigned* sync;                    // [0] barrier arrivals, [1] finished workgroups, [2] error flag (barrier timeout)
     unsigned long long* trace;         // optional: s_memrealtime stamps of workgroup 0 at the phase boundaries of the first blocks
+    int attn_split;                    // phase launches, workgroup-per-item attention: 2 = two workgroups share an item's cache rows and leave
+    float* ypart;                      //   unnormalised fp32 partial results [2][B][C] + (max, sum) pairs ml [2][B][nh][2]; the projection
+    float* ml;                         //   launch merges them while it stages its activations (1: one workgroup per item, bf16 y)
     int layer0;                        // phase kernels (ONLY != 0): the block this launch works on
     int have_l0;                       //   ... and its pointer record by value (host copy of the table given): no dependent load of the
     DecLayer l0;                       //   device table at the head of every launch
@@ -434,7 +437,12 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
             const int lane = tid & 63, wave = tid >> 6;
             const int nv = hs >> 3, ngrp = DTH / nv;
             const int ch = tid % nv, grp = tid / nv;
-            for (int item = wg; item < B * nh; item += nwg) {
+            // SPL workgroups per item (phase launches with few items): each takes a contiguous share of the cache rows [lo, hi)
+            const int SPL = (ONLY == 2 && p.attn_split == 2) ? 2 : 1;
+            const int tshare = SPL == 1 ? Tlen : (((Tlen + 1) >> 1) + 31) & ~31;
+            for (int witem = wg; witem < B * nh * SPL; witem += nwg) {
+                const int item = SPL == 1 ? witem : witem >> 1, spart = SPL == 1 ? 0 : witem & 1;
+                const int lo = spart * tshare, hi = spart == SPL - 1 ? Tlen : min(Tlen, tshare);
                 const int b = item / nh, h = item - b * nh;
                 const bf16_t* kb = L.kc + (int64_t)b * p.Tmax * C + h * hs;
                 const bf16_t* vb = L.vc + (int64_t)b * p.Tmax * C + h * hs;
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                     qs[2 * d2 + 1] = __uint_as_float(u & 0xffff0000u);
                 }
                 __syncthreads();
-                for (int r = tid; r < Tlen; r += DTH) {
+                for (int r = lo + tid; r < hi; r += DTH) {
                     const bf16_t* kr = kb + (int64_t)r * C;
                     float a = 0.f;
                     for (int i0 = 0; i0 < nv; i0 += 8) {              // 8 independent 16-byte loads in flight (a loop over nv serialised them)
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                 }
                 __syncthreads();
                 float mx = -INFINITY;
-                for (int r = tid; r < Tlen; r += DTH) mx = fmaxf(mx, sc[r]);
+                for (int r = lo + tid; r < hi; r += DTH) mx = fmaxf(mx, sc[r]);
                 mx = wave_max(mx);
                 if (lane == 0) rd[wave] = mx;
                 __syncthreads();
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
 #pragma unroll
                 for (int w = 1; w < DNW; ++w) mx = fmaxf(mx, rd[w]);
                 float s = 0.f;
-                for (int r = tid; r < Tlen; r += DTH) {
+                for (int r = lo + tid; r < hi; r += DTH) {
                     const float e = __expf(sc[r] - mx);
                     sc[r] = e;
                     s += e;
@@ -491,18 +499,18 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                 for (int w = 0; w < DNW; ++w) tot += rd[8 + w];
                 const float inv = 1.f / tot;
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int r0 = grp < ngrp ? grp : Tlen; r0 < Tlen; r0 += 4 * ngrp) {     // four rows (independent loads) in flight per lane
+                for (int r0 = grp < ngrp ? lo + grp : hi; r0 < hi; r0 += 4 * ngrp) {   // four rows (independent loads) in flight per lane
                     uint4 vq[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int r = r0 + u * ngrp;
-                        vq[u] = r >= Tlen ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? Mem<COH>::ld16(vnr + ch * 8)
+                        vq[u] = r >= hi ? make_uint4(0, 0, 0, 0) : r == Tlen - 1 ? Mem<COH>::ld16(vnr + ch * 8)
                                                                                    : *reinterpret_cast<const uint4*>(vb + (int64_t)r * C + ch * 8);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int r = r0 + u * ngrp;
-                        const float pt = r < Tlen ? sc[r] : 0.f;
+                        const float pt = r < hi ? sc[r] : 0.f;
                         float vv[8];
                         unpack8(vq[u], vv);
 #pragma unroll
@@ -532,8 +540,13 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
                         v0 += part[g * hs + 2 * d2];
                         v1 += part[g * hs + 2 * d2 + 1];
                     }
-                    Mem<COH>::st4(p.y + b * C + h * hs + 2 * d2, pack_bf16x2(v0 * inv, v1 * inv));
+                    if (SPL == 1) {
+                        Mem<COH>::st4(p.y + b * C + h * hs + 2 * d2, pack_bf16x2(v0 * inv, v1 * inv));
+                    } else {                                          // unnormalised share; an empty share leaves (-inf, 0, zeros)
+                        *reinterpret_cast<float2*>(p.ypart + ((int64_t)spart * B + b) * C + h * hs + 2 * d2) = make_float2(v0, v1);
+                    }
                 }
+                if (SPL == 2 && tid == 0) *reinterpret_cast<float2*>(p.ml + (((int64_t)spart * B + b) * nh + h) * 2) = make_float2(mx, tot);
             }
         }
         }
@@ -553,10 +566,28 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
         // ---- (3) output projection + residual (in place: an element of x is read and written by the same thread pair) -------------
         const bool eokw = eok && n < cw;
         if (ONLY == 0 || ONLY == 3) {
+        const bool merged = ONLY == 3 && p.attn_split == 2;
+        if (merged && wq < cbw) {
+            // the attention launch left two shares per (sequence, head): y = (a0 e^(m0 - m) + a1 e^(m1 - m)) / (l0 e^(m0 - m) + l1 e^(m1 - m)),
+            // built once per workgroup into LDS (bf16, the rounding the one-share form applies) while the weight loads are in flight
+            for (int e = tid; e < nrows * (C >> 1); e += DTH) {
+                const int m_ = e / (C >> 1), c2 = e - m_ * (C >> 1), col = 2 * c2, bb = row0 + m_, hh = col / hs;
+                const float2 s0 = *reinterpret_cast<const float2*>(p.ml + (((int64_t)0 * B + bb) * nh + hh) * 2);
+                const float2 s1 = *reinterpret_cast<const float2*>(p.ml + (((int64_t)1 * B + bb) * nh + hh) * 2);
+                const float mm = fmaxf(s0.x, s1.x);
+                const float f0 = s0.x == -INFINITY ? 0.f : __expf(s0.x - mm), f1 = s1.x == -INFINITY ? 0.f : __expf(s1.x - mm);
+                const float inv = 1.f / (s0.y * f0 + s1.y * f1);
+                const float2 a0 = *reinterpret_cast<const float2*>(p.ypart + ((int64_t)0 * B + bb) * C + col);
+                const float2 a1 = *reinterpret_cast<const float2*>(p.ypart + ((int64_t)1 * B + bb) * C + col);
+                *reinterpret_cast<unsigned*>(xn + m_ * C + col) = pack_bf16x2((a0.x * f0 + a1.x * f1) * inv, (a0.y * f0 + a1.y * f1) * inv);
+            }
+            __syncthreads();
+        }
         for (int blk = wq; blk < cbw; blk += nwq) {
             const int n0 = blk * cw;
             if (blk != wq) gemv_load_w(L.wo, C, n0, true, wf, cw);
-            float v = gemv16_reduce(gemv_compute<false, COH>(wf, C, p.y + (int64_t)row0 * C, C, nrows), red);
+            float v = gemv16_reduce(merged ? gemv_compute<true, COH>(wf, C, xn, C, nrows)
+                                           : gemv_compute<false, COH>(wf, C, p.y + (int64_t)row0 * C, C, nrows), red);
             if (tid < 256 && n < cw && L.bo != nullptr) v += L.bo[n0 + n];
             v = bf16_to_f32(f32_to_bf16(v));                          // (rounded like the separate kernels did)
             if (eokw) {
@@ -641,8 +672,10 @@ __global__ __launch_bounds__(DTH) void decode_stack_kernel(DecParams p) {
 
 extern "C" {
 
+// layout: q | kn | vn | y | m1 (bf16) | sync words + 128 time stamps (DVQ_DECODE_TRACE) | ypart fp32 [2][B][C] | ml fp32 [2][B][C / 8][2]
+static size_t dec_sync_offset(int64_t B, int64_t C, int64_t F) { return (size_t)(((4 * B * C + B * F) * 2 + 15) / 16 * 16); }
 size_t dvq_decode_stack_scratch_bytes(int64_t B, int64_t C, int64_t F) {
-    return (size_t)((4 * B * C + B * F) * 2 + 64 + 1024);         // (+ 128 time stamps of workgroup 0, DVQ_DECODE_TRACE)
+    return dec_sync_offset(B, C, F) + 64 + 1024 + (size_t)(2 * B * C * 4) + (size_t)(2 * B * (C / 8) * 2 * 4);
 }
 
 int dvq_decode_stack_status(const void* scratch, int64_t B, int64_t C, int64_t F, int reset, dvq_stream_t stream) {
@@ -689,7 +722,10 @@ int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C,
     p.vn = p.kn + B * C;
     p.y = p.vn + B * C;
     p.m1 = p.y + B * C;
-    p.sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + ((4 * B * C + B * F) * 2 + 15) / 16 * 16);
+    p.sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + dec_sync_offset(B, C, F));
+    p.ypart = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + dec_sync_offset(B, C, F) + 64 + 1024);
+    p.ml = p.ypart + 2 * B * C;
+    p.attn_split = 1;
     static const bool trace_env = getenv("DVQ_DECODE_TRACE") != nullptr;
     p.trace = trace_env ? reinterpret_cast<unsigned long long*>(p.sync + 8) : nullptr;
     const int nvh = hs >> 3;
@@ -733,7 +769,15 @@ int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C,
         // grids: the matrix-vector phases on every CU (each workgroup streams its slice of the weights; no barrier whose cost grows
         // with the grid), attention on as many workgroups as it has items (workgroup path) or on every CU (wave path)
         const int gv = cus / MB * MB;
-        const int ga = p.wave_attn ? gv : (int)((nitems < gv ? (nitems + MB - 1) / MB * MB : gv));
+        // few items (batch 8 x 16 heads = 128 on 256 CUs): two workgroups per item, each over half the cache rows; the projection
+        // launch merges the two shares (DVQ_DECODE_ATTN_SPLIT=0: one workgroup per item)
+        const bool split_env = [] {
+            const char* e = getenv("DVQ_DECODE_ATTN_SPLIT");
+            return e == nullptr || atoi(e) != 0;
+        }();
+        if (!p.wave_attn && MB == 1 && 2 * nitems <= gv && n_head <= C / 8 && split_env) p.attn_split = 2;
+        const int64_t aitems = nitems * p.attn_split;
+        const int ga = p.wave_attn ? gv : (int)((aitems < gv ? (aitems + MB - 1) / MB * MB : gv));
         const DecLayer* host = reinterpret_cast<const DecLayer*>(layers_host);
         p.have_l0 = host != nullptr;
         for (int l = 0; l < n_layers; ++l) {
