@@ -340,7 +340,29 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void attn_bwd_dq_kernel(Att
         }
     }
     const float lq = qok ? p.lse[(int64_t)bh * T + qrow] * LOG2E : 0.f;
-    const float dq_ = qok ? p.dsum[(int64_t)bh * T + qrow] : 0.f;
+    // dsum[query] = sum_ch dO * O: taken here from the dO fragments this wave holds anyway (+ the matching O fragments) and left in
+    // p.dsum for the dK kernel, which is launched after this one (a separate one-thread-per-row pass over dO and O was 38 us per layer)
+    float dq_ = 0.f;
+    if (HS > 128 || (p.dbg & 16)) {                              // (head size 256 has no registers to spare: the separate pass stays;
+        dq_ = qok ? p.dsum[(int64_t)bh * T + qrow] : 0.f;        //  DVQ_ATTN_DBG=16: A/B against the separate pass)
+    } else {
+        const bf16_t* op = p.o + (rowbase + qrow) * C + h * HS + 8 * half;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            Frag fo, fd;
+            fo.v = ldfrag(op + 16 * s, qok);
+            fd.v = dof[s];
+            const unsigned* a = &fo.u.x;
+            const unsigned* b2 = &fd.u.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dq_ = fmaf(__uint_as_float(a[j] << 16), __uint_as_float(b2[j] << 16), dq_);
+                dq_ = fmaf(__uint_as_float(a[j] & 0xffff0000u), __uint_as_float(b2[j] & 0xffff0000u), dq_);
+            }
+        }
+        dq_ += __shfl_xor(dq_, 32, 64);
+        if (qok && half == 0) p.dsum[(int64_t)bh * T + qrow] = dq_;
+    }
     f32x16 acc[NM];                                              // dQ^T [ch][query]
 #pragma unroll
     for (int mt = 0; mt < NM; ++mt) acc[mt] = zero16();
@@ -612,9 +634,10 @@ static bool split128_env() {
 template <int HS, bool MASKED>
 int launch_bwd_m(const AttnParams& p, dim3 grid, int64_t rows, hipStream_t stream) {
     using G = Geo<HS>;
-    attn_rowdot_kernel<HS><<<dim3((unsigned)cdiv64(rows * p.nh, 256)), dim3(256), 0, stream>>>(p, rows);
+    if (HS > 128 || (p.dbg & 16)) attn_rowdot_kernel<HS><<<dim3((unsigned)cdiv64(rows * p.nh, 256)), dim3(256), 0, stream>>>(p, rows);
     const int lds_kv = 2 * (2 * G::RTILE + 2 * G::CTILE), lds_q = 2 * (2 * G::RTILE + G::CTILE);
     dvq_ensure_dynamic_lds((const void*)attn_bwd_dq_kernel<HS, MASKED>, lds_q);
+    attn_bwd_dq_kernel<HS, MASKED><<<grid, dim3(256), lds_q, stream>>>(p);        // first: it also produces dsum for the dK kernel
     if constexpr (HS > 128) {
         dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 1, MASKED>, lds_kv);
         dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 2, MASKED>, lds_kv);
@@ -631,7 +654,6 @@ int launch_bwd_m(const AttnParams& p, dim3 grid, int64_t rows, hipStream_t strea
         dvq_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel<HS, 0, MASKED>, lds_kv);
         attn_bwd_dkv_kernel<HS, 0, MASKED><<<grid, dim3(256), lds_kv, stream>>>(p);
     }
-    attn_bwd_dq_kernel<HS, MASKED><<<grid, dim3(256), lds_q, stream>>>(p);
     return 0;
 }
 template <int HS>
