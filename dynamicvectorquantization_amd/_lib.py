@@ -93,6 +93,7 @@ SIGNATURES = {
     "dvq_nchw_to_nhwc_pad": (i32, [vp, i64, i64, i64, i64, i64, i32, vp, vp]),
     "dvq_nhwc_pad_to_nchw": (i32, [vp, i32, i64, i64, i64, i64, i64, vp, vp]),
     "dvq_gemm_nt": (i32, [vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp, i32, i32, vp]),
+    "dvq_gemm_nt_res": (i32, [vp, vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp, i32, vp]),
     "dvq_gemm_tn": (i32, [vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64, i32, vp]),
     "dvq_gemm_tn_colsum": (i32, [vp, vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp]),
     "dvq_softmax_rows": (i32, [vp, i32, i64, i64, f32, vp, vp]),

@@ -2666,6 +2666,31 @@ int dvq_gemm_nt(const void* A, const void* B, void* C, int dtype, int64_t M, int
     return DVQ_EINVAL;
 }
 
+// C = alpha * A B^T (+ bias) + R: the input-gradient GEMM of a Linear layer whose result is ADDED to an existing gradient of the same
+// shape (dx of the key projection onto dx of the query projection, ...) -- the sum leaves the fp32 accumulator, rounded once, instead of
+// through a separate add kernel.  R: same dtype / leading dimension / batch stride as C; may alias C.
+int dvq_gemm_nt_res(const void* A, const void* B, void* C, const void* R, int dtype, int64_t M, int64_t N, int64_t K, int64_t lda,
+                    int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, float alpha, const float* bias,
+                    int bias_mode, dvq_stream_t stream) {
+    DVQ_REQUIRE(A && B && C && R, DVQ_EINVAL, "dvq_gemm_nt_res: null pointer");
+    DVQ_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535 && M < (1ll << 31) && N < (1ll << 31), DVQ_ESHAPE,
+                "dvq_gemm_nt_res: bad shape");
+    DVQ_REQUIRE(bias_mode == 0 || bias != nullptr, DVQ_EINVAL, "dvq_gemm_nt_res: bias_mode without bias");
+    NtParams p{};
+    p.A = A; p.B = B; p.C = C; p.R = R; p.bias = bias;
+    p.mode = MODE_GEMM;
+    p.M = (int)M; p.Ncols = (int)N; p.Ktot = (int)K;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.stride = 1; p.KW = 1;
+    p.alpha = alpha; p.bias_mode = bias_mode;
+    p.act_slope = 1.f;
+    p.sA = sA; p.sB = sB; p.sC = sC;
+    if (dtype == DVQ_F32) return launch_nt<float>(p, batch, 0, (hipStream_t)stream);
+    if (dtype == DVQ_BF16) return launch_nt<bf16_t>(p, batch, 0, (hipStream_t)stream);
+    dvq_set_error("dvq_gemm_nt_res: bad dtype");
+    return DVQ_EINVAL;
+}
+
 static int gemm_tn_impl(const void* A, const void* B, float* C, float* colsum, int dtype, int64_t Mred, int64_t I, int64_t J, int64_t lda,
                         int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int impl, dvq_stream_t stream) {
     DVQ_REQUIRE(A && B && C, DVQ_EINVAL, "dvq_gemm_tn: null pointer");

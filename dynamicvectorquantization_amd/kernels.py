@@ -587,11 +587,16 @@ def probe_mfma_rate(random_operands=True):
 
 
 def gemm_nt(a, b, m, n, k, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, alpha=1.0, bias=None, bias_mode=0, out=None,
-            impl=0):
-    """C[b][m][n] = alpha * sum_k A[b][m][k] B[b][n][k] (+bias).  a, b, out are flat device tensors."""
+            impl=0, residual=None):
+    """C[b][m][n] = alpha * sum_k A[b][m][k] B[b][n][k] (+bias) (+residual, same layout as C).  a, b, out are flat device tensors."""
     if out is None:
         out = torch.empty(batch * m * ldc if sc == 0 else batch * sc, dtype=a.dtype, device=a.device)
     es = a.element_size()
+    if residual is not None:
+        _timed("gemm_nt", 2 * batch * m * n * k, es * batch * (m * k + n * k + 2 * m * n), lambda: check(
+            lib().dvq_gemm_nt_res(_p(a), _p(b), _p(out), _p(residual), dt(a), m, n, k, lda, ldb, ldc, batch, sa, sb, sc, alpha, _p(bias),
+                                  bias_mode, _s()), "dvq_gemm_nt_res"))
+        return out
     _timed("gemm_nt", 2 * batch * m * n * k, es * batch * (m * k + n * k + m * n), lambda: check(
         lib().dvq_gemm_nt(_p(a), _p(b), _p(out), dt(a), m, n, k, lda, ldb, ldc, batch, sa, sb, sc, alpha, _p(bias),
                           bias_mode, impl, _s()), "dvq_gemm_nt"))

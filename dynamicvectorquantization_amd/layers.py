@@ -223,7 +223,8 @@ class Linear(nn.Module):
             tape.s.update(x=x2d, w=w)
         return y.view(m, self.out_p)
 
-    def bwd(self, dy, tape, need_dx=True):
+    def bwd(self, dy, tape, need_dx=True, addend=None):
+        """addend [M, in]: an input gradient this layer's is added to (in the GEMM's epilogue: one rounding, no add kernel)"""
         x2d, w = tape.s["x"], tape.s["w"]
         m = x2d.shape[0]
         # dW[o][i] += sum_m dy[m][o] x[m][i]  straight into the fp32 gradient; db = column sums of dy
@@ -246,14 +247,14 @@ class Linear(nn.Module):
         # give 324 / 432 tiles for 256 CUs) and its HBM-bound partial fold overlaps MFMA-bound kernels.  DVQ_LINEAR_SIDE=0: main stream
         if need_dx and m >= 1024 and rt.side_wgrad_enabled() and os.environ.get("DVQ_LINEAR_SIDE", "1") != "0":
             wt = self._wt(w)                                                 # made on the main stream, before the fork
-            dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self.out_p, self.in_features)
+            dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self.out_p, self.in_features, residual=addend)
             rt.run_on_side(wgrad, dy, x2d)      # after the input gradient (forking before it measured the same: 82.3 vs 82.0 ms)
             return dx.view(m, self.in_features)
         wgrad()
         if not need_dx:
             return None
         wt = self._wt(w)                                                     # [in, out_p]
-        dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self.out_p, self.in_features)
+        dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self.out_p, self.in_features, residual=addend)
         return dx.view(m, self.in_features)
 
 

@@ -149,6 +149,11 @@ class CausalSelfAttention(nn.Module):
             dq, dk, dv = K.attn_causal_bwd(q, k, v, s_["y"], dy, s_["lse"], b, t, nh, 1.0 / math.sqrt(hs), p_drop, seed,
                                            drop_mask=s_.get("drop_mask"))
             dx = self.query.bwd(dq, tape.child("q"))
+            if os.environ.get("DVQ_LINEAR_ADDEND", "0") == "1":
+                # accumulating in the GEMM epilogues (dvq_gemm_nt_res) instead of two add kernels measured SLOWER: 82.2 vs 80.9 ms per
+                # step -- the HBM-bound adds overlap the weight-gradient GEMMs on the side stream, the epilogue work does not
+                dx = self.key.bwd(dk, tape.child("k"), addend=dx)
+                return self.value.bwd(dv, tape.child("v"), addend=dx)
             dx = K.add(dx, self.key.bwd(dk, tape.child("k")))
             return K.add(dx, self.value.bwd(dv, tape.child("v")))
         dyf, vf, qf = dy.reshape(-1), v.reshape(-1), q.reshape(-1)

@@ -239,6 +239,11 @@ int dvq_nhwc_pad_to_nchw(const void* in, int dtype, int64_t B, int64_t C, int64_
 int dvq_gemm_nt(const void* A, const void* B, void* C, int dtype, int64_t M, int64_t N, int64_t K, int64_t lda,
                 int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, float alpha,
                 const float* bias, int bias_mode, int impl, dvq_stream_t stream);
+/* the same product ADDED to R (same dtype / layout as C, may alias C): input gradients that accumulate onto an earlier one leave the fp32
+ * accumulator rounded once instead of passing through an add kernel (dx of the k / v projections onto dx of q, stackgpt.py:44-47) */
+int dvq_gemm_nt_res(const void* A, const void* B, void* C, const void* R, int dtype, int64_t M, int64_t N, int64_t K, int64_t lda,
+                    int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, float alpha, const float* bias,
+                    int bias_mode, dvq_stream_t stream);
 int dvq_gemm_tn(const void* A, const void* B, float* C, int dtype, int64_t Mred, int64_t I, int64_t J, int64_t lda,
                 int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int impl,
                 dvq_stream_t stream);
