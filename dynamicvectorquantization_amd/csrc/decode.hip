@@ -769,11 +769,12 @@ int dvq_decode_stack(const void* layers_dev, int n_layers, int64_t B, int64_t C,
         // grids: the matrix-vector phases on every CU (each workgroup streams its slice of the weights; no barrier whose cost grows
         // with the grid), attention on as many workgroups as it has items (workgroup path) or on every CU (wave path)
         const int gv = cus / MB * MB;
-        // few items (batch 8 x 16 heads = 128 on 256 CUs): two workgroups per item, each over half the cache rows; the projection
-        // launch merges the two shares (DVQ_DECODE_ATTN_SPLIT=0: one workgroup per item)
+        // few items (batch 8 x 16 heads = 128 on 256 CUs): DVQ_DECODE_ATTN_SPLIT=1 puts two workgroups on an item, each over half the
+        // cache rows, and the projection launch merges the two shares.  Off by default: in a same-box A/B the attention launch gained
+        // 4.3 us per block and the projection's merge lost 3.9 (5.80 k vs 5.91 k token-steps/s end to end)
         const bool split_env = [] {
             const char* e = getenv("DVQ_DECODE_ATTN_SPLIT");
-            return e == nullptr || atoi(e) != 0;
+            return e != nullptr && atoi(e) != 0;
         }();
         if (!p.wave_attn && MB == 1 && 2 * nitems <= gv && n_head <= C / 8 && split_env) p.attn_split = 2;
         const int64_t aitems = nitems * p.attn_split;
