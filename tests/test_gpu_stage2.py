@@ -520,6 +520,7 @@ def test_decode_stack_kernel_vs_per_kernel_token_steps(dev, monkeypatch, b, wgs,
     cfg = dict(SAMPLER_GPT_CFG, n_embd=256, n_head=4, position_layer=2, content_layer=3)
     steps = 14
     monkeypatch.setenv("DVQ_DECODE_MODE", mode)
+    monkeypatch.setenv("DVQ_DECODE_ATTN_SPLIT", "1" if b in (5, 7) else "0")      # two workgroups per attention item + merge in the projection
     monkeypatch.setenv("DVQ_DECODE_WGS", str(wgs))
     monkeypatch.setenv("DVQ_DECODE_WAVE_ATTN", str(wattn))      # attention by the whole workgroup / one wave / a pair of waves per item
     with rt.compute_dtype_ctx(torch.bfloat16):
