@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
         // {scale, shift} of channel pair (2 q, 2 q + 1) stored as {scale, scale', shift, shift'}: operands of the packed-fp32 instructions
         if (p.gn_ss != nullptr && tid < 128)
             ssl[(tid >> 2) * 4 + (tid & 1) * 2 + ((tid >> 1) & 1)] = p.gn_ss[((int64_t)n * p.Cin + c0) * 2 + tid];
-        __syncthreads();                            // vmcnt(0) + barrier: this chunk's halo (and its first weight stage) have landed
+        dvq_dma_barrier();                          // vmcnt(0) + barrier: this chunk's halo (and its first weight stage) have landed
         if (p.gn_ss != nullptr) {
             // fused GroupNorm + swish: y = z * sigmoid(z), z = x * scale[c] + shift[c], applied in place to the halo tile
             for (int q = tid; q < HROWS * 8; q += NTH) {
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
             load_frags(3, 1);
             mfma_step(0, IDS{}, I0{});
             // every wave has all its reads of this tap behind it and its share of the next tap's weights landed
-            __syncthreads();
+            dvq_dma_barrier();
             if constexpr (!LAST) {
                 set_tap(tap + 1, buf ^ 1);
                 load_frags(0, 0);
@@ -752,7 +752,7 @@ struct WgParams {
     const float* gn_ss;  // optional fused GroupNorm+swish on x: {scale, shift} fp32 [N][Cin][2] (recomputed, never stored)
     float* ws;           // split-K partials: [nsplit][gi*gj][9][128][64] fp32 (+ bias partials behind), or null -> atomics
     float* ws_bias;      // [nsplit][gi*gj][128]
-    int dbg;             // profiling experiments only (DVQ_WGRAD_DBG): 1 = do not wait for the DMA, 2 = skip the MFMA loop, 3 = no DMA
+    int dbg;             // profiling experiments only (DVQ_WGRAD_DBG): 2 = skip the MFMA loop, 3 = no DMA  (1, "do not wait for the DMA", is gone: racy)
 };
 
 // Cross-XCD fp32 atomics resolve at the memory side and cost far more than plain stores: with a workspace every
@@ -894,9 +894,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
             }
         }
     };
-    auto dma_wait = [&]() {
-        if (p.dbg != 1) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); };
 
     // fragment lane constants (transpose reads: lanes 4r..4r+3 of a 16-lane group address row r, 8 B each)
     const int g = lane >> 4, li = lane & 15;

@@ -9,6 +9,7 @@
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "libdvq_hip targets gfx950 (MI355X) only"
+
 #endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -18,6 +19,17 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short bf16_t;  // raw bf16 bits
 
 #define DVQ_WAVE 64
+
+// Barrier that PUBLISHES LDS-DMA data (buffer_load / global_load ... lds issued by this wave).  __syncthreads() alone is a
+// workgroup-scope fence + s_barrier, and that fence waits for LDS traffic (lgkmcnt) only on gfx950: whether the compiler also waits
+// for the DMA pieces depends on its alias guess for the LDS accesses behind the barrier.  A wave that passes with its pieces in flight
+// lets the other waves' ds_reads overtake them (seen once a second process shared the GPU; tools/lint_dma_barriers.py checks the
+// generated code of every kernel).  vmcnt(0) also drains any ordinary global load of the wave: use it where none is meant to stay in
+// flight across the barrier.
+__device__ __forceinline__ void dvq_dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 
 // ---------------------------------------------------------------------------------------------
 // error plumbing (host)

@@ -561,12 +561,12 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
 
     const int nk = (Kcls + BK - 1) / BK;
     issue(0, 0);
-    __syncthreads();                 // drains the DMA (vmcnt(0)) and publishes the stage
+    dvq_dma_barrier();                 // drains the DMA (vmcnt(0)) and publishes the stage
     for (int j = 0; j < nk; ++j) {
         const int buf = j & 1;
         if (j + 1 < nk) issue(j + 1, buf ^ 1);
         mma_stage_swz<T>(smem + buf * GSTAGEB, smem + buf * GSTAGEB + GOPB, acc, wm, wn, lane);
-        __syncthreads();
+        dvq_dma_barrier();
     }
     if ((p.ldc % VN) == 0) {
         nt_epilogue_vec<T>(p, acc, smem, m0, n0, bz, wm, wn, tid, pc);     // LDS-staged, 16-byte global accesses
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_wide_kernel(NtParams p) {
     const int swz = (l31 >> 1) & 7;                           // rows differ from l31 by multiples of 32: same swizzle
     const int nk = (p.Ktot + 63) / 64;
     issue(0, 0);
-    __syncthreads();
+    dvq_dma_barrier();
     for (int j = 0; j < nk; ++j) {
         const int buf = j & 1;
         if (j + 1 < nk) issue(j + 1, buf ^ 1);
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_wide_kernel(NtParams p) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][mt], b[ks & 1][nt], acc[mt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        dvq_dma_barrier();
     }
     // epilogue: the 256 x 256 tile is staged as bf16 (128 KiB = both stages) and leaves in 16-byte stores
     T* st = reinterpret_cast<T*>(smem);
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW == 4 ? 1 : 2) void gemm_n
     using VC = std::integral_constant<int, ND - Q1>;
 #pragma unroll
     for (int q = 0; q < ND; ++q) issue_one(q, 0, 0);
-    __syncthreads();
+    dvq_dma_barrier();
     set_stage(0);
     load_frags(0, 0);
 #pragma unroll
@@ -841,14 +841,14 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW == 4 ? 1 : 2) void gemm_n
         mfma_step(1, VC{});
         load_frags(3, 1);
         mfma_step(0, V0{});
-        __syncthreads();          // every wave has its reads of this slab behind it and its pieces of the next one landed
+        dvq_dma_barrier();          // every wave has its reads of this slab behind it and its pieces of the next one landed
         set_stage(buf ^ 1);
         load_frags(0, 0);
 #pragma unroll
         for (int q = 0; q < Q0; ++q) issue_one(q, jnn, buf);
         mfma_step(1, VA{});
     }
-    __syncthreads();              // (the last iteration's look-ahead reads)
+    dvq_dma_barrier();              // (the last iteration's look-ahead reads)
     // epilogue: the TM x 256 tile is staged as bf16 (512-byte rows, inside the two stages) and leaves in 16-byte stores
     const bool early_act = p.R == nullptr || p.res_mask;     // (residual / gate semantics of nt_epilogue_vec)
 #pragma unroll
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_nt_pipe_kernel(NtParam
     for (int q = 0; q < ND; ++q) issue_one(q, s1, 0);
     if (nk > 1) s1 = advance(s1);                             // slab j + 1
     Slab s2 = nk > 2 ? advance(s1) : s1;                      // slab j + 2
-    __syncthreads();
+    dvq_dma_barrier();
     set_stage(0);
     load_frags(0, 0);
 #pragma unroll
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_nt_pipe_kernel(NtParam
         mfma_step(1, VC{});
         load_frags(3, 1);
         mfma_step(0, V0{});
-        __syncthreads();          // every wave has its reads of this slab behind it and its pieces of the next one landed
+        dvq_dma_barrier();          // every wave has its reads of this slab behind it and its pieces of the next one landed
         set_stage(buf ^ 1);
         load_frags(0, 0);
 #pragma unroll
@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_nt_pipe_kernel(NtParam
         s1 = s2;
         if (j + 3 < nk) s2 = advance(s2);
     }
-    __syncthreads();              // (the last iteration's look-ahead reads and DMA)
+    dvq_dma_barrier();              // (the last iteration's look-ahead reads and DMA)
     // epilogue: the TM x TN tile is staged as bf16 (rows of TN * 2 bytes, inside the two stages) and leaves in 16-byte stores
     const bool early_act = p.R == nullptr || p.res_mask;
 #pragma unroll
@@ -1511,7 +1511,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_tr_kernel(TnParams p) {
     const int nk = (mend - mbeg + BK - 1) / BK;
     if (nk > 0) {
         issue(mbeg, 0);
-        __syncthreads();
+        dvq_dma_barrier();
         for (int j = 0; j < nk; ++j) {
             const int buf = j & 1;
             if (j + 1 < nk) issue(mbeg + (j + 1) * BK, buf ^ 1);
@@ -1542,7 +1542,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_tr_kernel(TnParams p) {
                     for (int nt = 0; nt < 2; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
             }
-            __syncthreads();
+            dvq_dma_barrier();
         }
     }
 

@@ -559,10 +559,12 @@ __global__ __launch_bounds__(64 * NW, 1) void vq_argmin_mfma_pipe_kernel(const X
                 for (int r = 0; r < 16; ++r) retire_row(cur, r, en_carry, c * 32 + l31);
             }
         }
-        __syncthreads();                            // vmcnt(0): stage c + 1 has landed; everyone is done reading stage c
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit (the barrier's fence waits for LDS only): this wave's pieces of stage c + 1 have landed
+        __syncthreads();                            // everyone's have; everyone is done reading stage c
     };
 
     issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if constexpr (!PIPE) {
         for (int c = 0; c < nstage; ++c) stage_body(accA, accA, c, false);
@@ -614,11 +616,22 @@ __global__ __launch_bounds__(64 * NW, 1) void vq_argmin_mfma_pipe_kernel(const X
 // per two k-steps instead of all at the head, the first k-step of a stage multiplies onto an inline zero (no accumulator
 // clears).  ~350 registers: one wave per SIMD by construction.
 // ---------------------------------------------------------------------------------------------
-template <int KSTEPS, int dbg = 0>
-__global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const bf16_t* __restrict__ x, const void* prep_c, int64_t N, int64_t K,
+union Bf16x8U {
+    bf16x8 v;
+    unsigned w[4];
+};
+
+// XT = float (round 4, second half): the same pipeline for fp32 rows.  A wave then owns ONE 32-row block whose two bf16 planes x1, x2
+// (x = x1 + x2 + r, |r| <= 2^-18 |x|) take the places of the two row blocks: x1.e1 + x1.e2 into one accumulator, x2.e1 into the other
+// (3 MFMAs per k-step; x2.e2 is below the bound's 2^-18 term), one retirement per row on their sum -- half the bookkeeping per MFMA of
+// the bf16 form.  128 rows per workgroup.
+template <int KSTEPS, int dbg = 0, typename XT = bf16_t>
+__global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const XT* __restrict__ x, const void* prep_c, int64_t N, int64_t K,
                                                                     int64_t* __restrict__ idx_out, VqWs* ws) {
+    constexpr bool XF32 = std::is_same<XT, float>::value;
+    constexpr int RPW = XF32 ? 32 : 64;       // rows per wave
     constexpr int D = KSTEPS * 16;
-    constexpr int NW = 4;                     // waves per workgroup (64 rows each)
+    constexpr int NW = 4;                     // waves per workgroup (64 rows each; 32 for fp32 rows)
     constexpr int ROWB = D * 2;               // LDS bytes per code row (unpadded, swizzled)
     constexpr int CPR = ROWB / 16;            // 16-byte chunks per row: 8 / 16 / 32
     constexpr int PIECE = 32 * ROWB;          // one bf16 plane of a 32-code stage
@@ -638,7 +651,7 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const bf16_t
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
     const int l31 = lane & 31;
-    const int64_t row0 = (int64_t)blockIdx.x * (64 * NW) + wave * 64;
+    const int64_t row0 = (int64_t)blockIdx.x * (RPW * NW) + wave * RPW;
     // (dbg bit 5: shader-clock stamps of workgroup 7, wave 0 in ws->pad[8 ..]: start, rows loaded, first stage landed, loop done, end)
     unsigned long long stamps[5];
     auto stamp = [&](int i) {
@@ -649,12 +662,34 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const bf16_t
     // ---- x fragments: the bf16 rows ARE the operand (x = x1 exactly).  The loads are issued here, the codebook DMA of the first two
     // stages right behind them, and only then are the norms computed: the 33 MB of rows and the first stages travel together ---------
     bf16x8 xa[2][KSTEPS];
+    float xsq = 0.f;                          // fp32 rows: the lane's share of |x|^2, taken from the unsplit values
+    if constexpr (XF32) {
+        const int64_t r = min(row0 + l31, N - 1);
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        // (rows past N read row N - 1: branch-free loads; their results are never stored)
-        const int64_t r = min(row0 + rb * 32 + l31, N - 1);
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const float4 lo = *reinterpret_cast<const float4*>(x + r * D + ks * 16 + half * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(x + r * D + ks * 16 + half * 8 + 4);
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            Bf16x8U u1, u2;
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) xa[rb][ks] = *reinterpret_cast<const bf16x8*>(x + r * D + ks * 16 + half * 8);
+            for (int j = 0; j < 8; j += 2) {
+                const unsigned p1 = pack_bf16x2(v[j], v[j + 1]);
+                const float r0 = v[j] - __uint_as_float(p1 << 16), r1 = v[j + 1] - __uint_as_float(p1 & 0xffff0000u);
+                u1.w[j >> 1] = p1;
+                u2.w[j >> 1] = pack_bf16x2(r0, r1);
+                xsq = fmaf(v[j], v[j], fmaf(v[j + 1], v[j + 1], xsq));
+            }
+            xa[0][ks] = u1.v;
+            xa[1][ks] = u2.v;
+        }
+    } else {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            // (rows past N read row N - 1: branch-free loads; their results are never stored)
+            const int64_t r = min(row0 + rb * 32 + l31, N - 1);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) xa[rb][ks] = *reinterpret_cast<const bf16x8*>(x + r * D + ks * 16 + half * 8);
+        }
     }
 
     // swizzle of the 16-B chunk index within a code row (conflict-free for the b128 lane groups of a 32-row fragment read)
@@ -690,8 +725,12 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const bf16_t
 #pragma unroll
     for (int i = 0; i < NPOST; ++i) issue_piece(nstage > 1 ? 1 : 0, 1, i, pvo[i]);
     // row norms (rounded up) for the error bound
+    if constexpr (XF32) {
+        xsq += __shfl_xor(xsq, 32, 64);
+        if (half == 0) xnorm[wave * 64 + l31] = sqrtf(xsq) * 1.000001f;
+    }
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < (XF32 ? 0 : 2); ++rb) {
         float sq = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks)
@@ -751,6 +790,7 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const bf16_t
     // of stage c + 1 -- and have a whole stage to land before the next barrier waits for them.
     // stage "-1" retires nothing real: zero accumulators and norm +inf (a score of +inf never wins and never ties)
     float en_prev = __builtin_inff();
+    float en_cur = pv.en[l31];                // stage 0's norms; stage c + 1's are requested inside stage c
     int c = 0;
     constexpr int KB = KSTEPS - 2;            // the barrier precedes k-step KB; NPOST pieces follow it (k-steps KB, KB + 1)
     bf16x8 g1[2], g2[2];                      // fragments of the first two k-steps of the NEXT stage
@@ -763,7 +803,7 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const bf16_t
     };
     auto stage_body = [&](f32x16 (&cur)[2], const f32x16 (&prev)[2]) {
         const int kprev = (c - 1) * 32 + l31;
-        const float en_cur = pv.en[c * 32 + l31];       // requested BEFORE the DMAs below: waiting for it never waits for them (in-order vmcnt)
+        float en_nxt = 0.f;
         // DMA is issued unconditionally (a branch would cut the k-steps' scheduling regions): past the last stage the pieces re-fetch
         // the last stage into a buffer nobody reads any more
         const int c1 = c + 1 < nstage ? c + 1 : nstage - 1, c2 = c + 2 < nstage ? c + 2 : nstage - 1;
@@ -777,11 +817,14 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const bf16_t
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             if (ks == KB) {
-                if constexpr (dbg & 16) {               // (dbg bit 4: no stage barrier -- racy)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                } else {
-                    __syncthreads();                    // vmcnt(0): this wave's pieces of stage c + 1 have landed; all waves are inside stage c
-                }
+                // the wait is EXPLICIT: __syncthreads() is a workgroup-scope fence + s_barrier, and on gfx950 that fence waits for LDS
+                // (lgkmcnt) only -- whether the compiler also waits for the DMA pieces depends on its alias guess for the ds_reads behind
+                // the barrier (the D = 64 float kernel had one stage body of its loop without any vmcnt: another wave's fragment reads
+                // could overtake this wave's pieces; seen as run-to-run different indices once a second process shared the GPU)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of stage c + 1 (and en of stage c) have landed
+                if constexpr (!(dbg & 16)) __syncthreads();             // all waves are inside stage c     (dbg bit 4: no stage barrier -- racy)
+                // |e|^2 of the NEXT stage, requested behind the barrier and before this stage's DMA pieces: a whole stage old at the next wait
+                en_nxt = pv.en[c1 * 32 + l31];
             }
             if (ks + PF < KSTEPS) {
                 if constexpr (dbg & 8) {                // (dbg bit 3: no fragment reads past the first two k-steps)
@@ -801,7 +844,7 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const bf16_t
                 cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0][ks], f1[ks], ks == 0 ? zero : cur[0], 0, 0, 0);
                 cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1][ks], f1[ks], ks == 0 ? zero : cur[1], 0, 0, 0);
                 cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0][ks], f2[ks], cur[0], 0, 0, 0);
-                cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1][ks], f2[ks], cur[1], 0, 0, 0);
+                if constexpr (!XF32) cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1][ks], f2[ks], cur[1], 0, 0, 0);
             } else {
                 const float v = __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, f1[ks][0]) << 16) +
                                 __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, f2[ks][0]) << 16);
@@ -811,8 +854,12 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const bf16_t
             if constexpr (!(dbg & 1)) {
 #pragma unroll
                 for (int j = 0; j < RPK; ++j) {
-                    retire_row(0, ks * RPK + j, prev[0][ks * RPK + j], en_prev, kprev);
-                    retire_row(1, ks * RPK + j, prev[1][ks * RPK + j], en_prev, kprev);
+                    if constexpr (XF32) {
+                        retire_row(0, ks * RPK + j, prev[0][ks * RPK + j] + prev[1][ks * RPK + j], en_prev, kprev);
+                    } else {
+                        retire_row(0, ks * RPK + j, prev[0][ks * RPK + j], en_prev, kprev);
+                        retire_row(1, ks * RPK + j, prev[1][ks * RPK + j], en_prev, kprev);
+                    }
                 }
             }
             // issue order of the k-step: MFMA, the two fragment reads, MFMA, [DMA piece], bookkeeping spread over the rest
@@ -823,17 +870,21 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const bf16_t
             __builtin_amdgcn_sched_group_barrier(0x002, 4 * RPK, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 4 * RPK, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4 * RPK, 0);
+            if constexpr (!XF32) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4 * RPK, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);      // keep the k-steps (and their fillers) in this order
         }
         en_prev = en_cur;
+        en_cur = en_nxt;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) fo[j] = (c % 3) == 2 ? fo[j] - 2 * STAGE : fo[j] + STAGE;      // the next buffer of the ring
         ++c;
     };
 
     stamp(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage 0 and the first pieces of stage 1 (explicit: see the stage barrier)
     __syncthreads();
     stamp(2);
 #pragma unroll
@@ -853,17 +904,23 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const bf16_t
     }
     if (nstage > 0) {
         const int klast = (nstage - 1) * 32 + l31;
+        if constexpr (XF32) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+            for (int r = 0; r < 16; ++r) retire_row(0, r, lastA ? accA[0][r] + accA[1][r] : accB[0][r] + accB[1][r], en_prev, klast);
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) retire_row(rb, r, lastA ? accA[rb][r] : accB[rb][r], en_prev, klast);
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) retire_row(rb, r, lastA ? accA[rb][r] : accB[rb][r], en_prev, klast);
+        }
     }
     stamp(3);
     const float emax = *pv.emax;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the trailing (unread) DMA pieces have landed too
     __syncthreads();                                    // every wave is done with the stage ring: it becomes the selection scratch
     float* scr = reinterpret_cast<float*>(smem) + wave * VQ_SEL_WORDS;
     vq_select_rows_lds<D>(b1[0], b2[0], i1[0], xnorm + wave * 64, emax, lane, row0, N, idx_out, ws, scr);
-    vq_select_rows_lds<D>(b1[1], b2[1], i1[1], xnorm + wave * 64 + 32, emax, lane, row0 + 32, N, idx_out, ws, scr);
+    if constexpr (!XF32) vq_select_rows_lds<D>(b1[1], b2[1], i1[1], xnorm + wave * 64 + 32, emax, lane, row0 + 32, N, idx_out, ws, scr);
     stamp(4);
     if constexpr (dbg & 32) {
         if (blockIdx.x == 7 && tid == 0) {
@@ -1320,13 +1377,18 @@ __global__ __launch_bounds__(256) void vq_distances_kernel(const XT* __restrict_
 }  // namespace
 
 // bf16 rows: 4 waves x 64 rows.  DVQ_VQ_DBG = 1 / 2 / 4 (D = 256 only): timing experiments without bookkeeping / MFMAs / DMA (WRONG results)
-template <int KS, int DB>
-static void vq_launch_rb2_dbg(const bf16_t* x, const void* prep, int64_t N, int64_t K, int64_t* idx, VqWs* ws, hipStream_t s) {
+template <int KS, int DB, typename XT>
+static void vq_launch_rb2_dbg(const XT* x, const void* prep, int64_t N, int64_t K, int64_t* idx, VqWs* ws, hipStream_t s) {
     constexpr int Dc = KS * 16;
     const size_t ring = 3 * (2 * 32 * (Dc * 2)), sel = 4 * VQ_SEL_WORDS * 4;
     const size_t lds = (ring > sel ? ring : sel) + 64 * 4 * 4;          // a ring of three 32-code stages (later: selection scratch) + the row norms
-    dvq_ensure_dynamic_lds((const void*)vq_argmin_mfma_rb2_kernel<KS, DB>, (int)lds);
-    vq_argmin_mfma_rb2_kernel<KS, DB><<<dim3((unsigned)cdiv64(N, 256)), dim3(256), lds, s>>>(x, prep, N, K, idx, ws);
+    const int rows_wg = std::is_same<XT, float>::value ? 128 : 256;
+    dvq_ensure_dynamic_lds((const void*)vq_argmin_mfma_rb2_kernel<KS, DB, XT>, (int)lds);
+    vq_argmin_mfma_rb2_kernel<KS, DB, XT><<<dim3((unsigned)cdiv64(N, rows_wg)), dim3(256), lds, s>>>(x, prep, N, K, idx, ws);
+}
+template <int KS>
+static void vq_launch_rb2(const float* x, const void* prep, int64_t N, int64_t K, int64_t* idx, VqWs* ws, hipStream_t s) {
+    vq_launch_rb2_dbg<KS, 0, float>(x, prep, N, K, idx, ws, s);
 }
 template <int KS>
 static void vq_launch_rb2(const bf16_t* x, const void* prep, int64_t N, int64_t K, int64_t* idx, VqWs* ws, hipStream_t s) {
@@ -1335,18 +1397,18 @@ static void vq_launch_rb2(const bf16_t* x, const void* prep, int64_t N, int64_t 
         return e != nullptr ? atoi(e) : 0;
     }();
     if constexpr (KS == 16) {
-        if (vdbg == 1) return vq_launch_rb2_dbg<KS, 1>(x, prep, N, K, idx, ws, s);
-        if (vdbg == 2) return vq_launch_rb2_dbg<KS, 2>(x, prep, N, K, idx, ws, s);
-        if (vdbg == 4) return vq_launch_rb2_dbg<KS, 4>(x, prep, N, K, idx, ws, s);
-        if (vdbg == 8) return vq_launch_rb2_dbg<KS, 8>(x, prep, N, K, idx, ws, s);
-        if (vdbg == 9) return vq_launch_rb2_dbg<KS, 9>(x, prep, N, K, idx, ws, s);
-        if (vdbg == 16) return vq_launch_rb2_dbg<KS, 16>(x, prep, N, K, idx, ws, s);
-        if (vdbg == 13) return vq_launch_rb2_dbg<KS, 13>(x, prep, N, K, idx, ws, s);
-        if (vdbg == 29) return vq_launch_rb2_dbg<KS, 29>(x, prep, N, K, idx, ws, s);
-        if (vdbg == 32) return vq_launch_rb2_dbg<KS, 32>(x, prep, N, K, idx, ws, s);
-        if (vdbg == 61) return vq_launch_rb2_dbg<KS, 61>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 1) return vq_launch_rb2_dbg<KS, 1, bf16_t>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 2) return vq_launch_rb2_dbg<KS, 2, bf16_t>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 4) return vq_launch_rb2_dbg<KS, 4, bf16_t>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 8) return vq_launch_rb2_dbg<KS, 8, bf16_t>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 9) return vq_launch_rb2_dbg<KS, 9, bf16_t>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 16) return vq_launch_rb2_dbg<KS, 16, bf16_t>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 13) return vq_launch_rb2_dbg<KS, 13, bf16_t>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 29) return vq_launch_rb2_dbg<KS, 29, bf16_t>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 32) return vq_launch_rb2_dbg<KS, 32, bf16_t>(x, prep, N, K, idx, ws, s);
+        if (vdbg == 61) return vq_launch_rb2_dbg<KS, 61, bf16_t>(x, prep, N, K, idx, ws, s);
     }
-    vq_launch_rb2_dbg<KS, 0>(x, prep, N, K, idx, ws, s);
+    vq_launch_rb2_dbg<KS, 0, bf16_t>(x, prep, N, K, idx, ws, s);
 }
 
 template <typename XT>
@@ -1387,11 +1449,12 @@ static int vq_argmin_impl(const XT* x, const float* cb, const void* prep, int64_
                 };
                 if (variant == 1) go(std::true_type{}, std::integral_constant<int, 4>{});
                 else if (variant == 2) go(std::false_type{}, std::integral_constant<int, 4>{});
-                else if (variant == 3 || !std::is_same<XT, bf16_t>::value) go(std::false_type{}, std::integral_constant<int, 8>{});
+                else if (variant == 3) go(std::false_type{}, std::integral_constant<int, 8>{});
                 else {
-                    // bf16 rows (default): 4 waves x 64 rows, one wave per SIMD, bookkeeping pipelined under the MFMAs.
+                    // default: 4 waves, one per SIMD, bookkeeping pipelined under the MFMAs: bf16 rows 64 per wave, fp32 rows 32 per wave
+                    // with their two bf16 planes in the places of the two row blocks.
                     // DVQ_VQ_VARIANT=3 keeps the 8-wave x 32-row kernel (A/B); DVQ_VQ_DBG = 1 / 2 / 4 timing experiments (WRONG results)
-                    if constexpr (std::is_same<XT, bf16_t>::value) vq_launch_rb2<KS>(x, prep, N, K, idx, ws, s);
+                    vq_launch_rb2<KS>(x, prep, N, K, idx, ws, s);
                 }
             }
         };

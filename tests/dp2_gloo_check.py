@@ -9,6 +9,8 @@ replays between them, the initial broadcast from rank 0.
 `python tests/dp2_gloo_check.py dp PORT OUT`   spawns ranks 0 and 1, each training on its half of every batch
 `python tests/dp2_gloo_check.py dp_full PORT OUT`  the same with the complete objective (both optimizers, LPIPS, PatchGAN)
 `python tests/dp2_gloo_check.py single 0 OUT`  one process, no process group, the whole batch
+`python tests/dp2_gloo_check.py dp_s2 | single_s2 ...`  the same pair for the stage-2 (StackGPT) step
+`python tests/dp2_gloo_check.py vq_share 0 -`  two processes + a copy stream share the GPU while the code search must stay exact
 Both write {losses, parameters, Adam moments, EMA buffers} of the autoencoder-only objective (mean losses: the average of the two
 half-batch gradients IS the full-batch gradient) to OUT (rank 0 only); the parent compares."""
 import os
@@ -111,6 +113,14 @@ def run_s2(rank, world, port, out):
         model.learning_rate, model.min_learning_rate, model.training_steps, model.steps_per_epoch = 1e-3, 0.0, 100, 10
         model.train()
         tr = Trainer(model, max_steps=6)
+        if os.environ.get("DVQ_DP2_DIAG"):              # forward-only repeats: is a difference there before any training, and does it move within a process?
+            for rep in range(3):
+                with torch.no_grad():
+                    _, z0 = model.encode_to_z(x)
+                    o0 = model.shared_step({"image": x}, 0)
+                say(f"diag rank {rank}/{world} rep {rep}: codes {[int(z0[k].double().sum()) for k in sorted(z0) if z0[k] is not None]} "
+                    f"content {float(o0['content_loss']):.8f} position {float(o0['position_loss']):.8f} "
+                    f"psum {float(sum(p.double().abs().sum() for p in model.transformer.parameters())):.6f}")
         losses = [float(tr.train_step({"image": x}, i)[0]) for i in range(5)]
         torch.cuda.synchronize()
     with torch.no_grad():
@@ -131,8 +141,52 @@ def run_s2(rank, world, port, out):
     say(f"DP2_RANK_OK {rank}")
 
 
+def run_vq_share(rank, world, port, out):
+    """the code search while the GPU is SHARED: a second process runs the same loop and a side stream of this one streams large
+    copies, so DMA latencies inside the kernels are long and irregular.  Every result must still be the exact argmin.  (What this
+    caught: the D = 64 search kernels passed a stage barrier with their own LDS-DMA pieces in flight -- correct on an idle GPU, a few
+    near-tied rows wrong under load.  The structural guard is tools/lint_dma_barriers.py; this is the stress test beside it.)"""
+    import numpy as np
+    import torch
+    torch.cuda.set_device(0)
+    from dynamicvectorquantization_amd import kernels as K
+    from oracle import vq as ovq
+    dev = torch.device("cuda:0")
+    hog_src = torch.empty(64 << 20, dtype=torch.float32, device=dev).normal_()
+    hog_dst = torch.empty_like(hog_src)
+    side = torch.cuda.Stream()
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    ncalls = 0
+    for (n, d, k) in ((2048, 64, 512), (4096 + 96, 64, 1024), (2048, 128, 512), (4096, 256, 1024)):
+        g = torch.Generator().manual_seed(1000 * n + d + rank)
+        x = torch.randn(n, d, generator=g)
+        cb = (torch.randn(k, d, generator=g) * 0.7)
+        cb[7] = cb[3]                                                  # an exact tie: the lowest index must win
+        xb = x.to(torch.bfloat16)
+        want32 = torch.from_numpy(ovq.argmin_exact(x.numpy(), cb.numpy())).to(dev)
+        want16 = torch.from_numpy(ovq.argmin_exact(xb.float().numpy(), cb.numpy())).to(dev)
+        x, xb, cb = x.to(dev), xb.to(dev), cb.to(dev)
+        prep = K.vq_prepare(cb)
+        for rep in range(60):
+            if rep % 4 == 0:
+                with torch.cuda.stream(side):
+                    hog_dst.copy_(hog_src)
+            bad += (K.vq_argmin(x, cb, prep) != want32).sum()
+            bad += (K.vq_argmin(xb, cb, prep) != want16).sum()
+            ncalls += 2
+    torch.cuda.synchronize()
+    say(f"vq_share rank {rank}: {ncalls} searches, {int(bad)} wrong indices")
+    assert int(bad) == 0, int(bad)
+    say(f"DP2_RANK_OK {rank}")
+
+
 def main():
     mode, port, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    if mode == "vq_share":
+        import torch.multiprocessing as mp
+        mp.spawn(run_vq_share, args=(2, port, out), nprocs=2, join=True)
+        say("DP2_OK")
+        return
     if mode == "single_s2":
         run_s2(0, 1, 0, out)
     elif mode == "dp_s2":

@@ -73,12 +73,26 @@ def test_two_rank_stage2_step_equals_single_process(dev, tmp_path):
         assert r.returncode == 0 and "DP2_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
         outs[mode] = np.load(out)
     dp, one = outs["dp_s2"], outs["single_s2"]
-    np.testing.assert_allclose(dp["losses"], one["losses"], rtol=2e-3, atol=2e-4)
+    # step 0 is the same arithmetic up to summation order; afterwards Adam (lr 1e-3, untrained weights) amplifies the fp32 ordering noise of
+    # the atomically summed weight gradients step by step (two single-process runs differ by the same few 1e-3)
+    np.testing.assert_allclose(dp["losses"][0], one["losses"][0], rtol=1e-5)
+    np.testing.assert_allclose(dp["losses"], one["losses"], rtol=1e-2, atol=1e-3)
     assert dp["losses"][-1] < dp["losses"][0]
     steps, lr, n_checked = dp["losses"].shape[0], 1e-3, 0
     for k in one.files:
         if k.startswith("p:"):
             a, b = dp[k].astype(np.float64), one[k].astype(np.float64)
-            assert np.linalg.norm(a - b) <= 2e-3 * np.linalg.norm(b) + 0.05 * lr * steps * a.size ** 0.5, k
+            assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b) + 0.1 * lr * steps * a.size ** 0.5, k
             n_checked += 1
     assert n_checked > 40
+
+
+@pytest.mark.gpu
+def test_vq_argmin_exact_while_gpu_is_shared(dev, tmp_path):
+    """two processes and a bandwidth-hungry copy stream share the GPU: every code search (fp32 and bf16 rows, D = 64 / 128 / 256,
+    a ragged row count, an exactly tied pair of codes) still returns the oracle's exact argmin.  Regression test of the LDS-DMA
+    barrier race (csrc/dvq_common.h dvq_dma_barrier, tools/lint_dma_barriers.py)."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "dp2_gloo_check.py"), "vq_share", "0", str(tmp_path / "x")],
+                       env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DP2_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("0 wrong indices") == 2, r.stdout[-1000:]
