@@ -73,16 +73,15 @@ def test_two_rank_stage2_step_equals_single_process(dev, tmp_path):
         assert r.returncode == 0 and "DP2_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
         outs[mode] = np.load(out)
     dp, one = outs["dp_s2"], outs["single_s2"]
-    # step 0 is the same arithmetic up to summation order; afterwards Adam (lr 1e-3, untrained weights) amplifies the fp32 ordering noise of
-    # the atomically summed weight gradients step by step (two single-process runs differ by the same few 1e-3)
-    np.testing.assert_allclose(dp["losses"][0], one["losses"][0], rtol=1e-5)
-    np.testing.assert_allclose(dp["losses"], one["losses"], rtol=1e-2, atol=1e-3)
+    # same arithmetic up to the summation order of the atomically accumulated weight gradients: measured agreement 5e-7 over all five
+    # steps (a 2.5e-5 difference at step 0 was how the LDS-DMA barrier race of the D = 64 code search showed itself)
+    np.testing.assert_allclose(dp["losses"], one["losses"], rtol=2e-5)
     assert dp["losses"][-1] < dp["losses"][0]
     steps, lr, n_checked = dp["losses"].shape[0], 1e-3, 0
     for k in one.files:
         if k.startswith("p:"):
             a, b = dp[k].astype(np.float64), one[k].astype(np.float64)
-            assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b) + 0.1 * lr * steps * a.size ** 0.5, k
+            assert np.linalg.norm(a - b) <= 2e-3 * np.linalg.norm(b) + 0.05 * lr * steps * a.size ** 0.5, k
             n_checked += 1
     assert n_checked > 40
 
