@@ -115,8 +115,11 @@ def walk(lines):
 def main():
     sources = sys.argv[1:] or [s for s in B.SOURCES if "load_lds" in open(os.path.join(B.CSRC, s)).read()]
     bad = 0
+    import concurrent.futures as cf
+    with cf.ThreadPoolExecutor(max_workers=len(sources)) as ex:          # the device assemblies are independent hipcc runs
+        asm = dict(zip(sources, ex.map(asm_of, sources)))
     for src in sources:
-        lines = asm_of(src)
+        lines = asm[src]
         starts = [(i, FUNC.match(l).group(1)) for i, l in enumerate(lines) if FUNC.match(l)]
         for j, (i0, name) in enumerate(starts):
             i1 = starts[j + 1][0] if j + 1 < len(starts) else len(lines)
