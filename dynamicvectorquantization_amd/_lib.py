@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdvq_hip.so")
+# DVQ_USE_PROBES_LIB=1 (tools/debug/ only): the -DDVQ_PROBES build with the wrong-result timing experiments (build.py --probes)
+LIB_PATH = os.path.join(HERE, "libdvq_hip_probes.so" if os.environ.get("DVQ_USE_PROBES_LIB", "0") == "1" else "libdvq_hip.so")
 
 F32, BF16 = 0, 1
 
@@ -85,6 +86,7 @@ SIGNATURES = {
     "dvq_maxpool2x2": (i32, [vp, i32, i64, i64, i64, i64, vp, vp]),
     "dvq_maxpool2x2_relu_bwd": (i32, [vp, vp, vp, i32, i64, i64, i64, i64, vp, vp]),
     "dvq_lpips_head": (i32, [vp, vp, vp, i32, i64, i64, i64, vp, f32, vp, vp]),
+    "dvq_lpips_head_drop": (i32, [vp, vp, vp, i32, i64, i64, i64, vp, f32, vp, f32, C.c_uint64, vp]),
     "dvq_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
     "dvq_conv2d_wgrad_oihw": (i32, [C.POINTER(ConvDesc), vp, vp, i64, i64, vp, vp, i32, vp]),
     "dvq_pack_weights_multi": (i32, [vp, i64, i64, vp]),

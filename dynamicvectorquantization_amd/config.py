@@ -175,3 +175,40 @@ def to_plain(o):
     if isinstance(o, list):
         return [to_plain(v) for v in o]
     return o
+
+
+# ---------------------------------------------------------------------------------------------
+# the shipped stage-1 YAML as the single source of a DQ-VAE's constructor arguments (bench.py, __graft_entry__.smoke)
+# ---------------------------------------------------------------------------------------------
+REPO_ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+STAGE1_DUAL_ENTROPY_YAML = "configs/stage1/dqvae-entropy-dual-r05_imagenet.yml"
+
+
+def stage1_config(yaml_path=STAGE1_DUAL_ENTROPY_YAML, dotlist=(), batch_size=None, objective="full", geometry=None) -> Cfg:
+    """`train.py --base <yaml> key=value ...` as a function (train.py:109-111): load the YAML, merge the dotlist.
+
+    batch_size : the one override a benchmark applies (`data.params.batch_size`)
+    objective  : "full" = the file's two-optimizer objective; "ae" = its LPIPS and GAN terms switched off
+                 (perceptual_weight = disc_factor = 0: L1 + codebook); "none" = modules.losses.vqperceptual.DummyLoss
+    geometry   : dict(ch, resolution, latent, zc, k, attn_enc, attn_dec) -- the shrunken / 64 x 64 variants the golden fixtures and
+                 smoke() use; every other value stays the file's
+    """
+    import os
+    path = yaml_path if os.path.isabs(yaml_path) else os.path.join(REPO_ROOT, yaml_path)
+    dot = list(dotlist)
+    if batch_size is not None:
+        dot.append(f"data.params.batch_size={int(batch_size)}")
+    if objective == "ae":
+        dot += ["model.params.lossconfig.params.perceptual_weight=0.0", "model.params.lossconfig.params.disc_factor=0.0"]
+    c = merge(load_yaml(path), from_dotlist(dot))
+    if objective == "none":
+        c.model.params.lossconfig = Cfg(target="modules.losses.vqperceptual.DummyLoss")
+    if geometry:
+        g, p = geometry, c.model.params
+        p.encoderconfig.params.update(ch=g["ch"], resolution=g["resolution"], z_channels=g["zc"], attn_resolutions=list(g["attn_enc"]))
+        p.decoderconfig.params.update(ch=g["ch"], in_ch=g["zc"], resolution=g["resolution"], attn_resolutions=list(g["attn_dec"]),
+                                      latent_size=g["latent"])
+        p.vqconfig.params.update(codebook_size=g["k"], codebook_dim=g["zc"])
+        p.quant_before_dim = p.quant_after_dim = g["zc"]
+        p.image_size = g["resolution"]
+    return c

@@ -679,10 +679,7 @@ int fill_params(AttnParams& p, const char* who, int dtype, int64_t B, int64_t T,
     p.inv_keep = 1.f / (1.f - p_drop);
     p.thr = (unsigned)((double)p_drop * 4294967296.0);
     dvq_dropout_seed(seed, &p.rm, &p.ra);
-    static const int dbg = [] {
-        const char* e = getenv("DVQ_ATTN_DBG");
-        return e != nullptr ? atoi(e) : 0;
-    }();
+    static const int dbg = dvq_probe_env("DVQ_ATTN_DBG");           // 0 unless built with -DDVQ_PROBES
     p.dbg = dbg;
     return DVQ_OK;
 }

@@ -635,9 +635,12 @@ __global__ __launch_bounds__(64) void halo_stats_finalize_kernel(const float* __
 
 }  // namespace
 
+#ifdef DVQ_PROBES
+// the persistent form (conv_halo2.hip: measured slower) is part of probe builds only
 int dvq_conv3x3_halo2_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N, int64_t H, int64_t W,
                           int64_t Cin, int64_t Cout, int flip, int up, const float* gn_ss, double* out_stats, int out_groups,
                           float act_slope, int res_mask, float mask_slope, hipStream_t stream);
+#endif
 
 extern "C" int dvq_halo_trace_read(unsigned long long* dst, int64_t max_records) {
     DVQ_REQUIRE(dst != nullptr && max_records > 0, DVQ_EINVAL, "dvq_halo_trace_read: bad arguments");
@@ -656,11 +659,13 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
                          double* out_stats, int out_groups, float act_slope, int res_mask, float mask_slope,
                          hipStream_t stream) {
     if (H % TH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
-    {   // the persistent kernel (conv_halo2.hip) takes the launches it is built for: 128-channel output blocks, >= 2 tiles per CU
+#ifdef DVQ_PROBES
+    {   // the persistent kernel (conv_halo2.hip, DVQ_HALO2=1) takes the launches it is built for: 128-channel output blocks, >= 2 tiles per CU
         const int rc2 = dvq_conv3x3_halo2_try(x, w, bias, residual, y, N, H, W, Cin, Cout, flip, up, gn_ss, out_stats, out_groups, act_slope,
                                               res_mask, mask_slope, stream);
         if (rc2 != 0) return rc2;
     }
+#endif
     const int cot = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;          // output-channel tile of the kernel instance
     if (out_stats != nullptr && (out_groups <= 0 || Cout % out_groups != 0 || cot % (Cout / out_groups) != 0)) return 0;
     if (out_stats != nullptr) {
@@ -676,10 +681,7 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     p.up = up;
     p.gn_ss = gn_ss; p.out_stats = out_stats; p.out_groups = out_groups;
     p.act_slope = act_slope; p.res_mask = res_mask; p.mask_slope = mask_slope;
-    static const int dbg_env = [] {
-        const char* e = getenv("DVQ_HALO_DBG");
-        return e != nullptr ? atoi(e) : 0;
-    }();
+    static const int dbg_env = dvq_probe_env("DVQ_HALO_DBG");       // 0 unless built with -DDVQ_PROBES
     p.dbg = dbg_env;
     const int ntiles = p.tiles_y * p.tiles_x;
     if (out_stats != nullptr) {
@@ -694,17 +696,18 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
     if (blocks * dmax >= (1ll << 32)) return 0;        // (exactness range of the scalar tile decode)
     p.nblocks = (int)blocks;
     p.mg_gn = magic(p.gn); p.mg_tx = magic(p.tiles_x); p.mg_ty = magic(p.tiles_y);
-    static const int lds_pad = [] {      // experiment (DVQ_HALO_LDS_PAD=1): > 80 KB of LDS = ONE workgroup per CU
-        const char* e = getenv("DVQ_HALO_LDS_PAD");
-        return e != nullptr && atoi(e) != 0 ? 90 * 1024 - LDSB : 0;
-    }();
+    // experiment (DVQ_HALO_LDS_PAD=1, probe builds): > 80 KB of LDS = ONE workgroup per CU
+    static const int lds_pad = dvq_probe_env("DVQ_HALO_LDS_PAD") != 0 ? 90 * 1024 - LDSB : 0;
     auto go = [&](auto kern) {
         dvq_ensure_dynamic_lds((const void*)kern, LDSB + lds_pad);
         kern<<<dim3((unsigned)blocks), dim3(256), LDSB + lds_pad, stream>>>(p);
     };
     if (cot == 128) {
-        if (p.dbg == 6) go(conv3x3_halo_kernel<4, true>);
-        else go(conv3x3_halo_kernel<4>);
+#ifdef DVQ_PROBES
+        if (p.dbg == 6) go(conv3x3_halo_kernel<4, true>);       // per-workgroup time stamps (dvq_halo_trace_read)
+        else
+#endif
+        go(conv3x3_halo_kernel<4>);
     } else if (cot == 64) {
         go(conv3x3_halo_kernel<2>);
     } else {
@@ -1125,10 +1128,7 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
     p.c_oihw = c_oihw;
     p.up = up;
     p.gn_ss = gn_ss;
-    static const int wdbg_env = [] {
-        const char* e = getenv("DVQ_WGRAD_DBG");
-        return e != nullptr ? atoi(e) : 0;
-    }();
+    static const int wdbg_env = dvq_probe_env("DVQ_WGRAD_DBG");     // 0 unless built with -DDVQ_PROBES
     p.dbg = wdbg_env;
     const int64_t nblk = (int64_t)p.gi * p.gj * p.nsplit;
     int64_t ws_bytes = 0;

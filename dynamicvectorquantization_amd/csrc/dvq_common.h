@@ -55,6 +55,20 @@ void dvq_set_error(const char* fmt, ...);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Probe modes -- timing experiments that REMOVE pieces of a kernel (no epilogue, no MFMA loop, DMA out of range ...) and therefore
+// produce wrong results -- exist only in builds made with -DDVQ_PROBES (`python -m dynamicvectorquantization_amd.build --probes`
+// -> libdvq_hip_probes.so, loaded when DVQ_USE_PROBES_LIB=1; tools/debug/ uses it).  In the product library their environment
+// variables (DVQ_HALO_DBG, DVQ_HALO_LDS_PAD, DVQ_WGRAD_DBG, DVQ_ATTN_DBG, DVQ_VQ_DBG, DVQ_HALO2*) are not read at all: a stray
+// variable cannot corrupt a training run.
+#ifdef DVQ_PROBES
+static inline int dvq_probe_env(const char* name) {
+    const char* e = getenv(name);
+    return e != nullptr ? atoi(e) : 0;
+}
+#else
+static inline int dvq_probe_env(const char*) { return 0; }
+#endif
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) costs ~0.3 ms per call: do it once per kernel symbol.
 void dvq_ensure_dynamic_lds(const void* kernel, int bytes);
 // caller-registered scratch buffer (dvq_set_workspace); null if none

@@ -138,14 +138,15 @@ __global__ __launch_bounds__(256) void maxpool2x2_relu_bwd_kernel(const T* __res
 template <typename T, int L>
 __global__ __launch_bounds__(256) void lpips_head_kernel(const T* __restrict__ f0, const T* __restrict__ f1,
                                                          const float* __restrict__ lin, int64_t N, int64_t HW,
-                                                         float* __restrict__ val, float gscale, T* __restrict__ df1) {
+                                                         float* __restrict__ val, float gscale, T* __restrict__ df1,
+                                                         unsigned drop_thr, float drop_scale, unsigned rm, unsigned ra) {
     constexpr int C = L * 8;
     constexpr int PPB = 256 / L;          // pixels per block pass
     const int lane = threadIdx.x % L, slot = threadIdx.x / L;
     const int64_t n = blockIdx.y;
-    float w[8];
+    float w0[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w[j] = lin[lane * 8 + j];
+    for (int j = 0; j < 8; ++j) w0[j] = lin[lane * 8 + j];
     const float inv_hw = 1.f / (float)HW;
     float vsum = 0.f;
     const int64_t chunk = (HW + gridDim.x - 1) / gridDim.x;
@@ -168,6 +169,18 @@ __global__ __launch_bounds__(256) void lpips_head_kernel(const T* __restrict__ f
         }
         const float r1 = sqrtf(s1);
         const float i0 = 1.f / (sqrtf(s0) + 1e-10f), i1 = 1.f / (r1 + 1e-10f);
+        // NetLinLayer's nn.Dropout() on the squared differences (lpips.py:64-70, active in the reference's training mode): element
+        // (n, pixel, channel) of the tap is kept with probability 1 - p and scaled by 1 / (1 - p) -- folded into the lin weight of this
+        // pixel; the decision is dvq_hash32 of (seed, element index) like every dropout of this library (drop_thr == 0: off)
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = w0[j];
+        if (drop_thr != 0u) {
+            const unsigned long long e0 = (unsigned long long)o;
+            const unsigned base = ra + (unsigned)(e0 >> 32) * 0x9E3779B1u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = dvq_hash32(((unsigned)e0 + j) * rm + base) >= drop_thr ? w0[j] * drop_scale : 0.f;
+        }
         float gn[8], acc = 0.f, tdot = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -242,7 +255,17 @@ int dvq_maxpool2x2_relu_bwd(const void* a, const void* dpool, const void* dtap, 
 
 int dvq_lpips_head(const void* f0, const void* f1, const float* lin, int dtype, int64_t N, int64_t HW, int64_t C, float* val,
                    float gscale, void* df1, dvq_stream_t stream) {
+    return dvq_lpips_head_drop(f0, f1, lin, dtype, N, HW, C, val, gscale, df1, 0.f, 0, stream);
+}
+
+int dvq_lpips_head_drop(const void* f0, const void* f1, const float* lin, int dtype, int64_t N, int64_t HW, int64_t C, float* val,
+                        float gscale, void* df1, float p_drop, uint64_t seed, dvq_stream_t stream) {
     DVQ_REQUIRE(f0 && f1 && lin && val && N > 0 && N < 65536 && HW > 0, DVQ_EINVAL, "dvq_lpips_head: bad arguments");
+    DVQ_REQUIRE(p_drop >= 0.f && p_drop < 1.f, DVQ_EINVAL, "dvq_lpips_head_drop: p_drop must be in [0, 1)");
+    const unsigned drop_thr = (unsigned)((double)p_drop * 4294967296.0);
+    const float drop_scale = 1.f / (1.f - p_drop);
+    unsigned rm = 1u, ra = 0u;
+    dvq_dropout_seed(seed, &rm, &ra);
     DVQ_REQUIRE(C == 64 || C == 128 || C == 256 || C == 512, DVQ_ESHAPE, "dvq_lpips_head: C must be 64/128/256/512 (VGG16 taps)");
     const int L = (int)(C / 8);
     const int ppb = 256 / L;
@@ -253,7 +276,7 @@ int dvq_lpips_head(const void* f0, const void* f1, const float* lin, int dtype, 
     hipStream_t s = (hipStream_t)stream;
 #define HEAD(L_)                                                                                                   \
     DVQ_DISPATCH_DTYPE(dtype, T, lpips_head_kernel<T, L_><<<grid, dim3(256), 0, s>>>((const T*)f0, (const T*)f1, lin, N, HW, val, \
-                                                                                    gscale, (T*)df1););
+                                                                                    gscale, (T*)df1, drop_thr, drop_scale, rm, ra););
     if (L == 8) { HEAD(8) } else if (L == 16) { HEAD(16) } else if (L == 32) { HEAD(32) } else { HEAD(64) }
 #undef HEAD
     DVQ_CHECK_LAUNCH("lpips_head");

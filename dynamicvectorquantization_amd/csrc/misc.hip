@@ -602,6 +602,11 @@ void* dvq_workspace_stream(hipStream_t stream, int64_t* bytes) {
     if (slot < 0) {
         for (int i = 0; i < DVQ_WS_SLOTS; ++i) {
             if (g_ws_pinned[i] || (slot >= 0 && g_ws_used[i] >= g_ws_used[slot])) continue;
+            // an owner that is CAPTURING counts as busy and is not queried: hipStreamQuery on a capturing stream is a capture-unsafe
+            // call and would invalidate the capture in progress (e.g. the side stream forked into a StepGraph capture that took its
+            // slot eagerly and has not asked for scratch during this capture yet)
+            hipStreamCaptureStatus oc = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(g_ws_stream[i], &oc) != hipSuccess || oc != hipStreamCaptureStatusNone) continue;
             if (hipStreamQuery(g_ws_stream[i]) == hipSuccess) slot = i;       // idle owner: nothing in flight uses the slot
         }
         (void)hipGetLastError();                 // (hipErrorNotReady of a busy stream is not an error of ours)
@@ -619,7 +624,7 @@ void* dvq_workspace_stream(hipStream_t stream, int64_t* bytes) {
 extern "C" {
 
 const char* dvq_last_error(void) { return g_err; }
-int dvq_version(void) { return 106; }
+int dvq_version(void) { return 107; }
 
 int dvq_set_workspace(void* ptr, int64_t bytes) {
     DVQ_REQUIRE((ptr == nullptr) == (bytes == 0) && bytes >= 0, DVQ_EINVAL, "dvq_set_workspace: bad arguments");

@@ -1392,10 +1392,8 @@ static void vq_launch_rb2(const float* x, const void* prep, int64_t N, int64_t K
 }
 template <int KS>
 static void vq_launch_rb2(const bf16_t* x, const void* prep, int64_t N, int64_t K, int64_t* idx, VqWs* ws, hipStream_t s) {
-    static const int vdbg = [] {
-        const char* e = getenv("DVQ_VQ_DBG");
-        return e != nullptr ? atoi(e) : 0;
-    }();
+#ifdef DVQ_PROBES
+    static const int vdbg = dvq_probe_env("DVQ_VQ_DBG");            // cycle-stamp / piece-removal variants: probe builds only
     if constexpr (KS == 16) {
         if (vdbg == 1) return vq_launch_rb2_dbg<KS, 1, bf16_t>(x, prep, N, K, idx, ws, s);
         if (vdbg == 2) return vq_launch_rb2_dbg<KS, 2, bf16_t>(x, prep, N, K, idx, ws, s);
@@ -1408,6 +1406,7 @@ static void vq_launch_rb2(const bf16_t* x, const void* prep, int64_t N, int64_t 
         if (vdbg == 32) return vq_launch_rb2_dbg<KS, 32, bf16_t>(x, prep, N, K, idx, ws, s);
         if (vdbg == 61) return vq_launch_rb2_dbg<KS, 61, bf16_t>(x, prep, N, K, idx, ws, s);
     }
+#endif
     vq_launch_rb2_dbg<KS, 0, bf16_t>(x, prep, N, K, idx, ws, s);
 }
 

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import json
 import math
+import os
 
 import numpy as np
 import torch
@@ -51,6 +52,11 @@ class DualGrainFixedEntropyRouter(nn.Module):
 
     def __init__(self, json_path, fine_grain_ratito):
         super().__init__()
+        if not os.path.isabs(json_path) and not os.path.exists(json_path):
+            # the shipped YAMLs name the table relative to the repository root (the reference is run from there): resolve it against
+            # this checkout when the process was started elsewhere
+            alt = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), json_path)
+            json_path = alt if os.path.exists(alt) else json_path
         with open(json_path, "r", encoding="utf-8") as f:
             content = json.load(f)
         self.fine_grain_threshold = content["{}".format(str(int(100 - fine_grain_ratito * 100)))]
@@ -718,6 +724,11 @@ class DualGrainVQModel(nn.Module):
             return None                      # injected test noise lives on the host
         if any(isinstance(m, ResnetBlock) and m.dropout.p > 0.0 for m in self.modules()):
             return None                      # dropout seeds are drawn on the host per call (a replay would repeat the masks)
+        if getattr(getattr(self.loss, "perceptual_loss", None), "lin_dropout", False):
+            return None                      # opt-in LPIPS lin-layer dropout: its seeds are drawn on the host per call
+        from .layers import ActNorm
+        if any(isinstance(m, ActNorm) and self.training and not m.inited() for m in self.modules()):
+            return None                      # ActNorm's data-dependent initialisation reads the batch on the host: first step(s) eager
         step = self.current_epoch if self.loss_with_epoch else self.global_step
         disc_on = None
         if hasattr(self.loss, "discriminator_iter_start"):

@@ -225,8 +225,9 @@ def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, prep: torch.Tensor | None
               return_flagged: bool = False):
     """x [N,D] (fp32/bf16), codebook [K,D] fp32 -> idx int64 [N] (exact argmin, lowest index on ties).
     return_flagged: also a device int32 [3] = rows of THIS call settled in fp64 {over all K codes (generic kernel only), over their
-    candidate list / flagged residue classes, of those: rows with more candidate classes than an entry lists}; it is a view of the
-    shared scratch, valid until the next search on this stream."""
+    candidate list / flagged residue classes, of those: rows with more candidate classes than an entry lists} -- a COPY made by a
+    kernel on this stream (the counters live in scratch shared by every search of this (device, stream, N); under capture in a graph-pool
+    buffer each replay refreshes)."""
     n, d = x.shape
     k = codebook.shape[0]
     assert codebook.dtype == torch.float32 and codebook.shape[1] == d
@@ -242,7 +243,7 @@ def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, prep: torch.Tensor | None
         _vq_ws.clear()            # a failed call may leave the counters armed
         raise
     if return_flagged:
-        return idx, ws[16:28].view(torch.int32)
+        return idx, ws[16:28].view(torch.int32).mul(1)
     return idx
 
 
@@ -743,13 +744,14 @@ def maxpool2x2_relu_bwd(a, dpool=None, dtap=None):
     return dz
 
 
-def lpips_head(f0, f1, lin, val, gscale=0.0, want_grad=False):
-    """val[n] (fp32, accumulated) += LPIPS term of one tap; returns d val / d f1 * gscale (or None)"""
+def lpips_head(f0, f1, lin, val, gscale=0.0, want_grad=False, p_drop=0.0, seed=0):
+    """val[n] (fp32, accumulated) += LPIPS term of one tap; returns d val / d f1 * gscale (or None).  p_drop > 0: NetLinLayer's
+    dropout on the squared differences (hash-seeded mask, the same in the value and in the gradient)"""
     n, c = f0.shape[0], f0.shape[-1]
     hw = f0.numel() // (n * c)
     df1 = torch.empty_like(f1) if want_grad else None
-    check(lib().dvq_lpips_head(_p(f0), _p(f1), _p(lin), dt(f0), n, hw, c, _p(val), float(gscale), _p(df1), _s()),
-          "dvq_lpips_head")
+    check(lib().dvq_lpips_head_drop(_p(f0), _p(f1), _p(lin), dt(f0), n, hw, c, _p(val), float(gscale), _p(df1), float(p_drop), int(seed),
+                                    _s()), "dvq_lpips_head_drop")
     return df1
 
 

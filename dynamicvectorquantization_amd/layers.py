@@ -327,18 +327,20 @@ class ActNorm(HipModule):
         self.loc = nn.Parameter(torch.zeros(1, num_features, 1, 1))
         self.scale = nn.Parameter(torch.ones(1, num_features, 1, 1))
         self.register_buffer("initialized", torch.tensor(0, dtype=torch.uint8))
+        self._inited = False                   # host-side mirror of `initialized` (None = unknown: re-read from the buffer)
         self.act = K.ACT_NONE
 
     def fwd(self, x, tape, act=None, update_running=True):
         act = self.act if act is None else act
         n, h, w, c = x.shape
         flat = x.view(1, n * h * w, c)
-        if self.training and int(self.initialized.item()) == 0:         # data-dependent initialisation (one host sync, once)
+        if self.training and not self.inited():                         # data-dependent initialisation (one host sync, once)
             with torch.no_grad():
                 f = x.float().reshape(-1, c)
                 self.loc.data.copy_((-f.mean(0)).view(1, c, 1, 1))
                 self.scale.data.copy_((1.0 / (f.std(0) + 1e-6)).view(1, c, 1, 1))
                 self.initialized.fill_(1)
+            self._inited = True
         cnt = float(n * h * w)
         mean = -self.loc.detach().view(c).double()
         stats = (torch.stack([mean, (1.0 - self.EPS) + mean * mean], dim=1) * cnt).view(1, c, 2).contiguous()
@@ -347,6 +349,17 @@ class ActNorm(HipModule):
         if tape is not None:
             tape.s.update(x=flat, mr=mr, act=act, shape=x.shape)
         return y.view(n, h, w, c)
+
+    def inited(self) -> bool:
+        """host-side copy of the `initialized` buffer: read from the device ONCE (a per-forward .item() is a host sync per layer and
+        step, and illegal during stream capture); refreshed when a state_dict is loaded"""
+        if self._inited is None:
+            self._inited = bool(int(self.initialized.item()) != 0)
+        return self._inited
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._inited = None
 
     def bwd(self, dy, tape, need_dw=True):
         s = tape.s

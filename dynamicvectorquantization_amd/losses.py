@@ -213,11 +213,15 @@ class LPIPS(nn.Module):
     kernel); every tap's normalise / difference / lin / spatial-mean is one kernel that also emits the gradient
     w.r.t. the reconstruction's features; the backward walks the reconstruction half only (dgrad kernels gated by the
     ReLU masks, max-pool routing fused with the tap gradient).  VGG16 and the lin layers are frozen, as in the reference.
-    NetLinLayer dropout is not applied (the reference leaves it active in training through Lightning's
-    model.train(); its expectation equals the value computed here)."""
+    NetLinLayer dropout: the reference leaves nn.Dropout(0.5) on the squared differences active in training (Lightning's
+    model.train() reaches the loss module; lpips.py:64-70).  `lin_dropout=True` (or DVQ_LPIPS_DROPOUT=1) applies it here -- in
+    training mode only, hash-seeded per call inside the head kernel, so the training distribution matches the reference's; the
+    draws are device-RNG dependent (parity unpinned), the default (off) computes the expectation of that value."""
 
-    def __init__(self, use_dropout=True):
+    def __init__(self, use_dropout=True, lin_dropout=None):
         super().__init__()
+        import os
+        self.lin_dropout = bool(use_dropout) and (os.environ.get("DVQ_LPIPS_DROPOUT", "0") == "1" if lin_dropout is None else bool(lin_dropout))
         self.scaling_layer = ScalingLayer()
         self.chns = [64, 128, 256, 512, 512]
         self.net = vgg16(pretrained=True, requires_grad=False)
@@ -307,7 +311,9 @@ class LPIPS(nn.Module):
         for k, outs in enumerate(acts):
             f = outs[-1]
             lin = getattr(self, f"lin{k}").model[-1].weight.reshape(-1)
-            dtaps.append(K.lpips_head(f[:b], f[b:], lin, val, gscale if want else 0.0, want))
+            pd = getattr(self, f"lin{k}").model[0].p if (self.lin_dropout and self.training) else 0.0
+            dtaps.append(K.lpips_head(f[:b], f[b:], lin, val, gscale if want else 0.0, want, p_drop=pd,
+                                      seed=rt.next_dropout_seed() if pd > 0.0 else 0))
         if not want:
             return val, None
         g = None

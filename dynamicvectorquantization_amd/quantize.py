@@ -42,6 +42,7 @@ class VQEmbedding(nn.Embedding):
         self._prep = None          # (version, prep buffer)
         self._cb_version = 0       # bumped by every in-place codebook rewrite (EMA); conv packs are unaffected
         self.restart_perm = None   # optional injected permutation (tests)
+        self.track_flagged = False  # True: every search leaves its re-rank counters in `last_flagged`
         self.last_flagged = None   # device int32 [3]: rows settled in fp64 by the last search (all codes, candidate list, of those: class scans only)
 
     # -- search -------------------------------------------------------------------------------------
@@ -79,8 +80,10 @@ class VQEmbedding(nn.Embedding):
             flat = flat.contiguous()
         cb = self._codebook()
         prep = self._prepared() if d in (64, 128, 256) else None
-        idx, flagged = K.vq_argmin(flat, cb, prep, impl=rt.impl(), return_flagged=True)
-        self.last_flagged = flagged
+        if self.track_flagged:          # diagnostics: a private copy of the search's re-rank counters (one extra small kernel)
+            idx, self.last_flagged = K.vq_argmin(flat, cb, prep, impl=rt.impl(), return_flagged=True)
+        else:
+            idx = K.vq_argmin(flat, cb, prep, impl=rt.impl())
         return idx.reshape(inputs.shape[:-1])
 
     # -- EMA ------------------------------------------------------------------------------------------

@@ -363,10 +363,21 @@ def run_on_side(fn, *tensors):
     st["stream"].wait_stream(cur)
     with torch.cuda.stream(st["stream"]):
         fn()
-    # the operands stay referenced until the current stream has waited for the side stream (join_side): freed after that point
-    # they are safe to re-use in stream order.  (Tensor.record_stream would defer the re-use of these -- large -- blocks to an event
-    # query instead and make the allocator grow the pool with synchronising hipMallocs for several steps.)
-    st["keep"].extend(t for t in tensors if t is not None)
+    # the operands stay referenced until the side stream is done with them: either the current stream has waited for the side stream
+    # (join_side) -- freed after that point they are safe to re-use in stream order -- or, on eagerly launched steps, an event recorded
+    # behind the launch has completed (then every stream may re-use them).  Without the second rule a step whose only join is the one
+    # before the optimizer (the stage-2 step without data parallelism) held every block's gradient temporaries -- ~0.4 GB per
+    # StackGPT block -- for the whole backward.  (Tensor.record_stream would defer the re-use of these -- large -- blocks
+    # to the allocator's own event queries and make it grow the pool with synchronising hipMallocs for several steps.)
+    keep = st["keep"]
+    ev = None
+    if not capturing():
+        free = st.setdefault("events", [])
+        while keep and keep[0][0] is not None and keep[0][0].query():
+            free.append(keep.pop(0)[0])
+        ev = free.pop() if free else torch.cuda.Event()
+        ev.record(st["stream"])
+    keep.append((ev, tuple(t for t in tensors if t is not None)))
     st["dirty"] = True
 
 
@@ -377,4 +388,6 @@ def join_side(device=None):
         if st["dirty"] and (device is None or torch.device(device).index in (None, key)):
             torch.cuda.current_stream(torch.device("cuda", key)).wait_stream(st["stream"])
             st["dirty"] = False
+            st.setdefault("events", []).extend(e for e, _ in st["keep"] if e is not None)
+            del st["events"][64:]
             st["keep"].clear()

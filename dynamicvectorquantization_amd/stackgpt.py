@@ -227,6 +227,11 @@ def _attn_append(attn, x2d, b, n, cache, t0):
         tk = min(tmax, (t + 7) // 8 * 8)
         if tk % 8 != 0:
             tk = t
+        if tk > t:
+            # probability 0 times a NaN / Inf left in rows [t, tk) by an overflowed earlier run (or a cache that was not
+            # zero-initialised) would still poison every query through the P V product: clear the few padding rows (prefill only)
+            kc[:, t:tk].zero_()
+            vc[:, t:tk].zero_()
         s = torch.empty(b * nh * n * tk, dtype=x2d.dtype, device=x2d.device)
         qf, kf = q.reshape(-1), kc.reshape(-1)
         for h in range(nh):

@@ -105,3 +105,23 @@ def vq_inputs(n: int, dim: int, k: int, dist: str = "normal", seed: int = 0):
     else:
         raise ValueError(dist)
     return x, cb
+
+
+def dqvae_golden_state(keys, shapes, variant: str, k: int, zc: int) -> dict:
+    """state_dict of the DQ-VAE goldens (tests/golden/dqvae_*.npz hold the key / shape lists and OUTPUTS only): every entry is
+    `det_param(key, shape)`; the codebook is either `spread` (wide: score gaps far above rounding, so the reference's code indices
+    are reproducible) or `refinit` (the reference's own U(+-1/K) initialisation: near ties).  numpy arrays, fp32."""
+    sd = {}
+    for kk, sh in zip(keys, shapes):
+        sd[kk] = det_param(kk, sh) if len(sh) else np.zeros((), dtype=np.float32)
+    if variant == "spread":
+        cbw = det_param("quantize.codebook.weight.spread", (k + 1, zc)) * np.sqrt(zc) * 1.2
+    else:
+        cbw = np.random.RandomState(3).uniform(-1.0 / k, 1.0 / k, size=(k + 1, zc)).astype(np.float32)
+    sd["quantize.codebook.weight"] = cbw.astype(np.float32)
+    return sd
+
+
+# geometries of the DQ-VAE fixtures: `small` = shrunken widths, `c1` = BASELINE config 1 (full width, 64 x 64 images)
+DQVAE_GEOM = {"small": dict(ch=32, resolution=64, latent=8, zc=64, k=512, attn_enc=[4, 8], attn_dec=[8]),
+              "c1": dict(ch=128, resolution=64, latent=8, zc=256, k=1024, attn_enc=[4, 8], attn_dec=[8])}

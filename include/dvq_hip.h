@@ -42,7 +42,8 @@ enum { DVQ_F32 = 0, DVQ_BF16 = 1 };
 enum { DVQ_OK = 0, DVQ_EINVAL = -1, DVQ_ESHAPE = -2, DVQ_EARCH = -3, DVQ_ELAUNCH = -4, DVQ_EWORKSPACE = -5 };
 
 const char* dvq_last_error(void);
-int dvq_version(void);     /* 106: round 4 (launch lists dvq_cmdlist_*, dvq_add_uniform, dvq_decode_stack_status + 64 sequences, drop_mask argument
+int dvq_version(void);     /* 107: round 5 (dvq_lpips_head_drop; probe modes compiled out of the product library: -DDVQ_PROBES);
+                            * 106: round 4 (launch lists dvq_cmdlist_*, dvq_add_uniform, dvq_decode_stack_status + 64 sequences, drop_mask argument
                             * of dvq_attn_causal_fwd / bwd + dvq_attn_causal_mask_bytes, dvq_layernorm_bwd_res, dvq_dropout_add, eight
                             * workspace slots + dvq_workspace_release, vq_argmin workspace report slots);
                             * 105: round 3 (fused constrained sampler, GroupNorm-backward partials argument,
@@ -297,6 +298,11 @@ int dvq_maxpool2x2_relu_bwd(const void* a, const void* dpool, const void* dtap, 
  * df1 (NULL to skip) = gscale * d val[n] / d f1, gated by f1 > 0.  C in {64,128,256,512}. */
 int dvq_lpips_head(const void* f0, const void* f1, const float* lin, int dtype, int64_t N, int64_t HW, int64_t C, float* val,
                    float gscale, void* df1, dvq_stream_t stream);
+/* the same with NetLinLayer's nn.Dropout(p_drop) on the squared differences (lpips.py:64-70; the reference leaves it active while
+ * training): element (n, pixel, channel) kept iff dvq_hash32 of (seed, element index) >= p_drop * 2^32, kept terms scaled by
+ * 1 / (1 - p_drop), in the value and in df1 alike.  p_drop == 0: identical to dvq_lpips_head. */
+int dvq_lpips_head_drop(const void* f0, const void* f1, const float* lin, int dtype, int64_t N, int64_t HW, int64_t C, float* val,
+                        float gscale, void* df1, float p_drop, uint64_t seed, dvq_stream_t stream);
 
 /* ---- feature-routed (Gumbel) dual / triple grain pieces: RouterDual.py:6-43, RouterTriple.py:6-56,
  * EncoderDual.py:130-156, EncoderTriple.py:143-183 ------------------------------------------------------------------ */

@@ -56,7 +56,18 @@ def get_parser():
     return parser
 
 
-def main():
+def save_image_normalized(x, path):
+    """torchvision.utils.save_image(x, path, normalize=True) for ONE [3,H,W] image: min-max scaled to [0,1]"""
+    import numpy as np
+    from PIL import Image
+    lo, hi = float(x.min()), float(x.max())
+    y = (np.clip(x, lo, hi) - lo) / max(hi - lo, 1e-5)
+    Image.fromarray((y.transpose(1, 2, 0) * 255.0 + 0.5).clip(0, 255).astype("uint8")).save(path)
+
+
+def main(per_image_png=False):
+    """per_image_png: the layout of the reference's scripts/sample_images/sample_dynamic_uncond.py (:40-102) -- one min-max normalised
+    PNG per sample, `batch_<i>_<j>.png`, in the `_image` directory, no pickles"""
     opt, _ = get_parser().parse_known_args()
     import time
 
@@ -68,9 +79,10 @@ def main():
     if opt.sample_with_fixed_pos:
         tag = "fixed_" + tag
     dir_img, dir_pkl = os.path.join(base, tag + "_image"), os.path.join(base, tag + "_pickle")
-    if opt.save_image:
+    if opt.save_image or per_image_png:
         os.makedirs(dir_img, exist_ok=True)
-    os.makedirs(dir_pkl, exist_ok=True)
+    if not per_image_png:
+        os.makedirs(dir_pkl, exist_ok=True)
 
     rt.set_compute_dtype(opt.dtype)
     if opt.seed is not None:
@@ -93,13 +105,19 @@ def main():
                                              top_k_pos=opt.top_k_pos, top_p_pos=opt.top_p_pos, process=False,
                                              fix_fine_position=opt.sample_with_fixed_pos)
             steps += batch_size * int(seqs[0].shape[1] + seqs[1].shape[1])
-            img = torch.clamp(model.decode_to_img(*seqs).float() * 0.5 + 0.5, 0, 1).cpu().numpy()
+            raw = model.decode_to_img(*seqs).float()
+            if per_image_png:
+                raw = raw.cpu().numpy()
+                for j in range(batch_size):
+                    save_image_normalized(raw[j], os.path.join(dir_img, "batch_{}_{}.png".format(i, j)))
+                continue
+            img = torch.clamp(raw * 0.5 + 0.5, 0, 1).cpu().numpy()
             if opt.save_image:
                 save_image_grid(img, os.path.join(dir_img, "batch_{}.png".format(i)))
             save_pickle(os.path.join(dir_pkl, "samples_({}_{}).pkl".format(i, total_batch)), img)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("sampled {} images, {} token steps in {:.2f} s ({:.0f} token-steps/s) -> {}".format(opt.sample_num, steps, dt, steps / dt, dir_pkl))
+    print("sampled {} images, {} token steps in {:.2f} s ({:.0f} token-steps/s) -> {}".format(opt.sample_num, steps, dt, steps / dt, dir_img if per_image_png else dir_pkl))
 
 
 if __name__ == "__main__":

@@ -20,6 +20,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 STEPS = 7
+# DVQ_DP2_BACKEND=nccl: one device per rank and the real RCCL backend (boxes with >= 2 GPUs: tests/test_gpu_dp2.py picks it when it
+# sees them); default gloo on one shared device
+BACKEND = os.environ.get("DVQ_DP2_BACKEND", "gloo")
 
 
 def say(*a):
@@ -30,12 +33,13 @@ def run(rank, world, port, out, loss="ae"):
     import numpy as np
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(0)
+    di = rank if (BACKEND == "nccl" and world > 1) else 0
+    torch.cuda.set_device(di)
     if world > 1:
-        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        dist.init_process_group(BACKEND, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     from dynamicvectorquantization_amd import runtime as rt, synth
     import test_gpu_stepgraph as T
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", di)
     full = [torch.from_numpy(synth.half_flat_images(4, 64, seed=140 + i)).to(dev) for i in range(3)]
     with rt.compute_dtype_ctx(torch.float32):
         # different seeds per rank: the Trainer's start-up broadcast (not equal seeding) must make the replicas identical
@@ -87,14 +91,15 @@ def run_s2(rank, world, port, out):
     import numpy as np
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(0)
+    di = rank if (BACKEND == "nccl" and world > 1) else 0
+    torch.cuda.set_device(di)
     if world > 1:
-        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        dist.init_process_group(BACKEND, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     from dynamicvectorquantization_amd import runtime as rt, synth
     from dynamicvectorquantization_amd.config import instantiate_from_config
     from dynamicvectorquantization_amd.trainer import Trainer
     import test_gpu_stage2 as S
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", di)
     cfg = copy.deepcopy(S.dualformer_config())
     cfg["params"]["transformer_config"]["params"].update(embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0)
     half = torch.from_numpy(synth.half_flat_images(32, 64, seed=511)).to(dev)

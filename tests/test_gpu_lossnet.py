@@ -82,6 +82,63 @@ def test_lpips_golden(dev, dtype, tol, gtol):
         assert tuple(v2.shape) == (2, 1, 1, 1) and _rel(v2.cpu().numpy(), g["lpips_val"]) < tol
 
 
+def test_lpips_lin_dropout_kernel(dev):
+    """NetLinLayer dropout inside the head kernel (dvq_lpips_head_drop; the reference: lpips.py:64-70, active in its training
+    mode).  The draws are device-RNG dependent (parity unpinned), so the checks are properties: p = 0 is the plain head bit for bit;
+    a seed reproduces its value; the mean over seeds is the undropped value (inverted dropout); the gradient the kernel returns is
+    the derivative of the SAME masked value (directional finite difference with the seed held)."""
+    from dynamicvectorquantization_amd import kernels as K
+    torch.manual_seed(11)
+    n, hw, c = 2, 48 * 48, 128
+    f0 = torch.relu(torch.randn(n, 48, 48, c, device=dev))
+    f1 = torch.relu(torch.randn(n, 48, 48, c, device=dev))
+    lin = torch.rand(c, device=dev) * (2.0 / c)
+
+    def head(f1_, p, seed, want=False):
+        val = torch.zeros(n, device=dev)
+        d = K.lpips_head(f0, f1_, lin, val, 1.0 if want else 0.0, want, p_drop=p, seed=seed)
+        return val, d
+
+    v0, d0 = head(f1, 0.0, 0, True)
+    vp, dp = head(f1, 0.0, 123, True)
+    assert torch.equal(v0, vp) and torch.equal(d0, dp)
+    va, da = head(f1, 0.5, 7, True)
+    vb, _ = head(f1, 0.5, 7)
+    vc, _ = head(f1, 0.5, 8)
+    assert torch.equal(va, vb) and not torch.equal(va, vc)
+    mean = torch.stack([head(f1, 0.5, 1000 + s)[0] for s in range(64)]).mean(0)
+    assert float(((mean - v0).abs() / v0).max()) < 0.01, (mean, v0)
+    # half of the elements carry no gradient, the rest twice the undropped one
+    frac_zero = float(((da == 0) & (d0 != 0)).float().sum() / (d0 != 0).float().sum())
+    assert 0.45 < frac_zero < 0.55, frac_zero
+    u = torch.randn_like(f1) * (f1 > 0)
+    eps = 1e-2
+    fd = (head(f1 + eps * u, 0.5, 7)[0].double().sum() - head(f1 - eps * u, 0.5, 7)[0].double().sum()) / (2 * eps)
+    an = (da.double() * u.double()).sum()
+    assert abs(float(fd - an)) < 2e-2 * abs(float(an)) + 1e-7, (float(fd), float(an))
+
+
+def test_lpips_module_lin_dropout_switch(dev):
+    """LPIPS(lin_dropout=True) drops only in training mode; the default module never does"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.losses import LPIPS, _padc
+    g = load_golden("lossnet")
+    with rt.compute_dtype_ctx(torch.float32):
+        lp = LPIPS(lin_dropout=True).to(dev)
+        _load_det(lp, "lpips.", synth.det_lpips_param)
+        cp = _padc(3, torch.float32)
+        x_p = K.nchw_to_nhwc_pad(torch.from_numpy(g["lpips_x"]).to(dev), cp, torch.float32)
+        r_p = K.nchw_to_nhwc_pad(torch.from_numpy(g["lpips_xrec"]).to(dev), cp, torch.float32)
+        lp.eval()
+        v_eval = lp.fwd(x_p, r_p)[0].clone()
+        assert _rel(v_eval.cpu().numpy(), g["lpips_val"].reshape(-1)) < 2e-3
+        lp.train()
+        v_a, v_b = lp.fwd(x_p, r_p)[0].clone(), lp.fwd(x_p, r_p)[0].clone()
+        assert not torch.equal(v_a, v_b) and not torch.equal(v_a, v_eval)            # a fresh mask per call
+        assert float(((v_a - v_eval).abs() / v_eval).max()) < 0.25
+
+
 def test_maxpool_and_head_kernels_vs_torch(dev):
     """kernel-level checks against a plain fp32 torch restatement (tie routing, ReLU gate, tap gradient)"""
     from dynamicvectorquantization_amd import kernels as K

@@ -440,6 +440,26 @@ def test_sampling_script_end_to_end(dev, tmp_path):
     assert "token-steps/s" in r.stdout
 
 
+def test_sample_images_script_end_to_end(dev, tmp_path):
+    """scripts/sample_images/sample_dynamic_uncond.py (the reference's PNG-writing twin): one normalised PNG per sample, no pickles"""
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "scripts/sample_images/sample_dynamic_uncond.py"), "--yaml_path",
+                        "configs/stage2/uncond_imagenet_p6c18.yml", "--batch_size", "2", "--sample_num", "3", "--top_k", "300",
+                        "--top_k_pos", "100", "--seed", "3", "--out_dir", str(tmp_path)],
+                       capture_output=True, text=True, timeout=900, cwd=repo)
+    assert r.returncode == 0, r.stderr[-3000:]
+    tag = "TopK-300-100_TopP-1.0-1.0_Temp-1.0"
+    files = sorted(os.listdir(os.path.join(str(tmp_path), tag + "_image")))
+    assert files == ["batch_0_0.png", "batch_0_1.png", "batch_1_0.png"]
+    assert not os.path.exists(os.path.join(str(tmp_path), tag + "_pickle"))
+    im = np.asarray(Image.open(os.path.join(str(tmp_path), tag + "_image", files[0])))
+    assert im.shape == (256, 256, 3) and im.min() == 0 and im.max() == 255          # min-max normalised
+
+
 def _torch_draw_probs(df, logits, temperature, k, p, rule):
     """filtered distribution of the op-by-op path (the reference's arithmetic) for `rule`"""
     from dynamicvectorquantization_amd.stage2 import top_k_logits, top_p_logits

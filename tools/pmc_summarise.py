@@ -8,9 +8,23 @@ gn_apply_kernel, which writes exactly as many bytes as it reads (same shape, sam
 """
 import collections
 import csv
+import glob
+import hashlib
 import json
+import os
 import re
 import sys
+
+
+def csrc_sha16():
+    """hash of the kernel sources this profile was taken with (bench.py compares it with the sources IT runs and says so in
+    roofline.traffic_source: the traffic figure is a committed profile, not an in-run measurement)"""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dynamicvectorquantization_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load(path):
@@ -29,7 +43,7 @@ def main():
         wf = (2.0 * sum(fetch[cal])) / sum(write[cal])
     out = {"_method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 0`; "
                       "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE x%.4f (calibrated on %s)" % (wf, cal),
-           "kernels": {}}
+           "csrc_sha16": csrc_sha16(), "commit": os.environ.get("HEAD_SHA", ""), "kernels": {}}
     for k in sorted(fetch, key=lambda k: -sum(fetch[k])):
         n = len(fetch[k])
         fb = 2.0 * sum(fetch[k]) / n
