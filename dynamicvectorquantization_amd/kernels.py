@@ -418,7 +418,9 @@ ACT_NONE, ACT_SWISH, ACT_LRELU, ACT_RELU = 0, 1, 2, 3      # include/dvq_hip.h D
 def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None, gn_ss=None, out_stats=None, out_groups=0, act=ACT_NONE):
     y = torch.empty(d.N, d.OH, d.OW, d.Cout, dtype=x.dtype, device=x.device)
     fl, nb = _conv_cost(d, x.element_size())
-    _tag(d, "fwd")
+    if _shape_tags:       # per-shape tables split the forward by epilogue / prologue variant (tools/debug/step_shapes.py)
+        _tag(d, "fwd" + ("+res" if residual is not None else "") + ("+gn" if gn_ss is not None else "") +
+             ("+st" if out_stats is not None else "") + ("+act" if act != ACT_NONE else ""))
     if out_stats is not None:
         ensure_workspace(x.device)        # per-tile statistics partials of the halo kernel
     if act != ACT_NONE:
