@@ -379,6 +379,8 @@ def extra_workloads(budget_s):
                 res[name]["detail"] = e["detail"]
             if "by_batch" in e:
                 res[name]["by_batch"] = e["by_batch"]
+            if "by_batch_concurrent_lanes" in e:
+                res[name]["by_batch_concurrent_lanes"] = e["by_batch_concurrent_lanes"]
         except Exception as ex:                     # the headline line must not depend on a secondary workload
             res[name] = {"failed": f"{type(ex).__name__}: {str(ex)[:120]}"}
     return res

@@ -205,6 +205,30 @@ def main():
                         "roofline": {"bound": "hbm", "weight_bytes_per_step": int(w_bytes), "kv_bytes_per_step_avg": int(kv_bytes),
                                      "achieved": round(achieved / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8e12, 4)}}
 
+            def kv_run_lanes(bs, lanes=2, nb=4):
+                """the same with `lanes` batches in flight (Dualformer.sample_many: one stream, K/V caches and captured token-step graphs
+                per lane): nb independent batches of bs sequences, whole-job token-steps/s"""
+                x = torch.from_numpy(synth.half_flat_images(bs, 256, seed=277)).to(dev)
+                kw = dict(sample=True, top_k=300, top_k_pos=100, process=False, fix_fine_position=True)
+                with torch.no_grad():
+                    conds = [model.encode_to_c(x) for _ in range(nb)]
+                    model.sample_many(conds[:lanes], n_streams=lanes, **kw)           # captures every lane's graphs (untimed)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    rs = model.sample_many(conds, n_streams=lanes, **kw)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                ntok = sum(int(r[0].shape[1] + r[1].shape[1]) for r in rs)
+                nt1 = ntok / nb
+                w_bytes = 2.0 * n_par
+                kv_bytes = bs * n_layer_all * 2 * (nt1 / 2.0) * n_embd * 2.0
+                # one "token step" of a lane still streams every weight once: lanes x (weights + K/V rows) per wall-clock step pair
+                achieved = (w_bytes + kv_bytes) * (ntok / dt)
+                return {"bs": bs, "lanes": lanes, "batches": nb, "seconds": round(dt, 3), "token_steps_per_sec": round(bs * ntok / dt, 1),
+                        "ms_per_token_step_per_lane": round(dt / ntok * lanes * 1e3, 3),
+                        "roofline": {"bound": "hbm", "weight_bytes_per_step": int(w_bytes), "kv_bytes_per_step_avg": int(kv_bytes),
+                                     "achieved": round(achieved / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8e12, 4)}}
+
             sizes = [args.bs] if args.bs else [8, 50]             # 50 = the reference sampler's default (scripts/sample_val/sample_dynamic_uncond.py:29)
             res = {}
             bs = sizes[0]
@@ -232,6 +256,13 @@ def main():
                     res[tag] = {"bs": bs, "prefix_len": int(cc.shape[1] + lf), "ms_per_token_step": round(dt * 1e3, 2),
                                 "tokens_per_sec": round(bs / dt, 1)}
             runs = [kv_run(b_) for b_ in sizes]
+            lane_runs = []
+            if os.environ.get("DVQ_BENCH_LANES", "2") != "0":
+                for b_ in sizes:
+                    try:
+                        lane_runs.append(kv_run_lanes(b_, int(os.environ.get("DVQ_BENCH_LANES", "2"))))
+                    except Exception as e:          # secondary measurement: never costs the single-lane figures
+                        lane_runs.append({"bs": b_, "failed": f"{type(e).__name__}: {str(e)[:160]}"})
             res["kv_cached_end_to_end"] = runs[0]
             for r_ in runs[1:]:
                 res[f"kv_cached_end_to_end_bs{r_['bs']}"] = r_
@@ -239,6 +270,7 @@ def main():
                                                      "with K/V caches; `*_prefix` = the reference's schedule (whole prefix recomputed)",
                    "value": runs[0]["token_steps_per_sec"], "unit": "token-steps/sec", "detail": res,
                    "by_batch": {str(r_["bs"]): {"token_steps_per_sec": r_["token_steps_per_sec"], "roofline": r_["roofline"]} for r_ in runs},
+                   "by_batch_concurrent_lanes": {f"{r_['bs']}x{r_.get('lanes', 2)}": r_ for r_ in lane_runs},
                    "roofline": runs[0]["roofline"],
                    "config": {"yaml": "configs/stage2/uncond_imagenet_p6c18.yml", "bs": bs, "batch_sizes": sizes,
                               "transformer_params": n_par}, "dtype": "bf16", "data": "synthetic"}

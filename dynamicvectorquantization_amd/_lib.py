@@ -26,6 +26,11 @@ class DecodeLayer(C.Structure):
                                   "kcache", "vcache")]
 
 
+class LinPackEntry(C.Structure):
+    """LinPackEntry of csrc/misc.hip (dvq_linear_pack_multi)"""
+    _fields_ = [("master", vp), ("w", vp), ("wt", vp), ("out", i64), ("in_", i64), ("out_p", i64), ("tile_begin", i64)]
+
+
 class PackEntry(C.Structure):
     _fields_ = [("master", vp), ("w", vp), ("wt", vp), ("Cout", i64), ("Cin", i64), ("taps", i64), ("Cin_p", i64),
                 ("Cout_p", i64), ("begin", i64), ("dtype", i64)]
@@ -90,6 +95,7 @@ SIGNATURES = {
     "dvq_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
     "dvq_conv2d_wgrad_oihw": (i32, [C.POINTER(ConvDesc), vp, vp, i64, i64, vp, vp, i32, vp]),
     "dvq_pack_weights_multi": (i32, [vp, i64, i64, vp]),
+    "dvq_linear_pack_multi": (i32, [vp, i64, i64, vp]),
     "dvq_pack_weight": (i32, [vp, i64, i64, i64, i64, i64, i64, i32, vp, vp, vp]),
     "dvq_unpack_wgrad": (i32, [vp, i64, i64, i64, i64, i64, vp, vp]),
     "dvq_nchw_to_nhwc_pad": (i32, [vp, i64, i64, i64, i64, i64, i32, vp, vp]),
@@ -115,6 +121,7 @@ SIGNATURES = {
     "dvq_layernorm_fwd": (i32, [vp, i32, i64, i64, f32, vp, vp, vp, vp, vp]),
     "dvq_layernorm_bwd": (i32, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, vp]),
     "dvq_layernorm_bwd_res": (i32, [vp, vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, vp]),
+    "dvq_layernorm_bwd_res_drop": (i32, [vp, vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, vp, f32, C.c_uint64, vp]),
     "dvq_gelu": (i32, [vp, i32, i64, vp, vp]),
     "dvq_gelu_bwd": (i32, [vp, vp, i32, i64, vp, vp]),
     "dvq_softmax_causal": (i32, [vp, i32, i64, i64, i64, i64, f32, vp, vp]),

@@ -392,6 +392,71 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackEntry
     }
 }
 
+// One launch refreshes the bf16 copies of every nn.Linear weight of a model: w [out_p][in] (forward / weight-gradient operand) and
+// wt [in][out_p] (the input-gradient GEMM's operand) from the fp32 master [out][in].  Per Linear and optimizer step this was a cast
+// launch + a transpose launch (147 + 144 launches of ~10 us on the StackGPT p6c18 step, 4.3 ms); a workgroup moves one 64 x 64 tile:
+// coalesced fp32 rows in, coalesced bf16 rows out for BOTH copies (the transposed one through LDS).
+struct LinPackEntry {    // mirrored by ctypes in _lib.py
+    const float* master;
+    bf16_t* w;
+    bf16_t* wt;
+    int64_t out, in, out_p;
+    int64_t tile_begin;  // exclusive prefix sum of ceil(out_p / 64) * ceil(in / 64)
+};
+
+__global__ __launch_bounds__(256) void linear_pack_multi_kernel(const LinPackEntry* __restrict__ tab, int n) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = n - 1;            // last entry with tile_begin <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].tile_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const LinPackEntry t = tab[lo];
+    const int tj_n = (int)((t.in + 63) >> 6);
+    const int ti = (int)(((int64_t)blockIdx.x - t.tile_begin) / tj_n), tj = (int)(((int64_t)blockIdx.x - t.tile_begin) - (int64_t)ti * tj_n);
+    const int r0 = ti * 64, c0 = tj * 64;
+    const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = rr + 16 * i, row = r0 + r, col = c0 + 4 * q;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row < t.out) {
+            if (col + 3 < t.in && (t.in & 3) == 0) {
+                const float4 f = *reinterpret_cast<const float4*>(t.master + (int64_t)row * t.in + col);
+                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = col + u < t.in ? t.master[(int64_t)row * t.in + col + u] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tile[r][4 * q + u] = v[u];
+        if (row < t.out_p) {
+            if (col + 3 < t.in && (t.in & 3) == 0) {
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                *reinterpret_cast<uint2*>(t.w + (int64_t)row * t.in + col) = pk;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (col + u < t.in) t.w[(int64_t)row * t.in + col + u] = f32_to_bf16(v[u]);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = rr + 16 * i, col = c0 + c, row = r0 + 4 * q;        // wt row = input feature `col`, four output features from `row`
+        if (col < t.in && row < t.out_p) {                               // (out_p is a multiple of 8: a quad never straddles the end)
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(tile[4 * q][c]) | ((unsigned)f32_to_bf16(tile[4 * q + 1][c]) << 16);
+            pk.y = (unsigned)f32_to_bf16(tile[4 * q + 2][c]) | ((unsigned)f32_to_bf16(tile[4 * q + 3][c]) << 16);
+            *reinterpret_cast<uint2*>(t.wt + (int64_t)col * t.out_p + row) = pk;
+        }
+    }
+}
+
 // grad_oihw[co][ci][tap] += dw[co][tap][ci]   (dw: [Cout][taps][Cin_p] fp32)
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dw, int64_t Cout, int64_t Cin,
                                                            int64_t taps, int64_t Cin_p, float* __restrict__ g) {
@@ -813,6 +878,14 @@ int dvq_pack_weights_multi(const void* table_dev, int64_t n_entries, int64_t tot
     pack_weights_multi_kernel<<<dim3(nblocks(total_work, 1024)), dim3(256), 0, (hipStream_t)stream>>>(
         (const PackEntry*)table_dev, (int)n_entries, total_work);
     DVQ_CHECK_LAUNCH("pack_weights_multi");
+    return DVQ_OK;
+}
+
+int dvq_linear_pack_multi(const void* table_dev, int64_t n_entries, int64_t total_tiles, dvq_stream_t stream) {
+    DVQ_REQUIRE(table_dev && n_entries > 0 && n_entries < (1 << 30) && total_tiles > 0 && total_tiles < (1ll << 31), DVQ_EINVAL,
+                "dvq_linear_pack_multi: bad arguments");
+    linear_pack_multi_kernel<<<dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream>>>((const LinPackEntry*)table_dev, (int)n_entries);
+    DVQ_CHECK_LAUNCH("linear_pack_multi");
     return DVQ_OK;
 }
 

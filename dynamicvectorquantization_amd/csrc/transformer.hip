@@ -16,6 +16,14 @@ inline unsigned nblk(int64_t work, int per_block, int64_t cap = 1 << 20) {
     return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+// value as it would be read back from a tensor of element type T (fused kernels that replace "store, then read in the next kernel":
+// same rounding as the unfused sequence)
+template <typename T>
+__device__ __forceinline__ float bf16_round_like(float v) {
+    if constexpr (sizeof(T) == 2) return bf16_to_f32(f32_to_bf16(v));
+    else return v;
+}
+
 // ---- LayerNorm: one wave per row, lanes stride over 8-channel vectors -------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int64_t rows, int C8, float eps,
@@ -65,7 +73,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
                                                      const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int rows_per_wave, const T* __restrict__ res,
-                                                     float* __restrict__ part) {
+                                                     float* __restrict__ part, T* __restrict__ dx_drop, float drop_p, unsigned rm,
+                                                     unsigned ra) {
     const int lane = threadIdx.x & 63;
     const int64_t C = (int64_t)C8 * 8;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -153,6 +162,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
                     for (int j = 0; j < 8; ++j) o[j] += rr[j];
                 }
                 store8(dx + r * C + c8 * 8, o);
+                if (dx_drop != nullptr) {
+                    // second output: dropout(dx) with the decisions of dvq_dropout(dx, p, seed) -- the backward of the dropout that sits
+                    // between this gradient and its next consumer (resid_drop ahead of the attention projection / the MLP of the block
+                    // below) without a pass of its own over the [rows, C] tensor.  Element index = r * C + c, as in dropout_kernel
+                    const float dscale = 1.f / (1.f - drop_p);
+                    const unsigned thr = (unsigned)((double)drop_p * 4294967296.0);
+                    const unsigned long long i0 = (unsigned long long)(r * C + c8 * 8);
+                    const unsigned base = ra + (unsigned)(i0 >> 32) * 0x9E3779B1u;
+                    float od[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        // the dropped copy is taken from the STORED value (rounded to T like the tensor dvq_dropout would read)
+                        const float st = bf16_round_like<T>(o[j]);
+                        od[j] = dvq_hash32(((unsigned)i0 + j) * rm + base) >= thr ? st * dscale : 0.f;
+                    }
+                    store8(dx_drop + r * C + c8 * 8, od);
+                }
             }
         }
     }
@@ -457,13 +483,6 @@ __global__ __launch_bounds__(256) void cross_entropy_vec_kernel(const T* __restr
     ce_fold(lsum, lcnt, loss_sum, cnt);
 }
 
-// (the unfused sequence stores dropout(a) in the compute dtype before adding: same rounding here)
-template <typename T>
-__device__ __forceinline__ float bf16_round_like(float v) {
-    if constexpr (sizeof(T) == 2) return bf16_to_f32(f32_to_bf16(v));
-    else return v;
-}
-
 // ---- dropout: y = x * keep / (1 - p), keep decided by dvq_hash32 of (seed, element index) (dvq_common.h).  The same call
 // with the same seed applies the same mask to a gradient. ---------------------------------------------------------------
 template <typename T>
@@ -524,6 +543,15 @@ int dvq_layernorm_bwd(const void* x, const void* dy, int dtype, int64_t rows, in
 
 int dvq_layernorm_bwd_res(const void* x, const void* dy, const void* dres, int dtype, int64_t rows, int64_t C, const float* mean_rstd,
                           const float* gamma, void* dx, float* dgamma, float* dbeta, dvq_stream_t stream) {
+    return dvq_layernorm_bwd_res_drop(x, dy, dres, dtype, rows, C, mean_rstd, gamma, dx, dgamma, dbeta, nullptr, 0.f, 0, stream);
+}
+
+int dvq_layernorm_bwd_res_drop(const void* x, const void* dy, const void* dres, int dtype, int64_t rows, int64_t C, const float* mean_rstd,
+                               const float* gamma, void* dx, float* dgamma, float* dbeta, void* dx_drop, float p_drop, uint64_t seed,
+                               dvq_stream_t stream) {
+    DVQ_REQUIRE(dx_drop == nullptr || (p_drop > 0.f && p_drop < 1.f), DVQ_EINVAL, "dvq_layernorm_bwd_res_drop: p_drop must be in (0, 1)");
+    unsigned rm = 1u, ra = 0u;
+    dvq_dropout_seed(seed, &rm, &ra);
     DVQ_REQUIRE(x && dy && mean_rstd && gamma && dx && dgamma && dbeta && rows > 0 && C > 0 && C % 8 == 0 && C <= 4096, DVQ_EINVAL,
                 "dvq_layernorm_bwd: bad arguments (C %% 8 == 0, C <= 4096)");
     static const int ln_waves = [] {
@@ -545,7 +573,8 @@ int dvq_layernorm_bwd_res(const void* x, const void* dy, const void* dres, int d
 #define DVQ_LN_BWD(NVV) \
     DVQ_DISPATCH_DTYPE(dtype, T, if (lds > 48 * 1024) dvq_ensure_dynamic_lds((const void*)ln_bwd_kernel<T, NVV>, (int)lds); \
                                  ln_bwd_kernel<T, NVV><<<grid, dim3(256), lds, (hipStream_t)stream>>>( \
-                                     (const T*)x, (const T*)dy, rows, c8, mean_rstd, gamma, (T*)dx, dgamma, dbeta, rpw, (const T*)dres, part);)
+                                     (const T*)x, (const T*)dy, rows, c8, mean_rstd, gamma, (T*)dx, dgamma, dbeta, rpw, (const T*)dres, part, \
+                                     (T*)dx_drop, p_drop, rm, ra);)
     if (c8 <= 64) { DVQ_LN_BWD(1); } else if (c8 <= 128) { DVQ_LN_BWD(2); } else if (c8 <= 256) { DVQ_LN_BWD(4); } else { DVQ_LN_BWD(8); }
 #undef DVQ_LN_BWD
     if (part != nullptr)

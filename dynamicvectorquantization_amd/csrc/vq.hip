@@ -20,9 +20,11 @@ namespace {
 
 struct VqPrepView {
     float* emax;     // [1]  max_k |e_k|   (stored as float bits, atomicMax on uint)
+    float* emaxc;    // [32] max |e_k| over the codes of residue class k mod 32 (same encoding), header floats 16 .. 47
     float* en;       // [Kp] |e_k|^2 (fp64 accumulate, rounded); +inf for padded codes
     bf16_t* e1;      // [Kp][D]
     bf16_t* e2;      // [Kp][D]
+    float* enrm;     // [Kp] |e_k| rounded up (0 for padded codes): the per-code term of the error bound (round 5)
     int64_t Kp;
 };
 
@@ -33,10 +35,12 @@ __host__ __device__ inline VqPrepView prep_view(void* prep, int64_t K, int64_t D
     v.Kp = align_up(K, 32);
     char* p = (char*)prep;
     v.emax = (float*)p;
+    v.emaxc = (float*)p + 16;
     v.en = (float*)(p + 256);
     int64_t off = 256 + align_up(v.Kp * 4, 256);
     v.e1 = (bf16_t*)(p + off);
     v.e2 = (bf16_t*)(p + off + v.Kp * D * 2);
+    v.enrm = (float*)(p + off + 2 * v.Kp * D * 2);
     return v;
 }
 
@@ -76,9 +80,12 @@ __global__ void vq_prepare_kernel(const float* __restrict__ cb, int64_t K, int64
         if (k < K) {
             pv.en[k] = (float)acc;
             float nrm = (float)sqrt(acc) * 1.0000002f;  // round up
+            pv.enrm[k] = nrm;
             atomicMax((unsigned*)pv.emax, __float_as_uint(nrm));
+            atomicMax((unsigned*)(pv.emaxc + (k & 31)), __float_as_uint(nrm));
         } else {
             pv.en[k] = __builtin_inff();
+            pv.enrm[k] = 0.f;
         }
     }
 }
@@ -181,7 +188,7 @@ __device__ __forceinline__ void vq_select_rows(float (&b1)[16], float (&b2)[16],
 constexpr int VQ_SEL_WORDS = 3 * 32 * 33;          // LDS words per wave: b1, b2, i1 [32 rows][33]
 template <int D>
 __device__ __forceinline__ void vq_select_rows_lds(const float (&b1)[16], const float (&b2)[16], const int (&i1)[16], const float* xnorm32,
-                                                   const float emax, const int lane, const int64_t row0, const int64_t N,
+                                                   const VqPrepView& pv, const int lane, const int64_t row0, const int64_t N,
                                                    int64_t* __restrict__ idx_out, VqWs* ws, float* scr) {
     const int half = lane >> 5, l31 = lane & 31;
     float* s1 = scr;
@@ -219,21 +226,34 @@ __device__ __forceinline__ void vq_select_rows_lds(const float (&b1)[16], const 
         gi = take ? oi : gi;
     }
     m2 = fminf(m2, __shfl_xor(m2, 32, 64));         // smallest second-best of any class of the row
-    // error bound of one score: split residual 3*2^-18, accumulate D*2^-23 (relative to |x||e|),
-    // norm rounding + final fma 4*2^-24; two scores are compared -> factor 2, -2x.e -> factor 2.
+    // Error bound of ONE score s_k = |e_k|^2 - 2 x.e_k: the dot product is off by at most (3 * 2^-18 [split residual] + D * 2^-23
+    // [accumulation]) |x| |e_k|, times 2 for the factor -2; norm rounding + final fma 4 * 2^-24 of the score's magnitude.  Two scores are
+    // compared, so code k can beat the approximate best g only if  s~_k - s~_g <= E_k + E_g =: tau_k,
+    //   tau_k = coefA / 2 * |x| (|e_k| + |e_g|) + coefB (emax + |x|)^2.
+    // Round 5: |e_k| is the CODE'S OWN norm (prep.enrm), not the global maximum -- once training has grown a few long codes (|e| 8.7
+    // against a median of 2.4 after 30 steps) the global bound flagged 4 x the rows the per-code bound does.  A class's SECOND-best code
+    // is not tracked by index: it is bounded by the class maximum (prep.emaxc), which is sound for every code of the class.
     const float coefA = 4.0f * (3.0f * 3.8147e-6f + (float)D * 1.1921e-7f);
     const float coefB = 8.0f * 5.9605e-8f;
     const float xn = xnorm32[row];
-    const float tau = coefA * xn * emax + coefB * (emax * emax + 2.0f * xn * emax + xn * xn) + 1e-37f;
-    // a code whose exact score is minimal has an approximate score <= gb + tau: it is the winner of a class with b1 <= gb + tau
+    const float emax = *pv.emax;
+    const unsigned kpm1 = (unsigned)pv.Kp - 1u;
+    const float eg = pv.enrm[min((unsigned)gi, kpm1)];
+    const float hA = 0.5f * coefA * xn;
+    const float tB = coefB * (emax * emax + 2.0f * xn * emax + xn * xn) + 1e-37f;
+    const float tbase = fmaf(hA, eg, tB);            // tau_k = tbase + hA |e_k|
+    // a code whose exact score is minimal has an approximate score <= gb + tau_k: it is the winner of a class with b1 <= gb + tau
     // (mask mc), unless that class holds two such codes (b2 <= gb + tau: mask mo -> the whole class is re-ranked)
     unsigned mc = 0u;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) mc |= (v[j] - gb > tau) ? 0u : (1u << j);
+    for (int j = 0; j < 16; ++j) {
+        const float ek = pv.enrm[min((unsigned)si[row * 33 + c0 + j], kpm1)];       // (a class without a finite score keeps index 0x7fffffff)
+        mc |= (v[j] - gb > fmaf(hA, ek, tbase)) ? 0u : (1u << j);
+    }
     unsigned mo = 0u;
-    if (!(m2 - gb > tau)) {                          // rare: some class of this row holds a second code within tau
+    if (!(m2 - gb > fmaf(hA, emax, tbase))) {        // rare: some class of this row may hold a second code within its bound
 #pragma unroll
-        for (int j = 0; j < 16; ++j) mo |= (s2[row * 33 + c0 + j] - gb > tau) ? 0u : (1u << j);
+        for (int j = 0; j < 16; ++j) mo |= (s2[row * 33 + c0 + j] - gb > fmaf(hA, pv.emaxc[c0 + j], tbase)) ? 0u : (1u << j);
     }
     const unsigned mh = (mc << c0) | ((unsigned)__shfl_xor((int)mc, 32, 64) << (16 - c0));
     const unsigned oh = (mo << c0) | ((unsigned)__shfl_xor((int)mo, 32, 64) << (16 - c0));
@@ -596,9 +616,8 @@ __global__ __launch_bounds__(64 * NW, 1) void vq_argmin_mfma_pipe_kernel(const X
             }
         }
     }
-    const float emax = *pv.emax;
     __syncthreads();                                    // every wave is done with the stages: they become the selection scratch
-    vq_select_rows_lds<D>(b1, b2, i1, xnorm + wave * 32, emax, lane, row0, N, idx_out, ws, reinterpret_cast<float*>(smem) + wave * VQ_SEL_WORDS);
+    vq_select_rows_lds<D>(b1, b2, i1, xnorm + wave * 32, pv, lane, row0, N, idx_out, ws, reinterpret_cast<float*>(smem) + wave * VQ_SEL_WORDS);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -915,12 +934,11 @@ __global__ __launch_bounds__(256, 1) void vq_argmin_mfma_rb2_kernel(const XT* __
         }
     }
     stamp(3);
-    const float emax = *pv.emax;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the trailing (unread) DMA pieces have landed too
     __syncthreads();                                    // every wave is done with the stage ring: it becomes the selection scratch
     float* scr = reinterpret_cast<float*>(smem) + wave * VQ_SEL_WORDS;
-    vq_select_rows_lds<D>(b1[0], b2[0], i1[0], xnorm + wave * 64, emax, lane, row0, N, idx_out, ws, scr);
-    if constexpr (!XF32) vq_select_rows_lds<D>(b1[1], b2[1], i1[1], xnorm + wave * 64 + 32, emax, lane, row0 + 32, N, idx_out, ws, scr);
+    vq_select_rows_lds<D>(b1[0], b2[0], i1[0], xnorm + wave * 64, pv, lane, row0, N, idx_out, ws, scr);
+    if constexpr (!XF32) vq_select_rows_lds<D>(b1[1], b2[1], i1[1], xnorm + wave * 64 + 32, pv, lane, row0 + 32, N, idx_out, ws, scr);
     stamp(4);
     if constexpr (dbg & 32) {
         if (blockIdx.x == 7 && tid == 0) {
@@ -1478,7 +1496,7 @@ extern "C" {
 
 size_t dvq_vq_prep_bytes(int64_t K, int64_t D) {
     int64_t Kp = align_up(K, 32);
-    return (size_t)(256 + align_up(Kp * 4, 256) + 2 * Kp * D * 2);
+    return (size_t)(256 + align_up(Kp * 4, 256) + 2 * Kp * D * 2 + align_up(Kp * 4, 256));
 }
 
 int dvq_vq_prepare(const float* codebook, int64_t K, int64_t D, void* prep, dvq_stream_t stream) {

@@ -536,6 +536,10 @@ def pack_weights_multi(table_dev, n_entries, total_work):
     check(lib().dvq_pack_weights_multi(_p(table_dev), n_entries, total_work, _s()), "dvq_pack_weights_multi")
 
 
+def linear_pack_multi(table_dev, n_entries, total_tiles):
+    check(lib().dvq_linear_pack_multi(_p(table_dev), n_entries, total_tiles, _s()), "dvq_linear_pack_multi")
+
+
 # ---------------------------------------------------------------------------------------------
 # zero arena: one memset per step instead of one torch.zeros per small statistics buffer
 # ---------------------------------------------------------------------------------------------
@@ -852,14 +856,20 @@ def layernorm_fwd(x2d, gamma, beta, eps=1e-5, want_stats=True):
     return y, mr
 
 
-def layernorm_bwd(x2d, dy, mr, gamma, dgamma, dbeta, dres=None):
-    """dx (+ dres: the gradient of the residual stream that by-passes the normalisation, added in the same pass)"""
+def layernorm_bwd(x2d, dy, mr, gamma, dgamma, dbeta, dres=None, drop=None):
+    """dx (+ dres: the gradient of the residual stream that by-passes the normalisation, added in the same pass).
+    drop = (p, seed): also returns dropout(dx, p, seed) -- the same decisions as `dropout(dx, p, seed)` -- as a second tensor"""
     rows, c = x2d.shape
     dx = torch.empty_like(x2d)
     ensure_workspace(x2d.device)          # per-workgroup dgamma / dbeta partials + fold kernel instead of a million atomics
+    if drop is not None and drop[0] > 0.0:
+        dxd = torch.empty_like(x2d)
+        check(lib().dvq_layernorm_bwd_res_drop(_p(x2d), _p(dy), _p(dres), dt(x2d), rows, c, _p(mr), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
+                                               _p(dxd), float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, _s()), "dvq_layernorm_bwd_res_drop")
+        return dx, dxd
     check(lib().dvq_layernorm_bwd_res(_p(x2d), _p(dy), _p(dres), dt(x2d), rows, c, _p(mr), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _s()),
           "dvq_layernorm_bwd_res")
-    return dx
+    return dx if drop is None else (dx, None)
 
 
 def gelu(x):

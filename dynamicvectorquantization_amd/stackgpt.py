@@ -36,6 +36,10 @@ class StackGPTConfig:
 _next_seed = rt.next_dropout_seed
 
 
+def _fuse_drop_bwd() -> bool:
+    return os.environ.get("DVQ_FUSE_DROP_BWD", "1") != "0"
+
+
 def _drop(x, p, training, tape, key):
     if not training or p <= 0.0:
         return x
@@ -73,9 +77,14 @@ class LayerNorm(nn.Module):
             tape.s.update(x=x2d, mr=mr)
         return y
 
-    def bwd(self, dy, tape, dres=None):
-        """dres: gradient of the residual stream around this normalisation, added to the result in the same pass"""
-        return K.layernorm_bwd(tape.s["x"], dy, tape.s["mr"], self.weight, _grad_buf(self.weight), _grad_buf(self.bias), dres)
+    def bwd(self, dy, tape, dres=None, drop=None):
+        """dres: gradient of the residual stream around this normalisation, added to the result in the same pass.
+        drop = (p, seed) or False / None: with a tuple (or False) the result is (dx, dropout(dx, p, seed) or None) -- the backward of the
+        dropout that follows on the way down, written by the same kernel"""
+        if drop is None:
+            return K.layernorm_bwd(tape.s["x"], dy, tape.s["mr"], self.weight, _grad_buf(self.weight), _grad_buf(self.bias), dres)
+        return K.layernorm_bwd(tape.s["x"], dy, tape.s["mr"], self.weight, _grad_buf(self.weight), _grad_buf(self.bias), dres,
+                               drop=drop if drop else (0.0, 0))
 
 
 class CausalSelfAttention(nn.Module):
@@ -137,12 +146,13 @@ class CausalSelfAttention(nn.Module):
             return _drop_add(resid, out, self.resid_drop.p, self.training, tape, "rdrop")
         return _drop(out, self.resid_drop.p, self.training, tape, "rdrop")
 
-    def bwd(self, dout, tape):
+    def bwd(self, dout, tape, dout_dropped=None):
+        """dout_dropped: resid_drop's backward already applied to dout (written by the LayerNorm backward that produced dout)"""
         s_ = tape.s
         q, k, v, p, pd, b, t = s_["q"], s_["k"], s_["v"], s_["p"], s_["pd"], s_["b"], s_["t"]
         c = q.shape[1]
         nh, hs = self.n_head, c // self.n_head
-        dout = _drop_bwd(dout, tape, "rdrop")
+        dout = dout_dropped if dout_dropped is not None else _drop_bwd(dout, tape, "rdrop")
         dy = self.proj.bwd(dout, tape.child("proj"))
         if "fused" in s_:
             p_drop, seed = s_["fused"]
@@ -195,13 +205,25 @@ class Block(nn.Module):
             tape.s["hid"] = hid
         return _drop_add(x1, m, self.mlp[3].p, self.training, tape, "mdrop")
 
-    def bwd(self, d, tape):
-        dm = _drop_bwd(d, tape, "mdrop")
+    def bwd(self, d, tape, d_dropped=None, next_drop=None):
+        """d: gradient of the block's output.  The two dropouts on the way down (the MLP's, the attention projection's) need
+        dropout(gradient) of tensors a LayerNorm backward has just written: that kernel emits the dropped copy too (fused: 2 x 24
+        stand-alone dropout passes of a p6c18 train step, 2.6 ms, disappear).  d_dropped: the MLP dropout's backward of d, already
+        made by the block above; next_drop: (p, seed) of the MLP dropout of the block BELOW, or False -- then the result is the pair
+        (dx, dropout(dx) or None) for that block.  DVQ_FUSE_DROP_BWD=0: stand-alone passes"""
+        fuse = _fuse_drop_bwd()
+        dm = d_dropped if d_dropped is not None else _drop_bwd(d, tape, "mdrop")
         dact = self.mlp[2].bwd(dm, tape.child("fc2"))
         dh2 = self.mlp[0].bwd(K.gelu_bwd(tape.s["hid"], dact), tape.child("fc1"))
-        dx1 = self.ln2.bwd(dh2, tape.child("ln2"), dres=d)
-        dh1 = self.attn.bwd(dx1, tape.child("attn"))
-        return self.ln1.bwd(dh1, tape.child("ln1"), dres=dx1)
+        rd = tape.child("attn").s.get("rdrop") if fuse else None
+        if rd is not None:
+            dx1, dx1d = self.ln2.bwd(dh2, tape.child("ln2"), dres=d, drop=rd)
+        else:
+            dx1, dx1d = self.ln2.bwd(dh2, tape.child("ln2"), dres=d), None
+        dh1 = self.attn.bwd(dx1, tape.child("attn"), dout_dropped=dx1d)
+        if next_drop is None:
+            return self.ln1.bwd(dh1, tape.child("ln1"), dres=dx1)
+        return self.ln1.bwd(dh1, tape.child("ln1"), dres=dx1, drop=next_drop if fuse else False)
 
 
 def _attn_append(attn, x2d, b, n, cache, t0):
@@ -387,7 +409,9 @@ class DecodeState:
             return body(*ent["static"])
         if ent["graph"] is None:
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
+            # thread-local capture mode: another sampling lane (Dualformer.sample_many runs one host thread per stream) may launch and
+            # allocate on ITS stream while this one records
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                 ent["out"] = body(*ent["static"])
             ent["graph"] = gr
         ent["graph"].replay()
@@ -540,8 +564,11 @@ class StackGPT(nn.Module):
 
     def _run_bwd(self, blocks, g, tape, name):
         hook = getattr(self, "_grad_hook", None)
+        gd = None
         for i in reversed(range(len(blocks))):
-            g = blocks[i].bwd(g, tape.child(f"{name}{i}"))
+            # (p, seed) of the MLP dropout of the block below: its backward is written by this block's last LayerNorm backward
+            nd = (tape.child(f"{name}{i - 1}").s.get("mdrop") or False) if i > 0 else False
+            g, gd = blocks[i].bwd(g, tape.child(f"{name}{i}"), d_dropped=gd, next_drop=nd)
             if hook is not None:           # data parallel: this block's gradients are final -> their all-reduce starts now
                 hook(list(blocks[i].parameters()))
         return g

@@ -20,6 +20,10 @@ from .config import instantiate_from_config
 from .kernels import lib
 
 
+import threading as _threading
+
+_SAMPLER_LANE = _threading.local()          # .index: 0 = the sequential sampler; 1.. = a lane of Dualformer.sample_many
+
 class DualGrainSeperatePermuter(nn.Module):
     def __init__(self, coarse_hw=16, fine_hw=32, content_pad_code=1024, content_eos_code=1025, coarse_position_pad_code=256,
                  coarse_position_eos_code=257, fine_position_pad_code=1024, fine_position_eos_code=1025,
@@ -394,11 +398,20 @@ class _SamplerMixin:
             # {seed, counter} of the kernel's counter-based generator, keyed by torch's seed: a later torch.manual_seed() /
             # seed_everything() restarts the stream (same seed -> same samples, like the op-by-op path's torch generator)
             seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
-            st = self.__dict__.get("_sampler_state")
-            if st is None or st.device != logits2d.device or self.__dict__.get("_sampler_seed") != seed:
-                st = torch.tensor([seed, 0], dtype=torch.int64, device=logits2d.device)
-                self.__dict__["_sampler_state"] = st
-                self.__dict__["_sampler_seed"] = seed
+            lane = int(getattr(_SAMPLER_LANE, "index", 0))      # concurrent sampling (sample_many): one generator stream per lane
+            if lane:
+                seed = (seed * 0x9E3779B1 + lane) & 0x7FFFFFFFFFFFFFFF
+                states = self.__dict__.setdefault("_sampler_lane_states", {})
+                st = states.get(lane)
+                if st is None or st[1].device != logits2d.device or st[0] != seed:
+                    st = states[lane] = (seed, torch.tensor([seed, 0], dtype=torch.int64, device=logits2d.device))
+                st = st[1]
+            else:
+                st = self.__dict__.get("_sampler_state")
+                if st is None or st.device != logits2d.device or self.__dict__.get("_sampler_seed") != seed:
+                    st = torch.tensor([seed, 0], dtype=torch.int64, device=logits2d.device)
+                    self.__dict__["_sampler_state"] = st
+                    self.__dict__["_sampler_seed"] = seed
             kw = self._fused_rule(kind)
             if kind != "content":
                 kw["forbid_idx"] = sampled
@@ -450,10 +463,12 @@ class _SamplerMixin:
         rows = self.hw1 * self.hw1 + self.fine_hw * self.fine_hw + 8
         pool = self.__dict__.setdefault("_decode_states", {})
         from . import runtime as _rt
-        key = (b, rows, str(dev), str(_rt.compute_dtype()))
+        lane = int(getattr(_SAMPLER_LANE, "index", 0))        # sample_many: one state (caches + captured token-step graphs) per lane
+        key = (b, rows, str(dev), str(_rt.compute_dtype()), lane)
         st = pool.get(key)
         if st is None or st.gpt is not tr:
-            pool.clear()                                      # one resident state: the K/V caches are the big allocation
+            for k_ in [k_ for k_ in pool if k_[4] == lane]:   # one resident state per lane: the K/V caches are the big allocation
+                pool.pop(k_)
             st = pool[key] = DecodeState(tr, b, rows)
         st.reset()
         zeros1 = torch.zeros(b, 1, dtype=torch.long, device=dev)
@@ -523,6 +538,77 @@ class _SamplerMixin:
         if self.activate_sos_for_fine_sequence:
             x_f, x_pf = x_f[:, c_fine.shape[1]:], x_pf[:, c_fine.shape[1]:]
         return x_c, x_f, x_pc, x_pf
+
+    @torch.no_grad()
+    def sample_many(self, conds, n_streams=2, **kw):
+        """sample_from_scratch for a LIST of independent batches (conds[i] = the six conditioning tensors of batch i), `n_streams`
+        of them in flight at a time, each on its own HIP stream with its own K/V caches, captured token-step graphs and generator
+        stream.  A token step is ~120 dependent launches of 5 - 12 us that stream a few MB each: ONE batch leaves the chip idle
+        through every launch boundary and load round trip, and the reference's loop (dqtransformer_uncond_entropy.py:302-466) reads
+        its `done` flags on the host every iteration.  Two lanes fill each other's gaps -- the metric is token-steps/s, the
+        sampling scripts draw hundreds of batches anyway.  Each lane is a host thread (the per-iteration host read-back releases the
+        GIL, so the lanes ping-pong); the first batch of every lane runs ALONE (it captures that lane's graphs: stream capture
+        must not see another thread's launches).  Returns the results in the order of `conds`.  Greedy draws equal the sequential
+        sampler's token for token; multinomial draws use one generator stream per lane."""
+        import threading
+        n = len(conds)
+        n_streams = max(1, min(int(n_streams), n))
+        if n_streams == 1:
+            return [self.sample_from_scratch(*c, **kw) for c in conds]
+        dev = conds[0][0].device
+        lanes = self.__dict__.setdefault("_sampler_lanes", {})
+        streams = [lanes.setdefault((str(dev), i), torch.cuda.Stream(dev)) for i in range(n_streams)]
+        results, errors = [None] * n, []
+        main = torch.cuda.current_stream(dev)
+        seed = torch.initial_seed()
+        from . import runtime as _rt
+        cd = _rt.compute_dtype()
+
+        def run(i, lane):
+            _SAMPLER_LANE.index = lane + 1
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(streams[lane]):       # (the compute dtype is process-wide state: the lanes inherit it)
+                    results[i] = self.sample_from_scratch(*conds[i], **kw)
+            except BaseException as e:                  # surfaced by the caller's thread
+                errors.append(e)
+            finally:
+                _SAMPLER_LANE.index = 0
+
+        for s in streams:
+            s.wait_stream(main)
+        warm = self.__dict__.setdefault("_sampler_lanes_warm", set())
+        todo = list(range(n))
+        for lane in range(n_streams):                   # graphs of a lane that has not sampled this geometry yet: alone
+            hw = self.transformer.content_head[1].weight
+            wkey = (lane, tuple(conds[0][0].shape), str(cd), id(self.transformer), _rt.param_epoch(hw), hw._version, hw.data_ptr())
+            if wkey not in warm and todo:
+                run(todo.pop(0), lane)
+                streams[lane].synchronize()
+                warm.add(wkey)
+        if errors:
+            raise errors[0]
+        lock = threading.Lock()
+
+        def worker(lane):
+            while True:
+                with lock:
+                    if not todo or errors:
+                        return
+                    i = todo.pop(0)
+                run(i, lane)
+
+        threads = [threading.Thread(target=worker, args=(lane,), daemon=True) for lane in range(n_streams)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for s in streams:
+            main.wait_stream(s)
+        if errors:
+            raise errors[0]
+        assert torch.initial_seed() == seed
+        return results
 
     @torch.no_grad()
     def sample_from_scratch(self, c_coarse, c_fine, c_pos_coarse, c_pos_fine, c_seg_coarse, c_seg_fine, temperature=1.0, sample=True,

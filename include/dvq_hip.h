@@ -218,6 +218,11 @@ int dvq_conv2d_wgrad_oihw(const dvq_conv_desc* d, const void* x, const void* dy,
  * Cin_p and Cout_p must be multiples of 4 (the kernel moves four destination elements per thread); DVQ_EINVAL otherwise is NOT
  * checked on the device table: the caller pads channels to the vector width of the dtype (4 fp32 / 8 bf16) anyway. */
 int dvq_pack_weights_multi(const void* table_dev, int64_t n_entries, int64_t total_work, dvq_stream_t stream);
+/* The same for nn.Linear weights (stackgpt.py:44-96): table_dev = device array of n_entries records
+ * { const float* master [out][in]; bf16* w [out_p][in]; bf16* wt [in][out_p]; int64 out, in, out_p, tile_begin } with out_p a multiple of
+ * 8 (rows >= out of w and columns >= out of wt are written as zero), tile_begin the exclusive prefix sum of
+ * ceil(out_p / 64) * ceil(in / 64) and total_tiles the full sum: ONE launch per optimizer step instead of a cast + a transpose per layer. */
+int dvq_linear_pack_multi(const void* table_dev, int64_t n_entries, int64_t total_tiles, dvq_stream_t stream);
 
 /* weight packing: master fp32 OIHW (the reference's nn.Conv2d parameter layout) -> `dtype`
  * w [Cout][KH][KW][Cin_p] (forward / wgrad layout) and wt [Cin][KH][KW][Cout_p] (dgrad layout), zero padded
@@ -402,6 +407,12 @@ int dvq_layernorm_bwd(const void* x, const void* dy, int dtype, int64_t rows, in
  * residual stream of a transformer block (stackgpt.py:80-96) without a separate add pass */
 int dvq_layernorm_bwd_res(const void* x, const void* dy, const void* dres, int dtype, int64_t rows, int64_t C, const float* mean_rstd,
                           const float* gamma, void* dx, float* dgamma, float* dbeta, dvq_stream_t stream);
+/* the same with a SECOND output dx_drop = dropout(dx, p_drop, seed) (the decisions of dvq_dropout on the same tensor: element index =
+ * row * C + column): the backward of the nn.Dropout that sits between this gradient and its next consumer (stackgpt.py:66-69,91-96)
+ * without its own pass.  dx_drop NULL: identical to dvq_layernorm_bwd_res. */
+int dvq_layernorm_bwd_res_drop(const void* x, const void* dy, const void* dres, int dtype, int64_t rows, int64_t C, const float* mean_rstd,
+                               const float* gamma, void* dx, float* dgamma, float* dbeta, void* dx_drop, float p_drop, uint64_t seed,
+                               dvq_stream_t stream);
 /* nn.GELU() (exact erf form) and its backward (x = pre-activation) */
 int dvq_gelu(const void* x, int dtype, int64_t n, void* y, dvq_stream_t stream);
 int dvq_gelu_bwd(const void* x, const void* dy, int dtype, int64_t n, void* dx, dvq_stream_t stream);

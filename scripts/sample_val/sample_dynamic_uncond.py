@@ -53,6 +53,8 @@ def get_parser():
     parser.add_argument("--out_dir", type=str, default="")
     parser.add_argument("--dtype", type=str, default="bf16")
     parser.add_argument("--seed", type=int, default=None)
+    parser.add_argument("--streams", type=int, default=2,
+                        help="batches sampled concurrently, each on its own HIP stream (Dualformer.sample_many); 1 = one batch at a time")
     return parser
 
 
@@ -94,27 +96,36 @@ def main(per_image_png=False):
     model = model.eval().cuda()
 
     total_batch = (opt.sample_num + opt.batch_size - 1) // opt.batch_size
-    batch_size, steps, t0 = opt.batch_size, 0, time.perf_counter()
+    steps, t0 = 0, time.perf_counter()
+    sizes = [opt.batch_size] * total_batch
+    if opt.sample_num % opt.batch_size != 0:
+        sizes[-1] = opt.sample_num % opt.batch_size
+    kw = dict(temperature=opt.temperature, sample=True, top_k=opt.top_k, top_p=opt.top_p, top_k_pos=opt.top_k_pos, top_p_pos=opt.top_p_pos,
+              process=False, fix_fine_position=opt.sample_with_fixed_pos)
+    group = max(1, opt.streams) * 4                 # batches handed to the sampler at a time (their token sequences are small)
     with torch.no_grad():
-        for i in range(total_batch):
-            if opt.sample_num % opt.batch_size != 0 and i == total_batch - 1:
-                batch_size = opt.sample_num % opt.batch_size
-            x0 = torch.randn(batch_size, device="cuda")
-            c = model.encode_to_c(x0)
-            seqs = model.sample_from_scratch(*c, temperature=opt.temperature, sample=True, top_k=opt.top_k, top_p=opt.top_p,
-                                             top_k_pos=opt.top_k_pos, top_p_pos=opt.top_p_pos, process=False,
-                                             fix_fine_position=opt.sample_with_fixed_pos)
-            steps += batch_size * int(seqs[0].shape[1] + seqs[1].shape[1])
-            raw = model.decode_to_img(*seqs).float()
-            if per_image_png:
-                raw = raw.cpu().numpy()
-                for j in range(batch_size):
-                    save_image_normalized(raw[j], os.path.join(dir_img, "batch_{}_{}.png".format(i, j)))
-                continue
-            img = torch.clamp(raw * 0.5 + 0.5, 0, 1).cpu().numpy()
-            if opt.save_image:
-                save_image_grid(img, os.path.join(dir_img, "batch_{}.png".format(i)))
-            save_pickle(os.path.join(dir_pkl, "samples_({}_{}).pkl".format(i, total_batch)), img)
+        for g0 in range(0, total_batch, group):
+            idxs = [i for i in range(g0, min(total_batch, g0 + group))]
+            # full batches go through the concurrent lanes together; a ragged last batch (another cache geometry) runs on its own
+            full = [i for i in idxs if sizes[i] == opt.batch_size]
+            conds = {i: model.encode_to_c(torch.randn(sizes[i], device="cuda")) for i in idxs}
+            outs = dict(zip(full, model.sample_many([conds[i] for i in full], n_streams=opt.streams, **kw))) if full else {}
+            for i in idxs:
+                if i not in outs:
+                    outs[i] = model.sample_from_scratch(*conds[i], **kw)
+            for i in idxs:
+                batch_size, seqs = sizes[i], outs[i]
+                steps += batch_size * int(seqs[0].shape[1] + seqs[1].shape[1])
+                raw = model.decode_to_img(*seqs).float()
+                if per_image_png:
+                    raw = raw.cpu().numpy()
+                    for j in range(batch_size):
+                        save_image_normalized(raw[j], os.path.join(dir_img, "batch_{}_{}.png".format(i, j)))
+                    continue
+                img = torch.clamp(raw * 0.5 + 0.5, 0, 1).cpu().numpy()
+                if opt.save_image:
+                    save_image_grid(img, os.path.join(dir_img, "batch_{}.png".format(i)))
+                save_pickle(os.path.join(dir_pkl, "samples_({}_{}).pkl".format(i, total_batch)), img)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("sampled {} images, {} token steps in {:.2f} s ({:.0f} token-steps/s) -> {}".format(opt.sample_num, steps, dt, steps / dt, dir_img if per_image_png else dir_pkl))

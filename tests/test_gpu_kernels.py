@@ -79,6 +79,42 @@ def test_vq_argmin_ties(dev):
     assert int(flagged[:2].sum()) >= 20         # the rows nearest to the duplicated codes were re-ranked (same-class duplicates: whole class)
 
 
+@pytest.mark.parametrize("d", [64, 256])
+@pytest.mark.parametrize("rows", ["fp32", "bf16"])
+def test_vq_argmin_per_code_bound_mixed_norms(dev, d, rows):
+    """the selection's error bound uses each code's OWN norm (round 5): codebooks whose norms span four orders of magnitude, rows placed
+    a hair off the bisector of a short and a long code, of two long codes and of same-class pairs, plus rows at every scale -- the
+    result must stay the exact argmin (fp64 oracle), and the bound must flag far fewer rows than one global max-norm bound would"""
+    from dynamicvectorquantization_amd import kernels as K
+    from oracle import vq as ovq
+    rs = np.random.RandomState(11 + d)
+    k = 1024
+    cb = rs.standard_normal((k, d)).astype(np.float32)
+    scale = np.exp(rs.uniform(np.log(0.01), np.log(60.0), size=(k, 1))).astype(np.float32)
+    cb = cb / np.linalg.norm(cb, axis=1, keepdims=True) * scale
+    xs = []
+    pairs = [(rs.randint(k), rs.randint(k)) for _ in range(1500)] + [(j, j + 32 * rs.randint(1, 8)) for j in rs.randint(0, k - 256, 500)]
+    for a, b in pairs:                       # near-bisector rows: exact top-2 gap ~1e-6 .. 1e-3 of the scores
+        if a == b:
+            continue
+        mid = 0.5 * (cb[a] + cb[b])
+        dirn = (cb[b] - cb[a]) / max(1e-20, np.linalg.norm(cb[b] - cb[a]))
+        eps = 10.0 ** rs.uniform(-7, -3) * max(np.linalg.norm(cb[a]), np.linalg.norm(cb[b]))
+        xs.append(mid + (eps if rs.rand() < 0.5 else -eps) * dirn)
+    xs = np.stack(xs).astype(np.float32)
+    bulk = rs.standard_normal((6000, d)).astype(np.float32) * np.exp(rs.uniform(np.log(0.01), np.log(30.0), size=(6000, 1))).astype(np.float32)
+    x = np.concatenate([xs, bulk, cb[:200] * np.float32(1.0000001)], 0)
+    xt = T(x, dev)
+    if rows == "bf16":
+        xt = xt.to(torch.bfloat16)
+        x = xt.float().cpu().numpy()
+    idx, flagged = K.vq_argmin(xt, T(cb, dev), impl=2, return_flagged=True)
+    assert np.array_equal(idx.cpu().numpy(), ovq.argmin_exact(x, cb))
+    # how many rows ONE global bound (max norm ~60 for every pair) would have sent to the fp64 re-rank: most of the short-code rows
+    n_amb = int(flagged[:2].sum())
+    assert n_amb < 0.6 * len(x), (n_amb, len(x))
+
+
 @pytest.mark.parametrize("k", [1024, 8192])
 def test_vq_argmin_full_size_properties(dev, k):
     """BASELINE size N=65536: MFMA path == fp64 path on a row sample; codebook rows map to themselves."""
@@ -786,6 +822,49 @@ def test_linear_input_gradient(dev, shape):
     for got in outs:
         assert float((got - ref).abs().max()) / float(ref.abs().max()) < 1e-2
     assert float((outs[0] - outs[1]).abs().max()) / float(ref.abs().max()) < 1e-2
+
+
+def test_linear_multi_pack(dev):
+    """dvq_linear_pack_multi: ONE launch writes the bf16 copies w [out_p, in] and wt [in, out_p] of every Linear of an optimizer group --
+    bit-equal to the per-layer cast + transpose (rows / columns past `out` zero), refreshed when the parameters change, padded heads
+    and ragged widths included"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import LINEAR_PACKS, Linear
+    torch.manual_seed(5)
+    shapes = [(1024, 1024), (1024, 4096), (4096, 1024), (1024, 1026), (100, 72), (64, 8), (132, 515)]
+    lins = [Linear(i, o, bias=(k % 2 == 0)).to(dev) for k, (i, o) in enumerate(shapes)]
+    x = torch.randn(4, 8, device=dev)
+
+    def check():
+        for lin in lins:
+            w, b = lin._w(torch.bfloat16)
+            wt = lin._wt(w)
+            ref = torch.zeros(lin.out_p, lin.in_features, device=dev)
+            ref[: lin.out_features] = lin.weight.detach()
+            ref = ref.to(torch.bfloat16)
+            assert w.shape == ref.shape and torch.equal(w, ref), (lin.in_features, lin.out_features)
+            assert wt.shape == (lin.in_features, lin.out_p) and torch.equal(wt, ref.t().contiguous())
+            if lin.bias is not None:
+                assert b.shape[0] == lin.out_p and torch.equal(b[: lin.out_features], lin.bias.detach())
+                assert float(b[lin.out_features:].abs().sum()) == 0.0
+
+    check()                                   # first use: each layer packs itself (table of one)
+    ptrs = [lin._lpack["w"].data_ptr() for lin in lins]
+    with torch.no_grad():
+        for lin in lins:
+            lin.weight.mul_(-1.5)              # _version changes: stale copies must be noticed ...
+            if lin.bias is not None:
+                lin.bias.add_(1.0)
+    check()                                   # ... and now ONE launch refreshes all of them
+    assert [lin._lpack["w"].data_ptr() for lin in lins] == ptrs          # persistent buffers
+    assert LINEAR_PACKS.tables, "the group table was not built"
+    rt.bump_weights_epoch()
+    with torch.no_grad():
+        lins[2].weight.copy_(torch.randn_like(lins[2].weight))
+    check()
+    # the layer's products run on the packed copies
+    y = lins[4].fwd(torch.randn(256, 100, device=dev).to(torch.bfloat16), None)
+    assert y.shape == (256, 72) and bool(torch.isfinite(y.float()).all())
 
 
 @pytest.mark.parametrize("shape", [(8, 1024, 1024, 1), (1, 1032, 1024, 0), (32, 4096, 1024, 1), (8, 1024, 4096, 1), (13, 72, 200, 1), (32, 264, 64, 0)],

@@ -108,9 +108,8 @@ def test_lpips_lin_dropout_kernel(dev):
     assert torch.equal(va, vb) and not torch.equal(va, vc)
     mean = torch.stack([head(f1, 0.5, 1000 + s)[0] for s in range(64)]).mean(0)
     assert float(((mean - v0).abs() / v0).max()) < 0.01, (mean, v0)
-    # half of the elements carry no gradient, the rest twice the undropped one
-    frac_zero = float(((da == 0) & (d0 != 0)).float().sum() / (d0 != 0).float().sum())
-    assert 0.45 < frac_zero < 0.55, frac_zero
+    # (a dropped element still receives gradient through the channel normalisation of its pixel: no zero pattern to look for --
+    #  the finite difference below is the check)
     u = torch.randn_like(f1) * (f1 > 0)
     eps = 1e-2
     fd = (head(f1 + eps * u, 0.5, 7)[0].double().sum() - head(f1 - eps * u, 0.5, 7)[0].double().sum()) / (2 * eps)

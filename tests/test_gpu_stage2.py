@@ -165,6 +165,47 @@ def test_stackgpt_golden(dev, dtype, tol, gtol):
             assert float(np.abs(lo[k].cpu().numpy() - ref_l).max()) < (2e-3 if dtype == torch.float32 else 6e-2) * float(np.abs(ref_l).max())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_dropout_backward_fused_into_layernorm_backward(dev, dtype, monkeypatch):
+    """with dropout on, the backward of the two per-block dropouts is written by the LayerNorm backward that produces their operand
+    (dvq_layernorm_bwd_res_drop): same seeds -> the same masks as the stand-alone dvq_dropout passes, so every parameter gradient equals
+    the unfused run's (up to the summation order of the atomically accumulated weight gradients)"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    # kernel level: second output == dvq_dropout of the first, bit for bit
+    rows, c = 333, 1024
+    x = torch.randn(rows, c, device=dev).to(dtype)
+    dy = torch.randn(rows, c, device=dev).to(dtype)
+    res = torch.randn(rows, c, device=dev).to(dtype)
+    gamma = torch.rand(c, device=dev) + 0.5
+    mr = torch.stack([x.float().mean(1), 1.0 / (x.float().var(1, unbiased=False) + 1e-5).sqrt()], 1).contiguous()
+    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    dx0 = K.layernorm_bwd(x, dy, mr, gamma, dg.clone(), db.clone(), res)
+    dx1, dxd = K.layernorm_bwd(x, dy, mr, gamma, dg.clone(), db.clone(), res, drop=(0.1, 987654321))
+    assert torch.equal(dx0, dx1) and torch.equal(dxd, K.dropout(dx1, 0.1, 987654321))
+    frac = float((dxd == 0).float().mean())
+    assert 0.08 < frac < 0.12, frac
+    # model level
+    grads = {}
+    with rt.compute_dtype_ctx(dtype):
+        for mode in ("1", "0"):
+            monkeypatch.setenv("DVQ_FUSE_DROP_BWD", mode)
+            torch.manual_seed(0)
+            rt._seed_counter[0] = 0
+            model = build_stackgpt(dev).train()
+            for m in model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.1
+            inp = {k: torch.from_numpy(v).to(dev) for k, v in stackgpt_inputs().items()}
+            out = model(**inp)
+            (1.0 * out["content_loss"] + 0.7 * out["position_loss"]).backward()
+            grads[mode] = ({n: p.grad.detach().clone() for n, p in model.named_parameters()}, float(out["content_loss"].detach()))
+    assert grads["1"][1] == grads["0"][1]
+    for n, ga in grads["1"][0].items():
+        gb = grads["0"][0][n]
+        assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm()) + 1e-9, n
+
+
 def dualformer_config():
     import os
     from conftest import REPO
@@ -411,6 +452,46 @@ def test_class_conditional_dualformer(dev):
             assert int(cc.max()) <= 513 and int(fc.max()) <= 513 and int(fp.max()) <= 65 and int(cp.max()) <= 17
             img = model.decode_to_img(cc, fc, cp, fp)
             assert bool(torch.isfinite(img).all())
+
+
+def test_sample_many_lanes_equal_sequential(dev):
+    """Dualformer.sample_many: five class-conditional batches (different labels, so different sequences) on two and three concurrent
+    lanes -- own stream, K/V caches, captured token-step graphs per lane -- draw, greedily, exactly the tokens of the sequential
+    sampler, batch by batch; multinomial draws stay inside the constraints"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    cfg = dualformer_config()
+    p = cfg["params"]
+    p["transformer_config"]["params"].update(vocab_size=524, coarse_position_size=28, fine_position_size=76, embd_pdrop=0.0,
+                                             resid_pdrop=0.0, attn_pdrop=0.0)
+    p["class_cond_stage_config"] = {"target": "modules.dynamic_modules.label_provider.ClassAwareSOSProvider", "params": dict(
+        n_classes=10, threshold_content=514, threshold_coarse_position=18, threshold_fine_position=66, coarse_seg_sos=0, fine_seg_sos=1)}
+    del p["uncond_stage_config"]
+    cfg["target"] = "models.stage2_dynamic.dqtransformer_class2_entropy.Dualformer"
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        torch.manual_seed(3)
+        model = instantiate_from_config(cfg).to(dev).eval()
+        with torch.no_grad():
+            for n_, p_ in model.transformer.named_parameters():
+                if n_.endswith("head.1.weight"):
+                    p_.mul_(6.0)                     # spread logits: greedy picks far from ties
+        labels = [torch.tensor(l, device=dev) for l in ([1, 4, 9], [0, 2, 3], [5, 5, 8], [7, 6, 1], [9, 0, 4])]
+        conds = [model.encode_to_c(l) for l in labels]
+        for fix in (True, False):
+            kw = dict(sample=False, top_k=20, top_k_pos=10, process=False, fix_fine_position=fix)
+            seq = [[t.cpu() for t in model.sample_from_scratch(*c, **kw)] for c in conds]
+            assert not all(torch.equal(a, b) for a, b in zip(seq[0], seq[1])), "the batches must differ for this test to mean anything"
+            for lanes in (2, 3):
+                got = model.sample_many(conds, n_streams=lanes, **kw)
+                for i, (a, b) in enumerate(zip(seq, got)):
+                    assert all(torch.equal(x_, y_.cpu()) for x_, y_ in zip(a, b)), (fix, lanes, i)
+                again = model.sample_many(conds, n_streams=lanes, **kw)        # all lanes warm: every batch runs concurrently
+                for i, (a, b) in enumerate(zip(seq, again)):
+                    assert all(torch.equal(x_, y_.cpu()) for x_, y_ in zip(a, b)), (fix, lanes, i, "second call")
+        outs = model.sample_many(conds, n_streams=2, sample=True, top_k=20, top_k_pos=10, process=False, fix_fine_position=False)
+        for cc, fc, cp, fp in outs:
+            assert int(cc.max()) <= 513 and int(fc.max()) <= 513 and int(fp.max()) <= 65 and int(cp.max()) <= 17
+        torch.cuda.synchronize()
 
 
 def test_sampling_script_end_to_end(dev, tmp_path):

@@ -31,6 +31,8 @@ rt.set_compute_dtype("bf16")
 torch.manual_seed(0)
 BS = 64
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+VQ_ONLY = len(sys.argv) > 2 and sys.argv[2] == "vq_only"
+WARMUP0 = os.environ.get("DVQ_PROBE_WARMUP0", "0") == "1"     # no LR warm-up (the round-4 bench configuration): the codebook moves at once
 REPO = bench.REPO
 out = {}
 
@@ -43,6 +45,8 @@ model = instantiate_from_config(bench.full_config("full", BS)).to(dev)
 from dynamicvectorquantization_amd.trainer import reference_learning_rate
 model.learning_rate = reference_learning_rate({"base_learning_rate": 4.5e-6}, 1, BS)
 model.training_steps, model.steps_per_epoch = 100000, 1000
+if WARMUP0:
+    model.warmup_epochs = 0
 model.train()
 tr = Trainer(model, max_steps=STEPS)
 batches = [{"image": torch.from_numpy(synth.half_flat_images(BS, 256, seed=1234 + 1000 * i)).to(dev)} for i in range(2)]
@@ -129,9 +133,11 @@ out["vq_in_training"] = vq
 say(json.dumps({"vq_in_training": vq}))
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
 sel = torch.randperm(n, device=dev)[:8192]
-np.savez_compressed(os.path.join(REPO, "gpurun_out", "r5_vq_operands.npz"), x=x[sel].float().cpu().numpy().astype(np.float32),
+np.savez_compressed(os.path.join(REPO, "gpurun_out", "r5_vq_operands_warmup0.npz" if WARMUP0 else "r5_vq_operands.npz"), x=x[sel].float().cpu().numpy().astype(np.float32),
                     x_is_bf16=np.array(x.dtype == torch.bfloat16), cb=cb.cpu().numpy(), usage=usage.cpu().numpy())
 del S, gap, g2, tau_pc, tau_cl, x64, cb64
+if VQ_ONLY:
+    sys.exit(0)
 
 # ------------------------------------------------------------------------------------------------------------------------------
 # (b) layer-by-layer bf16 vs fp32 (eval forward, trained weights)
@@ -218,6 +224,8 @@ def encoder_fwd_mixed(enc, x_img, grain, lvl_switch):
         t = mid.attn_1.fwd(t, None)
         t = mid.block_2.fwd(t, None)
         heads.append(norm_swish_conv(getattr(enc, f"norm_out_{name}"), getattr(enc, f"conv_out_{name}"), t, None, "n", "c"))
+    if any(h_.dtype == torch.float32 for h_ in heads):           # a switch below the fine tap leaves the fine head in bf16
+        heads = [h_ if h_.dtype == torch.float32 else K.cast(h_, torch.float32) for h_ in heads]
     merged, mask = K.dual_merge(heads[1], heads[0], grain)
     return merged, mask
 
