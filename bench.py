@@ -281,6 +281,12 @@ def parity_vs_reference(dev):
                  "qloss_rel_err": round(abs(float(qloss) - float(g[f"{variant}_qloss"])) / max(1e-12, abs(float(g[f"{variant}_qloss"]))), 6)}
             if variant == "refinit" and len(bad):
                 r["max_exact_top2_gap_of_mismatched"] = float(g[f"{variant}_gap"][bad].max())
+            # the decoder alone: the REFERENCE'S codes through this precision's codebook lookup + post_quant_conv + decoder (a flipped
+            # code replaces a whole latent cell, so recon_rel_err above jumps with every mismatch; this one has none by construction)
+            with torch.no_grad(), rt.compute_dtype_ctx(dt):
+                q = model.quantize.get_codebook_entry(torch.from_numpy(ref_codes.reshape(g[f"{variant}_codes"].shape).astype(np.int64)).to(dev))
+                rec2 = model.decode(q.permute(0, 3, 1, 2).contiguous().float()).float().cpu().numpy()
+            r["recon_rel_err_decoder_on_reference_codes"] = round(float(np.linalg.norm(rec2 - ref_rec) / np.linalg.norm(ref_rec)), 6)
             res[variant] = r
             del model
         out[tag] = res

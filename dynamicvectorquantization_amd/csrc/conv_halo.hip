@@ -1130,14 +1130,19 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
     p.gn_ss = gn_ss;
     static const int wdbg_env = dvq_probe_env("DVQ_WGRAD_DBG");     // 0 unless built with -DDVQ_PROBES
     p.dbg = wdbg_env;
-    const int64_t nblk = (int64_t)p.gi * p.gj * p.nsplit;
+    int64_t nblk = (int64_t)p.gi * p.gj * p.nsplit;
     int64_t ws_bytes = 0;
     char* wsp = (char*)dvq_workspace_stream(stream, &ws_bytes);
     const int64_t need = nblk * (9ll * 128 * 64 + 128) * 4;
-    const bool thin = Cout <= 32;
+    const bool det = dvq_deterministic() != 0;          // opt-in: partials + fold (fixed order) or one workgroup per tile, never atomics
+    const bool thin = Cout <= 32 && !det;               // (the thin variant flushes with atomics: deterministic runs take the 128-wide one)
     if (wsp != nullptr && ws_bytes >= need && p.nsplit > 1 && !thin) {
         p.ws = (float*)wsp;
         p.ws_bias = (float*)(wsp + nblk * 9ll * 128 * 64 * 4);
+    } else if (det && p.nsplit > 1) {                   // no scratch: unsplit
+        p.tiles_per_split = p.ntiles;
+        p.nsplit = 1;
+        nblk = (int64_t)p.gi * p.gj;
     }
     if (thin) {
         dvq_ensure_dynamic_lds((const void*)conv3x3_halo_wgrad_kernel<true>, 2 * WSTAGE);

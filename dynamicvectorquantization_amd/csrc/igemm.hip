@@ -2323,7 +2323,8 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
         int64_t splits = (p.thin ? 256 : 1024) / tiles;
         const int64_t max_splits = cdiv64(p.Mred, 4 * BK);
         if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
+        const bool det = dvq_deterministic() != 0;      // opt-in: no fp32 atomics from more than one workgroup per output element
+        if (splits < 1 || det) splits = 1;
         int64_t mps = cdiv64(cdiv64(p.Mred, splits), BK) * BK;
         splits = cdiv64(p.Mred, mps);
         p.m_per_split = (int)mps;
@@ -2349,7 +2350,11 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
             p.itiles = (int)cdiv64(p.I, 256);
             p.jtiles = (int)cdiv64(p.J, 256);
             const int64_t wtiles = (int64_t)p.itiles * p.jtiles * batch;
-            int64_t wsplits = wtiles >= 256 ? 1 : 256 / wtiles;
+            static const int wide_wgs = [] {        // workgroups a wide TN product aims at (A/B: fewer splits = less fold traffic)
+                const char* e = getenv("DVQ_TN_WIDE_WGS");
+                return e != nullptr && atoi(e) > 0 ? atoi(e) : 256;
+            }();
+            int64_t wsplits = wtiles >= wide_wgs ? 1 : wide_wgs / wtiles;
             // >= 16 stages per workgroup: prologue, partial-tile store and fold amortised (8 / 4 / 32 measured slower on the 1 x 1
             // weight gradients: 60 / 95 / 66 against 52 us at 65536 x 256 x 256)
             const int64_t wmax = cdiv64(p.Mred, 16 * BK);
@@ -2361,9 +2366,12 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
             int64_t ws_bytes = 0;
             char* wsp = (char*)dvq_workspace_stream(s, &ws_bytes);
             const int64_t need = (int64_t)p.nsplit * wtiles * 65536 * 4 + (int64_t)p.nsplit * p.itiles * 256 * 4;
-            if (wsp != nullptr && ws_bytes >= need && p.nsplit > 2 && batch == 1) {     // many splits per tile: partials + fold, no atomics
+            if (wsp != nullptr && ws_bytes >= need && (p.nsplit > 2 || (det && p.nsplit > 1)) && batch == 1) {     // many splits per tile: partials + fold, no atomics
                 p.ws = (float*)wsp;
                 p.ws_bias = (float*)(wsp + (int64_t)p.nsplit * wtiles * 65536 * 4);
+            } else if (det && p.nsplit > 1) {            // no scratch for the partials: one workgroup per tile walks the whole reduction
+                p.m_per_split = (int)(cdiv64(p.Mred, BK) * BK);
+                p.nsplit = 1;
             }
             dvq_ensure_dynamic_lds((const void*)gemm_tn_wide_pipe_kernel, 2 * WTSTG);
             gemm_tn_wide_pipe_kernel<<<dim3((unsigned)(p.itiles * p.jtiles * p.nsplit), 1, (unsigned)batch), dim3(512), 2 * WTSTG, s>>>(p);
@@ -2387,7 +2395,7 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
             const int64_t ptiles = (int64_t)p.itiles * p.jtiles * p.taps;
             int64_t psplits = pwgs_env / ptiles;
             if (psplits > npatch / 16) psplits = npatch / 16;       // >= 16 stages per workgroup: the 64-KiB atomic flush amortised
-            if (psplits < 1) psplits = 1;
+            if (psplits < 1 || det) psplits = 1;
             const int64_t pps = cdiv64(npatch, psplits);
             p.m_per_split = (int)pps;
             p.nsplit = (int)cdiv64(npatch, pps);

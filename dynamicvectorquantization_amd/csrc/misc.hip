@@ -686,7 +686,22 @@ void* dvq_workspace_stream(hipStream_t stream, int64_t* bytes) {
     return (char*)g_ws_ptr + (int64_t)slot * slot_bytes;
 }
 
+static int g_deterministic = -1;
+
 extern "C" {
+
+int dvq_deterministic(void) {
+    if (g_deterministic < 0) {
+        const char* e = getenv("DVQ_DETERMINISTIC");
+        g_deterministic = e != nullptr && atoi(e) != 0 ? 1 : 0;
+    }
+    return g_deterministic;
+}
+
+int dvq_set_deterministic(int on) {
+    g_deterministic = on != 0 ? 1 : 0;
+    return DVQ_OK;
+}
 
 const char* dvq_last_error(void) { return g_err; }
 int dvq_version(void) { return 107; }

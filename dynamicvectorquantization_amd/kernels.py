@@ -532,6 +532,15 @@ def conv2d_wgrad_oihw(d: ConvDesc, x, dy, cin_real, cout_real, grad_oihw, db=Non
                                     int(is_ohwi(grad_oihw)), _s()), "dvq_conv2d_wgrad_oihw"))
 
 
+def set_deterministic(on: bool):
+    """opt-in: weight-gradient split reductions run unsplit or through partials + a fold kernel (bit-reproducible gradients)"""
+    check(lib().dvq_set_deterministic(int(bool(on))), "dvq_set_deterministic")
+
+
+def deterministic() -> bool:
+    return bool(lib().dvq_deterministic())
+
+
 def pack_weights_multi(table_dev, n_entries, total_work):
     check(lib().dvq_pack_weights_multi(_p(table_dev), n_entries, total_work, _s()), "dvq_pack_weights_multi")
 

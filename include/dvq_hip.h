@@ -50,6 +50,13 @@ int dvq_version(void);     /* 107: round 5 (dvq_lpips_head_drop; probe modes com
                             * no vendor-library entry points; + dvq_decode_stack, dvq_gemm_tn_colsum) */
 /* 0 if the current HIP device is gfx950, DVQ_EARCH otherwise */
 int dvq_check_device(void);
+/* Deterministic summation (opt-in; default: environment DVQ_DETERMINISTIC=1, else off).  On: every split-reduction family of weight
+ * gradients -- the patch-stage and transpose-read convolution weight gradients, the plain TN products -- runs UNSPLIT or through
+ * workspace partials + a fold kernel, never through fp32 atomics from several workgroups: the gradients of a step are then
+ * bit-reproducible run to run (the halo weight gradient, the GroupNorm / LayerNorm backward reductions already fold partials in a
+ * fixed order).  Costs occupancy on the small-map shapes.  Scalar loss sums and the VQ-EMA statistics still use atomics. */
+int dvq_set_deterministic(int on);
+int dvq_deterministic(void);
 /* Diagnostics for the benchmark's roofline context (allocates, synchronises the stream; NOT for the hot path): TFLOP/s and shader
  * clock (MHz) that a register-only bf16 MFMA loop sustains on every CU for ~3 ms, with all-zero (random_operands = 0) or random
  * bf16 operands -- the power-limited ceiling of the matrix pipes, which depends on the operand bit patterns. */

@@ -571,6 +571,79 @@ def test_conv_weight_gradient_patch_kernel(dev, case):
         assert err < 1e-2, f"{name}: rel-to-max error {err}"
 
 
+DET_CASES = [(256, 256, 3, "down", 32, 32, 4), (256, 512, 4, "same", 16, 16, 4), (256, 256, 1, "same", 32, 32, 8), (128, 128, 3, "s1p1", 64, 64, 4),
+             (128, 8, 3, "s1p1", 64, 64, 4), (8, 64, 3, "s1p1", 64, 64, 4), (512, 512, 3, "s1p1", 16, 16, 8)]
+
+
+@pytest.mark.parametrize("case", DET_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_deterministic_weight_gradients(dev, case):
+    """dvq_set_deterministic(1): the split-reduction weight-gradient families (patch-stage / transpose-read / halo incl. its thin variant /
+    plain TN) give BIT-identical gradients launch after launch -- and the same values as the default (atomic) path up to summation order"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd.layers import Conv2d
+    cin, cout, k, kind, h, w_, n = case
+    rs = np.random.RandomState(3 * cin + cout + k)
+    kw = dict(same=dict(stride=1, padding=(k - 1) // 2), down=dict(stride=2, padding=0, asym_pad=True), s1p1=dict(stride=1, padding=1))[kind]
+    mod = Conv2d(cin, cout, k, **kw).to(dev)
+    x = T(bf16_round(rs.standard_normal((n, cin, h, w_)).astype(np.float32)), dev)
+    grads = {}
+    try:
+        with rt.compute_dtype_ctx(torch.bfloat16):
+            for det, reps in ((True, 4), (False, 1)):
+                K.set_deterministic(det)
+                assert K.deterministic() == det
+                out = []
+                for _ in range(reps):
+                    mod.weight.grad = mod.bias.grad = None
+                    xt = x.clone().requires_grad_(True)
+                    y = mod(xt)
+                    go = T(bf16_round(np.random.RandomState(5).standard_normal(tuple(y.shape)).astype(np.float32)), dev)
+                    (y.float() * go).sum().backward()
+                    out.append((mod.weight.grad.clone(), mod.bias.grad.clone()))
+                grads[det] = out
+    finally:
+        K.set_deterministic(False)
+    w0, b0 = grads[True][0]
+    for w_i, b_i in grads[True][1:]:
+        assert torch.equal(w_i, w0) and torch.equal(b_i, b0), "deterministic mode: gradients differ between identical launches"
+    wa, ba = grads[False][0]
+    assert float((wa - w0).norm()) <= 1e-5 * float(w0.norm()) and float((ba - b0).norm()) <= 1e-5 * float(b0.norm())
+
+
+def test_deterministic_linear_weight_gradient(dev):
+    """the plain TN family (Linear weight gradients on gemm_tn_wide_pipe): partials + fold for every split count in deterministic mode"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd.layers import Linear, Tape
+    torch.manual_seed(2)
+    try:
+        with rt.compute_dtype_ctx(torch.bfloat16):
+            for m, n_in, n_out in ((2048, 1024, 1024), (20736, 1024, 4096), (4096, 512, 264)):
+                lin = Linear(n_in, n_out).to(dev)
+                x = torch.randn(m, n_in, device=dev).to(torch.bfloat16)
+                dy = torch.zeros(m, lin.out_p, device=dev, dtype=torch.bfloat16)
+                dy[:, :n_out] = torch.randn(m, n_out, device=dev).to(torch.bfloat16)
+                res = {}
+                for det, reps in ((True, 3), (False, 1)):
+                    K.set_deterministic(det)
+                    out = []
+                    for _ in range(reps):
+                        lin.weight.grad = lin.bias.grad = None
+                        tape = Tape()
+                        lin.fwd(x, tape)
+                        lin.bwd(dy, tape)
+                        rt.join_side()
+                        out.append((lin.weight.grad.clone(), lin.bias.grad.clone()))
+                    res[det] = out
+                w0, b0 = res[True][0]
+                for w_i, b_i in res[True][1:]:
+                    assert torch.equal(w_i, w0) and torch.equal(b_i, b0), (m, n_in, n_out)
+                assert float((res[False][0][0] - w0).norm()) <= 1e-5 * float(w0.norm())
+    finally:
+        K.set_deterministic(False)
+
+
 HALO_CASES = [(64, 64, 8, 32, 2), (128, 128, 16, 32, 2), (64, 192, 8, 64, 1), (256, 128, 24, 32, 1), (128, 64, 8, 32, 1),
               (128, 8, 16, 32, 1), (64, 24, 8, 32, 2), (64, 40, 8, 64, 1)]      # thin outputs: 32- / 64-wide channel tiles
 

@@ -101,11 +101,12 @@ def test_lpips_lin_dropout_kernel(dev):
 
     v0, d0 = head(f1, 0.0, 0, True)
     vp, dp = head(f1, 0.0, 123, True)
-    assert torch.equal(v0, vp) and torch.equal(d0, dp)
+    close = lambda a, b: float(((a - b).abs() / b.abs()).max()) < 1e-5       # (val is folded with atomics: equal up to summation order)
+    assert close(v0, vp) and torch.equal(d0, dp)
     va, da = head(f1, 0.5, 7, True)
     vb, _ = head(f1, 0.5, 7)
     vc, _ = head(f1, 0.5, 8)
-    assert torch.equal(va, vb) and not torch.equal(va, vc)
+    assert close(va, vb) and not close(va, vc)
     mean = torch.stack([head(f1, 0.5, 1000 + s)[0] for s in range(64)]).mean(0)
     assert float(((mean - v0).abs() / v0).max()) < 0.01, (mean, v0)
     # (a dropped element still receives gradient through the channel normalisation of its pixel: no zero pattern to look for --
@@ -134,7 +135,8 @@ def test_lpips_module_lin_dropout_switch(dev):
         assert _rel(v_eval.cpu().numpy(), g["lpips_val"].reshape(-1)) < 2e-3
         lp.train()
         v_a, v_b = lp.fwd(x_p, r_p)[0].clone(), lp.fwd(x_p, r_p)[0].clone()
-        assert not torch.equal(v_a, v_b) and not torch.equal(v_a, v_eval)            # a fresh mask per call
+        far = lambda a, b: float(((a - b).abs() / b.abs()).max()) > 1e-4
+        assert far(v_a, v_b) and far(v_a, v_eval)                                     # a fresh mask per call
         assert float(((v_a - v_eval).abs() / v_eval).max()) < 0.25
 
 

@@ -200,7 +200,7 @@ def test_dropout_backward_fused_into_layernorm_backward(dev, dtype, monkeypatch)
             out = model(**inp)
             (1.0 * out["content_loss"] + 0.7 * out["position_loss"]).backward()
             grads[mode] = ({n: p.grad.detach().clone() for n, p in model.named_parameters()}, float(out["content_loss"].detach()))
-    assert grads["1"][1] == grads["0"][1]
+    assert abs(grads["1"][1] - grads["0"][1]) <= 1e-6 * abs(grads["0"][1])      # (the loss sums are folded with atomics)
     for n, ga in grads["1"][0].items():
         gb = grads["0"][0][n]
         assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm()) + 1e-9, n
