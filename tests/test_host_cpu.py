@@ -26,7 +26,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, n), f"{n} declared in include/dvq_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert lib.dvq_version() >= 100
-    assert lib.dvq_vq_prep_bytes(1024, 256) == 256 + 4096 + 2 * 1024 * 256 * 2
+    assert lib.dvq_vq_prep_bytes(1024, 256) == 256 + 4096 + 2 * 1024 * 256 * 2 + 4096        # header, |e|^2, two bf16 planes, |e| (round 5)
     assert lib.dvq_vq_argmin_workspace_bytes(65536) >= 4 * 65536
 
 
