@@ -2350,9 +2350,13 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
             p.itiles = (int)cdiv64(p.I, 256);
             p.jtiles = (int)cdiv64(p.J, 256);
             const int64_t wtiles = (int64_t)p.itiles * p.jtiles * batch;
-            static const int wide_wgs = [] {        // workgroups a wide TN product aims at (A/B: fewer splits = less fold traffic)
+            // workgroups a wide TN product aims at.  Round 5: 128, not one per CU -- these weight gradients run on the side stream beside
+            // the input-gradient GEMMs (layers.Linear.bwd), so half a chip's worth of workgroups is what they get anyway, and half the
+            // splits mean half the partials to write and fold: StackGPT p6c18 step 79.9 -> 77.9 ms (64: 81.3 ms; same-box A/B,
+            // profiles/r05_stage2_ab.txt).  DVQ_TN_WIDE_WGS overrides.
+            static const int wide_wgs = [] {
                 const char* e = getenv("DVQ_TN_WIDE_WGS");
-                return e != nullptr && atoi(e) > 0 ? atoi(e) : 256;
+                return e != nullptr && atoi(e) > 0 ? atoi(e) : 128;
             }();
             int64_t wsplits = wtiles >= wide_wgs ? 1 : wide_wgs / wtiles;
             // >= 16 stages per workgroup: prologue, partial-tile store and fold amortised (8 / 4 / 32 measured slower on the 1 x 1

@@ -8,6 +8,10 @@ else
     tail -25 /tmp/dvq_build.log
     exit 1
 fi
+if [ "${DVQ_BUILD_PROBES:-0}" = "1" ]; then
+    # the -DDVQ_PROBES twin (timing experiments with wrong results, persistent conv_halo2): tools/debug/ only, DVQ_USE_PROBES_LIB=1
+    python -m dynamicvectorquantization_amd.build --probes > /tmp/dvq_build_probes.log 2>&1 && echo "probe library built" || { tail -20 /tmp/dvq_build_probes.log; exit 1; }
+fi
 if [ "${DVQ_BUILD_LINT:-1}" != "0" ]; then
     if python tools/lint_dma_barriers.py > /tmp/dvq_lint.log 2>&1; then
         echo "dma-barrier lint ok ($(grep -c 'barriers,' /tmp/dvq_lint.log) kernels)"
