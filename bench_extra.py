@@ -126,6 +126,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             trainer.train_step(batches[i % len(batches)], warmup + i)
+        timed_steps.host_enqueue_s = time.perf_counter() - t0      # until the last step was handed over (no sync inside the loop)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
@@ -169,6 +170,7 @@ def main():
             out = {"workload": "stage2", "metric": "images/sec DQ-Transformer (StackGPT p6c18) train step over frozen DQ-VAE codes",
                    "value": round(bs * args.steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / args.steps * 1e3, 2),
                    "tokens_per_sec": round(bs * t_len * args.steps / dt, 1),
+                   "host_enqueue_ms_per_step": round(getattr(timed_steps, "host_enqueue_s", 0.0) / args.steps * 1e3, 2),
                    "config": {"yaml": "configs/stage2/uncond_imagenet_p6c18.yml", "bs": bs, "seq_len": int(t_len),
                               "transformer_params": n_par, "dropout": 0.1},
                    "mfma_frac_est": round(flops * args.steps / dt / 2.5e15, 4), "roofline": roof, "kernel_families": fam,
