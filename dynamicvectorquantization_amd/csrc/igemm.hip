@@ -1183,6 +1183,9 @@ struct TnParams {
     float* ws_bias;  //   registered workspace, folded by gemm_tn_wide_reduce_kernel; null -> fp32 atomics straight into C
     int thin;        // conv, J == 8 (image-channel inputs): the B tile's 16 chunks are the TAPS (column = tap * 8 + channel), one
                      //   workgroup accumulates every tap instead of a 1/16-full tile per tap
+    float* dws;      // deterministic mode (dvq_set_deterministic): split s STORES its partial of C at dws + s * dws_stride (same element
+    int64_t dws_stride;   //   offsets as C, which must be one contiguous span) and its bias partial at dws_bias + s * I; tn_det_fold_kernel
+    float* dws_bias;      //   adds the slices to C / colsumA in split order.  null: fp32 atomics straight into C (default)
 };
 
 __device__ __forceinline__ int64_t tn_c_offset(const TnParams& p, int row, int tap, int col) {
@@ -1562,7 +1565,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_tr_kernel(TnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < p.I) atomicAdd(Cg + tn_c_offset(p, row, ctap, col), acc[mt][nt][r]);
+                if (row < p.I) {
+                    if (p.dws != nullptr) p.dws[(int64_t)split * p.dws_stride + tn_c_offset(p, row, ctap, col)] = acc[mt][nt][r];
+                    else atomicAdd(Cg + tn_c_offset(p, row, ctap, col), acc[mt][nt][r]);
+                }
             }
     }
     if (do_bias) {
@@ -1570,7 +1576,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_tr_kernel(TnParams p) {
         for (int t = 0; t < 2; ++t) {
             const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);    // the two lane halves hold different m
             const int col = i0 + wm * 64 + t * 32 + l31;
-            if (half == 0 && col < p.I) atomicAdd(p.colsumA + col, v);
+            if (half == 0 && col < p.I) {
+                if (p.dws_bias != nullptr) p.dws_bias[(int64_t)split * p.I + col] = v;
+                else atomicAdd(p.colsumA + col, v);
+            }
         }
     }
 }
@@ -1760,7 +1769,10 @@ __global__ __launch_bounds__(256, 2) void conv_tn_patch_kernel(TnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < p.I) atomicAdd(Cg + tn_c_offset(p, row, tap, col), acc[mt][nt][r]);
+                if (row < p.I) {
+                    if (p.dws != nullptr) p.dws[(int64_t)split * p.dws_stride + tn_c_offset(p, row, tap, col)] = acc[mt][nt][r];
+                    else atomicAdd(Cg + tn_c_offset(p, row, tap, col), acc[mt][nt][r]);
+                }
             }
     }
     if (do_bias) {
@@ -1768,7 +1780,10 @@ __global__ __launch_bounds__(256, 2) void conv_tn_patch_kernel(TnParams p) {
         for (int t = 0; t < 2; ++t) {
             const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);
             const int col = i0 + wm * 64 + t * 32 + l31;
-            if (half == 0 && col < p.I) atomicAdd(p.colsumA + col, v);
+            if (half == 0 && col < p.I) {
+                if (p.dws_bias != nullptr) p.dws_bias[(int64_t)split * p.I + col] = v;
+                else atomicAdd(p.colsumA + col, v);
+            }
         }
     }
 #endif
@@ -2305,6 +2320,43 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
     return DVQ_OK;
 }
 
+// deterministic mode: C[e] += sum over the splits' partial slices, in split order (one thread per element: a fixed summation order)
+__global__ __launch_bounds__(256) void tn_det_fold_kernel(float* __restrict__ C, const float* __restrict__ ws, int nsplit, int64_t stride,
+                                                          int64_t n, float* __restrict__ colsum, const float* __restrict__ ws_bias, int I) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) {
+        float acc = 0.f;
+        for (int sidx = 0; sidx < nsplit; ++sidx) acc += ws[(int64_t)sidx * stride + e];
+        C[e] += acc;
+    }
+    if (colsum != nullptr && e < I) {
+        float acc = 0.f;
+        for (int sidx = 0; sidx < nsplit; ++sidx) acc += ws_bias[(int64_t)sidx * I + e];
+        colsum[e] += acc;
+    }
+}
+
+// deterministic partials for the split TN kernels: C must be ONE contiguous span of `span` floats (a parameter's gradient is)
+static bool tn_det_setup(TnParams& p, int64_t batch, hipStream_t s, int64_t* span_out) {
+    const int64_t row_w = (int64_t)p.taps * p.Jc;
+    if (batch != 1 || p.nsplit <= 1 || (!p.c_oihw && p.ldc != row_w)) return false;
+    const int64_t span = (int64_t)p.I * row_w;
+    int64_t ws_bytes = 0;
+    char* wsp = (char*)dvq_workspace_stream(s, &ws_bytes);
+    const int64_t need = ((int64_t)p.nsplit * span + (int64_t)p.nsplit * p.I) * 4;
+    if (wsp == nullptr || ws_bytes < need) return false;
+    p.dws = (float*)wsp;
+    p.dws_stride = span;
+    p.dws_bias = p.colsumA != nullptr ? (float*)wsp + (int64_t)p.nsplit * span : nullptr;
+    *span_out = span;
+    return true;
+}
+static void tn_det_fold(const TnParams& p, int64_t span, hipStream_t s) {
+    const int64_t n = span > p.I ? span : p.I;
+    tn_det_fold_kernel<<<dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s>>>(p.C, p.dws, p.nsplit, p.dws_stride, span, p.dws_bias ? p.colsumA : nullptr,
+                                                                           p.dws_bias, p.I);
+}
+
 template <typename T>
 int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
     constexpr int VN = Vec<T>::N;
@@ -2323,8 +2375,10 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
         int64_t splits = (p.thin ? 256 : 1024) / tiles;
         const int64_t max_splits = cdiv64(p.Mred, 4 * BK);
         if (splits > max_splits) splits = max_splits;
-        const bool det = dvq_deterministic() != 0;      // opt-in: no fp32 atomics from more than one workgroup per output element
-        if (splits < 1 || det) splits = 1;
+        // opt-in: no fp32 atomics from more than one workgroup per output element.  bf16 operands only (the training path): the fp32
+        // parity-mode kernel keeps its splits and atomics (unsplit it would put 9 workgroups on a 4-M-row reduction)
+        const bool det = dvq_deterministic() != 0 && sizeof(T) == 2;
+        if (splits < 1) splits = 1;
         int64_t mps = cdiv64(cdiv64(p.Mred, splits), BK) * BK;
         splits = cdiv64(p.Mred, mps);
         p.m_per_split = (int)mps;
@@ -2399,14 +2453,34 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
             const int64_t ptiles = (int64_t)p.itiles * p.jtiles * p.taps;
             int64_t psplits = pwgs_env / ptiles;
             if (psplits > npatch / 16) psplits = npatch / 16;       // >= 16 stages per workgroup: the 64-KiB atomic flush amortised
-            if (psplits < 1 || det) psplits = 1;
-            const int64_t pps = cdiv64(npatch, psplits);
+            if (psplits < 1) psplits = 1;
+            int64_t pps = cdiv64(npatch, psplits);
             p.m_per_split = (int)pps;
             p.nsplit = (int)cdiv64(npatch, pps);
+            int64_t dspan = 0;
+            const bool dfold = det && p.nsplit > 1 && tn_det_setup(p, batch, s, &dspan);      // partials + fold in split order
+            if (det && p.nsplit > 1 && !dfold) {                                             // no scratch / strided C: unsplit
+                p.m_per_split = (int)npatch;
+                p.nsplit = 1;
+            }
             dvq_ensure_dynamic_lds((const void*)conv_tn_patch_kernel, 2 * TSTAGEB);
             conv_tn_patch_kernel<<<dim3((unsigned)(ptiles * p.nsplit)), dim3(256), 2 * TSTAGEB, s>>>(p);
             DVQ_CHECK_LAUNCH("conv_tn_patch");
+            if (dfold) {
+                tn_det_fold(p, dspan, s);
+                DVQ_CHECK_LAUNCH("tn_det_fold");
+            }
             return DVQ_OK;
+        }
+        int64_t gspan = 0;
+        bool gfold = false;
+        if (det && p.nsplit > 1) {
+            gfold = sizeof(T) == 2 && impl != 3 && tn_det_setup(p, batch, s, &gspan);          // (the transpose-read kernel stores partials)
+            if (!gfold) {                                                                    // other kernels / no scratch: unsplit
+                p.m_per_split = (int)(cdiv64(p.Mred, BK) * BK);
+                p.nsplit = 1;
+                grid = dim3((unsigned)(p.itiles * p.jtiles * tapblk), 1, (unsigned)batch);
+            }
         }
         if (sizeof(T) == 2 && impl != 3) {      // LDS-DMA + transpose-read kernel
             if (p.conv) {
@@ -2424,6 +2498,10 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
             igemm_tn_kernel<T, false><<<grid, dim3(256), 2 * GSTAGEB, s>>>(p);
         }
         DVQ_CHECK_LAUNCH("igemm_tn");
+        if (gfold) {
+            tn_det_fold(p, gspan, s);
+            DVQ_CHECK_LAUNCH("tn_det_fold");
+        }
     } else {
         int64_t nout = (int64_t)p.I * p.taps * p.J + (p.colsumA ? p.I : 0);
         unsigned blocks = (unsigned)(cdiv64(nout, 4) < 8192 ? cdiv64(nout, 4) : 8192);
