@@ -16,6 +16,7 @@ Weak scaling: bs/GPU is fixed, value = global images / max-over-ranks time.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -616,6 +617,7 @@ def main():
     if args.objective == "full" and not args.no_ae_only:
         # SURVEY 8d asks for both accountings: the autoencoder-only step (L1 + codebook) beside the complete objective
         del model
+        gc.collect()              # (model <-> tape closures are reference cycles: free the first model's saved activations now)
         torch.cuda.empty_cache()
         k2 = max(2, min(4, args.steps))
         dt2, _, _, m2 = run("ae", k2, 2, False)
@@ -623,6 +625,7 @@ def main():
         ae_only = {"value": round(ips2, 2), "unit": "images/sec", "steps": k2, "warmup": 2, "ms_per_step": round(dt2 / k2 * 1e3, 3),
                    "objective": OBJECTIVES["ae"], "step_mfma_frac": round(ips2 / world * STEP_FLOP_PER_IMG["ae"] / PEAK_BF16, 4)}
         del m2
+        gc.collect()
     fp32_mode = None
     if args.objective == "full" and args.dtype == "bf16" and world == 1 and not args.no_fp32_mode:
         # the precision that meets north_star's tolerance (index-exact, 1e-3) -- the SAME workload with the kernels'
@@ -630,6 +633,7 @@ def main():
         # against the fp32 matrix peak.  3 timed eager steps (a step takes ~1 s: host launch work is irrelevant, nothing is recorded)
         try:
             model = None
+            gc.collect()
             torch.cuda.empty_cache()
             rt.set_compute_dtype("fp32")
             k3 = 3
@@ -652,10 +656,12 @@ def main():
                          "note": "the complete two-optimizer step of the same workload in parity mode: every kernel instantiated for fp32 "
                                  "operands (this is the mode the reference goldens are met in at 1e-3 / index-exact: parity_vs_reference.fp32)"}
             del m3
+            gc.collect()
         except Exception as e:          # evidence block: never costs the headline line
             fp32_mode = {"failed": f"{type(e).__name__}: {str(e)[:200]}"}
         finally:
             rt.set_compute_dtype(args.dtype)
+            gc.collect()
             torch.cuda.empty_cache()
     if rank == 0:
         ips = world * args.bs * args.steps / dt_

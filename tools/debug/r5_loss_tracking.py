@@ -7,6 +7,7 @@ magnitude -- so the measure is the LOSS curves, not bit patterns.)
 
     python tools/debug/r5_loss_tracking.py [steps]   ->  gpurun_out/r5_loss_tracking.json
 """
+import gc
 import json
 import os
 import sys
@@ -50,6 +51,7 @@ def run(tag, dtype, warmup, perturb=0.0, steps=STEPS):
     print(f"{tag}: {steps} steps in {time.time() - t0:.1f} s; last losses {rows[-1]}", flush=True)
     fin = {n: p.detach().float().clone() for n, p in model.named_parameters() if p.requires_grad and not n.startswith("loss.perceptual")}
     del tr, model
+    gc.collect()                 # (the model <-> tape closures form reference cycles: without this the next run starts with the last tape resident)
     torch.cuda.empty_cache()
     return rows, fin
 
@@ -66,18 +68,26 @@ def compare(a, b):
 
 
 res = {"steps": STEPS, "bs": BS, "objective": "complete two-optimizer step, shipped YAML"}
-# A: no LR warm-up (every Adam step moves every weight by ~lr): bf16 vs fp32, and -- the control -- fp32 vs fp32 with the input images
-#    moved by 1e-6 x N(0,1) (far below one 8-bit grey level): how far do two CORRECT runs drift apart?
-a_bf16, a_fp32, a_ctrl = run("A bf16", "bf16", False), run("A fp32", "fp32", False), run("A fp32 (images + 1e-6 noise)", "fp32", False, 1e-6)
-res["no_warmup"] = {"losses_bf16": a_bf16[0], "losses_fp32": a_fp32[0], "losses_fp32_control": a_ctrl[0],
-                    "bf16_vs_fp32": compare(a_bf16, a_fp32), "fp32_control_vs_fp32": compare(a_ctrl, a_fp32)}
-del a_bf16, a_fp32, a_ctrl
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
+OUT = os.path.join(bench.REPO, "gpurun_out", "r5_loss_tracking_B.json" if ONLY == "B" else "r5_loss_tracking.json")
+if ONLY != "B":
+    # A: no LR warm-up (every Adam step moves every weight by ~lr): bf16 vs fp32, and -- the control -- fp32 vs fp32 with the input images
+    #    moved by 1e-6 x N(0,1) (far below one 8-bit grey level): how far do two CORRECT runs drift apart?
+    a_bf16, a_fp32, a_ctrl = run("A bf16", "bf16", False), run("A fp32", "fp32", False), run("A fp32 (images + 1e-6 noise)", "fp32", False, 1e-6)
+    res["no_warmup"] = {"losses_bf16": a_bf16[0], "losses_fp32": a_fp32[0], "losses_fp32_control": a_ctrl[0],
+                        "bf16_vs_fp32": compare(a_bf16, a_fp32), "fp32_control_vs_fp32": compare(a_ctrl, a_fp32)}
+    del a_bf16, a_fp32, a_ctrl
+    os.makedirs(os.path.join(bench.REPO, "gpurun_out"), exist_ok=True)
+    json.dump(res, open(os.path.join(bench.REPO, "gpurun_out", "r5_loss_tracking.json"), "w"), indent=1)
+    for kk, v in res["no_warmup"].items():
+        if isinstance(v, dict):
+            print("no_warmup", kk, {x: v[x] for x in v if x != "rel_diff_per_step"}, flush=True)
 # B: the YAML's own warm-up (lr ramps from ~0): the trajectories stay together and the difference is the forward / backward precision
 b_bf16, b_fp32 = run("B bf16", "bf16", True, steps=8), run("B fp32", "fp32", True, steps=8)
 res["yaml_warmup"] = {"losses_bf16": b_bf16[0], "losses_fp32": b_fp32[0], "bf16_vs_fp32": compare(b_bf16, b_fp32)}
 os.makedirs(os.path.join(bench.REPO, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(bench.REPO, "gpurun_out", "r5_loss_tracking.json"), "w"), indent=1)
+json.dump(res, open(OUT, "w"), indent=1)
 for k in ("no_warmup", "yaml_warmup"):
-    for kk, v in res[k].items():
+    for kk, v in res.get(k, {}).items():
         if isinstance(v, dict):
             print(k, kk, {x: v[x] for x in v if x != "rel_diff_per_step"})
