@@ -614,14 +614,72 @@ class Trainer:
         torch.save(self.state_dict(), tmp)
         os.replace(tmp, path)
 
-    def fit(self, batch_fn, ckpt_path=None, save_every=0, is_rank0=True):
-        """`ckpt_path` + `save_every` (steps): rank 0 rewrites last.ckpt periodically, so a preempted run resumes with `-r`"""
+    @torch.no_grad()
+    def validate(self, batches):
+        """Lightning's validation loop (train.py:233-262 runs it every `check_val_every_n_epoch`): eval mode, `validation_step` on every
+        batch, the logged scalars averaged over the batches -- and over the ranks under data parallelism (`sync_dist=True` of
+        dqvae_dual_entropy.py:185-201) -- train mode restored.  -> {name: float}"""
+        m = self.model
+        was_training = m.training
+        m.eval()
+        sums, n = {}, 0
+        try:
+            for i, b in enumerate(batches):
+                m._logged = {}
+                m.validation_step(b, i)
+                for k, v in m._logged.items():
+                    if torch.is_tensor(v) and v.numel() == 1 or isinstance(v, (int, float)):
+                        sums[k] = sums.get(k, 0.0) + (v.detach().double() if torch.is_tensor(v) else float(v))
+                n += 1
+        finally:
+            m.train(was_training)
+            m._logged = {}
+        if n == 0:
+            return {}
+        keys = sorted(sums)
+        dev = next(m.parameters()).device
+        vec = torch.stack([torch.as_tensor(sums[k], dtype=torch.float64, device=dev).reshape(()) for k in keys]) / n
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(vec)
+            vec /= dist.get_world_size()
+        return {k: float(x) for k, x in zip(keys, vec.cpu())}
+
+    def fit(self, batch_fn, ckpt_path=None, save_every=0, is_rank0=True, val_fn=None, val_every=0, save_top_k=0):
+        """`ckpt_path` + `save_every` (steps): rank 0 rewrites last.ckpt periodically, so a preempted run resumes with `-r`.
+        `val_fn()` -> iterable of validation batches, run every `val_every` steps and after the last one; with a `monitor` on the model
+        (the YAMLs say `monitor: val_rec_loss`) the `save_top_k` best checkpoints by that metric are kept next to last.ckpt as
+        `epoch=<e>-<monitor>=<value>.ckpt` -- pytorch_lightning.callbacks.ModelCheckpoint(monitor, save_top_k, save_last=True, mode="min")
+        of the reference's train.py:152-183"""
         self.model.train()
+        best = []                                     # (value, path), ascending
+        monitor = getattr(self.model, "monitor", None)
+
+        def run_validation(step):
+            metrics = self.validate(val_fn())
+            self.last_val_metrics = metrics
+            if is_rank0 and metrics:
+                print(f"validation @ step {step + 1}: " + " ".join(f"{k}={v:.5f}" for k, v in metrics.items()), flush=True)
+            if not (ckpt_path and is_rank0 and save_top_k and monitor and monitor in metrics):
+                return
+            val = metrics[monitor]
+            if len(best) < save_top_k or val < best[-1][0]:
+                epoch = step // max(1, int(getattr(self.model, "steps_per_epoch", 1) or 1))
+                path = os.path.join(os.path.dirname(os.path.abspath(ckpt_path)), f"epoch={epoch}-{monitor}={val:.4f}.ckpt")
+                self.save_checkpoint(path)
+                best.append((val, path))
+                best.sort(key=lambda t: t[0])
+                for _, old in best[save_top_k:]:
+                    if os.path.exists(old) and old != path:
+                        os.remove(old)
+                del best[save_top_k:]
+
         for step in range(int(self.model.global_step), self.max_steps):
             losses = self.train_step(batch_fn(step), step)
             if self.log_every and step % self.log_every == 0:
                 print(f"step {step}: " + " ".join(f"{float(l):.5f}" for l in losses), flush=True)
             if ckpt_path and save_every and is_rank0 and (step + 1) % save_every == 0 and step + 1 < self.max_steps:
                 self.save_checkpoint(ckpt_path)
+            if val_fn is not None and val_every and ((step + 1) % val_every == 0 or step + 1 == self.max_steps):
+                run_validation(step)
         if ckpt_path and is_rank0:
             self.save_checkpoint(ckpt_path)

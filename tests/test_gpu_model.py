@@ -170,6 +170,44 @@ def test_packed_weights_follow_the_optimizer(dev):
         assert checked >= 1
 
 
+def test_trainer_validation_loop_and_monitor_checkpoints(dev, tmp_path):
+    """Lightning's validation loop + ModelCheckpoint(monitor) of the reference's train.py:152-183 / dqvae_dual_entropy.py:185-201:
+    Trainer.validate runs validation_step in eval mode (no parameter, EMA-buffer or BatchNorm-statistic moves), averages the logged
+    scalars, restores train mode; fit() validates every `val_every` steps and keeps the `save_top_k` best checkpoints by `monitor`"""
+    import os
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.trainer import Trainer
+    with rt.compute_dtype_ctx(torch.bfloat16):
+        torch.manual_seed(0)
+        model, _ = build("small", dev, "spread", loss="full")
+        model.learning_rate, model.training_steps, model.steps_per_epoch = 1e-3, 100, 2
+        model.monitor = "val_rec_loss"
+        model.train()
+        tr = Trainer(model, max_steps=6, use_graph=False)
+        xs = [torch.from_numpy(synth.half_flat_images(2, 64, seed=40 + i)).to(dev) for i in range(4)]
+        vs = [{"image": torch.from_numpy(synth.half_flat_images(2, 64, seed=90 + i)).to(dev)} for i in range(3)]
+        tr.train_step({"image": xs[0]}, 0)
+        before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        m1 = tr.validate(vs)
+        assert model.training, "train mode must be restored"
+        after = model.state_dict()
+        assert all(torch.equal(before[k], after[k]) for k in before), "validation must not move any parameter or buffer"
+        for key in ("val_rec_loss", "val_aeloss", "val_total_loss", "val_quant_loss", "val_disc_loss", "val_fine_ratio"):
+            assert key in m1 and np.isfinite(m1[key]), (key, sorted(m1))
+        assert m1["val_d_weight"] == 0.0                         # reference: the adaptive weight's autograd.grad fails in eval -> 0
+        m2 = tr.validate(vs)
+        assert abs(m1["val_rec_loss"] - m2["val_rec_loss"]) <= 1e-5 * abs(m1["val_rec_loss"])          # eval forward: repeatable
+        assert abs(m1["val_rec_loss"] - tr.validate(vs[:1])["val_rec_loss"]) > 0                       # a mean over the batches given
+        ckpt = str(tmp_path / "checkpoints" / "last.ckpt")
+        tr.fit(lambda step: {"image": xs[step % 4]}, ckpt_path=ckpt, val_fn=lambda: iter(vs), val_every=2, save_top_k=2)
+        files = sorted(os.listdir(os.path.dirname(ckpt)))
+        assert "last.ckpt" in files
+        best = [f for f in files if f.startswith("epoch=") and "val_rec_loss=" in f]
+        assert 1 <= len(best) <= 2, files                        # three validations (steps 2, 4, 6), at most save_top_k kept
+        sd = torch.load(os.path.join(os.path.dirname(ckpt), best[0]), map_location="cpu", weights_only=False)
+        assert "state_dict" in sd and "optimizer_states" in sd and np.isfinite(tr.last_val_metrics["val_rec_loss"])
+
+
 def test_trainer_checkpoint_resume(dev):
     """Trainer.state_dict / load_state_dict (train.py -r): a fresh process state restored from the checkpoint continues the run --
     same parameters, Adam moments, LR-schedule position, step counter, VQ-EMA and BatchNorm buffers -> same next losses"""

@@ -34,7 +34,9 @@ def get_parser():
     p.add_argument("-l", "--logger", type=str, default="none")
     p.add_argument("-d", "--debug", action="store_true")
     p.add_argument("-p", "--project", type=str, default="dvq")
-    p.add_argument("--save_n", type=int, default=1)
+    p.add_argument("--save_n", type=int, default=3, help="save top-n checkpoints by the model's `monitor` (train.py:48 of the reference)")
+    p.add_argument("--check_val_every_n_epoch", type=int, default=1, help="validation pass every n epochs (0: never)")
+    p.add_argument("--val_batches", type=int, default=4, help="synthetic data: batches per validation pass")
     p.add_argument("--activate_ddp_share", action="store_true")
     p.add_argument("--gpus", type=str, default="1")
     p.add_argument("--max_epochs", type=int, default=1)
@@ -174,7 +176,29 @@ def run(rank, world, opt, unknown):
             print(f"resumed from {resume_ckpt} at global step {model.global_step}")
     # last.ckpt is rewritten (atomically, rank 0) every --save_every steps / once per epoch and at the end: a crashed or
     # preempted run continues with `-r <logdir>`
-    trainer.fit(batch_fn, ckpt_path=ckpt_path, save_every=opt.save_every or opt.steps_per_epoch, is_rank0=rank == 0)
+    # validation (Lightning's loop in the reference): the YAML's validation set with --real_data, else a fixed set of synthetic batches;
+    # the model's `monitor` (val_rec_loss in the shipped stage-1 YAMLs) picks the --save_n best checkpoints kept beside last.ckpt
+    val_fn = None
+    if opt.check_val_every_n_epoch > 0 and hasattr(model, "validation_step"):
+        if opt.real_data:
+            vloader = dm.val_dataloader()
+
+            def val_fn():
+                for b in vloader:
+                    yield {image_key: b["image"], **({"class_label": b["class_label"]} if "class_label" in b and n_classes is not None else {})}
+        else:
+            vpool = [torch.from_numpy(synth.half_flat_images(bs, size, seed=opt.seed + 7919 + 977 * rank + i)).to(dev)
+                     for i in range(max(1, opt.val_batches))]
+
+            def val_fn():
+                for i, im in enumerate(vpool):
+                    b = {image_key: im}
+                    if n_classes is not None:
+                        g = torch.Generator().manual_seed(opt.seed + 31 * i)
+                        b["class_label"] = torch.randint(0, n_classes, (bs,), generator=g).to(dev)
+                    yield b
+    trainer.fit(batch_fn, ckpt_path=ckpt_path, save_every=opt.save_every or opt.steps_per_epoch, is_rank0=rank == 0, val_fn=val_fn,
+                val_every=opt.check_val_every_n_epoch * opt.steps_per_epoch, save_top_k=opt.save_n)
     if rank == 0:
         print("saved", ckpt_path)
     if world > 1:
