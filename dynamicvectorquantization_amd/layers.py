@@ -188,7 +188,11 @@ class Linear(nn.Module):
             ent = getattr(self, "_lpack", None)
             if ent is None or ent["w"].device != self.weight.device:
                 ent = LINEAR_PACKS.register(self)
-            if ent["key"] != ep:
+            if ent["key"] is None:
+                # first use of this layer: pack it alone (a group launch here would re-pack every layer registered so far once per
+                # NEW layer -- the first forward of a 150-Linear model then did ~11 000 layer packs: 32 ms, profiles/r05_v1_stage2_*)
+                LINEAR_PACKS.pack_one(self)
+            elif ent["key"] != ep:
                 LINEAR_PACKS.repack(self.weight.device, getattr(self.weight, "_dvq_group", 0))
                 if ent["key"] != ep:
                     LINEAR_PACKS.pack_one(self)
