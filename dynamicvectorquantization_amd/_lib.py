@@ -43,6 +43,8 @@ SIGNATURES = {
     "dvq_check_device": (i32, []),
     "dvq_set_deterministic": (i32, [i32]),
     "dvq_deterministic": (i32, []),
+    "dvq_set_fp32_split": (i32, [i32]),
+    "dvq_fp32_split": (i32, []),
     "dvq_probe_mfma_rate": (i32, [i32, vp, vp, vp]),
     "dvq_vq_prep_bytes": (sz, [i64, i64]),
     "dvq_vq_prepare": (i32, [vp, i64, i64, vp, vp]),

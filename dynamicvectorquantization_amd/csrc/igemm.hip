@@ -49,6 +49,7 @@ struct NtParams {
     float mask_slope;
     int par;             // TCONV, stride 2: GEMM rows are grouped by output-pixel parity class (y & 1, x & 1); a tile then
     int par_tiles;       //   contracts only over the taps that reach its class (1/4 of a 4x4 kernel) -- M tiles per class
+    int split3;          // fp32 operands: 1 = two bf16 planes + three bf16 MFMA passes (dvq_set_fp32_split), 0 = v_mfma_f32_32x32x2_f32
 };
 
 // parity-class row order of the stride-2 input gradient: class-local index m -> (image, y, x) of class pc = 2 * (y & 1) + (x & 1)
@@ -78,9 +79,11 @@ struct Vec {
 // -------------------------------------------------------------------------------------------------
 // MFMA over one LDS stage: acc[mt][nt] += A(64 rows of this wave) x B(64 rows of this wave)^T
 // -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8_bf16(const f32x4& c0, const f32x4& c1, bf16x8& hi, bf16x8& lo);
+
 template <typename T>
 __device__ __forceinline__ void mma_stage(const char* sA, const char* sB, f32x16 (&acc)[2][2], int wm, int wn,
-                                          int lane) {
+                                          int lane, bool split3 = false) {
     const int l31 = lane & 31, half = lane >> 5;
     const char* pa = sA + (wm * 64 + l31) * ROWB + half * 16;
     const char* pb = sB + (wn * 64 + l31) * ROWB + half * 16;
@@ -98,6 +101,26 @@ __device__ __forceinline__ void mma_stage(const char* sA, const char* sB, f32x16
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    } else if (split3) {                     // fp32 operands as two bf16 planes, three MFMA passes (see split8_bf16)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                split8_bf16(*reinterpret_cast<const f32x4*>(pa + t * 32 * ROWB + (2 * u) * 32),
+                            *reinterpret_cast<const f32x4*>(pa + t * 32 * ROWB + (2 * u + 1) * 32), ah[t], al[t]);
+                split8_bf16(*reinterpret_cast<const f32x4*>(pb + t * 32 * ROWB + (2 * u) * 32),
+                            *reinterpret_cast<const f32x4*>(pb + t * 32 * ROWB + (2 * u + 1) * 32), bh[t], bl[t]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                }
         }
     } else {
 #pragma unroll
@@ -347,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(NtParams p) {
     for (int j = 0; j < nk; ++j) {
         const int buf = j & 1;
         if (j + 1 < nk) g_load(j + 1);
-        mma_stage<T>(smem + buf * STAGEB, smem + buf * STAGEB + OPB, acc, wm, wn, lane);
+        mma_stage<T>(smem + buf * STAGEB, smem + buf * STAGEB + OPB, acc, wm, wn, lane, p.split3 != 0);
         if (j + 1 < nk) s_store(buf ^ 1);
         __syncthreads();
     }
@@ -376,9 +399,32 @@ constexpr int GSTAGEB = 2 * GOPB;
 enum { SWZ_NT = 0, SWZ_TN = 1 };
 __device__ __forceinline__ int swz_tn(int r) { return ((r >> 3) & 3) | ((((r >> 1) ^ (r >> 5)) & 1) << 2); }
 
+// fp32 operands on the bf16 matrix pipe (dvq_set_fp32_split, round 5): x = hi + lo with hi = x rounded to bf16 and lo = x - hi (exact in
+// fp32, |lo| <= 2^-9 |x|) rounded to bf16; the product runs as lo.hi + hi.lo + hi.hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation --
+// the VQ search's scheme (section 4) -- ~2^-17 relative error per term (lo.lo dropped, lo rounded) instead of 2^-24, at 3/16 of the
+// fp32-MFMA issue time.  The lane's 8
+// k-values of a 16-k step are the two 4-float chunks it would feed to v_mfma_f32_32x32x2_f32 one by one: A and B use the same chunk
+// arithmetic, so element e of lane (row, half) is the same k on both sides -- any such pairing is a valid contraction order.
+__device__ __forceinline__ void split8_bf16(const f32x4& c0, const f32x4& c1, bf16x8& hi, bf16x8& lo) {
+    dvq_u32x4 h, l;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x4& c = q == 0 ? c0 : c1;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned ph = pack_bf16x2(c[2 * e], c[2 * e + 1]);                     // round to nearest even
+            h[2 * q + e] = ph;
+            const float r0 = c[2 * e] - __uint_as_float(ph << 16), r1 = c[2 * e + 1] - __uint_as_float(ph & 0xffff0000u);
+            l[2 * q + e] = pack_bf16x2(r0, r1);
+        }
+    }
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+
 template <typename T, int SWZ = SWZ_NT>
 __device__ __forceinline__ void mma_stage_swz(const char* sA, const char* sB, f32x16 (&acc)[2][2], int wm, int wn,
-                                              int lane) {
+                                              int lane, bool split3 = false) {
     const int l31 = lane & 31, half = lane >> 5;
     // rows are wm*64 + t*32 + l31: only bit 5 of the row depends on t
     int swz[2];
@@ -401,6 +447,27 @@ __device__ __forceinline__ void mma_stage_swz(const char* sA, const char* sB, f3
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    } else if (split3) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int o0 = ((4 * u + half) ^ swz[t]) << 4, o1 = ((4 * u + 2 + half) ^ swz[t]) << 4;
+                split8_bf16(*reinterpret_cast<const f32x4*>(pa + t * 32 * GROW + o0), *reinterpret_cast<const f32x4*>(pa + t * 32 * GROW + o1),
+                            ah[t], al[t]);
+                split8_bf16(*reinterpret_cast<const f32x4*>(pb + t * 32 * GROW + o0), *reinterpret_cast<const f32x4*>(pb + t * 32 * GROW + o1),
+                            bh[t], bl[t]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                }
         }
     } else {
 #pragma unroll
@@ -565,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
     for (int j = 0; j < nk; ++j) {
         const int buf = j & 1;
         if (j + 1 < nk) issue(j + 1, buf ^ 1);
-        mma_stage_swz<T>(smem + buf * GSTAGEB, smem + buf * GSTAGEB + GOPB, acc, wm, wn, lane);
+        mma_stage_swz<T>(smem + buf * GSTAGEB, smem + buf * GSTAGEB + GOPB, acc, wm, wn, lane, p.split3 != 0);
         dvq_dma_barrier();
     }
     if ((p.ldc % VN) == 0) {
@@ -1186,6 +1253,7 @@ struct TnParams {
     float* dws;      // deterministic mode (dvq_set_deterministic): split s STORES its partial of C at dws + s * dws_stride (same element
     int64_t dws_stride;   //   offsets as C, which must be one contiguous span) and its bias partial at dws_bias + s * I; tn_det_fold_kernel
     float* dws_bias;      //   adds the slices to C / colsumA in split order.  null: fp32 atomics straight into C (default)
+    int split3;           // fp32 operands: two bf16 planes + three bf16 MFMA passes (dvq_set_fp32_split)
 };
 
 __device__ __forceinline__ int64_t tn_c_offset(const TnParams& p, int row, int tap, int col) {
@@ -1351,7 +1419,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
         for (int j = 0; j < nk; ++j) {
             const int buf = j & 1;
             if (j + 1 < nk) g_load(mbeg + (j + 1) * BK);
-            mma_stage_swz<T, SWZ_TN>(smem + buf * GSTAGEB, smem + buf * GSTAGEB + GOPB, acc, wm, wn, lane);
+            mma_stage_swz<T, SWZ_TN>(smem + buf * GSTAGEB, smem + buf * GSTAGEB + GOPB, acc, wm, wn, lane, p.split3 != 0);
             if (j + 1 < nk) s_store(buf ^ 1);
             __syncthreads();
         }
@@ -2183,6 +2251,7 @@ __global__ void naive_tn_kernel(TnParams p) {
 template <typename T>
 int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
     constexpr int VN = Vec<T>::N;
+    p.split3 = sizeof(T) == 4 && dvq_fp32_split() != 0;
     p.gm = (int)cdiv64(p.M, TILE);
     p.gn = (int)cdiv64(p.Ncols, TILE);
     bool mfma_ok = p.Ktot % VN == 0 && p.ldb % VN == 0 && p.lda % VN == 0 && (p.stride == 1 || p.stride == 2);
@@ -2361,6 +2430,7 @@ template <typename T>
 int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
     constexpr int VN = Vec<T>::N;
     constexpr int BK = Vec<T>::BK;
+    p.split3 = sizeof(T) == 4 && dvq_fp32_split() != 0;
     bool mfma_ok = p.lda % VN == 0 && p.ldb % VN == 0 && p.sA % VN == 0 && p.sB % VN == 0;
     DVQ_REQUIRE(!(impl >= 2 && impl != 5 && impl != 6 && impl != 7 && impl != 8 && !mfma_ok), DVQ_ESHAPE, "igemm_tn: MFMA path needs lda, ldb multiples of %d", VN);
     const bool use_mfma = impl >= 2 || (impl == 0 && mfma_ok && (int64_t)p.Mred >= 256);

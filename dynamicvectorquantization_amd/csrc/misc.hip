@@ -687,6 +687,7 @@ void* dvq_workspace_stream(hipStream_t stream, int64_t* bytes) {
 }
 
 static int g_deterministic = -1;
+static int g_fp32_split = -1;
 
 extern "C" {
 
@@ -700,6 +701,19 @@ int dvq_deterministic(void) {
 
 int dvq_set_deterministic(int on) {
     g_deterministic = on != 0 ? 1 : 0;
+    return DVQ_OK;
+}
+
+int dvq_fp32_split(void) {
+    if (g_fp32_split < 0) {
+        const char* e = getenv("DVQ_FP32_SPLIT");
+        g_fp32_split = e != nullptr && atoi(e) != 0 ? 1 : 0;
+    }
+    return g_fp32_split;
+}
+
+int dvq_set_fp32_split(int on) {
+    g_fp32_split = on != 0 ? 1 : 0;
     return DVQ_OK;
 }
 

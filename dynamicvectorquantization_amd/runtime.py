@@ -19,23 +19,49 @@ def compute_dtype() -> torch.dtype:
     return _compute_dtype
 
 
+_fp32_split = None          # None: the library's default (environment DVQ_FP32_SPLIT); True / False: set explicitly
+
+
+def fp32_split() -> bool:
+    """fp32 compute with the matrix products on split-bf16 planes (three bf16 MFMA passes, ~2^-17 relative error per product): `fp32x3`"""
+    from . import _lib
+    return bool(_lib.load().dvq_fp32_split())
+
+
+def set_fp32_split(on):
+    global _fp32_split
+    from . import _lib
+    _fp32_split = None if on is None else bool(on)
+    if on is not None:
+        _lib.check(_lib.load().dvq_set_fp32_split(int(bool(on))), "dvq_set_fp32_split")
+
+
 def set_compute_dtype(dtype):
+    """torch.float32 / torch.bfloat16, or "bf16" | "fp32" (exact fp32 matrix instructions) | "fp32x3" (fp32 tensors, products as three
+    bf16 MFMA passes on split operands: the fast tolerance-meeting mode).  A torch dtype leaves the fp32 product mode as it is."""
     global _compute_dtype
     if isinstance(dtype, str):
-        dtype = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
-                 "bfloat16": torch.bfloat16}[dtype]
+        if dtype in ("fp32x3", "float32x3"):
+            set_fp32_split(True)
+            dtype = torch.float32
+        else:
+            if dtype in ("fp32", "float32") and _fp32_split:
+                set_fp32_split(False)
+            dtype = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}[dtype]
     assert dtype in (torch.float32, torch.bfloat16)
     _compute_dtype = dtype
 
 
 @contextlib.contextmanager
 def compute_dtype_ctx(dtype):
-    old = _compute_dtype
+    old, old_split = _compute_dtype, _fp32_split
     set_compute_dtype(dtype)
     try:
         yield
     finally:
         set_compute_dtype(old)
+        if _fp32_split != old_split:
+            set_fp32_split(bool(old_split) if old_split is not None else False)
 
 
 def weights_epoch() -> int:

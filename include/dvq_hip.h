@@ -57,6 +57,12 @@ int dvq_check_device(void);
  * fixed order).  Costs occupancy on the small-map shapes.  Scalar loss sums and the VQ-EMA statistics still use atomics. */
 int dvq_set_deterministic(int on);
 int dvq_deterministic(void);
+/* fp32 operands on the bf16 matrix pipe (opt-in; default: environment DVQ_FP32_SPLIT=1, else off): the fp32 instantiations of the
+ * convolution / GEMM kernels split every operand element into two bf16 planes (x = hi + lo) in registers and run hi.hi + hi.lo + lo.hi as
+ * three v_mfma_f32_32x32x16_bf16 passes with fp32 accumulation instead of v_mfma_f32_32x32x2_f32: ~2^-17 relative error per product
+ * (fp32: 2^-24) at 3/16 of the matrix-pipe time.  Activations, statistics, gradients and accumulators stay fp32 (`--dtype fp32x3`). */
+int dvq_set_fp32_split(int on);
+int dvq_fp32_split(void);
 /* Diagnostics for the benchmark's roofline context (allocates, synchronises the stream; NOT for the hot path): TFLOP/s and shader
  * clock (MHz) that a register-only bf16 MFMA loop sustains on every CU for ~3 ms, with all-zero (random_operands = 0) or random
  * bf16 operands -- the power-limited ceiling of the matrix pipes, which depends on the operand bit patterns. */

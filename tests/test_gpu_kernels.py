@@ -571,6 +571,64 @@ def test_conv_weight_gradient_patch_kernel(dev, case):
         assert err < 1e-2, f"{name}: rel-to-max error {err}"
 
 
+@pytest.mark.parametrize("case", [(128, 128, 3, "same", 32, 32, 2), (256, 256, 3, "down", 32, 32, 2), (64, 128, 4, "same", 31, 31, 2),
+                                  (256, 256, 1, "same", 16, 16, 4), (8, 64, 3, "same", 64, 64, 2), (128, 8, 3, "same", 64, 64, 2)],
+                         ids=lambda c: "-".join(map(str, c)))
+def test_fp32_split_bf16_products(dev, case):
+    """`fp32x3` (dvq_set_fp32_split): fp32 tensors, every matrix product as three bf16 MFMA passes on two-plane operands.  Forward,
+    input gradient, weight and bias gradient of a convolution against the exact-fp32 instantiation of the same kernels and against
+    float64: the split products must be ~2^-17-accurate (two orders of magnitude inside north_star's 1e-3), not bf16-accurate"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d
+    cin, cout, k, kind, h, w_, n = case
+    rs = np.random.RandomState(cin + 3 * cout + k)
+    kw = dict(same=dict(stride=1, padding=(k - 1) // 2), down=dict(stride=2, padding=0, asym_pad=True))[kind]
+    mod = Conv2d(cin, cout, k, **kw).to(dev)
+    x = T(rs.standard_normal((n, cin, h, w_)).astype(np.float32), dev)
+    res = {}
+    for mode in ("fp32", "fp32x3"):
+        with rt.compute_dtype_ctx(mode):
+            assert rt.fp32_split() == (mode == "fp32x3")
+            mod.weight.grad = mod.bias.grad = None
+            xt = x.clone().requires_grad_(True)
+            y = mod(xt)
+            go = T(np.random.RandomState(5).standard_normal(tuple(y.shape)).astype(np.float32), dev)
+            (y * go).sum().backward()
+            res[mode] = [t.detach().double().cpu() for t in (y, xt.grad, mod.weight.grad, mod.bias.grad)]
+    assert not rt.fp32_split()
+    # float64 reference on the CPU
+    xr = x.double().cpu().requires_grad_(True)
+    wr, br = mod.weight.detach().double().cpu().requires_grad_(True), mod.bias.detach().double().cpu().requires_grad_(True)
+    xin = torch.nn.functional.pad(xr, (0, 1, 0, 1)) if kind == "down" else xr
+    yr = F.conv2d(xin, wr, br, stride=kw["stride"], padding=0 if kind == "down" else kw["padding"])
+    (yr * go.double().cpu()).sum().backward()
+    ref = [yr.detach(), xr.grad, wr.grad, br.grad]
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    for name, a3, a1, r in zip(("y", "dx", "dw", "db"), res["fp32x3"], res["fp32"], ref):
+        e3, e1 = rel(a3, r), rel(a1, r)
+        assert e1 < 5e-6, (name, e1)
+        assert e3 < 3e-5, (name, e3)                      # bf16 products would sit at ~3e-3
+    assert rel(res["fp32x3"][0], res["fp32"][0]) > 0        # the split path really ran (it is not bit-identical to fp32 MFMA)
+
+
+def test_fp32_split_gemms(dev):
+    """plain NT / TN products (Linear layers, attention GEMMs) in fp32x3 against float64"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    torch.manual_seed(4)
+    m, n, k = 777, 264, 520
+    a, b = torch.randn(m, k, device=dev), torch.randn(n, k, device=dev)
+    ref = a.double() @ b.double().t()
+    c, d = torch.randn(m, 136, device=dev), torch.randn(m, 200, device=dev)
+    ref_tn = c.double().t() @ d.double()
+    for mode, tol in (("fp32", 3e-6), ("fp32x3", 3e-5)):
+        with rt.compute_dtype_ctx(mode):
+            got = K.gemm_nt(a, b, m, n, k, k, k, n).view(m, n).double()
+            got_tn = K.gemm_tn(c, d, m, 136, 200, 136, 200, 200).view(136, 200).double()
+        assert float((got - ref).norm() / ref.norm()) < tol, mode
+        assert float((got_tn - ref_tn).norm() / ref_tn.norm()) < tol, mode
+
+
 DET_CASES = [(256, 256, 3, "down", 32, 32, 4), (256, 512, 4, "same", 16, 16, 4), (256, 256, 1, "same", 32, 32, 8), (128, 128, 3, "s1p1", 64, 64, 4),
              (128, 8, 3, "s1p1", 64, 64, 4), (8, 64, 3, "s1p1", 64, 64, 4), (512, 512, 3, "s1p1", 16, 16, 8)]
 

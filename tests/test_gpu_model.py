@@ -120,6 +120,28 @@ def test_dqvae_forward_backward_golden(dev, tag, impl):
                 assert np.all(g[f"{variant}_gap"][bad] < 1e-6), g[f"{variant}_gap"][bad]
 
 
+def test_dqvae_forward_golden_fp32x3(dev):
+    """the reference goldens in `fp32x3` (fp32 tensors, matrix products as three bf16 MFMA passes on split operands): the fast mode that is
+    meant to meet north_star's tolerance -- grain map exact, code indices exact on the spread codebook, reconstruction within 1e-3"""
+    from dynamicvectorquantization_amd import runtime as rt
+    x = torch.from_numpy(synth.half_flat_images(2, 64, seed=4321)).to(dev)
+    for tag in ("small", "c1"):
+        with rt.compute_dtype_ctx("fp32x3"):
+            model, g = build(tag, dev, "spread")
+            model.eval()
+            with torch.no_grad():
+                rec, qloss, grain, gate, ent = model(x)
+            assert np.array_equal(grain.cpu().numpy().astype(np.int8), g["spread_grain"])
+            codes = model._last["codes"].cpu().numpy().astype(np.int32)
+            assert np.array_equal(codes.reshape(-1), g["spread_codes"].reshape(-1)), tag
+            np.testing.assert_allclose(rec.cpu().numpy(), g["spread_rec"], rtol=1e-3, atol=1e-3)
+            np.testing.assert_allclose(qloss.item(), g["spread_qloss"], rtol=1e-3)
+            err = float(np.linalg.norm(rec.cpu().numpy() - g["spread_rec"]) / np.linalg.norm(g["spread_rec"]))
+            _report("fp32x3_recon_rel_err", tag=tag, err=err)
+            assert err < 1e-3, (tag, err)
+    assert not rt.fp32_split()
+
+
 def test_train_step_bf16_smoke(dev):
     """two optimizer steps of the AE-only objective in bf16: finite loss that moves, EMA buffers updated"""
     from dynamicvectorquantization_amd import runtime as rt
