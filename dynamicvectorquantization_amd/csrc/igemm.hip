@@ -83,7 +83,7 @@ __device__ __forceinline__ void split8_bf16(const f32x4& c0, const f32x4& c1, bf
 
 template <typename T>
 __device__ __forceinline__ void mma_stage(const char* sA, const char* sB, f32x16 (&acc)[2][2], int wm, int wn,
-                                          int lane, bool split3 = false) {
+                                          int lane, bool split3 = false) {     // (runtime flag: the register-staged kernel is an A/B path only)
     const int l31 = lane & 31, half = lane >> 5;
     const char* pa = sA + (wm * 64 + l31) * ROWB + half * 16;
     const char* pb = sB + (wn * 64 + l31) * ROWB + half * 16;
@@ -422,9 +422,9 @@ __device__ __forceinline__ void split8_bf16(const f32x4& c0, const f32x4& c1, bf
     lo = __builtin_bit_cast(bf16x8, l);
 }
 
-template <typename T, int SWZ = SWZ_NT>
+template <typename T, int SWZ = SWZ_NT, bool S3 = false>
 __device__ __forceinline__ void mma_stage_swz(const char* sA, const char* sB, f32x16 (&acc)[2][2], int wm, int wn,
-                                              int lane, bool split3 = false) {
+                                              int lane) {
     const int l31 = lane & 31, half = lane >> 5;
     // rows are wm*64 + t*32 + l31: only bit 5 of the row depends on t
     int swz[2];
@@ -448,7 +448,7 @@ __device__ __forceinline__ void mma_stage_swz(const char* sA, const char* sB, f3
                 for (int nt = 0; nt < 2; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
         }
-    } else if (split3) {
+    } else if constexpr (S3) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             bf16x8 ah[2], al[2], bh[2], bl[2];
@@ -490,7 +490,7 @@ __device__ __forceinline__ void mma_stage_swz(const char* sA, const char* sB, f3
     }
 }
 
-template <typename T, int MODE, bool TAPU>
+template <typename T, int MODE, bool TAPU, bool S3 = false>      // S3: fp32 operands as two bf16 planes, three bf16 MFMA passes (fp32x3)
 __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
     constexpr int VN = Vec<T>::N;
     constexpr int BK = Vec<T>::BK;
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_glds_kernel(NtParams p) {
     for (int j = 0; j < nk; ++j) {
         const int buf = j & 1;
         if (j + 1 < nk) issue(j + 1, buf ^ 1);
-        mma_stage_swz<T>(smem + buf * GSTAGEB, smem + buf * GSTAGEB + GOPB, acc, wm, wn, lane, p.split3 != 0);
+        mma_stage_swz<T, SWZ_NT, S3>(smem + buf * GSTAGEB, smem + buf * GSTAGEB + GOPB, acc, wm, wn, lane);
         dvq_dma_barrier();
     }
     if ((p.ldc % VN) == 0) {
@@ -1260,7 +1260,7 @@ __device__ __forceinline__ int64_t tn_c_offset(const TnParams& p, int row, int t
     return p.c_oihw ? ((int64_t)row * p.Jc + col) * p.taps + tap : (int64_t)row * p.ldc + (int64_t)tap * p.Jc + col;
 }
 
-template <typename T, bool CONV>
+template <typename T, bool CONV, bool S3 = false>
 __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
     constexpr int VN = Vec<T>::N;      // 8 (bf16) / 4 (fp32): block edge of the register transpose
     constexpr int BK = Vec<T>::BK;     // 64 / 32 reduction rows per stage
@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(TnParams p) {
         for (int j = 0; j < nk; ++j) {
             const int buf = j & 1;
             if (j + 1 < nk) g_load(mbeg + (j + 1) * BK);
-            mma_stage_swz<T, SWZ_TN>(smem + buf * GSTAGEB, smem + buf * GSTAGEB + GOPB, acc, wm, wn, lane, p.split3 != 0);
+            mma_stage_swz<T, SWZ_TN, S3>(smem + buf * GSTAGEB, smem + buf * GSTAGEB + GOPB, acc, wm, wn, lane);
             if (j + 1 < nk) s_store(buf ^ 1);
             __syncthreads();
         }
@@ -2369,7 +2369,14 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
             dvq_ensure_dynamic_lds((const void*)kern, 2 * GSTAGEB);
             kern<<<grid, dim3(256), 2 * GSTAGEB, s>>>(p);
         };
-        if (p.mode == MODE_GEMM) go(igemm_nt_glds_kernel<T, MODE_GEMM, false>);
+        constexpr bool F32 = sizeof(T) == 4;
+        if (F32 && p.split3) {              // fp32x3: the split-bf16 instantiations (separate kernels: the exact-fp32 code is untouched)
+            if (p.mode == MODE_GEMM) go(igemm_nt_glds_kernel<T, MODE_GEMM, false, F32>);
+            else if (p.mode == MODE_FWD && tapu) go(igemm_nt_glds_kernel<T, MODE_FWD, true, F32>);
+            else if (p.mode == MODE_FWD) go(igemm_nt_glds_kernel<T, MODE_FWD, false, F32>);
+            else if (tapu) go(igemm_nt_glds_kernel<T, MODE_TCONV, true, F32>);
+            else go(igemm_nt_glds_kernel<T, MODE_TCONV, false, F32>);
+        } else if (p.mode == MODE_GEMM) go(igemm_nt_glds_kernel<T, MODE_GEMM, false>);
         else if (p.mode == MODE_FWD && tapu) go(igemm_nt_glds_kernel<T, MODE_FWD, true>);
         else if (p.mode == MODE_FWD) go(igemm_nt_glds_kernel<T, MODE_FWD, false>);
         else if (tapu) go(igemm_nt_glds_kernel<T, MODE_TCONV, true>);
@@ -2559,6 +2566,15 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
             } else {
                 dvq_ensure_dynamic_lds((const void*)igemm_tn_tr_kernel<false>, 2 * TSTAGEB);
                 igemm_tn_tr_kernel<false><<<grid, dim3(256), 2 * TSTAGEB, s>>>(p);
+            }
+        } else if (sizeof(T) == 4 && p.split3) {          // fp32x3
+            constexpr bool F32 = sizeof(T) == 4;
+            if (p.conv) {
+                dvq_ensure_dynamic_lds((const void*)igemm_tn_kernel<T, true, F32>, 2 * GSTAGEB);
+                igemm_tn_kernel<T, true, F32><<<grid, dim3(256), 2 * GSTAGEB, s>>>(p);
+            } else {
+                dvq_ensure_dynamic_lds((const void*)igemm_tn_kernel<T, false, F32>, 2 * GSTAGEB);
+                igemm_tn_kernel<T, false, F32><<<grid, dim3(256), 2 * GSTAGEB, s>>>(p);
             }
         } else if (p.conv) {
             dvq_ensure_dynamic_lds((const void*)igemm_tn_kernel<T, true>, 2 * GSTAGEB);

@@ -46,7 +46,7 @@ def get_parser():
     p.add_argument("--real_data", action="store_true",
                    help="instantiate the config's `data:` section (data.build.DataModuleFromConfig -> GPU input pipeline, "
                         "$DVQ_IMAGENET_ROOT/train|val) instead of synthetic batches")
-    p.add_argument("--precision", type=str, default="bf16", help="compute dtype of the HIP path: bf16 | fp32")
+    p.add_argument("--precision", type=str, default="bf16", help="compute dtype of the HIP path: bf16 | fp32 | fp32x3 (fp32 tensors, products as three bf16 MFMA passes on split operands)")
     p.add_argument("--logdir", type=str, default="logs")
     p.add_argument("--save_every", type=int, default=0,
                    help="rewrite checkpoints/last.ckpt every N steps (0: once per epoch) -- atomic, rank 0 only")
