@@ -111,11 +111,13 @@ def test_lpips_lin_dropout_kernel(dev):
     assert float(((mean - v0).abs() / v0).max()) < 0.01, (mean, v0)
     # (a dropped element still receives gradient through the channel normalisation of its pixel: no zero pattern to look for --
     #  the finite difference below is the check)
-    u = torch.randn_like(f1) * (f1 > 0)
-    eps = 1e-2
+    # along the gradient itself (a random direction has a directional derivative of ~1e-7: each pixel's term is scale invariant and the
+    # value is folded with fp32 atomics, so the difference quotient would be noise): u = da / |da|, derivative = |da|
+    u = (da.double() / da.double().norm()).float()
+    eps = 0.5            # (|da| ~ 7e-5: the values move by ~3.5e-5 each way, three orders above their summation noise; u's entries are < 0.02)
     fd = (head(f1 + eps * u, 0.5, 7)[0].double().sum() - head(f1 - eps * u, 0.5, 7)[0].double().sum()) / (2 * eps)
     an = (da.double() * u.double()).sum()
-    assert abs(float(fd - an)) < 2e-2 * abs(float(an)) + 1e-7, (float(fd), float(an))
+    assert float(an) > 2e-5 and abs(float(fd - an)) < 3e-2 * abs(float(an)), (float(fd), float(an))
 
 
 def test_lpips_module_lin_dropout_switch(dev):
