@@ -37,6 +37,12 @@ def run(rank, world, port, out, loss="ae"):
     torch.cuda.set_device(di)
     if world > 1:
         dist.init_process_group(BACKEND, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        if BACKEND == "nccl":                 # the group works at all (the parent skips -- not fails -- when RCCL cannot come up on this box)
+            probe = torch.ones(4, device=f"cuda:{di}")
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            assert float(probe[0]) == world
+            say(f"DP2_PG_OK {rank}")
     from dynamicvectorquantization_amd import runtime as rt, synth
     import test_gpu_stepgraph as T
     dev = torch.device("cuda", di)
