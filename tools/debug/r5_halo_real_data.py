@@ -66,6 +66,24 @@ def timed(c, x, reps=20):
     return s.elapsed_time(e) / reps
 
 
+def timed_after_producer(c, x, reps=20, fresh=True):
+    """the same call, but -- like in the step -- its input has JUST been written by an HBM-bound kernel (a copy of x) into a buffer the
+    allocator hands out for the occasion; only the convolution is bracketed by the events"""
+    tot = 0.0
+    keep = []
+    for r in range(reps + 3):
+        xi = x.clone() if fresh else x
+        st = K.zeros_small((c["d"].N, 32, 2), torch.float64, dev) if c["stats"] else None
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        y = orig(c["d"], xi, c["w"], c["bias"], c["residual"], gn_ss=c["gn_ss"], out_stats=st, out_groups=c["groups"] if c["stats"] else 0)
+        e.record()
+        keep.append((s, e))
+        del xi, y
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in keep[3:]) / reps
+
+
 print("variant            captured activations   swish(N(0,1))   N(0,1)   zeros      [ms per launch, 64 x 256^2 x 128 -> 128]")
 for key in sorted(cap):
     c = cap[key]
@@ -78,3 +96,5 @@ for key in sorted(cap):
     row = [timed(c, c["x"]), timed(c, xs), timed(c, xn), timed(c, xz), timed(c, c["x"])]
     print(f"fwd+{key or 'plain':10s}  {row[0]:.4f} (again {row[4]:.4f})      {row[1]:.4f}        {row[2]:.4f}   {row[3]:.4f}    "
           f"input mean {float(xf.mean()):+.3f} std {float(xf.std()):.3f} zero fraction {float((xf == 0).float().mean()):.3f}")
+    print(f"      the same call right after an HBM-bound producer wrote its input (events around the convolution only): "
+          f"{timed_after_producer(c, c['x']):.4f} ms; events per launch without the producer: {timed_after_producer(c, c['x'], fresh=False):.4f} ms")
