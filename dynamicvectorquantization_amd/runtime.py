@@ -54,14 +54,19 @@ def set_compute_dtype(dtype):
 
 @contextlib.contextmanager
 def compute_dtype_ctx(dtype):
-    old, old_split = _compute_dtype, _fp32_split
+    """compute dtype (and fp32 product mode) inside the block, both restored afterwards -- the library's flag to what it WAS (which may
+    have come from the environment), the Python-side record likewise"""
+    global _fp32_split
+    old, old_flag = _compute_dtype, _fp32_split
+    old_lib = fp32_split() if isinstance(dtype, str) and dtype.startswith(("fp32", "float32")) else None
     set_compute_dtype(dtype)
     try:
         yield
     finally:
         set_compute_dtype(old)
-        if _fp32_split != old_split:
-            set_fp32_split(bool(old_split) if old_split is not None else False)
+        if old_lib is not None and fp32_split() != old_lib:
+            set_fp32_split(old_lib)
+        _fp32_split = old_flag
 
 
 def weights_epoch() -> int:

@@ -577,15 +577,20 @@ class _SamplerMixin:
 
         for s in streams:
             s.wait_stream(main)
-        warm = self.__dict__.setdefault("_sampler_lanes_warm", set())
         todo = list(range(n))
+        b0 = int(conds[0][0].size(0))
+        rows = self.hw1 * self.hw1 + self.fine_hw * self.fine_hw + 8
+
+        def lane_is_warm(lane):
+            """this lane's DecodeState exists for the geometry, was built on the current weights and holds captured token-step graphs"""
+            st = self.__dict__.get("_decode_states", {}).get((b0, rows, str(dev), str(cd), lane + 1))
+            return (st is not None and st.gpt is self.transformer and st._sig == st._weights_signature() and
+                    (not st.use_graph or any(e.get("graph") is not None for e in st._steps.values())))
+
         for lane in range(n_streams):                   # graphs of a lane that has not sampled this geometry yet: alone
-            hw = self.transformer.content_head[1].weight
-            wkey = (lane, tuple(conds[0][0].shape), str(cd), id(self.transformer), _rt.param_epoch(hw), hw._version, hw.data_ptr())
-            if wkey not in warm and todo:
+            if todo and not lane_is_warm(lane):
                 run(todo.pop(0), lane)
                 streams[lane].synchronize()
-                warm.add(wkey)
         if errors:
             raise errors[0]
         lock = threading.Lock()
