@@ -134,7 +134,7 @@ def build_stackgpt(dev):
     return model
 
 
-@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 5e-3), (torch.bfloat16, 2e-2, 8e-2)])
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 5e-3), ("fp32x3", 3e-4, 6e-3), (torch.bfloat16, 2e-2, 8e-2)])
 def test_stackgpt_golden(dev, dtype, tol, gtol):
     """teacher-forced losses, parameter gradients (incl. embeddings with padding rows) and logits vs the reference StackGPT"""
     from dynamicvectorquantization_amd import runtime as rt
@@ -162,7 +162,7 @@ def test_stackgpt_golden(dev, dtype, tol, gtol):
         for k in ("position_logits", "content_logits"):
             assert tuple(lo[k].shape) == g[k].shape
             ref_l = g[k]
-            assert float(np.abs(lo[k].cpu().numpy() - ref_l).max()) < (2e-3 if dtype == torch.float32 else 6e-2) * float(np.abs(ref_l).max())
+            assert float(np.abs(lo[k].cpu().numpy() - ref_l).max()) < (6e-2 if dtype == torch.bfloat16 else 2e-3) * float(np.abs(ref_l).max())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
@@ -226,7 +226,7 @@ def dualformer_config():
 
 
 @pytest.mark.parametrize("kind", ["uncond", "class"])
-@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 3e-4, 6e-3), (torch.bfloat16, 3e-2, 1e-1)])
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 3e-4, 6e-3), ("fp32x3", 4e-4, 8e-3), (torch.bfloat16, 3e-2, 1e-1)])
 def test_dualformer_forward_golden(dev, kind, dtype, tol, gtol):
     """Dualformer.training_step of BOTH stage-2 models (uncond: dqtransformer_uncond_entropy.py:180-234, class-conditional:
     dqtransformer_class2_entropy.py) against the reference on a ragged image batch: frozen DQ-VAE -> codes -> permuter ->
@@ -259,7 +259,8 @@ def test_dualformer_forward_golden(dev, kind, dtype, tol, gtol):
                  "class_label": torch.tensor([3, 0, 9], dtype=torch.long, device=dev)}
         with torch.no_grad():
             _, z = model.encode_to_z(batch["image"])
-        if dtype == torch.float32:          # the frozen first stage's codes (hence every sequence) are exact in parity mode
+        if dtype != torch.bfloat16:         # the frozen first stage's codes (hence every sequence) are exact in parity mode (fp32 and
+                                            # fp32x3: the split products leave these margins alone)
             for k in ("coarse_content", "fine_content", "coarse_position", "fine_position", "coarse_segment", "fine_segment"):
                 assert np.array_equal(z[k].cpu().numpy(), g[f"{kind}.z.{k}"]), k
         else:                               # bf16 activations may flip a few near-tie codes; positions / lengths never change
