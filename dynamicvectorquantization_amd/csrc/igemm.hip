@@ -2809,6 +2809,93 @@ int dvq_conv2d_wgrad_oihw_ex(const dvq_conv_desc* d, const void* x, const void* 
     return launch_tn<bf16_t>(p, 1, d->impl, (hipStream_t)stream);
 }
 
+// -------------------------------------------------------------------------------------------------
+// fp32x3 weight gradients at LAUNCH level (round 5).  A weight gradient is accumulated in fp32 whatever the operand type (atomics or
+// partials + fold into the fp32 gradient), so the three products of the split scheme -- lo.hi + hi.lo + hi.hi, see split8_bf16 -- can be
+// three launches of the bf16 weight-gradient kernels (halo / patch / transpose-read: 600 - 1200 TFLOP/s) on bf16 PLANES of the fp32
+// operands instead of one launch of the register-staged fp32 kernel that splits at every fragment read (140 - 190 TFLOP/s nominal, and
+// 9 passes over the activations for a 3 x 3 kernel).  The planes are written once per operand by an HBM-bound pass (4 B read, 4 B
+// written per element) into caller-provided scratch; channels are padded from the fp32 layout's multiple of 4 to the bf16 kernels'
+// multiple of 8 on the way.  Same rounding as split8_bf16: hi = RNE(x), lo = RNE(x - hi).
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                                           int64_t rows, int cin, int cout) {
+    const int cpr = cout >> 3;                          // 8-channel chunks per output row
+    const int64_t total = rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int c0 = (int)(i - r * cpr) << 3;
+        const float* src = x + r * cin + c0;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (c0 < cin) a = *reinterpret_cast<const float4*>(src);            // cin % 4 == 0
+        if (c0 + 4 < cin) b = *reinterpret_cast<const float4*>(src + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint4 h, l;
+        unsigned* hp = &h.x;
+        unsigned* lp = &l.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned ph = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            hp[e] = ph;
+            lp[e] = pack_bf16x2(v[2 * e] - __uint_as_float(ph << 16), v[2 * e + 1] - __uint_as_float(ph & 0xffff0000u));
+        }
+        *reinterpret_cast<uint4*>(hi + r * cout + c0) = h;
+        *reinterpret_cast<uint4*>(lo + r * cout + c0) = l;
+    }
+}
+
+inline int64_t pad8(int64_t c) { return (c + 7) & ~(int64_t)7; }
+
+}  // namespace
+
+int dvq_split_bf16_planes(const float* x, void* hi, void* lo, int64_t rows, int64_t cin, int64_t cout, dvq_stream_t stream) {
+    DVQ_REQUIRE(x && hi && lo, DVQ_EINVAL, "dvq_split_bf16_planes: null pointer");
+    DVQ_REQUIRE(rows > 0 && cin > 0 && cin % 4 == 0 && cout % 8 == 0 && cout >= cin && cout < (1 << 20), DVQ_ESHAPE,
+                "dvq_split_bf16_planes: needs cin %% 4 == 0, cout %% 8 == 0, cout >= cin");
+    const int64_t total = rows * (cout / 8);
+    int64_t blocks = cdiv64(total, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    split_planes_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(x, (bf16_t*)hi, (bf16_t*)lo, rows, (int)cin, (int)cout);
+    DVQ_CHECK_LAUNCH("split_planes");
+    return DVQ_OK;
+}
+
+int64_t dvq_conv2d_wgrad_x3_scratch_bytes(const dvq_conv_desc* d) {
+    if (d == nullptr || d->dtype != DVQ_F32) return 0;
+    const int64_t xrows = d->N * (d->H >> d->upsample) * (d->W >> d->upsample), yrows = d->N * d->OH * d->OW;
+    return 4 * (xrows * pad8(d->Cin) + yrows * pad8(d->Cout)) + 1024;       // two bf16 planes per operand, 256-B aligned starts
+}
+
+int dvq_conv2d_wgrad_oihw_x3(const dvq_conv_desc* d, const void* x, const void* dy, int64_t cin_real, int64_t cout_real,
+                             float* grad_oihw, float* dbias, int ohwi, void* scratch, int64_t scratch_bytes, dvq_stream_t stream) {
+    if (int e = conv_check(d, "dvq_conv2d_wgrad_oihw_x3")) return e;
+    DVQ_REQUIRE(d->dtype == DVQ_F32, DVQ_EINVAL, "dvq_conv2d_wgrad_oihw_x3: fp32 operands only");
+    DVQ_REQUIRE(x && dy && grad_oihw && scratch && cin_real > 0 && cin_real <= d->Cin && cout_real > 0 && cout_real <= d->Cout,
+                DVQ_EINVAL, "dvq_conv2d_wgrad_oihw_x3: bad arguments");
+    DVQ_REQUIRE(scratch_bytes >= dvq_conv2d_wgrad_x3_scratch_bytes(d) && ((uintptr_t)scratch & 15) == 0, DVQ_EWORKSPACE,
+                "dvq_conv2d_wgrad_oihw_x3: scratch too small (dvq_conv2d_wgrad_x3_scratch_bytes) or not 16-B aligned");
+    const int64_t xrows = d->N * (d->H >> d->upsample) * (d->W >> d->upsample), yrows = d->N * d->OH * d->OW;
+    const int64_t c8 = pad8(d->Cin), o8 = pad8(d->Cout);
+    auto up256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+    char* base = (char*)scratch;
+    char* xh = base;
+    char* xl = xh + up256(xrows * c8 * 2);
+    char* yh = xl + up256(xrows * c8 * 2);
+    char* yl = yh + up256(yrows * o8 * 2);
+    if (int e = dvq_split_bf16_planes((const float*)x, xh, xl, xrows, d->Cin, c8, stream)) return e;
+    if (int e = dvq_split_bf16_planes((const float*)dy, yh, yl, yrows, d->Cout, o8, stream)) return e;
+    dvq_conv_desc b = *d;
+    b.dtype = DVQ_BF16;
+    b.Cin = c8;
+    b.Cout = o8;
+    // small terms first; the bias gradient (column sums of dy) is the sum over BOTH dy planes, taken on the two launches that read x_hi
+    if (int e = dvq_conv2d_wgrad_oihw_ex(&b, xl, yh, cin_real, cout_real, grad_oihw, nullptr, ohwi, nullptr, stream)) return e;
+    if (int e = dvq_conv2d_wgrad_oihw_ex(&b, xh, yl, cin_real, cout_real, grad_oihw, dbias, ohwi, nullptr, stream)) return e;
+    return dvq_conv2d_wgrad_oihw_ex(&b, xh, yh, cin_real, cout_real, grad_oihw, dbias, ohwi, nullptr, stream);
+}
+
 int dvq_gemm_nt(const void* A, const void* B, void* C, int dtype, int64_t M, int64_t N, int64_t K, int64_t lda,
                 int64_t ldb, int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, float alpha,
                 const float* bias, int bias_mode, int impl, dvq_stream_t stream) {

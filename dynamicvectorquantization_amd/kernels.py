@@ -516,11 +516,35 @@ def ensure_workspace(device):
         _workspace.update(dev=device, buf=buf)
 
 
+def _wgrad_x3_planes() -> bool:
+    """DVQ_X3_WGRAD_PLANES=0: fp32x3 weight gradients stay on the fp32 kernel that splits at every fragment read (A/B switch)"""
+    return os.environ.get("DVQ_X3_WGRAD_PLANES", "1") != "0"
+
+
+def split_bf16_planes(x2d, cout=None):
+    """fp32 [rows, C] -> (hi, lo) bf16 [rows, cout]: hi = RNE(x), lo = RNE(x - hi); channels >= C are zero"""
+    rows, c = x2d.shape
+    cout = c if cout is None else cout
+    hi = torch.empty(rows, cout, dtype=torch.bfloat16, device=x2d.device)
+    lo = torch.empty_like(hi)
+    check(lib().dvq_split_bf16_planes(_p(x2d), _p(hi), _p(lo), rows, c, cout, _s()), "dvq_split_bf16_planes")
+    return hi, lo
+
+
 def conv2d_wgrad_oihw(d: ConvDesc, x, dy, cin_real, cout_real, grad_oihw, db=None, gn_ss=None):
     """accumulate the weight gradient straight into the [Cout,Cin,KH,KW] fp32 grad (and db into [Cout]);
     gn_ss: the fused GroupNorm+swish of the forward is re-applied to x inside the kernel"""
     fl, nb = _conv_cost(d, x.element_size())
     ensure_workspace(x.device)
+    if gn_ss is None and _wgrad_x3_planes() and x.dtype == torch.float32 and d.impl == 0 and bool(lib().dvq_fp32_split()):
+        # fp32x3: bf16 planes of both operands (scratch from the caching allocator), three launches of the bf16 weight-gradient kernels
+        _tag(d, "wgrad x3 planes")
+        need = int(lib().dvq_conv2d_wgrad_x3_scratch_bytes(C.byref(d)))
+        scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _timed("conv_wgrad_x3_planes", fl, nb, lambda: check(
+            lib().dvq_conv2d_wgrad_oihw_x3(C.byref(d), _p(x), _p(dy), cin_real, cout_real, _praw(grad_oihw), _p(db),
+                                           int(is_ohwi(grad_oihw)), _p(scratch), need, _s()), "dvq_conv2d_wgrad_oihw_x3"))
+        return
     _tag(d, "wgrad")
     if gn_ss is not None:
         _timed("conv3x3_halo_wgrad_kernel", fl, nb, lambda: check(

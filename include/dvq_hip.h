@@ -42,7 +42,8 @@ enum { DVQ_F32 = 0, DVQ_BF16 = 1 };
 enum { DVQ_OK = 0, DVQ_EINVAL = -1, DVQ_ESHAPE = -2, DVQ_EARCH = -3, DVQ_ELAUNCH = -4, DVQ_EWORKSPACE = -5 };
 
 const char* dvq_last_error(void);
-int dvq_version(void);     /* 107: round 5 (dvq_lpips_head_drop; probe modes compiled out of the product library: -DDVQ_PROBES);
+int dvq_version(void);     /* 108: round 5 (dvq_split_bf16_planes, dvq_conv2d_wgrad_oihw_x3: fp32x3 weight gradients on the bf16 kernels);
+                            * 107: round 5 (dvq_lpips_head_drop; probe modes compiled out of the product library: -DDVQ_PROBES);
                             * 106: round 4 (launch lists dvq_cmdlist_*, dvq_add_uniform, dvq_decode_stack_status + 64 sequences, drop_mask argument
                             * of dvq_attn_causal_fwd / bwd + dvq_attn_causal_mask_bytes, dvq_layernorm_bwd_res, dvq_dropout_add, eight
                             * workspace slots + dvq_workspace_release, vq_argmin workspace report slots);
@@ -191,6 +192,16 @@ int dvq_conv2d_fwd_ex(const dvq_conv_desc* d, const void* x, const void* w, cons
                       void* y, const float* gn_scale_shift, double* out_stats, int out_groups, dvq_stream_t stream);
 int dvq_conv2d_wgrad_oihw_ex(const dvq_conv_desc* d, const void* x, const void* dy, int64_t cin_real, int64_t cout_real,
                              float* grad_oihw, float* dbias, int ohwi, const float* gn_scale_shift, dvq_stream_t stream);
+/* fp32x3 weight gradient (dvq_set_fp32_split) at launch level: x / dy fp32 (descriptor dtype DVQ_F32, channels padded to 4) are split
+ * into bf16 planes hi = RNE(v), lo = RNE(v - hi) in `scratch` (>= dvq_conv2d_wgrad_x3_scratch_bytes(d), 16-B aligned; channels re-padded
+ * to 8) and the gradient is accumulated by THREE launches of the bf16 weight-gradient kernels, x_lo.dy_hi + x_hi.dy_lo + x_hi.dy_hi --
+ * the same three products and fp32 accumulation the in-kernel split forms, at the bf16 kernels' speed.  Arguments as
+ * dvq_conv2d_wgrad_oihw; any convolution geometry the bf16 path takes.  dvq_split_bf16_planes: x fp32 [rows][cin] -> two bf16
+ * [rows][cout] tensors (cin % 4 == 0, cout % 8 == 0, cout >= cin; channels >= cin are zero). */
+int dvq_split_bf16_planes(const float* x, void* hi, void* lo, int64_t rows, int64_t cin, int64_t cout, dvq_stream_t stream);
+int64_t dvq_conv2d_wgrad_x3_scratch_bytes(const dvq_conv_desc* d);
+int dvq_conv2d_wgrad_oihw_x3(const dvq_conv_desc* d, const void* x, const void* dy, int64_t cin_real, int64_t cout_real,
+                             float* grad_oihw, float* dbias, int ohwi, void* scratch, int64_t scratch_bytes, dvq_stream_t stream);
 /* scale_shift[n][c] = {rstd*gamma, beta - mean*rstd*gamma} from the fp64 statistics; mean_rstd (fp32 [N][G][2]) optional */
 int dvq_gn_scale_shift(const double* stats, const float* gamma, const float* beta, int64_t N, int64_t HW, int64_t C, int G,
                        float eps, float* scale_shift, float* mean_rstd, dvq_stream_t stream);

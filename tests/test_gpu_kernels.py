@@ -571,15 +571,62 @@ def test_conv_weight_gradient_patch_kernel(dev, case):
         assert err < 1e-2, f"{name}: rel-to-max error {err}"
 
 
+def test_split_bf16_planes(dev):
+    """dvq_split_bf16_planes: hi = RNE(x) (torch's own fp32 -> bf16 cast), lo = RNE(x - hi); hi + lo reproduces x to ~2^-17; channels
+    beyond the fp32 tensor's (4-padded -> 8-padded) are zero"""
+    from dynamicvectorquantization_amd import kernels as K
+    torch.manual_seed(3)
+    for rows, c, cout in ((1000, 128, 128), (777, 4, 8), (513, 12, 16), (64, 64, 64)):
+        x = torch.randn(rows, c, device=dev) * torch.logspace(-6, 6, rows, device=dev)[:, None]
+        hi, lo = K.split_bf16_planes(x, cout)
+        assert torch.equal(hi[:, :c], x.to(torch.bfloat16))
+        assert torch.equal(lo[:, :c], (x - hi[:, :c].float()).to(torch.bfloat16))
+        if cout > c:
+            assert float(hi[:, c:].float().abs().max()) == 0.0 and float(lo[:, c:].float().abs().max()) == 0.0
+        err = (hi[:, :c].float() + lo[:, :c].float() - x).abs() / x.abs().clamp_min(1e-30)
+        assert float(err.max()) < 2.0 ** -16
+
+
+def test_fp32_split_weight_gradient_upsampled_input(dev, monkeypatch):
+    """the plane-splitting weight gradient on a convolution that reads its input through the folded nearest x2 upsample (the stored
+    tensor is half-size: the planes are too), against the in-kernel split"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d
+    torch.manual_seed(8)
+    mod = Conv2d(128, 128, 3, stride=1, padding=1, upsample=True).to(dev)
+    x = torch.randn(2, 128, 16, 32, device=dev)
+    got = {}
+    with rt.compute_dtype_ctx("fp32x3"):
+        for planes in ("1", "0"):
+            monkeypatch.setenv("DVQ_X3_WGRAD_PLANES", planes)
+            mod.weight.grad = mod.bias.grad = None
+            xt = x.clone().requires_grad_(True)
+            y = mod(xt)
+            assert tuple(y.shape) == (2, 128, 32, 64)
+            go = torch.randn(y.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+            (y * go).sum().backward()
+            got[planes] = (mod.weight.grad.double().clone(), mod.bias.grad.double().clone())
+    xr = torch.nn.functional.interpolate(x.double().cpu(), scale_factor=2.0, mode="nearest")
+    wr = mod.weight.detach().double().cpu().requires_grad_(True)
+    br = mod.bias.detach().double().cpu().requires_grad_(True)
+    (F.conv2d(xr, wr, br, padding=1) * go.double().cpu()).sum().backward()
+    for planes in ("1", "0"):
+        for a, r in zip(got[planes], (wr.grad, br.grad)):
+            assert float((a.cpu() - r).norm() / r.norm()) < 3e-5, planes
+
+
+@pytest.mark.parametrize("planes", ["1", "0"], ids=["wgrad-planes", "wgrad-in-kernel"])
 @pytest.mark.parametrize("case", [(128, 128, 3, "same", 32, 32, 2), (256, 256, 3, "down", 32, 32, 2), (64, 128, 4, "same", 31, 31, 2),
-                                  (256, 256, 1, "same", 16, 16, 4), (8, 64, 3, "same", 64, 64, 2), (128, 8, 3, "same", 64, 64, 2)],
+                                  (256, 256, 1, "same", 16, 16, 4), (8, 64, 3, "same", 64, 64, 2), (128, 8, 3, "same", 64, 64, 2),
+                                  (4, 64, 3, "same", 64, 64, 2), (128, 4, 3, "same", 64, 64, 2)],
                          ids=lambda c: "-".join(map(str, c)))
-def test_fp32_split_bf16_products(dev, case):
+def test_fp32_split_bf16_products(dev, case, planes, monkeypatch):
     """`fp32x3` (dvq_set_fp32_split): fp32 tensors, every matrix product as three bf16 MFMA passes on two-plane operands.  Forward,
     input gradient, weight and bias gradient of a convolution against the exact-fp32 instantiation of the same kernels and against
     float64: the split products must be ~2^-17-accurate (two orders of magnitude inside north_star's 1e-3), not bf16-accurate"""
     from dynamicvectorquantization_amd import runtime as rt
     from dynamicvectorquantization_amd.layers import Conv2d
+    monkeypatch.setenv("DVQ_X3_WGRAD_PLANES", planes)     # weight gradient: bf16 planes + three launches of the bf16 kernels / in-kernel split
     cin, cout, k, kind, h, w_, n = case
     rs = np.random.RandomState(cin + 3 * cout + k)
     kw = dict(same=dict(stride=1, padding=(k - 1) // 2), down=dict(stride=2, padding=0, asym_pad=True))[kind]

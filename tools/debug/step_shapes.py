@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-geometry conv timings of ONE headline train step (DVQ_PROFILE_SHAPES=1): which shapes the implicit-GEMM / halo kernel
-families spend their time on.  HIP events around every launch; prints rows sorted by time."""
+families spend their time on.  HIP events around every launch; prints rows sorted by time.  DVQ_SHAPES_DTYPE=bf16|fp32|fp32x3."""
 import os, sys
 os.environ["DVQ_PROFILE_SHAPES"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -12,7 +12,7 @@ from dynamicvectorquantization_amd.trainer import Trainer
 
 dev = torch.device("cuda", 0)
 _lib.check(_lib.load().dvq_check_device(), "dvq_check_device")
-rt.set_compute_dtype("bf16")
+rt.set_compute_dtype(os.environ.get("DVQ_SHAPES_DTYPE", "bf16"))
 torch.manual_seed(0)
 bs = 64
 model = instantiate_from_config(bench.full_config("full")).to(dev)
