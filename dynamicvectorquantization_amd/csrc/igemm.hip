@@ -422,6 +422,12 @@ __device__ __forceinline__ void split8_bf16(const f32x4& c0, const f32x4& c1, bf
     lo = __builtin_bit_cast(bf16x8, l);
 }
 
+#ifdef DVQ_PROBES
+// timing experiments on the fp32x3 main loop (DVQ_X3_DBG, probe library only; wrong results): 1 = the two 16-B chunks are taken as
+// ready-made hi / lo planes (no split arithmetic: what operands pre-split in HBM would cost), 2 = split, but one MFMA pass of three
+__device__ int g_x3_dbg;
+#endif
+
 template <typename T, int SWZ = SWZ_NT, bool S3 = false>
 __device__ __forceinline__ void mma_stage_swz(const char* sA, const char* sB, f32x16 (&acc)[2][2], int wm, int wn,
                                               int lane) {
@@ -449,12 +455,24 @@ __device__ __forceinline__ void mma_stage_swz(const char* sA, const char* sB, f3
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
         }
     } else if constexpr (S3) {
+#ifdef DVQ_PROBES
+        const int x3dbg = g_x3_dbg;
+#endif
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int o0 = ((4 * u + half) ^ swz[t]) << 4, o1 = ((4 * u + 2 + half) ^ swz[t]) << 4;
+#ifdef DVQ_PROBES
+                if (x3dbg == 1) {
+                    ah[t] = *reinterpret_cast<const bf16x8*>(pa + t * 32 * GROW + o0);
+                    al[t] = *reinterpret_cast<const bf16x8*>(pa + t * 32 * GROW + o1);
+                    bh[t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * GROW + o0);
+                    bl[t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * GROW + o1);
+                    continue;
+                }
+#endif
                 split8_bf16(*reinterpret_cast<const f32x4*>(pa + t * 32 * GROW + o0), *reinterpret_cast<const f32x4*>(pa + t * 32 * GROW + o1),
                             ah[t], al[t]);
                 split8_bf16(*reinterpret_cast<const f32x4*>(pb + t * 32 * GROW + o0), *reinterpret_cast<const f32x4*>(pb + t * 32 * GROW + o1),
@@ -464,6 +482,13 @@ __device__ __forceinline__ void mma_stage_swz(const char* sA, const char* sB, f3
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
+#ifdef DVQ_PROBES
+                    if (x3dbg == 2) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt][0] += __builtin_bit_cast(float, (al[mt][0] != bl[nt][0]) ? 0 : 1) * 0.f;       // keep the lo planes alive
+                        continue;
+                    }
+#endif
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
@@ -2370,6 +2395,16 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
             kern<<<grid, dim3(256), 2 * GSTAGEB, s>>>(p);
         };
         constexpr bool F32 = sizeof(T) == 4;
+#ifdef DVQ_PROBES
+        {
+            static const int x3dbg = dvq_probe_env("DVQ_X3_DBG");
+            static bool x3set = false;
+            if (!x3set) {
+                x3set = true;
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_x3_dbg), &x3dbg, sizeof(int));
+            }
+        }
+#endif
         if (F32 && p.split3) {              // fp32x3: the split-bf16 instantiations (separate kernels: the exact-fp32 code is untouched)
             if (p.mode == MODE_GEMM) go(igemm_nt_glds_kernel<T, MODE_GEMM, false, F32>);
             else if (p.mode == MODE_FWD && tapu) go(igemm_nt_glds_kernel<T, MODE_FWD, true, F32>);
