@@ -424,7 +424,7 @@ __device__ __forceinline__ void split8_bf16(const f32x4& c0, const f32x4& c1, bf
 
 #ifdef DVQ_PROBES
 // timing experiments on the fp32x3 main loop (DVQ_X3_DBG, probe library only; wrong results): 1 = the two 16-B chunks are taken as
-// ready-made hi / lo planes (no split arithmetic: what operands pre-split in HBM would cost), 2 = split, but one MFMA pass of three
+// ready-made hi / lo planes (no split arithmetic: what operands pre-split in HBM would cost), 2 = split, but one MFMA pass of three, 3 = like 1 for the B operand only
 __device__ int g_x3_dbg;
 #endif
 
@@ -468,6 +468,13 @@ __device__ __forceinline__ void mma_stage_swz(const char* sA, const char* sB, f3
                 if (x3dbg == 1) {
                     ah[t] = *reinterpret_cast<const bf16x8*>(pa + t * 32 * GROW + o0);
                     al[t] = *reinterpret_cast<const bf16x8*>(pa + t * 32 * GROW + o1);
+                    bh[t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * GROW + o0);
+                    bl[t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * GROW + o1);
+                    continue;
+                }
+                if (x3dbg == 3) {          // only the B operand (the weights of a convolution) arrives as planes
+                    split8_bf16(*reinterpret_cast<const f32x4*>(pa + t * 32 * GROW + o0), *reinterpret_cast<const f32x4*>(pa + t * 32 * GROW + o1),
+                                ah[t], al[t]);
                     bh[t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * GROW + o0);
                     bl[t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * GROW + o1);
                     continue;
