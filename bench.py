@@ -498,7 +498,8 @@ def main():
         calib = None
         if args.mode == "eager" and launch_mode == "graph":
             trainer.use_graph, launch_mode = False, "eager"
-        elif args.mode == "auto" and launch_mode == "graph" and world == 1:
+        elif args.mode == "auto" and launch_mode == "graph" and world == 1 and args.dtype == "bf16":
+            # (fp32 / fp32x3 steps are GPU-bound by a wide margin and their recording holds ~125 GB: no eager working set beside it)
             # untimed calibration: eager steps run the conv weight gradients on a second stream (a replay of the recorded step
             # cannot: DESIGN 3a) and win by ~2.5 % when one host core keeps up with the launches; the recorded step wins otherwise
             def probe(use_graph, n=3):

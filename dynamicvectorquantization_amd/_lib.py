@@ -68,6 +68,10 @@ SIGNATURES = {
     "dvq_conv2d_fwd_ex": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "dvq_conv2d_wgrad_oihw_ex": (i32, [C.POINTER(ConvDesc), vp, vp, i64, i64, vp, vp, i32, vp, vp]),
     "dvq_split_bf16_planes": (i32, [vp, vp, vp, i64, i64, i64, vp]),
+    "dvq_conv3x3_x3_ok": (i32, [C.POINTER(ConvDesc), i32]),
+    "dvq_conv3x3_x3_scratch_bytes": (i64, [C.POINTER(ConvDesc), i32]),
+    "dvq_conv2d_fwd_x3": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp, i64, vp]),
+    "dvq_conv2d_dgrad_x3": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp, i64, vp]),
     "dvq_conv2d_wgrad_x3_scratch_bytes": (i64, [C.POINTER(ConvDesc)]),
     "dvq_conv2d_wgrad_oihw_x3": (i32, [C.POINTER(ConvDesc), vp, vp, i64, i64, vp, vp, i32, vp, i64, vp]),
     "dvq_gn_scale_shift": (i32, [vp, vp, vp, i64, i64, i64, i32, f32, vp, vp, vp]),

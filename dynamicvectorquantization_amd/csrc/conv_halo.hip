@@ -87,7 +87,12 @@ constexpr int VOFF_OOB = 0x7ffffff0;            // beyond every descriptor's ran
 // activation is skipped, staging and store addresses are lane constants + immediate / scalar offsets (buffer stores through a
 // per-image descriptor), the GroupNorm statistics use v_dot2_f32_bf16 on channel PAIRS (2 instead of 6 instructions per dword).
 // Rejected variants (measured): 2 waves x (4 x 4 tiles), 8 waves x (2 x 2 tiles), un-pipelined loop, s_setprio.
-template <int NT, bool TRACE = false>
+//
+// OUT32 (round 5, fp32x3): Y and R are FP32 tensors; the accumulators leave the kernel unrounded.  The bf16 input then carries the three
+// products of the split scheme side by side on the channel axis -- x' = [x_hi | x_lo | x_hi], w' = [w_hi | w_hi | w_lo], 3 Cin channels --
+// so one launch forms x_hi.w_hi + x_lo.w_hi + x_hi.w_lo in its fp32 accumulators (dvq_conv2d_fwd_x3 / dvq_conv2d_dgrad_x3, igemm.hip).
+// Only the epilogue differs: the 256 px x CO_T tile is staged 64 channels (256-B fp32 rows) at a time through the same 64 KiB.
+template <int NT, bool TRACE = false, bool OUT32 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (buffer-descriptor builtins exist in the device pass only; the host pass needs just the stub)
     constexpr int NW = 4, MT = 2, NTH = 256;
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
     // of ~450 unpack / add / pack vector instructions per lane in the store loop, which issue once per MFMA of the CU neighbour
     // (fwd + residual at 128 -> 128, 256^2, B = 64: 1.166 ms with the vector adds against 1.011 ms without a residual).  The sum is
     // rounded once (fp32 accumulator) where the reference rounds the conv output and the sum.  DVQ_HALO_DBG=3 keeps the vector path.
-    const bool res_mfma = NT == 4 && p.R != nullptr && !p.res_mask && p.dbg != 3 && p.dbg != 9;
+    const bool res_mfma = !OUT32 && NT == 4 && p.R != nullptr && !p.res_mask && p.dbg != 3 && p.dbg != 9;
     auto issue_residual = [&]() {
         // wave's own 64 pixels x 128 channels, one 1-KiB DMA per 4 pixels; 16-byte chunk c of pixel px sits at position c ^ (px & 7)
         const __amdgpu_buffer_rsrc_t rsRd = __builtin_amdgcn_make_buffer_rsrc(
@@ -394,6 +399,74 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
         }
     }
 
+    if constexpr (OUT32) {
+        // ---- fp32 epilogue: rounds of 64 output channels; row lp = tile pixel, 16 chunks of 4 floats, chunk c at position c ^ (lp & 15) --
+        static_assert(NT == 4 || NT == 2, "fp32 output: 64-channel staging rounds");
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // nothing is in flight here (the last tap's barrier waited); said explicitly for
+                                                              // tools/lint_dma_barriers.py, whose path merge also walks "main loop skipped"
+        float* Y32 = reinterpret_cast<float*>(p.Y);
+        const float* R32 = reinterpret_cast<const float*>(p.R);
+        const bool act = p.act_slope != 1.f;
+        const bool resv = p.R != nullptr;
+        const bool early_act = act && (!resv || p.res_mask);
+        const int tq = tid >> 4, ch = tid & 15;             // store loop: pixel lp = tq + 16 i (row i >> 1, column 16 (i & 1) + tq), chunk ch
+        const int64_t img = (int64_t)n * p.H * p.W * p.Cout;
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(Y32 + img, 0, p.H * p.W * p.Cout * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(resv ? R32 + img : Y32 + img), 0,
+                                                                             p.H * p.W * p.Cout * 4, 0x00020000);
+        const int so_tile = ((y0 * p.W + x0) * p.Cout) * 4;
+        auto so_iter = [&](int i) { return so_tile + (((i >> 1) * p.W + 16 * (i & 1)) * p.Cout) * 4; };
+        auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory"); };
+        const int cst = l31 & 15;
+        const char* lane_ld = smem + tq * 256 + ((ch ^ tq) << 4);
+#pragma unroll
+        for (int h = 0; h < NT / 2; ++h) {
+            const int col = n0 + 64 * h + ch * 4;
+            const int vo_px = col < p.Cout ? (tq * p.Cout + col) * 4 : VOFF_OOB;
+            if (h > 0) lds_barrier();                       // the previous round's rows have been read
+#pragma unroll
+            for (int ntl = 0; ntl < 2; ++ntl)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int nt = 2 * h + ntl;
+                        f32x4 v = {acc[mt][nt][4 * j], acc[mt][nt][4 * j + 1], acc[mt][nt][4 * j + 2], acc[mt][nt][4 * j + 3]};
+                        if (early_act) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.act_slope;
+                        }
+                        const int chunk = ntl * 8 + 2 * j + half;
+                        *reinterpret_cast<f32x4*>(smem + (MT * wm * 32 + mt * 32 + l31) * 256 + ((cst ^ chunk) << 4)) = v;
+                    }
+            lds_barrier();
+#pragma unroll
+            for (int i0 = 0; i0 < 16; i0 += 8) {            // residual / gate rows requested eight at a time, ahead of their use
+                f32x4 rpre[8];
+                if (resv) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        rpre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo_px, so_iter(i0 + i), 0));
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(lane_ld + (i0 + i) * (16 * 256));
+                    if (resv) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (p.res_mask) v[k] *= rpre[i][k] > 0.f ? 1.f : p.mask_slope;
+                            else {
+                                v[k] += rpre[i][k];
+                                if (act) v[k] = v[k] > 0.f ? v[k] : v[k] * p.act_slope;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvq_u32x4, v), rsY, vo_px, so_iter(i0 + i), 0);
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: stage the 256 px x CO_T tile as bf16 rows, then 16-byte stores -------------------------------------------
     // (measured alternatives, all slower: 4-byte stores straight from the accumulators after a DPP lane-pair exchange; 8 waves x
     //  (1 x 4) tiles at 4 waves per SIMD -- 5 fragment reads per 4 MFMAs instead of 6 per 8 makes the loop LDS-bound.)
@@ -654,13 +727,14 @@ extern "C" int dvq_halo_trace_read(unsigned long long* dst, int64_t max_records)
 
 // Returns 1 if the halo kernel handled the call, 0 if the shape is not eligible (caller falls back to igemm),
 // negative on error.  x: [N,H,W,Cin] bf16; w: rows of [9][Cin]; y: [N,H,W,Cout].
-int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N,
+static int halo_try_impl(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N,
                          int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, int up, const float* gn_ss,
                          double* out_stats, int out_groups, float act_slope, int res_mask, float mask_slope,
-                         hipStream_t stream) {
-    if (H % TH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
+                         hipStream_t stream, bool out32) {
+    if (H % TH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % (out32 ? 4 : 8) != 0) return 0;
+    if (out32 && (Cout <= 32 || gn_ss != nullptr || out_stats != nullptr || H * W * Cout * 4 >= (1ll << 31))) return 0;
 #ifdef DVQ_PROBES
-    {   // the persistent kernel (conv_halo2.hip, DVQ_HALO2=1) takes the launches it is built for: 128-channel output blocks, >= 2 tiles per CU
+    if (!out32) {   // the persistent kernel (conv_halo2.hip, DVQ_HALO2=1) takes the launches it is built for: 128-channel output blocks, >= 2 tiles per CU
         const int rc2 = dvq_conv3x3_halo2_try(x, w, bias, residual, y, N, H, W, Cin, Cout, flip, up, gn_ss, out_stats, out_groups, act_slope,
                                               res_mask, mask_slope, stream);
         if (rc2 != 0) return rc2;
@@ -702,7 +776,10 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
         dvq_ensure_dynamic_lds((const void*)kern, LDSB + lds_pad);
         kern<<<dim3((unsigned)blocks), dim3(256), LDSB + lds_pad, stream>>>(p);
     };
-    if (cot == 128) {
+    if (out32) {
+        if (cot == 128) go(conv3x3_halo_kernel<4, false, true>);
+        else go(conv3x3_halo_kernel<2, false, true>);
+    } else if (cot == 128) {
 #ifdef DVQ_PROBES
         if (p.dbg == 6) go(conv3x3_halo_kernel<4, true>);       // per-workgroup time stamps (dvq_halo_trace_read)
         else
@@ -721,6 +798,22 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
         return DVQ_ELAUNCH;
     }
     return 1;
+}
+
+int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const void* residual, void* y, int64_t N,
+                         int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, int up, const float* gn_ss,
+                         double* out_stats, int out_groups, float act_slope, int res_mask, float mask_slope,
+                         hipStream_t stream) {
+    return halo_try_impl(x, w, bias, residual, y, N, H, W, Cin, Cout, flip, up, gn_ss, out_stats, out_groups, act_slope, res_mask,
+                         mask_slope, stream, false);
+}
+
+// bf16 x / w, FP32 residual (or gate) and output: the fp32x3 form (see the OUT32 note at the kernel)
+int dvq_conv3x3_halo_out32_try(const void* x, const void* w, const float* bias, const float* residual, float* y, int64_t N,
+                               int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, int up, float act_slope, int res_mask,
+                               float mask_slope, hipStream_t stream) {
+    return halo_try_impl(x, w, bias, residual, y, N, H, W, Cin, Cout, flip, up, nullptr, nullptr, 0, act_slope, res_mask, mask_slope,
+                         stream, true);
 }
 
 // =================================================================================================

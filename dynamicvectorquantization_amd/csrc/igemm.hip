@@ -2674,6 +2674,48 @@ int dvq_tconv4x4s2_thin_try(const void* dy, const void* wt, void* dx, int64_t N,
 
 static float act_slope_of(int act) { return act == DVQ_ACT_RELU ? 0.f : act == DVQ_ACT_LRELU ? 0.2f : 1.f; }
 
+int dvq_conv3x3_halo_out32_try(const void* x, const void* w, const float* bias, const float* residual, float* y, int64_t N,
+                               int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flip, int up, float act_slope, int res_mask,
+                               float mask_slope, hipStream_t stream);
+
+// fp32x3 on the halo kernel (dvq_conv2d_fwd_x3 below): bf16 planes side by side on the channel axis
+// MODE 0 (activations): [hi | lo | hi]; MODE 1 (weights, rows = Cout x 9): [hi | hi | lo].  c % 8 == 0.
+template <int MODE>
+__global__ __launch_bounds__(256) void split_concat3_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int64_t rows, int c) {
+    const int cpr = c >> 3;
+    const int64_t total = rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int c0 = (int)(i - r * cpr) << 3;
+        const float* src = x + r * c + c0;
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint4 h, l;
+        unsigned* hp = &h.x;
+        unsigned* lp = &l.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned ph = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            hp[e] = ph;
+            lp[e] = pack_bf16x2(v[2 * e] - __uint_as_float(ph << 16), v[2 * e + 1] - __uint_as_float(ph & 0xffff0000u));
+        }
+        bf16_t* dst = out + r * 3 * c + c0;
+        *reinterpret_cast<uint4*>(dst) = h;
+        *reinterpret_cast<uint4*>(dst + c) = MODE == 0 ? l : h;
+        *reinterpret_cast<uint4*>(dst + 2 * c) = MODE == 0 ? h : l;
+    }
+}
+
+static int split_concat3(const float* x, void* out, int64_t rows, int64_t c, int mode, hipStream_t s) {
+    const int64_t total = rows * (c / 8);
+    int64_t blocks = cdiv64(total, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (mode == 0) split_concat3_kernel<0><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (bf16_t*)out, rows, (int)c);
+    else split_concat3_kernel<1><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (bf16_t*)out, rows, (int)c);
+    DVQ_CHECK_LAUNCH("split_concat3");
+    return DVQ_OK;
+}
+
 static bool halo_eligible(const dvq_conv_desc* d) {
     return d->dtype == DVQ_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->OH == d->H && d->OW == d->W && (d->impl == 0 || d->impl == 4);
@@ -2936,6 +2978,82 @@ int dvq_conv2d_wgrad_oihw_x3(const dvq_conv_desc* d, const void* x, const void* 
     if (int e = dvq_conv2d_wgrad_oihw_ex(&b, xl, yh, cin_real, cout_real, grad_oihw, nullptr, ohwi, nullptr, stream)) return e;
     if (int e = dvq_conv2d_wgrad_oihw_ex(&b, xh, yl, cin_real, cout_real, grad_oihw, dbias, ohwi, nullptr, stream)) return e;
     return dvq_conv2d_wgrad_oihw_ex(&b, xh, yh, cin_real, cout_real, grad_oihw, dbias, ohwi, nullptr, stream);
+}
+
+// -------------------------------------------------------------------------------------------------
+// fp32x3 forward / input gradient of the 3 x 3 / stride 1 / pad 1 convolutions on the HALO kernel (round 5).  The three products of the
+// split scheme are laid side by side on the channel axis of bf16 operands -- x' = [x_hi | x_lo | x_hi] and, per tap,
+// w' = [w_hi | w_hi | w_lo], 3 Cin channels -- so ONE launch of the bf16 halo kernel forms x_hi.w_hi + x_lo.w_hi + x_hi.w_lo in its fp32
+// accumulators, and its fp32-output instantiation (conv_halo.hip, OUT32) stores them unrounded, after the fp32 residual / gate /
+// activation.  Same products, same accumulation type as the in-kernel split of igemm_nt_glds_kernel<float, S3>, on a kernel that stages
+// every activation once for all 9 taps (the fp32 kernel: 200 - 250 TFLOP/s nominal, bound by its 2-us stages, section 3 of DESIGN.md).
+// Costs: one HBM-bound pass writes x' (4 B read + 6 B written per element), the weights are re-laid per call (Cout x 9 x Cin elements).
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+// cs: channels of the streamed operand (x: Cin / dy: Cout), co: channels produced
+bool x3_halo_shape_ok(const dvq_conv_desc* d, int64_t cs, int64_t co) {
+    return d->dtype == DVQ_F32 && d->impl == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+           d->OH == d->H && d->OW == d->W && d->H % 8 == 0 && d->W % 32 == 0 && cs % 64 == 0 && co > 32 && co % 4 == 0 &&
+           d->N * d->H * d->W * (3 * cs > co ? 3 * cs : co) < (1ll << 31) && co * 27 * cs < (1ll << 31) && d->H * d->W * co * 4 < (1ll << 31);
+}
+
+inline int64_t up256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+}  // namespace
+
+/* 1: dvq_conv2d_fwd_x3 (dgrad = 0) / dvq_conv2d_dgrad_x3 (dgrad = 1) take this descriptor */
+int dvq_conv3x3_x3_ok(const dvq_conv_desc* d, int dgrad) {
+    if (d == nullptr) return 0;
+    return dgrad ? x3_halo_shape_ok(d, d->Cout, d->Cin) : x3_halo_shape_ok(d, d->Cin, d->Cout);
+}
+
+int64_t dvq_conv3x3_x3_scratch_bytes(const dvq_conv_desc* d, int dgrad) {
+    if (!dvq_conv3x3_x3_ok(d, dgrad)) return 0;
+    const int64_t cs = dgrad ? d->Cout : d->Cin, co = dgrad ? d->Cin : d->Cout;
+    const int64_t rows = dgrad ? d->N * d->H * d->W : d->N * (d->H >> d->upsample) * (d->W >> d->upsample);
+    return up256(rows * 3 * cs * 2) + up256(co * 9 * 3 * cs * 2);
+}
+
+int dvq_conv2d_fwd_x3(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y, int act,
+                      void* scratch, int64_t scratch_bytes, dvq_stream_t stream) {
+    if (int e = conv_check(d, "dvq_conv2d_fwd_x3")) return e;
+    DVQ_REQUIRE(x && w && y && scratch, DVQ_EINVAL, "dvq_conv2d_fwd_x3: null pointer");
+    DVQ_REQUIRE(dvq_conv3x3_x3_ok(d, 0), DVQ_ESHAPE, "dvq_conv2d_fwd_x3: shape not eligible (dvq_conv3x3_x3_ok)");
+    DVQ_REQUIRE(act == DVQ_ACT_NONE || residual == nullptr, DVQ_EINVAL, "dvq_conv2d_fwd_x3: activation and residual together");
+    DVQ_REQUIRE(scratch_bytes >= dvq_conv3x3_x3_scratch_bytes(d, 0) && ((uintptr_t)scratch & 15) == 0, DVQ_EWORKSPACE,
+                "dvq_conv2d_fwd_x3: scratch too small (dvq_conv3x3_x3_scratch_bytes) or not 16-B aligned");
+    const int64_t rows = d->N * (d->H >> d->upsample) * (d->W >> d->upsample);
+    char* xs = (char*)scratch;
+    char* wsx = xs + up256(rows * 3 * d->Cin * 2);
+    if (int e = split_concat3((const float*)x, xs, rows, d->Cin, 0, (hipStream_t)stream)) return e;
+    if (int e = split_concat3((const float*)w, wsx, d->Cout * 9, d->Cin, 1, (hipStream_t)stream)) return e;
+    const int rc = dvq_conv3x3_halo_out32_try(xs, wsx, bias, (const float*)residual, (float*)y, d->N, d->H, d->W, 3 * d->Cin, d->Cout, 0,
+                                              d->upsample, act_slope_of(act), 0, 0.f, (hipStream_t)stream);
+    if (rc < 0) return rc;
+    DVQ_REQUIRE(rc == 1, DVQ_ESHAPE, "dvq_conv2d_fwd_x3: the halo kernel refused the shape");
+    return DVQ_OK;
+}
+
+int dvq_conv2d_dgrad_x3(const dvq_conv_desc* d, const void* dy, const void* wt, void* dx, void* ws, const void* mask, int mask_act,
+                        void* scratch, int64_t scratch_bytes, dvq_stream_t stream) {
+    if (int e = conv_check(d, "dvq_conv2d_dgrad_x3")) return e;
+    DVQ_REQUIRE(mask == nullptr || ((mask_act == DVQ_ACT_RELU || mask_act == DVQ_ACT_LRELU) && !d->upsample), DVQ_EINVAL,
+                "dvq_conv2d_dgrad_x3: mask needs act in {relu, lrelu} and no folded upsample");
+    DVQ_REQUIRE(dy && wt && dx && scratch && (!d->upsample || ws), DVQ_EINVAL, "dvq_conv2d_dgrad_x3: null pointer");
+    DVQ_REQUIRE(dvq_conv3x3_x3_ok(d, 1), DVQ_ESHAPE, "dvq_conv2d_dgrad_x3: shape not eligible (dvq_conv3x3_x3_ok)");
+    DVQ_REQUIRE(scratch_bytes >= dvq_conv3x3_x3_scratch_bytes(d, 1) && ((uintptr_t)scratch & 15) == 0, DVQ_EWORKSPACE,
+                "dvq_conv2d_dgrad_x3: scratch too small (dvq_conv3x3_x3_scratch_bytes) or not 16-B aligned");
+    const int64_t rows = d->N * d->H * d->W;
+    char* ys = (char*)scratch;
+    char* wsx = ys + up256(rows * 3 * d->Cout * 2);
+    if (int e = split_concat3((const float*)dy, ys, rows, d->Cout, 0, (hipStream_t)stream)) return e;
+    if (int e = split_concat3((const float*)wt, wsx, d->Cin * 9, d->Cout, 1, (hipStream_t)stream)) return e;
+    const int rc = dvq_conv3x3_halo_out32_try(ys, wsx, nullptr, (const float*)mask, (float*)(d->upsample ? ws : dx), d->N, d->H, d->W,
+                                              3 * d->Cout, d->Cin, 1, 0, 1.f, mask != nullptr, act_slope_of(mask_act), (hipStream_t)stream);
+    if (rc < 0) return rc;
+    DVQ_REQUIRE(rc == 1, DVQ_ESHAPE, "dvq_conv2d_dgrad_x3: the halo kernel refused the shape");
+    return d->upsample ? dvq_sumpool2x2(ws, d->dtype, d->N, d->H / 2, d->W / 2, d->Cin, dx, stream) : DVQ_OK;
 }
 
 int dvq_gemm_nt(const void* A, const void* B, void* C, int dtype, int64_t M, int64_t N, int64_t K, int64_t lda,

@@ -718,7 +718,7 @@ int dvq_set_fp32_split(int on) {
 }
 
 const char* dvq_last_error(void) { return g_err; }
-int dvq_version(void) { return 108; }
+int dvq_version(void) { return 109; }
 
 int dvq_set_workspace(void* ptr, int64_t bytes) {
     DVQ_REQUIRE((ptr == nullptr) == (bytes == 0) && bytes >= 0, DVQ_EINVAL, "dvq_set_workspace: bad arguments");

@@ -415,9 +415,24 @@ def conv_fused_ok(d: ConvDesc) -> bool:
 ACT_NONE, ACT_SWISH, ACT_LRELU, ACT_RELU = 0, 1, 2, 3      # include/dvq_hip.h DVQ_ACT_*
 
 
+def _x3_halo(d: ConvDesc, t, dgrad: bool) -> bool:
+    """fp32x3 forward / input gradient of this call on the halo kernel (bf16 planes on the channel axis, fp32 output)?
+    DVQ_X3_HALO=0: stay on the fp32 kernel that splits at every fragment read (A/B switch)"""
+    return (t.dtype == torch.float32 and d.KH == 3 and d.stride == 1 and os.environ.get("DVQ_X3_HALO", "1") != "0" and
+            bool(lib().dvq_fp32_split()) and bool(lib().dvq_conv3x3_x3_ok(C.byref(d), int(dgrad))))
+
+
 def conv2d_fwd(d: ConvDesc, x, w, bias, residual=None, gn_ss=None, out_stats=None, out_groups=0, act=ACT_NONE):
     y = torch.empty(d.N, d.OH, d.OW, d.Cout, dtype=x.dtype, device=x.device)
     fl, nb = _conv_cost(d, x.element_size())
+    if gn_ss is None and out_stats is None and _x3_halo(d, x, False):
+        _tag(d, "fwd x3 halo" + ("+res" if residual is not None else "") + ("+act" if act != ACT_NONE else ""))
+        need = int(lib().dvq_conv3x3_x3_scratch_bytes(C.byref(d), 0))
+        scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _timed("conv_x3_halo", fl, nb, lambda: check(
+            lib().dvq_conv2d_fwd_x3(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), _p(y), act, _p(scratch), need, _s()),
+            "dvq_conv2d_fwd_x3"))
+        return y
     if _shape_tags:       # per-shape tables split the forward by epilogue / prologue variant (tools/debug/step_shapes.py)
         _tag(d, "fwd" + ("+res" if residual is not None else "") + ("+gn" if gn_ss is not None else "") +
              ("+st" if out_stats is not None else "") + ("+act" if act != ACT_NONE else ""))
@@ -444,6 +459,14 @@ def conv2d_dgrad(d: ConvDesc, dy, wt, mask=None, mask_act=ACT_NONE):
     dx = torch.empty(d.N, sh, sw, d.Cin, dtype=dy.dtype, device=dy.device)
     ws = torch.empty(d.N, d.H, d.W, d.Cin, dtype=dy.dtype, device=dy.device) if d.upsample else None
     fl, nb = _conv_cost(d, dy.element_size())
+    if _x3_halo(d, dy, True):
+        _tag(d, "dgrad x3 halo")
+        need = int(lib().dvq_conv3x3_x3_scratch_bytes(C.byref(d), 1))
+        scratch = torch.empty(need, dtype=torch.uint8, device=dy.device)
+        _timed("conv_x3_halo", fl, nb, lambda: check(
+            lib().dvq_conv2d_dgrad_x3(C.byref(d), _p(dy), _p(wt), _p(dx), _p(ws), _p(mask), mask_act, _p(scratch), need, _s()),
+            "dvq_conv2d_dgrad_x3"))
+        return dx
     _tag(d, "dgrad")
     _timed("conv3x3_halo_kernel" if _halo_eligible(d) and d.H % 8 == 0 and d.Cout % 64 == 0 else _nt_family(d, True), fl, nb,
            lambda: check(

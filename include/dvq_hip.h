@@ -42,7 +42,8 @@ enum { DVQ_F32 = 0, DVQ_BF16 = 1 };
 enum { DVQ_OK = 0, DVQ_EINVAL = -1, DVQ_ESHAPE = -2, DVQ_EARCH = -3, DVQ_ELAUNCH = -4, DVQ_EWORKSPACE = -5 };
 
 const char* dvq_last_error(void);
-int dvq_version(void);     /* 108: round 5 (dvq_split_bf16_planes, dvq_conv2d_wgrad_oihw_x3: fp32x3 weight gradients on the bf16 kernels);
+int dvq_version(void);     /* 109: round 5 (dvq_conv2d_fwd_x3 / dvq_conv2d_dgrad_x3: fp32x3 3 x 3 convolutions on the halo kernel, fp32 output);
+                            * 108: round 5 (dvq_split_bf16_planes, dvq_conv2d_wgrad_oihw_x3: fp32x3 weight gradients on the bf16 kernels);
                             * 107: round 5 (dvq_lpips_head_drop; probe modes compiled out of the product library: -DDVQ_PROBES);
                             * 106: round 4 (launch lists dvq_cmdlist_*, dvq_add_uniform, dvq_decode_stack_status + 64 sequences, drop_mask argument
                             * of dvq_attn_causal_fwd / bwd + dvq_attn_causal_mask_bytes, dvq_layernorm_bwd_res, dvq_dropout_add, eight
@@ -202,6 +203,18 @@ int dvq_split_bf16_planes(const float* x, void* hi, void* lo, int64_t rows, int6
 int64_t dvq_conv2d_wgrad_x3_scratch_bytes(const dvq_conv_desc* d);
 int dvq_conv2d_wgrad_oihw_x3(const dvq_conv_desc* d, const void* x, const void* dy, int64_t cin_real, int64_t cout_real,
                              float* grad_oihw, float* dbias, int ohwi, void* scratch, int64_t scratch_bytes, dvq_stream_t stream);
+/* fp32x3 forward / input gradient of a 3 x 3, stride 1, pad 1 convolution on the halo kernel: operands fp32 (descriptor dtype DVQ_F32,
+ * arguments as dvq_conv2d_fwd / dvq_conv2d_fwd_act and dvq_conv2d_dgrad_mask), split into bf16 planes laid side by side on the channel
+ * axis ([x_hi | x_lo | x_hi] against [w_hi | w_hi | w_lo]) in `scratch`, ONE launch of the bf16 halo kernel, fp32 residual / gate /
+ * activation and fp32 output -- the three products and the fp32 accumulation of dvq_set_fp32_split at the halo kernel's speed.
+ * dvq_conv3x3_x3_ok(d, dgrad): shapes taken (H % 8 == 0, W % 32 == 0, streamed channels % 64 == 0, produced channels > 32);
+ * scratch >= dvq_conv3x3_x3_scratch_bytes(d, dgrad), 16-B aligned.  act != DVQ_ACT_NONE excludes a residual. */
+int dvq_conv3x3_x3_ok(const dvq_conv_desc* d, int dgrad);
+int64_t dvq_conv3x3_x3_scratch_bytes(const dvq_conv_desc* d, int dgrad);
+int dvq_conv2d_fwd_x3(const dvq_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y, int act,
+                      void* scratch, int64_t scratch_bytes, dvq_stream_t stream);
+int dvq_conv2d_dgrad_x3(const dvq_conv_desc* d, const void* dy, const void* wt, void* dx, void* ws, const void* mask, int mask_act,
+                        void* scratch, int64_t scratch_bytes, dvq_stream_t stream);
 /* scale_shift[n][c] = {rstd*gamma, beta - mean*rstd*gamma} from the fp64 statistics; mean_rstd (fp32 [N][G][2]) optional */
 int dvq_gn_scale_shift(const double* stats, const float* gamma, const float* beta, int64_t N, int64_t HW, int64_t C, int G,
                        float eps, float* scale_shift, float* mean_rstd, dvq_stream_t stream);

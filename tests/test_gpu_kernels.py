@@ -615,18 +615,71 @@ def test_fp32_split_weight_gradient_upsampled_input(dev, monkeypatch):
             assert float((a.cpu() - r).norm() / r.norm()) < 3e-5, planes
 
 
+def test_fp32_split_halo_variants(dev, monkeypatch):
+    """fp32x3 forward / input gradient on the halo kernel (bf16 planes on the channel axis, fp32 output: dvq_conv2d_fwd_x3 /
+    dvq_conv2d_dgrad_x3) against float64 and against the in-kernel split (DVQ_X3_HALO=0): residual, fused ReLU / LeakyReLU, gated input
+    gradient, folded nearest x2 upsample, 64- / 128- / 192-channel outputs (one and two staging rounds, a partial channel block)"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d
+    torch.manual_seed(11)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    with rt.compute_dtype_ctx("fp32x3"):
+        for cin, cout, h, w_, n, up in ((128, 128, 16, 32, 2, False), (64, 64, 8, 64, 3, False), (128, 192, 8, 32, 2, False),
+                                        (256, 128, 16, 32, 1, False), (128, 128, 16, 32, 2, True)):
+            conv = Conv2d(cin, cout, 3, stride=1, padding=1, upsample=up).to(dev)
+            x = torch.randn(n, h >> up, w_ >> up, cin, device=dev)
+            d = conv._desc(x)
+            monkeypatch.setenv("DVQ_X3_HALO", "1")
+            assert K._x3_halo(d, x, False) and K._x3_halo(d, x, True), (cin, cout, h, w_, n, up, rt.fp32_split(), d.impl, d.H, d.W, d.OH, d.OW, d.Cin, d.Cout, d.pad_t)
+            w, wt, bias = conv.packed(torch.float32)
+            res = torch.randn(n, h, w_, cout, device=dev)
+            dy = torch.randn(n, h, w_, cout, device=dev)
+            mask = torch.randn(n, h, w_, cin, device=dev)
+            xr = x.double().permute(0, 3, 1, 2)
+            if up:
+                xr = torch.nn.functional.interpolate(xr, scale_factor=2.0, mode="nearest")
+            xr = xr.requires_grad_(True)
+            yr = F.conv2d(xr, conv.weight.detach().double(), conv.bias.detach().double(), padding=1)
+            gx, = torch.autograd.grad(yr, xr, dy.double().permute(0, 3, 1, 2))
+            yr = yr.detach().permute(0, 2, 3, 1)
+            gx = gx.permute(0, 2, 3, 1)
+            if up:
+                gx = gx.reshape(n, h // 2, 2, w_ // 2, 2, cin).sum((2, 4))
+            out = {}
+            for halo in ("1", "0"):
+                monkeypatch.setenv("DVQ_X3_HALO", halo)
+                o = {"y": K.conv2d_fwd(d, x, w, bias), "y+res": K.conv2d_fwd(d, x, w, bias, res),
+                     "relu": K.conv2d_fwd(d, x, w, bias, act=K.ACT_RELU), "lrelu": K.conv2d_fwd(d, x, w, bias, act=K.ACT_LRELU),
+                     "dx": K.conv2d_dgrad(d, dy, wt)}
+                if not up:
+                    o["dx relu"] = K.conv2d_dgrad(d, dy, wt, mask, K.ACT_RELU)
+                    o["dx lrelu"] = K.conv2d_dgrad(d, dy, wt, mask, K.ACT_LRELU)
+                out[halo] = o
+            ref = {"y": yr, "y+res": yr + res.double(), "relu": yr.clamp_min(0), "lrelu": torch.where(yr > 0, yr, 0.2 * yr), "dx": gx}
+            if not up:
+                ref["dx relu"] = gx * (mask > 0)
+                ref["dx lrelu"] = gx * torch.where(mask > 0, 1.0, 0.2).double()
+            for k, r in ref.items():
+                assert rel(out["1"][k], r) < 3e-5, (cin, cout, up, k, rel(out["1"][k], r))
+                assert rel(out["0"][k], r) < 3e-5, (cin, cout, up, k, "in-kernel")
+            assert not torch.equal(out["1"]["y"], out["0"]["y"])          # two different kernels really ran
+
+
+@pytest.mark.parametrize("halo", ["1", "0"], ids=["halo", "nt-glds"])
 @pytest.mark.parametrize("planes", ["1", "0"], ids=["wgrad-planes", "wgrad-in-kernel"])
 @pytest.mark.parametrize("case", [(128, 128, 3, "same", 32, 32, 2), (256, 256, 3, "down", 32, 32, 2), (64, 128, 4, "same", 31, 31, 2),
                                   (256, 256, 1, "same", 16, 16, 4), (8, 64, 3, "same", 64, 64, 2), (128, 8, 3, "same", 64, 64, 2),
                                   (4, 64, 3, "same", 64, 64, 2), (128, 4, 3, "same", 64, 64, 2)],
                          ids=lambda c: "-".join(map(str, c)))
-def test_fp32_split_bf16_products(dev, case, planes, monkeypatch):
+def test_fp32_split_bf16_products(dev, case, planes, halo, monkeypatch):
     """`fp32x3` (dvq_set_fp32_split): fp32 tensors, every matrix product as three bf16 MFMA passes on two-plane operands.  Forward,
     input gradient, weight and bias gradient of a convolution against the exact-fp32 instantiation of the same kernels and against
     float64: the split products must be ~2^-17-accurate (two orders of magnitude inside north_star's 1e-3), not bf16-accurate"""
     from dynamicvectorquantization_amd import runtime as rt
     from dynamicvectorquantization_amd.layers import Conv2d
     monkeypatch.setenv("DVQ_X3_WGRAD_PLANES", planes)     # weight gradient: bf16 planes + three launches of the bf16 kernels / in-kernel split
+    monkeypatch.setenv("DVQ_X3_HALO", halo)               # 3 x 3 forward / input gradient: halo kernel on concatenated planes / in-kernel split
     cin, cout, k, kind, h, w_, n = case
     rs = np.random.RandomState(cin + 3 * cout + k)
     kw = dict(same=dict(stride=1, padding=(k - 1) // 2), down=dict(stride=2, padding=0, asym_pad=True))[kind]
