@@ -20,6 +20,7 @@ done
 ff=$(find gpurun_out/pmcb_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find gpurun_out/pmcb_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_summarise.py "$ff" "$fw" gpurun_out/${TAG}_bench_pmc.json | tail -4
 DVQ_SIDE_WGRAD=0 TOP=160 timeout 300 python tools/debug/step_shapes.py 2>/dev/null | grep -v "Warn\|return get_obj" > gpurun_out/${TAG}_step_shapes.txt; echo "shapes exit $?"
+DVQ_SHAPES_DTYPE=fp32x3 DVQ_SIDE_WGRAD=0 TOP=80 timeout 300 python tools/debug/step_shapes.py 2>/dev/null | grep -v "Warn\|return get_obj" > gpurun_out/${TAG}_x3_step_shapes.txt; echo "x3 shapes exit $?"
 timeout 300 python tools/conv_bench.py --no-check 2>/dev/null | grep -v "Warn\|return get_obj" > gpurun_out/${TAG}_conv_bench.txt; echo "conv_bench exit $?"
 if [ -f dynamicvectorquantization_amd/libdvq_hip_probes.so ]; then
 { echo "# 128->128 @256^2 B=64 halo conv (tools/debug/halo_data_probe.py, probe library): complete kernel / main loop only (DVQ_HALO_DBG=1) / epilogue only (=2)";
