@@ -638,8 +638,8 @@ def main():
                 gc.collect()
                 torch.cuda.empty_cache()
                 rt.set_compute_dtype(dtype_name)
-                k3 = 3
-                dt3, _, prof3, m3 = run("full", k3, 1, True, no_graph=True)
+                k3, w3 = 3, 2              # (two untimed steps behind the two set-up steps: the caching allocator has stopped growing by then)
+                dt3, _, prof3, m3 = run("full", k3, w3, True, no_graph=True)
                 ips3 = world * args.bs * k3 / dt3
                 fam3 = {k: v for k, v in prof3.items() if k != "vq_argmin" and v["ms"] > 0}
                 dom3 = max(fam3, key=lambda k: fam3[k]["ms"]) if fam3 else None
@@ -652,7 +652,7 @@ def main():
                              "avg_launch_ms": round(v["ms"] / max(1, v["launches"]), 4)}
                     if dtype_name == "fp32x3":
                         roof3["note"] = "algorithmic flop against the bf16 peak; the kernel issues 3 bf16 MFMA passes per product"
-                out3 = {"value": round(ips3, 2), "unit": "images/sec", "steps": k3, "warmup": 1, "ms_per_step": round(dt3 / k3 * 1e3, 2),
+                out3 = {"value": round(ips3, 2), "unit": "images/sec", "steps": k3, "warmup": w3, "ms_per_step": round(dt3 / k3 * 1e3, 2),
                         "dtype": dtype_name, "launch": "eager", "roofline": roof3,
                         "kernel_families": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"], 2),
                                                 "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in fam3.items()}}
