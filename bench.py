@@ -74,20 +74,22 @@ def _cpu_baseline_worker(threads, bs, objective="full", budget_s=15.0):
     from oracle import train_step as ots
     torch.manual_seed(0)
     model = instantiate_from_config(full_config(objective))          # reference-identical init + key names (CPU tensors)
-    full = model.state_dict()
-    sd = {k: v.detach().clone() for k, v in full.items() if not k.startswith("loss.")}
-    sd_d = {k[len("loss.discriminator."):]: v.detach().clone() for k, v in full.items() if k.startswith("loss.discriminator.")}
-    sd_l = {k[len("loss.perceptual_loss."):]: v.detach().clone() for k, v in full.items() if k.startswith("loss.perceptual_loss.")}
-    del model, full
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    param_keys = [k for k, _ in model.named_parameters()]
+    del model
     thr = oent.threshold_from_table(THR_JSON, 0.5)
     x = torch.from_numpy(synth.half_flat_images(bs, 256, seed=1234))
+    # the reference draws torch.randperm(N) per EMA update for the code restart (quantize2_mask.py:97); here: one seeded permutation
+    perm = np.random.RandomState(0).permutation(bs * (256 // 8) ** 2)
     t0 = time.time()
     n = 0
     while True:
+        # oracle.train_step is pinned against the reference's own two-optimizer step (tests/golden/train_step_*.npz): both
+        # training-mode autoencoder forwards with their EMA codebook updates, LPIPS, adaptive GAN weight, both Adam updates
         if objective == "full":
-            ots.full_objective_steps(sd, sd_d, sd_l, [x], thr, steps=1)
+            ots.full_objective_steps(state, param_keys, [x], thr, steps=1, restart_perm=perm)
         else:
-            ots.train_steps(sd, [x], thr, steps=1)
+            ots.ae_only_steps(state, param_keys, [x], thr, steps=1, restart_perm=perm)
         n += 1
         if time.time() - t0 > budget_s or n >= 10:      # ~budget_s of CPU work
             break

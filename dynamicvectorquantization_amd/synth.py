@@ -125,3 +125,77 @@ def dqvae_golden_state(keys, shapes, variant: str, k: int, zc: int) -> dict:
 # geometries of the DQ-VAE fixtures: `small` = shrunken widths, `c1` = BASELINE config 1 (full width, 64 x 64 images)
 DQVAE_GEOM = {"small": dict(ch=32, resolution=64, latent=8, zc=64, k=512, attn_enc=[4, 8], attn_dec=[8]),
               "c1": dict(ch=128, resolution=64, latent=8, zc=256, k=1024, attn_enc=[4, 8], attn_dec=[8])}
+
+
+# ---- the pinned training step (tests/golden/train_step.npz; tools/gen_golden.py::gen_train_step) ------------------------------
+def train_step_param(key: str, shape, k: int, zc: int) -> np.ndarray:
+    """deterministic value of ONE parameter of the complete stage-1 model (autoencoder + `loss.discriminator.*` +
+    `loss.perceptual_loss.*`), by state_dict key: the same naming the lossnet / dqvae fixtures use"""
+    if key == "quantize.codebook.weight":
+        return (det_param("quantize.codebook.weight.spread", (k + 1, zc)) * np.sqrt(zc) * 1.2).astype(np.float32)
+    if key.startswith("loss.discriminator."):
+        return det_param("disc." + key[len("loss.discriminator."):], shape)
+    if key.startswith("loss.perceptual_loss."):
+        return det_lpips_param("lpips." + key[len("loss.perceptual_loss."):], shape)
+    return det_param(key, shape)
+
+
+def train_step_vq_state(k: int, zc: int):
+    """(cluster_size_ema, embed_ema) at the start of the pinned training run: even codes are LIVE (EMA count 3..7: they
+    survive the decay and take the normalised-EMA path), odd codes start at the constructor's zeros (count < 1 after the first
+    update: they take the restart path, quantize2_mask.py:102-105)"""
+    cb = train_step_param("quantize.codebook.weight", (k + 1, zc), k, zc)[:-1]
+    n0 = (5.0 + 2.0 * _rs("train_step.cluster_size_ema").uniform(-1, 1, size=(k,))).astype(np.float32)
+    n0[1::2] = 0.0
+    return n0, (cb * n0[:, None]).astype(np.float32)
+
+
+def half_flat_layout(batch: int, size: int = 256, patch: int = 16, seed: int = 1234, fine_fraction: float = 0.5) -> np.ndarray:
+    """bool [B, size/patch, size/patch]: which patches of half_flat_images(...) are the noise (fine-grain) ones"""
+    g = size // patch
+    n_fine = int(round(g * g * fine_fraction))
+    out = np.zeros((batch, g * g), dtype=bool)
+    for b in range(batch):
+        rs = np.random.RandomState((seed * 1000003 + b) % (2 ** 32))
+        out[b, rs.permutation(g * g)[:n_fine]] = True
+    return out.reshape(batch, g, g)
+
+
+def train_step_batches(steps: int, bs: int, size: int = 64):
+    return [half_flat_images(bs, size, seed=7100 + s) for s in range(steps)]
+
+
+def train_step_restart_perm(step: int, bs: int, k: int, size: int = 64) -> np.ndarray:
+    """the permutation injected for torch.randperm(N) in the EMA updates of step `step` of the pinned run (quantize2_mask.py:97;
+    N = bs * (size/8)^2 rows of the fine grid).  A coarse cell contributes FOUR identical rows (its feature vector is repeated 2x2), so
+    a generic permutation restarts several codes with the same vector; the reference then resolves the resulting exact ties by the
+    rounding noise of its fp32 addmm, which nothing can reproduce.  This permutation's first K entries are pairwise DISTINCT rows
+    (every fine-grain row, one row per coarse cell) in seeded random order; the rest follow.  Any permutation is a legal draw."""
+    fine = half_flat_layout(bs, size, 16, seed=7100 + step)              # [B, g, g] over 16-pixel patches = coarse cells
+    g = fine.shape[1]
+    hw = 2 * g
+    distinct = []
+    for b in range(bs):
+        for i in range(hw):
+            for j in range(hw):
+                if fine[b, i // 2, j // 2] or (i % 2 == 0 and j % 2 == 0):
+                    distinct.append(b * hw * hw + i * hw + j)
+    distinct = np.array(distinct, dtype=np.int64)
+    assert len(distinct) >= k, (len(distinct), k)
+    rs = _rs(f"train_step.restart_perm.{step}")
+    head = distinct[rs.permutation(len(distinct))]
+    rest = np.setdiff1d(np.arange(bs * hw * hw, dtype=np.int64), head)
+    return np.concatenate([head, rest[rs.permutation(len(rest))]])
+
+
+def apply_train_step_state(model, k: int, zc: int):
+    """write the pinned run's start state into a stage-1 model (the reference's class or this repo's -- same parameter names):
+    every parameter by name, the VQ EMA buffers; BatchNorm / ScalingLayer buffers keep their constructor values"""
+    import torch
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(torch.from_numpy(train_step_param(name, tuple(p.shape), k, zc)).to(p.device))
+        n0, s0 = train_step_vq_state(k, zc)
+        cbm = model.quantize.codebook
+        cbm.cluster_size_ema.copy_(torch.from_numpy(n0).to(cbm.cluster_size_ema.device))
+        cbm.embed_ema.copy_(torch.from_numpy(s0).to(cbm.embed_ema.device))

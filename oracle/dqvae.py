@@ -117,7 +117,7 @@ def encoder_dual(sd, x, x_entropy, threshold, prefix="encoder"):
     up = lambda t: t.repeat_interleave(2, dim=-1).repeat_interleave(2, dim=-2)
     idx_rep = up(indices).unsqueeze(1)
     h_dual = torch.where(idx_rep == 0, up(hc), hf)
-    mask = torch.where(idx_rep == 0, torch.tensor(0.25), torch.tensor(1.0))
+    mask = torch.where(idx_rep == 0, torch.tensor(0.25), torch.tensor(1.0)).to(hf.dtype)
     return {"h_dual": h_dual, "indices": indices, "codebook_mask": mask, "gate": gate,
             "h_coarse": hc, "h_fine": hf}
 
@@ -128,7 +128,7 @@ def position_bias(sd, latent, prefix="decoder"):
     lin = torch.linspace(-1, 1, latent)
     xs = lin.view(1, 1, 1, -1).repeat(1, 1, latent, 1)
     ys = lin.view(1, 1, -1, 1).repeat(1, 1, 1, latent)
-    coord = torch.cat([xs, ys], dim=1)
+    coord = torch.cat([xs, ys], dim=1).to(sd[prefix + ".position_bias_fourier.lff.ffm.conv.weight"].dtype)
     four = torch.sin(conv(sd, prefix + ".position_bias_fourier.lff.ffm.conv", coord))
     col = sd[prefix + ".position_bias_learned.col_embed.weight"][:latent]          # [w, C]
     row = sd[prefix + ".position_bias_learned.row_embed.weight"][:latent]          # [h, C]

@@ -72,8 +72,8 @@ def vgg16_taps(sd, x, prefix="net."):
 
 def lpips(sd, x, xrec, prefix=""):
     """-> [B,1,1,1]"""
-    shift = torch.tensor(LPIPS_SHIFT)[None, :, None, None]
-    scale = torch.tensor(LPIPS_SCALE)[None, :, None, None]
+    shift = torch.tensor(LPIPS_SHIFT, dtype=x.dtype)[None, :, None, None]
+    scale = torch.tensor(LPIPS_SCALE, dtype=x.dtype)[None, :, None, None]
     t0 = vgg16_taps(sd, (x - shift) / scale, prefix + "net.")
     t1 = vgg16_taps(sd, (xrec - shift) / scale, prefix + "net.")
     val = 0
@@ -91,9 +91,10 @@ def hinge_d(lr, lf):
 
 
 def generator_loss(sd_disc, sd_lpips, x, xrec, qloss, last_layer, perceptual_weight=1.0, disc_factor=1.0,
-                   disc_weight=1.0, disc_weight_max=None, codebook_weight=1.0, n_layers=3):
+                   disc_weight=1.0, disc_weight_max=None, codebook_weight=1.0, n_layers=3, running=None):
     """optimizer_idx == 0 branch (vqperceptual_multidisc.py:109-153).  xrec must be a function of `last_layer`
-    (a leaf requiring grad).  Returns dict(loss, nll, p, g, d_weight)."""
+    (a leaf requiring grad).  Returns dict(loss, nll, p, g, d_weight, rec_mean).  `running`: optional dict receiving the
+    BatchNorm running statistics this training-mode discriminator pass leaves (oracle.losses.patchgan)."""
     rec = torch.abs(x - xrec)
     if perceptual_weight > 0:
         p = lpips(sd_lpips, x, xrec)
@@ -101,7 +102,7 @@ def generator_loss(sd_disc, sd_lpips, x, xrec, qloss, last_layer, perceptual_wei
     else:
         p = torch.zeros(1)
     nll = rec.mean()
-    logits_fake = patchgan(sd_disc, xrec, n_layers)
+    logits_fake = patchgan(sd_disc, xrec, n_layers, running=running)
     g = -logits_fake.mean()
     ng = torch.autograd.grad(nll, last_layer, retain_graph=True)[0]
     gg = torch.autograd.grad(g, last_layer, retain_graph=True)[0]
@@ -109,7 +110,7 @@ def generator_loss(sd_disc, sd_lpips, x, xrec, qloss, last_layer, perceptual_wei
     if disc_weight_max is not None:
         dw = dw.clamp(max=disc_weight_max)
     loss = nll + dw * disc_factor * g + codebook_weight * qloss.mean()
-    return {"loss": loss, "nll": nll, "p": p, "g": g, "d_weight": dw}
+    return {"loss": loss, "nll": nll, "p": p, "g": g, "d_weight": dw, "rec_mean": rec.detach().mean()}
 
 
 def discriminator_loss(sd_disc, x, xrec, disc_factor=1.0, n_layers=3, running=None):

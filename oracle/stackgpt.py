@@ -45,14 +45,20 @@ def forward(sd, n_head, coarse_content, fine_content, coarse_position, fine_posi
             coarse_position_target=None, fine_position_target=None, content_pad=1024, cpos_pad=256, fpos_pad=1024):
     lc = coarse_position.size(1)
     content = torch.cat([coarse_content, fine_content], dim=1)
-    x = sd["content_emb.weight"][content[:, :-1]]
-    pos = torch.cat([sd["content_coarse_pos_emb.weight"][coarse_position], sd["content_fine_pos_emb.weight"][fine_position[:, :-1]]], dim=1)
+    # nn.Embedding(padding_idx = the pad code) (stackgpt.py:141-144): same lookup, but the pad row receives NO gradient
+    def table(name, pad):
+        w = sd[name]
+        return lambda idx: F.embedding(idx, w, padding_idx=pad if pad is not None and 0 <= pad < w.shape[0] else None)
+    emb_c, emb_cp, emb_fp = table("content_emb.weight", content_pad), table("content_coarse_pos_emb.weight", cpos_pad), table(
+        "content_fine_pos_emb.weight", fpos_pad)
+    x = emb_c(content[:, :-1])
+    pos = torch.cat([emb_cp(coarse_position), emb_fp(fine_position[:, :-1])], dim=1)
     t = pos.shape[1]
     x = x + pos + sd["pos_emb"][:, :t, :]
     if "seg_emb.weight" in sd:
         x = x + sd["seg_emb.weight"][torch.cat([coarse_seg, fine_seg], dim=1)[:, :-1]]
     ph = _stack(sd, "position_transformer", x, n_head)
-    upd = torch.cat([sd["content_coarse_pos_emb.weight"][coarse_position[:, 1:]], sd["content_fine_pos_emb.weight"][fine_position]], dim=1)
+    upd = torch.cat([emb_cp(coarse_position[:, 1:]), emb_fp(fine_position)], dim=1)
     ch = _stack(sd, "content_transformer", ph + upd, n_head)
     cl, pl = _head(sd, "content_head", ch), _head(sd, "position_head", ph)
     if content_target is None:

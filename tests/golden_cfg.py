@@ -39,3 +39,53 @@ def dualformer_cfg(kind, json_path="scripts/tools/thresholds/entropy_thresholds_
             fine_seg_sos=1)))
     return dict(transformer_config=dict(target="modules.dynamic_modules.stackgpt.StackGPT", params=gpt), first_stage_config=fs,
                 permuter_config=perm, content_loss_weight=1.0, position_loss_weight=0.7, weight_decay=0.01, warmup_epochs=0, **cond)
+
+
+# ---- the pinned training step (tests/golden/train_step.npz) ------------------------------------------------------------
+# geometry names = synth.DQVAE_GEOM; bs is chosen so that one batch gives 2K rows (K = 512 / 1024): the restart path then takes
+# `vectors[randperm][:K]` without quantize2_mask.py:57-64's rand_like noise (which no fixture could pin), and the injected
+# permutation can pick K pairwise distinct rows (synth.train_step_restart_perm).
+# `small`: 3 steps under a 1-step linear warm-up (step 0 runs at lr = 0: moments and EMA move, parameters must not), then cosine decay
+# towards min_lr; `c1`: BASELINE config 1's full-width model, 2 steps (the lr = 0 warm-up step, then one real step).
+# lr = 2e-5: at 1e-4 the third step is chaotic -- Adam's first updates are sign-like (+-lr whatever |g|), entries with rounding-level
+# gradients flip, and the next forward then differs by enough to flip codes with fp64 gaps > 1e-4 in ANY fp32 implementation.
+TRAIN_STEP = {
+    "small": dict(geom="small", bs=16, steps=3, lr=2e-5, min_lr=2e-6, warmup_epochs=0.1, steps_per_epoch=10, training_steps=50, ndf=16),
+    "c1": dict(geom="c1", bs=32, steps=2, lr=2e-5, min_lr=0.0, warmup_epochs=0.1, steps_per_epoch=10, training_steps=50, ndf=32),
+}
+TRAIN_STEP_WATCH = [
+    "encoder.conv_in.weight", "encoder.down.0.block.0.conv1.weight", "encoder.down.3.attn.0.q.weight", "encoder.conv_out_fine.bias",
+    "encoder.conv_out_coarse.weight", "encoder.down.1.block.1.norm2.weight", "quant_conv.weight", "post_quant_conv.bias",
+    "decoder.conv_in.weight", "decoder.conv_out.weight", "decoder.up.1.upsample.conv.weight", "decoder.mid.block_1.norm1.bias",
+    "decoder.position_bias_learned.row_embed.weight", "decoder.norm_out.weight",
+    "loss.discriminator.main.0.weight", "loss.discriminator.main.0.bias", "loss.discriminator.main.5.weight",
+    "loss.discriminator.main.6.weight", "loss.discriminator.main.11.weight", "loss.discriminator.main.11.bias",
+]
+TRAIN_STEP_SAMPLE = 4096          # elements kept per watched tensor (a strided sample of the flattened tensor)
+
+
+def train_step_stride(numel):
+    return max(1, numel // TRAIN_STEP_SAMPLE)
+
+
+def train_step_lossconfig(ndf):
+    """the shipped YAML's lossconfig (configs/stage1/dqvae-entropy-dual-r05_imagenet.yml) with a narrower PatchGAN"""
+    return dict(target="modules.losses.vqperceptual_multidisc.VQLPIPSWithDiscriminator", params=dict(
+        disc_start=0, disc_init=True, disc_conditional=False, disc_loss="hinge", disc_factor=1.0, disc_weight=1.0, disc_weight_max=0.75,
+        codebook_weight=1.0, pixelloss_weight=1.0, perceptual_weight=1.0,
+        disc_config=dict(target="modules.discriminator.model.NLayerDiscriminator",
+                         params=dict(input_nc=3, ndf=ndf, n_layers=3, use_actnorm=False))))
+
+
+# stage 2: Dualformer (uncond) over the frozen small DQ-VAE, AdamW(betas .9/.95) with the decay / no-decay groups of
+# dqtransformer_uncond_entropy.py:92-143; one warm-up step at lr 0, then two steps on the cosine schedule; ragged 3-image batches
+TRAIN_STEP_S2 = dict(steps=3, lr=1e-3, min_lr=1e-4, warmup_epochs=0.1, steps_per_epoch=10, training_steps=40, weight_decay=0.01)
+TRAIN_STEP_S2_WATCH = ["content_emb.weight", "content_coarse_pos_emb.weight", "pos_emb", "seg_emb.weight",
+                       "position_transformer.0.attn.key.weight", "position_transformer.0.attn.query.bias", "position_transformer.1.mlp.0.weight",
+                       "content_transformer.1.attn.proj.weight", "content_transformer.0.ln1.weight", "content_transformer.0.ln1.bias",
+                       "position_head.1.weight", "content_head.1.weight"]
+
+
+def train_step_s2_batch(step):
+    from dynamicvectorquantization_amd import synth
+    return synth.ragged_grain_images(64, seed=131 + 10 * step)

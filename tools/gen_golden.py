@@ -1020,9 +1020,207 @@ def gen_ckpt_layout():
     np.savez_compressed(os.path.join(GOLD, "ckpt_layout.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------
+def _sample(tn, stride=None):
+    a = tn.detach().reshape(-1).numpy()
+    from golden_cfg import train_step_stride
+    return a[:: (stride or train_step_stride(a.size))].astype(np.float32).copy()
+
+
+def run_reference_train_steps(tag):
+    """Drive the REFERENCE DualGrainVQModel through Lightning's automatic-optimization order for two optimizers, by hand
+    (pytorch_lightning is not installed; its loop for this module is: per batch, per optimizer i: toggle_optimizer(i) ->
+    training_step(batch, idx, i) -> zero_grad -> backward -> optimizer.step(); then every `interval: step` scheduler steps;
+    then global_step += 1).  dqvae_dual_entropy.py:154-183 (training_step), :206-231 (configure_optimizers).
+    torch.randperm is replaced by the injected permutation for the EMA restart (quantize2_mask.py:97); LPIPS stays in eval mode
+    (NetLinLayer dropout off, oracle/losses.py header).  Returns {key: np.ndarray} -- the fixture's content."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from golden_cfg import TRAIN_STEP, TRAIN_STEP_WATCH, train_step_lossconfig
+    from models.stage1_dynamic.dqvae_dual_entropy import DualGrainVQModel
+    c = TRAIN_STEP[tag]
+    g = synth.DQVAE_GEOM[c["geom"]]
+    k, zc = g["k"], g["zc"]
+    torch.manual_seed(0)
+    model = build_dqvae(**g)
+    cfg_loss = train_step_lossconfig(c["ndf"])
+    from utils.utils import instantiate_from_config
+    model.loss = instantiate_from_config(cfg_loss)
+    synth.apply_train_step_state(model, k, zc)
+    model.learning_rate, model.min_learning_rate = c["lr"], c["min_lr"]
+    model.warmup_epochs, model.steps_per_epoch, model.training_steps = c["warmup_epochs"], c["steps_per_epoch"], c["training_steps"]
+    model.current_epoch, model.global_step = 0, 0
+    logged = {}
+    model.log = lambda name, value, **kw: logged.__setitem__(name, float(value))
+    model.log_dict = lambda d, **kw: logged.update({kk: float(v) for kk, v in d.items()})
+    model.train()
+    model.loss.perceptual_loss.eval()
+    opts, scheds = model.configure_optimizers()
+    n_rows = c["bs"] * g["latent"] ** 2
+    assert n_rows >= k, (n_rows, k)
+    perm = [None]
+    orig_randperm = torch.randperm
+    torch.randperm = lambda m, device=None, **kw: t(perm[0].copy()) if m == n_rows else orig_randperm(m, **kw)
+    out = {}
+    params = dict(model.named_parameters())
+    cbm = model.quantize.codebook
+    # the reference's own VQ inputs per forward: codes, and the fp64 top-2 gap to judge near ties
+    vq_in = []
+    hook = cbm.register_forward_hook(lambda m, inp, outp: vq_in.append((inp[0].detach().reshape(-1, zc).numpy().copy(), outp[1].reshape(-1).numpy().copy())))
+    try:
+        for step, xb in enumerate(synth.train_step_batches(c["steps"], c["bs"], g["resolution"])):
+            batch = {"image": t(xb)}
+            perm[0] = synth.train_step_restart_perm(step, c["bs"], k, g["resolution"])
+            for oi, opt in enumerate(opts):
+                owned = {id(p) for grp in opt.param_groups for p in grp["params"]}
+                saved = {n_: p.requires_grad for n_, p in params.items()}
+                for n_, p in params.items():           # LightningModule.toggle_optimizer
+                    if id(p) not in owned:
+                        p.requires_grad_(False)
+                out[f"s{step}.o{oi}.lr"] = np.float64(opt.param_groups[0]["lr"])
+                w_before = cbm.weight.detach().numpy()[:-1].copy()
+                loss = model.training_step(batch, step, oi)
+                opt.zero_grad()
+                loss.backward()
+                if step == 0:
+                    for n_ in TRAIN_STEP_WATCH:
+                        if params[n_].grad is not None:
+                            out[f"s0.grad.{n_}"] = _sample(params[n_].grad)
+                opt.step()
+                for n_, p in params.items():           # untoggle_optimizer
+                    p.requires_grad_(saved[n_])
+                pre = f"s{step}.o{oi}."
+                out[pre + "loss"] = np.float32(loss.item())
+                x_in, codes = vq_in.pop()
+                assert not vq_in
+                _, gap = ovq.argmin_exact(x_in, w_before, return_gap=True)
+                out[pre + "codes"] = codes.astype(np.int16)
+                out[pre + "gap"] = gap.astype(np.float32)
+                out[pre + "cluster_size_ema"] = cbm.cluster_size_ema.numpy().copy()
+                out[pre + "embed_ema"] = cbm.embed_ema.numpy()[:: k // 64].copy()          # 64 rows of K
+                out[pre + "codebook"] = cbm.weight.detach().numpy()[:-1][:: k // 64].copy()
+            for k_, v_ in logged.items():
+                out[f"s{step}.log.{k_}"] = np.float32(v_)
+            for sc in scheds:
+                sc["scheduler"].step()
+            model.global_step += 1
+            for n_ in TRAIN_STEP_WATCH:
+                out[f"s{step}.param.{n_}"] = _sample(params[n_])
+                opt = opts[1] if n_.startswith("loss.discriminator.") else opts[0]
+                st = opt.state[params[n_]]
+                out[f"s{step}.exp_avg.{n_}"] = _sample(st["exp_avg"])
+                out[f"s{step}.exp_avg_sq.{n_}"] = _sample(st["exp_avg_sq"])
+                assert int(st["step"]) == step + 1
+    finally:
+        torch.randperm = orig_randperm
+        hook.remove()
+    for n_, b in model.loss.discriminator.named_buffers():
+        out["final.disc_buf." + n_] = b.numpy().copy()
+    sd = model.state_dict()
+    out["state_keys"] = np.array(list(sd.keys()))
+    out["state_shapes"] = np.array([",".join(map(str, sd[kk].shape)) for kk in sd.keys()])
+    out["param_keys"] = np.array([n_ for n_, _ in model.named_parameters()])
+    return out, model
+
+
+def run_reference_dualformer_steps():
+    """the REFERENCE Dualformer (uncond) through Lightning's single-optimizer order: training_step -> zero_grad -> backward ->
+    AdamW.step -> scheduler.step (dqtransformer_uncond_entropy.py:92-143 configure_optimizers, :217-234 training_step)"""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from golden_cfg import TRAIN_STEP_S2, TRAIN_STEP_S2_WATCH, dualformer_cfg, train_step_s2_batch
+    from models.stage2_dynamic.dqtransformer_uncond_entropy import Dualformer
+    from test_oracle_golden import dqvae_state_dict
+    c = TRAIN_STEP_S2
+    g_small = np.load(os.path.join(GOLD, "dqvae_small.npz"), allow_pickle=False)
+    cfg = dualformer_cfg("uncond")
+    cfg["weight_decay"], cfg["warmup_epochs"] = c["weight_decay"], c["warmup_epochs"]
+    model = Dualformer(**cfg)
+    model.first_stage_model.load_state_dict(dqvae_state_dict(g_small, "spread", 512, 64))
+    with torch.no_grad():
+        for n_, p in model.transformer.named_parameters():
+            v = synth.det_param("dualformer.uncond." + n_, p.shape)
+            p.copy_(t(v * (0.3 if n_ == "pos_emb" else 1.0)))
+    model.learning_rate, model.min_learning_rate = c["lr"], c["min_lr"]
+    model.steps_per_epoch, model.training_steps = c["steps_per_epoch"], c["training_steps"]
+    model.train()
+    logged = {}
+    model.log = lambda name, value, **kw: logged.__setitem__(name, float(value))
+    (opt,), (sched,) = model.configure_optimizers()
+    params = dict(model.transformer.named_parameters())
+    group_of = {id(p): gi for gi, grp in enumerate(opt.param_groups) for p in grp["params"]}
+    out = {"decay_names": np.array(sorted(n_ for n_, p in params.items() if group_of[id(p)] == 0))}
+    assert opt.param_groups[0]["weight_decay"] == c["weight_decay"] and opt.param_groups[1]["weight_decay"] == 0.0
+    for step in range(c["steps"]):
+        batch = {"image": t(train_step_s2_batch(step))}
+        out[f"s{step}.lr"] = np.float64(opt.param_groups[0]["lr"])
+        loss = model.training_step(batch, step)
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            for n_ in TRAIN_STEP_S2_WATCH:
+                out[f"s0.grad.{n_}"] = _sample(params[n_].grad)
+        opt.step()
+        sched["scheduler"].step()
+        out[f"s{step}.loss"] = np.float32(loss.item())
+        for k_, v_ in logged.items():
+            out[f"s{step}.log.{k_}"] = np.float32(v_)
+        for n_ in TRAIN_STEP_S2_WATCH:
+            st = opt.state[params[n_]]
+            out[f"s{step}.param.{n_}"] = _sample(params[n_])
+            out[f"s{step}.exp_avg.{n_}"] = _sample(st["exp_avg"])
+            out[f"s{step}.exp_avg_sq.{n_}"] = _sample(st["exp_avg_sq"])
+    assert all(p.grad is None for p in model.first_stage_model.parameters())
+    sd = model.state_dict()
+    out["state_keys"] = np.array(list(sd.keys()))
+    out["state_shapes"] = np.array([",".join(map(str, sd[kk].shape)) for kk in sd.keys()])
+    return out
+
+
+def gen_train_step():
+    """tests/golden/train_step_{small,c1}.npz: the reference's complete two-optimizer training step, several steps in a row"""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from golden_cfg import TRAIN_STEP
+    from oracle import train_step as ots
+    for tag in TRAIN_STEP:
+        out, _ = run_reference_train_steps(tag)
+        c = TRAIN_STEP[tag]
+        for step in range(c["steps"]):
+            print(f"  train_step {tag} step {step}: lr {out[f's{step}.o0.lr']:.3e} aeloss {out[f's{step}.o0.loss']:.6f} discloss {out[f's{step}.o1.loss']:.6f} "
+                  f"d_weight {out[f's{step}.log.train_d_weight']:.4f} min gap {min(out[f's{step}.o0.gap'].min(), out[f's{step}.o1.gap'].min()):.2e} "
+                  f"restarted {int((out[f's{step}.o0.cluster_size_ema'] == 1).sum())}/{int((out[f's{step}.o1.cluster_size_ema'] == 1).sum())}")
+        meta = {kk: out[kk] for kk in ("state_keys", "state_shapes", "param_keys")}
+        g = synth.DQVAE_GEOM[c["geom"]]
+        o = ots.reference_schedule_steps(tag, meta)
+        missing = [kk for kk in out if kk not in o and not kk.startswith(("state_", "param_keys"))]
+        assert not missing, missing
+        from golden_cfg import train_step_stride
+        summ = ots.summarize(ots.compare_records(o, out, start_param=ots.sampled_start_param(meta, g["k"], g["zc"], train_step_stride)))
+        for (step, grp), err in sorted(summ.items()):
+            if not grp.startswith("scalar:train_"):
+                print(f"  pin train_step.{tag}.{step}.{grp:24s} err={err:.3e}")
+        bad = ots.check_summary(summ)
+        if bad:
+            raise SystemExit(f"oracle.train_step does not match the reference: {bad}")
+        np.savez_compressed(os.path.join(GOLD, f"train_step_{tag}.npz"), **out)
+    # ---- stage 2 ----
+    from golden_cfg import TRAIN_STEP_S2
+    out = run_reference_dualformer_steps()
+    for step in range(TRAIN_STEP_S2["steps"]):
+        print(f"  train_step dualformer step {step}: lr {out[f's{step}.lr']:.3e} loss {out[f's{step}.loss']:.6f}")
+    o = ots.dualformer_schedule_steps(out)
+    missing = [kk for kk in out if kk not in o and not kk.startswith(("state_", "decay_names"))]
+    assert not missing, missing
+    summ = ots.summarize(ots.compare_records(o, out, start_param=ots.dualformer_start_param(out)))
+    for (step, grp), err in sorted(summ.items()):
+        print(f"  pin train_step.dualformer.{step}.{grp:24s} err={err:.3e}")
+    bad = ots.check_summary(summ, ots.PIN_BOUNDS_S2)
+    if bad:
+        raise SystemExit(f"oracle.train_step (stage 2) does not match the reference: {bad}")
+    np.savez_compressed(os.path.join(GOLD, "train_step_dualformer.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter,stackgpt,sampler,dualformer,ckpt_layout,vq_distances,options")
+    ap.add_argument("--only", default="vq,entropy,blocks,dqvae,losses,lossnet,featrouted,permuter,stackgpt,sampler,dualformer,ckpt_layout,vq_distances,options,train_step")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -1030,7 +1228,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for name in args.only.split(","):
         print(f"[gen] {name}")
-        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter, "stackgpt": gen_stackgpt, "sampler": gen_sampler, "dualformer": gen_dualformer, "ckpt_layout": gen_ckpt_layout, "vq_distances": gen_vq_distances, "options": gen_options}[name]()
+        {"vq": gen_vq, "entropy": gen_entropy, "blocks": gen_blocks, "dqvae": gen_dqvae, "losses": gen_losses, "lossnet": gen_lossnet, "featrouted": gen_featrouted, "permuter": gen_permuter, "stackgpt": gen_stackgpt, "sampler": gen_sampler, "dualformer": gen_dualformer, "ckpt_layout": gen_ckpt_layout, "vq_distances": gen_vq_distances, "options": gen_options, "train_step": gen_train_step}[name]()
     print("done ->", GOLD)
 
 
