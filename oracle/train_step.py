@@ -261,15 +261,27 @@ def compare_records(got, ref, start_param=None, skip=()):
     the fixture: the reference's LPIPS / GAN parameter gradients differ from an fp64 evaluation of the same graph by 0.4 - 0.5 % of
     the tensor's max, its L1 / codebook-loss gradients by 1.5e-5)."""
     res = {}
+    # "late" forwards = those that run after the first autoencoder update with lr > 0: from there on the two runs no longer start from
+    # bit-identical parameters (Adam's sign-level differences), so code flips at small gaps and their EMA consequences are expected
+    first_real = min([int(k.split(".")[0][1:]) for k in ref if k.endswith(".o0.lr") and float(ref[k]) > 0] or [1 << 30])
+
+    def late(key):
+        parts = key.split(".")
+        if not (parts[0][0] == "s" and parts[0][1:].isdigit() and len(parts) > 1 and parts[1] in ("o0", "o1")):
+            return False
+        st, oi = int(parts[0][1:]), int(parts[1][1:])
+        return (st, oi) > (first_real, 0)
+
     for key in ref:
-        if key in skip or key not in got or key.startswith(("state_", "param_keys")) or key.endswith(".gap"):
+        if key in skip or key not in got or key.startswith(("state_", "param_keys", "decay_names")) or key.endswith(".gap"):
             continue
         a, b = np.asarray(got[key]), np.asarray(ref[key])
+        sfx = "_late" if late(key) else ""
         if key.endswith(".codes"):
             gap = np.asarray(ref[key[:-len("codes")] + "gap"])
             bad = a.reshape(-1) != b.reshape(-1)
-            res[key] = ("codes", int((bad & (gap >= 1e-4)).sum()))
-            res[key + "_near"] = ("codes_near", int((bad & (gap < 1e-4)).sum()))
+            res[key] = ("codes" + sfx, int((bad & (gap >= 1e-4)).sum()))
+            res[key + "_near"] = ("codes_near" + sfx, int((bad & (gap < 1e-4)).sum()))
         elif key.endswith("num_batches_tracked"):
             res[key] = ("scalar", float(abs(int(a) - int(b))))
         elif b.ndim == 0:
@@ -283,7 +295,7 @@ def compare_records(got, ref, start_param=None, skip=()):
             else:
                 res[key] = ("dparam", float(np.linalg.norm(da - db) / np.linalg.norm(db)))
         else:
-            res[key] = ("l2", _l2(a, b))
+            res[key] = ("l2" + sfx, _l2(a, b))
     return res
 
 
@@ -293,14 +305,15 @@ def summarize(cmp):
     for key, (kind, err) in cmp.items():
         parts = key.split(".")
         step = parts[0]
+        disc = "_disc" if ".loss.discriminator." in key else ""          # the discriminator's tensors: see PIN_BOUNDS
         if kind in ("dparam", "dparam0"):
-            grp = kind
+            grp = kind + disc
         elif ".exp_avg_sq." in key:
-            grp = "exp_avg_sq"
+            grp = "exp_avg_sq" + disc
         elif ".exp_avg." in key:
-            grp = "exp_avg"
+            grp = "exp_avg" + disc
         elif ".grad." in key:
-            grp = "grad"
+            grp = "grad" + disc
         elif kind.startswith("codes"):
             grp = kind
         elif step == "final":
@@ -308,7 +321,7 @@ def summarize(cmp):
         elif kind == "scalar":
             grp = "scalar:" + parts[-1]
         else:
-            grp = parts[-1]
+            grp = parts[-1] + ("_late" if kind.endswith("_late") else "")
         out[(step, grp)] = max(out.get((step, grp), 0.0), err)
     return out
 
@@ -316,11 +329,17 @@ def summarize(cmp):
 # worst allowed distance per summarize() group.  "cpu" = this oracle against the reference (both fp32 on the host: summation order
 # only); the GPU levels are set in tests/test_gpu_trainstep.py from measurements on MI355X.
 PIN_BOUNDS = {
-    "codes": 0, "codes_near": 2,
+    "codes": 0, "codes_near": 1, "codes_late": 8, "codes_near_late": 12,
     "cluster_size_ema": 1e-5, "embed_ema": 1e-5, "codebook": 1e-5,
-    "scalar:lr": 1e-12, "scalar:loss": 2e-4, "scalar": 5e-3,
-    "grad": 5e-2, "exp_avg": 5e-2, "exp_avg_sq": 5e-2,
-    "dparam0": 0.0, "dparam": 0.2, "disc_buf": 2e-3,
+    "cluster_size_ema_late": 5e-3, "embed_ema_late": 5e-3, "codebook_late": 5e-3,
+    "scalar:lr": 1e-12, "scalar:loss": 2e-4, "scalar": 5e-3, "s2:scalar:loss": 2e-3, "s2:scalar": 3e-2,
+    # means of signed PatchGAN logits near zero (|mean| ~ 0.1 of values ~ +-1): cancellation
+    "scalar:train_logits_fake": 5e-2, "scalar:train_logits_real": 5e-2, "s2:scalar:train_logits_fake": 5e-2, "s2:scalar:train_logits_real": 5e-2,
+    "grad": 5e-2, "exp_avg": 5e-2, "exp_avg_sq": 5e-2, "s2:exp_avg": 0.15, "s2:exp_avg_sq": 0.15,
+    # the discriminator's hinge gradient is 0.5 * (grad mean D(rec) - grad mean D(x)): a small difference of two large, nearly equal
+    # terms while D cannot tell the two apart, so rounding in D's products is amplified ~1e4 x in ITS parameter gradients
+    "grad_disc": 5e-2, "exp_avg_disc": 5e-2, "exp_avg_sq_disc": 5e-2, "s2:exp_avg_disc": 0.15, "s2:exp_avg_sq_disc": 0.15,
+    "dparam0": 0.0, "dparam": 0.2, "dparam0_disc": 0.0, "dparam_disc": 0.2, "disc_buf": 5e-3,
 }
 
 
@@ -328,7 +347,7 @@ def check_summary(summary, bounds=PIN_BOUNDS):
     """[(step, group, err, bound)] of the groups that exceed their bound"""
     bad = []
     for (step, grp), err in sorted(summary.items()):
-        b = bounds.get(grp, bounds["scalar"] if grp.startswith("scalar:") else None)
+        b = bounds.get(f"{step}:{grp}", bounds.get(grp, bounds["scalar"] if grp.startswith("scalar:") else None))     # "s2:codes_near" overrides "codes_near"
         assert b is not None, grp
         if err > b:
             bad.append((step, grp, err, b))

@@ -59,8 +59,11 @@ TRAIN_STEP_WATCH = [
     "decoder.conv_in.weight", "decoder.conv_out.weight", "decoder.up.1.upsample.conv.weight", "decoder.mid.block_1.norm1.bias",
     "decoder.position_bias_learned.row_embed.weight", "decoder.norm_out.weight",
     "loss.discriminator.main.0.weight", "loss.discriminator.main.0.bias", "loss.discriminator.main.5.weight",
-    "loss.discriminator.main.6.weight", "loss.discriminator.main.11.weight", "loss.discriminator.main.11.bias",
+    "loss.discriminator.main.6.weight", "loss.discriminator.main.8.weight", "loss.discriminator.main.11.weight",
 ]
+# not watched on purpose: parameters whose exact gradient is ZERO at this state (conv biases in front of a normalisation, attention key
+# biases, and the PatchGAN's final bias while every hinge term is active: 0.5 * (-1 + 1)) -- their fp32 gradient is rounding noise and
+# Adam turns its sign into a full +-lr move, in the reference as much as here
 TRAIN_STEP_SAMPLE = 4096          # elements kept per watched tensor (a strided sample of the flattened tensor)
 
 

@@ -129,16 +129,29 @@ def test_dqvae_forward_golden_fp32x3(dev):
         with rt.compute_dtype_ctx("fp32x3"):
             model, g = build(tag, dev, "spread")
             model.eval()
-            with torch.no_grad():
-                rec, qloss, grain, gate, ent = model(x)
+            rec, qloss, grain, gate, ent = model(x)
             assert np.array_equal(grain.cpu().numpy().astype(np.int8), g["spread_grain"])
             codes = model._last["codes"].cpu().numpy().astype(np.int32)
             assert np.array_equal(codes.reshape(-1), g["spread_codes"].reshape(-1)), tag
-            np.testing.assert_allclose(rec.cpu().numpy(), g["spread_rec"], rtol=1e-3, atol=1e-3)
+            np.testing.assert_allclose(rec.detach().cpu().numpy(), g["spread_rec"], rtol=1e-3, atol=1e-3)
             np.testing.assert_allclose(qloss.item(), g["spread_qloss"], rtol=1e-3)
-            err = float(np.linalg.norm(rec.cpu().numpy() - g["spread_rec"]) / np.linalg.norm(g["spread_rec"]))
+            err = float(np.linalg.norm(rec.detach().cpu().numpy() - g["spread_rec"]) / np.linalg.norm(g["spread_rec"]))
             _report("fp32x3_recon_rel_err", tag=tag, err=err)
             assert err < 1e-3, (tag, err)
+            # the backward of the same mode against the reference's parameter gradients (the `grad.*` entries the fp32 test uses)
+            gout = torch.from_numpy(synth.det_param(f"dqvae.{tag}.gout", tuple(rec.shape))).to(dev)
+            ((rec * gout).sum() / rec.numel() * 100.0 + qloss).backward()
+            params = dict(model.named_parameters())
+            worst = 0.0
+            for key in [k for k in g.files if k.startswith("grad.")]:
+                got = params[key[5:]].grad.cpu().numpy()
+                ref = g[key]
+                if got.size != ref.size:
+                    got = got.reshape(-1)[:: max(1, got.size // 20000)]
+                e = float(np.abs(got.reshape(ref.shape) - ref).max()) / max(1e-9, float(np.abs(ref).max()))
+                worst = max(worst, e)
+                assert e < 5e-3, f"{tag} {key}: rel-to-max grad error {e}"
+            _report("fp32x3_grad_rel_to_max", tag=tag, worst=worst)
     assert not rt.fp32_split()
 
 

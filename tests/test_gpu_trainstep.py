@@ -94,16 +94,21 @@ def run_hip_train_steps(tag, dev, mode, use_graph=False):
     return out
 
 
-# worst allowed distance per group (oracle/train_step.py::summarize), measured on MI355X and recorded in gpurun_out/test_reports.jsonl;
-# the oracle's own distance to the reference (both fp32 on the host) is in oracle.train_step.PIN_BOUNDS for comparison
-GPU_BOUNDS = {
-    "fp32": {"codes": 0, "codes_near": 2, "cluster_size_ema": 1e-4, "embed_ema": 1e-4, "codebook": 1e-4,
-             "scalar:lr": 1e-12, "scalar:loss": 1e-3, "scalar": 1e-2,
-             "grad": 5e-2, "exp_avg": 5e-2, "exp_avg_sq": 8e-2, "dparam0": 0.0, "dparam": 0.25, "disc_buf": 5e-3},
-    "fp32x3": {"codes": 0, "codes_near": 2, "cluster_size_ema": 1e-4, "embed_ema": 1e-4, "codebook": 1e-4,
-               "scalar:lr": 1e-12, "scalar:loss": 1e-3, "scalar": 1e-2,
-               "grad": 5e-2, "exp_avg": 5e-2, "exp_avg_sq": 8e-2, "dparam0": 0.0, "dparam": 0.25, "disc_buf": 5e-3},
-}
+# worst allowed distance per group (oracle/train_step.py::summarize), from measurements on MI355X (gpurun_out/test_reports.jsonl, kept in
+# profiles/r06_train_step_parity.txt); the oracle's own distance to the reference (both fp32 on the host) is oracle.train_step.PIN_BOUNDS.
+# Steps 0 and 1 start from bit-identical parameters (step 0 runs at lr 0), so they are held to rounding level; step 2 starts from
+# parameters that already carry Adam's sign-level differences (`dparam` of step 1) and may flip a few codes whose fp64 top-2 gap is < 1e-4.
+def _bounds(mode):
+    from oracle.train_step import PIN_BOUNDS
+    b = dict(PIN_BOUNDS)                # fp32 (exact fp32 matrix instructions): the same bounds the host oracle is pinned with
+    if mode == "fp32x3":                # products at ~2^-17: rounding-level near ties may flip from the first forward on, and the
+        #                                 ill-conditioned discriminator gradients (PIN_BOUNDS) carry ~10 % (measured 0.11 / 0.18)
+        b.update({"codes_near": 2, "cluster_size_ema": 1e-3, "scalar:loss": 1e-3, "scalar": 3e-2,
+                  "scalar:train_logits_fake": 0.3, "scalar:train_logits_real": 0.3, "s2:scalar:train_logits_fake": 0.3, "s2:scalar:train_logits_real": 0.3,
+                  "grad": 0.1, "exp_avg": 0.1, "exp_avg_sq": 0.1, "s2:exp_avg": 0.2, "s2:exp_avg_sq": 0.2,
+                  "grad_disc": 0.25, "exp_avg_disc": 0.25, "exp_avg_sq_disc": 0.35, "s2:exp_avg_disc": 0.35, "s2:exp_avg_sq_disc": 0.35,
+                  "dparam_disc": 0.35})
+    return b
 
 
 @pytest.mark.parametrize("mode", ["fp32", "fp32x3"])
@@ -118,9 +123,11 @@ def test_train_step_golden(dev, tag, mode):
     got = run_hip_train_steps(tag, dev, mode)
     missing = [k_ for k_ in ref if k_ not in got and not k_.startswith(("state_", "param_keys")) and not k_.endswith(".gap")]
     assert not missing, missing
-    summ = ots.summarize(ots.compare_records(got, ref, start_param=ots.sampled_start_param(meta, geom["k"], geom["zc"], train_step_stride)))
+    cmp = ots.compare_records(got, ref, start_param=ots.sampled_start_param(meta, geom["k"], geom["zc"], train_step_stride))
+    summ = ots.summarize(cmp)
     _report("train_step_golden", tag=tag, mode=mode, **{f"{s}.{grp}": float(e) for (s, grp), e in sorted(summ.items())})
-    bad = ots.check_summary(summ, GPU_BOUNDS[mode])
+    _report("train_step_golden_keys", tag=tag, mode=mode, **{k_: float(e) for k_, (_, e) in sorted(cmp.items()) if ".log." not in k_})
+    bad = ots.check_summary(summ, _bounds(mode))
     assert not bad, bad
 
 
@@ -217,8 +224,9 @@ def test_hip_adam_matches_torch_optim(dev, kind):
 # ---- stage 2: Dualformer + AdamW --------------------------------------------------------------------------------------------------
 S2_BOUNDS = {
     # fp32 = exact fp32 matrix instructions; fp32x3 = three bf16 MFMA passes on split operands (~2^-17 per product)
-    "fp32": {"scalar:lr": 1e-12, "scalar:loss": 1e-4, "scalar": 1e-3, "grad": 5e-3, "exp_avg": 5e-3, "exp_avg_sq": 1e-2, "dparam0": 0.0, "dparam": 2e-2},
-    "fp32x3": {"scalar:lr": 1e-12, "scalar:loss": 2e-4, "scalar": 1e-3, "grad": 8e-3, "exp_avg": 8e-3, "exp_avg_sq": 1.6e-2, "dparam0": 0.0, "dparam": 3e-2},
+    # measured on MI355X: fp32 4.7e-7 / 7.0e-7 / 2.1e-6 (grad / exp_avg_sq / dparam), fp32x3 1.2e-5 / 1.7e-5 / 4.4e-5
+    "fp32": {"scalar:lr": 1e-12, "scalar:loss": 1e-5, "scalar": 1e-5, "grad": 1e-5, "exp_avg": 1e-5, "exp_avg_sq": 2e-5, "dparam0": 0.0, "dparam": 5e-5},
+    "fp32x3": {"scalar:lr": 1e-12, "scalar:loss": 1e-5, "scalar": 2e-5, "grad": 1e-4, "exp_avg": 1e-4, "exp_avg_sq": 2e-4, "dparam0": 0.0, "dparam": 5e-4},
 }
 
 
