@@ -3020,6 +3020,7 @@ int dvq_conv2d_fwd_x3(const dvq_conv_desc* d, const void* x, const void* w, cons
     if (int e = conv_check(d, "dvq_conv2d_fwd_x3")) return e;
     DVQ_REQUIRE(x && w && y && scratch, DVQ_EINVAL, "dvq_conv2d_fwd_x3: null pointer");
     DVQ_REQUIRE(dvq_conv3x3_x3_ok(d, 0), DVQ_ESHAPE, "dvq_conv2d_fwd_x3: shape not eligible (dvq_conv3x3_x3_ok)");
+    DVQ_REQUIRE(act == DVQ_ACT_NONE || act == DVQ_ACT_RELU || act == DVQ_ACT_LRELU, DVQ_EINVAL, "dvq_conv2d_fwd_x3: bad act");
     DVQ_REQUIRE(act == DVQ_ACT_NONE || residual == nullptr, DVQ_EINVAL, "dvq_conv2d_fwd_x3: activation and residual together");
     DVQ_REQUIRE(scratch_bytes >= dvq_conv3x3_x3_scratch_bytes(d, 0) && ((uintptr_t)scratch & 15) == 0, DVQ_EWORKSPACE,
                 "dvq_conv2d_fwd_x3: scratch too small (dvq_conv3x3_x3_scratch_bytes) or not 16-B aligned");

@@ -421,7 +421,8 @@ __global__ __launch_bounds__(256) void linear_pack_multi_kernel(const LinPackEnt
         const int r = rr + 16 * i, row = r0 + r, col = c0 + 4 * q;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (row < t.out) {
-            if (col + 3 < t.in && (t.in & 3) == 0) {
+            // the fp32 master is a view into the flat parameter buffer at an unpadded offset: 16-B loads only when it is aligned
+            if (col + 3 < t.in && (t.in & 3) == 0 && (reinterpret_cast<uintptr_t>(t.master) & 15) == 0) {
                 const float4 f = *reinterpret_cast<const float4*>(t.master + (int64_t)row * t.in + col);
                 v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
             } else {

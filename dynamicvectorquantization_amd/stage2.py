@@ -549,7 +549,9 @@ class _SamplerMixin:
         sampling scripts draw hundreds of batches anyway.  Each lane is a host thread (the per-iteration host read-back releases the
         GIL, so the lanes ping-pong); the first batch of every lane runs ALONE (it captures that lane's graphs: stream capture
         must not see another thread's launches).  Returns the results in the order of `conds`.  Greedy draws equal the sequential
-        sampler's token for token; multinomial draws use one generator stream per lane."""
+        sampler's token for token; multinomial draws use one generator stream per lane.  The assignment is STATIC -- batch i runs
+        on lane i % n_streams, each lane takes its batches in order -- so a fixed (seed, n_streams) reproduces the same samples run
+        to run whatever the thread timing."""
         import threading
         n = len(conds)
         n_streams = max(1, min(int(n_streams), n))
@@ -577,7 +579,7 @@ class _SamplerMixin:
 
         for s in streams:
             s.wait_stream(main)
-        todo = list(range(n))
+        queues = [list(range(lane, n, n_streams)) for lane in range(n_streams)]
         b0 = int(conds[0][0].size(0))
         rows = self.hw1 * self.hw1 + self.fine_hw * self.fine_hw + 8
 
@@ -588,19 +590,16 @@ class _SamplerMixin:
                     (not st.use_graph or any(e.get("graph") is not None for e in st._steps.values())))
 
         for lane in range(n_streams):                   # graphs of a lane that has not sampled this geometry yet: alone
-            if todo and not lane_is_warm(lane):
-                run(todo.pop(0), lane)
+            if queues[lane] and not lane_is_warm(lane):
+                run(queues[lane].pop(0), lane)
                 streams[lane].synchronize()
         if errors:
             raise errors[0]
-        lock = threading.Lock()
 
         def worker(lane):
-            while True:
-                with lock:
-                    if not todo or errors:
-                        return
-                    i = todo.pop(0)
+            for i in queues[lane]:
+                if errors:
+                    return
                 run(i, lane)
 
         threads = [threading.Thread(target=worker, args=(lane,), daemon=True) for lane in range(n_streams)]

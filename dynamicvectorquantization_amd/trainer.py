@@ -331,6 +331,10 @@ def broadcast_model(model, src=0):
         return
     for _, t in _replicated_tensors(model):
         dist.broadcast(t, src)
+    from .layers import ActNorm
+    for m in model.modules():
+        if isinstance(m, ActNorm):
+            m._inited = None               # the `initialized` buffer was just overwritten in place: re-read it, do not trust the host mirror
     rt.bump_weights_epoch()
 
 

@@ -493,6 +493,16 @@ def test_sample_many_lanes_equal_sequential(dev):
         for cc, fc, cp, fp in outs:
             assert int(cc.max()) <= 513 and int(fc.max()) <= 513 and int(fp.max()) <= 65 and int(cp.max()) <= 17
         torch.cuda.synchronize()
+        # a fixed seed reproduces the multinomial samples run to run: batch i always runs on lane i % n_streams, in order, so the
+        # per-lane generator streams see the same batches whatever the thread timing (restart the streams = a fresh process)
+        draws = []
+        for _ in range(3):
+            model.__dict__.pop("_sampler_lane_states", None)
+            o = model.sample_many(conds, n_streams=2, sample=True, top_k=20, top_k_pos=10, process=False, fix_fine_position=False)
+            draws.append([[t.cpu() for t in b] for b in o])
+        for other in draws[1:]:
+            for a, b in zip(draws[0], other):
+                assert all(torch.equal(x_, y_) for x_, y_ in zip(a, b))
 
 
 def test_sampling_script_end_to_end(dev, tmp_path):
