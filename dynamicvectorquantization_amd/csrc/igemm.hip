@@ -1003,6 +1003,230 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW == 4 ? 1 : 2) void gemm_n
 }
 
 // -------------------------------------------------------------------------------------------------
+// 256 x 256 NT GEMM with an 8-phase main loop (the structure of cdna_hip_programming.md section 5's 256^2 template, written for the
+// 32 x 32 x 16 MFMA): the DMA queue is NEVER drained inside the loop.  gemm_nt_wide_pipe_kernel above waits vmcnt(0) at every K slab
+// (one slab in flight); here the operands move as HALF-TILES of 128 rows x 64 k (16 KiB = two 1-KiB pieces per wave), one per
+// phase, seven of them ahead of the MFMAs, and the only wait is a counted vmcnt(6) once per K tile.
+//   LDS     8 half-tile slots (128 KiB): K tile t lives in slots 4 (t & 1) + {0: B0, 1: A0, 2: B1, 3: A1} (A0 / A1 = rows 0..127 /
+//           128..255 of the tile, B likewise for columns); rows are 128 B, 16-byte chunk c of row r at c ^ ((r >> 1) & 7) (the
+//           permutation is applied to the DMA SOURCE address, the LDS image is lane-linear).
+//   waves   8 = 2 (wr) x 4 (wc); a wave owns rows wr * 64 .. + 64 of BOTH A halves and columns wc * 32 .. + 32 of BOTH B halves, i.e.
+//           four 64 x 32 quadrants (A half i, B half j), 2 MFMA tiles each.  A phase = one quadrant over the whole K tile (8 MFMAs):
+//             phase 0 (A0, B0): reads 4 B0 + 8 A0 fragments      stages A1 of tile t + 1
+//             phase 1 (A0, B1): reads 4 B1                        stages B0 of tile t + 2
+//             phase 2 (A1, B1): reads 8 A1                        stages A0 of tile t + 2
+//             phase 3 (A1, B0): reads nothing (B0 kept)           stages B1 of tile t + 2, then s_waitcnt vmcnt(6)
+//           Every phase is [reads + 2 DMA pieces] s_barrier [8 MFMAs behind the compiler's counted lgkmcnt waits] s_barrier; the wr = 1 waves run ONE
+//           barrier behind the wr = 0 waves, so on every SIMD one wave issues MFMAs while its partner issues reads and DMA.
+//   RAW     a half-tile is read one phase (= at least two barriers, for both wave groups) after the vmcnt that retires it:
+//           phase 3's vmcnt(6) leaves the three youngest half-tiles (B0, A0, B1 of t + 2) in flight -> tile t + 1 is complete.
+//   WAR     a slot is re-staged two phases after its last read, except B0's (one phase): its four reads are issued first in phase 0
+//           and retired by s_waitcnt lgkmcnt(8) BEFORE that phase's first barrier.
+// K tiles past the end are re-fetches of the last tile into slots that are already dead; the queue is drained once, before the
+// epilogue.  Epilogue: gemm_nt_wide_pipe_kernel's (packed bf16 tile through LDS, 16-byte stores).  Needs what that kernel needs.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(NtParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using T = bf16_t;
+    constexpr int HTB = 128 * GROW;                          // bytes of a half-tile slot
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wi = xcd_remap(blockIdx.x, p.gm * p.gn);
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * p.gn;
+    const int grp = wi / per_group, rem = wi - grp * per_group;
+    const int gsz = min(p.gm - grp * GROUP_M, GROUP_M);
+    const int m0 = (grp * GROUP_M + rem % gsz) * WT, n0 = (rem / gsz) * WT;
+    const int64_t bz = blockIdx.z;
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
+    const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Bg), 0, 0x7fffffff, 0x00020000);
+    // DMA: wave w sends pieces 2w, 2w + 1 (8 rows each) of every half-tile; lane -> row (lane >> 3), source chunk (lane & 7) ^ swizzle
+    const int lrow = lane >> 3, cpos = lane & 7;
+    int voA[2][2], voB[2][2];                               // [half][piece]: byte offset of this lane's 16 bytes in K tile 0
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = (2 * wave + e) * 8 + lrow;
+            const int ch = (cpos ^ ((r >> 1) & 7)) * 8;
+            voA[i][e] = (int)(((int64_t)min(m0 + i * 128 + r, p.M - 1) * p.lda + ch) * 2);
+            voB[i][e] = (int)(((int64_t)min(n0 + i * 128 + r, p.Ncols - 1) * p.ldb + ch) * 2);
+        }
+    const int nk = p.Ktot / 64;
+    // half-tile q of the stream order (0: B0, 1: A0, 2: B1, 3: A1) of K tile kt into slot `slot`
+    auto stage = [&](auto qtag, int kt, int slot) {
+        constexpr int q = decltype(qtag)::value;
+        const int so = min(kt, nk - 1) * 128;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            auto dst = (__attribute__((address_space(3))) void*)(smem + slot * HTB + (2 * wave + e) * 1024);
+            if constexpr ((q & 1) != 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, voA[q >> 1][e], so, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, voB[q >> 1][e], so, 0, 0);
+        }
+    };
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>;
+    using Q3 = std::integral_constant<int, 3>;
+    f32x16 acc[2][2][2];                                    // [A half][B half][row tile of the quadrant]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][f][r] = 0.f;
+    // fragment addresses: byte offset of (row, 16-k step ks) inside a half-tile; `par` toggles between the two K-tile regions
+    const int swz = ((l31 >> 1) & 7) ^ half;                 // chunk (2 ks + half) ^ ((row >> 1) & 7) = 2 ks ^ swz
+    int ra[4], rb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        ra[ks] = (wr * 64 + l31) * GROW + (((2 * ks) ^ swz) << 4);
+        rb[ks] = (wc * 32 + l31) * GROW + (((2 * ks) ^ swz) << 4);
+    }
+    bf16x8 a[2][4], b0[4], b1[4];
+    auto read_a = [&](int i) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) a[f][ks] = *reinterpret_cast<const bf16x8*>(smem + ra[ks] + (2 * i + 1) * HTB + f * 32 * GROW);
+    };
+    auto read_b = [&](int j, bf16x8 (&b)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) b[ks] = *reinterpret_cast<const bf16x8*>(smem + rb[ks] + 2 * j * HTB);
+    };
+    // (measured at 8192^3, MI355X: the compiler's counted lgkmcnt waits between the MFMAs beat a blanket lgkmcnt(0) ahead of them, 1347
+    // vs 1308 TFLOP/s, and s_setprio 1 around the MFMAs costs 1-2 % with 32 x 32 MFMAs -- 1375 without either)
+    auto mfma8 = [&](int i, int j, bf16x8 (&b)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                acc[i][j][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks], a[f][ks], acc[i][j][f], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // prologue: K tile 0 and B0, A0, B1 of tile 1 (seven half-tiles); tile 0 has landed when at most three are outstanding
+    stage(Q0{}, 0, 0);
+    stage(Q1{}, 0, 1);
+    stage(Q2{}, 0, 2);
+    stage(Q3{}, 0, 3);
+    stage(Q0{}, 1, 4);
+    stage(Q1{}, 1, 5);
+    stage(Q2{}, 1, 6);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    bar();
+    if (wr == 1) bar();                                       // the second wave group runs one barrier behind
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        const int cur = (t & 1) * 4, nxt = cur ^ 4;
+        // ---- phase 0: quadrant (A0, B0) ----
+        read_b(0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(Q3{}, t + 1, nxt + 3);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");    // the four B0 reads have returned: slot B0 may be re-staged next phase
+        bar();
+        mfma8(0, 0, b0);
+        bar();
+        // ---- phase 1: quadrant (A0, B1) ----
+        read_b(1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(Q0{}, t + 2, cur + 0);
+        bar();
+        mfma8(0, 1, b1);
+        bar();
+        // ---- phase 2: quadrant (A1, B1) ----
+        read_a(1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(Q1{}, t + 2, cur + 1);
+        bar();
+        mfma8(1, 1, b1);
+        bar();
+        // ---- phase 3: quadrant (A1, B0) ----
+        stage(Q2{}, t + 2, cur + 2);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // all but the three youngest half-tiles: K tile t + 1 is complete
+        bar();
+        mfma8(1, 0, b0);
+        bar();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                      // the other K-tile region
+            ra[ks] ^= 4 * HTB;
+            rb[ks] ^= 4 * HTB;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (re-fetches past the end) nothing may land in the output staging
+    if (wr == 0) bar();
+    bar();
+    // epilogue: the 256 x 256 tile is staged as bf16 (512-byte rows) and leaves in 16-byte stores
+    const bool early_act = p.R == nullptr || p.res_mask;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+            const int lc = j * 128 + wc * 32 + 8 * jq + 4 * half;        // first of this lane's 4 columns
+            float4 bq = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias_mode == 1 && n0 + lc < p.Ncols) bq = *reinterpret_cast<const float4*>(p.bias + n0 + lc);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const int lr = i * 128 + wr * 64 + f * 32 + l31;
+                    const float brow = (p.bias_mode == 2 && m0 + lr < p.M) ? p.bias[m0 + lr] : 0.f;
+                    const f32x16& c = acc[i][j][f];
+                    float v[4] = {c[4 * jq] * p.alpha + bq.x + brow, c[4 * jq + 1] * p.alpha + bq.y + brow,
+                                  c[4 * jq + 2] * p.alpha + bq.z + brow, c[4 * jq + 3] * p.alpha + bq.w + brow};
+                    if (early_act) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.act_slope;
+                    }
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    const int chunk = (j * 16 + wc * 4 + jq) ^ (lr & 31);
+                    *reinterpret_cast<uint2*>(smem + lr * (WT * 2) + chunk * 16 + half * 8) = pk;
+                }
+        }
+    }
+    __syncthreads();
+    T* __restrict__ Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
+    const T* __restrict__ Rg = p.R ? reinterpret_cast<const T*>(p.R) + bz * p.sC : nullptr;
+#pragma unroll 4
+    for (int it = 0; it < (WT * WT / 8) / 512; ++it) {
+        const int q = tid + 512 * it;
+        const int lr = q >> 5, ch = q & 31;
+        const int row = m0 + lr, col = n0 + ch * 8;
+        if (row >= p.M || col >= p.Ncols) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(smem + lr * (WT * 2) + ((ch ^ (lr & 31)) << 4));
+        const int64_t o = (int64_t)row * p.ldc + col;
+        if (Rg != nullptr) {
+            const uint4 rv = *reinterpret_cast<const uint4*>(Rg + o);
+            unsigned* pv = &v.x;
+            const unsigned* pr = &rv.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = nt_res(p, __uint_as_float(pv[k] << 16), __uint_as_float(pr[k] << 16));
+                const float hi = nt_res(p, __uint_as_float(pv[k] & 0xffff0000u), __uint_as_float(pr[k] & 0xffff0000u));
+                pv[k] = pack_bf16x2(lo, hi);
+            }
+        }
+        *reinterpret_cast<uint4*>(Cg + o) = v;
+    }
+#endif
+}
+
+// -------------------------------------------------------------------------------------------------
 // Pipelined implicit-GEMM convolution (bf16): the main loop of gemm_nt_wide_pipe_kernel with the A rows gathered through the
 // convolution geometry -- strided, 4 x 4, 1 x 1 and small-map convolutions (forward: MODE_FWD) and their input gradients
 // (MODE_TCONV; stride 2 by output parity class like igemm_nt_glds_kernel), i.e. everything the 3 x 3 halo kernel does not take.
@@ -2288,11 +2512,11 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
     p.gn = (int)cdiv64(p.Ncols, TILE);
     bool mfma_ok = p.Ktot % VN == 0 && p.ldb % VN == 0 && p.lda % VN == 0 && (p.stride == 1 || p.stride == 2);
     if (p.mode == MODE_GEMM) mfma_ok = mfma_ok && (p.sA % VN == 0) && (p.sB % VN == 0);
-    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && impl != 6 && impl != 7 && impl != 8 && impl != 9 && !mfma_ok), DVQ_ESHAPE,
+    DVQ_REQUIRE(!(impl >= 2 && impl != 5 && impl != 6 && impl != 7 && impl != 8 && impl != 9 && impl != 10 && !mfma_ok), DVQ_ESHAPE,
                 "igemm_nt: MFMA path needs K, lda, ldb multiples of %d (K=%d lda=%lld ldb=%lld) and stride 1/2", VN,
                 p.Ktot, (long long)p.lda, (long long)p.ldb);
     DVQ_REQUIRE(!(impl == 3 && !mfma_ok), DVQ_ESHAPE, "igemm_nt: register-staged MFMA path unsupported for this shape");
-    const bool use_mfma = impl == 2 || impl == 3 || ((impl == 0 || impl == 5 || impl == 6 || impl == 7 || impl == 8 || impl == 9) && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
+    const bool use_mfma = impl == 2 || impl == 3 || ((impl == 0 || impl == 5 || impl == 6 || impl == 7 || impl == 8 || impl == 9 || impl == 10) && mfma_ok && (int64_t)p.M * p.Ncols >= 1024);
     if constexpr (sizeof(T) == 2) {
         // 256 x 256 macro tiles pay off on long reductions that fill the chip for several rounds (8192^3: 1036 vs 812 TFLOP/s);
         // on the StackGPT shapes (K = 1024 .. 4096, 324 .. 1296 tiles) the 128 x 128 kernel is faster (tools/gemm_probe.py),
@@ -2300,13 +2524,24 @@ int launch_nt(NtParams p, int64_t batch, int impl, hipStream_t s) {
         // a 1 x 1 / stride 1 / unpadded convolution (forward, or input gradient through the transposed pack) IS a plain GEMM
         const bool conv1x1 = p.mode != MODE_GEMM && p.Ktot == (int)p.lda && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 &&
                              p.up == 0 && p.LH == p.DH && p.LW == p.DW && p.par == 0;
-        if ((impl == 0 || impl == 5 || impl == 6 || impl == 7 || impl == 8) && mfma_ok && (p.mode == MODE_GEMM || (conv1x1 && impl == 0)) &&
-            (p.R == nullptr || impl == 0 || impl == 6) && p.ldc % VN == 0 && p.M >= 256 && p.Ncols >= 256) {
+        if ((impl == 0 || impl == 5 || impl == 6 || impl == 7 || impl == 8 || impl == 10) && mfma_ok && (p.mode == MODE_GEMM || (conv1x1 && impl == 0)) &&
+            (p.R == nullptr || impl == 0 || impl == 6 || impl == 10) && p.ldc % VN == 0 && p.M >= 256 && p.Ncols >= 256) {
             const int64_t wgm = cdiv64(p.M, WT), wgn = cdiv64(p.Ncols, WT);
             // pipelined main loop: faster than both the 128 x 128 kernel and the plain wide one on every tools/gemm_probe.py
             // shape (679 / 775 / 865 / 870 / 1141 against 575 / 640 / 594 / 779 / 840 and 535 / 593 / 636 / 695 / 1050 TFLOP/s)
             const bool pipe_ok = p.Ncols % 8 == 0 && p.Ktot % 64 == 0 && (int64_t)p.M * p.lda < (1ll << 30) &&
                                  (int64_t)p.Ncols * p.ldb < (1ll << 30);
+            // the 8-phase main loop (counted vmcnt, seven half-tiles ahead): long reductions over several rounds of tiles -- 8192^3 runs at
+            // 1375 TFLOP/s against 1129 for the kernel below and 1332 for hipBLASLt's best solution on the same box (tools/gemm8p_probe.py);
+            // its prologue (112 KiB before the first MFMA) and lock-step rounds lose at K <= 4096 / a single round (4096^3: 1181 vs 1280)
+            if ((impl == 10 || (impl == 0 && p.Ktot >= 4096 && wgm * wgn * batch >= 512)) && pipe_ok) {
+                p.gm = (int)wgm;
+                p.gn = (int)wgn;
+                dvq_ensure_dynamic_lds((const void*)gemm_nt_8phase_kernel, 8 * 128 * GROW);
+                gemm_nt_8phase_kernel<<<dim3((unsigned)(wgm * wgn), 1, (unsigned)batch), dim3(512), 8 * 128 * GROW, s>>>(p);
+                DVQ_CHECK_LAUNCH("gemm_nt_8phase");
+                return DVQ_OK;
+            }
             if (impl == 7 && pipe_ok) {            // experiment: 4 waves x (4 x 4 tiles), one wave per SIMD
                 p.gm = (int)wgm;
                 p.gn = (int)wgn;

@@ -1000,8 +1000,9 @@ def test_tconv4x4s2_thin_kernel(dev, case):
     assert np.abs(outs[0] - outs[1]).max() / np.abs(dref).max() < 1e-2
 
 
-@pytest.mark.parametrize("impl", [5, 6, 7, 8], ids=["plain", "pipelined", "pipelined-4wave", "pipelined-192"])
-@pytest.mark.parametrize("shape", [(3, 600, 520, 200, 1), (1, 2048, 1032, 512, 2), (2, 1296, 648, 128, 0), (1, 300, 264, 64, 1)])
+@pytest.mark.parametrize("impl", [5, 6, 7, 8, 10], ids=["plain", "pipelined", "pipelined-4wave", "pipelined-192", "8phase"])
+@pytest.mark.parametrize("shape", [(3, 600, 520, 200, 1), (1, 2048, 1032, 512, 2), (2, 1296, 648, 128, 0), (1, 300, 264, 64, 1),
+                                   (1, 1100, 776, 448, 1), (2, 520, 512, 4160, 2)])
 def test_gemm_nt_wide_kernel(dev, shape, impl):
     """256 x 256 macro-tile GEMMs (bf16; impl 5 = plain main loop, impl 6 = the software-pipelined one the automatic dispatch uses
     for large plain products the library does not take): ragged M / N / K tails, a single K slab, bias per column / row, batches --
@@ -1023,6 +1024,25 @@ def test_gemm_nt_wide_kernel(dev, shape, impl):
     got = out.view(b, m, n).float().cpu()
     err = float((got - ref).abs().max()) / float(ref.abs().max())
     assert err < 1e-2, err
+
+
+def test_gemm_nt_8phase_long_reduction(dev):
+    """the 8-phase 256 x 256 kernel (counted vmcnt, DMA queue never drained) where the automatic dispatch takes it -- K >= 4096 over at
+    least two rounds of tiles -- and forced (impl 10) on an odd number of K tiles with ragged row / column tails: the WHOLE output against
+    an fp32 product of the same bf16 operands, and bit-identical results over repeated launches"""
+    from dynamicvectorquantization_amd import kernels as K
+    torch.manual_seed(11)
+    for (m, n, k, impl) in ((8192, 4096, 4096, 0), (4100, 2056, 4160, 10), (8192, 8192, 8192, 0)):
+        a2 = (torch.rand(m, k, device=dev) * 2 - 1).to(torch.bfloat16)
+        b2 = (torch.rand(n, k, device=dev) * 2 - 1).to(torch.bfloat16)
+        bias = torch.randn(n, device=dev)
+        outs = [K.gemm_nt(a2.reshape(-1), b2.reshape(-1), m, n, k, k, k, n, bias=bias, bias_mode=1, alpha=0.5, impl=impl) for _ in range(4)]
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        worst = 0.0
+        for r0 in range(0, m, 2048):
+            ref = 0.5 * torch.matmul(a2[r0:r0 + 2048].float(), b2.float().t()) + bias[None, :]
+            worst = max(worst, float((outs[0].view(m, n)[r0:r0 + 2048].float() - ref).abs().max() / ref.abs().max()))
+        assert worst < 6e-3, (m, n, k, worst)            # bf16 output rounding (2^-9 of the largest entry) + accumulation order
 
 
 @pytest.mark.parametrize("shape", [(2048, 1024, 1024), (1304, 512, 1032), (20736, 4096, 1024)], ids=lambda s: "x".join(map(str, s)))
@@ -1377,7 +1397,7 @@ def test_pipelined_kernels_reproduce_bitwise_full_size(dev):
         m, n, k = 20736, 1024, 4096
         a = torch.randn(m, k, device=dev).to(torch.bfloat16).reshape(-1)
         b = torch.randn(n, k, device=dev).to(torch.bfloat16).reshape(-1)
-        for impl in (6, 8):
+        for impl in (6, 8, 10):
             same(lambda: [K.gemm_nt(a, b, m, n, k, k, k, n, impl=impl)])
         a2 = torch.randn(m, 1024, device=dev).to(torch.bfloat16).reshape(-1)
         b2 = torch.randn(m, 4096, device=dev).to(torch.bfloat16).reshape(-1)

@@ -30,6 +30,10 @@ ALLOW = [
     ("conv_halo.hip", "conv3x3_halo_kernel", 1,
      "the bias-publication barrier ahead of the main loop is LDS-only on purpose (inline s_waitcnt lgkmcnt(0) + s_barrier): the first halo / "
      "weight DMA stays in flight across it and is waited for by the chunk barrier (dvq_dma_barrier) that follows"),
+    ("igemm.hip", "gemm_nt_8phase_kernel", 10,
+     "by design: the 8-phase main loop never drains the DMA queue.  A half-tile is published by the counted s_waitcnt vmcnt(6) of phase 3 "
+     "(all but the three youngest half-tiles have landed) followed by TWO barriers before its first ds_read; the other barriers of a K tile "
+     "separate read and MFMA sections only.  The queue is drained (vmcnt(0)) ahead of the epilogue's barrier."),
     ("conv_halo.hip", "conv3x3_halo_wgrad_kernel", 1,
      "false positive of the path merge: the barrier behind the fused GroupNorm pass runs only when gn_ss != nullptr, the prefetch issue "
      "ahead of it only when gn_ss == nullptr (in the GroupNorm mode the next tile is issued BEHIND that barrier)"),
