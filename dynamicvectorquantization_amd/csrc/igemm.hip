@@ -2317,6 +2317,247 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_pipe_kernel(TnParams p) {
 #endif
 }
 
+// -------------------------------------------------------------------------------------------------
+// 256 x 256 TN GEMM with the 8-phase main loop of gemm_nt_8phase_kernel (the DMA queue is never drained; seven half-tiles ahead; one
+// counted vmcnt(6) per K tile): the weight gradients of the transformer's Linear layers, C[i][j] += sum_m A[m][i] B[m][j] with a long
+// reduction per workgroup (>= 16 K tiles of 64 rows).  Operands stay in their natural [m][column] layout; a half-tile is 64 reduction
+// rows x 128 columns (256-byte LDS rows, 16 KiB = two 1-KiB DMA pieces of 4 rows per wave), chunk c of row r at c ^ ((r & 3) << 2)
+// -- the layout the transpose reads (ds_read_b64_tr_b16, as gemm_tn_wide_pipe_kernel) walk without bank conflicts.
+// Slots, stream order, phases, RAW / WAR argument: gemm_nt_8phase_kernel's header (A0 / A1 = columns i0 .. + 127 / + 128 .. + 255 of A).
+// Phase 0 issues 24 transpose reads (8 for B0 first); s_waitcnt lgkmcnt(15) -- the counter's maximum -- retires at least those 8
+// before the barrier that lets the next phase re-stage B0's slot.  The DMA is inline assembly (the compiler would order every
+// transpose read behind all LDS-DMA it knows of).  Epilogue as gemm_tn_wide_pipe_kernel (workspace partials or fp32 atomics).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_tn_8phase_kernel(TnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using T = bf16_t;
+    constexpr int HROW = 256;                                // LDS row bytes of a half-tile: 128 bf16 columns
+    constexpr int HTB = 64 * HROW;                           // 16 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;                 // 2 x 4 waves: 64 i-columns of both A halves x 32 j-columns of both B halves
+    const int per_split = p.itiles * p.jtiles;
+    int bx = xcd_remap(blockIdx.x, per_split * p.nsplit);
+    const int split = bx / per_split;
+    bx -= split * per_split;
+    const int it = bx % p.itiles, jt = bx / p.itiles;
+    const int i0 = it * 256, j0 = jt * 256;
+    const int64_t bz = blockIdx.z;
+    const T* Ag = reinterpret_cast<const T*>(p.A) + bz * p.sA;
+    const T* Bg = reinterpret_cast<const T*>(p.B) + bz * p.sB;
+    const int mbeg = split * p.m_per_split;
+    const int mend = min(p.Mred, mbeg + p.m_per_split);
+    const int nk = (mend - mbeg + 63) / 64;
+
+    auto make_rsrc = [&](const T* base, int64_t bytes) {
+        const unsigned long long a = (unsigned long long)base;
+        dvq_int32x4 r;
+        r.x = (int)(unsigned)a;
+        r.y = (int)(unsigned)(a >> 32);
+        r.z = (int)bytes;                                    // reads at or past this byte offset return zero
+        r.w = 0x00020000;
+        r.x = __builtin_amdgcn_readfirstlane(r.x);
+        r.y = __builtin_amdgcn_readfirstlane(r.y);
+        r.z = __builtin_amdgcn_readfirstlane(r.z);
+        return r;
+    };
+    const dvq_int32x4 rsA = make_rsrc(Ag, (int64_t)mend * p.lda * 2), rsB = make_rsrc(Bg, (int64_t)mend * p.ldb * 2);
+    // DMA piece e (0 / 1) of this wave in a half-tile: rows (2 wave + e) * 4 + (lane >> 4), chunk position lane & 15 <- source chunk pos ^ ((row & 3) << 2)
+    int voA[2][2], voB[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = (2 * wave + e) * 4 + (lane >> 4);
+            const int cg = (lane & 15) ^ ((row & 3) << 2);
+            voA[i][e] = (int)(((int64_t)(mbeg + row) * p.lda + i0 + i * 128 + cg * 8) * 2);
+            voB[i][e] = (int)(((int64_t)(mbeg + row) * p.ldb + j0 + i * 128 + cg * 8) * 2);
+        }
+    const int sstepA = (int)(64 * p.lda * 2), sstepB = (int)(64 * p.ldb * 2);      // bytes per K tile
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    auto stage = [&](auto qtag, int kt, int slot) {          // half-tile q of the stream order (0: B0, 1: A0, 2: B1, 3: A1)
+        constexpr int q = decltype(qtag)::value;
+        const int ktc = min(kt, nk - 1);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned l = lds0 + (unsigned)(slot * HTB + (2 * wave + e) * 1024);
+            const bool isA = (q & 1) != 0;
+            const int so = __builtin_amdgcn_readfirstlane(ktc * (isA ? sstepA : sstepB));
+            const int vo = isA ? voA[q >> 1][e] : voB[q >> 1][e];
+            const dvq_int32x4 rs = isA ? rsA : rsB;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(l), "v"(vo), "s"(rs), "s"(so) : "memory");
+        }
+    };
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>;
+    using Q3 = std::integral_constant<int, 3>;
+    // fragment addressing (igemm_tn_tr_kernel's): a 16-lane group reads 4 rows x 16 columns per ds_read_b64_tr_b16
+    const int g = lane >> 4, li = lane & 15;
+    const int frow = 8 * (g >> 1) + (li >> 2);               // + 16 ks (+ 4 for the second read)
+    const int fz = ((li >> 2) & 3) << 2;
+    int offA[2], offB;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) offA[f] = frow * HROW + (((wr * 8 + f * 4 + 2 * (g & 1) + ((li & 3) >> 1)) ^ fz) << 4) + (li & 1) * 8;
+    offB = frow * HROW + (((wc * 4 + 2 * (g & 1) + ((li & 3) >> 1)) ^ fz) << 4) + (li & 1) * 8;
+    const bool do_bias = p.colsumA != nullptr && jt == 0 && wc == 0;
+    float bsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+
+    f32x16 acc[2][2][2];                                    // [A half][B half][i tile of the quadrant]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][f][r] = 0.f;
+    int par = 0;                                             // byte offset of the current K tile's slot group (0 / 4 * HTB)
+    auto frag = [&](int off, int ks) -> bf16x8 {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(smem + off + (ks * 16) * HROW));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(smem + off + (ks * 16 + 4) * HROW));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    bf16x8 a[2][4], b0[4], b1[4];
+    auto read_a = [&](int i) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) a[f][ks] = frag(par + (2 * i + 1) * HTB + offA[f], ks);
+    };
+    auto read_b = [&](int j, bf16x8 (&b)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) b[ks] = frag(par + 2 * j * HTB + offB, ks);
+    };
+    auto bias_of = [&](int i) {                              // column sums of A (dbias) from the fragments just read
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 u = __builtin_bit_cast(uint4, a[f][ks]);
+                bsum[i][f] += (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) +
+                              (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u)) +
+                              (__uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u)) +
+                              (__uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u));
+            }
+    };
+    auto mfma8 = [&](int i, int j, bf16x8 (&b)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                acc[i][j][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[f][ks], b[ks], acc[i][j][f], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nk > 0) {
+        stage(Q0{}, 0, 0);
+        stage(Q1{}, 0, 1);
+        stage(Q2{}, 0, 2);
+        stage(Q3{}, 0, 3);
+        stage(Q0{}, 1, 4);
+        stage(Q1{}, 1, 5);
+        stage(Q2{}, 1, 6);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        bar();
+        if (wr == 1) bar();                                   // the second wave group runs one barrier behind
+#pragma unroll 1
+        for (int t = 0; t < nk; ++t) {
+            const int cur = (t & 1) * 4, nxt = cur ^ 4;
+            // ---- phase 0: quadrant (A0, B0) ----
+            read_b(0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(Q3{}, t + 1, nxt + 3);
+            asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");   // >= 9 of the 24 reads have returned, the 8 of B0 among them
+            bar();
+            if (do_bias) bias_of(0);
+            mfma8(0, 0, b0);
+            bar();
+            // ---- phase 1: quadrant (A0, B1) ----
+            read_b(1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(Q0{}, t + 2, cur + 0);
+            bar();
+            mfma8(0, 1, b1);
+            bar();
+            // ---- phase 2: quadrant (A1, B1) ----
+            read_a(1);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(Q1{}, t + 2, cur + 1);
+            bar();
+            if (do_bias) bias_of(1);
+            mfma8(1, 1, b1);
+            bar();
+            // ---- phase 3: quadrant (A1, B0) ----
+            stage(Q2{}, t + 2, cur + 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // all but the three youngest half-tiles: K tile t + 1 is complete
+            bar();
+            mfma8(1, 0, b0);
+            bar();
+            par ^= 4 * HTB;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wr == 0) bar();
+    }
+
+    const int l31 = lane & 31, half = lane >> 5;
+    if (p.ws != nullptr) {
+        float* tile = p.ws + ((int64_t)split * per_split + it + (int64_t)jt * p.itiles) * 65536;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tile[(i * 128 + wr * 64 + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 256 + j * 128 + wc * 32 + l31] = acc[i][j][f][r];
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const float v = bsum[i][f] + __shfl_xor(bsum[i][f], 32, 64);
+                    if (half == 0) p.ws_bias[((int64_t)split * p.itiles + it) * 256 + i * 128 + wr * 64 + f * 32 + l31] = v;
+                }
+        }
+        return;
+    }
+    float* __restrict__ Cg = p.C + bz * p.sC;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = j0 + j * 128 + wc * 32 + l31;
+        if (col >= p.Jc) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i0 + i * 128 + wr * 64 + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < p.I) atomicAdd(Cg + tn_c_offset(p, row, 0, col), acc[i][j][f][r]);
+                }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const float v = bsum[i][f] + __shfl_xor(bsum[i][f], 32, 64);    // the two lane halves hold different m
+                const int col = i0 + i * 128 + wr * 64 + f * 32 + l31;
+                if (half == 0 && col < p.I) atomicAdd(p.colsumA + col, v);
+            }
+    }
+#endif
+}
+
 // C[i][j] += sum over the splits of the workspace partials (one writer per element: plain read-modify-write, deterministic order)
 __global__ __launch_bounds__(256) void gemm_tn_wide_reduce_kernel(TnParams p) {
     const int ntile = p.itiles * p.jtiles;
@@ -2785,9 +3026,20 @@ int launch_tn(TnParams p, int64_t batch, int impl, hipStream_t s) {
                 p.m_per_split = (int)(cdiv64(p.Mred, BK) * BK);
                 p.nsplit = 1;
             }
-            dvq_ensure_dynamic_lds((const void*)gemm_tn_wide_pipe_kernel, 2 * WTSTG);
-            gemm_tn_wide_pipe_kernel<<<dim3((unsigned)(p.itiles * p.jtiles * p.nsplit), 1, (unsigned)batch), dim3(512), 2 * WTSTG, s>>>(p);
-            DVQ_CHECK_LAUNCH("gemm_tn_wide_pipe");
+            // the 8-phase main loop (DMA queue never drained) unless DVQ_TN_8PHASE=0 / impl 6 ask for the per-stage-drain kernel (A/B, tests)
+            static const int tn8_env = [] {
+                const char* e = getenv("DVQ_TN_8PHASE");
+                return e != nullptr ? atoi(e) : 1;
+            }();
+            if (tn8_env != 0 && impl == 0 && (p.sA * 2) % 16 == 0 && (p.sB * 2) % 16 == 0) {
+                dvq_ensure_dynamic_lds((const void*)gemm_tn_8phase_kernel, 8 * 64 * 256);
+                gemm_tn_8phase_kernel<<<dim3((unsigned)(p.itiles * p.jtiles * p.nsplit), 1, (unsigned)batch), dim3(512), 8 * 64 * 256, s>>>(p);
+                DVQ_CHECK_LAUNCH("gemm_tn_8phase");
+            } else {
+                dvq_ensure_dynamic_lds((const void*)gemm_tn_wide_pipe_kernel, 2 * WTSTG);
+                gemm_tn_wide_pipe_kernel<<<dim3((unsigned)(p.itiles * p.jtiles * p.nsplit), 1, (unsigned)batch), dim3(512), 2 * WTSTG, s>>>(p);
+                DVQ_CHECK_LAUNCH("gemm_tn_wide_pipe");
+            }
             if (p.ws != nullptr) {
                 gemm_tn_wide_reduce_kernel<<<dim3((unsigned)(wtiles * 256)), dim3(256), 0, s>>>(p);
                 DVQ_CHECK_LAUNCH("gemm_tn_wide_reduce");

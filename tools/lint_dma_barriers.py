@@ -34,6 +34,9 @@ ALLOW = [
      "by design: the 8-phase main loop never drains the DMA queue.  A half-tile is published by the counted s_waitcnt vmcnt(6) of phase 3 "
      "(all but the three youngest half-tiles have landed) followed by TWO barriers before its first ds_read; the other barriers of a K tile "
      "separate read and MFMA sections only.  The queue is drained (vmcnt(0)) ahead of the epilogue's barrier."),
+    ("igemm.hip", "gemm_tn_8phase_kernel", 10,
+     "by design, as gemm_nt_8phase_kernel: counted s_waitcnt vmcnt(6) once per K tile, two barriers between that wait and the first transpose "
+     "read of the half-tiles it retires, vmcnt(0) ahead of the barrier that ends the loop"),
     ("conv_halo.hip", "conv3x3_halo_wgrad_kernel", 1,
      "false positive of the path merge: the barrier behind the fused GroupNorm pass runs only when gn_ss != nullptr, the prefetch issue "
      "ahead of it only when gn_ss == nullptr (in the GroupNorm mode the next tile is issued BEHIND that barrier)"),
