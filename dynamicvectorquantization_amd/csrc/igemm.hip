@@ -1023,7 +1023,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW == 4 ? 1 : 2) void gemm_n
 //   WAR     a slot is re-staged two phases after its last read, except B0's (one phase): its four reads are issued first in phase 0
 //           and retired by s_waitcnt lgkmcnt(8) BEFORE that phase's first barrier.
 // K tiles past the end are re-fetches of the last tile into slots that are already dead; the queue is drained once, before the
-// epilogue.  Epilogue: gemm_nt_wide_pipe_kernel's (packed bf16 tile through LDS, 16-byte stores).  Needs what that kernel needs.
+// epilogue.  (Tried and removed, round 6: a PERSISTENT form whose half-tile stream runs on across tile boundaries and whose epilogue
+// stores the accumulators straight from registers, 8 bytes per lane -- correct, but 16 % slower at 4096^3 and 8 - 18 % at K = 1024:
+// 32 row-per-lane stores per wave are issue-bound, ~18 k cycles per tile, far more than the prologue + LDS-staged epilogue they replace.)  Epilogue: gemm_nt_wide_pipe_kernel's (packed bf16 tile through LDS, 16-byte stores).  Needs what that kernel needs.
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(NtParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
