@@ -188,14 +188,45 @@ def train_step_restart_perm(step: int, bs: int, k: int, size: int = 64) -> np.nd
     return np.concatenate([head, rest[rs.permutation(len(rest))]])
 
 
-def apply_train_step_state(model, k: int, zc: int):
+def apply_train_step_state(model, k: int, zc: int, scale=None):
     """write the pinned run's start state into a stage-1 model (the reference's class or this repo's -- same parameter names):
-    every parameter by name, the VQ EMA buffers; BatchNorm / ScalingLayer buffers keep their constructor values"""
+    every parameter by name (times scale[name] where given), the VQ EMA buffers; BatchNorm / ScalingLayer buffers keep their
+    constructor values"""
     import torch
     with torch.no_grad():
         for name, p in model.named_parameters():
-            p.copy_(torch.from_numpy(train_step_param(name, tuple(p.shape), k, zc)).to(p.device))
+            v = train_step_param(name, tuple(p.shape), k, zc)
+            if scale and name in scale:
+                v = (v * np.float32(scale[name])).astype(np.float32)
+            p.copy_(torch.from_numpy(v).to(p.device))
         n0, s0 = train_step_vq_state(k, zc)
         cbm = model.quantize.codebook
         cbm.cluster_size_ema.copy_(torch.from_numpy(n0).to(cbm.cluster_size_ema.device))
         cbm.embed_ema.copy_(torch.from_numpy(s0).to(cbm.embed_ema.device))
+
+
+def train_step_gumbel(step: int, bs: int, hc: int = 2, heads: int = 3) -> np.ndarray:
+    """Exp(1) noise injected into F.gumbel_softmax's Tensor.exponential_ in BOTH forwards of step `step` of the pinned triple-grain run"""
+    return np.random.RandomState(4211 + step).exponential(size=(bs, hc, hc, heads)).astype(np.float32)
+
+
+def distinct_row_perm(indices: np.ndarray, n_heads: int, k: int, name: str) -> np.ndarray:
+    """restart permutation whose first K entries are pairwise distinct rows, from a grain map: indices [B, hc, hc] in 0 .. n_heads-1
+    (0 = coarsest) over the coarsest grid; a cell of grain g is repeated 2^(n_heads-1-g) times along both axes of the fine grid"""
+    b, hc, _ = indices.shape
+    f = 1 << (n_heads - 1)
+    hw = hc * f
+    distinct = []
+    for bi in range(b):
+        for i in range(hw):
+            for j in range(hw):
+                r = 1 << (n_heads - 1 - int(indices[bi, i // f, j // f]))
+                if i % r == 0 and j % r == 0:
+                    distinct.append(bi * hw * hw + i * hw + j)
+    distinct = np.array(distinct, dtype=np.int64)
+    rs = _rs(name)
+    head = distinct[rs.permutation(len(distinct))]
+    rest = np.setdiff1d(np.arange(b * hw * hw, dtype=np.int64), head)
+    perm = np.concatenate([head, rest[rs.permutation(len(rest))]])
+    assert len(distinct) >= k, (len(distinct), k)
+    return perm

@@ -116,6 +116,47 @@ def ae_forward(sd, x, threshold, beta=0.25, decay=0.99, train=True, restart_perm
     return odq.decoder(sd, z), qloss
 
 
+def ae_forward_routed(sd, x, n_heads, exponential, beta=0.25, decay=0.99, restart_perm=None, record=None):
+    """(rec, qloss, gate, indices): the feature-routed (Gumbel straight-through) DQ-VAE in train mode -- oracle.routing's encoder,
+    then the same VQ / EMA / decoder sequence as ae_forward (dqvae_triple_feat.py:83-100, EncoderTriple.py, RouterTriple.py)"""
+    from . import routing as oro
+    enc = oro.encoder_feature_routed(sd, x, n_heads, exponential)
+    h = odq.conv(sd, "quant_conv", enc["h"])
+    b, d, hh, ww = h.shape
+    flat = h.permute(0, 2, 3, 1).reshape(-1, d)
+    w = sd[CB + "weight"]
+    cb = w[:-1].detach().clone()
+    flat_np = flat.detach().numpy()
+    idx_np, gap = ovq.argmin_exact(flat_np, cb.numpy(), return_gap=True)
+    xq = cb[torch.from_numpy(idx_np)]
+    m = enc["codebook_mask"].permute(0, 2, 3, 1).reshape(-1, 1)
+    qloss = beta * torch.mean((xq - flat) ** 2 * m) + torch.mean((xq - flat.detach()) ** 2 * m)
+    k = cb.shape[0]
+    rows = flat_np[np.asarray(restart_perm)][:k] if restart_perm is not None else None
+    n_ema, s_ema, w_new = ovq.ema_update(flat_np, idx_np, sd[CB + "cluster_size_ema"].numpy(), sd[CB + "embed_ema"].numpy(), decay=decay,
+                                         restart_rows=rows)
+    with torch.no_grad():
+        sd[CB + "cluster_size_ema"].copy_(torch.from_numpy(n_ema))
+        sd[CB + "embed_ema"].copy_(torch.from_numpy(s_ema))
+        w[:-1].copy_(torch.from_numpy(w_new))
+    if record is not None:
+        record["codes"], record["gap"], record["indices"] = idx_np, gap, enc["indices"].numpy()
+    st = flat + (xq - flat).detach()
+    z = odq.conv(sd, "post_quant_conv", st.reshape(b, hh, ww, d).permute(0, 3, 1, 2))
+    return odq.decoder(sd, z), qloss, enc["gate"]
+
+
+def budget_triple(gate, target_fine_ratio, target_median_ratio, gamma, min_grain_size, median_grain_size, max_grain_size):
+    """BudgetConstraint_NormedSeperateRatioMSE_TripleGrain (modules/dynamic_modules/budget.py:30-60); gate [B, 3, h, w]"""
+    min_c = min_grain_size * min_grain_size
+    med_c = median_grain_size * median_grain_size - min_c
+    max_c = max_grain_size * max_grain_size - min_c
+    b = gate.shape[0]
+    r_med = ((gate[:, 0] + 4.0 * gate[:, 1] + gate[:, 2]).sum() / b - min_c) / med_c
+    r_fine = ((gate[:, 0] + 16.0 * gate[:, 2] + gate[:, 1]).sum() / b - min_c) / max_c
+    return gamma * (r_fine - target_fine_ratio) ** 2 + (r_med - target_median_ratio) ** 2
+
+
 def _split_state(state):
     sd = {k: v for k, v in state.items() if not k.startswith("loss.")}
     sd_d = {k[len("loss.discriminator."):]: v for k, v in state.items() if k.startswith("loss.discriminator.")}
@@ -125,7 +166,7 @@ def _split_state(state):
 
 def run_steps(state, param_keys, batches, threshold, lr, min_lr=0.0, warmup_steps=0, max_steps=1,
               scheduler_type="linear-warmup_cosine-decay", restart_perm=None, disc_weight_max=0.75, perceptual_weight=1.0,
-              disc_factor=1.0, watch=(), stride=lambda n: 1, record_grads=True):
+              disc_factor=1.0, watch=(), stride=lambda n: 1, record_grads=True, routed=None):
     """The reference's two-optimizer schedule for len(batches) steps, in place on `state` ({reference state_dict key: fp32 torch
     tensor}, autoencoder + `loss.discriminator.*` + `loss.perceptual_loss.*`; buffers included).  param_keys: the names that are
     nn.Parameters (the rest are buffers).  Returns {fixture key: value} with the keys tools/gen_golden.py::run_reference_train_steps
@@ -167,10 +208,18 @@ def run_steps(state, param_keys, batches, threshold, lr, min_lr=0.0, warmup_step
         set_grad(ae_named, True)
         set_grad(d_named, False)
         rec_info = {}
-        rec, qloss = ae_forward(sd, x, threshold, restart_perm=perm, record=rec_info)
+        bl = None
+        if routed is None:
+            rec, qloss = ae_forward(sd, x, threshold, restart_perm=perm, record=rec_info)
+        else:
+            rec, qloss, gate = ae_forward_routed(sd, x, routed["n_heads"], torch.as_tensor(routed["exponential"][step]), restart_perm=perm,
+                                                 record=rec_info)
+            bl = budget_triple(gate, **routed["budget"])
         run = {}
         r = olo.generator_loss(sd_d, sd_l, x, rec, qloss, sd["decoder.conv_out.weight"], perceptual_weight=perceptual_weight,
                                disc_factor=disc_factor, disc_weight_max=disc_weight_max, running=run)
+        if bl is not None:
+            r["loss"] = r["loss"] + bl
         r["loss"].backward()
         _bn_commit(sd_d, run, 1)
         if step == 0 and record_grads:
@@ -192,13 +241,22 @@ def run_steps(state, param_keys, batches, threshold, lr, min_lr=0.0, warmup_step
         out[lg + "train_d_weight"] = np.float32(r["d_weight"].item())
         out[lg + "train_disc_factor"] = np.float32(disc_factor)
         out[lg + "train_g_loss"] = np.float32(r["g"].item())
-        out[lg + "train_fine_ratio"] = np.float32(oent.entropy_gate(oent.patch_entropy(x.numpy()), threshold)[..., 1].mean())
+        if routed is None:
+            out[lg + "train_fine_ratio"] = np.float32(oent.entropy_gate(oent.patch_entropy(x.numpy()), threshold)[..., 1].mean())
+        else:
+            out[lg + "train_budget_loss"] = np.float32(bl.item())
+            out[lg + "train_fine_radio"] = np.float32((rec_info["indices"] == 2).mean())
+            out[lg + "train_median_radio"] = np.float32((rec_info["indices"] == 1).mean())
         # ---- optimizer 1: the discriminator, on a SECOND training-mode autoencoder forward ----
         set_grad(ae_named, False)
         set_grad(d_named, True)
         rec_info = {}
         with torch.no_grad():
-            rec2, _ = ae_forward(sd, x, threshold, restart_perm=perm, record=rec_info)
+            if routed is None:
+                rec2, _ = ae_forward(sd, x, threshold, restart_perm=perm, record=rec_info)
+            else:
+                rec2, _, _ = ae_forward_routed(sd, x, routed["n_heads"], torch.as_tensor(routed["exponential"][step]), restart_perm=perm,
+                                               record=rec_info)
         run = {}
         d_loss, lr_, lf_ = olo.discriminator_loss(sd_d, x, rec2, disc_factor=disc_factor, running=run)
         d_loss.backward()
@@ -354,13 +412,15 @@ def check_summary(summary, bounds=PIN_BOUNDS):
     return bad
 
 
-def sampled_start_param(meta, k, zc, stride):
+def sampled_start_param(meta, k, zc, stride, scale=None):
     """name -> the strided sample of the pinned start value of a parameter (fp64), for compare_records(start_param=...)"""
     from dynamicvectorquantization_amd import synth
     shapes = {str(kk): tuple(int(v) for v in str(s).split(",")) if str(s) else () for kk, s in zip(meta["state_keys"], meta["state_shapes"])}
 
     def p0(name):
         a = synth.train_step_param(name, shapes[name], k, zc).reshape(-1)
+        if scale and name in scale:
+            a = (a * np.float32(scale[name])).astype(np.float32)
         return a[:: stride(a.size)].astype(np.float64)
     return p0
 
@@ -384,7 +444,25 @@ def reference_schedule_steps(tag, meta):
                      restart_perm=perms, watch=TRAIN_STEP_WATCH, stride=train_step_stride)
 
 
-def pinned_start_state(meta, k, zc):
+def triple_schedule_steps(meta):
+    """the pinned triple-grain run (tests/golden_cfg.TRAIN_STEP_TRIPLE); meta = the fixture (state_keys / state_shapes / param_keys and the
+    per-step restart permutations `s<step>.perm`, which were derived from the reference's own grain maps)"""
+    import os
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "tests"))
+    from golden_cfg import TRAIN_STEP_TRIPLE, TRAIN_STEP_TRIPLE_WATCH, TRIPLE_BUDGET, train_step_stride
+    from dynamicvectorquantization_amd import synth
+    c = TRAIN_STEP_TRIPLE
+    state = pinned_start_state(meta, c["k"], c["zc"], scale={"encoder.router.gate.2.weight": c["last_gate_scale"]})
+    perms = [np.asarray(meta[f"s{s_}.perm"]) for s_ in range(c["steps"])]
+    routed = dict(n_heads=3, exponential=[synth.train_step_gumbel(s_, c["bs"]) for s_ in range(c["steps"])], budget=dict(TRIPLE_BUDGET))
+    return run_steps(state, [str(k) for k in meta["param_keys"]], synth.train_step_batches(c["steps"], c["bs"], 64), None,
+                     lr=c["lr"], min_lr=c["min_lr"], warmup_steps=c["steps_per_epoch"] * c["warmup_epochs"], max_steps=c["training_steps"],
+                     restart_perm=perms, watch=TRAIN_STEP_TRIPLE_WATCH, stride=train_step_stride, routed=routed)
+
+
+def pinned_start_state(meta, k, zc, scale=None):
     """{key: tensor} of the pinned run's start: parameters from synth.train_step_param, VQ EMA buffers from synth.train_step_vq_state,
     BatchNorm buffers at their constructor values, LPIPS ScalingLayer constants"""
     from dynamicvectorquantization_amd import synth
@@ -394,7 +472,10 @@ def pinned_start_state(meta, k, zc):
         key = str(key)
         shape = tuple(int(v) for v in str(shp).split(",")) if str(shp) else ()
         if key in pk:
-            state[key] = torch.from_numpy(synth.train_step_param(key, shape, k, zc).copy())
+            v = synth.train_step_param(key, shape, k, zc).copy()
+            if scale and key in scale:
+                v = (v * np.float32(scale[key])).astype(np.float32)
+            state[key] = torch.from_numpy(v)
         elif key.endswith("running_var"):
             state[key] = torch.ones(shape)
         elif key.endswith("num_batches_tracked"):

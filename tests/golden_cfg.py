@@ -92,3 +92,24 @@ TRAIN_STEP_S2_WATCH = ["content_emb.weight", "content_coarse_pos_emb.weight", "p
 def train_step_s2_batch(step):
     from dynamicvectorquantization_amd import synth
     return synth.ragged_grain_images(64, seed=131 + 10 * step)
+
+
+# triple-grain (feature-routed, Gumbel straight-through) DQ-VAE with the shipped objective incl. the budget loss on the gate
+# (configs/stage1/dqvae-triple-r-03-03_imagenet.yml), shrunken geometry of featrouted_triple.npz; Exp(1) noise injected on both sides
+TRAIN_STEP_TRIPLE = dict(bs=32, steps=2, lr=2e-5, min_lr=0.0, warmup_epochs=0.1, steps_per_epoch=10, training_steps=50, ndf=16, k=512, zc=64,
+                         last_gate_scale=6.0)
+TRAIN_STEP_TRIPLE_WATCH = [
+    "encoder.conv_in.weight", "encoder.down.0.block.0.conv1.weight", "encoder.conv_out_fine.bias", "encoder.conv_out_coarse.weight",
+    "encoder.conv_out_median.weight", "encoder.mid_median.block_1.conv1.weight", "encoder.router.feature_norm_fine.weight",
+    "encoder.router.gate.0.weight", "encoder.router.gate.0.bias", "encoder.router.gate.2.weight", "quant_conv.weight",
+    "decoder.conv_in.weight", "decoder.conv_out.weight", "decoder.norm_out.weight",
+    "loss.discriminator.main.0.weight", "loss.discriminator.main.5.weight", "loss.discriminator.main.8.weight", "loss.discriminator.main.11.weight",
+]
+TRIPLE_BUDGET = dict(target_fine_ratio=0.3, target_median_ratio=0.3, gamma=1.0, min_grain_size=8, median_grain_size=16, max_grain_size=32)
+
+
+def train_step_triple_lossconfig(ndf):
+    c = train_step_lossconfig(ndf)
+    c["params"]["budget_loss_config"] = dict(target="modules.dynamic_modules.budget.BudgetConstraint_NormedSeperateRatioMSE_TripleGrain",
+                                             params=dict(TRIPLE_BUDGET))
+    return c

@@ -30,14 +30,28 @@ def run_hip_train_steps(tag, dev, mode, use_graph=False):
     from dynamicvectorquantization_amd.config import instantiate_from_config
     from dynamicvectorquantization_amd.trainer import Trainer
     from test_gpu_model import GEOM, model_config
-    c = TRAIN_STEP[tag]
-    g = GEOM[c["geom"]]
+    triple = tag == "triple"
+    if triple:
+        from golden_cfg import TRAIN_STEP_TRIPLE, TRAIN_STEP_TRIPLE_WATCH, train_step_triple_lossconfig
+        from test_gpu_featrouted import feat_model_config
+        c = TRAIN_STEP_TRIPLE
+        g = dict(k=c["k"], zc=c["zc"], resolution=64)
+        watch = TRAIN_STEP_TRIPLE_WATCH
+        gold = load_golden("train_step_triple")
+    else:
+        c = TRAIN_STEP[tag]
+        g = GEOM[c["geom"]]
+        watch = TRAIN_STEP_WATCH
     k, zc = g["k"], g["zc"]
     out = {}
     with rt.compute_dtype_ctx(mode):
         torch.manual_seed(0)
-        model = instantiate_from_config(model_config(**g, loss="full", ndf=c["ndf"])).to(dev)
-        synth.apply_train_step_state(model, k, zc)
+        if triple:
+            model = instantiate_from_config(feat_model_config("triple", k=k, zc=zc, loss=train_step_triple_lossconfig(c["ndf"]))).to(dev)
+            synth.apply_train_step_state(model, k, zc, scale={"encoder.router.gate.2.weight": c["last_gate_scale"]})
+        else:
+            model = instantiate_from_config(model_config(**g, loss="full", ndf=c["ndf"])).to(dev)
+            synth.apply_train_step_state(model, k, zc)
         rt.bump_weights_epoch()
         model.learning_rate, model.min_learning_rate = c["lr"], c["min_lr"]
         model.warmup_epochs, model.steps_per_epoch, model.training_steps = c["warmup_epochs"], c["steps_per_epoch"], c["training_steps"]
@@ -63,7 +77,7 @@ def run_hip_train_steps(tag, dev, mode, use_graph=False):
                 out[pre + "lr"] = np.float64(tr.opts[oi].param_groups[0]["lr"])
                 snap(pre)                     # the EMA update of this optimizer's forward has run; the next forward has not
                 if s == 0:
-                    for n_ in TRAIN_STEP_WATCH:
+                    for n_ in watch:
                         if n_.startswith("loss.discriminator.") == (oi == 1):
                             out[f"s0.grad.{n_}"] = _sample(params[n_].grad)
                 return orig_steps[oi](closure)
@@ -73,7 +87,11 @@ def run_hip_train_steps(tag, dev, mode, use_graph=False):
             o.step = wrap(oi)
         for step, xb in enumerate(synth.train_step_batches(c["steps"], c["bs"], g["resolution"])):
             cur["step"] = step
-            cbm.restart_perm = torch.from_numpy(synth.train_step_restart_perm(step, c["bs"], k, g["resolution"]))
+            if triple:              # the fixture's inputs: restart permutation (from the reference's grain map) and the Gumbel noise
+                cbm.restart_perm = torch.from_numpy(gold[f"s{step}.perm"].astype(np.int64))
+                model.encoder.gumbel_exponential = torch.from_numpy(synth.train_step_gumbel(step, c["bs"])).to(dev)
+            else:
+                cbm.restart_perm = torch.from_numpy(synth.train_step_restart_perm(step, c["bs"], k, g["resolution"]))
             losses = tr.train_step({"image": torch.from_numpy(xb).to(dev)}, step)
             torch.cuda.synchronize()
             for oi, l in enumerate(losses):
@@ -82,7 +100,7 @@ def run_hip_train_steps(tag, dev, mode, use_graph=False):
                 out[f"s{step}.log.{k_}"] = np.float32(float(v_))
             states = [tr._optimizer_state_dict(o) for o in tr.opts]
             index = [{id(p): i for i, p in enumerate(p_ for grp in o.param_groups for p_ in grp["params"])} for o in tr.opts]
-            for n_ in TRAIN_STEP_WATCH:
+            for n_ in watch:
                 oi = 1 if n_.startswith("loss.discriminator.") else 0
                 st = states[oi]["state"][index[oi][id(params[n_])]]
                 assert int(float(st["step"])) == step + 1
@@ -127,6 +145,51 @@ def test_train_step_golden(dev, tag, mode):
     summ = ots.summarize(cmp)
     _report("train_step_golden", tag=tag, mode=mode, **{f"{s}.{grp}": float(e) for (s, grp), e in sorted(summ.items())})
     _report("train_step_golden_keys", tag=tag, mode=mode, **{k_: float(e) for k_, (_, e) in sorted(cmp.items()) if ".log." not in k_})
+    bad = ots.check_summary(summ, _bounds(mode))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("tag", ["small", "c1"])
+def test_train_step_bf16_distance_report(dev, tag):
+    """the BENCHMARKED precision against the same fixtures: bf16 cannot meet the fp32 bounds (north_star's tolerance is missed by the bf16
+    forward already), so this test REPORTS its distances (gpurun_out/test_reports.jsonl -> profiles/) and asserts only
+    what must hold at any precision: the lr = 0 step leaves every parameter untouched, the learning rates are the reference's, losses are
+    within 5 % and the Adam moments' relative L2 distance stays below 1"""
+    from oracle import train_step as ots
+    from test_gpu_model import GEOM, _report
+    g = load_golden(f"train_step_{tag}")
+    ref = {k_: g[k_] for k_ in g.files}
+    meta = {k_: g[k_] for k_ in ("state_keys", "state_shapes", "param_keys")}
+    geom = GEOM[TRAIN_STEP[tag]["geom"]]
+    got = run_hip_train_steps(tag, dev, torch.bfloat16)
+    summ = ots.summarize(ots.compare_records(got, ref, start_param=ots.sampled_start_param(meta, geom["k"], geom["zc"], train_step_stride)))
+    _report("train_step_bf16_distance", tag=tag, **{f"{s}.{grp}": float(e) for (s, grp), e in sorted(summ.items())})
+    for (s, grp), e in summ.items():
+        if grp.startswith("dparam0") or grp == "scalar:lr":
+            assert e <= 1e-12, (s, grp, e)
+        if grp == "scalar:loss":
+            assert e < 5e-2, (s, grp, e)
+        if grp in ("exp_avg", "grad"):
+            assert e < 1.0, (s, grp, e)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp32x3"])
+def test_triple_train_step_golden(dev, mode):
+    """the feature-routed TRIPLE-grain model (BASELINE config 4's family) through its two-optimizer step against the reference
+    (tests/golden/train_step_triple.npz): Gumbel straight-through routing with the injected noise, budget loss on the gate, router
+    parameters trained by optimizer 0; dqvae_triple_feat.py:102-136,164-196"""
+    from golden_cfg import TRAIN_STEP_TRIPLE as C
+    from oracle import train_step as ots
+    from test_gpu_model import _report
+    g = load_golden("train_step_triple")
+    ref = {k_: g[k_] for k_ in g.files}
+    got = run_hip_train_steps("triple", dev, mode)
+    skip = tuple(k_ for k_ in ref if k_.endswith((".perm", ".grain")))
+    missing = [k_ for k_ in ref if k_ not in got and not k_.startswith(("state_", "param_keys")) and not k_.endswith(".gap") and k_ not in skip]
+    assert not missing, missing
+    p0 = ots.sampled_start_param(ref, C["k"], C["zc"], train_step_stride, scale={"encoder.router.gate.2.weight": C["last_gate_scale"]})
+    summ = ots.summarize(ots.compare_records(got, ref, start_param=p0, skip=skip))
+    _report("triple_train_step_golden", mode=mode, **{f"{s}.{grp}": float(e) for (s, grp), e in sorted(summ.items())})
     bad = ots.check_summary(summ, _bounds(mode))
     assert not bad, bad
 

@@ -1035,17 +1035,26 @@ def run_reference_train_steps(tag):
     torch.randperm is replaced by the injected permutation for the EMA restart (quantize2_mask.py:97); LPIPS stays in eval mode
     (NetLinLayer dropout off, oracle/losses.py header).  Returns {key: np.ndarray} -- the fixture's content."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
-    from golden_cfg import TRAIN_STEP, TRAIN_STEP_WATCH, train_step_lossconfig
-    from models.stage1_dynamic.dqvae_dual_entropy import DualGrainVQModel
-    c = TRAIN_STEP[tag]
-    g = synth.DQVAE_GEOM[c["geom"]]
-    k, zc = g["k"], g["zc"]
-    torch.manual_seed(0)
-    model = build_dqvae(**g)
-    cfg_loss = train_step_lossconfig(c["ndf"])
+    from golden_cfg import (TRAIN_STEP, TRAIN_STEP_TRIPLE, TRAIN_STEP_TRIPLE_WATCH, TRAIN_STEP_WATCH, train_step_lossconfig,
+                            train_step_triple_lossconfig)
     from utils.utils import instantiate_from_config
-    model.loss = instantiate_from_config(cfg_loss)
-    synth.apply_train_step_state(model, k, zc)
+    triple = tag == "triple"
+    torch.manual_seed(0)
+    if triple:
+        c = TRAIN_STEP_TRIPLE
+        g = dict(k=c["k"], zc=c["zc"], latent=8, resolution=64)
+        k, zc = c["k"], c["zc"]
+        model = build_feat_model("triple", k=k, zc=zc)
+        model.loss = instantiate_from_config(train_step_triple_lossconfig(c["ndf"]))
+        synth.apply_train_step_state(model, k, zc, scale={"encoder.router.gate.2.weight": c["last_gate_scale"]})
+        TRAIN_STEP_WATCH = TRAIN_STEP_TRIPLE_WATCH
+    else:
+        c = TRAIN_STEP[tag]
+        g = synth.DQVAE_GEOM[c["geom"]]
+        k, zc = g["k"], g["zc"]
+        model = build_dqvae(**g)
+        model.loss = instantiate_from_config(train_step_lossconfig(c["ndf"]))
+        synth.apply_train_step_state(model, k, zc)
     model.learning_rate, model.min_learning_rate = c["lr"], c["min_lr"]
     model.warmup_epochs, model.steps_per_epoch, model.training_steps = c["warmup_epochs"], c["steps_per_epoch"], c["training_steps"]
     model.current_epoch, model.global_step = 0, 0
@@ -1059,6 +1068,7 @@ def run_reference_train_steps(tag):
     assert n_rows >= k, (n_rows, k)
     perm = [None]
     orig_randperm = torch.randperm
+    orig_exponential = torch.Tensor.exponential_
     torch.randperm = lambda m, device=None, **kw: t(perm[0].copy()) if m == n_rows else orig_randperm(m, **kw)
     out = {}
     params = dict(model.named_parameters())
@@ -1069,7 +1079,21 @@ def run_reference_train_steps(tag):
     try:
         for step, xb in enumerate(synth.train_step_batches(c["steps"], c["bs"], g["resolution"])):
             batch = {"image": t(xb)}
-            perm[0] = synth.train_step_restart_perm(step, c["bs"], k, g["resolution"])
+            if triple:
+                # Exp(1) noise of F.gumbel_softmax injected (both forwards of the step draw the same); the restart permutation puts K
+                # pairwise distinct rows first, judged by the grain map the model routes this batch to (stored: it is an input of the run)
+                expo = synth.train_step_gumbel(step, c["bs"])
+                torch.Tensor.exponential_ = lambda self, *a, **kw: self.copy_(t(expo).reshape(self.shape))
+                cbm.eval()
+                with torch.no_grad():
+                    _, _, grain0, _ = model(batch["image"])
+                cbm.train()
+                vq_in.clear()
+                perm[0] = synth.distinct_row_perm(grain0.numpy(), 3, k, f"train_step.triple.perm.{step}")
+                out[f"s{step}.perm"] = perm[0].astype(np.int32)
+                out[f"s{step}.grain"] = grain0.numpy().astype(np.int8)
+            else:
+                perm[0] = synth.train_step_restart_perm(step, c["bs"], k, g["resolution"])
             for oi, opt in enumerate(opts):
                 owned = {id(p) for grp in opt.param_groups for p in grp["params"]}
                 saved = {n_: p.requires_grad for n_, p in params.items()}
@@ -1112,6 +1136,7 @@ def run_reference_train_steps(tag):
                 assert int(st["step"]) == step + 1
     finally:
         torch.randperm = orig_randperm
+        torch.Tensor.exponential_ = orig_exponential
         hook.remove()
     for n_, b in model.loss.discriminator.named_buffers():
         out["final.disc_buf." + n_] = b.numpy().copy()
@@ -1201,6 +1226,28 @@ def gen_train_step():
         if bad:
             raise SystemExit(f"oracle.train_step does not match the reference: {bad}")
         np.savez_compressed(os.path.join(GOLD, f"train_step_{tag}.npz"), **out)
+    # ---- triple grain ----
+    from golden_cfg import TRAIN_STEP_TRIPLE
+    out, _ = run_reference_train_steps("triple")
+    for step in range(TRAIN_STEP_TRIPLE["steps"]):
+        print(f"  train_step triple step {step}: lr {out[f's{step}.o0.lr']:.3e} aeloss {out[f's{step}.o0.loss']:.6f} discloss {out[f's{step}.o1.loss']:.6f} "
+              f"budget {out[f's{step}.log.train_budget_loss']:.4f} grains {np.bincount(out[f's{step}.grain'].reshape(-1), minlength=3)} "
+              f"min gap {min(out[f's{step}.o0.gap'].min(), out[f's{step}.o1.gap'].min()):.2e}")
+    o = ots.triple_schedule_steps(out)
+    skip = tuple(kk for kk in out if kk.endswith((".perm", ".grain")))
+    missing = [kk for kk in out if kk not in o and not kk.startswith(("state_", "param_keys")) and kk not in skip]
+    assert not missing, missing
+    meta = {kk: out[kk] for kk in ("state_keys", "state_shapes", "param_keys")}
+    p0 = ots.sampled_start_param(meta, TRAIN_STEP_TRIPLE["k"], TRAIN_STEP_TRIPLE["zc"], train_step_stride,
+                                 scale={"encoder.router.gate.2.weight": TRAIN_STEP_TRIPLE["last_gate_scale"]})
+    summ = ots.summarize(ots.compare_records(o, out, start_param=p0, skip=skip))
+    for (step, grp), err in sorted(summ.items()):
+        if not grp.startswith("scalar:train_"):
+            print(f"  pin train_step.triple.{step}.{grp:24s} err={err:.3e}")
+    bad = ots.check_summary(summ)
+    if bad:
+        raise SystemExit(f"oracle.train_step (triple) does not match the reference: {bad}")
+    np.savez_compressed(os.path.join(GOLD, "train_step_triple.npz"), **out)
     # ---- stage 2 ----
     from golden_cfg import TRAIN_STEP_S2
     out = run_reference_dualformer_steps()
