@@ -22,7 +22,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdvq_hip.so")
 LIB_PROBES = os.path.join(HERE, "libdvq_hip_probes.so")
 PROBE_SOURCES = ["conv_halo2.hip"]          # compiled and linked into the probe library only
-SOURCES = ["vq.hip", "entropy.hip", "groupnorm.hip", "igemm.hip", "conv_halo.hip", "misc.hip", "lossnet.hip", "router.hip", "permuter.hip", "transformer.hip", "attention.hip", "imgproc.hip", "decode.hip", "cmdlist.hip"]
+SOURCES = ["vq.hip", "entropy.hip", "groupnorm.hip", "igemm.hip", "conv_halo.hip", "misc.hip", "lossnet.hip", "router.hip", "permuter.hip", "transformer.hip", "attention.hip", "attention2.hip", "imgproc.hip", "decode.hip", "cmdlist.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 # per-file additions.  vq.hip: no SLP vectorisation -- it pairs the scalar fp32 bookkeeping between the MFMAs of the argmin main loop
 # into v_pk_fma_f32 / v_pk_add_f32, which issue more slowly beside a busy matrix pipe than the two instructions they replace

@@ -23,6 +23,7 @@
 // fragments (padded rows: conflict-free ds_read_b128 / ds_read_b64).  Waves beyond their causal range idle for <= 3 tiles.
 #include <type_traits>
 
+#include "attn_v2.h"
 #include "dvq_common.h"
 
 namespace {
@@ -684,6 +685,26 @@ int fill_params(AttnParams& p, const char* who, int dtype, int64_t B, int64_t T,
     return DVQ_OK;
 }
 
+// head size 128 runs on the round-6 kernels (attention2.hip: LDS-DMA ring, transpose reads instead of channel-major copies);
+// DVQ_ATTN_V2=0 keeps the first generation for A/B runs
+static bool attn_v2_env() {
+    static const bool v = [] {
+        const char* e = getenv("DVQ_ATTN_V2");
+        return e == nullptr || atoi(e) != 0;
+    }();
+    return v;
+}
+Attn2Args v2_args(const AttnParams& p, int64_t B) {
+    Attn2Args a{};
+    a.q = p.q; a.k = p.k; a.v = p.v; a.o = p.o; a.dout = p.dout;
+    a.out = p.out; a.dq = p.dq; a.dk = p.dk; a.dv = p.dv;
+    a.lse = p.lse; a.dsum = p.dsum;
+    a.B = (int)B; a.T = p.T; a.nh = p.nh;
+    a.scale = p.scale; a.inv_keep = p.inv_keep; a.thr = p.thr; a.rm = p.rm; a.ra = p.ra;
+    a.mask = p.mask;
+    return a;
+}
+
 }  // namespace
 
 extern "C" {
@@ -706,11 +727,16 @@ int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, 
     AttnParams p{};
     int rc = fill_params(p, "dvq_attn_causal_fwd", dtype, B, T, n_head, head_dim, scale, p_drop, seed);
     if (rc != DVQ_OK) return rc;
-    rc = dvq_transpose(v, dtype, B, T, p.C, scratch, stream);                        // v^T [B][C][T]
-    if (rc != DVQ_OK) return rc;
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.vt = (const bf16_t*)scratch;
     p.out = (bf16_t*)out; p.lse = lse;
     p.mask = (unsigned long long*)drop_mask;
+    if (head_dim == 128 && attn_v2_env()) {
+        dvq_attn2_fwd(v2_args(p, B), (hipStream_t)stream);
+        DVQ_CHECK_LAUNCH("attn_causal_fwd");
+        return DVQ_OK;
+    }
+    rc = dvq_transpose(v, dtype, B, T, p.C, scratch, stream);                        // v^T [B][C][T]
+    if (rc != DVQ_OK) return rc;
     const int nqt = (int)((T + 31) / 32);
     const dim3 grid((unsigned)((nqt + 3) / 4), (unsigned)(B * n_head));
     if (head_dim == 64) launch_fwd<64>(p, grid, (hipStream_t)stream);
@@ -731,14 +757,19 @@ int dvq_attn_causal_bwd(const void* q, const void* k, const void* v, const void*
     bf16_t* kt = qt + elems;
     bf16_t* dot = kt + elems;
     float* dsum = reinterpret_cast<float*>(dot + elems);
-    if ((rc = dvq_transpose(q, dtype, B, T, p.C, qt, stream)) != DVQ_OK) return rc;
-    if ((rc = dvq_transpose(k, dtype, B, T, p.C, kt, stream)) != DVQ_OK) return rc;
-    if ((rc = dvq_transpose(dout, dtype, B, T, p.C, dot, stream)) != DVQ_OK) return rc;
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (const bf16_t*)out; p.dout = (const bf16_t*)dout;
     p.qt = qt; p.kt = kt; p.dot = dot;
     p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
     p.lse = const_cast<float*>(lse); p.dsum = dsum;
     p.mask = (unsigned long long*)const_cast<void*>(drop_mask);
+    if (head_dim == 128 && attn_v2_env()) {
+        dvq_attn2_bwd(v2_args(p, B), (hipStream_t)stream);
+        DVQ_CHECK_LAUNCH("attn_causal_bwd");
+        return DVQ_OK;
+    }
+    if ((rc = dvq_transpose(q, dtype, B, T, p.C, qt, stream)) != DVQ_OK) return rc;
+    if ((rc = dvq_transpose(k, dtype, B, T, p.C, kt, stream)) != DVQ_OK) return rc;
+    if ((rc = dvq_transpose(dout, dtype, B, T, p.C, dot, stream)) != DVQ_OK) return rc;
     const int nt = (int)((T + 31) / 32);
     const dim3 grid((unsigned)((nt + 3) / 4), (unsigned)(B * n_head));
     if (head_dim == 64) launch_bwd<64>(p, grid, B * T, (hipStream_t)stream);

@@ -1,0 +1,18 @@
+// Internal interface between attention.hip (C ABI entry points, geometry checks) and attention2.hip (the round-6 causal kernels for
+// head size 128).  Not part of include/dvq_hip.h.
+#pragma once
+#include "dvq_common.h"
+
+struct Attn2Args {
+    const bf16_t *q, *k, *v, *o, *dout;      // [B*T][C] row-major, C = nh * 128
+    bf16_t *out, *dq, *dk, *dv;
+    float* lse;                              // [B][nh][T]
+    float* dsum;                             // [B][nh][T]: rowsum(dO * O), written by the dQ kernel, read by the dK / dV kernels
+    int B, T, nh;
+    float scale, inv_keep;
+    unsigned thr, rm, ra;                    // dropout: keep iff dvq_hash32(idx * rm + ra) >= thr (thr == 0: no dropout)
+    unsigned long long* mask;                // optional keep-decision words (attention.hip: drop_tile)
+};
+
+int dvq_attn2_fwd(const Attn2Args& a, hipStream_t stream);
+int dvq_attn2_bwd(const Attn2Args& a, hipStream_t stream);
