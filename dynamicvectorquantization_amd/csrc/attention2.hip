@@ -146,6 +146,24 @@ struct TileDma {
     }
 };
 
+// Workgroup -> (block x of the sequence, (batch, head) bh).  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs
+// (private L2 each).  order 1 (DVQ_ATTN2_ORDER=1, needs BH % 8 == 0): the nx blocks of one (batch, head) get ids 8 (nx m + x) + c, bh = 8 m + c --
+// they start together on the SAME XCD and walk the same operand tiles at about the same time, so a tile is fetched from HBM / MALL once
+// and the re-reads are L2 hits.  order 0 (default): x major, longest blocks of every (batch, head) first -- measured faster at the p6c18
+// geometry (forward 0.082 vs 0.098 ms, backward 0.302 vs 0.329): the tail of short workgroups matters more than the L2 hit rate, and
+// with BH % 8 == 0 the blocks of one (batch, head) share an XCD in this order too.
+__device__ __forceinline__ void decode_block(int id, int BH, int nx, int order, int& x, int& bh) {
+    if (order == 1) {
+        const int c = id & 7, j = id >> 3;
+        const int m = j / nx;
+        x = j - m * nx;
+        bh = 8 * m + c;
+    } else {
+        x = id / BH;
+        bh = id - x * BH;
+    }
+}
+
 __device__ __forceinline__ int64_t drop_tile(int bh, int nt, int qt, int kt) { return (((int64_t)bh * nt + qt) * nt + kt) * 16; }
 
 // [ch][row] accumulators (4 tiles of 32 channels) -> row-major [row][128 channels] bf16: lane = row, 4 consecutive channels per
@@ -175,9 +193,10 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p) {
     const Geo g(lane);
     const int l31 = g.l31, half = g.half;
     const int T = p.T, C = p.nh * HS, BH = p.B * p.nh;
-    const int x = blockIdx.x / BH, bh = blockIdx.x - x * BH;      // x = 0: the last (longest) query tiles
-    const int b = bh / p.nh, h = bh - b * p.nh;
     const int nqt = (T + 31) >> 5;
+    int x, bh;                                                    // x = 0: the last (longest) query tiles
+    decode_block(blockIdx.x, BH, (nqt + 3) >> 2, p.order, x, bh);
+    const int b = bh / p.nh, h = bh - b * p.nh;
     const int qt_max = nqt - 1 - 4 * x;
     const int qt = qt_max - wave;                                 // wave 0 owns the last tile of the group
     const bool active = qt >= 0;
@@ -319,9 +338,10 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(Attn2Args p) {
     const Geo g(lane);
     const int l31 = g.l31, half = g.half;
     const int T = p.T, C = p.nh * HS, BH = p.B * p.nh;
-    const int x = blockIdx.x / BH, bh = blockIdx.x - x * BH;
-    const int b = bh / p.nh, h = bh - b * p.nh;
     const int nqt = (T + 31) >> 5;
+    int x, bh;
+    decode_block(blockIdx.x, BH, (nqt + 3) >> 2, p.order, x, bh);
+    const int b = bh / p.nh, h = bh - b * p.nh;
     const int qt_max = nqt - 1 - 4 * x;
     const int qt = qt_max - wave;
     const bool active = qt >= 0;
@@ -437,9 +457,10 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args p) {
     const Geo g(lane);
     const int l31 = g.l31, half = g.half;
     const int T = p.T, C = p.nh * HS, BH = p.B * p.nh;
-    const int x = blockIdx.x / BH, bh = blockIdx.x - x * BH;      // x = 0: the first (longest) key tiles
-    const int b = bh / p.nh, h = bh - b * p.nh;
     const int nt = (T + 31) >> 5;
+    int x, bh;                                                    // x = 0: the first (longest) key tiles
+    decode_block(blockIdx.x, BH, (nt + 3) >> 2, p.order, x, bh);
+    const int b = bh / p.nh, h = bh - b * p.nh;
     const int kt_min = 4 * x;
     const int kt = kt_min + wave;
     const bool active = kt < nt;
@@ -539,8 +560,17 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args p) {
 #endif
 }
 
+static int order_env() {
+    static const int v = [] {
+        const char* e = getenv("DVQ_ATTN2_ORDER");
+        return e == nullptr ? 0 : atoi(e);
+    }();
+    return v;
+}
+
 template <typename K>
-void launch(K kernel, const Attn2Args& a, int lds, hipStream_t stream) {
+void launch(K kernel, Attn2Args a, int lds, hipStream_t stream) {
+    a.order = (a.B * a.nh) % 8 == 0 ? order_env() : 0;
     const int nt = (a.T + 31) / 32;
     const dim3 grid((unsigned)(((nt + 3) / 4) * a.B * a.nh));
     dvq_ensure_dynamic_lds((const void*)kernel, lds);

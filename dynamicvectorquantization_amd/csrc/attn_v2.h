@@ -12,6 +12,7 @@ struct Attn2Args {
     float scale, inv_keep;
     unsigned thr, rm, ra;                    // dropout: keep iff dvq_hash32(idx * rm + ra) >= thr (thr == 0: no dropout)
     unsigned long long* mask;                // optional keep-decision words (attention.hip: drop_tile)
+    int order;                               // workgroup numbering (attention2.hip: decode_block); set by the launcher
 };
 
 int dvq_attn2_fwd(const Attn2Args& a, hipStream_t stream);

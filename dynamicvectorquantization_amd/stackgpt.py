@@ -117,11 +117,13 @@ class CausalSelfAttention(nn.Module):
             # one kernel per direction, scores stay in registers (csrc/attention.hip)
             p_drop = self.attn_drop.p if self.training else 0.0
             seed = _next_seed() if p_drop > 0.0 else 0
-            # DVQ_ATTN_DROP_MASK=1: the forward leaves its keep decisions (1 bit per score) for the three backward kernels instead of
-            # each hashing every element again.  Measured on the p6c18 step: 84.14 vs 84.06 ms -- the backward kernels wait on
-            # LDS refills and barriers, not on VALU issue (profiles/r04_attn_bwd_probe.txt) -- so the 20 MB per layer stay unspent
+            # the forward leaves its keep decisions (1 bit per score, 14 MB per layer at the p6c18 geometry) for the three backward
+            # kernels instead of each hashing every element again (19 of ~30 vector-ALU issue slots per score).  With the first-generation
+            # kernels this bought nothing (84.14 vs 84.06 ms per step: they waited on LDS refills and barriers,
+            # profiles/r04_attn_bwd_probe.txt); with the round-6 kernels (csrc/attention2.hip) the backward is 0.301 instead of 0.437 ms
+            # per layer.  DVQ_ATTN_DROP_MASK=0: rehash
             dm = None
-            if tape is not None and p_drop > 0.0 and os.environ.get("DVQ_ATTN_DROP_MASK", "0") == "1":
+            if tape is not None and p_drop > 0.0 and os.environ.get("DVQ_ATTN_DROP_MASK", "1") == "1":
                 dm = K.attn_causal_drop_mask(q, b, t, nh)
             y, lse = K.attn_causal_fwd(q, k, v, b, t, nh, 1.0 / math.sqrt(hs), p_drop, seed, drop_mask=dm)
             if tape is not None:
