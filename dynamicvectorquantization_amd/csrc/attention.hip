@@ -702,6 +702,7 @@ Attn2Args v2_args(const AttnParams& p, int64_t B) {
     a.B = (int)B; a.T = p.T; a.nh = p.nh;
     a.scale = p.scale; a.inv_keep = p.inv_keep; a.thr = p.thr; a.rm = p.rm; a.ra = p.ra;
     a.mask = p.mask;
+    a.causal = p.causal;
     return a;
 }
 
@@ -790,10 +791,15 @@ int dvq_attn_full_fwd(const void* q, const void* k, const void* v, int dtype, in
     AttnParams p{};
     int rc = fill_params(p, "dvq_attn_full_fwd", dtype, B, T, 1, C, scale, 0.f, 0, 0);
     if (rc != DVQ_OK) return rc;
-    rc = dvq_transpose(v, dtype, B, T, p.C, scratch, stream);                        // v^T [B][C][T]
-    if (rc != DVQ_OK) return rc;
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.vt = (const bf16_t*)scratch;
     p.out = (bf16_t*)out; p.lse = lse;
+    if (C == 256 && attn_v2_env()) {
+        dvq_attn2_fwd(v2_args(p, B), (hipStream_t)stream);
+        DVQ_CHECK_LAUNCH("attn_full_fwd");
+        return DVQ_OK;
+    }
+    rc = dvq_transpose(v, dtype, B, T, p.C, scratch, stream);                        // v^T [B][C][T]
+    if (rc != DVQ_OK) return rc;
     const int nqt = (int)(T / 32);
     launch_fwd<256>(p, dim3((unsigned)((nqt + 3) / 4), (unsigned)B), (hipStream_t)stream);
     DVQ_CHECK_LAUNCH("attn_full_fwd");
@@ -811,13 +817,18 @@ int dvq_attn_full_bwd(const void* q, const void* k, const void* v, const void* o
     bf16_t* kt = qt + elems;
     bf16_t* dot = kt + elems;
     float* dsum = reinterpret_cast<float*>(dot + elems);
-    if ((rc = dvq_transpose(q, dtype, B, T, p.C, qt, stream)) != DVQ_OK) return rc;
-    if ((rc = dvq_transpose(k, dtype, B, T, p.C, kt, stream)) != DVQ_OK) return rc;
-    if ((rc = dvq_transpose(dout, dtype, B, T, p.C, dot, stream)) != DVQ_OK) return rc;
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (const bf16_t*)out; p.dout = (const bf16_t*)dout;
     p.qt = qt; p.kt = kt; p.dot = dot;
     p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
     p.lse = const_cast<float*>(lse); p.dsum = dsum;
+    if (C == 256 && attn_v2_env()) {
+        dvq_attn2_bwd(v2_args(p, B), (hipStream_t)stream);
+        DVQ_CHECK_LAUNCH("attn_full_bwd");
+        return DVQ_OK;
+    }
+    if ((rc = dvq_transpose(q, dtype, B, T, p.C, qt, stream)) != DVQ_OK) return rc;
+    if ((rc = dvq_transpose(k, dtype, B, T, p.C, kt, stream)) != DVQ_OK) return rc;
+    if ((rc = dvq_transpose(dout, dtype, B, T, p.C, dot, stream)) != DVQ_OK) return rc;
     const int nt = (int)(T / 32);
     launch_bwd<256>(p, dim3((unsigned)((nt + 3) / 4), (unsigned)B), B * T, (hipStream_t)stream);
     DVQ_CHECK_LAUNCH("attn_full_bwd");

@@ -31,9 +31,6 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int HS = 128;
-constexpr int ROWB = 256;               // bytes of an LDS row: 128 bf16 channels
-constexpr int TILEB = 64 * ROWB;        // one 64-row operand tile: 16 KiB
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -43,6 +40,19 @@ union Frag {
     uint4 u;
     bf16x8 v;
     uint2 h[2];
+};
+
+// head-size dependent geometry: LDS rows of HS bf16 channels, 64-row operand tiles, 1-KiB DMA pieces
+template <int HS>
+struct Cfg {
+    static constexpr int ROWB = HS * 2;             // bytes of an LDS row
+    static constexpr int TILEB = 64 * ROWB;         // one 64-row operand tile: 16 KiB (128) / 32 KiB (256)
+    static constexpr int NS = HS / 16;              // 16-channel k-steps of the first GEMMs
+    static constexpr int NM = HS / 32;              // 32-channel accumulator tiles of the second GEMMs
+    static constexpr int CPR = ROWB / 16;           // 16-byte chunks per row
+    static constexpr int RPP = 1024 / ROWB;         // rows per DMA piece
+    static constexpr int NPW = 64 / RPP / 4;        // pieces per wave and tile
+    static constexpr int WPC = HS <= 128 ? 2 : 1;   // workgroups per CU (registers: 2 x 256 or 1 x 512 per SIMD lane)
 };
 
 // accumulator register r of half `half` -> row inside the 32-row tile; ccol: the part that does not depend on the lane
@@ -71,6 +81,18 @@ __device__ __forceinline__ bf16x8 ldfrag(const bf16_t* p, bool ok) {
     return f.v;
 }
 
+// reductions over the two 32-lane halves (lanes l and l + 32 hold the same query / key): v_permlane32_swap_b32 exchanges the upper half of
+// its first operand with the lower half of its second -- fed the same value twice it returns {low half everywhere, high half everywhere}
+// (one VALU instruction instead of a ds_bpermute round trip through the LDS)
+__device__ __forceinline__ float half_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // buffer descriptor in SGPRs: reads at or past `bytes` return zero (rows >= T of a (batch) slice)
 __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;
@@ -96,17 +118,22 @@ __device__ __forceinline__ void dma_barrier() {
     __syncthreads();
 }
 
+// swizzle of the LDS image: 16-byte chunk c of row r sits at chunk position c ^ swz(r) (low four bits of the chunk index only: the two
+// 256-byte halves of a head-size-256 row swizzle alike)
+__device__ __forceinline__ int swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
 // Lane constants of the LDS image (see the header): row-fragment reads and transpose reads of a 64-row tile
+template <int HS>
 struct Geo {
+    static constexpr int ROWB = Cfg<HS>::ROWB;
     int l31, half;
-    int roff, rx;               // row fragments: row l31, chunk (2 st + half) ^ f(l31)  ->  byte (st << 5) ^ rx
-    int trow, tmx, tcol[2];     // transpose reads: row 4 half + (li >> 2) (+ 8 for the second read), chunk (4 mt + cl) ^ f(row)
+    int roff, rx;               // row fragments: row l31, chunk (2 st + half) ^ swz(l31)  ->  byte (st << 5) ^ rx
+    int trow, tmx, tcol[2];     // transpose reads: row 4 half + (li >> 2) (+ 8 for the second read), chunk (4 mt + cl) ^ swz(row)
     __device__ __forceinline__ explicit Geo(int lane) {
         l31 = lane & 31;
         half = lane >> 5;
-        const int f = ((l31 & 3) << 2) | ((l31 >> 2) & 3);
         roff = l31 * ROWB;
-        rx = (half ^ f) << 4;
+        rx = (half ^ swz(l31)) << 4;
         const int g = lane >> 4, li = lane & 15;
         const int cl = 2 * (g & 1) + ((li & 3) >> 1);
         trow = (4 * half + (li >> 2)) * ROWB;
@@ -127,22 +154,24 @@ struct Geo {
     }
 };
 
-// DMA of one 64-row tile of a row-major [rows][C] matrix (head slice of 128 channels): wave w moves pieces 4 w .. 4 w + 3 (rows
-// 16 w + 4 e + (lane >> 4)); position lane & 15 of a row receives source chunk (lane & 15) ^ f(row)
+// DMA of one 64-row tile of a row-major [rows][C] matrix (head slice of HS channels): wave w moves pieces NPW w .. NPW w + NPW - 1
+// (RPP rows each); position (lane % CPR) of a row receives source chunk (lane % CPR) ^ swz(row)
+template <int HS>
 struct TileDma {
-    int voff[4];
+    using G = Cfg<HS>;
+    int voff[G::NPW];
     __device__ __forceinline__ TileDma(int lane, int wave, int C, int h) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = 16 * wave + 4 * e + (lane >> 4);
-            const int c = (lane & 15) ^ (((lane >> 4) << 2) | e);
+        for (int e = 0; e < G::NPW; ++e) {
+            const int row = (wave * G::NPW + e) * G::RPP + lane / G::CPR;
+            const int c = (lane % G::CPR) ^ swz(row);
             voff[e] = (row * C + h * HS + c * 8) * 2;
         }
     }
     __device__ __forceinline__ void issue(const i32x4& rs, int row0, int C, unsigned lds_tile, int wave) const {
         const int so = __builtin_amdgcn_readfirstlane(row0 * C * 2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dma16(lds_tile + (unsigned)((4 * wave + e) * 1024), voff[e], rs, so);
+        for (int e = 0; e < G::NPW; ++e) dma16(lds_tile + (unsigned)((G::NPW * wave + e) * 1024), voff[e], rs, so);
     }
 };
 
@@ -166,11 +195,12 @@ __device__ __forceinline__ void decode_block(int id, int BH, int nx, int order, 
 
 __device__ __forceinline__ int64_t drop_tile(int bh, int nt, int qt, int kt) { return (((int64_t)bh * nt + qt) * nt + kt) * 16; }
 
-// [ch][row] accumulators (4 tiles of 32 channels) -> row-major [row][128 channels] bf16: lane = row, 4 consecutive channels per
+// [ch][row] accumulators (NM tiles of 32 channels) -> row-major [row][HS channels] bf16: lane = row, 4 consecutive channels per
 // register quad (8-byte stores)
-__device__ __forceinline__ void store_ct(bf16_t* dst /* row base + head offset */, const f32x16 (&acc)[4], int half, float mul) {
+template <int NM>
+__device__ __forceinline__ void store_ct(bf16_t* dst /* row base + head offset */, const f32x16 (&acc)[NM], int half, float mul) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < NM; ++mt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 w;
@@ -181,20 +211,27 @@ __device__ __forceinline__ void store_ct(bf16_t* dst /* row base + head offset *
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// forward: one wave per 32 queries, four neighbouring query tiles per workgroup; the workgroup walks 64-key tiles 0 .. diagonal.
-// LDS: 2 stages x (K 16 KiB | V 16 KiB) = 64 KiB, two workgroups per CU.
+// forward: one wave per 32 queries, four neighbouring query tiles per workgroup; the workgroup walks the 64-key tiles (causal: 0 ..
+// diagonal).  LDS: 2 K slots + 2 V slots of one tile each (64 KiB at head size 128: two workgroups per CU; 128 KiB at 256: one).
+// Tried and removed (round 6): software pipelining over key tiles inside the wave -- the score MFMAs of tile kt + 1 issued beside the
+// softmax of tile kt, K one tile further ahead than V in the ring, issue order pinned by sched_group_barrier.  The second score
+// accumulator pair and the compiler's hoisted fragment reads pushed the kernel over its register budget (42 - 84 spilled registers at
+// head size 128, 155 plus 1300 accumulator-file moves at 256); scratch reloads drain the DMA queue (vmcnt counts both), and the
+// forward ran 0.102 (0.276 with dropout) instead of 0.066 (0.086) ms at the p6c18 geometry, 0.379 instead of 0.148 ms at head size 256.
 // ------------------------------------------------------------------------------------------------------------------
-template <bool DROP, bool WMASK>
-__global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p) {
+template <int HS, bool CAUSAL, bool DROP, bool WMASK>
+__global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_fwd_kernel(Attn2Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    using G = Cfg<HS>;
+    constexpr int NS = G::NS, NM = G::NM, TILEB = G::TILEB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const Geo g(lane);
+    const Geo<HS> g(lane);
     const int l31 = g.l31, half = g.half;
     const int T = p.T, C = p.nh * HS, BH = p.B * p.nh;
     const int nqt = (T + 31) >> 5;
-    int x, bh;                                                    // x = 0: the last (longest) query tiles
+    int x, bh;                                                    // x = 0: the last (causal: longest) query tiles
     decode_block(blockIdx.x, BH, (nqt + 3) >> 2, p.order, x, bh);
     const int b = bh / p.nh, h = bh - b * p.nh;
     const int qt_max = nqt - 1 - 4 * x;
@@ -204,44 +241,38 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p) {
     const bool qok = active && qrow < T;
     const int64_t rowbase = (int64_t)b * T;
     const i32x4 rsK = make_rsrc(p.k + rowbase * C, (unsigned)(T * C * 2)), rsV = make_rsrc(p.v + rowbase * C, (unsigned)(T * C * 2));
-    const TileDma dma(lane, wave, C, h);
+    const TileDma<HS> dma(lane, wave, C, h);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
-    auto stage = [&](int kt) {
-        const unsigned base = lds0 + (unsigned)((kt & 1) * 2 * TILEB);
-        dma.issue(rsK, 64 * kt, C, base, wave);
-        dma.issue(rsV, 64 * kt, C, base + TILEB, wave);
-    };
-    const int nk = (qt_max >> 1) + 1;                              // 64-key tiles 0 .. the one holding key tile qt_max
-    stage(0);
-    bf16x8 qf[8];
+    // slots: K tiles at [0, 2 TILEB), V tiles at [2 TILEB, 4 TILEB)
+    auto issue_k = [&](int kt) { dma.issue(rsK, 64 * kt, C, lds0 + (unsigned)((kt & 1) * TILEB), wave); };
+    auto issue_v = [&](int kt) { dma.issue(rsV, 64 * kt, C, lds0 + (unsigned)((2 + (kt & 1)) * TILEB), wave); };
+    const int last_t = CAUSAL ? qt_max : nqt - 1;                  // last 32-key tile any wave of the workgroup sees
+    const int nk = (last_t >> 1) + 1;                              // 64-key tiles
+    const int my_last = CAUSAL ? qt : nqt - 1;                     // last 32-key tile THIS wave sees
+    auto vis = [&](int t32) { return active && t32 <= my_last; };
+    issue_k(0);
+    bf16x8 qf[NS];
     {
         const bf16_t* qp = p.q + (rowbase + qrow) * C + h * HS + 8 * half;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) qf[s] = ldfrag(qp + 16 * s, qok);
+        for (int s = 0; s < NS; ++s) qf[s] = ldfrag(qp + 16 * s, qok);
     }
-    f32x16 oacc[4];
+    f32x16 oacc[NM];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) oacc[mt] = zero16();
+    for (int mt = 0; mt < NM; ++mt) oacc[mt] = zero16();
     float m_run = -INFINITY, l_run = 0.f;                         // running max (log2 domain, scaled) and sum
     const float c2 = p.scale * LOG2E;
     const unsigned xrow = ((unsigned)(((int64_t)bh * T + qrow) * T) + 4u * half) * p.rm + p.ra;   // dropout: hash input of key 0
 
-    for (int kt = 0; kt < nk; ++kt) {
-        dma_barrier();                                            // tile kt has landed; everybody is done with the other stage
-        if (kt + 1 < nk) stage(kt + 1);
-        const char* kl = smem + (kt & 1) * 2 * TILEB;
-        const char* vl = kl + TILEB;
-        const int t0 = 2 * kt;
-        if (active && t0 <= qt) {
-            const bool two = t0 < qt;                             // the second 32-key tile is (partly) visible too
-            f32x16 s0 = zero16(), s1 = zero16();
+    auto scores = [&](const char* kl, int sub) {
+        f32x16 s = zero16();
 #pragma unroll
-            for (int st = 0; st < 8; ++st) s0 = MFMA(g.rfrag(kl, 0, st), qf[st], s0);
-            if (two) {
-#pragma unroll
-                for (int st = 0; st < 8; ++st) s1 = MFMA(g.rfrag(kl, 1, st), qf[st], s1);
-            }
-            // causal mask on the diagonal tile (keys >= T lie above the diagonal of every valid query)
+        for (int st = 0; st < NS; ++st) s = MFMA(g.rfrag(kl, sub, st), qf[st], s);
+        return s;
+    };
+    // online softmax of one 64-key tile held as two accumulators (s1 only if `two`), dropout, P V
+    auto softmax_pv = [&](f32x16 s0, f32x16 s1, int t0, bool two, const char* vl) {
+        if constexpr (CAUSAL) {                                   // diagonal tile (keys >= T lie above the diagonal of every valid query)
             if (t0 == qt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s0[r] = 32 * t0 + crow(r, half) <= qrow ? s0[r] : -INFINITY;
@@ -249,77 +280,98 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s1[r] = 32 * t0 + 32 + crow(r, half) <= qrow ? s1[r] : -INFINITY;
             }
-            float mraw = s0[0];
+        }
+        float mraw = s0[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mraw = fmaxf(mraw, s0[r]);
-            if (two) {
+        for (int r = 1; r < 16; ++r) mraw = fmaxf(mraw, s0[r]);
+        if (two) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mraw = fmaxf(mraw, s1[r]);
-            }
-            mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
-            const float mx = fmaxf(m_run, mraw * c2);
-            const float mref = mx == -INFINITY ? 0.f : mx;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - mref);
-            float rs = 0.f;
+            for (int r = 0; r < 16; ++r) mraw = fmaxf(mraw, s1[r]);
+        }
+        mraw = half_max(mraw);
+        const float mx = fmaxf(m_run, mraw * c2);
+        const float mref = mx == -INFINITY ? 0.f : mx;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - mref);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, -mref));
+            rs += s0[r];
+        }
+        if (two) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, -mref));
-                rs += s0[r];
+                s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, -mref));
+                rs += s1[r];
             }
-            if (two) {
+        }
+        rs = half_sum(rs);
+        l_run = l_run * alpha + rs;
+        m_run = mx;
+        if (!__all(alpha == 1.f)) {                               // the running maximum settles after a few tiles
+#pragma unroll
+            for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+        }
+        if constexpr (DROP) {
+            auto drop = [&](f32x16& s, int t32) {
+                const unsigned xb = xrow + (unsigned)(32 * t32) * p.rm;
+                unsigned long long mine = 0;                     // lane r keeps the ballot of register r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, -mref));
-                    rs += s1[r];
-                }
-            }
-            rs += __shfl_xor(rs, 32, 64);
-            l_run = l_run * alpha + rs;
-            m_run = mx;
-            if (!__all(alpha == 1.f)) {                           // the running maximum settles after a few tiles
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
-            }
-            if constexpr (DROP) {
-                auto drop = [&](f32x16& s, int t32) {
-                    const unsigned xb = xrow + (unsigned)(32 * t32) * p.rm;
-                    unsigned long long mine = 0;                 // lane r keeps the ballot of register r
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const bool keep = dvq_hash32(xb + (unsigned)ccol(r) * p.rm) >= p.thr;
-                        if constexpr (WMASK) {
-                            const unsigned long long m = __ballot(keep);
-                            mine = lane == r ? m : mine;
-                        }
-                        s[r] = keep ? s[r] * p.inv_keep : 0.f;
-                    }
+                    const bool keep = dvq_hash32(xb + (unsigned)ccol(r) * p.rm) >= p.thr;
                     if constexpr (WMASK) {
-                        if (lane < 16) p.mask[drop_tile(bh, nqt, qt, t32) + lane] = mine;
+                        const unsigned long long m = __ballot(keep);
+                        mine = lane == r ? m : mine;
                     }
-                };
-                drop(s0, t0);
-                if (two) drop(s1, t0 + 1);
-            }
+                    s[r] = keep ? s[r] * p.inv_keep : 0.f;
+                }
+                if constexpr (WMASK) {
+                    if (lane < 16) p.mask[drop_tile(bh, nqt, qt, t32) + lane] = mine;
+                }
+            };
+            drop(s0, t0);
+            if (two) drop(s1, t0 + 1);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = pack8(s0, s2);
+#pragma unroll
+            for (int mt = 0; mt < NM; ++mt) oacc[mt] = MFMA(g.tfrag(vl, 0, mt, s2), pf, oacc[mt]);
+        }
+        if (two) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pf = pack8(s0, s2);
+                const bf16x8 pf = pack8(s1, s2);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) oacc[mt] = MFMA(g.tfrag(vl, 0, mt, s2), pf, oacc[mt]);
+                for (int mt = 0; mt < NM; ++mt) oacc[mt] = MFMA(g.tfrag(vl, 1, mt, s2), pf, oacc[mt]);
             }
-            if (two) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 pf = pack8(s1, s2);
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) oacc[mt] = MFMA(g.tfrag(vl, 1, mt, s2), pf, oacc[mt]);
-                }
+        }
+    };
+
+    {
+        issue_v(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            dma_barrier();                                        // tile kt has landed; everybody is done with the other slots
+            if (kt + 1 < nk) {
+                issue_k(kt + 1);
+                issue_v(kt + 1);
+            }
+            const char* kl = smem + (kt & 1) * TILEB;
+            const char* vl = smem + (2 + (kt & 1)) * TILEB;
+            const int t0 = 2 * kt;
+            if (vis(t0)) {
+                const bool two = vis(t0 + 1);
+                const f32x16 s0 = scores(kl, 0);
+                f32x16 s1 = zero16();
+                if (two) s1 = scores(kl, 1);
+                softmax_pv(s0, s1, t0, two, vl);
             }
         }
     }
     if (qok) {
-        store_ct(p.out + (rowbase + qrow) * C + h * HS, oacc, half, 1.f / l_run);
+        store_ct<NM>(p.out + (rowbase + qrow) * C + h * HS, oacc, half, 1.f / l_run);
         if (half == 0) p.lse[(int64_t)bh * T + qrow] = (m_run + __builtin_amdgcn_logf(l_run)) * (1.f / LOG2E);
     }
 #endif
@@ -327,15 +379,18 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // backward, dQ: same walk as the forward; per 32-key tile S^T = K Q^T, dP^T = V dO^T, dS^T = P (drop(dP) - D), dQ^T += K^T dS^T.
-// Also leaves D = rowsum(dO * O) in p.dsum for the dK kernel (launched behind this one).  LDS as the forward.
+// Also leaves D = rowsum(dO * O) in p.dsum for the dK kernel (launched behind this one).
+// LDS: 2 stages x (K tile | V tile).
 // ------------------------------------------------------------------------------------------------------------------
-template <bool DROP, bool MASKED>
-__global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(Attn2Args p) {
+template <int HS, bool CAUSAL, bool DROP, bool MASKED>
+__global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_bwd_dq_kernel(Attn2Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    using G = Cfg<HS>;
+    constexpr int NS = G::NS, NM = G::NM, TILEB = G::TILEB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const Geo g(lane);
+    const Geo<HS> g(lane);
     const int l31 = g.l31, half = g.half;
     const int T = p.T, C = p.nh * HS, BH = p.B * p.nh;
     const int nqt = (T + 31) >> 5;
@@ -349,21 +404,23 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(Attn2Args p) {
     const bool qok = active && qrow < T;
     const int64_t rowbase = (int64_t)b * T;
     const i32x4 rsK = make_rsrc(p.k + rowbase * C, (unsigned)(T * C * 2)), rsV = make_rsrc(p.v + rowbase * C, (unsigned)(T * C * 2));
-    const TileDma dma(lane, wave, C, h);
+    const TileDma<HS> dma(lane, wave, C, h);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
     auto stage = [&](int kt) {
         const unsigned base = lds0 + (unsigned)((kt & 1) * 2 * TILEB);
         dma.issue(rsK, 64 * kt, C, base, wave);
         dma.issue(rsV, 64 * kt, C, base + TILEB, wave);
     };
-    const int nk = (qt_max >> 1) + 1;
+    const int last_t = CAUSAL ? qt_max : nqt - 1;
+    const int nk = (last_t >> 1) + 1;
+    const int my_last = CAUSAL ? qt : nqt - 1;
     stage(0);
-    bf16x8 qf[8], dof[8];
+    bf16x8 qf[NS], dof[NS];
     float dq_ = 0.f;                                              // D[query] = sum_ch dO * O
     {
         const int64_t e0 = (rowbase + qrow) * C + h * HS + 8 * half;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < NS; ++s) {
             qf[s] = ldfrag(p.q + e0 + 16 * s, qok);
             dof[s] = ldfrag(p.dout + e0 + 16 * s, qok);
             Frag fo, fd;
@@ -377,13 +434,13 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(Attn2Args p) {
                 dq_ = fmaf(__uint_as_float(a[j] & 0xffff0000u), __uint_as_float(b2[j] & 0xffff0000u), dq_);
             }
         }
-        dq_ += __shfl_xor(dq_, 32, 64);
+        dq_ = half_sum(dq_);
         if (qok && half == 0) p.dsum[(int64_t)bh * T + qrow] = dq_;
     }
     const float nlq = qok ? -p.lse[(int64_t)bh * T + qrow] * LOG2E : 0.f;
-    f32x16 acc[4];                                                // dQ^T [ch][query]
+    f32x16 acc[NM];                                               // dQ^T [ch][query]
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = zero16();
+    for (int mt = 0; mt < NM; ++mt) acc[mt] = zero16();
     const float c2 = p.scale * LOG2E;
     const unsigned xrow = ((unsigned)(((int64_t)bh * T + qrow) * T) + 4u * half) * p.rm + p.ra;
 
@@ -395,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(Attn2Args p) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int t32 = 2 * kt + sub;
-            if (!active || t32 > qt) continue;
+            if (!active || t32 > my_last) continue;
             unsigned long long mk[16];                           // the tile's 16 select masks: scalar loads, issued ahead of the first GEMMs
             if constexpr (DROP && MASKED) {
                 const unsigned long long* mw = p.mask + drop_tile(bh, nqt, __builtin_amdgcn_readfirstlane(qt), t32);
@@ -404,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(Attn2Args p) {
             }
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-            for (int st = 0; st < 8; ++st) {
+            for (int st = 0; st < NS; ++st) {
                 s = MFMA(g.rfrag(kl, sub, st), qf[st], s);
                 dp = MFMA(g.rfrag(vl, sub, st), dof[st], dp);
             }
@@ -425,40 +482,41 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(Attn2Args p) {
                     s[r] = pr * (gr - dq_);                       // d loss / d (scaled score)
                 }
             };
-            if (t32 == qt) elementwise(std::true_type{});
+            if (CAUSAL && t32 == qt) elementwise(std::true_type{});
             else elementwise(std::false_type{});
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 df = pack8(s, s2);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA(g.tfrag(kl, sub, mt, s2), df, acc[mt]);
+                for (int mt = 0; mt < NM; ++mt) acc[mt] = MFMA(g.tfrag(kl, sub, mt, s2), df, acc[mt]);
             }
         }
     }
-    if (qok) store_ct(p.dq + (rowbase + qrow) * C + h * HS, acc, half, p.scale);
+    if (qok) store_ct<NM>(p.dq + (rowbase + qrow) * C + h * HS, acc, half, p.scale);
 #endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // backward, dV (MODE 1) or dK (MODE 2): one wave per 32 keys, four neighbouring key tiles per workgroup, which walks the 64-query
-// tiles from its first key tile to the end.  Two launches of 64 accumulator registers each (two waves per SIMD) instead of one of 128;
-// the score tile is computed by both.  LDS: 2 stages x (Q 16 KiB | dO 16 KiB | lse 256 B | D 256 B), two workgroups per CU.
+// tiles (causal: from its first key tile to the end).  Two launches of NM accumulator tiles each instead of one of 2 NM; the score
+// tile is computed by both.  LDS: 2 stages x (Q tile | dO tile | lse 256 B | D 256 B).
 // Rows >= T read as zero everywhere (Q, dO, lse, D): their P = exp2(0) = 1 meets dO = 0 and dS = 1 * (0 - 0), so only the causal
 // diagonal needs a per-element test.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int KV_STAGE = 2 * TILEB + 512;
-template <int MODE, bool DROP, bool MASKED>
-__global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args p) {
+template <int HS, bool CAUSAL, int MODE, bool DROP, bool MASKED>
+__global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_bwd_dkv_kernel(Attn2Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr bool DO_DV = MODE == 1, DO_DK = MODE == 2;
+    using G = Cfg<HS>;
+    constexpr int NS = G::NS, NM = G::NM, TILEB = G::TILEB, KV_STAGE = 2 * TILEB + 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const Geo g(lane);
+    const Geo<HS> g(lane);
     const int l31 = g.l31, half = g.half;
     const int T = p.T, C = p.nh * HS, BH = p.B * p.nh;
     const int nt = (T + 31) >> 5;
-    int x, bh;                                                    // x = 0: the first (longest) key tiles
+    int x, bh;                                                    // x = 0: the first (causal: longest) key tiles
     decode_block(blockIdx.x, BH, (nt + 3) >> 2, p.order, x, bh);
     const int b = bh / p.nh, h = bh - b * p.nh;
     const int kt_min = 4 * x;
@@ -469,9 +527,9 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args p) {
     const int64_t rowbase = (int64_t)b * T;
     const i32x4 rsQ = make_rsrc(p.q + rowbase * C, (unsigned)(T * C * 2)), rsD = make_rsrc(p.dout + rowbase * C, (unsigned)(T * C * 2));
     const i32x4 rsL = make_rsrc(p.lse + (int64_t)bh * T, (unsigned)(T * 4)), rsS = make_rsrc(p.dsum + (int64_t)bh * T, (unsigned)(T * 4));
-    const TileDma dma(lane, wave, C, h);
+    const TileDma<HS> dma(lane, wave, C, h);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
-    const int q64_first = kt_min >> 1, nq64 = (nt + 1) >> 1;
+    const int q64_first = CAUSAL ? kt_min >> 1 : 0, nq64 = (nt + 1) >> 1;
     auto stage = [&](int q64) {
         const unsigned base = lds0 + (unsigned)(((q64 - q64_first) & 1) * KV_STAGE);
         dma.issue(rsQ, 64 * q64, C, base, wave);
@@ -481,18 +539,18 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args p) {
         if (wave == 1) dma4(base + 2 * TILEB + 256, lane * 4, rsS, so);
     };
     stage(q64_first);
-    bf16x8 kf[8], vf[8];
+    bf16x8 kf[NS], vf[NS];
     {
         const int64_t e0 = (rowbase + krow) * C + h * HS + 8 * half;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < NS; ++s) {
             kf[s] = ldfrag(p.k + e0 + 16 * s, kok);
             if constexpr (DO_DK) vf[s] = ldfrag(p.v + e0 + 16 * s, kok);
         }
     }
-    f32x16 acc[4];                                                // dV^T or dK^T [ch][key]
+    f32x16 acc[NM];                                               // dV^T or dK^T [ch][key]
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = zero16();
+    for (int mt = 0; mt < NM; ++mt) acc[mt] = zero16();
     const float c2 = p.scale * LOG2E;
     // dropout: hash input of query 0 of (batch, head) bh for this lane's key; a query row adds T * rm
     const unsigned xkey = ((unsigned)((int64_t)bh * T * T) + (unsigned)krow + 4u * half * (unsigned)T) * p.rm + p.ra;
@@ -509,12 +567,12 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args p) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int qt = 2 * q64 + sub;
-            if (!active || qt < kt || qt >= nt) continue;
+            if (!active || (CAUSAL && qt < kt) || qt >= nt) continue;
             unsigned mword = 0;
             if constexpr (DROP && MASKED) mword = mlane[2 * drop_tile(bh, nt, qt, kt)] >> (4 * half);   // query 8 g + 4 half + i is bit 8 g + i
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-            for (int st = 0; st < 8; ++st) {
+            for (int st = 0; st < NS; ++st) {
                 s = MFMA(g.rfrag(ql, sub, st), kf[st], s);
                 if constexpr (DO_DK) dp = MFMA(g.rfrag(dl, sub, st), vf[st], dp);
             }
@@ -546,17 +604,17 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args p) {
                     }
                 }
             };
-            if (qt == kt) second(std::true_type{});
+            if (CAUSAL && qt == kt) second(std::true_type{});
             else second(std::false_type{});
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 f = pack8(s, s2);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA(g.tfrag(DO_DV ? dl : ql, sub, mt, s2), f, acc[mt]);
+                for (int mt = 0; mt < NM; ++mt) acc[mt] = MFMA(g.tfrag(DO_DV ? dl : ql, sub, mt, s2), f, acc[mt]);
             }
         }
     }
-    if (kok) store_ct((DO_DV ? p.dv : p.dk) + (rowbase + krow) * C + h * HS, acc, half, DO_DV ? 1.f : p.scale);
+    if (kok) store_ct<NM>((DO_DV ? p.dv : p.dk) + (rowbase + krow) * C + h * HS, acc, half, DO_DV ? 1.f : p.scale);
 #endif
 }
 
@@ -577,30 +635,37 @@ void launch(K kernel, Attn2Args a, int lds, hipStream_t stream) {
     kernel<<<grid, dim3(256), lds, stream>>>(a);
 }
 
+template <int HS, bool CAUSAL>
+void fwd_hs(const Attn2Args& a, hipStream_t stream) {
+    const int lds = 4 * Cfg<HS>::TILEB;
+    if (a.thr == 0) launch(attn2_fwd_kernel<HS, CAUSAL, false, false>, a, lds, stream);
+    else if constexpr (CAUSAL) {
+        if (a.mask != nullptr) launch(attn2_fwd_kernel<HS, true, true, true>, a, lds, stream);
+        else launch(attn2_fwd_kernel<HS, true, true, false>, a, lds, stream);
+    }
+}
+
+template <int HS, bool CAUSAL, bool DROP, bool MASKED>
+void bwd_variant(const Attn2Args& a, hipStream_t stream) {
+    const int lds_q = 4 * Cfg<HS>::TILEB, lds_kv = 2 * (2 * Cfg<HS>::TILEB + 512);
+    launch(attn2_bwd_dq_kernel<HS, CAUSAL, DROP, MASKED>, a, lds_q, stream);                // first: it also produces dsum for the dK kernel
+    launch(attn2_bwd_dkv_kernel<HS, CAUSAL, 1, DROP, MASKED>, a, lds_kv, stream);
+    launch(attn2_bwd_dkv_kernel<HS, CAUSAL, 2, DROP, MASKED>, a, lds_kv, stream);
+}
+
 }  // namespace
 
+// causal: head size 128 (dropout optional); full attention: head size 256, no dropout (attention.hip checks the geometry)
 int dvq_attn2_fwd(const Attn2Args& a, hipStream_t stream) {
-    const int lds = 4 * TILEB;
-    if (a.thr == 0) launch(attn2_fwd_kernel<false, false>, a, lds, stream);
-    else if (a.mask != nullptr) launch(attn2_fwd_kernel<true, true>, a, lds, stream);
-    else launch(attn2_fwd_kernel<true, false>, a, lds, stream);
+    if (a.causal) fwd_hs<128, true>(a, stream);
+    else fwd_hs<256, false>(a, stream);
     return DVQ_OK;
 }
 
 int dvq_attn2_bwd(const Attn2Args& a, hipStream_t stream) {
-    const int lds_q = 4 * TILEB, lds_kv = 2 * KV_STAGE;
-    if (a.thr == 0) {
-        launch(attn2_bwd_dq_kernel<false, false>, a, lds_q, stream);            // first: it also produces dsum for the dK kernel
-        launch(attn2_bwd_dkv_kernel<1, false, false>, a, lds_kv, stream);
-        launch(attn2_bwd_dkv_kernel<2, false, false>, a, lds_kv, stream);
-    } else if (a.mask != nullptr) {
-        launch(attn2_bwd_dq_kernel<true, true>, a, lds_q, stream);
-        launch(attn2_bwd_dkv_kernel<1, true, true>, a, lds_kv, stream);
-        launch(attn2_bwd_dkv_kernel<2, true, true>, a, lds_kv, stream);
-    } else {
-        launch(attn2_bwd_dq_kernel<true, false>, a, lds_q, stream);
-        launch(attn2_bwd_dkv_kernel<1, true, false>, a, lds_kv, stream);
-        launch(attn2_bwd_dkv_kernel<2, true, false>, a, lds_kv, stream);
-    }
+    if (!a.causal) bwd_variant<256, false, false, false>(a, stream);
+    else if (a.thr == 0) bwd_variant<128, true, false, false>(a, stream);
+    else if (a.mask != nullptr) bwd_variant<128, true, true, true>(a, stream);
+    else bwd_variant<128, true, true, false>(a, stream);
     return DVQ_OK;
 }

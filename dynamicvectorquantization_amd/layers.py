@@ -824,10 +824,11 @@ class AttnBlock(HipModule):
         q, k, v, p = st["q"], st["k"], st["v"], st["p"]
         impl = rt.impl()
         do = self.proj_out.bwd(dy, tape.child("proj"))
-        if p is None and os.environ.get("DVQ_ATTNBLOCK_BWD", "gemm") == "gemm":
-            # fused forward, backward on the pipelined batched GEMM kernels: the probabilities are recomputed (q k^T, row softmax)
-            # into scratch that lives only inside this call.  Measured against the flash-style backward kernels at head size 256
-            # (attn_bwd_dq / dkv: one wave per SIMD, 512 registers, 170 TFLOP/s): DESIGN.md section 3.
+        if p is None and os.environ.get("DVQ_ATTNBLOCK_BWD", "flash") == "gemm":
+            # DVQ_ATTNBLOCK_BWD=gemm: fused forward, backward on the pipelined batched GEMM kernels -- the probabilities are recomputed
+            # (q k^T, row softmax) into scratch that lives only inside this call.  This was the default while the flash-style backward at
+            # head size 256 ran at 175 TFLOP/s (first-generation kernels, 0.98 ms per call at B 64, T 1024, against 0.68 ms here); the
+            # round-6 kernels (csrc/attention2.hip) take 0.45 ms, so the fused backward below is the default again.
             s = K.gemm_nt(q, k, n, n, c, c, c, n, batch=b, sa=n * c, sb=n * c, sc=n * n, impl=impl)
             p = K.softmax_rows(s, b * n, n, float(int(c) ** (-0.5)))
             del s
