@@ -657,6 +657,20 @@ class Trainer:
         self.model.train()
         best = []                                     # (value, path), ascending
         monitor = getattr(self.model, "monitor", None)
+        if ckpt_path and is_rank0 and save_top_k and monitor:
+            # a resumed run (-r) starts from the monitored checkpoints already on disk (Lightning keeps best_k_models inside the
+            # checkpoint; here the file names carry the value): without this, old files were never compared or pruned again
+            import glob
+            import re
+            pat = re.compile(r"epoch=\d+-" + re.escape(monitor) + r"=(-?\d+(?:\.\d+)?(?:[eE][-+]?\d+)?)\.ckpt$")
+            for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(ckpt_path)), f"epoch=*-{glob.escape(monitor)}=*.ckpt")):
+                mt = pat.search(os.path.basename(f))
+                if mt:
+                    best.append((float(mt.group(1)), f))
+            best.sort(key=lambda t: t[0])
+            for _, old in best[save_top_k:]:
+                os.remove(old)
+            del best[save_top_k:]
 
         def run_validation(step):
             metrics = self.validate(val_fn())

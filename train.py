@@ -180,7 +180,10 @@ def run(rank, world, opt, unknown):
     # the model's `monitor` (val_rec_loss in the shipped stage-1 YAMLs) picks the --save_n best checkpoints kept beside last.ckpt
     val_fn = None
     if opt.check_val_every_n_epoch > 0 and hasattr(model, "validation_step"):
-        if opt.real_data:
+        if opt.real_data and "validation" not in getattr(dm, "datasets", {"validation": None}):
+            if rank == 0:
+                print("the data config has no validation split: training without the validation loop")
+        elif opt.real_data:
             vloader = dm.val_dataloader()
 
             def val_fn():
