@@ -46,7 +46,8 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True, probes: bool = False) -> str:
     obj_dir = OBJ + "_probes" if probes else OBJ
     lib = LIB_PROBES if probes else LIB
-    flags = FLAGS + (["-DDVQ_PROBES"] if probes else [])
+    # DVQ_BUILD_EXTRA_FLAGS: extra compiler flags for A/B builds on the GPU box (e.g. -DDVQ_STREAM_NT=0); use with --force
+    flags = FLAGS + (["-DDVQ_PROBES"] if probes else []) + os.environ.get("DVQ_BUILD_EXTRA_FLAGS", "").split()
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "dvq_common.h"), os.path.join(HERE, "..", "include", "dvq_hip.h")]

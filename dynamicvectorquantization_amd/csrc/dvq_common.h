@@ -129,6 +129,49 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<uint4*>(p) = a;
 }
 
+// streaming variants for passes over tensors far larger than the caches (GroupNorm at 256 x 256: 1 GB per operand): nontemporal
+// loads / stores -- the lines are not kept in L2 / Infinity Cache, where they would only evict each other.  -DDVQ_STREAM_NT=0: plain
+#ifndef DVQ_STREAM_NT
+#define DVQ_STREAM_NT 1
+#endif
+__device__ __forceinline__ void load8_nt(const float* p, float (&v)[8]) {
+#if DVQ_STREAM_NT
+    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + 1);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+#else
+    load8(p, v);
+#endif
+}
+__device__ __forceinline__ void load8_nt(const bf16_t* p, float (&v)[8]) {
+#if DVQ_STREAM_NT
+    const dvq_u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const dvq_u32x4*>(p));
+    v[0] = __uint_as_float(a[0] << 16); v[1] = __uint_as_float(a[0] & 0xffff0000u);
+    v[2] = __uint_as_float(a[1] << 16); v[3] = __uint_as_float(a[1] & 0xffff0000u);
+    v[4] = __uint_as_float(a[2] << 16); v[5] = __uint_as_float(a[2] & 0xffff0000u);
+    v[6] = __uint_as_float(a[3] << 16); v[7] = __uint_as_float(a[3] & 0xffff0000u);
+#else
+    load8(p, v);
+#endif
+}
+__device__ __forceinline__ void store8_nt(float* p, const float (&v)[8]) {
+#if DVQ_STREAM_NT
+    const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(p));
+    __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(p) + 1);
+#else
+    store8(p, v);
+#endif
+}
+__device__ __forceinline__ void store8_nt(bf16_t* p, const float (&v)[8]) {
+#if DVQ_STREAM_NT
+    const dvq_u32x4 a = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    __builtin_nontemporal_store(a, reinterpret_cast<dvq_u32x4*>(p));
+#else
+    store8(p, v);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave / block reductions
 // ---------------------------------------------------------------------------------------------

@@ -8,6 +8,10 @@
 // atomic per (block, group)), so E[x^2]-E[x]^2 is evaluated in fp64.
 #include "dvq_common.h"
 
+#ifndef DVQ_GN_UNROLL
+#define DVQ_GN_UNROLL 2
+#endif
+
 namespace {
 
 // pixels per block: 1024 for large maps; small maps (HW <= 4096) use 64 so that N * HW / rows still fills the chip
@@ -95,7 +99,22 @@ __device__ __forceinline__ void gn_mean_rstd(const double* stats, int64_t n, int
     rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-template <typename T, int ACT>
+// NT: the operand is far larger than the Infinity Cache (launcher: > 192 MB) -- nontemporal loads / stores, the pass does not sweep the
+// caches.  Measured (tools/debug/gn_probe.py, N 64, bf16): apply 626 -> 566 us and backward 1076 -> 1007 us at 256 x 256 x 128,
+// 171 -> 136 and 294 -> 262 at 128 x 128 x 128; on operands that FIT the caches (the PatchGAN's BatchNorm layers, 33 - 67 MB) the
+// same hint costs 60 - 80 %, hence the size switch.
+template <bool NT, typename T>
+__device__ __forceinline__ void ld8(const T* p, float (&v)[8]) {
+    if constexpr (NT) load8_nt(p, v);
+    else load8(p, v);
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void st8(T* p, const float (&v)[8]) {
+    if constexpr (NT) store8_nt(p, v);
+    else store8(p, v);
+}
+
+template <typename T, int ACT, bool NT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int64_t HW, int64_t C, int G, float eps,
                                                        const double* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -136,27 +155,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     for (; p + 3 * rpp < p_end; p += 4 * rpp) {
         float v[4][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) load8(x + off + (p + u * rpp) * C, v[u]);
+        for (int u = 0; u < 4; ++u) ld8<NT>(x + off + (p + u * rpp) * C, v[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[u][j] = act_fwd<ACT>(fmaf(v[u][j], sc[j], sh[j]));
-            store8(y + off + (p + u * rpp) * C, v[u]);
+            st8<NT>(y + off + (p + u * rpp) * C, v[u]);
         }
     }
     for (; p < p_end; p += rpp) {
         float v[8];
-        load8(x + off + p * C, v);
+        ld8<NT>(x + off + p * C, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float z = fmaf(v[j], sc[j], sh[j]);
             v[j] = act_fwd<ACT>(z);
         }
-        store8(y + off + p * C, v);
+        st8<NT>(y + off + p * C, v);
     }
 }
 
-template <typename T, int ACT>
+template <typename T, int ACT, bool NT>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                             int64_t HW, int64_t C, int G,
                                                             const float* __restrict__ mean_rstd,
@@ -185,10 +204,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
         }
         const int64_t p_end = min((int64_t)(blockIdx.x + 1) * gn_rows_per_block(HW), HW);
         const int64_t off = n * HW * C + col * 8;
-        for (int64_t p = (int64_t)blockIdx.x * gn_rows_per_block(HW) + prow; p < p_end; p += ge.rows_per_pass) {
-            float v[8], g8[8];
-            load8(x + off + p * C, v);
-            load8(dy + off + p * C, g8);
+        int64_t p = (int64_t)blockIdx.x * gn_rows_per_block(HW) + prow;
+        const int64_t rpp = ge.rows_per_pass;
+        auto accumulate = [&](const float (&v)[8], const float (&g8)[8]) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float xh = (v[j] - mu[j]) * rs[j];
@@ -197,6 +215,24 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
                 a[j] += dz;
                 b[j] = fmaf(dz, xh, b[j]);
             }
+        };
+#if DVQ_GN_UNROLL > 1
+        for (; p + rpp < p_end; p += 2 * rpp) {          // two rows per trip: four 16-byte loads in flight per thread
+            float v[2][8], g8[2][8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                ld8<NT>(x + off + (p + u * rpp) * C, v[u]);
+                ld8<NT>(dy + off + (p + u * rpp) * C, g8[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) accumulate(v[u], g8[u]);
+        }
+#endif
+        for (; p < p_end; p += rpp) {
+            float v[8], g8[8];
+            ld8<NT>(x + off + p * C, v);
+            ld8<NT>(dy + off + p * C, g8);
+            accumulate(v, g8);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -262,7 +298,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
     if (c < C && (c & (cpg - 1)) == 0) red[(n * G + c / cpg) * 2 + ab] += w;
 }
 
-template <typename T, int ACT>
+template <typename T, int ACT, bool NT>
 __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t HW,
                                                         int64_t C, int G, const float* __restrict__ mean_rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -293,10 +329,9 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x,
     }
     const int64_t p_end = min((int64_t)(blockIdx.x + 1) * gn_rows_per_block(HW), HW);
     const int64_t off = n * HW * C + col * 8;
-    for (int64_t p = (int64_t)blockIdx.x * gn_rows_per_block(HW) + prow; p < p_end; p += ge.rows_per_pass) {
-        float v[8], g8[8];
-        load8(x + off + p * C, v);
-        load8(dy + off + p * C, g8);
+    int64_t p = (int64_t)blockIdx.x * gn_rows_per_block(HW) + prow;
+    const int64_t rpp = ge.rows_per_pass;
+    auto row_dx = [&](float (&v)[8], const float (&g8)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xh = (v[j] - mu[j]) * rs[j];
@@ -304,13 +339,39 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x,
             if (ACT != ACT_NONE) dz *= act_grad<ACT>(fmaf(xh, ga[j], be[j]));
             v[j] = rs[j] * (dz * ga[j] - m1[j] - xh * m2[j]);
         }
+    };
+#if DVQ_GN_UNROLL > 1
+    for (; p + rpp < p_end; p += 2 * rpp) {              // two rows per trip: four (six with an addend) 16-byte loads in flight per thread
+        float v[2][8], g8[2][8], ad[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            ld8<NT>(x + off + (p + u * rpp) * C, v[u]);
+            ld8<NT>(dy + off + (p + u * rpp) * C, g8[u]);
+            if (addend != nullptr) ld8<NT>(addend + off + (p + u * rpp) * C, ad[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            row_dx(v[u], g8[u]);
+            if (addend != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[u][j] += ad[u][j];
+            }
+            st8<NT>(dx + off + (p + u * rpp) * C, v[u]);
+        }
+    }
+#endif
+    for (; p < p_end; p += rpp) {
+        float v[8], g8[8];
+        ld8<NT>(x + off + p * C, v);
+        ld8<NT>(dy + off + p * C, g8);
+        row_dx(v, g8);
         if (addend != nullptr) {       // gradient of a residual branch that joins here (ResnetBlock skip path)
             float ad[8];
-            load8(addend + off + p * C, ad);
+            ld8<NT>(addend + off + p * C, ad);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += ad[j];
         }
-        store8(dx + off + p * C, v);
+        st8<NT>(dx + off + p * C, v);
     }
 }
 
@@ -336,6 +397,8 @@ __global__ __launch_bounds__(256) void gn_scale_shift_kernel(const double* __res
         mean_rstd[e * 2 + 1] = r;
     }
 }
+
+constexpr int64_t GN_STREAM_BYTES = 192ll << 20;     // operands above this size stream past the caches (ld8 / st8)
 
 int gn_check(const char* who, int64_t N, int64_t HW, int64_t C, int G) {
     DVQ_REQUIRE(N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C % 8 == 0 && C / 8 <= 256 && N <= 65535, DVQ_ESHAPE,
@@ -375,10 +438,13 @@ int dvq_gn_apply(const void* x, int dtype, int64_t N, int64_t HW, int64_t C, int
     if (int e = gn_check("dvq_gn_apply", N, HW, C, G)) return e;
     dim3 grid((unsigned)cdiv64(HW, gn_rows_per_block(HW)), (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
-#define GN_ACT_SWITCH(KERN, LDS, ...)                                                              \
-    if (silu == ACT_SILU) KERN<T, ACT_SILU><<<grid, dim3(256), LDS, s>>>(__VA_ARGS__);              \
-    else if (silu == ACT_LRELU) KERN<T, ACT_LRELU><<<grid, dim3(256), LDS, s>>>(__VA_ARGS__);       \
-    else KERN<T, ACT_NONE><<<grid, dim3(256), LDS, s>>>(__VA_ARGS__);
+#define GN_ACT_SWITCH_NT(KERN, NTV, LDS, ...)                                                           \
+    if (silu == ACT_SILU) KERN<T, ACT_SILU, NTV><<<grid, dim3(256), LDS, s>>>(__VA_ARGS__);             \
+    else if (silu == ACT_LRELU) KERN<T, ACT_LRELU, NTV><<<grid, dim3(256), LDS, s>>>(__VA_ARGS__);      \
+    else KERN<T, ACT_NONE, NTV><<<grid, dim3(256), LDS, s>>>(__VA_ARGS__);
+#define GN_ACT_SWITCH(KERN, LDS, ...)                                                                   \
+    if (N * HW * C * (int64_t)sizeof(T) > GN_STREAM_BYTES) { GN_ACT_SWITCH_NT(KERN, true, LDS, __VA_ARGS__) } \
+    else { GN_ACT_SWITCH_NT(KERN, false, LDS, __VA_ARGS__) }
     DVQ_DISPATCH_DTYPE(dtype, T, GN_ACT_SWITCH(gn_apply_kernel, 2 * G * sizeof(float), (const T*)x, HW, C, G, eps, stats, gamma, beta, (T*)y, mean_rstd));
     DVQ_CHECK_LAUNCH("gn_apply");
     return DVQ_OK;
