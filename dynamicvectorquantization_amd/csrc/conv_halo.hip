@@ -48,6 +48,7 @@ struct HaloParams {
     float mask_slope;
     int dbg;             // profiling experiments only (DVQ_HALO_DBG): 1 = skip the epilogue, 2 = skip the MFMA loop, 6 = per-workgroup
                          //   time stamps (tools/debug/halo_trace.py)
+    int nt_out;          // 1: the output tensor is larger than the Infinity Cache -- nontemporal stores (DVQ_HALO_NT=0: never)
     int nblocks;         // N * tiles_y * tiles_x * gn
     unsigned mg_gn, mg_tx, mg_ty;      // fdiv_u32 magics of gn, tiles_x, tiles_y
 };
@@ -576,7 +577,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
                     }
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvq_u32x4, v), rsY, vo_px, so_iter(i), 0);
+            // (aux 2 = nontemporal: an output far larger than the Infinity Cache is not worth keeping there, see HaloParams::nt_out)
+            if (p.nt_out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvq_u32x4, v), rsY, vo_px, so_iter(i), 2);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvq_u32x4, v), rsY, vo_px, so_iter(i), 0);
             if (p.out_stats != nullptr && p.dbg == 9 && p.R != nullptr) {
                 // MEASUREMENT ONLY (DVQ_HALO_DBG=9, tools/debug/halo_data_probe.py): the arithmetic a GroupNorm-backward reduction
                 // fused into this epilogue would execute per element -- xhat, z, sigmoid, swish', dz, two accumulations -- on the
@@ -755,6 +758,11 @@ static int halo_try_impl(const void* x, const void* w, const float* bias, const 
     p.up = up;
     p.gn_ss = gn_ss; p.out_stats = out_stats; p.out_groups = out_groups;
     p.act_slope = act_slope; p.res_mask = res_mask; p.mask_slope = mask_slope;
+    static const int nt_env = [] {
+        const char* e = getenv("DVQ_HALO_NT");
+        return e == nullptr ? 1 : atoi(e);
+    }();
+    p.nt_out = nt_env && !out32 && N * H * W * Cout * 2 > (192ll << 20);
     static const int dbg_env = dvq_probe_env("DVQ_HALO_DBG");       // 0 unless built with -DDVQ_PROBES
     p.dbg = dbg_env;
     const int ntiles = p.tiles_y * p.tiles_x;
