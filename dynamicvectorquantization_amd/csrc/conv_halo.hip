@@ -49,6 +49,7 @@ struct HaloParams {
     int dbg;             // profiling experiments only (DVQ_HALO_DBG): 1 = skip the epilogue, 2 = skip the MFMA loop, 6 = per-workgroup
                          //   time stamps (tools/debug/halo_trace.py)
     int nt_out;          // 1: the output tensor is larger than the Infinity Cache -- nontemporal stores (DVQ_HALO_NT=0: never)
+    int nt_in;           // 1: the same for the input halo loads, when one workgroup column covers all output channels (DVQ_HALO_NT_IN)
     int nblocks;         // N * tiles_y * tiles_x * gn
     unsigned mg_gn, mg_tx, mg_ty;      // fdiv_u32 magics of gn, tiles_x, tiles_y
 };
@@ -188,11 +189,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
             p.dbg == 39 || p.dbg == 40 ? 0 : (tb * p.Cin + c0) * 2, 0, 0);      // (39 / 40: every tap re-reads the same 16 KB: L1 hits)
     };
     auto issue_halo_buf = [&](int c0) {
+        if (p.nt_in) {                      // (aux 2 = nontemporal: an input far larger than the caches streams past them, the weights stay)
 #pragma unroll
-        for (int i = 0; i < NHP; ++i)
-            if (wave + NW * i < HPIECES)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(halo + (wave + NW * i) * 8 * ROWB), 16,
-                                                         hvo[i], c0 * 2, 0, 0);
+            for (int i = 0; i < NHP; ++i)
+                if (wave + NW * i < HPIECES)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(halo + (wave + NW * i) * 8 * ROWB), 16,
+                                                             hvo[i], c0 * 2, 0, 2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NHP; ++i)
+                if (wave + NW * i < HPIECES)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(halo + (wave + NW * i) * 8 * ROWB), 16,
+                                                             hvo[i], c0 * 2, 0, 0);
+        }
     };
 
     const int swzB = (l31 >> 1) & 7;
@@ -763,6 +772,11 @@ static int halo_try_impl(const void* x, const void* w, const float* bias, const 
         return e == nullptr ? 1 : atoi(e);
     }();
     p.nt_out = nt_env && !out32 && N * H * W * Cout * 2 > (192ll << 20);
+    static const int nt_in_env = [] {
+        const char* e = getenv("DVQ_HALO_NT_IN");
+        return e == nullptr ? 0 : atoi(e);
+    }();
+    p.nt_in = nt_in_env && p.gn == 1 && (N * H * W * Cin * 2 >> up >> up) > (192ll << 20);
     static const int dbg_env = dvq_probe_env("DVQ_HALO_DBG");       // 0 unless built with -DDVQ_PROBES
     p.dbg = dbg_env;
     const int ntiles = p.tiles_y * p.tiles_x;
@@ -857,6 +871,7 @@ struct WgParams {
     float* ws;           // split-K partials: [nsplit][gi*gj][9][128][64] fp32 (+ bias partials behind), or null -> atomics
     float* ws_bias;      // [nsplit][gi*gj][128]
     int dbg;             // profiling experiments only (DVQ_WGRAD_DBG): 2 = skip the MFMA loop, 3 = no DMA  (1, "do not wait for the DMA", is gone: racy)
+    int nt;              // 1: operands larger than the Infinity Cache, read by one workgroup column -- nontemporal DMA (DVQ_WGRAD_NT)
 };
 
 // Cross-XCD fp32 atomics resolve at the memory side and cost far more than plain stores: with a workspace every
@@ -980,14 +995,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(base + (wave + 8 * i) * 4 * 256));
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(l), "v"(vo_dy[i]), "s"(rsD));
+            if (p.nt) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" : : "s"(l), "v"(vo_dy[i]), "s"(rsD));
+            else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(l), "v"(vo_dy[i]), "s"(rsD));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (wave + 8 * i < WHPIECES) {
                 const int vo = (fl_h[i] & edge) ? VOFF_OOB : vo_h[i];
                 const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(base + WDYB + (wave + 8 * i) * 8 * ROWB));
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(l), "v"(vo), "s"(rsX));
+                if (p.nt) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" : : "s"(l), "v"(vo), "s"(rsX));
+                else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(l), "v"(vo), "s"(rsX));
             }
         }
         if (++it_tx == p.tiles_x) {
@@ -1231,6 +1248,11 @@ int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* 
     p.gn_ss = gn_ss;
     static const int wdbg_env = dvq_probe_env("DVQ_WGRAD_DBG");     // 0 unless built with -DDVQ_PROBES
     p.dbg = wdbg_env;
+    static const int wnt_env = [] {
+        const char* e = getenv("DVQ_WGRAD_NT");
+        return e == nullptr ? 0 : atoi(e);
+    }();
+    p.nt = wnt_env && N * H * W * Cout * 2 > (192ll << 20);
     int64_t nblk = (int64_t)p.gi * p.gj * p.nsplit;
     int64_t ws_bytes = 0;
     char* wsp = (char*)dvq_workspace_stream(stream, &ws_bytes);

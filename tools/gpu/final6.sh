@@ -46,6 +46,13 @@ for k, v in acc.most_common(40):
     print("%8.2f ms/step %7.1f calls/step  %s" % (v / 5e6, cnt[k] / 5.0, k[:110]))
 P
 rm -rf gpurun_out/prof_s2; echo "stage2 prof done"; head -3 gpurun_out/${TAG}_stage2_step_table.txt
+{ echo "# causal attention, p6c18 geometry (B 32, T 648, 8 heads x 128, dropout 0.1): round-6 kernels (csrc/attention2.hip), drop mask / rehash / no dropout, then the first generation"
+  for m in 1 0; do echo "## v2 MASK=$m"; MASK=$m timeout 200 python tools/debug/attn_probe.py 2>&1 | grep "fwd\|bwd"; done
+  echo "## v2 no dropout"; PDROP=0 timeout 200 python tools/debug/attn_probe.py 2>&1 | grep "fwd\|bwd"
+  echo "## first generation (DVQ_ATTN_V2=0) MASK=0"; DVQ_ATTN_V2=0 MASK=0 timeout 200 python tools/debug/attn_probe.py 2>&1 | grep "fwd\|bwd"
+  echo "# AttnBlock attention (B 64, T 1024, one head of 256): round-6 kernels, then the first generation"
+  timeout 200 python tools/debug/attn_full_bench.py 2>&1 | grep "attn_full\|AttnBlock"
+  echo "## first generation"; DVQ_ATTN_V2=0 timeout 200 python tools/debug/attn_full_bench.py 2>&1 | grep "attn_full"; } > gpurun_out/${TAG}_attention_probe.txt
 timeout 300 python tools/gemm8p_probe.py 2>&1 | grep "^NT\|repeat" > gpurun_out/${TAG}_gemm_nt_probe.txt
 { timeout 200 python tools/probes/tn_probe.py 2>&1 | grep "TN\|DVQ"; DVQ_TN_WIDE_WGS=256 timeout 200 python tools/probes/tn_probe.py 2>&1 | grep "TN\|DVQ" | sed 's/^/[256 workgroups] /'; } > gpurun_out/${TAG}_gemm_tn_probe.txt
 python - <<'P'

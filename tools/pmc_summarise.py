@@ -37,7 +37,10 @@ def load(path):
 
 def main():
     fetch, write = load(sys.argv[1]), load(sys.argv[2])
-    cal = "gn_apply_kernel<unsigned short, 1>"
+    # (round 6: the kernel has a nontemporal variant for operands larger than the Infinity Cache; calibrate on the plain one when
+    #  the run has it -- cache-resident operands -- else on the streaming one)
+    cal = next((c for c in ("gn_apply_kernel<unsigned short, 1, false>", "gn_apply_kernel<unsigned short, 1, true>",
+                            "gn_apply_kernel<unsigned short, 1>") if c in fetch and c in write), "gn_apply_kernel<unsigned short, 1>")
     wf = 1.0
     if cal in fetch and cal in write:
         wf = (2.0 * sum(fetch[cal])) / sum(write[cal])
