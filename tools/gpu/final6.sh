@@ -32,7 +32,7 @@ kt=$(find gpurun_out/prof_s2 -name "*kernel_trace.csv" | head -1)
 python - "$kt" <<'P' > gpurun_out/${TAG}_stage2_step_table.txt
 import csv, sys, collections
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-att = [i for i, r in enumerate(rows) if "attn_fwd_kernel<128>" in r["Kernel_Name"]]
+att = [i for i, r in enumerate(rows) if "attn2_fwd_kernel<128" in r["Kernel_Name"] or "attn_fwd_kernel<128>" in r["Kernel_Name"]]
 per_step = 24
 nsteps = len(att) // per_step
 keep_from = att[(nsteps - 5) * per_step]            # the last five steps: steady state
