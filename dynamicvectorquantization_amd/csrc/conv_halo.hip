@@ -411,7 +411,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
 
     if constexpr (OUT32) {
         // ---- fp32 epilogue: rounds of 64 output channels; row lp = tile pixel, 16 chunks of 4 floats, chunk c at position c ^ (lp & 15) --
-        static_assert(NT == 4 || NT == 2, "fp32 output: 64-channel staging rounds");
+        // (NT == 1, round 6: one round whose rows are half filled -- the thin 128 -> 3 output convolution in fp32x3; the store loop drops
+        //  the chunks past Cout)
+        constexpr int NROUND = NT >= 2 ? NT / 2 : 1, NTL = NT >= 2 ? 2 : 1;
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // nothing is in flight here (the last tap's barrier waited); said explicitly for
                                                               // tools/lint_dma_barriers.py, whose path merge also walks "main loop skipped"
         float* Y32 = reinterpret_cast<float*>(p.Y);
@@ -430,12 +432,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
         const int cst = l31 & 15;
         const char* lane_ld = smem + tq * 256 + ((ch ^ tq) << 4);
 #pragma unroll
-        for (int h = 0; h < NT / 2; ++h) {
+        for (int h = 0; h < NROUND; ++h) {
             const int col = n0 + 64 * h + ch * 4;
             const int vo_px = col < p.Cout ? (tq * p.Cout + col) * 4 : VOFF_OOB;
             if (h > 0) lds_barrier();                       // the previous round's rows have been read
 #pragma unroll
-            for (int ntl = 0; ntl < 2; ++ntl)
+            for (int ntl = 0; ntl < NTL; ++ntl)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -744,7 +746,7 @@ static int halo_try_impl(const void* x, const void* w, const float* bias, const 
                          double* out_stats, int out_groups, float act_slope, int res_mask, float mask_slope,
                          hipStream_t stream, bool out32) {
     if (H % TH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % (out32 ? 4 : 8) != 0) return 0;
-    if (out32 && (Cout <= 32 || gn_ss != nullptr || out_stats != nullptr || H * W * Cout * 4 >= (1ll << 31))) return 0;
+    if (out32 && (gn_ss != nullptr || out_stats != nullptr || H * W * Cout * 4 >= (1ll << 31))) return 0;
 #ifdef DVQ_PROBES
     if (!out32) {   // the persistent kernel (conv_halo2.hip, DVQ_HALO2=1) takes the launches it is built for: 128-channel output blocks, >= 2 tiles per CU
         const int rc2 = dvq_conv3x3_halo2_try(x, w, bias, residual, y, N, H, W, Cin, Cout, flip, up, gn_ss, out_stats, out_groups, act_slope,
@@ -800,7 +802,8 @@ static int halo_try_impl(const void* x, const void* w, const float* bias, const 
     };
     if (out32) {
         if (cot == 128) go(conv3x3_halo_kernel<4, false, true>);
-        else go(conv3x3_halo_kernel<2, false, true>);
+        else if (cot == 64) go(conv3x3_halo_kernel<2, false, true>);
+        else go(conv3x3_halo_kernel<1, false, true>);
     } else if (cot == 128) {
 #ifdef DVQ_PROBES
         if (p.dbg == 6) go(conv3x3_halo_kernel<4, true>);       // per-workgroup time stamps (dvq_halo_trace_read)
@@ -872,6 +875,9 @@ struct WgParams {
     float* ws_bias;      // [nsplit][gi*gj][128]
     int dbg;             // profiling experiments only (DVQ_WGRAD_DBG): 2 = skip the MFMA loop, 3 = no DMA  (1, "do not wait for the DMA", is gone: racy)
     int nt;              // 1: operands larger than the Infinity Cache, read by one workgroup column -- nontemporal DMA (DVQ_WGRAD_NT)
+    int plane_n;         // fp32x3 in ONE launch (round 6): X and DY each hold two bf16 planes [hi; lo] of plane_n images, N = 3 plane_n, and
+                         // "image" n of the tile walk is the product (x_lo, dy_hi), (x_hi, dy_lo), (x_hi, dy_hi) for n / plane_n = 0, 1, 2 --
+                         // the three products of the split scheme accumulate in the same fp32 registers / partials.  0: ordinary operands
 };
 
 // Cross-XCD fp32 atomics resolve at the memory side and cost far more than plain stores: with a workspace every
@@ -984,9 +990,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
     };
     auto issue = [&](int /*t*/, int buf) {
         const int y0 = it_ty * WTH, x0 = it_tx * TW;
-        const wg_int32x4 rsD = make_rsrc(p.DY + (((int64_t)it_n * p.H + y0) * p.W + x0) * p.Cout);
+        int nx = it_n, ny = it_n;
+        if (p.plane_n != 0) {                        // fp32x3 planes: (x_lo, dy_hi), (x_hi, dy_lo), (x_hi, dy_hi)
+            const int pl = it_n / p.plane_n, im = it_n - pl * p.plane_n;
+            nx = (pl == 0 ? p.plane_n : 0) + im;
+            ny = (pl == 1 ? p.plane_n : 0) + im;
+        }
+        const wg_int32x4 rsD = make_rsrc(p.DY + (((int64_t)ny * p.H + y0) * p.W + x0) * p.Cout);
         // (for the first tile of the tensor this base lies one row and one pixel before it: only masked lanes would go there)
-        const wg_int32x4 rsX = make_rsrc(p.X + (((int64_t)it_n * SHt + (y0 >> p.up) - 1) * SWd + (x0 >> p.up) - 1) * p.Cin);
+        const wg_int32x4 rsX = make_rsrc(p.X + (((int64_t)nx * SHt + (y0 >> p.up) - 1) * SWd + (x0 >> p.up) - 1) * p.Cin);
         const int edge = (it_ty == 0 ? 1 : 0) | (it_ty == p.tiles_y - 1 ? 2 : 0) | (it_tx == 0 ? 4 : 0) | (it_tx == p.tiles_x - 1 ? 8 : 0) | 16;
         char* base = smem + buf * WSTAGE;
         // issued from inline assembly: the compiler orders every ds_read_b64_tr behind ALL LDS-DMA it knows to be pending
@@ -1038,8 +1050,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const bool do_bias = p.DB != nullptr && j0 == 0 && nt == 0;
+    const bool do_bias_wg = p.DB != nullptr && j0 == 0 && nt == 0;
     float bsum = 0.f;
+    const int bias_from = p.plane_n * p.tiles_x * p.tiles_y;      // fp32x3 planes: dy_hi is met twice -- the (x_lo, dy_hi) tiles do not count
 
     if (tbeg < tend) {
         issue(tbeg, 0);
@@ -1047,6 +1060,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
         __syncthreads();
         for (int t = tbeg; t < tend; ++t) {
             const int buf = (t - tbeg) & 1;
+            const bool do_bias = do_bias_wg && t >= bias_from;
             if (p.gn_ss == nullptr && t + 1 < tend && p.dbg != 3) issue(t + 1, buf ^ 1);
             const char* sdy = smem + buf * WSTAGE;
             const char* shl = sdy + WDYB;
@@ -1197,7 +1211,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
                 const int col = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 tile[tap * 8192 + col * 64 + nt * 32 + l31] = acc[tap][r];
             }
-        if (do_bias) {
+        if (do_bias_wg) {
             const float v = bsum + __shfl_xor(bsum, 32, 64);
             if (half == 0) p.ws_bias[((int64_t)split * (p.gi * p.gj) + wi) * 128 + mt * 32 + l31] = v;
         }
@@ -1216,7 +1230,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
                 }
             }
     }
-    if (do_bias) {
+    if (do_bias_wg) {
         const float v = bsum + __shfl_xor(bsum, 32, 64);       // the two lane halves hold different pixels
         const int co = n0 + mt * 32 + l31;
         if (half == 0 && co < p.cout_real) atomicAdd(p.DB + co, v);
@@ -1226,12 +1240,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_wgrad_kernel(WgParams p) 
 }  // namespace
 
 // 1 = handled, 0 = not eligible, negative = error
+static int halo_wgrad_impl(const void* x, const void* dy, float* dw, float* db, int64_t N, int64_t H, int64_t W,
+                           int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw, int up,
+                           const float* gn_ss, int64_t plane_n, hipStream_t stream);
+
 int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* db, int64_t N, int64_t H, int64_t W,
                                int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw, int up,
                                const float* gn_ss, hipStream_t stream) {
+    return halo_wgrad_impl(x, dy, dw, db, N, H, W, Cin, Cout, cin_real, cout_real, c_oihw, up, gn_ss, 0, stream);
+}
+
+// fp32x3 weight gradient in one launch: x / dy point at two contiguous bf16 planes [hi; lo] of N images each (WgParams::plane_n)
+int dvq_conv3x3_halo_wgrad_planes_try(const void* x_planes, const void* dy_planes, float* dw, float* db, int64_t N, int64_t H, int64_t W,
+                                      int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw, int up, hipStream_t stream) {
+    return halo_wgrad_impl(x_planes, dy_planes, dw, db, 3 * N, H, W, Cin, Cout, cin_real, cout_real, c_oihw, up, nullptr, N, stream);
+}
+
+static int halo_wgrad_impl(const void* x, const void* dy, float* dw, float* db, int64_t N, int64_t H, int64_t W,
+                           int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw, int up,
+                           const float* gn_ss, int64_t plane_n, hipStream_t stream) {
     if (H % WTH != 0 || W % TW != 0 || Cin % 64 != 0 || Cout % 8 != 0) return 0;
     if (N * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31)) return 0;
     WgParams p{};
+    p.plane_n = (int)plane_n;
     p.X = (const bf16_t*)x; p.DY = (const bf16_t*)dy; p.DW = dw; p.DB = db;
     p.N = (int)N; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout;
     p.cin_real = (int)cin_real; p.cout_real = (int)cout_real;

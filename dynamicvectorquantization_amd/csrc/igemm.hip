@@ -3154,6 +3154,8 @@ int dvq_conv3x3_halo_try(const void* x, const void* w, const float* bias, const 
 int dvq_conv3x3_halo_wgrad_try(const void* x, const void* dy, float* dw, float* db, int64_t N, int64_t H, int64_t W,
                                int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw, int up,
                                const float* gn_ss, hipStream_t stream);
+int dvq_conv3x3_halo_wgrad_planes_try(const void* x_planes, const void* dy_planes, float* dw, float* db, int64_t N, int64_t H, int64_t W,
+                                      int64_t Cin, int64_t Cout, int64_t cin_real, int64_t cout_real, int c_oihw, int up, hipStream_t stream);
 
 int dvq_conv3x3_thin_k_try(const void* x, const void* w, const float* bias, void* y, int64_t N, int64_t H, int64_t W, int64_t Cout,
                            int flip, float act_slope, hipStream_t stream);
@@ -3463,6 +3465,19 @@ int dvq_conv2d_wgrad_oihw_x3(const dvq_conv_desc* d, const void* x, const void* 
     b.dtype = DVQ_BF16;
     b.Cin = c8;
     b.Cout = o8;
+    // 3 x 3 / stride 1 / pad 1 on the halo kernel: ONE launch over "3 N images" -- image n of plane triple (x_lo, dy_hi), (x_hi, dy_lo),
+    // (x_hi, dy_hi) -- instead of three launches with three folds of the partials (the planes of an operand are contiguous: eligible
+    // shapes have plane sizes that are multiples of 256 bytes).  DVQ_WGRAD_X3_ONE=0: three launches
+    static const int one_env = [] {
+        const char* e = getenv("DVQ_WGRAD_X3_ONE");
+        return e == nullptr ? 1 : atoi(e);
+    }();
+    if (one_env && halo_eligible(&b) && xl == xh + xrows * c8 * 2 && yl == yh + yrows * o8 * 2) {
+        const int rc = dvq_conv3x3_halo_wgrad_planes_try(xh, yh, grad_oihw, dbias, d->N, d->H, d->W, c8, o8, cin_real, cout_real, ohwi ? 0 : 1,
+                                                         d->upsample, (hipStream_t)stream);
+        if (rc < 0) return rc;
+        if (rc == 1) return DVQ_OK;
+    }
     // small terms first; the bias gradient (column sums of dy) is the sum over BOTH dy planes, taken on the two launches that read x_hi
     if (int e = dvq_conv2d_wgrad_oihw_ex(&b, xl, yh, cin_real, cout_real, grad_oihw, nullptr, ohwi, nullptr, stream)) return e;
     if (int e = dvq_conv2d_wgrad_oihw_ex(&b, xh, yl, cin_real, cout_real, grad_oihw, dbias, ohwi, nullptr, stream)) return e;
@@ -3483,7 +3498,7 @@ namespace {
 // cs: channels of the streamed operand (x: Cin / dy: Cout), co: channels produced
 bool x3_halo_shape_ok(const dvq_conv_desc* d, int64_t cs, int64_t co) {
     return d->dtype == DVQ_F32 && d->impl == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
-           d->OH == d->H && d->OW == d->W && d->H % 8 == 0 && d->W % 32 == 0 && cs % 64 == 0 && co > 32 && co % 4 == 0 &&
+           d->OH == d->H && d->OW == d->W && d->H % 8 == 0 && d->W % 32 == 0 && cs % 64 == 0 && co >= 4 && co % 4 == 0 &&
            d->N * d->H * d->W * (3 * cs > co ? 3 * cs : co) < (1ll << 31) && co * 27 * cs < (1ll << 31) && d->H * d->W * co * 4 < (1ll << 31);
 }
 

@@ -666,6 +666,33 @@ def test_fp32_split_halo_variants(dev, monkeypatch):
             assert not torch.equal(out["1"]["y"], out["0"]["y"])          # two different kernels really ran
 
 
+def test_fp32_split_halo_thin_output(dev, monkeypatch):
+    """fp32x3 forward of a THIN-output 3x3 convolution (the decoder's 128 -> 3 conv_out, channels padded to 4) on the halo kernel's
+    32-channel instance with the fp32 epilogue (one half-filled staging round) against float64 and the in-kernel split path"""
+    from dynamicvectorquantization_amd import kernels as K
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.layers import Conv2d
+    torch.manual_seed(12)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    with rt.compute_dtype_ctx("fp32x3"):
+        for cin, cout, h, w_, n in ((128, 4, 16, 32, 2), (64, 8, 8, 64, 3), (128, 32, 8, 32, 1)):
+            conv = Conv2d(cin, cout, 3, stride=1, padding=1).to(dev)
+            x = torch.randn(n, h, w_, cin, device=dev)
+            d = conv._desc(x)
+            monkeypatch.setenv("DVQ_X3_HALO", "1")
+            assert K._x3_halo(d, x, False), (cin, cout)
+            w, wt, bias = conv.packed(torch.float32)
+            yr = F.conv2d(x.double().permute(0, 3, 1, 2), conv.weight.detach().double(), conv.bias.detach().double(), padding=1).permute(0, 2, 3, 1)
+            out = {}
+            for halo in ("1", "0"):
+                monkeypatch.setenv("DVQ_X3_HALO", halo)
+                out[halo] = {"y": K.conv2d_fwd(d, x, w, bias), "lrelu": K.conv2d_fwd(d, x, w, bias, act=K.ACT_LRELU)}
+            for k, r in (("y", yr), ("lrelu", torch.where(yr > 0, yr, 0.2 * yr))):
+                assert rel(out["1"][k][..., :cout], r) < 3e-5, (cin, cout, k, rel(out["1"][k][..., :cout], r))
+                assert rel(out["0"][k][..., :cout], r) < 3e-5, (cin, cout, k, "in-kernel")
+            assert not torch.equal(out["1"]["y"], out["0"]["y"])
+
+
 @pytest.mark.parametrize("halo", ["1", "0"], ids=["halo", "nt-glds"])
 @pytest.mark.parametrize("planes", ["1", "0"], ids=["wgrad-planes", "wgrad-in-kernel"])
 @pytest.mark.parametrize("case", [(128, 128, 3, "same", 32, 32, 2), (256, 256, 3, "down", 32, 32, 2), (64, 128, 4, "same", 31, 31, 2),
