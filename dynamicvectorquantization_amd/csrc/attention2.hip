@@ -504,9 +504,9 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_bwd_dq_kernel(Attn2Ar
 // diagonal needs a per-element test.
 // ------------------------------------------------------------------------------------------------------------------
 template <int HS, bool CAUSAL, int MODE, bool DROP, bool MASKED>
-__global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_bwd_dkv_kernel(Attn2Args p) {
+__global__ __launch_bounds__(256, MODE == 0 ? 1 : Cfg<HS>::WPC) void attn2_bwd_dkv_kernel(Attn2Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr bool DO_DV = MODE == 1, DO_DK = MODE == 2;
+    constexpr bool DO_DV = MODE != 2, DO_DK = MODE != 1;          // MODE 0: both in one launch (one wave per SIMD, 2 NM accumulator tiles)
     using G = Cfg<HS>;
     constexpr int NS = G::NS, NM = G::NM, TILEB = G::TILEB, KV_STAGE = 2 * TILEB + 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -548,9 +548,11 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_bwd_dkv_kernel(Attn2A
             if constexpr (DO_DK) vf[s] = ldfrag(p.v + e0 + 16 * s, kok);
         }
     }
-    f32x16 acc[NM];                                               // dV^T or dK^T [ch][key]
+    f32x16 acc[NM], acc2[MODE == 0 ? NM : 1];                     // dV^T or dK^T [ch][key]; MODE 0: acc = dV^T, acc2 = dK^T
 #pragma unroll
     for (int mt = 0; mt < NM; ++mt) acc[mt] = zero16();
+#pragma unroll
+    for (int mt = 0; mt < (MODE == 0 ? NM : 1); ++mt) acc2[mt] = zero16();
     const float c2 = p.scale * LOG2E;
     // dropout: hash input of query 0 of (batch, head) bh for this lane's key; a query row adds T * rm
     const unsigned xkey = ((unsigned)((int64_t)bh * T * T) + (unsigned)krow + 4u * half * (unsigned)T) * p.rm + p.ra;
@@ -594,7 +596,12 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_bwd_dkv_kernel(Attn2A
                             if constexpr (MASKED) keep = (mword >> (8 * gq + i)) & 1u;
                             else keep = dvq_hash32(xb + (unsigned)ccol(r) * trm) >= p.thr;
                         }
-                        if constexpr (DO_DV) {
+                        if constexpr (MODE == 0) {
+                            float gr = dp[r];
+                            if constexpr (DROP) gr = keep ? gr * p.inv_keep : 0.f;
+                            dp[r] = pr * (gr - d4[i]);                                    // d loss / d (scaled score)
+                            s[r] = DROP ? (keep ? pr * p.inv_keep : 0.f) : pr;             // dropped-out probabilities
+                        } else if constexpr (DO_DV) {
                             s[r] = DROP ? (keep ? pr * p.inv_keep : 0.f) : pr;             // dropped-out probabilities
                         } else {
                             float gr = dp[r];
@@ -611,10 +618,18 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_bwd_dkv_kernel(Attn2A
                 const bf16x8 f = pack8(s, s2);
 #pragma unroll
                 for (int mt = 0; mt < NM; ++mt) acc[mt] = MFMA(g.tfrag(DO_DV ? dl : ql, sub, mt, s2), f, acc[mt]);
+                if constexpr (MODE == 0) {
+                    const bf16x8 f2 = pack8(dp, s2);
+#pragma unroll
+                    for (int mt = 0; mt < NM; ++mt) acc2[mt] = MFMA(g.tfrag(ql, sub, mt, s2), f2, acc2[mt]);
+                }
             }
         }
     }
-    if (kok) store_ct<NM>((DO_DV ? p.dv : p.dk) + (rowbase + krow) * C + h * HS, acc, half, DO_DV ? 1.f : p.scale);
+    if (kok) {
+        store_ct<NM>((DO_DV ? p.dv : p.dk) + (rowbase + krow) * C + h * HS, acc, half, DO_DV ? 1.f : p.scale);
+        if constexpr (MODE == 0) store_ct<NM>(p.dk + (rowbase + krow) * C + h * HS, acc2, half, p.scale);
+    }
 #endif
 }
 
@@ -645,10 +660,24 @@ void fwd_hs(const Attn2Args& a, hipStream_t stream) {
     }
 }
 
+static int dkv_one_env() {
+    static const int v = [] {
+        const char* e = getenv("DVQ_ATTN2_DKV_ONE");
+        return e == nullptr ? 0 : atoi(e);
+    }();
+    return v;
+}
+
 template <int HS, bool CAUSAL, bool DROP, bool MASKED>
 void bwd_variant(const Attn2Args& a, hipStream_t stream) {
     const int lds_q = 4 * Cfg<HS>::TILEB, lds_kv = 2 * (2 * Cfg<HS>::TILEB + 512);
     launch(attn2_bwd_dq_kernel<HS, CAUSAL, DROP, MASKED>, a, lds_q, stream);                // first: it also produces dsum for the dK kernel
+    if constexpr (HS == 128) {
+        if (dkv_one_env()) {                                                                  // DVQ_ATTN2_DKV_ONE=1: dV and dK in one launch (A/B)
+            launch(attn2_bwd_dkv_kernel<HS, CAUSAL, 0, DROP, MASKED>, a, lds_kv, stream);
+            return;
+        }
+    }
     launch(attn2_bwd_dkv_kernel<HS, CAUSAL, 1, DROP, MASKED>, a, lds_kv, stream);
     launch(attn2_bwd_dkv_kernel<HS, CAUSAL, 2, DROP, MASKED>, a, lds_kv, stream);
 }
