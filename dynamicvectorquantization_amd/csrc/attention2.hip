@@ -247,15 +247,16 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_fwd_kernel(Attn2Args 
     auto issue_k = [&](int kt) { dma.issue(rsK, 64 * kt, C, lds0 + (unsigned)((kt & 1) * TILEB), wave); };
     auto issue_v = [&](int kt) { dma.issue(rsV, 64 * kt, C, lds0 + (unsigned)((2 + (kt & 1)) * TILEB), wave); };
     const int last_t = CAUSAL ? qt_max : nqt - 1;                  // last 32-key tile any wave of the workgroup sees
-    const int nk = (last_t >> 1) + 1;                              // 64-key tiles
+    const int nk = p.dbg != 0 ? 0 : (last_t >> 1) + 1;             // 64-key tiles (DVQ_ATTN2_DBG, probe builds: 1 = no tile loop at all,
+                                                                   //   2 = nor the output stores, 3 = nor the Q fragment loads / first DMA)
     const int my_last = CAUSAL ? qt : nqt - 1;                     // last 32-key tile THIS wave sees
     auto vis = [&](int t32) { return active && t32 <= my_last; };
-    issue_k(0);
+    if (p.dbg != 3) issue_k(0);
     bf16x8 qf[NS];
     {
         const bf16_t* qp = p.q + (rowbase + qrow) * C + h * HS + 8 * half;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) qf[s] = ldfrag(qp + 16 * s, qok);
+        for (int s = 0; s < NS; ++s) qf[s] = ldfrag(qp + 16 * s, qok && p.dbg != 3);
     }
     f32x16 oacc[NM];
 #pragma unroll
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_fwd_kernel(Attn2Args 
             }
         }
     }
-    if (qok) {
+    if (qok && p.dbg != 2) {
         store_ct<NM>(p.out + (rowbase + qrow) * C + h * HS, oacc, half, 1.f / l_run);
         if (half == 0) p.lse[(int64_t)bh * T + qrow] = (m_run + __builtin_amdgcn_logf(l_run)) * (1.f / LOG2E);
     }
@@ -644,6 +645,8 @@ static int order_env() {
 template <typename K>
 void launch(K kernel, Attn2Args a, int lds, hipStream_t stream) {
     a.order = (a.B * a.nh) % 8 == 0 ? order_env() : 0;
+    static const int dbg = dvq_probe_env("DVQ_ATTN2_DBG");         // 0 unless built with -DDVQ_PROBES
+    a.dbg = dbg;
     const int nt = (a.T + 31) / 32;
     const dim3 grid((unsigned)(((nt + 3) / 4) * a.B * a.nh));
     dvq_ensure_dynamic_lds((const void*)kernel, lds);

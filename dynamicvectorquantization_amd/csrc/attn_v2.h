@@ -13,6 +13,7 @@ struct Attn2Args {
     unsigned thr, rm, ra;                    // dropout: keep iff dvq_hash32(idx * rm + ra) >= thr (thr == 0: no dropout)
     unsigned long long* mask;                // optional keep-decision words (attention.hip: drop_tile)
     int causal;                              // 1: causal, head size 128;  0: full attention, one head of size 256 (AttnBlock), T % 32 == 0
+    int dbg;                                 // timing experiments (probe builds only, results wrong): 1 = forward without its tile loop
     int order;                               // workgroup numbering (attention2.hip: decode_block); set by the launcher
 };
 
