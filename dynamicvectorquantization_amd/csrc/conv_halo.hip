@@ -16,6 +16,8 @@
 namespace {
 
 
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+
 constexpr int TH = 8, TW = 32;                 // pixel tile
 constexpr int HW_ = TW + 2;                    // halo width
 constexpr int HROWS = (TH + 2) * HW_;          // 340 halo pixels
@@ -49,6 +51,7 @@ struct HaloParams {
     int dbg;             // profiling experiments only (DVQ_HALO_DBG): 1 = skip the epilogue, 2 = skip the MFMA loop, 6 = per-workgroup
                          //   time stamps (tools/debug/halo_trace.py)
     int nt_out;          // 1: the output tensor is larger than the Infinity Cache -- nontemporal stores (DVQ_HALO_NT=0: never)
+    int mfma_stats;      // 1: output statistics on the matrix pipe where the epilogue supports it (DVQ_HALO_MFMA_STATS=0: vector path)
     int nt_in;           // 1: the same for the input halo loads, when one workgroup column covers all output channels (DVQ_HALO_NT_IN)
     int nblocks;         // N * tiles_y * tiles_x * gn
     unsigned mg_gn, mg_tx, mg_ty;      // fdiv_u32 magics of gn, tiles_x, tiles_y
@@ -546,6 +549,75 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
     if constexpr (TRACE) tr[2] = wall_clock64();
     const int cpg = p.out_stats != nullptr ? p.Cout / p.out_groups : 0;     // channels per group: power of two <= 32 (launcher)
     const bool pairs = cpg >= 2 && p.dbg != 8 && p.dbg != 9;        // statistics per channel PAIR (v_dot2_f32_bf16: one instruction per dword and moment)
+    // GroupNorm statistics on the MATRIX pipe (round 6; 128-channel tiles, groups of 4 or 8 channels, no vector-path residual): wave w
+    // takes channel tile w of the staged bf16 tile as MFMA operands Y^T (lane = channel, 8 pixels per k-step, formed by
+    // ds_read_b64_tr_b16 from the pixel-major rows) and accumulates  Y^T Y  (its diagonal = sums of squares) and  Y^T 1  (sums) over the
+    // 256 pixels: 32 MFMAs per wave (5.5 % of the tile's 576) and ~40 vector instructions, instead of 128 v_dot2_f32_bf16 + 16
+    // cross-lane folds per lane in the store loop -- instructions that issue once per MFMA of the CU neighbour (see the kernel header).
+    // Same values as stored (bf16), fp32 accumulation; HaloParams::mfma_stats = 0 (DVQ_HALO_MFMA_STATS=0) keeps the vector path.
+    bool mfma_stats = false;
+    if constexpr (NT == 4 && !OUT32) mfma_stats = p.mfma_stats && p.out_stats != nullptr && !resv && (cpg == 4 || cpg == 8) && p.dbg == 0;
+    if constexpr (NT == 4 && !OUT32) {
+        if (mfma_stats) {
+            const int g4 = lane >> 4, li = lane & 15;
+            const int c_lo = 4 * wave + 2 * (g4 & 1) + ((li & 3) >> 1);      // 16-byte chunk (8 channels) holding this lane's 4 columns
+            const int r0 = 8 * half + (li >> 2);                              // (pixel & 15) of the first read; the second is 4 rows on
+            const char* q0 = smem + r0 * ROWS + ((c_lo ^ r0) << 4) + (li & 1) * 8;
+            const char* q1 = smem + (r0 + 4) * ROWS + ((c_lo ^ (r0 + 4)) << 4) + (li & 1) * 8;
+            f32x16 ssq, ssum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ssq[r] = ssum[r] = 0.f;
+            const dvq_u32x4 o4 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+            const bf16x8 onesf = __builtin_bit_cast(bf16x8, o4);
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0 + ks * 16 * ROWS));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q1 + ks * 16 * ROWS));
+                const bf16x8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                ssq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, f, ssq, 0, 0, 0);
+                ssum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, onesf, ssum, 0, 0, 0);
+            }
+            // C layout: lane -> column l31, register r -> row (r & 3) + 8 (r >> 2) + 4 half.  Sums: any column, rows = channels; the four
+            // registers 4 b .. 4 b + 3 are the channels 8 b + 4 half .. + 3 (one group of 4, half a group of 8).
+            const int b_sel = l31 >> 3, h_sel = (l31 >> 2) & 1;
+            float t4[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) t4[b] = (ssum[4 * b] + ssum[4 * b + 1]) + (ssum[4 * b + 2] + ssum[4 * b + 3]);
+            float s1 = b_sel == 0 ? t4[0] : b_sel == 1 ? t4[1] : b_sel == 2 ? t4[2] : t4[3];
+            // diagonal of Y^T Y: row == column  <=>  register (l31 & 3) + 4 (l31 >> 3) in the half (l31 >> 2) & 1
+            float dsel[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int a = l31 & 3;
+                dsel[b] = a == 0 ? ssq[4 * b] : a == 1 ? ssq[4 * b + 1] : a == 2 ? ssq[4 * b + 2] : ssq[4 * b + 3];
+            }
+            float s2 = b_sel == 0 ? dsel[0] : b_sel == 1 ? dsel[1] : b_sel == 2 ? dsel[2] : dsel[3];
+            if (half != h_sel) s2 = 0.f;
+            if (cpg == 4 && half != h_sel) s1 = 0.f;                            // (groups of 8: both halves carry one half of the group)
+            s2 += __shfl_xor(s2, 1, 64);
+            s2 += __shfl_xor(s2, 2, 64);
+            if (cpg == 8) s2 += __shfl_xor(s2, 4, 64);
+            {   // the two 32-lane halves (v_permlane32_swap: {low half everywhere, high half everywhere})
+                const auto w1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
+                s1 = __uint_as_float(w1[0]) + __uint_as_float(w1[1]);
+                const auto w2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+                s2 = __uint_as_float(w2[0]) + __uint_as_float(w2[1]);
+            }
+            const int c0ch = 32 * wave + l31;                                   // first channel of this lane's group (when it leads one)
+            if (half == 0 && (l31 & (cpg - 1)) == 0 && n0 + c0ch < p.Cout) {
+                const int gg = (n0 + c0ch) / cpg;
+                if (p.stat_part != nullptr) {
+                    const int ntiles = p.tiles_y * p.tiles_x;
+                    float* dst = p.stat_part + ((((int64_t)n * p.out_groups + gg) * ntiles) + ty * p.tiles_x + tx) * 2;
+                    dst[0] = s1;
+                    dst[1] = s2;
+                } else {
+                    atomicAdd(&p.out_stats[((int64_t)n * p.out_groups + gg) * 2], (double)s1);
+                    atomicAdd(&p.out_stats[((int64_t)n * p.out_groups + gg) * 2 + 1], (double)s2);
+                }
+            }
+        }
+    }
     float gs[8], gq[8];                 // output statistics of this thread's 8 channels / 4 pairs (chunk ch in every iteration)
 #pragma unroll
     for (int k = 0; k < 8; ++k) gs[k] = gq[k] = 0.f;
@@ -610,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
                         gq[2 * k + hh] = fmaf(dz, xh, gq[2 * k + hh]);
                     }
                 }
-            } else if (p.out_stats != nullptr) {
+            } else if (p.out_stats != nullptr && !mfma_stats) {
                 const unsigned* pv = &v.x;
                 if (pairs) {
 #pragma unroll
@@ -633,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloParams p) {
         }
     }
     if constexpr (TRACE) tr[3] = wall_clock64();
-    if (p.out_stats != nullptr) {
+    if (p.out_stats != nullptr && !mfma_stats) {
         // lanes l, l + CPRW, l + 2 CPRW, ... of a wave hold partials of the same 8 channels: fold them with shuffles, park one
         // row per wave in LDS, add the NW rows per channel (or pair), fold the channels of a group (a power of two, lanes adjacent)
         const int nval = pairs ? 4 : 8;         // values per thread and moment; a staged column index is ch * nval + k
@@ -774,6 +846,11 @@ static int halo_try_impl(const void* x, const void* w, const float* bias, const 
         return e == nullptr ? 1 : atoi(e);
     }();
     p.nt_out = nt_env && !out32 && N * H * W * Cout * 2 > (192ll << 20);
+    static const int ms_env = [] {
+        const char* e = getenv("DVQ_HALO_MFMA_STATS");
+        return e == nullptr ? 1 : atoi(e);
+    }();
+    p.mfma_stats = ms_env;
     static const int nt_in_env = [] {
         const char* e = getenv("DVQ_HALO_NT_IN");
         return e == nullptr ? 0 : atoi(e);
@@ -859,7 +936,6 @@ constexpr int WHPIECES = (WHROWS + 7) / 8;          // 26
 constexpr int WHALOB = WHPIECES * 8 * ROWB;         // 26624
 constexpr int WSTAGE = WDYB + WHALOB;               // 59392
 constexpr int WNPIECES = 32 + WHPIECES;             // 58 DMA pieces per stage
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 
 struct WgParams {
     const bf16_t* X;     // [N,H,W,Cin]
