@@ -28,7 +28,8 @@ class DecodeLayer(C.Structure):
 
 class LinPackEntry(C.Structure):
     """LinPackEntry of csrc/misc.hip (dvq_linear_pack_multi)"""
-    _fields_ = [("master", vp), ("w", vp), ("wt", vp), ("out", i64), ("in_", i64), ("out_p", i64), ("tile_begin", i64)]
+    _fields_ = [("master", vp), ("w", vp), ("wt", vp), ("out", i64), ("in_", i64), ("out_p", i64), ("tile_begin", i64),
+                ("wt_ld", i64), ("bias_src", vp), ("bias_dst", vp)]
 
 
 class PackEntry(C.Structure):
@@ -144,6 +145,8 @@ SIGNATURES = {
     "dvq_attn_causal_mask_bytes": (i64, [i64, i64, i32]),
     "dvq_attn_causal_fwd": (i32, [vp, vp, vp, i32, i64, i64, i32, i32, f32, f32, C.c_uint64, vp, vp, vp, vp, vp]),
     "dvq_attn_causal_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i64, i32, i32, f32, f32, C.c_uint64, vp, vp, vp, vp, vp, vp]),
+    "dvq_attn_causal_fwd_ld": (i32, [vp, vp, vp, i64, i32, i64, i64, i32, i32, f32, f32, C.c_uint64, vp, vp, vp, vp]),
+    "dvq_attn_causal_bwd_ld": (i32, [vp, vp, vp, i64, vp, vp, vp, i32, i64, i64, i32, i32, f32, f32, C.c_uint64, vp, vp, vp, vp, vp, vp]),
     "dvq_attn_full_scratch_bytes": (i64, [i64, i64, i32, i32]),
     "dvq_attn_full_fwd": (i32, [vp, vp, vp, i32, i64, i64, i32, f32, vp, vp, vp, vp]),
     "dvq_attn_full_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i64, i32, f32, vp, vp, vp, vp, vp]),

@@ -703,6 +703,7 @@ Attn2Args v2_args(const AttnParams& p, int64_t B) {
     a.scale = p.scale; a.inv_keep = p.inv_keep; a.thr = p.thr; a.rm = p.rm; a.ra = p.ra;
     a.mask = p.mask;
     a.causal = p.causal;
+    a.ldq = p.C;
     return a;
 }
 
@@ -721,9 +722,29 @@ int64_t dvq_attn_causal_mask_bytes(int64_t B, int64_t T, int n_head) {
     return B * n_head * nt * nt * 16 * 8;
 }
 
+static int attn_causal_fwd_impl(const void* q, const void* k, const void* v, int64_t ldqkv, int dtype, int64_t B, int64_t T, int n_head,
+                                int head_dim, float scale, float p_drop, uint64_t seed, void* out, float* lse, void* scratch,
+                                void* drop_mask, dvq_stream_t stream);
+
 int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, int64_t B, int64_t T, int n_head, int head_dim,
                         float scale, float p_drop, uint64_t seed, void* out, float* lse, void* scratch, void* drop_mask,
                         dvq_stream_t stream) {
+    return attn_causal_fwd_impl(q, k, v, (int64_t)n_head * head_dim, dtype, B, T, n_head, head_dim, scale, p_drop, seed, out, lse, scratch,
+                                drop_mask, stream);
+}
+
+int dvq_attn_causal_fwd_ld(const void* q, const void* k, const void* v, int64_t ldqkv, int dtype, int64_t B, int64_t T, int n_head,
+                           int head_dim, float scale, float p_drop, uint64_t seed, void* out, float* lse, void* drop_mask,
+                           dvq_stream_t stream) {
+    DVQ_REQUIRE(head_dim == 128 && attn_v2_env(), DVQ_ESHAPE, "dvq_attn_causal_fwd_ld: a row pitch needs the head-size-128 kernels of attention2.hip");
+    DVQ_REQUIRE(ldqkv >= (int64_t)n_head * head_dim && ldqkv % 8 == 0 && (double)T * (double)ldqkv * 2.0 < 4294967296.0, DVQ_ESHAPE,
+                "dvq_attn_causal_fwd_ld: bad pitch");
+    return attn_causal_fwd_impl(q, k, v, ldqkv, dtype, B, T, n_head, head_dim, scale, p_drop, seed, out, lse, out /* unused */, drop_mask, stream);
+}
+
+static int attn_causal_fwd_impl(const void* q, const void* k, const void* v, int64_t ldqkv, int dtype, int64_t B, int64_t T, int n_head,
+                                int head_dim, float scale, float p_drop, uint64_t seed, void* out, float* lse, void* scratch,
+                                void* drop_mask, dvq_stream_t stream) {
     DVQ_REQUIRE(q && k && v && out && lse && scratch, DVQ_EINVAL, "dvq_attn_causal_fwd: null pointer");
     AttnParams p{};
     int rc = fill_params(p, "dvq_attn_causal_fwd", dtype, B, T, n_head, head_dim, scale, p_drop, seed);
@@ -732,10 +753,13 @@ int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, 
     p.out = (bf16_t*)out; p.lse = lse;
     p.mask = (unsigned long long*)drop_mask;
     if (head_dim == 128 && attn_v2_env()) {
-        dvq_attn2_fwd(v2_args(p, B), (hipStream_t)stream);
+        Attn2Args a = v2_args(p, B);
+        a.ldq = (int)ldqkv;
+        dvq_attn2_fwd(a, (hipStream_t)stream);
         DVQ_CHECK_LAUNCH("attn_causal_fwd");
         return DVQ_OK;
     }
+    DVQ_REQUIRE(ldqkv == p.C, DVQ_ESHAPE, "dvq_attn_causal_fwd: the first-generation kernels take contiguous q, k, v");
     rc = dvq_transpose(v, dtype, B, T, p.C, scratch, stream);                        // v^T [B][C][T]
     if (rc != DVQ_OK) return rc;
     const int nqt = (int)((T + 31) / 32);
@@ -746,9 +770,30 @@ int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, 
     return DVQ_OK;
 }
 
+static int attn_causal_bwd_impl(const void* q, const void* k, const void* v, int64_t ldqkv, const void* out, const void* dout, const float* lse,
+                                int dtype, int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop, uint64_t seed, void* dq,
+                                void* dk, void* dv, void* scratch, const void* drop_mask, dvq_stream_t stream);
+
 int dvq_attn_causal_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse, int dtype,
                         int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop, uint64_t seed, void* dq, void* dk,
                         void* dv, void* scratch, const void* drop_mask, dvq_stream_t stream) {
+    return attn_causal_bwd_impl(q, k, v, (int64_t)n_head * head_dim, out, dout, lse, dtype, B, T, n_head, head_dim, scale, p_drop, seed, dq, dk,
+                                dv, scratch, drop_mask, stream);
+}
+
+int dvq_attn_causal_bwd_ld(const void* q, const void* k, const void* v, int64_t ldqkv, const void* out, const void* dout, const float* lse,
+                           int dtype, int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop, uint64_t seed, void* dq,
+                           void* dk, void* dv, void* scratch, const void* drop_mask, dvq_stream_t stream) {
+    DVQ_REQUIRE(head_dim == 128 && attn_v2_env(), DVQ_ESHAPE, "dvq_attn_causal_bwd_ld: a row pitch needs the head-size-128 kernels of attention2.hip");
+    DVQ_REQUIRE(ldqkv >= (int64_t)n_head * head_dim && ldqkv % 8 == 0 && (double)T * (double)ldqkv * 2.0 < 4294967296.0, DVQ_ESHAPE,
+                "dvq_attn_causal_bwd_ld: bad pitch");
+    return attn_causal_bwd_impl(q, k, v, ldqkv, out, dout, lse, dtype, B, T, n_head, head_dim, scale, p_drop, seed, dq, dk, dv, scratch, drop_mask,
+                                stream);
+}
+
+static int attn_causal_bwd_impl(const void* q, const void* k, const void* v, int64_t ldqkv, const void* out, const void* dout, const float* lse,
+                                int dtype, int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop, uint64_t seed, void* dq,
+                                void* dk, void* dv, void* scratch, const void* drop_mask, dvq_stream_t stream) {
     DVQ_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && scratch, DVQ_EINVAL, "dvq_attn_causal_bwd: null pointer");
     AttnParams p{};
     int rc = fill_params(p, "dvq_attn_causal_bwd", dtype, B, T, n_head, head_dim, scale, p_drop, seed);
@@ -764,10 +809,13 @@ int dvq_attn_causal_bwd(const void* q, const void* k, const void* v, const void*
     p.lse = const_cast<float*>(lse); p.dsum = dsum;
     p.mask = (unsigned long long*)const_cast<void*>(drop_mask);
     if (head_dim == 128 && attn_v2_env()) {
-        dvq_attn2_bwd(v2_args(p, B), (hipStream_t)stream);
+        Attn2Args a = v2_args(p, B);
+        a.ldq = (int)ldqkv;
+        dvq_attn2_bwd(a, (hipStream_t)stream);
         DVQ_CHECK_LAUNCH("attn_causal_bwd");
         return DVQ_OK;
     }
+    DVQ_REQUIRE(ldqkv == p.C, DVQ_ESHAPE, "dvq_attn_causal_bwd: the first-generation kernels take contiguous q, k, v");
     if ((rc = dvq_transpose(q, dtype, B, T, p.C, qt, stream)) != DVQ_OK) return rc;
     if ((rc = dvq_transpose(k, dtype, B, T, p.C, kt, stream)) != DVQ_OK) return rc;
     if ((rc = dvq_transpose(dout, dtype, B, T, p.C, dot, stream)) != DVQ_OK) return rc;

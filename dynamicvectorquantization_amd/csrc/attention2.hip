@@ -240,12 +240,13 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_fwd_kernel(Attn2Args 
     const int qrow = qt * 32 + l31;
     const bool qok = active && qrow < T;
     const int64_t rowbase = (int64_t)b * T;
-    const i32x4 rsK = make_rsrc(p.k + rowbase * C, (unsigned)(T * C * 2)), rsV = make_rsrc(p.v + rowbase * C, (unsigned)(T * C * 2));
-    const TileDma<HS> dma(lane, wave, C, h);
+    const int L = p.ldq;                                          // row pitch of q / k / v (C, or 3 C inside a fused [q | k | v] matrix)
+    const i32x4 rsK = make_rsrc(p.k + rowbase * L, (unsigned)(T * L * 2)), rsV = make_rsrc(p.v + rowbase * L, (unsigned)(T * L * 2));
+    const TileDma<HS> dma(lane, wave, L, h);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
     // slots: K tiles at [0, 2 TILEB), V tiles at [2 TILEB, 4 TILEB)
-    auto issue_k = [&](int kt) { dma.issue(rsK, 64 * kt, C, lds0 + (unsigned)((kt & 1) * TILEB), wave); };
-    auto issue_v = [&](int kt) { dma.issue(rsV, 64 * kt, C, lds0 + (unsigned)((2 + (kt & 1)) * TILEB), wave); };
+    auto issue_k = [&](int kt) { dma.issue(rsK, 64 * kt, L, lds0 + (unsigned)((kt & 1) * TILEB), wave); };
+    auto issue_v = [&](int kt) { dma.issue(rsV, 64 * kt, L, lds0 + (unsigned)((2 + (kt & 1)) * TILEB), wave); };
     const int last_t = CAUSAL ? qt_max : nqt - 1;                  // last 32-key tile any wave of the workgroup sees
     const int nk = p.dbg != 0 ? 0 : (last_t >> 1) + 1;             // 64-key tiles (DVQ_ATTN2_DBG, probe builds: 1 = no tile loop at all,
                                                                    //   2 = nor the output stores, 3 = nor the Q fragment loads / first DMA)
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_fwd_kernel(Attn2Args 
     if (p.dbg != 3) issue_k(0);
     bf16x8 qf[NS];
     {
-        const bf16_t* qp = p.q + (rowbase + qrow) * C + h * HS + 8 * half;
+        const bf16_t* qp = p.q + (rowbase + qrow) * L + h * HS + 8 * half;
 #pragma unroll
         for (int s = 0; s < NS; ++s) qf[s] = ldfrag(qp + 16 * s, qok && p.dbg != 3);
     }
@@ -404,13 +405,14 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_bwd_dq_kernel(Attn2Ar
     const int qrow = qt * 32 + l31;
     const bool qok = active && qrow < T;
     const int64_t rowbase = (int64_t)b * T;
-    const i32x4 rsK = make_rsrc(p.k + rowbase * C, (unsigned)(T * C * 2)), rsV = make_rsrc(p.v + rowbase * C, (unsigned)(T * C * 2));
-    const TileDma<HS> dma(lane, wave, C, h);
+    const int L = p.ldq;                                          // row pitch of q / k / v / dq (dout and o: C)
+    const i32x4 rsK = make_rsrc(p.k + rowbase * L, (unsigned)(T * L * 2)), rsV = make_rsrc(p.v + rowbase * L, (unsigned)(T * L * 2));
+    const TileDma<HS> dma(lane, wave, L, h);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
     auto stage = [&](int kt) {
         const unsigned base = lds0 + (unsigned)((kt & 1) * 2 * TILEB);
-        dma.issue(rsK, 64 * kt, C, base, wave);
-        dma.issue(rsV, 64 * kt, C, base + TILEB, wave);
+        dma.issue(rsK, 64 * kt, L, base, wave);
+        dma.issue(rsV, 64 * kt, L, base + TILEB, wave);
     };
     const int last_t = CAUSAL ? qt_max : nqt - 1;
     const int nk = (last_t >> 1) + 1;
@@ -419,10 +421,10 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_bwd_dq_kernel(Attn2Ar
     bf16x8 qf[NS], dof[NS];
     float dq_ = 0.f;                                              // D[query] = sum_ch dO * O
     {
-        const int64_t e0 = (rowbase + qrow) * C + h * HS + 8 * half;
+        const int64_t e0 = (rowbase + qrow) * C + h * HS + 8 * half, eq = (rowbase + qrow) * L + h * HS + 8 * half;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            qf[s] = ldfrag(p.q + e0 + 16 * s, qok);
+            qf[s] = ldfrag(p.q + eq + 16 * s, qok);
             dof[s] = ldfrag(p.dout + e0 + 16 * s, qok);
             Frag fo, fd;
             fo.v = ldfrag(p.o + e0 + 16 * s, qok);
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_bwd_dq_kernel(Attn2Ar
             }
         }
     }
-    if (qok) store_ct<NM>(p.dq + (rowbase + qrow) * C + h * HS, acc, half, p.scale);
+    if (qok) store_ct<NM>(p.dq + (rowbase + qrow) * L + h * HS, acc, half, p.scale);
 #endif
 }
 
@@ -526,14 +528,15 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : Cfg<HS>::WPC) void attn2_bwd_d
     const int krow = kt * 32 + l31;
     const bool kok = active && krow < T;
     const int64_t rowbase = (int64_t)b * T;
-    const i32x4 rsQ = make_rsrc(p.q + rowbase * C, (unsigned)(T * C * 2)), rsD = make_rsrc(p.dout + rowbase * C, (unsigned)(T * C * 2));
+    const int L = p.ldq;                                          // row pitch of q / k / v / dk / dv (dout: C)
+    const i32x4 rsQ = make_rsrc(p.q + rowbase * L, (unsigned)(T * L * 2)), rsD = make_rsrc(p.dout + rowbase * C, (unsigned)(T * C * 2));
     const i32x4 rsL = make_rsrc(p.lse + (int64_t)bh * T, (unsigned)(T * 4)), rsS = make_rsrc(p.dsum + (int64_t)bh * T, (unsigned)(T * 4));
-    const TileDma<HS> dma(lane, wave, C, h);
+    const TileDma<HS> dma(lane, wave, C, h), dmaq(lane, wave, L, h);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
     const int q64_first = CAUSAL ? kt_min >> 1 : 0, nq64 = (nt + 1) >> 1;
     auto stage = [&](int q64) {
         const unsigned base = lds0 + (unsigned)(((q64 - q64_first) & 1) * KV_STAGE);
-        dma.issue(rsQ, 64 * q64, C, base, wave);
+        dmaq.issue(rsQ, 64 * q64, L, base, wave);
         dma.issue(rsD, 64 * q64, C, base + TILEB, wave);
         const int so = __builtin_amdgcn_readfirstlane(64 * q64 * 4);
         if (wave == 0) dma4(base + 2 * TILEB, lane * 4, rsL, so);
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : Cfg<HS>::WPC) void attn2_bwd_d
     stage(q64_first);
     bf16x8 kf[NS], vf[NS];
     {
-        const int64_t e0 = (rowbase + krow) * C + h * HS + 8 * half;
+        const int64_t e0 = (rowbase + krow) * L + h * HS + 8 * half;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             kf[s] = ldfrag(p.k + e0 + 16 * s, kok);
@@ -628,8 +631,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : Cfg<HS>::WPC) void attn2_bwd_d
         }
     }
     if (kok) {
-        store_ct<NM>((DO_DV ? p.dv : p.dk) + (rowbase + krow) * C + h * HS, acc, half, DO_DV ? 1.f : p.scale);
-        if constexpr (MODE == 0) store_ct<NM>(p.dk + (rowbase + krow) * C + h * HS, acc2, half, p.scale);
+        store_ct<NM>((DO_DV ? p.dv : p.dk) + (rowbase + krow) * L + h * HS, acc, half, DO_DV ? 1.f : p.scale);
+        if constexpr (MODE == 0) store_ct<NM>(p.dk + (rowbase + krow) * L + h * HS, acc2, half, p.scale);
     }
 #endif
 }

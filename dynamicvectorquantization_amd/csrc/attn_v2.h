@@ -9,6 +9,8 @@ struct Attn2Args {
     float* lse;                              // [B][nh][T]
     float* dsum;                             // [B][nh][T]: rowsum(dO * O), written by the dQ kernel, read by the dK / dV kernels
     int B, T, nh;
+    int ldq;                                 // row pitch (elements) of q, k, v, dq, dk, dv: C, or 3 C when they are column blocks of one
+                                             // fused [M][3 C] projection output; out, o, dout always have pitch C
     float scale, inv_keep;
     unsigned thr, rm, ra;                    // dropout: keep iff dvq_hash32(idx * rm + ra) >= thr (thr == 0: no dropout)
     unsigned long long* mask;                // optional keep-decision words (attention.hip: drop_tile)

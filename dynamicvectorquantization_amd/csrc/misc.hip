@@ -402,6 +402,10 @@ struct LinPackEntry {    // mirrored by ctypes in _lib.py
     bf16_t* wt;
     int64_t out, in, out_p;
     int64_t tile_begin;  // exclusive prefix sum of ceil(out_p / 64) * ceil(in / 64)
+    int64_t wt_ld;       // row pitch of wt in elements (0: out_p).  Larger when wt is a column block of a wider matrix -- the fused
+                         //   [Wk^T | Wq^T | Wv^T] operand of the attention projections' single input-gradient GEMM (stackgpt.py)
+    const float* bias_src;   // optional: the layer's fp32 bias [out] ...
+    float* bias_dst;         // ... copied here (a slice of the fused projection's concatenated bias); null: nothing
 };
 
 __global__ __launch_bounds__(256) void linear_pack_multi_kernel(const LinPackEntry* __restrict__ tab, int n) {
@@ -416,6 +420,9 @@ __global__ __launch_bounds__(256) void linear_pack_multi_kernel(const LinPackEnt
     const int ti = (int)(((int64_t)blockIdx.x - t.tile_begin) / tj_n), tj = (int)(((int64_t)blockIdx.x - t.tile_begin) - (int64_t)ti * tj_n);
     const int r0 = ti * 64, c0 = tj * 64;
     const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;
+    const int64_t wt_ld = t.wt_ld != 0 ? t.wt_ld : t.out_p;
+    if (t.bias_dst != nullptr && tj == 0 && threadIdx.x < 64 && r0 + (int)threadIdx.x < t.out)
+        t.bias_dst[r0 + threadIdx.x] = t.bias_src[r0 + threadIdx.x];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = rr + 16 * i, row = r0 + r, col = c0 + 4 * q;
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(256) void linear_pack_multi_kernel(const LinPackEnt
             uint2 pk;
             pk.x = (unsigned)f32_to_bf16(tile[4 * q][c]) | ((unsigned)f32_to_bf16(tile[4 * q + 1][c]) << 16);
             pk.y = (unsigned)f32_to_bf16(tile[4 * q + 2][c]) | ((unsigned)f32_to_bf16(tile[4 * q + 3][c]) << 16);
-            *reinterpret_cast<uint2*>(t.wt + (int64_t)col * t.out_p + row) = pk;
+            *reinterpret_cast<uint2*>(t.wt + (int64_t)col * wt_ld + row) = pk;
         }
     }
 }

@@ -1026,6 +1026,41 @@ def attn_causal_bwd(q, k, v, out, dout, lse, b, t, n_head, scale, p_drop=0.0, se
     return dq, dk, dv
 
 
+def attn_causal_fwd_fused(qkv, cols, b, t, n_head, scale, p_drop=0.0, seed=0, drop_mask=None):
+    """q, k, v as column blocks of ONE projection output qkv [B*T, 3 C] (cols = their first columns, order (q, k, v)): no copies, the
+    kernels take the row pitch (dvq_attn_causal_fwd_ld; head size 128) -> (out [B*T, C], lse)"""
+    m, ld = qkv.shape
+    c = ld // 3
+    assert qkv.is_contiguous() and ld == 3 * c and c == n_head * 128
+    flat = qkv.view(-1)
+    q, k, v = (flat[o:] for o in cols)                 # (pointer offsets: the kernels walk rows with the pitch ld)
+    out = torch.empty(m, c, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(b, n_head, t, dtype=torch.float32, device=qkv.device)
+    _timed("attn_causal_fwd", 2 * b * t * t * c, 4 * m * c * qkv.element_size(), lambda: check(
+        lib().dvq_attn_causal_fwd_ld(_p(q), _p(k), _p(v), ld, dt(qkv), b, t, n_head, c // n_head, float(scale), float(p_drop),
+                                     int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out), _p(lse), _p(drop_mask), _s()),
+        "dvq_attn_causal_fwd_ld"))
+    return out, lse
+
+
+def attn_causal_bwd_fused(qkv, cols, out, dout, lse, b, t, n_head, scale, p_drop=0.0, seed=0, drop_mask=None):
+    """-> dqkv [B*T, 3 C]: the three gradients as column blocks in the layout of qkv (one input-gradient GEMM consumes them)"""
+    m, ld = qkv.shape
+    c = ld // 3
+    flat = qkv.view(-1)
+    q, k, v = (flat[o:] for o in cols)
+    dqkv = torch.empty_like(qkv)
+    dflat = dqkv.view(-1)
+    dq, dk, dv = (dflat[o:] for o in cols)
+    scratch = _attn_scratch(out, b, t, n_head, True)
+    _timed("attn_causal_bwd", 5 * b * t * t * c, 8 * m * c * qkv.element_size(), lambda: check(
+        lib().dvq_attn_causal_bwd_ld(_p(q), _p(k), _p(v), ld, _p(out), _p(dout), _p(lse), dt(qkv), b, t, n_head, c // n_head, float(scale),
+                                     float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(dq), _p(dk), _p(dv), _p(scratch), _p(drop_mask),
+                                     _s()),
+        "dvq_attn_causal_bwd_ld"))
+    return dqkv
+
+
 def attn_full_ok(q, t):
     """eligibility of the fused single-head full attention (AttnBlock): bf16, C = 256, T % 32 == 0"""
     return (q.dtype == torch.bfloat16 and q.shape[-1] == 256 and t % 32 == 0 and q.shape[0] // max(1, t) <= 65535

@@ -219,6 +219,11 @@ class Linear(nn.Module):
         self._wtcache = (w, wt)
         return wt
 
+    def _wt_ld(self, w):
+        """row pitch of `_wt(w)` (out_p unless the layer's transposed copy is a column block of a fused operand)"""
+        ent = getattr(self, "_lpack", None)
+        return ent.get("wt_ld", self.out_p) if ent is not None and w is ent["w"] else self.out_p
+
     def _w_uncached(self, dtype):
         w = K.cast(self.weight.detach().contiguous(), dtype)
         b = self.bias.detach() if self.bias is not None else None
@@ -267,14 +272,14 @@ class Linear(nn.Module):
         # give 324 / 432 tiles for 256 CUs) and its HBM-bound partial fold overlaps MFMA-bound kernels.  DVQ_LINEAR_SIDE=0: main stream
         if need_dx and m >= 1024 and rt.side_wgrad_enabled() and os.environ.get("DVQ_LINEAR_SIDE", "1") != "0":
             wt = self._wt(w)                                                 # made on the main stream, before the fork
-            dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self.out_p, self.in_features, residual=addend)
+            dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self._wt_ld(w), self.in_features, residual=addend)
             rt.run_on_side(wgrad, dy, x2d)      # after the input gradient (forking before it measured the same: 82.3 vs 82.0 ms)
             return dx.view(m, self.in_features)
         wgrad()
         if not need_dx:
             return None
         wt = self._wt(w)                                                     # [in, out_p]
-        dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self.out_p, self.in_features, residual=addend)
+        dx = K.gemm_nt(dy, wt, m, self.in_features, self.out_p, self.out_p, self._wt_ld(w), self.in_features, residual=addend)
         return dx.view(m, self.in_features)
 
 
@@ -291,15 +296,21 @@ class _LinearPackRegistry:
     def _key(m):
         return (rt.param_epoch(m.weight), m.weight.data_ptr(), m.weight._version)
 
-    def register(self, mod):
+    def register(self, mod, w=None, wt=None, wt_ld=0, bias_dst=None):
+        """w / wt / bias_dst: caller-owned destinations instead of private buffers -- slices of the row-concatenated operand of several
+        projections that share their input (stackgpt.CausalSelfAttention: [Wk; Wq; Wv], its transpose with row pitch wt_ld, and the
+        concatenated bias); wt is then a FLAT tensor starting at the layer's first column"""
         import weakref
         dev = mod.weight.device
-        ent = {"w": torch.zeros(mod.out_p, mod.in_features, dtype=torch.bfloat16, device=dev),
-               "wt": torch.zeros(mod.in_features, mod.out_p, dtype=torch.bfloat16, device=dev), "key": None, "bias_key": None,
+        known = getattr(mod, "_lpack", None) is not None
+        ent = {"w": w if w is not None else torch.zeros(mod.out_p, mod.in_features, dtype=torch.bfloat16, device=dev),
+               "wt": wt if wt is not None else torch.zeros(mod.in_features, mod.out_p, dtype=torch.bfloat16, device=dev),
+               "wt_ld": int(wt_ld) if wt is not None else mod.out_p, "bias_dst": bias_dst, "key": None, "bias_key": None,
                "bias_p": (torch.zeros(mod.out_p, dtype=torch.float32, device=dev)
                           if mod.bias is not None and mod.out_p != mod.out_features else None)}
         mod._lpack = ent
-        self.items.setdefault(dev, []).append(weakref.ref(mod))
+        if not known:
+            self.items.setdefault(dev, []).append(weakref.ref(mod))
         for k in [k for k in self.tables if k[0] == dev]:
             self.tables.pop(k, None)
         return ent
@@ -313,8 +324,10 @@ class _LinearPackRegistry:
             begin = 0
             for i, m in enumerate(mods):
                 e = m._lpack
+                bd = e.get("bias_dst")
                 arr[i] = LinPackEntry(m.weight.data_ptr(), e["w"].data_ptr(), e["wt"].data_ptr(), m.out_features, m.in_features, m.out_p,
-                                      begin)
+                                      begin, e.get("wt_ld", m.out_p), m.bias.data_ptr() if bd is not None else None,
+                                      bd.data_ptr() if bd is not None else None)
                 begin += -(-m.out_p // 64) * -(-m.in_features // 64)
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(mods[0].weight.device)
             tab = {"sig": sig, "table": raw, "n": len(mods), "tiles": begin}

@@ -104,9 +104,55 @@ class CausalSelfAttention(nn.Module):
         self.n_head = config.n_head
         self._n_unmasked = int(getattr(config, "n_unmasked", 0) or 0)
 
+    def _qkv_pack(self):
+        """ONE bf16 operand for the three projections of the same input (stackgpt.py:46-48 of the reference runs them as three Linear
+        layers): rows [Wk; Wq; Wv] for the forward GEMM (N = 3 C), its transpose [Wk^T | Wq^T | Wv^T] for the single input-gradient GEMM
+        (K = 3 C) and the concatenated bias.  The buffers belong to the Linear pack registry's entries of the three layers, i.e. they are
+        refreshed by the same launch that repacks every Linear after an optimizer step; the fp32 masters, their gradients and the
+        state_dict stay three separate parameters"""
+        from .layers import LINEAR_PACKS
+        dev = self.key.weight.device
+        ent = getattr(self, "_qkv", None)
+        if ent is None or ent["w"].device != dev:
+            c = self.key.in_features
+            wcat = torch.zeros(3 * c, c, dtype=torch.bfloat16, device=dev)
+            wtcat = torch.zeros(c, 3 * c, dtype=torch.bfloat16, device=dev)
+            bcat = torch.zeros(3 * c, dtype=torch.float32, device=dev)
+            for i, lin in enumerate((self.key, self.query, self.value)):
+                LINEAR_PACKS.register(lin, w=wcat[i * c:(i + 1) * c], wt=wtcat.view(-1)[i * c:], wt_ld=3 * c, bias_dst=bcat[i * c:(i + 1) * c])
+            ent = self._qkv = {"w": wcat, "wt": wtcat, "b": bcat}
+        for lin in (self.key, self.query, self.value):
+            lin._w(torch.bfloat16)                      # (re)packs when the parameters changed: one launch for the whole optimizer group
+        return ent
+
+    def _qkv_fusable(self, x2d, hs):
+        return (hs == 128 and x2d.dtype == torch.bfloat16 and os.environ.get("DVQ_QKV_FUSED", "1") != "0" and
+                os.environ.get("DVQ_ATTN_V2", "1") != "0" and os.environ.get("DVQ_LINEAR_MULTIPACK", "1") != "0" and
+                all(l.bias is not None and l.out_p == l.out_features for l in (self.key, self.query, self.value)))
+
     def fwd(self, x2d, b, t, tape, resid=None):
         c = x2d.shape[1]
         nh, hs = self.n_head, c // self.n_head
+        if K.attn_causal_ok(x2d, nh, b, t) and not self._n_unmasked and self._qkv_fusable(x2d, hs):
+            # key / query / value as ONE GEMM (N = 3 C) into [M, 3 C]; the attention kernels read the three column blocks with the row
+            # pitch 3 C; the backward writes dk / dq / dv into the same layout and takes the input gradient as ONE GEMM over K = 3 C
+            # (three GEMMs + two adds before).  DVQ_QKV_FUSED=0: three Linear layers
+            m = x2d.shape[0]
+            pk = self._qkv_pack()
+            qkv = K.gemm_nt(x2d, pk["w"], m, 3 * c, c, c, c, 3 * c, bias=pk["b"], bias_mode=1).view(m, 3 * c)
+            cols = (c, 0, 2 * c)                                 # first columns of q, k, v in [k | q | v]
+            p_drop = self.attn_drop.p if self.training else 0.0
+            seed = _next_seed() if p_drop > 0.0 else 0
+            dm = None
+            if tape is not None and p_drop > 0.0 and os.environ.get("DVQ_ATTN_DROP_MASK", "1") == "1":
+                dm = K.attn_causal_drop_mask(x2d, b, t, nh)
+            y, lse = K.attn_causal_fwd_fused(qkv, cols, b, t, nh, 1.0 / math.sqrt(hs), p_drop, seed, drop_mask=dm)
+            out = self.proj.fwd(y, _child(tape, "proj"))
+            if tape is not None:
+                tape.s.update(qkv=qkv, cols=cols, fused=(p_drop, seed), y=y, lse=lse, drop_mask=dm, x=x2d, b=b, t=t)
+            if resid is not None:
+                return _drop_add(resid, out, self.resid_drop.p, self.training, tape, "rdrop")
+            return _drop(out, self.resid_drop.p, self.training, tape, "rdrop")
         # (the key projection on the side stream beside the other two -- three independent GEMMs with partly empty last rounds --
         #  measured no gain: 82.0 vs 82.0 ms per step)
         k = self.key.fwd(x2d, _child(tape, "k"))
@@ -151,6 +197,8 @@ class CausalSelfAttention(nn.Module):
     def bwd(self, dout, tape, dout_dropped=None):
         """dout_dropped: resid_drop's backward already applied to dout (written by the LayerNorm backward that produced dout)"""
         s_ = tape.s
+        if "qkv" in s_:
+            return self._bwd_qkv(dout, tape, dout_dropped)
         q, k, v, p, pd, b, t = s_["q"], s_["k"], s_["v"], s_["p"], s_["pd"], s_["b"], s_["t"]
         c = q.shape[1]
         nh, hs = self.n_head, c // self.n_head
@@ -187,6 +235,34 @@ class CausalSelfAttention(nn.Module):
         dx = K.add(dx, self.key.bwd(K.cast(dk32.view(b * t, c), dy.dtype), tape.child("k")))
         dx = K.add(dx, self.value.bwd(K.cast(dv32.view(b * t, c), dy.dtype), tape.child("v")))
         return dx
+
+
+    def _bwd_qkv(self, dout, tape, dout_dropped):
+        """backward of the fused-projection forward: attention backward into [dk | dq | dv] ([M, 3 C]), ONE input-gradient GEMM over
+        K = 3 C, the three weight / bias gradients from column blocks of that matrix (side stream, like Linear.bwd)"""
+        s_ = tape.s
+        qkv, cols, x2d, b, t = s_["qkv"], s_["cols"], s_["x"], s_["b"], s_["t"]
+        m, c3 = qkv.shape
+        c = c3 // 3
+        nh, hs = self.n_head, c // self.n_head
+        dout = dout_dropped if dout_dropped is not None else _drop_bwd(dout, tape, "rdrop")
+        dy = self.proj.bwd(dout, tape.child("proj"))
+        p_drop, seed = s_["fused"]
+        dqkv = K.attn_causal_bwd_fused(qkv, cols, s_["y"], dy, s_["lse"], b, t, nh, 1.0 / math.sqrt(hs), p_drop, seed,
+                                       drop_mask=s_.get("drop_mask"))
+        pk = self._qkv_pack()
+        dflat = dqkv.view(-1)
+
+        def wgrad():
+            for i, lin in enumerate((self.key, self.query, self.value)):
+                K.gemm_tn(dflat[i * c:], x2d, m, c, c, c3, c, c, out=_grad_buf(lin.weight), colsum=_grad_buf(lin.bias))
+
+        dx = K.gemm_nt(dqkv, pk["wt"], m, c, c3, c3, c3, c)
+        if m >= 1024 and rt.side_wgrad_enabled() and os.environ.get("DVQ_LINEAR_SIDE", "1") != "0":
+            rt.run_on_side(wgrad, dqkv, x2d)
+        else:
+            wgrad()
+        return dx.view(m, c)
 
 
 class Block(nn.Module):

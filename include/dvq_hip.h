@@ -256,9 +256,12 @@ int dvq_conv2d_wgrad_oihw(const dvq_conv_desc* d, const void* x, const void* dy,
  * checked on the device table: the caller pads channels to the vector width of the dtype (4 fp32 / 8 bf16) anyway. */
 int dvq_pack_weights_multi(const void* table_dev, int64_t n_entries, int64_t total_work, dvq_stream_t stream);
 /* The same for nn.Linear weights (stackgpt.py:44-96): table_dev = device array of n_entries records
- * { const float* master [out][in]; bf16* w [out_p][in]; bf16* wt [in][out_p]; int64 out, in, out_p, tile_begin } with out_p a multiple of
+ * { const float* master [out][in]; bf16* w [out_p][in]; bf16* wt [in][out_p]; int64 out, in, out_p, tile_begin, wt_ld;
+ *   const float* bias_src; float* bias_dst } with out_p a multiple of
  * 8 (rows >= out of w and columns >= out of wt are written as zero), tile_begin the exclusive prefix sum of
- * ceil(out_p / 64) * ceil(in / 64) and total_tiles the full sum: ONE launch per optimizer step instead of a cast + a transpose per layer. */
+ * ceil(out_p / 64) * ceil(in / 64) and total_tiles the full sum: ONE launch per optimizer step instead of a cast + a transpose per layer.
+ * wt_ld: row pitch of wt (0 = out_p); bias_src / bias_dst (may be null): the layer's fp32 bias copied into a slice of a concatenated
+ * bias -- both serve projections that share their input and run as ONE GEMM over row-concatenated weights (key / query / value). */
 int dvq_linear_pack_multi(const void* table_dev, int64_t n_entries, int64_t total_tiles, dvq_stream_t stream);
 
 /* weight packing: master fp32 OIHW (the reference's nn.Conv2d parameter layout) -> `dtype`
@@ -500,6 +503,17 @@ int dvq_attn_causal_fwd(const void* q, const void* k, const void* v, int dtype, 
 int dvq_attn_causal_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse, int dtype,
                         int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop, uint64_t seed, void* dq, void* dk,
                         void* dv, void* scratch, const void* drop_mask, dvq_stream_t stream);
+/* The same with a ROW PITCH for q, k, v (and dq, dk, dv): ldqkv elements between consecutive rows, e.g. 3 * n_head * head_dim when the
+ * three are column blocks of one fused [B*T][3 C] projection output (stackgpt.py:46-48 computes them as three Linear layers over the
+ * same input: one GEMM here) and the three gradients are written as column blocks of one [B*T][3 C] matrix that feeds ONE input-
+ * gradient GEMM.  out / dout keep pitch C.  Head size 128 only (csrc/attention2.hip); the backward's scratch holds rowsum(dO * O):
+ * dvq_attn_causal_scratch_bytes(.., backward = 1) bytes.  DVQ_ESHAPE otherwise. */
+int dvq_attn_causal_fwd_ld(const void* q, const void* k, const void* v, int64_t ldqkv, int dtype, int64_t B, int64_t T, int n_head,
+                           int head_dim, float scale, float p_drop, uint64_t seed, void* out, float* lse, void* drop_mask,
+                           dvq_stream_t stream);
+int dvq_attn_causal_bwd_ld(const void* q, const void* k, const void* v, int64_t ldqkv, const void* out, const void* dout, const float* lse,
+                           int dtype, int64_t B, int64_t T, int n_head, int head_dim, float scale, float p_drop, uint64_t seed, void* dq,
+                           void* dk, void* dv, void* scratch, const void* drop_mask, dvq_stream_t stream);
 /* Single-head FULL (non-causal) self-attention of the DQ-VAE's AttnBlock (modules/diffusionmodules/model.py:168-192:
  * w = softmax_j(q^T k * C^-1/2), h = v w^T) for C = 256 (bf16, T %% 32 == 0): the same flash kernels as above with one head of
  * size C, no mask, no dropout; q, k, v, out [B*T][C]; lse fp32 [B][T].  The [B,T,T] score tensor never reaches HBM.  Other

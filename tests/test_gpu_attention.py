@@ -205,3 +205,48 @@ def test_attnblock_fused_equals_unfused_path(dev, monkeypatch):
         assert not K.attn_full_ok(torch.empty(64, 512, dtype=torch.bfloat16, device=dev), 64)
     for a, b_ in zip(res["fused"], res["gemm"]):
         assert float((a - b_).abs().max()) <= 3e-2 * float(b_.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_fused_qkv_projection_equals_three_linears(dev, monkeypatch, p_drop):
+    """CausalSelfAttention (stackgpt.py:41-69 of the reference: three Linear layers over the same input) with key / query / value as ONE
+    GEMM over row-concatenated weights, the attention kernels reading column blocks of its [M, 3 C] output with a row pitch and ONE
+    input-gradient GEMM over K = 3 C (DVQ_QKV_FUSED=1, the default for head size 128) against the three-Linear path of the same module:
+    output, input gradient and the six parameter gradients; then a second step after a parameter change (the fused operand must follow
+    the repack)"""
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd import stackgpt as sg
+    from dynamicvectorquantization_amd.layers import Tape
+    torch.manual_seed(5)
+    cfg = sg.StackGPTConfig(n_embd=256, n_head=2, block_size=128, attn_pdrop=p_drop, resid_pdrop=0.0)
+    attn = sg.CausalSelfAttention(cfg).to(dev)
+    attn.train()
+    b, t, c = 3, 72, 256
+    x = (torch.randn(b * t, c, device=dev) * 0.7).to(torch.bfloat16)
+    dy = torch.randn(b * t, c, device=dev).to(torch.bfloat16)
+    names = [n for n, _ in attn.named_parameters()]
+
+    def run(fused):
+        monkeypatch.setenv("DVQ_QKV_FUSED", "1" if fused else "0")
+        for p_ in attn.parameters():
+            p_.grad = torch.zeros_like(p_)
+        rt._seed_counter[0] = 1000                       # the same dropout seeds in both runs
+        with rt.compute_dtype_ctx(torch.bfloat16):
+            tape = Tape()
+            y = attn.fwd(x, b, t, tape)
+            assert ("qkv" in tape.s) == fused
+            dx = attn.bwd(dy, tape)
+        torch.cuda.synchronize()
+        return y.float(), dx.float(), {n: p_.grad.clone() for n, p_ in attn.named_parameters()}
+
+    rel = lambda a, r: float((a - r).norm() / r.norm().clamp_min(1e-20))
+    for step in range(2):
+        y1, dx1, g1 = run(True)
+        y0, dx0, g0 = run(False)
+        assert rel(y1, y0) < 1e-2 and rel(dx1, dx0) < 2e-2, (step, rel(y1, y0), rel(dx1, dx0))
+        for n in names:
+            assert rel(g1[n], g0[n]) < 2e-2, (step, n, rel(g1[n], g0[n]))
+        with torch.no_grad():                            # an optimizer step: every packed copy must follow
+            for p_ in attn.parameters():
+                p_.add_(0.05 * torch.randn_like(p_))
+        rt.bump_weights_epoch()
