@@ -113,7 +113,9 @@ class CausalSelfAttention(nn.Module):
         from .layers import LINEAR_PACKS
         dev = self.key.weight.device
         ent = getattr(self, "_qkv", None)
-        if ent is None or ent["w"].device != dev:
+        lp = getattr(self.key, "_lpack", None)
+        # (a copied / moved module: the layers' pack entries must still BE slices of this module's buffers)
+        if ent is None or ent["w"].device != dev or lp is None or lp["w"].data_ptr() != ent["w"].data_ptr():
             c = self.key.in_features
             wcat = torch.zeros(3 * c, c, dtype=torch.bfloat16, device=dev)
             wtcat = torch.zeros(c, 3 * c, dtype=torch.bfloat16, device=dev)
