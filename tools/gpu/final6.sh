@@ -53,6 +53,7 @@ rm -rf gpurun_out/prof_s2; echo "stage2 prof done"; head -3 gpurun_out/${TAG}_st
   echo "# AttnBlock attention (B 64, T 1024, one head of 256): round-6 kernels, then the first generation"
   timeout 200 python tools/debug/attn_full_bench.py 2>&1 | grep "attn_full\|AttnBlock"
   echo "## first generation"; DVQ_ATTN_V2=0 timeout 200 python tools/debug/attn_full_bench.py 2>&1 | grep "attn_full"; } > gpurun_out/${TAG}_attention_probe.txt
+{ for ms in 1 0; do echo "== DVQ_HALO_MFMA_STATS=$ms"; DVQ_HALO_MFMA_STATS=$ms timeout 120 python tools/debug/halo_stats_check.py 2>&1 | grep "^N"; done; } > gpurun_out/${TAG}_halo_stats_check.txt
 timeout 300 python tools/gemm8p_probe.py 2>&1 | grep "^NT\|repeat" > gpurun_out/${TAG}_gemm_nt_probe.txt
 { timeout 200 python tools/probes/tn_probe.py 2>&1 | grep "TN\|DVQ"; DVQ_TN_WIDE_WGS=256 timeout 200 python tools/probes/tn_probe.py 2>&1 | grep "TN\|DVQ" | sed 's/^/[256 workgroups] /'; } > gpurun_out/${TAG}_gemm_tn_probe.txt
 python - <<'P'
