@@ -447,20 +447,40 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_bwd_dq_kernel(Attn2Ar
     const float c2 = p.scale * LOG2E;
     const unsigned xrow = ((unsigned)(((int64_t)bh * T + qrow) * T) + 4u * half) * p.rm + p.ra;
 
+    // keep words of the two 32-key halves of a 64-key tile: word r of a half is the select mask of register r (drop_tile).  Lanes 0 .. 15
+    // fetch them one tile AHEAD as a vector load (8 bytes each); v_readlane moves word r into the scalar pair the select needs -- 32
+    // cheap instructions per half instead of a scalar load whose ~1 us latency (14 MB per layer: HBM) sat between the first GEMMs and
+    // the element-wise pass of every tile
+    auto mask_words = [&](int kt, uint2 (&w)[2]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int t32 = 2 * kt + sub;
+            w[sub] = make_uint2(0u, 0u);
+            if (active && t32 <= my_last && lane < 16)
+                w[sub] = *reinterpret_cast<const uint2*>(p.mask + drop_tile(bh, nqt, qt, t32) + lane);
+        }
+    };
+    uint2 mnext[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+    if constexpr (DROP && MASKED) mask_words(0, mnext);
     for (int kt = 0; kt < nk; ++kt) {
-        dma_barrier();
-        if (kt + 1 < nk) stage(kt + 1);
+        dma_barrier();                                            // (also waits for the keep words requested an iteration ago)
+        const uint2 mcur[2] = {mnext[0], mnext[1]};
+        if (kt + 1 < nk) {
+            stage(kt + 1);
+            if constexpr (DROP && MASKED) mask_words(kt + 1, mnext);
+        }
         const char* kl = smem + (kt & 1) * 2 * TILEB;
         const char* vl = kl + TILEB;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int t32 = 2 * kt + sub;
             if (!active || t32 > my_last) continue;
-            unsigned long long mk[16];                           // the tile's 16 select masks: scalar loads, issued ahead of the first GEMMs
+            unsigned long long mk[16];                           // the tile's 16 select masks
             if constexpr (DROP && MASKED) {
-                const unsigned long long* mw = p.mask + drop_tile(bh, nqt, __builtin_amdgcn_readfirstlane(qt), t32);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mk[r] = mw[r];
+                for (int r = 0; r < 16; ++r)
+                    mk[r] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mcur[sub].y, r) << 32) |
+                            (unsigned)__builtin_amdgcn_readlane((int)mcur[sub].x, r);
             }
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -564,9 +584,24 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : Cfg<HS>::WPC) void attn2_bwd_d
     // keep bits of this lane's key over a tile's 32 queries (attention.hip: drop_tile): one 4-byte load per tile
     const unsigned* mlane = reinterpret_cast<const unsigned*>(p.mask) + 2 * ((l31 & 3) + 4 * (l31 >> 3)) + ((l31 >> 2) & 1);
 
+    // the keep words of a 64-query tile's two 32-query halves, fetched one tile ahead (a 4-byte load per lane and half from a 14-MB
+    // buffer: its latency would otherwise sit between the score MFMAs and the element-wise pass of every tile)
+    auto mask_words = [&](int q64, unsigned (&w)[2]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int qt = 2 * q64 + sub;
+            w[sub] = (active && (!CAUSAL || qt >= kt) && qt < nt) ? mlane[2 * drop_tile(bh, nt, qt, kt)] : 0u;
+        }
+    };
+    unsigned mnext[2] = {0u, 0u};
+    if constexpr (DROP && MASKED) mask_words(q64_first, mnext);
     for (int q64 = q64_first; q64 < nq64; ++q64) {
-        dma_barrier();
-        if (q64 + 1 < nq64) stage(q64 + 1);
+        dma_barrier();                                            // (also waits for the keep words requested an iteration ago)
+        unsigned mcur[2] = {mnext[0], mnext[1]};
+        if (q64 + 1 < nq64) {
+            stage(q64 + 1);
+            if constexpr (DROP && MASKED) mask_words(q64 + 1, mnext);
+        }
         const char* ql = smem + ((q64 - q64_first) & 1) * KV_STAGE;
         const char* dl = ql + TILEB;
         const float* stl = reinterpret_cast<const float*>(ql + 2 * TILEB);
@@ -574,8 +609,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : Cfg<HS>::WPC) void attn2_bwd_d
         for (int sub = 0; sub < 2; ++sub) {
             const int qt = 2 * q64 + sub;
             if (!active || (CAUSAL && qt < kt) || qt >= nt) continue;
-            unsigned mword = 0;
-            if constexpr (DROP && MASKED) mword = mlane[2 * drop_tile(bh, nt, qt, kt)] >> (4 * half);   // query 8 g + 4 half + i is bit 8 g + i
+            const unsigned mword = mcur[sub] >> (4 * half);           // query 8 g + 4 half + i is bit 8 g + i
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
