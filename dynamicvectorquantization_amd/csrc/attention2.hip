@@ -210,6 +210,36 @@ __device__ __forceinline__ void store_ct(bf16_t* dst /* row base + head offset *
         }
 }
 
+// The same through a wave-private LDS slab (32 rows x HS channels, chunk c of row r at c ^ (r & 15)): 8-byte column writes, then whole
+// rows leave as 16-byte stores -- 16 lanes cover one 256-byte row segment instead of every lane touching 16 (32) different rows with
+// 8-byte stores.  `slab` must be LDS no wave of the workgroup still reads (the ring stage the last tile did NOT use); only this wave
+// touches it, so an LDS wait is all the synchronisation it needs.  nvalid: rows of the tile inside the sequence.
+template <int HS>
+__device__ __forceinline__ void store_ct_lds(char* slab, bf16_t* dst_row0 /* row 0 of the tile + head offset */, int64_t pitch,
+                                             const f32x16 (&acc)[HS / 32], int lane, float mul, int nvalid) {
+    constexpr int ROWB = HS * 2, CPR = ROWB / 16;
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < HS / 32; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w;
+            w.x = pack_bf16x2(acc[mt][4 * g + 0] * mul, acc[mt][4 * g + 1] * mul);
+            w.y = pack_bf16x2(acc[mt][4 * g + 2] * mul, acc[mt][4 * g + 3] * mul);
+            const int c = 4 * mt + g;
+            *reinterpret_cast<uint2*>(slab + l31 * ROWB + ((c ^ (l31 & 15)) << 4) + half * 8) = w;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int RPI = 64 / CPR;                                 // rows per store instruction: 4 (head size 128) / 2 (256)
+    const int c = lane % CPR, r0 = lane / CPR;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+        const int r = r0 + RPI * i;
+        const uint4 v = *reinterpret_cast<const uint4*>(slab + r * ROWB + ((c ^ (r & 15)) << 4));
+        if (r < nvalid) *reinterpret_cast<uint4*>(dst_row0 + (int64_t)r * pitch + c * 8) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // forward: one wave per 32 queries, four neighbouring query tiles per workgroup; the workgroup walks the 64-key tiles (causal: 0 ..
 // diagonal).  LDS: 2 K slots + 2 V slots of one tile each (64 KiB at head size 128: two workgroups per CU; 128 KiB at 256: one).
@@ -372,9 +402,11 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_fwd_kernel(Attn2Args 
             }
         }
     }
-    if (qok && p.dbg != 2) {
-        store_ct<NM>(p.out + (rowbase + qrow) * C + h * HS, oacc, half, 1.f / l_run);
-        if (half == 0) p.lse[(int64_t)bh * T + qrow] = (m_run + __builtin_amdgcn_logf(l_run)) * (1.f / LOG2E);
+    if (active && p.dbg != 2) {
+        // (the ring slots the last tile did not use: K slot nk & 1 for waves 0 / 1, V slot for waves 2 / 3)
+        char* slab = smem + ((wave < 2 ? 0 : 2) + (nk & 1)) * TILEB + (wave & 1) * (TILEB / 2);
+        store_ct_lds<HS>(slab, p.out + (rowbase + qt * 32) * C + h * HS, C, oacc, lane, 1.f / l_run, T - qt * 32);
+        if (qok && half == 0) p.lse[(int64_t)bh * T + qrow] = (m_run + __builtin_amdgcn_logf(l_run)) * (1.f / LOG2E);
     }
 #endif
 }
@@ -515,7 +547,10 @@ __global__ __launch_bounds__(256, Cfg<HS>::WPC) void attn2_bwd_dq_kernel(Attn2Ar
             }
         }
     }
-    if (qok) store_ct<NM>(p.dq + (rowbase + qrow) * L + h * HS, acc, half, p.scale);
+    if (active) {
+        char* slab = smem + (nk & 1) * 2 * TILEB + wave * (TILEB / 2);          // the stage the last tile did not use
+        store_ct_lds<HS>(slab, p.dq + (rowbase + qt * 32) * L + h * HS, L, acc, lane, p.scale, T - qt * 32);
+    }
 #endif
 }
 
@@ -664,9 +699,13 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : Cfg<HS>::WPC) void attn2_bwd_d
             }
         }
     }
-    if (kok) {
-        store_ct<NM>((DO_DV ? p.dv : p.dk) + (rowbase + krow) * L + h * HS, acc, half, DO_DV ? 1.f : p.scale);
-        if constexpr (MODE == 0) store_ct<NM>(p.dk + (rowbase + krow) * L + h * HS, acc2, half, p.scale);
+    if (active) {
+        char* slab = smem + ((nq64 - q64_first) & 1) * KV_STAGE + wave * (TILEB / 2);      // the stage the last tile did not use
+        store_ct_lds<HS>(slab, (DO_DV ? p.dv : p.dk) + (rowbase + kt * 32) * L + h * HS, L, acc, lane, DO_DV ? 1.f : p.scale, T - kt * 32);
+        if constexpr (MODE == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            store_ct_lds<HS>(slab, p.dk + (rowbase + kt * 32) * L + h * HS, L, acc2, lane, p.scale, T - kt * 32);
+        }
     }
 #endif
 }
