@@ -1259,10 +1259,15 @@ __global__ __launch_bounds__(256) void vq_embed_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 constexpr int EMA_SLICE = 1024;   // rows per (code, slice) work item
 
-// One wave per (code k, slice of EMA_SLICE rows): scan the slice's indices 64 at a time (all loads issued
-// up front), accumulate the matching rows, flush with one fp32 atomic per dimension.  Work per wave is
-// bounded by the slice even when code usage is extremely skewed (untrained codebooks).
-template <typename T>
+// One wave per (code k, slice of EMA_SLICE rows): scan the slice's indices 64 at a time, accumulate the matching rows, flush with one
+// fp32 atomic per dimension.  Work per wave is bounded by the slice even when code usage is extremely skewed (untrained codebooks).
+// Round 6: every load is UNCONDITIONAL (clamped address, value masked afterwards).  Written as `n < nend && idx[n] == k` /
+// `d < D ? row[d] : 0` the compiler emitted each load under its own branch with its own s_waitcnt vmcnt(0): 16 dependent round trips
+// for the indices and one per row element group -- with an untrained codebook a handful of codes own most rows, the hottest (code,
+// slice) wave walked several hundred rows one round trip after the other and set the kernel's duration (413 us per launch in the
+// headline step).  The matching rows now form a compact list (slice order: same rows, same summation order as before) that is walked
+// four rows per trip with all 4 NJ loads in flight.  NJ = ceil(D / 64) rounded up to a power of two (launcher).
+template <typename T, int NJ>
 __global__ __launch_bounds__(64) void vq_ema_stats_kernel(const T* __restrict__ x, const int64_t* __restrict__ idx,
                                                           int64_t N, int64_t K, int64_t D,
                                                           float* __restrict__ stats) {
@@ -1270,36 +1275,49 @@ __global__ __launch_bounds__(64) void vq_ema_stats_kernel(const T* __restrict__ 
     const int64_t nbeg = (int64_t)blockIdx.y * EMA_SLICE, nend = min(N, nbeg + EMA_SLICE);
     const int lane = threadIdx.x;
     constexpr int NCH = EMA_SLICE / 64;
+    int64_t iv[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) iv[q] = idx[min(nbeg + q * 64 + lane, N - 1)];       // 16 independent loads, one wait
     unsigned long long hit[NCH];
     int count = 0;
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
-        const int64_t n = nbeg + q * 64 + lane;
-        const bool h = n < nend && idx[n] == k;
-        hit[q] = __ballot(h);
+        hit[q] = __ballot(nbeg + q * 64 + lane < nend && iv[q] == k);
         count += __popcll(hit[q]);
     }
     if (count == 0) return;
-    constexpr int MAXJ = 16;                 // D <= 1024
-    float acc[MAXJ];
+    __shared__ unsigned short rows_l[EMA_SLICE];
+    {
+        int base = 0;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-        unsigned long long m = hit[q];
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const T* row = x + (nbeg + q * 64 + b) * D;
-#pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-                const int64_t d = lane + 64 * j;
-                if (d < D) acc[j] += ElemIO<T>::load(row + d);
-            }
+        for (int q = 0; q < NCH; ++q) {
+            const unsigned long long below = hit[q] & ((1ull << lane) - 1ull);
+            if ((hit[q] >> lane) & 1ull) rows_l[base + __popcll(below)] = (unsigned short)(q * 64 + lane);
+            base += __popcll(hit[q]);
         }
     }
+    __syncthreads();
+    float acc[NJ];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+    int dj[NJ];                                  // this lane's columns, clamped into the row (masked when past D)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) dj[j] = (int)min((int64_t)(lane + 64 * j), D - 1);
+    for (int i = 0; i < count; i += 4) {
+        float v[4][NJ];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const T* row = x + (nbeg + rows_l[min(i + u, count - 1)]) * D;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) v[u][j] = ElemIO<T>::load(row + dj[j]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] += (i + u < count && lane + 64 * j < D) ? v[u][j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
         const int64_t d = lane + 64 * j;
         if (d < D) atomicAdd(stats + k * (D + 1) + d, acc[j]);
     }
@@ -1582,7 +1600,10 @@ int dvq_vq_ema_stats(const void* x, int dtype, const int64_t* idx, int64_t N, in
     }
     dim3 grid((unsigned)K, (unsigned)cdiv64(N, EMA_SLICE));
     DVQ_REQUIRE(grid.y <= 65535, DVQ_ESHAPE, "dvq_vq_ema_stats: N too large");
-    DVQ_DISPATCH_DTYPE(dtype, T, vq_ema_stats_kernel<T><<<grid, dim3(64), 0, s>>>((const T*)x, idx, N, K, D, stats););
+#define DVQ_EMA_STATS(NJV) DVQ_DISPATCH_DTYPE(dtype, T, vq_ema_stats_kernel<T, NJV><<<grid, dim3(64), 0, s>>>((const T*)x, idx, N, K, D, stats);)
+    if (D <= 64) { DVQ_EMA_STATS(1); } else if (D <= 128) { DVQ_EMA_STATS(2); } else if (D <= 256) { DVQ_EMA_STATS(4); }
+    else if (D <= 512) { DVQ_EMA_STATS(8); } else { DVQ_EMA_STATS(16); }
+#undef DVQ_EMA_STATS
     DVQ_CHECK_LAUNCH("vq_ema_stats");
     return DVQ_OK;
 }
