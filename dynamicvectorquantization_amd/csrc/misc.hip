@@ -485,6 +485,31 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __re
     }
 }
 
+// Image tensors (C <= 4 planes) into one 16-byte channel vector per pixel (8 bf16 / 4 fp32): one PIXEL per thread -- C coalesced plane
+// reads (unconditional, clamped plane index: a guarded load compiles to a branch with its own vmcnt(0)), one 16-byte store, one 64-bit
+// division per pixel instead of three per element.  The element-wise kernel above ran at 1.5 TB/s (80 us for a 64 x 3 x 256 x 256
+// batch, eight launches per headline step); this one is bound by its 117 MB of traffic.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_px_kernel(const float* __restrict__ in, int64_t B, int C, int64_t HW,
+                                                              T* __restrict__ out) {
+    constexpr int NV = 16 / sizeof(T);
+    const int64_t total = B * HW;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t b = e / HW, p = e - b * HW;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float t = in[(b * C + min(c, C - 1)) * HW + p];
+            v[c] = c < C ? t : 0.f;
+        }
+        if constexpr (NV == 8) {
+            store8(out + e * 8, v);
+        } else {
+            *reinterpret_cast<float4*>(out + e * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_pad_to_nchw_kernel(const T* __restrict__ in, int64_t B, int64_t C,
                                                                int64_t HW, int64_t Cp, float* __restrict__ out) {
@@ -938,6 +963,12 @@ int dvq_unpack_wgrad(const float* dw, int64_t Cout, int64_t Cin, int64_t KH, int
 int dvq_nchw_to_nhwc_pad(const float* in, int64_t B, int64_t C, int64_t H, int64_t W, int64_t Cp, int dtype, void* out,
                          dvq_stream_t stream) {
     DVQ_REQUIRE(in && out && Cp >= C, DVQ_EINVAL, "dvq_nchw_to_nhwc_pad: bad arguments");
+    if (C <= 4 && Cp == (dtype == DVQ_F32 ? 4 : 8)) {
+        DVQ_DISPATCH_DTYPE(dtype, T, nchw_to_nhwc_px_kernel<T><<<dim3(nblocks(B * H * W, 256)), dim3(256), 0,
+                                                                 (hipStream_t)stream>>>(in, B, (int)C, H * W, (T*)out););
+        DVQ_CHECK_LAUNCH("nchw_to_nhwc_px");
+        return DVQ_OK;
+    }
     DVQ_DISPATCH_DTYPE(dtype, T, nchw_to_nhwc_pad_kernel<T><<<dim3(nblocks(B * H * W * Cp, 256)), dim3(256), 0,
                                                               (hipStream_t)stream>>>(in, B, C, H * W, Cp, (T*)out););
     DVQ_CHECK_LAUNCH("nchw_to_nhwc_pad");

@@ -989,6 +989,26 @@ def test_sum_batch(dev, shape, dtype):
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.sqrt(rows))
 
 
+@pytest.mark.parametrize("case", [(3, 3, 17, 23, 0), (2, 1, 8, 8, 0), (2, 4, 33, 5, 0), (5, 3, 64, 64, 16), (2, 6, 9, 7, 0)],
+                         ids=lambda c: "-".join(map(str, c)))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_nchw_to_nhwc_pad_layout(dev, case, dtype):
+    """image entry layout: the one-pixel-per-thread kernel (C <= 4 into one 16-byte channel vector) and the element-wise kernel
+    (wider pads / more planes) -- exact copy with zero padding channels, and its inverse"""
+    from dynamicvectorquantization_amd import kernels as K
+    b, c, h, w, cp = case
+    vec = 4 if dtype == torch.float32 else 8
+    cp = cp or vec * -(-c // vec)
+    x = np.random.RandomState(b * 100 + c).standard_normal((b, c, h, w)).astype(np.float32)
+    if dtype == torch.bfloat16:
+        x = bf16_round(x)
+    out = K.nchw_to_nhwc_pad(T(x, dev), cp, dtype)
+    ref = np.zeros((b, h, w, cp), np.float32)
+    ref[..., :c] = x.transpose(0, 2, 3, 1)
+    assert np.array_equal(out.float().cpu().numpy(), ref)
+    assert np.array_equal(K.nhwc_pad_to_nchw(out, c).cpu().numpy(), x)
+
+
 @pytest.mark.parametrize("case", [(64, 2, 16, 24), (64, 1, 64, 64), (32, 3, 6, 10)], ids=lambda c: "-".join(map(str, c)))
 def test_tconv4x4s2_thin_kernel(dev, case):
     """input gradient of the PatchGAN's first conv (4x4 / s2 / p1, 3 image channels) on the thin transposed-conv kernel"""
