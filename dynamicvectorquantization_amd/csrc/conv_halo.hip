@@ -1345,7 +1345,20 @@ static int halo_wgrad_impl(const void* x, const void* dy, float* dw, float* db, 
     p.tiles_x = (int)(W / TW); p.tiles_y = (int)(H / WTH);
     p.ntiles = (int)(N * p.tiles_y * p.tiles_x);
     p.gi = (int)cdiv64(Cout, 128); p.gj = (int)(Cin / 64);
-    int64_t nsplit = 256 / ((int64_t)p.gi * p.gj);         // ~one resident workgroup (8 waves) per CU
+    // Workgroups of one launch = CUs it occupies for its whole duration (8 waves x <= 256 VGPRs + 116 KiB of LDS: nothing else becomes
+    // resident beside one).  Round 6: 128, not one per CU -- the weight gradients run on the side stream BESIDE the main stream's
+    // kernels (layers.Conv2d.bwd), and with every CU taken the HBM-bound GroupNorm backward that follows the input gradient could not
+    // start until the launch retired.  Same-box A/B of the headline step (tools/gpu/wg.sh, two alternating rounds): 256 -> 421.5 / 422.3,
+    // 224 -> 425.2 / 425.5, 160 -> 428.4 / 429.1, 128 -> 428.7 / 429.0, 96 -> 425.4 / 425.7, 64 -> 385.3 / 385.9 img/s; the launch alone
+    // is slower (1.10 -> 1.63 ms at 64 x 256 x 256 x 128: not 2x, the matrix pipes of a full chip run at a lower clock), the pair
+    // weight gradient || GroupNorm backward hides 53 % of the shorter instead of 10 % (tools/debug/overlap_probe.py).
+    // Half the splits also halve the partials to fold.  DVQ_WGRAD_WGS overrides.
+    static const int wgs_env = [] {
+        const char* e = getenv("DVQ_WGRAD_WGS");
+        const int v = e == nullptr ? 128 : atoi(e);
+        return v < 8 ? 8 : v;
+    }();
+    int64_t nsplit = wgs_env / ((int64_t)p.gi * p.gj);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > p.ntiles) nsplit = p.ntiles;
     p.tiles_per_split = (int)cdiv64(p.ntiles, nsplit);
