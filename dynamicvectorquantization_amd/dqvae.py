@@ -647,6 +647,9 @@ class DualGrainVQModel(nn.Module):
 
     def training_step(self, batch, batch_idx, optimizer_idx):
         x = self.get_input(batch, self.image_key)
+        prefetch = getattr(self.loss, "prefetch_targets", None)
+        if prefetch is not None:      # target-only work of the loss starts on the side stream, beside the forward below
+            prefetch(x, optimizer_idx, self.current_epoch if self.loss_with_epoch else self.global_step)
         if optimizer_idx == 1 and self.reuse_generator_forward and getattr(self, "_gen_out", None) is not None:
             xrec, qloss, indices, gate, x_entropy = self._gen_out
         elif optimizer_idx == 1:

@@ -13,6 +13,8 @@ VALUE of the perceptual term with real weights; the computation itself is pinned
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -206,6 +208,10 @@ class vgg16(nn.Module):
         return [[getattr(self, name)[j] for j in range(len(idxs))] for name, idxs, _ in self.SLICES]
 
 
+_GEN_SIDE = os.environ.get("DVQ_GEN_SIDE", "1") != "0"
+_LOSS_PREFETCH = os.environ.get("DVQ_LOSS_PREFETCH", "1") != "0"
+
+
 class LPIPS(nn.Module):
     """Learned perceptual metric (modules/losses/lpips.py:11-50) on the HIP kernels.
 
@@ -289,15 +295,9 @@ class LPIPS(nn.Module):
             self._aff = (key, a, b)
         return self._aff[1], self._aff[2]
 
-    def fwd(self, x_p, r_p, gscale=None):
-        """x_p / r_p: NHWC channel-padded images (target, reconstruction).  Returns (val fp32 [B], d_r) where
-        d_r = gscale * d sum_b(val[b]) / d r_p when gscale is given, else None."""
-        b = x_p.shape[0]
-        a_c, b_c = self._affine(x_p.dtype, x_p.device)
-        h = K.affine_channels(torch.cat([x_p, r_p], 0), a_c, b_c)
-        want = gscale is not None
-        acts = []                 # per slice: list of post-ReLU outputs
-        descs = []
+    def _trunk(self, h):
+        """VGG16 slices on the scaled image batch h -> per slice the list of post-ReLU outputs"""
+        acts = []
         for si, convs in enumerate(self.net.convs()):
             if si > 0:
                 h = K.maxpool2x2(h)
@@ -306,25 +306,48 @@ class LPIPS(nn.Module):
                 h = conv.fwd(h, None, act=K.ACT_RELU)
                 outs.append(h)
             acts.append(outs)
-        val = K.zeros_small((b,), torch.float32, x_p.device)
+        return acts
+
+    def target_features(self, x_p):
+        """the five tap activations of the TARGET images alone (they do not depend on the autoencoder: VQLPIPSWithDiscriminator
+        issues this on the side stream before the autoencoder's forward and hands the result to fwd(target_taps=...))"""
+        a_c, b_c = self._affine(x_p.dtype, x_p.device)
+        return [outs[-1] for outs in self._trunk(K.affine_channels(x_p, a_c, b_c))]
+
+    def fwd(self, x_p, r_p, gscale=None, target_taps=None):
+        """x_p / r_p: NHWC channel-padded images (target, reconstruction).  Returns (val fp32 [B], d_r) where
+        d_r = gscale * d sum_b(val[b]) / d r_p when gscale is given, else None.
+        target_taps: target_features(x_p) computed earlier -- the trunk then runs on the reconstruction alone (same kernels on B
+        instead of 2 B images; every image's values are independent of the batch it is in)."""
+        b = r_p.shape[0]
+        a_c, b_c = self._affine(r_p.dtype, r_p.device)
+        want = gscale is not None
+        if target_taps is None:
+            acts = self._trunk(K.affine_channels(torch.cat([x_p, r_p], 0), a_c, b_c))
+            off = b               # rows of the reconstruction in the trunk's tensors
+            taps_x = [outs[-1][:b] for outs in acts]
+        else:
+            acts = self._trunk(K.affine_channels(r_p, a_c, b_c))
+            off = 0
+            taps_x = target_taps
+        val = K.zeros_small((b,), torch.float32, r_p.device)
         dtaps = []
         for k, outs in enumerate(acts):
-            f = outs[-1]
             lin = getattr(self, f"lin{k}").model[-1].weight.reshape(-1)
             pd = getattr(self, f"lin{k}").model[0].p if (self.lin_dropout and self.training) else 0.0
-            dtaps.append(K.lpips_head(f[:b], f[b:], lin, val, gscale if want else 0.0, want, p_drop=pd,
+            dtaps.append(K.lpips_head(taps_x[k], outs[-1][off:], lin, val, gscale if want else 0.0, want, p_drop=pd,
                                       seed=rt.next_dropout_seed() if pd > 0.0 else 0))
         if not want:
             return val, None
         g = None
         for si in range(4, -1, -1):
             convs, outs = self.net.convs()[si], acts[si]
-            a_tap = outs[-1][b:]
+            a_tap = outs[-1][off:]
             dz = dtaps[si] if si == 4 else K.maxpool2x2_relu_bwd(a_tap, dpool=g, dtap=dtaps[si])
             for j in range(len(convs) - 1, -1, -1):
                 conv = convs[j]
                 if j > 0:
-                    src = outs[j - 1][b:]
+                    src = outs[j - 1][off:]
                     d = conv._desc(src)
                     dz = K.conv2d_dgrad(d, dz, conv.packed(src.dtype)[1], mask=src, mask_act=K.ACT_RELU)
                 else:
@@ -422,6 +445,39 @@ class VQLPIPSWithDiscriminator(nn.Module):
             self.budget_loss = instantiate_from_config(budget_loss_config)
 
     # -- generator branch ---------------------------------------------------------------------------------------
+    def prefetch_targets(self, inputs, optimizer_idx, global_step):
+        """The part of this step's loss that depends on the TARGET images only -- generator step: their VGG16 tap activations;
+        discriminator step: the PatchGAN forward of the real images -- issued on the side stream BEFORE the autoencoder's forward
+        (models call this at the top of training_step), so that it runs beside the autoencoder's HBM-bound passes instead of after
+        them.  forward() picks the results up if it is then called with the same tensor; DVQ_LOSS_PREFETCH=0 switches it off."""
+        self._pre = None
+        if not (_LOSS_PREFETCH and rt.side_wgrad_enabled() and torch.is_grad_enabled() and self.training and inputs.is_cuda):
+            return
+        x = inputs.contiguous().float()
+        cd = rt.compute_dtype()
+        cp = _padc(3, cd)
+        st = {"key": (x.data_ptr(), tuple(x.shape), int(optimizer_idx), cd), "x": x}
+        if optimizer_idx == 0 and self.perceptual_weight > 0:
+            def work():
+                st["x_p"] = K.nchw_to_nhwc_pad(x, cp, cd)
+                st["taps"] = self.perceptual_loss.target_features(st["x_p"])
+        elif optimizer_idx == 1 and any(p.requires_grad for p in self.discriminator.parameters()):
+            def work():
+                st["t_real"] = Tape()
+                st["lr"] = self.discriminator.fwd(K.nchw_to_nhwc_pad(x, cp, cd), st["t_real"])
+        else:
+            return
+        rt.run_on_side(work, x)
+        self._pre = st
+
+    def _take_prefetched(self, x, optimizer_idx):
+        """the record prefetch_targets left for exactly this call (the current stream then waits for the side stream), else None"""
+        st, self._pre = getattr(self, "_pre", None), None
+        if st is None or st["key"] != (x.data_ptr(), tuple(x.shape), int(optimizer_idx), rt.compute_dtype()):
+            return None
+        rt.join_side(x.device)
+        return st
+
     def _generator(self, x, xrec, want_grad, last_layer, disc_factor):
         """-> dict(nll, p, g, d_weight [device scalars], g_rec NCHW fp32 or None)"""
         cd = rt.compute_dtype()
@@ -429,16 +485,33 @@ class VQLPIPSWithDiscriminator(nn.Module):
         dev = x.device
         numel = x.numel()
         b = x.shape[0]
+        pre = self._take_prefetched(x, 0) if want_grad else None
         l1_sum, g_l1 = K.l1_loss(x, xrec, scale_dev=torch.full((1,), 1.0 / numel, device=dev) if want_grad else None,
                                  want_grad=want_grad)
         rec_mean = (l1_sum / numel).to(torch.float32).reshape(())
-        x_p = K.nchw_to_nhwc_pad(x, cp, cd)
+        x_p = pre["x_p"] if pre is not None else K.nchw_to_nhwc_pad(x, cp, cd)
         r_p = K.nchw_to_nhwc_pad(xrec, cp, cd)
         out = {"rec": rec_mean}
         g_nll = K.nchw_to_nhwc_pad(g_l1, cp, cd) if want_grad else None
+        # The GAN branch (PatchGAN forward + input-gradient backward of the reconstruction) and the perceptual branch (VGG16 forward +
+        # backward) only share r_p: with both wanted, the GAN branch runs on the side stream so that its HBM-bound BatchNorm /
+        # activation passes and the perceptual branch's pooling passes overlap the other branch's convolutions (DVQ_GEN_SIDE=0: off)
+        gan_side = None
+        if want_grad and disc_factor != 0 and self.perceptual_weight > 0 and _GEN_SIDE and rt.side_wgrad_enabled():
+            gan_side = {}
+
+            def gan_branch():
+                tape_ = Tape()
+                lf = self.discriminator.fwd(r_p, tape_)
+                gl, (dl,), _ = _logit_loss_and_grad(self.gen_loss, lf)
+                gan_side["g"] = gl
+                gan_side["g_g"] = self.discriminator.bwd(dl, tape_, need_dw=False)
+
+            rt.run_on_side(gan_branch, r_p)
         if self.perceptual_weight > 0:
             # nll = mean over B*3*H*W elements of (|x-xrec| + pw * p[b])  ->  d nll / d p[b] = pw / B
-            val, d_r = self.perceptual_loss.fwd(x_p, r_p, gscale=self.perceptual_weight / b if want_grad else None)
+            val, d_r = self.perceptual_loss.fwd(x_p, r_p, gscale=self.perceptual_weight / b if want_grad else None,
+                                                target_taps=pre["taps"] if pre is not None else None)
             out["p"] = val.mean()
             nll = rec_mean + self.perceptual_weight * out["p"]
             if want_grad:
@@ -455,15 +528,19 @@ class VQLPIPSWithDiscriminator(nn.Module):
             out["g_rec"] = K.nhwc_pad_to_nchw(g_nll, 3) if want_grad else None
             return out
         disc = self.discriminator
-        tape = Tape() if want_grad else None
-        logits_fake = disc.fwd(r_p, tape)
-        g_loss, (dlog,), _ = _logit_loss_and_grad(self.gen_loss, logits_fake)
-        out["g"] = g_loss
-        if not want_grad:
-            out["d_weight"] = torch.zeros((), device=dev)     # reference: autograd.grad fails in eval -> 0
-            out["g_rec"] = None
-            return out
-        g_g = disc.bwd(dlog, tape, need_dw=False)
+        if gan_side is not None:
+            rt.join_side(dev)
+            out["g"], g_g = gan_side["g"], gan_side["g_g"]
+        else:
+            tape = Tape() if want_grad else None
+            logits_fake = disc.fwd(r_p, tape)
+            g_loss, (dlog,), _ = _logit_loss_and_grad(self.gen_loss, logits_fake)
+            out["g"] = g_loss
+            if not want_grad:
+                out["d_weight"] = torch.zeros((), device=dev)     # reference: autograd.grad fails in eval -> 0
+                out["g_rec"] = None
+                return out
+            g_g = disc.bwd(dlog, tape, need_dw=False)
         if self.disc_adaptive_loss:
             hook = getattr(last_layer, "_dvq_wgrad", None)
             if hook is None:
@@ -546,8 +623,12 @@ class _DiscLossFn(torch.autograd.Function):
         cp = _padc(3, cd)
         disc = mod.discriminator
         with torch.no_grad():
+            pre = mod._take_prefetched(x, 1) if want_grad else None
             t_real, t_fake = (Tape(), Tape()) if want_grad else (None, None)
-            lr = disc.fwd(K.nchw_to_nhwc_pad(x, cp, cd), t_real)
+            if pre is not None:       # the real images' forward ran on the side stream beside the autoencoder (prefetch_targets)
+                lr, t_real = pre["lr"], pre["t_real"]
+            else:
+                lr = disc.fwd(K.nchw_to_nhwc_pad(x, cp, cd), t_real)
             lf = disc.fwd(K.nchw_to_nhwc_pad(xrec, cp, cd), t_fake)
             loss, grads, leaves = _logit_loss_and_grad(lambda a, b: disc_factor * mod.disc_loss(a, b), lr, lf)
         ctx.state = (disc, t_real, t_fake, grads) if want_grad else None
