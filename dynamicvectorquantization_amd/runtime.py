@@ -391,6 +391,9 @@ def run_on_side(fn, *tensors):
     """launch fn() on the side stream after everything issued so far on the current stream; `tensors` are what it reads"""
     st = side_stream(tensors[0].device if tensors else None)
     cur = torch.cuda.current_stream()
+    if cur == st["stream"]:        # already inside work that was forked to the side stream (a head's backward issuing its weight gradients)
+        fn()
+        return
     st["stream"].wait_stream(cur)
     with torch.cuda.stream(st["stream"]):
         fn()
@@ -417,6 +420,8 @@ def join_side(device=None):
     of a recorded segment)"""
     for key, st in _side.items():
         if st["dirty"] and (device is None or torch.device(device).index in (None, key)):
+            if torch.cuda.current_stream(torch.device("cuda", key)) == st["stream"]:
+                continue           # called from work that itself runs on the side stream: nothing to wait for, the fork stays open
             torch.cuda.current_stream(torch.device("cuda", key)).wait_stream(st["stream"])
             st["dirty"] = False
             st.setdefault("events", []).extend(e for e, _ in st["keep"] if e is not None)
