@@ -228,6 +228,76 @@ def test_train_step_golden_graph_replay_matches_eager(dev):
     assert float((n0 - n1).abs().max() / n0.abs().max()) < 5e-2
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_two_stream_loss_schedule_matches_single_stream(dev, mode, monkeypatch):
+    """losses.VQLPIPSWithDiscriminator on two streams (PatchGAN branch of the generator loss on the side stream, target-only work
+    prefetched beside the autoencoder's forward: LPIPS on B images against stored target taps instead of one 2 B batch) must give
+    the step the single-stream schedule gives: every image's values are independent of the batch it is evaluated in.  Compared on
+    ONE step from identical parameters (later steps carry Adam's sign-level amplification of rounding noise and code flips, which the
+    golden tests bound separately): both losses and every parameter gradient at the moment its optimizer steps."""
+    from dynamicvectorquantization_amd import losses as L
+    from dynamicvectorquantization_amd import runtime as rt
+    from dynamicvectorquantization_amd.config import instantiate_from_config
+    from dynamicvectorquantization_amd.trainer import Trainer
+    from test_gpu_model import GEOM, model_config
+    c, g = TRAIN_STEP["small"], GEOM["small"]
+    res = []
+    for two_stream in (True, False):
+        monkeypatch.setattr(L, "_GEN_SIDE", two_stream)
+        monkeypatch.setattr(L, "_LOSS_PREFETCH", two_stream)
+        with rt.compute_dtype_ctx(mode):
+            torch.manual_seed(0)
+            model = instantiate_from_config(model_config(**g, loss="full", ndf=c["ndf"])).to(dev)
+            synth.apply_train_step_state(model, g["k"], g["zc"])
+            rt.bump_weights_epoch()
+            model.learning_rate, model.min_learning_rate = c["lr"], c["min_lr"]
+            model.warmup_epochs, model.steps_per_epoch, model.training_steps = 0.3, 10, 50
+            model.train()
+            tr = Trainer(model, max_steps=1, use_graph=False)
+            grads = {}
+            names = {id(p): n for n, p in model.named_parameters()}
+
+            def wrap(o, orig):
+                def step(closure=None):
+                    for grp in o.param_groups:
+                        for p in grp["params"]:
+                            if p.grad is not None:
+                                grads[names[id(p)]] = p.grad.detach().float().clone()
+                    return orig(closure)
+                return step
+
+            for o in tr.opts:
+                o.step = wrap(o, o.step)
+            x = torch.from_numpy(next(iter(synth.train_step_batches(1, c["bs"], g["resolution"])))).to(dev)
+            ls = [float(l) for l in tr.train_step({"image": x}, 0)]
+            torch.cuda.synchronize()
+            res.append((ls, grads))
+    (l1, g1), (l0, g0) = res
+    np.testing.assert_allclose(np.array(l1), np.array(l0), rtol=1e-5 if mode == "fp32" else 1e-4)
+    assert set(g1) == set(g0) and len(g0) > 100
+    # rms difference per tensor relative to the tensor's rms gradient; tensors whose exact gradient is zero (conv biases in front of a
+    # normalisation: pure rounding noise in both runs) are measured against 1e-3 of the largest rms gradient of the model instead
+    rms = {n: float(g0[n].pow(2).mean().sqrt()) for n in g0}
+    floor = 1e-3 * max(rms.values())
+    worst, worst_noise = ("", 0.0), ("", 0.0)
+    for n in g0:
+        d = float((g1[n] - g0[n]).pow(2).mean().sqrt())
+        if rms[n] >= floor:
+            worst = max(worst, (n, d / rms[n]), key=lambda t: t[1])
+        else:
+            worst_noise = max(worst_noise, (n, d / floor), key=lambda t: t[1])
+    num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in g0)
+    den = sum(float(g0[n].pow(2).sum()) for n in g0)
+    from test_gpu_model import _report
+    _report("two_stream_vs_single_stream_gradients", mode=mode, worst=worst, worst_noise=worst_noise, global_rel=(num / den) ** 0.5)
+    # fp32: atomic / split-reduction order.  bf16: one-ulp differences of the BatchNorm statistics re-round activations, and fifty
+    # layers of backward amplify that on the reduction-heavy tensors (biases of the first layers): bounded loosely per tensor, tightly
+    # over all gradient elements
+    assert worst[1] <= (1e-4 if mode == "fp32" else 0.3), worst
+    assert (num / den) ** 0.5 <= (1e-5 if mode == "fp32" else 3e-2), (num / den) ** 0.5
+    assert worst_noise[1] <= (1e-2 if mode == "fp32" else 1.0), worst_noise      # i.e. below 1e-5 (bf16: 1e-3) of the largest rms gradient
+
+
 # ---- the fused optimizer kernels against torch.optim ----------------------------------------------------------------------------
 @pytest.mark.parametrize("kind", ["adam", "adamw"])
 def test_hip_adam_matches_torch_optim(dev, kind):
