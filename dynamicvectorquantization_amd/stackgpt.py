@@ -488,13 +488,27 @@ class DecodeState:
         if not self.use_graph or ent["calls"] == 1:
             return body(*ent["static"])
         if ent["graph"] is None:
-            gr = torch.cuda.CUDAGraph()
+            # replayed as a launch list (csrc/cmdlist.hip: the recorded launches re-issued on this lane's stream, ~2 us of host time
+            # each) unless DVQ_DECODE_REPLAY=graph: hipGraphLaunch of a ~130-node token step costs ~0.8 ms of host time on ROCm 7.2,
+            # which capped concurrent lanes at 1250 token steps / s whatever their number (profiles/r06_sampler_lanes.txt)
+            as_list = os.environ.get("DVQ_DECODE_REPLAY", "list") == "list"
+            gr = torch.cuda.CUDAGraph(keep_graph=True) if as_list else torch.cuda.CUDAGraph()
             # thread-local capture mode: another sampling lane (Dualformer.sample_many runs one host thread per stream) may launch and
             # allocate on ITS stream while this one records
             with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                 ent["out"] = body(*ent["static"])
-            ent["graph"] = gr
-        ent["graph"].replay()
+            ent["graph"], ent["list"] = gr, None
+            if as_list:
+                from ._lib import DvqError
+                try:
+                    ent["list"] = K.CmdList(gr)
+                except DvqError:          # a node kind the list cannot re-issue (a torch memcpy): this body replays as a hipGraph
+                    ent["list"] = None
+        if ent.get("list") is not None:
+            cur = torch.cuda.current_stream()
+            ent["list"].replay(cur, cur)
+        else:
+            ent["graph"].replay()
         return ent["out"].clone()
 
     def _position_row_body(self, pos_table):
