@@ -18,6 +18,7 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per sampling lane (dynamicvectorquantization_amd/__init__.py)
 
 import torch  # noqa: E402
 
@@ -207,7 +208,7 @@ def main():
                         "roofline": {"bound": "hbm", "weight_bytes_per_step": int(w_bytes), "kv_bytes_per_step_avg": int(kv_bytes),
                                      "achieved": round(achieved / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8e12, 4)}}
 
-            def kv_run_lanes(bs, lanes=2, nb=4):
+            def kv_run_lanes(bs, lanes=4, nb=8):
                 """the same with `lanes` batches in flight (Dualformer.sample_many: one stream, K/V caches and captured token-step graphs
                 per lane): nb independent batches of bs sequences, whole-job token-steps/s"""
                 x = torch.from_numpy(synth.half_flat_images(bs, 256, seed=277)).to(dev)
@@ -259,10 +260,10 @@ def main():
                                 "tokens_per_sec": round(bs / dt, 1)}
             runs = [kv_run(b_) for b_ in sizes]
             lane_runs = []
-            if os.environ.get("DVQ_BENCH_LANES", "2") != "0":
+            if os.environ.get("DVQ_BENCH_LANES", "4") != "0":
                 for b_ in sizes:
                     try:
-                        lane_runs.append(kv_run_lanes(b_, int(os.environ.get("DVQ_BENCH_LANES", "2"))))
+                        lane_runs.append(kv_run_lanes(b_, int(os.environ.get("DVQ_BENCH_LANES", "4"))))
                     except Exception as e:          # secondary measurement: never costs the single-lane figures
                         lane_runs.append({"bs": b_, "failed": f"{type(e).__name__}: {str(e)[:160]}"})
             res["kv_cached_end_to_end"] = runs[0]

@@ -15,6 +15,7 @@ import pickle
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per sampling lane (see dynamicvectorquantization_amd/__init__.py)
 
 
 def save_pickle(fname, data):
@@ -53,7 +54,7 @@ def get_parser():
     parser.add_argument("--out_dir", type=str, default="")
     parser.add_argument("--dtype", type=str, default="bf16")
     parser.add_argument("--seed", type=int, default=None)
-    parser.add_argument("--streams", type=int, default=2,
+    parser.add_argument("--streams", type=int, default=4,
                         help="batches sampled concurrently, each on its own HIP stream (Dualformer.sample_many); 1 = one batch at a time")
     return parser
 
