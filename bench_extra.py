@@ -18,7 +18,12 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per sampling lane (dynamicvectorquantization_amd/__init__.py)
+if "sampling" in sys.argv:
+    # HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (ROCm 7.2 default: 4, of which the sampler's lanes saw TWO:
+    # kernels of streams that share a queue serialise).  Eight queues let four sampling lanes run four token steps at once
+    # (profiles/r06_sampler_lanes.txt).  Sampling only: the triple-grain TRAINING step loses 15 % with eight queues (233.7 / 241.4 vs
+    # 203.7 / 198.3 img/s, same box), the dual-grain and stage-2 steps are neutral.  Read when the HIP runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 

@@ -15,7 +15,7 @@ import pickle
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per sampling lane (see dynamicvectorquantization_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per sampling lane (bench_extra.py has the measurements); sampling only
 
 
 def save_pickle(fname, data):
