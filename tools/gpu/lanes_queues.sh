@@ -1,4 +1,5 @@
 #!/bin/bash
+# sampler throughput by hardware-queue count (GPU_MAX_HW_QUEUES) x lanes -> gpurun_out/r06_sampler_hwq.txt (profiles/r06_sampler_lanes.txt, table 3)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 for q in 4 8 16; do for l in 2 4 6; do
