@@ -456,7 +456,7 @@ def test_class_conditional_dualformer(dev):
 
 
 def test_sample_many_lanes_equal_sequential(dev):
-    """Dualformer.sample_many: five class-conditional batches (different labels, so different sequences) on two and three concurrent
+    """Dualformer.sample_many: five class-conditional batches (different labels, so different sequences) on two, three and four concurrent
     lanes -- own stream, K/V caches, captured token-step graphs per lane -- draw, greedily, exactly the tokens of the sequential
     sampler, batch by batch; multinomial draws stay inside the constraints"""
     from dynamicvectorquantization_amd import runtime as rt
@@ -482,7 +482,7 @@ def test_sample_many_lanes_equal_sequential(dev):
             kw = dict(sample=False, top_k=20, top_k_pos=10, process=False, fix_fine_position=fix)
             seq = [[t.cpu() for t in model.sample_from_scratch(*c, **kw)] for c in conds]
             assert not all(torch.equal(a, b) for a, b in zip(seq[0], seq[1])), "the batches must differ for this test to mean anything"
-            for lanes in (2, 3):
+            for lanes in (2, 3, 4):       # 4 = the sampling scripts' default
                 got = model.sample_many(conds, n_streams=lanes, **kw)
                 for i, (a, b) in enumerate(zip(seq, got)):
                     assert all(torch.equal(x_, y_.cpu()) for x_, y_ in zip(a, b)), (fix, lanes, i)
